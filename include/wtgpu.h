@@ -1,0 +1,116 @@
+/* wtgpu.h — C-ABI of the MI355X-native wave_tracer hot path (libwtgpu.so).
+ *
+ * Drop-in seam (seam S1): this library replaces the block fan-out of the reference's render loop,
+ *     scene_renderer_t::render()                    src/scene/render.cpp:381-579
+ *       -> block_renderer_t -> integrator_t::integrate(ctx, block, pixel, spp)     src/scene/render.cpp:99-113,
+ *                                                                                  include/wt/integrator/integrator.hpp:44-57
+ * i.e. everything between "scene + ADS are built" and "film storage is developed".  The host keeps scene parsing,
+ * film development/tonemapping and image I/O; it hands over a flattened scene description and gets back the
+ * three linear film accumulators  value = sum(w*v), weight = sum(w), light = sum(light-image splats), exactly the
+ * quantities film_storage_t holds (include/wt/sensor/film/film_storage.hpp:196-252), from which
+ *     pixel = value/weight + light/spe        (film_storage.hpp:256-287, src/scene/render.cpp:245-291).
+ *
+ * Plain C types only; opaque handles; int status returns (0 = ok); no exceptions cross the boundary.
+ * One wtgpu_scene may be uploaded to one device per process (one process per GPU).
+ */
+#ifndef WTGPU_H
+#define WTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wtgpu_scene wtgpu_scene;
+
+enum { WTGPU_OK = 0, WTGPU_ERR_INVALID = 1, WTGPU_ERR_NO_DEVICE = 2, WTGPU_ERR_HIP = 3, WTGPU_ERR_OOM = 4, WTGPU_ERR_OVERFLOW = 5 };
+
+/* Parameters of a bundled scene; negative/zero fields select the scene file's defaults.
+ * Mirrors the CLI `-D res=..` defines + integrator attributes the reference reads
+ * (src/main.cpp:805-928; src/integrator/plt_bdpt.cpp:169-174). */
+typedef struct wtgpu_scene_params {
+    uint32_t res;
+    int32_t max_depth;
+    int32_t fsd;
+    int32_t mis;
+    int32_t rr;
+    int32_t force_ray_tracing; /* --ray-tracing (include/wt/wt_context.hpp:43) */
+    int32_t mesh_detail;       /* 0: low-poly stand-ins, 1: full tessellation */
+    uint32_t lut_n_theta, lut_m; /* resolution of the regenerated Fraunhofer iCDF LUT (0: default) */
+    uint32_t debug_only_s, debug_only_t; /* test hook: 0 = all strategies; v>0 evaluates only s (t) = v-1 with unit MIS weight */
+} wtgpu_scene_params;
+
+typedef struct wtgpu_scene_info {
+    uint32_t width, height, channels;
+    uint32_t n_tris, n_edges, n_nodes, n_leaves, n_shapes, n_emitters, n_materials;
+    int32_t max_depth;
+    uint32_t sensor_type; /* 0 perspective, 1 virtual_plane */
+    double fsd_lut_power[2]; /* integrals of the regenerated LUT densities (compare: PA1, PA2 of fsd.hpp:59-61) */
+    uint64_t bytes_per_sample_state; /* device bytes of per-sample path/vertex state */
+} wtgpu_scene_info;
+
+/* Device counters (the reference's stat collectors: include/wt/integrator/stats.hpp:27-83, include/wt/ads/ads_stats.hpp),
+ * the inputs of the algorithmic-bytes formula of SURVEY.md §8(d). */
+typedef struct wtgpu_counters {
+    uint64_t samples;
+    uint64_t segments, ray_queries, cone_queries, vertices, connections, shadow_rays;
+    uint64_t cone_tri_overflow, edge_overflow, fsd_edge_overflow, fsd_pool_overflow, fsd_interactions, null_interactions;
+    uint64_t surface_interactions, light_splats;
+    uint64_t walk_iteration_cap_hits;
+} wtgpu_counters;
+
+/* Host-side scene baking (no GPU needed): builds one of the bundled scenes
+ * ("double_slits" = scenes/diffraction_simple/double_slits.xml, "cornell_box" = scenes/cornell-box/box.xml stand-in,
+ * "furnace" = test scene).  Replaces scene_bootstrap_t<xml_loader_t,bvh8w_constructor_t> (src/main.cpp:634-648). */
+int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params, wtgpu_scene** out);
+
+/* Wraps an already flattened scene (a `wt::scene_t`, wave_tracer_amd/csrc/wt/scene.h, with host pointers that must
+ * outlive the handle).  This is the entry point a port of the reference's own loader would call. */
+int wtgpu_scene_create_from_desc(const void* scene_desc_host, wtgpu_scene** out);
+
+int wtgpu_scene_get_info(const wtgpu_scene* scene, wtgpu_scene_info* info);
+
+/* Host pointer to the flattened `wt::scene_t` (for CPU-side checkers and tools). */
+const void* wtgpu_scene_host_desc(const wtgpu_scene* scene);
+
+/* Copies the flattened scene to `device` and allocates the per-sample path state for `max_batch_samples` samples
+ * per launch (0: default).  Fails with WTGPU_ERR_NO_DEVICE when no HIP device is present: there is no CPU fallback. */
+int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_samples);
+
+/* Renders sample indices [sample_begin, sample_end) of every sensor element (the `spp` loop of
+ * integrator_t::integrate for all pixels) and accumulates into the caller-owned DEVICE film buffers
+ *     d_value  [height][width][channels] f64,  d_weight [height][width] f64,  d_light [height][width][channels] f64.
+ * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous w.r.t. the host except for the
+ * small per-round queue-size readbacks.  RNG: Philox-4x32-10 keyed by `seed`, counter = (pixel, sample, stream). */
+int wtgpu_render(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin, uint64_t sample_end,
+                 uint64_t seed);
+
+/* Per-query ADS entry points (ads_t::intersect(ray) / integrator::traverse(cone), include/wt/ads/ads.hpp:71-113,
+ * include/wt/integrator/traversal.hpp:94-172) on device-resident arrays; used by the traversal parity tests.
+ * rays:  n x {ox,oy,oz, dx,dy,dz, tmin,tmax}            cones: n x {ox,oy,oz, dx,dy,dz, tan_alpha, x0, ecc, lambda_m} */
+int wtgpu_trace_rays(wtgpu_scene* scene, void* stream, const float* d_rays, uint32_t n, float* d_dist, uint32_t* d_tuid, float* d_bary,
+                     uint32_t* d_front);
+int wtgpu_traverse_cones(wtgpu_scene* scene, void* stream, const float* d_cones, uint32_t n, uint32_t cap, float* d_dist, uint32_t* d_flags,
+                         uint32_t* d_ntris, uint32_t* d_tris);
+
+/* Accumulated device counters since upload / last reset. */
+int wtgpu_get_counters(wtgpu_scene* scene, wtgpu_counters* out);
+int wtgpu_reset_counters(wtgpu_scene* scene);
+
+/* Average device time [ms] of each kernel of the last wtgpu_render call, measured with hipEvents on `stream`:
+ * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact (sum), out[3]=connect, out[4]=number of rounds. */
+int wtgpu_last_render_timings(const wtgpu_scene* scene, float out[8]);
+
+/* Host-side film development (render_context_t::develop, src/scene/render.cpp:245-291):
+ * out[h][w][c] = value/weight (0 if weight==0) + light * (1/spe). */
+int wtgpu_develop(const wtgpu_scene* scene, const double* value, const double* weight, const double* light, uint64_t spe, float* out);
+
+void wtgpu_scene_destroy(wtgpu_scene* scene);
+const char* wtgpu_last_error(void);
+const char* wtgpu_scene_stats_json(const wtgpu_scene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WTGPU_H */

@@ -1,0 +1,170 @@
+// oracle/oracle.cpp — CPU checker for the wave_tracer_amd hot path.            *** TEST INFRASTRUCTURE ***
+//
+// What this is: a scalar, per-sample, per-pixel CPU rendering loop that follows the reference's control flow
+// (src/integrator/plt_bdpt.cpp:43-148: for each sample { spectral+emitter sample; sensor sample; sensor subpath;
+// emitter subpath; all (s,t) connections with MIS; splat }), parallelised over pixel tiles with std::thread like the
+// reference's render loop (src/scene/render.cpp:99-172: 24x24-pixel blocks).  It is used ONLY by tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product path.
+//
+// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path and cannot be built here
+// (all submodules / LFS assets are absent), so this checker cannot be validated against the
+// reference's own outputs.  It shares the low-level physics headers (wave_tracer_amd/csrc/wt/*.h, each function
+// citing the reference file:line it restates) with the HIP kernels; what it checks independently is the GPU
+// orchestration (wavefront scheduling, SoA state, LDS stacks, queues, atomics) — sample for sample, with identical
+// counter-based random numbers.  The physics primitives themselves are pinned by closed-form / numpy / scipy
+// known-answer tests in tests/test_kat.py and by the analytic double-slit fringe gate.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../wave_tracer_amd/csrc/wt/bdpt.h"
+
+using namespace wt;
+
+namespace {
+
+constexpr uint32_t kMaxWalkIters = 96;   // must match kernels.hip (cap on trace/interact rounds per subpath)
+
+struct sample_scratch_t {
+    std::vector<uint32_t> svert, evert;   // vertex stores (stride 1)
+    stack_entry_t stack[128];
+    uint32_t tris[kMaxConeTris];
+};
+
+void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
+    unsigned long long* pa = reinterpret_cast<unsigned long long*>(&a);
+    const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(&b);
+    for (size_t i = 0; i < sizeof(bdpt_counters_t) / sizeof(unsigned long long); ++i) pa[i] += pb[i];
+}
+
+void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream,
+              sample_scratch_t& scr, bdpt_counters_t& ctr) {
+    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    const uint_list_t tris{scr.tris, 1, kMaxConeTris};
+    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+        const cone_t env = walk_trace_envelope(sc, w);
+        const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris);
+        ctr.segments++;
+        ctr.ray_queries += tr.n_ray_queries;
+        ctr.cone_queries += tr.n_cone_queries;
+        ctr.cone_tri_overflow += tr.overflow;
+        w.active = bdpt_walk_step(sc, w, tr, tris, vs, pool, seed, sample_id, stream, &ctr) ? 1u : 0u;
+    }
+    w.active = 0;
+}
+
+}   // namespace
+
+extern "C" {
+
+// Renders samples [sample_begin, sample_end) of every pixel into (value, weight, light) (accumulating).
+// `scene_host` points to a wt::scene_t whose pointers are host pointers.
+int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
+                  int n_threads, unsigned long long* counters_out /* sizeof(bdpt_counters_t)/8 entries or NULL */) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const uint32_t W = sc.sensor.width, H = sc.sensor.height;
+    film_t film{value, weight, light, W, H, sc.sensor.channels};
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    const uint32_t B = 24;   // include/wt/wt_context.hpp:45
+    const uint32_t bx = (W + B - 1) / B, by = (H + B - 1) / B;
+    std::atomic<uint32_t> next{0};
+    std::vector<bdpt_counters_t> ctrs(n_threads);
+    for (auto& c : ctrs) std::memset(&c, 0, sizeof(c));
+    // FSD aperture pool: per thread, reset per sample (apertures only live for one sample)
+    auto worker = [&](int tid) {
+        sample_scratch_t scr;
+        scr.svert.resize(kMaxVerts * kVertexWords);
+        scr.evert.resize(kMaxVerts * kVertexWords);
+        std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);
+        std::vector<fsd_edge_t> edges((2 * kMaxVerts + 8) * (size_t)kFsdMaxEdges);
+        uint32_t pool_counter = 0;
+        const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size()};
+        bdpt_counters_t& ctr = ctrs[tid];
+        const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+        for (;;) {
+            const uint32_t blk = next.fetch_add(1);
+            if (blk >= bx * by) break;
+            const uint32_t x0 = (blk % bx) * B, y0 = (blk / bx) * B;
+            for (uint32_t y = y0; y < std::min(H, y0 + B); ++y)
+                for (uint32_t x = x0; x < std::min(W, x0 + B); ++x)
+                    for (uint64_t s = sample_begin; s < sample_end; ++s) {
+                        const uint64_t pix = (uint64_t)y * W + x;
+                        const uint64_t sample_id = (pix << 32) | (s & 0xFFFFFFFFull);
+                        pool_counter = 0;
+                        sample_ctx_t ctx;
+                        walk_t sw, ew;
+                        const vertex_store_t svs{scr.svert.data(), 1, 0}, evs{scr.evert.data(), 1, 0};
+                        bdpt_generate(sc, seed, sample_id, x, y, ctx, sw, ew, svs, evs);
+                        run_walk(sc, sw, svs, pool, seed, sample_id, STREAM_SENSOR_WALK, scr, ctr);
+                        run_walk(sc, ew, evs, pool, seed, sample_id, STREAM_EMITTER_WALK, scr, ctr);
+                        bdpt_connect_all(sc, pool, film, svs, evs, (int)sw.nverts, (int)ew.nverts, ctx, seed, sample_id, stack, &ctr, nullptr);
+                    }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
+    if (counters_out) {
+        bdpt_counters_t total;
+        std::memset(&total, 0, sizeof(total));
+        for (auto& c : ctrs) add_counters(total, c);
+        std::memcpy(counters_out, &total, sizeof(total));
+    }
+    return 0;
+}
+
+int oracle_counters_count() { return (int)(sizeof(bdpt_counters_t) / sizeof(unsigned long long)); }
+
+// ---- per-query entry points for the traversal parity tests ---------------------------------------------------
+// rays: n x {ox,oy,oz,dx,dy,dz,tmin,tmax}; out: n x {dist, tuid(as float bits), bx, by, front}
+int oracle_trace_rays(const void* scene_host, const float* rays, uint32_t n, float* out_dist, uint32_t* out_tuid, float* out_bary, uint32_t* out_front) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    stack_entry_t st[128];
+    const stack_ref_t stack = make_flat_stack(st, 128);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* r = rays + 8 * i;
+        ray_hit_t h;
+        ads_intersect_ray(sc, vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, range_t{r[6], r[7]}, stack, h);
+        out_dist[i] = h.dist;
+        out_tuid[i] = h.tuid;
+        out_bary[2 * i] = h.bx;
+        out_bary[2 * i + 1] = h.by;
+        out_front[i] = h.front_face;
+    }
+    return 0;
+}
+// cones: n x {ox,oy,oz, dx,dy,dz, tan_alpha, x0, ecc, lambda_m}; runs the full traverse() policy.
+// out: dist, ballistic flag, ntris, sorted tri ids (cap per query)
+int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n, uint32_t cap, float* out_dist, uint32_t* out_flags, uint32_t* out_ntris,
+                          uint32_t* out_tris) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    stack_entry_t st[128];
+    const stack_ref_t stack = make_flat_stack(st, 128);
+    std::vector<uint32_t> tl(kMaxConeTris);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* c = cones + 10 * i;
+        const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+        const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+        const uint_list_t tris{tl.data(), 1, kMaxConeTris};
+        const trav_result_t tr = traverse(sc, env, c[9], WT_INF, false, stack, tris);
+        out_dist[i] = tr.dist;
+        out_flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
+        out_ntris[i] = tr.ballistic ? (tr.empty ? 0 : 1) : tr.ntris;
+        for (uint32_t j = 0; j < cap; ++j) out_tris[(size_t)i * cap + j] = kInvalid;
+        if (tr.ballistic) {
+            if (!tr.empty) out_tris[(size_t)i * cap] = tr.tuid;
+        } else {
+            std::vector<uint32_t> s(tl.begin(), tl.begin() + tr.ntris);
+            std::sort(s.begin(), s.end());
+            for (uint32_t j = 0; j < tr.ntris && j < cap; ++j) out_tris[(size_t)i * cap + j] = s[j];
+        }
+    }
+    return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Builds libwtgpu.so / liboracle.so if they are missing (hipcc cross-compiles without a GPU)."""
+    import __graft_entry__ as g
+    from wave_tracer_amd.api import lib_path
+    if not os.path.exists(lib_path()) or not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so")):
+        g.build()
+    return True

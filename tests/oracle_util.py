@@ -1,0 +1,40 @@
+"""Loader for the CPU checker (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def load_oracle():
+    global _lib
+    if _lib is None:
+        p = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+        if not os.path.exists(p):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        lib = C.CDLL(p)
+        lib.oracle_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.oracle_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.oracle_traverse_cones.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+ORACLE_COUNTERS = ["segments", "ray_queries", "cone_queries", "vertices", "connections", "shadow_rays", "cone_tri_overflow", "edge_overflow",
+                   "fsd_edge_overflow", "fsd_pool_overflow", "fsd_interactions", "null_interactions", "surface_interactions", "light_splats"]
+
+
+def oracle_render(scene, sample_begin, sample_end, seed, threads=0):
+    lib = load_oracle()
+    H, W, Cn = scene.height, scene.width, scene.channels
+    value = np.zeros((H, W, Cn), np.float64)
+    weight = np.zeros((H, W), np.float64)
+    light = np.zeros((H, W, Cn), np.float64)
+    ctr = np.zeros(lib.oracle_counters_count(), np.uint64)
+    rc = lib.oracle_render(scene.host_desc(), sample_begin, sample_end, seed, value.ctypes.data, weight.ctypes.data, light.ctypes.data, threads,
+                           ctr.ctypes.data)
+    assert rc == 0
+    return value, weight, light, dict(zip(ORACLE_COUNTERS, [int(x) for x in ctr]))

@@ -1,0 +1,150 @@
+"""ctypes binding of the C-ABI in include/wtgpu.h (libwtgpu.so).  No compute happens in Python."""
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libwtgpu.so")
+
+
+class WtgpuError(RuntimeError):
+    pass
+
+
+class SceneParams(C.Structure):
+    _fields_ = [("res", C.c_uint32), ("max_depth", C.c_int32), ("fsd", C.c_int32), ("mis", C.c_int32), ("rr", C.c_int32),
+                ("force_ray_tracing", C.c_int32), ("mesh_detail", C.c_int32), ("lut_n_theta", C.c_uint32), ("lut_m", C.c_uint32),
+                ("debug_only_s", C.c_uint32), ("debug_only_t", C.c_uint32)]
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("n_tris", C.c_uint32), ("n_edges", C.c_uint32),
+                ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_shapes", C.c_uint32), ("n_emitters", C.c_uint32),
+                ("n_materials", C.c_uint32), ("max_depth", C.c_int32), ("sensor_type", C.c_uint32), ("fsd_lut_power", C.c_double * 2),
+                ("bytes_per_sample_state", C.c_uint64)]
+
+
+COUNTER_FIELDS = ["samples", "segments", "ray_queries", "cone_queries", "vertices", "connections", "shadow_rays", "cone_tri_overflow",
+                  "edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow", "fsd_interactions", "null_interactions",
+                  "surface_interactions", "light_splats", "walk_iteration_cap_hits"]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in COUNTER_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in COUNTER_FIELDS}
+
+
+# every symbol include/wtgpu.h declares
+SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_scene_get_info", "wtgpu_scene_host_desc",
+           "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
+           "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
+           "wtgpu_scene_stats_json"]
+
+_lib = None
+
+
+def load_library():
+    """Loads libwtgpu.so; raises loudly if the HIP extension has not been built (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise WtgpuError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"(hipcc --offload-arch=gfx950); wave_tracer_amd has no CPU fallback")
+    lib = C.CDLL(p)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    lib.wtgpu_scene_create_named.argtypes = [C.c_char_p, C.POINTER(SceneParams), C.POINTER(vp)]
+    lib.wtgpu_scene_create_from_desc.argtypes = [vp, C.POINTER(vp)]
+    lib.wtgpu_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    lib.wtgpu_scene_host_desc.argtypes = [vp]
+    lib.wtgpu_scene_host_desc.restype = vp
+    lib.wtgpu_scene_upload.argtypes = [vp, i32, u64]
+    lib.wtgpu_render.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64]
+    lib.wtgpu_trace_rays.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+    lib.wtgpu_traverse_cones.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    lib.wtgpu_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    lib.wtgpu_reset_counters.argtypes = [vp]
+    lib.wtgpu_last_render_timings.argtypes = [vp, C.POINTER(C.c_float * 8)]
+    lib.wtgpu_develop.argtypes = [vp, vp, vp, vp, u64, vp]
+    lib.wtgpu_scene_destroy.argtypes = [vp]
+    lib.wtgpu_scene_destroy.restype = None
+    lib.wtgpu_last_error.restype = C.c_char_p
+    lib.wtgpu_scene_stats_json.argtypes = [vp]
+    lib.wtgpu_scene_stats_json.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise WtgpuError(f"wtgpu error {rc}: {load_library().wtgpu_last_error().decode()}")
+
+
+class Scene:
+    """Handle of a flattened scene (host-baked; optionally uploaded to one GPU)."""
+
+    def __init__(self, name, res=256, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, mesh_detail=1, lut=(0, 0), only_s=None, only_t=None):
+        lib = load_library()
+        p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, mesh_detail, lut[0], lut[1],
+                        0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1)
+        h = C.c_void_p()
+        _check(lib.wtgpu_scene_create_named(name.encode(), C.byref(p), C.byref(h)))
+        self._h = h
+        self.name = name
+        info = SceneInfo()
+        _check(lib.wtgpu_scene_get_info(h, C.byref(info)))
+        self.info = info
+        self.width, self.height, self.channels = info.width, info.height, info.channels
+        self.device = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def host_desc(self):
+        return load_library().wtgpu_scene_host_desc(self._h)
+
+    def stats(self):
+        return json.loads(load_library().wtgpu_scene_stats_json(self._h).decode())
+
+    def upload(self, device=0, max_batch_samples=0):
+        _check(load_library().wtgpu_scene_upload(self._h, int(device), int(max_batch_samples)))
+        self.device = int(device)
+        return self
+
+    def render_into(self, value, weight, light, sample_begin, sample_end, seed, stream=None):
+        """value/weight/light: CUDA(HIP) float64 torch tensors [H,W,C], [H,W], [H,W,C] (accumulated into)."""
+        sp = C.c_void_p(stream) if stream else None
+        _check(load_library().wtgpu_render(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), int(sample_begin),
+                                           int(sample_end), int(seed)))
+
+    def counters(self):
+        c = Counters()
+        _check(load_library().wtgpu_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        _check(load_library().wtgpu_reset_counters(self._h))
+
+    def timings(self):
+        t = (C.c_float * 8)()
+        _check(load_library().wtgpu_last_render_timings(self._h, C.byref(t)))
+        return {"generate_ms": t[0], "trace_ms": t[1], "interact_ms": t[2], "connect_ms": t[3], "rounds": int(t[4]),
+                "trace_launches": int(t[5]), "batches": int(t[6])}
+
+    def close(self):
+        if self._h:
+            load_library().wtgpu_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,149 @@
+// wave_tracer_amd — host-side scene baking: procedural meshes -> world-space triangles -> binned-SAH BVH ->
+// 8-wide collapse -> wedge/edge table -> spectral tables -> emitter/sensor sampling tables -> flattened wt::scene_t.
+//
+// This replaces, for the hot path's needs only, the reference's scene loader + ADS constructor (which cannot be
+// built here: tinybvh/pugixml/... are absent):
+//   src/ads/bvh_constructor.cpp:123-251 (SAH build; tinybvh replaced by an own binned-SAH builder),
+//   src/ads/bvh8w_constructor.cpp:27-103,153-268 (collapse 3 binary levels into one 8-wide node),
+//   include/wt/ads/edge_classification.hpp:31-238 (edges), src/mesh/*.cpp (procedural shapes),
+//   src/scene/scene_build_sensor_sampling_data.cpp:40-150 (emitter x sensitivity tables).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../wt/scene.h"
+
+namespace wth {
+
+struct dvec3 {
+    double x, y, z;
+};
+struct xform_t {   // row-major 4x4, column-vector convention: p' = M p
+    double m[16];
+    static xform_t identity();
+    static xform_t translate(double x, double y, double z);
+    static xform_t scale(double x, double y, double z);
+    static xform_t rotate(double ax, double ay, double az, double angle_rad);
+    static xform_t lookat(dvec3 origin, dvec3 target, dvec3 up);
+    static xform_t from_rows(const double r[16]);
+    xform_t operator*(const xform_t& o) const;
+    dvec3 point(dvec3 p) const;
+    dvec3 vector(dvec3 v) const;
+    dvec3 normal(dvec3 n) const;   // inverse-transpose for normals (normalised)
+};
+
+struct mesh_t {
+    std::vector<dvec3> verts;
+    std::vector<dvec3> normals;     // empty: face normals
+    std::vector<std::array<float, 2>> uvs;   // empty: no uv
+    std::vector<std::array<uint32_t, 3>> tris;
+};
+mesh_t mesh_rectangle(dvec3 p, dvec3 x, dvec3 y);
+mesh_t mesh_rectangle_scaled(double length);
+mesh_t mesh_cube(double length);
+mesh_t mesh_sphere(dvec3 centre, double r, int tessellation);
+mesh_t mesh_blob(double r, int recursion, double bump, int freq, uint32_t seed);
+mesh_t mesh_cylinder(dvec3 p0, dvec3 p1, double radius, int tessellation);
+mesh_t mesh_prism(double length, double height, double angle_rad);
+
+class scene_builder_t {
+public:
+    scene_builder_t();
+    // spectra
+    int spectrum_const(float re, float im = 0.f);
+    int spectrum_discrete(float wavelength_mm, float value);
+    int spectrum_from_wavelength_table(const float* values_re, const float* values_im, int n, float lmin_nm, float lstep_nm);
+    int spectrum_blackbody(float T, float scale);
+    int spectrum_named(const std::string& name);   // "Al","Au","SF5","SF11","BK7","Ag","Cu","CFL2534","CMF_X/Y/Z"
+    // real-valued spectrum evaluation on the host (for baking)
+    float spectrum_eval(int id, float k) const;
+
+    int add_material(const wt::material_t& m);
+    int add_shape(const mesh_t& mesh, const xform_t& to_world, int material, bool face_normals = false);
+    int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);
+    int add_emitter_area(int shape, int spectrum, float scale, float pse_scale);
+
+    void set_sensor_perspective(const xform_t& to_world, double fov_rad, uint32_t w, uint32_t h, float pse_scale, bool ray_trace_only);
+    void set_sensor_virtual_plane(const xform_t& to_world, double extent_x, double extent_y, uint32_t w, uint32_t h, float tan_alpha);
+    void set_film_rfilter_scale(float s);
+    // response: "RGB" (CIE colourspace, given white point XYZ) or monochromatic discrete line
+    void set_response_rgb(const float white_xyz[3]);
+    void set_response_mono_discrete(float wavelength_mm);
+    void set_integrator(const wt::integrator_opts_t& o);
+    void set_fsd_lut_resolution(uint32_t n_theta, uint32_t m);
+
+    // builds everything; the returned scene points into this builder's storage
+    const wt::scene_t& finalize();
+    const wt::scene_t& scene() const { return sc_; }
+    std::string stats() const;
+
+private:
+    struct shape_rec_t {
+        int material;
+        int emitter;
+        std::vector<uint32_t> tri_first;   // index of first world tri
+        uint32_t tri_begin, tri_count;
+    };
+    struct wtri_t {
+        wt::vec3 a, b, c, n;
+        wt::vec3 n0, n1, n2;
+        wt::vec2 uv0, uv1, uv2;
+        uint32_t has_uv;
+        uint32_t shape, shape_tri;
+    };
+    void build_bvh();
+    void build_edges();
+    void build_sampling_tables();
+    void build_fsd_lut();
+
+    std::vector<wtri_t> wtris_;   // world triangles in insertion order
+    std::vector<shape_rec_t> shape_recs_;
+    // flattened storage
+    std::vector<wt::tri_geo_t> tri_geo_;
+    std::vector<wt::tri_meta_t> tri_meta_;
+    std::vector<wt::tri_shade_t> tri_shade_;
+    std::vector<wt::edge_t> edges_;
+    std::vector<wt::bvh8_node_t> nodes_;
+    std::vector<wt::bvh8_leaf_t> leaves_;
+    std::vector<wt::shape_t> shapes_;
+    std::vector<uint32_t> shape_tri_tuid_;
+    std::vector<float> shape_tri_cdf_;
+    std::vector<wt::material_t> materials_;
+    std::vector<wt::spectrum_t> spectra_;
+    std::vector<float> spectra_data_;
+    std::vector<wt::emitter_t> emitters_;
+    std::vector<float> emitter_cdf_;
+    std::vector<wt::kdist_t> kdists_;
+    std::vector<float> kdist_data_;
+    std::vector<float> lut_theta1_, lut_theta2_, lut1_, lut2_;
+    uint32_t lut_n_theta_ = 512, lut_m_ = 512;
+    float rfilter_scale_ = 1.f;
+    bool response_is_rgb_ = true;
+    float mono_lambda_mm_ = 0.f;
+    int sensitivity_spec_ = -1;
+    wt::scene_t sc_;
+    bool finalized_ = false;
+    uint32_t bvh_max_depth_ = 0;
+    double lut_power_[2] = {0, 0};
+
+public:
+    double fsd_lut_power(int which) const { return lut_power_[which]; }
+};
+
+// bundled scenes (host/scenes.cpp)
+struct scene_params_t {
+    uint32_t res;
+    int32_t max_depth;     // <0: scene default
+    int32_t fsd;           // <0: default; 0/1
+    int32_t mis, rr;       // <0: default
+    int32_t force_ray_tracing;
+    int32_t mesh_detail;   // 0: low-poly stand-ins (tests), 1: full stand-in tessellation
+    uint32_t lut_n_theta, lut_m;
+    uint32_t debug_only_s, debug_only_t;
+};
+// names: "double_slits", "cornell_box", "furnace" (diffuse box test scene)
+bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b);
+
+}   // namespace wth

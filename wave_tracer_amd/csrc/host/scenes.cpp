@@ -1,0 +1,229 @@
+// wave_tracer_amd — the bundled scenes, built procedurally (the reference's XML loader cannot be built here and
+// most of its mesh/texture assets are Git-LFS stubs).
+//
+//   "double_slits" : scenes/diffraction_simple/double_slits.xml + bits/geometry.xml exactly as shipped (pattern
+//                    sensor, screen=true, reflectors=false), minus the two `directional` preview emitters whose
+//                    overlap with the 50 um monochromatic sensor is ~1e-9 of the spot's power.
+//   "cornell_box"  : scenes/cornell-box/box.xml with the three PLY meshes replaced by procedural stand-ins of
+//                    comparable triangle counts, the bitmap texture by its constant stand-in and the lens by an
+//                    oblate dielectric spheroid.  Everything else (walls, prism, ball, pipe, cube source, both
+//                    spots, camera, integrator options, materials, spectra) follows the XML.
+//   "furnace"      : closed diffuse box + small area light, perspective camera inside (test scene).
+#include <cmath>
+#include <stdexcept>
+
+#include "scene_builder.h"
+
+namespace wth {
+using namespace wt;
+
+static const double cm = 1e-2, mm = 1e-3;
+static inline double deg(double d) { return d * M_PI / 180.0; }
+
+static material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided) {
+    material_t m{};
+    m.type = MAT_DIFFUSE;
+    m.two_sided = two_sided;
+    m.scale = 1.f;
+    m.refl_spec = refl_spec;
+    m.refl_tex_scale = tex_scale;
+    m.ior_spec = m.ext_ior_spec = -1;
+    m.refl_scale = m.trans_scale = 1.f;
+    m.gamma = 3.f;
+    return m;
+}
+static material_t mat_dielectric(int ior_spec) {
+    material_t m{};
+    m.type = MAT_DIELECTRIC;
+    m.scale = 1.f;
+    m.refl_spec = -1;
+    m.ior_spec = ior_spec;
+    m.ext_ior_spec = -1;
+    m.refl_scale = m.trans_scale = 1.f;
+    m.gamma = 3.f;
+    return m;
+}
+static material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, bool two_sided, float scale) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM;
+    m.two_sided = two_sided;
+    m.scale = scale;
+    m.refl_spec = -1;
+    m.ior_spec = ior_spec;
+    m.ext_ior_spec = -1;
+    m.profile = fractal ? PROFILE_FRACTAL : PROFILE_DIRAC;
+    m.roughness = roughness;
+    m.gamma = gamma;
+    m.refl_scale = m.trans_scale = 1.f;
+    return m;
+}
+static void apply_opts(const scene_params_t& p, integrator_opts_t& o) {
+    if (p.max_depth >= 0) o.max_depth = p.max_depth;
+    if (p.fsd >= 0) o.FSD = p.fsd;
+    if (p.mis >= 0) o.MIS = p.mis;
+    if (p.rr >= 0) o.RR = p.rr;
+    if (p.force_ray_tracing > 0) o.force_ray_tracing = 1;
+    o.debug_only_s = p.debug_only_s;
+    o.debug_only_t = p.debug_only_t;
+}
+
+// ---- scenes/diffraction_simple/double_slits.xml ---------------------------------------------------------------
+static void build_double_slits(const scene_params_t& p, scene_builder_t& b) {
+    const double L = -500, Lscale = 1633, S = 50, E = 5, extent = 250, D = 12, H = 20, Z = -15, lambda = .05, W = .65, Wslit = .35;
+    integrator_opts_t o{};
+    o.max_depth = 16;
+    o.MIS = o.RR = o.FSD = o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    if (p.lut_m) b.set_fsd_lut_resolution(p.lut_n_theta, p.lut_m);
+
+    // sensor "pattern": virtual_plane, alpha=.001deg, film res x res/4, rfilter_scale .05, monochromatic lambda
+    const uint32_t w = p.res, h = std::max(1u, p.res / 4);
+    b.set_sensor_virtual_plane(xform_t::lookat({0, 0, (S - .0001) * mm}, {0, 0, E * mm}, {0, -1, 0}), extent * mm, extent / 4 * mm, w, h,
+                               (float)std::tan(deg(.001)));
+    b.set_film_rfilter_scale(.05f);
+    b.set_response_mono_discrete((float)lambda);
+
+    // emitter "source": spot, beam_width .1deg, cutoff .2deg, discrete line lambda, value Lscale
+    const int em_spec = b.spectrum_discrete((float)lambda, (float)Lscale);
+    b.add_emitter_spot(xform_t::lookat({0, 0, L * mm}, {0, 0, 0}, {0, 1, 0}), em_spec, 1.f, (float)deg(.2), (float)deg(.1), -1.f, 1.f);
+
+    // materials. composite BSDFs/spectra are resolved at the sensor's single wavelength (50 um -> "1um .. 1m" bins)
+    const int screen_ior = b.spectrum_const(1.f, 100.f);
+    const int m_screen = b.add_material(mat_spm(screen_ior, true, .3f, 3.f, true, 1.f));
+    const int m_floor = b.add_material(mat_diffuse(b.spectrum_const(.1f), 1.f, true));
+    const int m_wall = b.add_material(mat_diffuse(b.spectrum_const(.9f), 1.f, true));
+
+    const xform_t I = xform_t::identity();
+    // wall, floor (bits/geometry.xml)
+    b.add_shape(mesh_rectangle({-100 * mm, -H * mm, S * mm}, {200 * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_wall);
+    b.add_shape(mesh_rectangle({-100 * mm, -H * mm, (L - 100) * mm}, {200 * mm, 0, 0}, {0, 0, (S - L + 100) * mm}), I, m_floor);
+    // screen: three rectangles leaving two slits of width Wslit centred at +-W/2
+    b.add_shape(mesh_rectangle({-D / 2 * mm, -H * mm, Z * mm}, {(D / 2 - (W + Wslit) / 2) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+    b.add_shape(mesh_rectangle({(-W / 2 + Wslit / 2) * mm, -H * mm, Z * mm}, {(W - Wslit) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+    b.add_shape(mesh_rectangle({(W + Wslit) / 2 * mm, -H * mm, Z * mm}, {(D / 2 - (W + Wslit) / 2) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+}
+
+// ---- scenes/cornell-box/box.xml (stand-in) ----------------------------------------------------------------------
+static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
+    integrator_opts_t o{};
+    o.max_depth = 16;
+    o.MIS = o.RR = o.FSD = o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    if (p.lut_m) b.set_fsd_lut_resolution(p.lut_n_theta, p.lut_m);
+
+    b.set_sensor_perspective(xform_t::lookat({0, 1 * cm, 6.8 * cm}, {0, 1 * cm, 0}, {0, 1, 0}), deg(19.75), p.res, p.res, 1.f, false);
+    const float D55[3] = {0.95682f, 1.00000f, 0.92149f};
+    b.set_response_rgb(D55);
+
+    // materials
+    const int tiles = b.add_material(mat_diffuse(b.spectrum_const(.35f), .5f, true));   // scale .35 x bitmap (stand-in .5)
+    const int right_wall = b.add_material(mat_diffuse(b.spectrum_const(.6f), 1.f, true));
+    const int screen = b.add_material(mat_spm(b.spectrum_named("Al"), true, .01f, 3.f, true, .1f));
+    const int gold = b.add_material(mat_spm(b.spectrum_named("Au"), false, 0.f, 3.f, false, 1.f));
+    const int sf5 = b.add_material(mat_dielectric(b.spectrum_named("SF5")));
+    const int sf11 = b.add_material(mat_dielectric(b.spectrum_named("SF11")));
+    const int pipe_m = b.add_material(mat_diffuse(b.spectrum_const(.0215f), 1.f, true));
+    const int cube_m = b.add_material(mat_diffuse(b.spectrum_const(.01f), 1.f, false));
+
+    auto M = [](std::initializer_list<double> r) {
+        double v[16];
+        int i = 0;
+        for (double x : r) v[i++] = x;
+        return xform_t::from_rows(v);
+    };
+    const mesh_t rect = mesh_rectangle_scaled(2 * cm);
+    b.add_shape(rect, M({0, 1, 0, 0, 0, 0, 2, 0, 1, 0, 0, 0, 0, 0, 0, 1}), tiles);                 // floor
+    b.add_shape(rect, M({-1, 0, 0, 0, 0, 0, -2, 2 * cm, 0, -1, 0, 0, 0, 0, 0, 1}), tiles);         // ceiling
+    b.add_shape(rect, M({0, 1, 0, 0, -1, 0, 0, 1 * cm, 0, 0, 2, -1 * cm, 0, 0, 0, 1}), tiles);     // back wall
+    b.add_shape(rect, M({0, 0, -2, 1 * cm, -1, 0, 0, 1 * cm, 0, 1, 0, 0, 0, 0, 0, 1}), right_wall);
+    b.add_shape(rect, M({0, 0, 2, -1 * cm, -1, 0, 0, 1 * cm, 0, -1, 0, 0, 0, 0, 0, 1}), tiles);    // left wall
+
+    const int rec_big = p.mesh_detail ? 6 : 3;   // 81920 / 1280 triangles
+    // "dragon" stand-in: gold blob, scale 4.8 x 1cm model units (~ +-0.4cm), rotated 150deg about y, translated
+    b.add_shape(mesh_blob(.1 * cm, rec_big, .12, 9, 17),
+                xform_t::translate(.05 * cm, .55 * cm, 0) * xform_t::scale(4.0, 5.2, 3.0) * xform_t::rotate(0, 1, 0, deg(150)), gold);
+    // prism (length 6mm, height 1.2mm, 90deg), translate(-.705cm,.15cm,0)
+    b.add_shape(mesh_prism(6 * mm, 1.2 * mm, deg(90)), xform_t::translate(-.705 * cm, .15 * cm, 0), sf5);
+    // ball: sphere r=1.4mm at (-.65cm,.3cm,0), to_world scale y=.25
+    b.add_shape(mesh_sphere({-.65 * cm, .3 * cm, 0}, 1.4 * mm, 32), xform_t::scale(1, .25, 1), sf11);
+    // "bunny" stand-in: SF5 blob near (.50cm,.89cm,-.09cm)
+    b.add_shape(mesh_blob(.1 * cm, rec_big, .10, 6, 41),
+                xform_t::translate(.50 * cm, 1.19 * cm, -.09 * cm) * xform_t::rotate(0, 1, 0, deg(-35)) * xform_t::scale(2.6, 3.0, 2.2), sf5);
+    // "screen" stand-in for star_big.ply: thin plate, face normals, Al fractal (scaled .1), rotated about z, at x=-.425cm
+    b.add_shape(mesh_cube(1 * cm), xform_t::translate(-.425 * cm, 1 * cm, 0) * xform_t::scale(.01, .5, .45), screen, true);
+    // "dragon_lens" stand-in: oblate SF11 spheroid r=1.5mm at (.045,.65,3.5)cm, axis ~ rotate(-.2,1,0; 72deg)
+    b.add_shape(mesh_sphere({0, 0, 0}, 1.5 * mm, 48),
+                xform_t::translate(.045 * cm, .65 * cm, 3.5 * cm) * xform_t::rotate(-.2, 1, 0, deg(72)) * xform_t::scale(1, 1, .12), sf11);
+    // pipe
+    b.add_shape(mesh_cylinder({-1.1 * cm, 1 * cm, 0}, {-.97 * cm, 1 * cm, 0}, .033 * cm, 32), xform_t::identity(), pipe_m);
+    // cube_source: length .20cm, scale(3.1,.04,3.1), translate(.05,.02,-.05)cm, diffuse .01, area emitter blackbody 7000K x 4e-5
+    const int cube = b.add_shape(mesh_cube(.20 * cm), xform_t::translate(.05 * cm, .02 * cm, -.05 * cm) * xform_t::scale(3.1, .04, 3.1), cube_m);
+    b.add_emitter_area(cube, b.spectrum_blackbody(7000.f, 1.f), 4e-5f, 1.f);
+
+    // spots: both at (-.99cm,1cm,0) looking +x; CFL emission
+    const int cfl = b.spectrum_named("CFL2534");
+    const xform_t spot_x = xform_t::lookat({-.99 * cm, 1 * cm, 0}, {1 * cm, 1 * cm, 0}, {0, 1, 0});
+    b.add_emitter_spot(spot_x, cfl, 1.5f, (float)deg(3), (float)deg(1), -1.f, .45f);
+    b.add_emitter_spot(spot_x, cfl, 2e-2f, (float)deg(55), (float)deg(1), -1.f, .25f);
+}
+
+// ---- test scene: closed diffuse box with an area light -------------------------------------------------------------
+static void build_furnace(const scene_params_t& p, scene_builder_t& b) {
+    integrator_opts_t o{};
+    o.max_depth = 8;
+    o.MIS = o.RR = 1;
+    o.FSD = 0;
+    o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    if (p.lut_m) b.set_fsd_lut_resolution(p.lut_n_theta, p.lut_m);
+    b.set_sensor_perspective(xform_t::lookat({0, 0, .9}, {0, 0, 0}, {0, 1, 0}), deg(60), p.res, p.res, 1.f, false);
+    const float E[3] = {1, 1, 1};
+    b.set_response_rgb(E);
+    const int grey = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    const int lightm = b.add_material(mat_diffuse(b.spectrum_const(.0f), 1.f, false));
+    b.add_shape(mesh_cube(2.0), xform_t::identity(), grey);
+    const int q = b.add_shape(mesh_rectangle({-.25, .95, -.25}, {0, 0, .5}, {.5, 0, 0}), xform_t::identity(), lightm);
+    b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
+    // an occluder with silhouette edges in the middle of the room
+    b.add_shape(mesh_cube(.3), xform_t::translate(.2, -.3, -.2) * xform_t::rotate(0, 1, 0, deg(30)), grey);
+}
+
+// ---- test scene: "white furnace": closed cube whose inner faces are diffuse (albedo .5) area emitters.  The radiance
+// seen by the camera is Le * sum_{i<=max_depth} albedo^i, independent of position (closed-form gate for BSDF sampling,
+// pdfs, MIS and Russian roulette).
+static void build_white_furnace(const scene_params_t& p, scene_builder_t& b) {
+    integrator_opts_t o{};
+    o.max_depth = 4;
+    o.MIS = o.RR = 1;
+    o.FSD = 0;
+    o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    b.set_sensor_perspective(xform_t::lookat({0.1, -0.2, .3}, {0.3, 0.1, -1}, {0, 1, 0}), deg(50), p.res, p.res, 1.f, false);
+    const float E[3] = {1, 1, 1};
+    b.set_response_rgb(E);
+    const int grey = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, false));
+    // point-mirrored cube with face normals => geometric normals point inwards
+    const int q = b.add_shape(mesh_cube(2.0), xform_t::scale(-1, -1, -1), grey, true);
+    b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
+}
+
+bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
+    if (name == "double_slits")
+        build_double_slits(p, b);
+    else if (name == "cornell_box")
+        build_cornell_box(p, b);
+    else if (name == "furnace")
+        build_furnace(p, b);
+    else if (name == "white_furnace")
+        build_white_furnace(p, b);
+    else
+        return false;
+    b.finalize();
+    return true;
+}
+
+}   // namespace wth

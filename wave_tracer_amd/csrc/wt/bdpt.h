@@ -1,0 +1,868 @@
+// wave_tracer_amd — the bidirectional PLT integrator `plt_bdpt`: path vertices, subpath random walks, subpath
+// connections and MIS.
+//
+// Reference: src/integrator/plt_bdpt.cpp:43-148 (per-sample loop),
+//            include/wt/integrator/plt_bdpt/plt_bdpt_detail.hpp:70-183 (walk data), 192-346 (interactions),
+//            348-419 (find_closest_triangle), 421-526 (random_walk), 528-581 (subpath generation),
+//            604-720 (MIS), 722-745 (connect_and_integrate), 747-923 (connect_subpaths);
+//            include/wt/integrator/plt_bdpt/vertex.hpp:49-565.
+//
+// The reference's recursion / std::vector<vertex_t> / unique_ptr<fsd> arena become: an explicit walk state, a
+// strided vertex store (one SoA "plane" per vertex index) and a pool of fixed-capacity FSD apertures.  The
+// functions here are the building blocks shared by the HIP wavefront kernels (kernels.hip) and by the scalar
+// per-sample CPU loop of the checker (oracle/).
+#pragma once
+#include <cstddef>
+
+#include "bvh.h"
+#include "film.h"
+#include "fsd.h"
+
+namespace wt {
+
+constexpr uint32_t kMaxVerts = 18;       // max_depth(16) + 2
+constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
+constexpr uint32_t kMaxEdgeIds = 64;     // device cap of the de-duplicated edge set
+
+enum vertex_type_e : uint32_t { VT_SENSOR = 0, VT_EMITTER = 1, VT_SURFACE = 2, VT_MEDIUM = 3, VT_FSD = 4 };
+enum geo_kind_e : uint32_t { GEO_NONE = 0, GEO_POINT = 1, GEO_SURFACE = 2 };
+
+struct vertex_t {
+    uint32_t type;
+    uint32_t transport;
+    uint32_t delta;
+    uint32_t fraunhofer_fsd;
+    float pdf_fwd, pdf_bwd;
+    float rr_weight;
+    int32_t ref;          // emitter index (emitter vertex), material index (surface vertex)
+    int32_t emitter_of_shape;   // surface vertex: emitter attached to the hit shape (-1 none)
+    uint32_t fsd_slot;    // aperture pool slot (fsd vertex)
+    uint32_t geo_kind;
+    uint32_t has_beam;
+    surface_t surf;       // GEO_POINT: only surf.wp is meaningful
+    beam_t beam;          // beam arriving at this vertex
+};
+constexpr size_t kVertexWords = sizeof(vertex_t) / 4;
+
+// strided vertex store: vertex v of walk `idx` = words at base[(v*kVertexWords + w)*stride + idx]
+struct vertex_store_t {
+    uint32_t* base;
+    size_t stride;
+    size_t idx;
+    WT_HD void load(uint32_t v, vertex_t& out) const { soa_load(base + (size_t)v * kVertexWords * stride, stride, idx, out); }
+    WT_HD void store(uint32_t v, const vertex_t& in) const { soa_store(base + (size_t)v * kVertexWords * stride, stride, idx, in); }
+    template <class F>
+    WT_HD void store_word(uint32_t v, size_t word, F value) const {
+        static_assert(sizeof(F) == 4, "");
+        uint32_t w;
+        __builtin_memcpy(&w, &value, 4);
+        base[((size_t)v * kVertexWords + word) * stride + idx] = w;
+    }
+    template <class F>
+    WT_HD F load_word(uint32_t v, size_t word) const {
+        const uint32_t w = base[((size_t)v * kVertexWords + word) * stride + idx];
+        F f;
+        __builtin_memcpy(&f, &w, 4);
+        return f;
+    }
+};
+#define WT_VWORD(field) (offsetof(vertex_t, field) / 4)
+
+struct fsd_pool_t {
+    fsd_aperture_t* hdr;
+    fsd_edge_t* edges;     // [cap][kFsdMaxEdges]
+    uint32_t* counter;     // bump allocator
+    uint32_t cap;
+};
+WT_HD fsd_edges_ref_t fsd_pool_edges(const fsd_pool_t& p, uint32_t slot) {
+    return fsd_edges_ref_t{p.edges + (size_t)slot * kFsdMaxEdges, 1};
+}
+WT_HD uint32_t fsd_pool_alloc(const fsd_pool_t& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p.counter, 1u);
+#else
+    return __atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED);
+#endif
+}
+
+// ---- vertex helpers (vertex.hpp) --------------------------------------------------------------------
+WT_HD vec3 vertex_wp(const vertex_t& v) { return v.surf.wp; }
+WT_HD bool vertex_is_on_surface(const scene_t& sc, const vertex_t& v) {
+    return v.type == VT_SURFACE || (v.type == VT_EMITTER && emitter_is_area(sc.emitters[v.ref])) ||
+           (v.type == VT_SENSOR && v.geo_kind == GEO_SURFACE);
+}
+WT_HD bool vertex_has_real_surface(const scene_t& sc, const vertex_t& v) {
+    return v.type == VT_SURFACE || (v.type == VT_EMITTER && emitter_is_area(sc.emitters[v.ref]));
+}
+// ng()/ns(): sensors report (0,0,1) (vertex.hpp:271-287)
+WT_HD vec3 vertex_ng(const scene_t& sc, const vertex_t& v) { return vertex_has_real_surface(sc, v) ? v.surf.geo.n : vec3{0, 0, 1}; }
+WT_HD vec3 vertex_ns(const scene_t& sc, const vertex_t& v) { return vertex_has_real_surface(sc, v) ? v.surf.shading.n : vec3{0, 0, 1}; }
+WT_HD bool vertex_is_interaction(const vertex_t& v) { return v.type == VT_FSD || v.type == VT_SURFACE || v.type == VT_MEDIUM; }
+WT_HD bool vertex_on_emitter(const vertex_t& v) { return v.type == VT_EMITTER || (v.type == VT_SURFACE && v.emitter_of_shape >= 0); }
+WT_HD int vertex_get_emitter(const vertex_t& v) { return v.type == VT_EMITTER ? v.ref : v.emitter_of_shape; }
+WT_HD bool vertex_is_delta_emitter(const scene_t& sc, const vertex_t& v) {
+    return v.type == VT_EMITTER && (emitter_is_delta_direction(sc.emitters[v.ref]) || emitter_is_delta_position(sc.emitters[v.ref]));
+}
+WT_HD bool vertex_is_delta_sensor(const scene_t& sc, const vertex_t& v) {
+    return v.type == VT_SENSOR && (sensor_is_delta_direction(sc.sensor) || sensor_is_delta_position(sc.sensor));
+}
+WT_HD bool vertex_is_connectible(const scene_t& sc, const vertex_t& v) {
+    switch (v.type) {
+    case VT_FSD: return true;
+    case VT_EMITTER: return !emitter_is_delta_direction(sc.emitters[v.ref]);
+    case VT_SENSOR: return !sensor_is_delta_direction(sc.sensor);
+    case VT_SURFACE: return !material_is_delta_only(sc, v.ref);
+    default: return false;
+    }
+}
+WT_HD vec3 geo_offseted_ray_origin(const scene_t& sc, const vertex_t& v, vec3 ro, vec3 rd) {
+    return v.geo_kind == GEO_SURFACE ? surface_offseted_ray_origin(sc, v.surf, ro, rd) : ro;
+}
+
+// convert_directional_density_to_area (vertex.hpp:224-243)
+WT_HD float convert_directional_density_to_area(const scene_t& sc, float dpdf_tagged, vec3 p, const vertex_t& next) {
+    const float dens = pd_density_or_zero(dpdf_tagged);
+    if (dens == 0.f) return 0.f;
+    const vec3 d = vertex_wp(next) - p;
+    const float d2 = length2(d);
+    if (d2 == 0.f) return WT_INF;
+    float ppdf = dens * (1.f / d2);
+    if (vertex_is_on_surface(sc, next)) ppdf *= fabsf(dot(vertex_ng(sc, next), normalize(d)));
+    return ppdf;
+}
+WT_HD float vertex_pdf_next_from_sensor(const scene_t& sc, const vertex_t& v, const vertex_t& next) {
+    const vec3 dl = vertex_wp(next) - vertex_wp(v);
+    const float recp_dist2 = 1.f / length2(dl);
+    const vec3 d = dl * sqrtf(recp_dist2);
+    const float dpdf = pd_density_or_zero(sensor_pdf_direction(sc, d));
+    float ppdf = dpdf * recp_dist2;
+    if (vertex_is_on_surface(sc, next)) ppdf *= fabsf(dot(vertex_ng(sc, next), d));
+    return ppdf;
+}
+WT_HD float vertex_pdf_sensor(const scene_t& sc) { return pd_density_or_zero(sensor_pdf_position(sc)); }
+WT_HD float vertex_pdf_next_from_emitter(const scene_t& sc, const vertex_t& v, const vertex_t& next) {
+    const vec3 dl = vertex_wp(next) - vertex_wp(v);
+    const float recp_dist2 = 1.f / length2(dl);
+    const vec3 d = dl * sqrtf(recp_dist2);
+    const int ei = vertex_get_emitter(v);
+    const float dpdf = pd_density_or_zero(emitter_pdf_direction(sc, ei, d, vertex_has_real_surface(sc, v) ? &v.surf : nullptr));
+    float ppdf = dpdf * recp_dist2;
+    if (vertex_is_on_surface(sc, next)) ppdf *= fabsf(dot(vertex_ng(sc, next), d));
+    return ppdf;
+}
+WT_HD float vertex_pdf_emitter(const scene_t& sc, const vertex_t& v) {
+    const int ei = vertex_get_emitter(v);
+    return sc.emitters[ei].select_pmf * pd_density_or_zero(emitter_pdf_position(sc, ei));
+}
+// vertex_t::pdf (vertex.hpp:444-487)
+WT_HD float vertex_pdf(const scene_t& sc, const fsd_pool_t& pool, const vertex_t& v, const vertex_t* prev, const vertex_t& next, uint32_t mode) {
+    if (v.type == VT_EMITTER) return vertex_pdf_next_from_emitter(sc, v, next);
+    if (v.type == VT_SENSOR) return vertex_pdf_next_from_sensor(sc, v, next);
+    const vec3 p = vertex_wp(v);
+    const vec3 wiworld = normalize(vertex_wp(*prev) - p);
+    const vec3 woworld = normalize(vertex_wp(next) - p);
+    float pdf = 0.f;
+    if (v.type == VT_SURFACE) {
+        const vec3 wi = to_local(v.surf.shading, wiworld), wo = to_local(v.surf.shading, woworld);
+        pdf = material_pdf(sc, v.ref, wi, wo, v.beam.k, mode);
+    } else if (v.type == VT_FSD) {
+        const fsd_aperture_t ap = pool.hdr[v.fsd_slot];
+        pdf = fsd_pdf(ap, fsd_pool_edges(pool, v.fsd_slot), to_local(ap.frame, woworld));
+    }
+    return convert_directional_density_to_area(sc, pdf, p, next);
+}
+
+// vertex_t::interact (vertex.hpp:330-413): beam arriving at `v` transformed towards `next`.
+WT_HD bool vertex_interact(const scene_t& sc, const fsd_pool_t& pool, const vertex_t& v, const vertex_t& next, bool ignore_fsd, beam_t& out) {
+    const vec3 wiworld = -v.beam.env.d;
+    const float k = v.beam.k;
+    float f = 0.f;
+    if (v.fraunhofer_fsd && !ignore_fsd) {
+        const fsd_aperture_t ap = pool.hdr[v.fsd_slot];
+        const vec3 woworld = normalize(vertex_wp(next) - vertex_wp(v));
+        f = fsd_pdf(ap, fsd_pool_edges(pool, v.fsd_slot), to_local(ap.frame, woworld));
+    }
+    if (v.type == VT_SURFACE) {
+        const surface_t& srf = v.surf;
+        const vec3 woworld = normalize(vertex_wp(next) - vertex_wp(v));
+        const vec3 wi = to_local(srf.shading, wiworld), wo = to_local(srf.shading, woworld);
+        const vec3 ng = srf.geo.n, ns = srf.shading.n;
+        const float wig = dot(wiworld, ng), wog = dot(woworld, ng);
+        const float wis = wi.z, wos = wo.z;
+        if (wig * wis <= 0.f || wog * wos <= 0.f) return false;
+        mueller_t M = material_f(sc, v.ref, wi, wo, k, v.transport);
+        float scale = 1.f / fabsf(wos);
+        if (!veq(ns, ng)) scale *= shading_normals_correction_scale(v.transport, wig, wog, wis, wos);
+        M = M * scale;
+        if (f > 0.f) M = M + mueller_identity() * f;
+        if (mueller_mean_intensity(M) == 0.f) return false;
+        out = v.beam;
+        beam_transform_surface_interaction(out, srf, woworld, M, 1.f);
+        return true;
+    }
+    if (v.type == VT_FSD) {
+        const vec3 p = vertex_wp(v);
+        const float beam_dist = dot(p - v.beam.env.o, v.beam.env.d);
+        const vec3 woworld = normalize(vertex_wp(next) - p);
+        out = v.beam;
+        beam_transform_region_interaction(out, p, beam_dist, woworld, f);
+        return true;
+    }
+    return false;
+}
+
+// integrator::shadow (traversal.hpp:319-333): TRUE if occluded
+WT_HD bool bdpt_shadow(const scene_t& sc, const vertex_t& a, const vertex_t& b, const stack_ref_t& stack, bvh_counters_t* ctr) {
+    const vec3 start_wp = vertex_wp(a), end_wp = vertex_wp(b);
+    const vec3 rd = normalize(end_wp - start_wp);
+    const vec3 o = geo_offseted_ray_origin(sc, a, start_wp, rd);
+    const vec3 t = geo_offseted_ray_origin(sc, b, end_wp, -rd);
+    const float dist = length(t - o);
+    const vec3 d = (t - o) / dist;
+    return ads_shadow_ray(sc, o, d, range_t{0.f, dist}, stack, ctr);
+}
+
+// ---- walk state -----------------------------------------------------------------------------------------
+struct walk_t {
+    beam_t beam;
+    float pdf_from_prev;   // tagged solid-angle pd of sampling the next vertex from the last one
+    float throughput, rr_weight;
+    uint32_t nverts;
+    uint32_t active;
+    uint32_t rng_draws;
+    // cached data of the last vertex (vertices.back())
+    vec3 prev_wp, prev_ng;
+    uint32_t prev_on_surface;
+    uint32_t prev_offset_tuid;   // triangle used for the self-intersection offset (kInvalid: none)
+};
+
+#define WT_WALK_NVERTS_WORD (offsetof(walk_t, nverts) / 4)
+
+struct sample_ctx_t {
+    float k;
+    float recp_spectral_pd;
+    float k_density;
+    sensor_element_t element;
+};
+
+struct bdpt_counters_t {
+    unsigned long long segments, ray_queries, cone_queries, vertices, connections, shadow_rays;
+    unsigned long long cone_tri_overflow, edge_overflow, fsd_edge_overflow, fsd_pool_overflow, fsd_interactions, null_interactions;
+    unsigned long long surface_interactions, light_splats;
+};
+
+WT_HD void walk_cache_prev(const scene_t& sc, walk_t& w, const vertex_t& v) {
+    w.prev_wp = vertex_wp(v);
+    w.prev_ng = vertex_ng(sc, v);
+    w.prev_on_surface = vertex_is_on_surface(sc, v);
+    w.prev_offset_tuid = v.geo_kind == GEO_SURFACE ? v.surf.tuid : kInvalid;
+}
+
+// plt_bdpt.cpp:54-87 + generate_{sensor,emitter}_subpath: draws the spectral/emitter/sensor samples and creates
+// vertex 0 of both subpaths.
+WT_HD void bdpt_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, uint32_t px, uint32_t py, sample_ctx_t& ctx, walk_t& sw, walk_t& ew,
+                         const vertex_store_t& svs, const vertex_store_t& evs) {
+    sampler_t smp = make_sampler(seed, sample_id, STREAM_SCENE);
+    const emitter_k_sample_t ek = scene_sample_emitter_and_spectrum(sc, smp);
+    const float k = ek.wavenumber.k;
+    const emitter_sample_t es = emitter_sample(sc, ek.emitter, k, smp);
+    const bool disc = pd_is_discrete(ek.wavenumber.wpd);
+    ctx.k = k;
+    ctx.recp_spectral_pd = disc ? 1.f / pd_mass(ek.wavenumber.wpd) : 1.f / scene_sum_spectral_pdf(sc, k);
+    ctx.k_density = disc ? pd_mass(ek.wavenumber.wpd) : ek.wavenumber.wpd;
+    const sensor_sample_t ss = sensor_sample(sc, px, py, k, smp);
+    ctx.element = ss.element;
+
+    vertex_t v;
+    // create_sensor (vertex.hpp:77-88)
+    v.type = VT_SENSOR;
+    v.transport = TRANSPORT_BACKWARD;
+    v.delta = 0;
+    v.fraunhofer_fsd = 0;
+    v.pdf_fwd = -1.f;
+    v.pdf_bwd = pd_density_or_zero(ss.ppd);
+    v.rr_weight = 1.f;
+    v.ref = -1;
+    v.emitter_of_shape = -1;
+    v.fsd_slot = kInvalid;
+    v.has_beam = 1;
+    v.beam = ss.beam;
+    if (ss.has_surface) {
+        v.geo_kind = GEO_SURFACE;
+        v.surf = ss.surface;
+    } else {
+        v.geo_kind = GEO_POINT;
+        v.surf = make_dummy_surface(vec3{0, 0, 1}, ss.beam.env.o);
+    }
+    svs.store(0, v);
+    sw.beam = ss.beam;
+    sw.pdf_from_prev = ss.dpd;
+    sw.throughput = 1.f;
+    sw.rr_weight = 1.f;
+    sw.nverts = 1;
+    sw.active = 1;
+    sw.rng_draws = 0;
+    walk_cache_prev(sc, sw, v);
+
+    // create_emitter (vertex.hpp:111-121)
+    v.type = VT_EMITTER;
+    v.transport = TRANSPORT_FORWARD;
+    v.pdf_fwd = pd_density_or_zero(es.ppd) * ek.emitter_pdf;
+    v.pdf_bwd = -1.f;
+    v.ref = ek.emitter;
+    v.beam = es.beam;
+    if (es.has_surface) {
+        v.geo_kind = GEO_SURFACE;
+        v.surf = es.surface;
+    } else {
+        v.geo_kind = GEO_POINT;
+        v.surf = make_dummy_surface(vec3{0, 0, 1}, es.beam.env.o);
+    }
+    evs.store(0, v);
+    ew.beam = es.beam;
+    ew.pdf_from_prev = es.dpd;
+    ew.throughput = 1.f;
+    ew.rr_weight = 1.f;
+    ew.nverts = 1;
+    ew.active = 1;
+    ew.rng_draws = 0;
+    walk_cache_prev(sc, ew, v);
+}
+
+// envelope used for tracing the next segment (traversal.hpp:276-288): origin offset away from the last surface
+WT_HD cone_t walk_trace_envelope(const scene_t& sc, const walk_t& w) {
+    cone_t env = w.beam.env;
+    if (w.prev_offset_tuid != kInvalid) {
+        const tri_geo_t g = sc.tri_geo[w.prev_offset_tuid];
+        const vec3 err = triangle_fp_errors(g.a, g.b, g.c, env.o);
+        const float offset_dist = dot(err, vabs(w.prev_ng));
+        const vec3 offset = offset_dist * w.prev_ng;
+        env.o = env.o + (dot(env.d, offset) >= 0.f ? offset : -offset);
+    }
+    return env;
+}
+
+// bdpt_walk_data_t::append_vertex (plt_bdpt_detail.hpp:95-121)
+WT_HD bool walk_append_vertex(const scene_t& sc, walk_t& w, const vertex_store_t& vs, vertex_t& v, float pdf_fwd, float pdf_revr) {
+    if (veq(w.prev_wp, vertex_wp(v))) return false;
+    // pdf of sampling v from the previous vertex
+    const float pv = convert_directional_density_to_area(sc, w.pdf_from_prev, w.prev_wp, v);
+    if (v.transport == TRANSPORT_FORWARD)
+        v.pdf_fwd = pv;
+    else
+        v.pdf_bwd = pv;
+    v.beam = w.beam;
+    v.has_beam = 1;
+    // reversed pdf of the previous vertex (sampling prev from v)
+    {
+        const float dens = pd_density_or_zero(pdf_revr);
+        float prev_rev = 0.f;
+        if (dens != 0.f) {
+            const vec3 d = w.prev_wp - vertex_wp(v);
+            const float d2 = length2(d);
+            if (d2 == 0.f)
+                prev_rev = WT_INF;
+            else {
+                prev_rev = dens * (1.f / d2);
+                if (w.prev_on_surface) prev_rev *= fabsf(dot(w.prev_ng, normalize(d)));
+            }
+        }
+        // pdf_reversed(): backward transport -> pdf_fwd, forward -> pdf_bwd
+        vs.store_word(w.nverts - 1, v.transport == TRANSPORT_BACKWARD ? WT_VWORD(pdf_fwd) : WT_VWORD(pdf_bwd), prev_rev);
+    }
+    w.pdf_from_prev = pdf_fwd;
+    vs.store(w.nverts, v);
+    w.nverts++;
+    walk_cache_prev(sc, w, v);
+    return true;
+}
+
+// continue_walk (plt_bdpt_detail.hpp:167-182)
+WT_HD bool walk_continue(const scene_t& sc, walk_t& w, const vertex_store_t& vs, bool allow_RR, sampler_t& smp) {
+    if ((int)w.nverts > sc.opts.max_depth + 1) return false;
+    if (!allow_RR || !sc.opts.RR) return true;
+    vs.store_word(w.nverts - 1, WT_VWORD(rr_weight), w.rr_weight);
+    const float r = w.throughput < 1.f ? fmaxf_(w.throughput, .5f) : 1.f;
+    if (sampler_r(smp) <= r) {
+        const float scale = 1.f / r;
+        w.rr_weight *= scale;
+        w.throughput *= scale;
+        return true;
+    }
+    return false;
+}
+
+// One random-walk step after the beam has been traced (plt_bdpt_detail.hpp:421-526 minus the traverse() call).
+// Returns TRUE if the walk continues (another segment must be traced).
+template <class TriList>
+WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr, const TriList& tris, const vertex_store_t& vs,
+                          const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream, bdpt_counters_t* ctr) {
+    if (tr.empty) return false;   // no intersection (TODO in the reference: infinite emitters)
+    sampler_t smp = make_sampler(seed, sample_id, stream, w.rng_draws);
+    beam_t& beam = w.beam;
+    const float beam_dist = tr.dist;
+    const range_t izr{beam_dist, beam_dist + tr.region_depth};
+    const bool is_ballistic = tr.ballistic || beam_is_ray(beam);
+    const vec3 origin_wp = tr.origin;
+    const vec3 interaction_wp = origin_wp + izr.min * beam.env.d;
+    const frame_t beam_frame = cone_frame(beam.env);
+    const cone_t envelope = beam.env;
+    const vec3 sd3 = beam_footprint(beam, beam_dist) / kBeamEnvelope;   // std_dev
+    const vec2 sigma{sd3.x, sd3.y};
+
+    // primary triangle
+    uint32_t primary = kInvalid;
+    ray_tri_hit_t phit{WT_INF, 0.f, 0.f};
+    float integrated_flux = 0.f;
+    if (is_ballistic) {
+        primary = tr.tuid;
+        phit.dist = tr.dist;
+        phit.bx = tr.bx;
+        phit.by = tr.by;
+    } else {
+        // find_closest_triangle (plt_bdpt_detail.hpp:362-419)
+        for (uint32_t i = 0; i < tr.ntris; ++i) {
+            const uint32_t tuid = tris[i];
+            const tri_geo_t g = sc.tri_geo[tuid];
+            const float fptol = cone_intersection_tolerance(origin_wp, g.a, g.b, g.c);
+            ray_tri_hit_t h;
+            if (intersect_ray_tri(origin_wp, beam.env.d, g.a, g.b, g.c, grow(izr, fptol), h) && h.dist < phit.dist) {
+                primary = tuid;
+                phit = h;
+            }
+        }
+        if (primary == kInvalid) {
+            const float csz = centre(izr);
+            for (uint32_t i = 0; i < tr.ntris; ++i) {
+                const tri_geo_t g = sc.tri_geo[tris[i]];
+                const bool front_face = dot(g.n, -beam.env.d) > 0.f;
+                if (front_face != (tr.front_face != 0)) continue;
+                const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
+                                                      to_local(beam_frame, g.c - envelope.o), izr);
+                for (int t = 0; t < ct.tris; ++t) {
+                    vec3 a, b, c;
+                    clip_tri_get(ct, t, a, b, c);
+                    const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz),
+                               pc = cone_project_local(envelope, c, csz);
+                    integrated_flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
+                }
+            }
+        }
+    }
+
+    bool do_RR = true;
+    bool ok = true;
+    if (primary != kInvalid) {
+        // ---- sample_surface_interaction (plt_bdpt_detail.hpp:192-270)
+        const tri_geo_t g = sc.tri_geo[primary];
+        const vec3 sampled_tri_wp = origin_wp + envelope.d * phit.dist;
+        surface_t srf = make_surface(sc, primary, g.n, vec2{phit.bx, phit.by}, sampled_tri_wp);
+        srf.footprint = beam_surface_footprint_static(beam, srf, beam_dist);
+        const shape_t shp = sc.shapes[srf.shape];
+        const float k = beam.k;
+        const uint32_t transport = beam.transport;
+        const vec3 ng = srf.geo.n, ns = srf.shading.n;
+        const vec3 wiworld = -beam.env.d;
+        const vec3 wi = to_local(srf.shading, wiworld);
+        const float wig = dot(wiworld, ng), wis = wi.z;
+        ok = wig * wis > 0.f;
+        bsdf_sample_t bs;
+        if (ok) {
+            bs = material_sample(sc, shp.material, wi, k, transport, smp);
+            ok = bs.valid && bs.dpd != 0.f;
+        }
+        if (ok) {
+            const bool is_delta = pd_is_discrete(bs.dpd);
+            const vec3 wo = bs.wo;
+            const vec3 woworld = normalize(to_world(srf.shading, wo));
+            const float wog = dot(woworld, ng), wos = wo.z;
+            if (ctr) ctr->surface_interactions++;
+            ok = wog * wos > 0.f;
+            if (ok) {
+                const float pdf_revr = material_pdf(sc, shp.material, wo, wi, k, flip_transport(transport));
+                vertex_t v;
+                v.type = VT_SURFACE;
+                v.transport = transport;
+                v.delta = is_delta;
+                v.fraunhofer_fsd = 0;
+                v.pdf_fwd = v.pdf_bwd = -1.f;
+                v.rr_weight = 1.f;
+                v.ref = shp.material;
+                v.emitter_of_shape = shp.emitter;
+                v.fsd_slot = kInvalid;
+                v.geo_kind = GEO_SURFACE;
+                v.surf = srf;
+                ok = walk_append_vertex(sc, w, vs, v, bs.dpd, pdf_revr);
+                if (ok) {
+                    if (ctr) ctr->vertices++;
+                    float ws = 1.f;
+                    if (!veq(ns, ng)) ws *= shading_normals_correction_scale(transport, wig, wog, wis, wos);
+                    // transform_surface_interaction (plt_bdpt_detail.hpp:123-136)
+                    beam_transform_surface_interaction(beam, srf, woworld, bs.M, ws);
+                    w.throughput *= ws * mueller_mean_intensity(bs.M);
+                    if (transport == TRANSPORT_BACKWARD && bs.eta != 1.f) w.throughput /= sqr(bs.eta);
+                }
+            }
+        }
+    } else {
+        // gather the ordered, de-duplicated edge set of the interaction region (traversal_common.hpp:124-148)
+        uint32_t edge_ids[kMaxEdgeIds];
+        uint32_t n_edge_ids = 0;
+        if (sc.opts.FSD && !is_ballistic) {
+            for (uint32_t i = 0; i < tr.ntris; ++i) {
+                const tri_meta_t m = sc.tri_meta[tris[i]];
+                for (int e = 0; e < 3; ++e) {
+                    const uint32_t id = m.edge[e];
+                    if (id == kInvalid) continue;
+                    uint32_t pos = 0;
+                    while (pos < n_edge_ids && edge_ids[pos] < id) ++pos;
+                    if (pos < n_edge_ids && edge_ids[pos] == id) continue;
+                    if (n_edge_ids == kMaxEdgeIds) {
+                        if (ctr) ctr->edge_overflow++;
+                        continue;
+                    }
+                    for (uint32_t j = n_edge_ids; j > pos; --j) edge_ids[j] = edge_ids[j - 1];
+                    edge_ids[pos] = id;
+                    ++n_edge_ids;
+                }
+            }
+        }
+        if (n_edge_ids > 0) {
+            // ---- sample_fraunhofer_fsd_interaction (plt_bdpt_detail.hpp:287-346)
+            const float I = 1.f - integrated_flux;
+            const uint32_t slot = fsd_pool_alloc(pool);
+            if (slot >= pool.cap) {
+                if (ctr) ctr->fsd_pool_overflow++;
+                ok = false;
+            } else {
+                fsd_aperture_t ap;
+                const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
+                fsd_build_aperture(sc, beam_frame, beam.k, I, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
+                pool.hdr[slot] = ap;
+                if (ctr && ap.overflow) ctr->fsd_edge_overflow += ap.overflow;
+                if (ap.n_edges == 0) {
+                    beam_transform_restart(beam, interaction_wp, beam_dist);
+                    do_RR = false;
+                } else {
+                    const fsd_sample_t fs = fsd_sample(sc, ap, ed, smp);
+                    ok = !(fs.dpd == 0.f || fs.weight == 0.f);
+                    if (ok) {
+                        if (ctr) ctr->fsd_interactions++;
+                        const vec3 woworld = to_world(ap.frame, fs.wo);
+                        vertex_t v;
+                        v.type = VT_FSD;
+                        v.transport = beam.transport;
+                        v.delta = 0;
+                        v.fraunhofer_fsd = 1;
+                        v.pdf_fwd = v.pdf_bwd = -1.f;
+                        v.rr_weight = 1.f;
+                        v.ref = -1;
+                        v.emitter_of_shape = -1;
+                        v.fsd_slot = slot;
+                        v.geo_kind = GEO_POINT;
+                        v.surf = make_dummy_surface(vec3{0, 0, 1}, interaction_wp);
+                        ok = walk_append_vertex(sc, w, vs, v, fs.dpd, fs.dpd);
+                        if (ok) {
+                            if (ctr) ctr->vertices++;
+                            beam_transform_region_interaction(beam, interaction_wp, beam_dist, woworld, fs.weight);
+                            w.throughput *= fs.weight;
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---- null interaction (plt_bdpt_detail.hpp:273-284)
+            do_RR = false;
+            beam_transform_restart(beam, interaction_wp, beam_dist);
+            if (ctr) ctr->null_interactions++;
+        }
+    }
+    bool cont = false;
+    if (ok) cont = walk_continue(sc, w, vs, do_RR, smp);
+    w.rng_draws = smp.draws;
+    return cont;
+}
+
+// ---- connections -------------------------------------------------------------------------------------------
+struct connect_ret_t {
+    stokes_t L;
+    vertex_t temporary_vert;
+    uint32_t has_temp;
+    sensor_element_t element;
+    uint32_t has_element;
+};
+
+// connect_and_integrate (plt_bdpt_detail.hpp:722-745)
+WT_HD stokes_t connect_and_integrate(const scene_t& sc, const beam_t& db, const vertex_t& dv, const beam_t& eb, const vertex_t& ev,
+                                     const stack_ref_t& stack, bdpt_counters_t* ctr, bvh_counters_t* bctr) {
+    if (beam_intensity(db) == 0.f || beam_intensity(eb) == 0.f) return stokes_zero();
+    if (ctr) ctr->shadow_rays++;
+    if (bdpt_shadow(sc, dv, ev, stack, bctr)) return stokes_zero();
+    return integrate_beams(db, eb);
+}
+
+WT_HD void make_temp_vertex(vertex_t& v, uint32_t type, uint32_t transport, int ref, bool has_surface, const surface_t& surface, vec3 p) {
+    v.type = type;
+    v.transport = transport;
+    v.delta = 0;
+    v.fraunhofer_fsd = 0;
+    v.pdf_fwd = v.pdf_bwd = -1.f;
+    v.rr_weight = 1.f;
+    v.ref = ref;
+    v.emitter_of_shape = -1;
+    v.fsd_slot = kInvalid;
+    v.has_beam = 0;
+    if (has_surface) {
+        v.geo_kind = GEO_SURFACE;
+        v.surf = surface;
+    } else {
+        v.geo_kind = GEO_POINT;
+        v.surf = make_dummy_surface(vec3{0, 0, 1}, p);
+    }
+}
+
+// connect_subpaths (plt_bdpt_detail.hpp:747-923).  nS/nT = number of vertices of the emitter/sensor subpaths.
+WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t,
+                        uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, connect_ret_t& ret, bdpt_counters_t* ctr, bvh_counters_t* bctr) {
+    ret.L = stokes_zero();
+    ret.has_temp = 0;
+    ret.has_element = 0;
+    sampler_t smp = make_sampler(seed, sample_id, STREAM_CONNECT + (uint32_t)t * 32u + (uint32_t)s);
+    if (ctr) ctr->connections++;
+
+    if (s == 0) {
+        vertex_t last;
+        svs.load(t - 1, last);
+        if (vertex_on_emitter(last)) {
+            beam_t QE = last.beam;
+            beam_scale(QE, last.rr_weight);
+            ret.L = emitter_Li(sc, vertex_get_emitter(last), QE, last.surf);
+        }
+    } else if (t == 0) {
+        if (sensor_is_virtual(sc.sensor)) {
+            vertex_t last, current;
+            evs.load(s - 1, last);
+            evs.load(s - 2, current);
+            const vec3 wp_end = vertex_wp(last);
+            const beam_t& beam = last.beam;
+            const float dist = length(wp_end - beam.env.o);
+            sensor_direct_connection_t dc = vplane_Si(sc, beam, range_t{0.f, dist});
+            if (dc.valid) {
+                ret.element = dc.element;
+                ret.has_element = 1;
+                float wgt = current.rr_weight;
+                if (vertex_is_on_surface(sc, current) && vertex_is_interaction(current) && !current.delta)
+                    wgt /= fabsf(dot(dc.beam.env.d, vertex_ns(sc, current)));
+                wgt /= fabsf(dot(dc.beam.env.d, dc.surface.geo.n));
+                beam_scale(dc.beam, wgt);
+                make_temp_vertex(ret.temporary_vert, VT_SENSOR, TRANSPORT_BACKWARD, -1, true, dc.surface, dc.beam.env.o);
+                ret.has_temp = 1;
+                ret.L = integrate_beams(dc.beam, beam);
+            }
+        }
+    } else if (s == 1) {
+        vertex_t last;
+        svs.load(t - 1, last);
+        if (vertex_is_connectible(sc, last)) {
+            const float k = last.beam.k;
+            const vec3 wp = vertex_wp(last);
+            emitter_direct_sample_t ed = scene_sample_emitter_direct(sc, wp, k, smp);
+            if ((pd_is_discrete(ed.dpd) || ed.dpd != 0.f) && beam_intensity(ed.beam) > 0.f) {
+                float wgt = last.rr_weight;
+                if (vertex_is_on_surface(sc, last)) wgt *= fabsf(dot(ed.beam.env.d, vertex_ns(sc, last)));
+                beam_scale(ed.beam, wgt);
+                make_temp_vertex(ret.temporary_vert, VT_EMITTER, TRANSPORT_FORWARD, ed.emitter, ed.has_surface, ed.surface, ed.beam.env.o);
+                ret.has_temp = 1;
+                beam_t db;
+                if (vertex_interact(sc, pool, last, ret.temporary_vert, false, db))
+                    ret.L = connect_and_integrate(sc, db, last, ed.beam, ret.temporary_vert, stack, ctr, bctr);
+            }
+        }
+    } else if (t == 1) {
+        vertex_t last;
+        evs.load(s - 1, last);
+        const bool is_virtual = sensor_is_virtual(sc.sensor);
+        const bool do_direct = (is_virtual || last.type != VT_FSD) && vertex_is_connectible(sc, last);
+        if (do_direct) {
+            sensor_direct_sample_t sd = sensor_sample_direct(sc, vertex_wp(last), last.beam.k, smp);
+            if ((pd_is_discrete(sd.dpd) || sd.dpd != 0.f) && beam_intensity(sd.beam) > 0.f) {
+                float wgt = last.rr_weight;
+                if (vertex_is_on_surface(sc, last)) wgt *= fabsf(dot(sd.beam.env.d, vertex_ns(sc, last)));
+                beam_scale(sd.beam, wgt);
+                make_temp_vertex(ret.temporary_vert, VT_SENSOR, TRANSPORT_BACKWARD, -1, sd.has_surface, sd.surface, sd.beam.env.o);
+                ret.has_temp = 1;
+                beam_t eb;
+                if (vertex_interact(sc, pool, last, ret.temporary_vert, false, eb)) {
+                    ret.L = connect_and_integrate(sc, sd.beam, ret.temporary_vert, eb, last, stack, ctr, bctr);
+                    ret.element = sd.element;
+                    ret.has_element = 1;
+                }
+            }
+        }
+    } else {
+        vertex_t ev, sv;
+        evs.load(s - 1, ev);
+        svs.load(t - 1, sv);
+        const vec3 dl = vertex_wp(ev) - vertex_wp(sv);
+        if (vertex_is_connectible(sc, ev) && vertex_is_connectible(sc, sv) && !(dl.x == 0.f && dl.y == 0.f && dl.z == 0.f)) {
+            beam_t eb, db;
+            const bool heb = vertex_interact(sc, pool, ev, sv, true, eb);
+            const bool hdb = vertex_interact(sc, pool, sv, ev, true, db);
+            if (heb && hdb) {
+                const float recp_d2 = 1.f / length2(dl);
+                const vec3 d = dl * sqrtf(recp_d2);
+                float wev = ev.rr_weight;
+                float wsv = sv.rr_weight * recp_d2;
+                if (vertex_is_on_surface(sc, sv)) wev *= fabsf(dot(vertex_ns(sc, sv), d));
+                if (vertex_is_on_surface(sc, ev)) wsv *= fabsf(dot(vertex_ns(sc, ev), d));
+                beam_scale(db, wsv);
+                beam_scale(eb, wev);
+                ret.L = connect_and_integrate(sc, db, sv, eb, ev, stack, ctr, bctr);
+            }
+        }
+    }
+}
+
+// bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720)
+WT_HD float bdpt_mis_weight(const scene_t& sc, const fsd_pool_t& pool, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t,
+                            const connect_ret_t& cr) {
+    if (s + t <= 2) return 1.f;
+    float spdf[kMaxVerts], srev[kMaxVerts], epdf[kMaxVerts], erev[kMaxVerts];
+    uint32_t sdel[kMaxVerts], edel[kMaxVerts];
+    // bdpt_populate_subpaths_pdfs
+    for (int i = 0; i < t; ++i) {
+        spdf[i] = svs.load_word<float>(i, WT_VWORD(pdf_bwd));
+        srev[i] = svs.load_word<float>(i, WT_VWORD(pdf_fwd));
+        sdel[i] = svs.load_word<uint32_t>(i, WT_VWORD(delta));
+    }
+    for (int i = 0; i < s; ++i) {
+        epdf[i] = evs.load_word<float>(i, WT_VWORD(pdf_fwd));
+        erev[i] = evs.load_word<float>(i, WT_VWORD(pdf_bwd));
+        edel[i] = evs.load_word<uint32_t>(i, WT_VWORD(delta));
+    }
+    const vertex_t& tv = cr.temporary_vert;
+    vertex_t sv0, ev0;
+    bool have_sv0 = false, have_ev0 = false;
+    if (s == 0) {
+        vertex_t last, prev;
+        svs.load(t - 1, last);
+        svs.load(t - 2, prev);
+        srev[t - 1] = vertex_pdf_emitter(sc, last);
+        srev[t - 2] = vertex_pdf_next_from_emitter(sc, last, prev);
+    } else if (t == 0) {
+        vertex_t last, prev;
+        if (sensor_is_virtual(sc.sensor))
+            last = tv;
+        else
+            evs.load(s - 1, last);
+        evs.load(s - 2, prev);
+        erev[s - 1] = vertex_pdf_sensor(sc);
+        erev[s - 2] = vertex_pdf_next_from_sensor(sc, last, prev);
+    } else if (s == 1) {
+        vertex_t last, prev;
+        svs.load(t - 1, last);
+        svs.load(t - 2, prev);
+        srev[t - 1] = vertex_pdf_next_from_emitter(sc, tv, last);
+        erev[0] = vertex_pdf(sc, pool, last, &prev, tv, TRANSPORT_BACKWARD);
+        epdf[0] = vertex_pdf_emitter(sc, tv);
+    } else if (t == 1) {
+        vertex_t last, prev;
+        evs.load(s - 1, last);
+        evs.load(s - 2, prev);
+        erev[s - 1] = vertex_pdf_next_from_sensor(sc, tv, last);
+        srev[0] = vertex_pdf(sc, pool, last, &prev, tv, TRANSPORT_FORWARD);
+        spdf[0] = vertex_pdf_sensor(sc);
+    } else {
+        vertex_t ev, sv, ev_prev, sv_prev;
+        evs.load(s - 1, ev);
+        svs.load(t - 1, sv);
+        evs.load(s - 2, ev_prev);
+        svs.load(t - 2, sv_prev);
+        erev[s - 1] = vertex_pdf(sc, pool, sv, &sv_prev, ev, TRANSPORT_BACKWARD);
+        erev[s - 2] = vertex_pdf(sc, pool, ev, &sv, ev_prev, TRANSPORT_BACKWARD);
+        srev[t - 1] = vertex_pdf(sc, pool, ev, &ev_prev, sv, TRANSPORT_FORWARD);
+        srev[t - 2] = vertex_pdf(sc, pool, sv, &ev, sv_prev, TRANSPORT_FORWARD);
+    }
+    if (t > 0) sdel[t - 1] = 0;
+    if (s > 0) edel[s - 1] = 0;
+    bool delta_emitter, delta_sensor;
+    if (s == 1)
+        delta_emitter = vertex_is_delta_emitter(sc, tv);
+    else if (s > 1) {
+        evs.load(0, ev0);
+        have_ev0 = true;
+        delta_emitter = vertex_is_delta_emitter(sc, ev0);
+    } else
+        delta_emitter = true;
+    if (t == 1)
+        delta_sensor = vertex_is_delta_sensor(sc, tv);
+    else if (t > 1) {
+        svs.load(0, sv0);
+        have_sv0 = true;
+        delta_sensor = vertex_is_delta_sensor(sc, sv0);
+    } else
+        delta_sensor = true;
+    (void)have_sv0;
+    (void)have_ev0;
+
+    float sum_Ri = 0.f, ri = 1.f;
+    for (int i = t - 1; i >= 0; --i) {
+        const float fwd = (finitef(spdf[i]) && spdf[i] > FLT_EPSILON) ? spdf[i] : 1.f;
+        const float rev = (finitef(srev[i]) && srev[i] > FLT_EPSILON) ? srev[i] : 1.f;
+        ri *= rev / fwd;
+        if (!sdel[i] && !(i > 0 ? (sdel[i - 1] != 0) : delta_sensor)) sum_Ri += ri;
+    }
+    ri = 1.f;
+    for (int i = s - 1; i >= 0; --i) {
+        const float fwd = (finitef(epdf[i]) && epdf[i] > FLT_EPSILON) ? epdf[i] : 1.f;
+        const float rev = (finitef(erev[i]) && erev[i] > FLT_EPSILON) ? erev[i] : 1.f;
+        ri *= rev / fwd;
+        if (!edel[i] && !(i > 0 ? (edel[i - 1] != 0) : delta_emitter)) sum_Ri += ri;
+    }
+    return 1.f / (1.f + sum_Ri);
+}
+
+// One (s,t) strategy of plt_bdpt.cpp:105-140.  Returns the flux to be accumulated into L (t>1) and performs the
+// light-image splat itself for t<=1.
+WT_HD stokes_t bdpt_strategy(const scene_t& sc, const fsd_pool_t& pool, const film_t& film, const vertex_store_t& svs, const vertex_store_t& evs, int s,
+                             int t, const sample_ctx_t& ctx, uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, bdpt_counters_t* ctr,
+                             bvh_counters_t* bctr) {
+    connect_ret_t cr;
+    bdpt_connect(sc, pool, svs, evs, s, t, seed, sample_id, stack, cr, ctr, bctr);
+    if (!(cr.L.s[0] > 0.f)) return stokes_zero();
+    float mis;
+    if (sc.opts.debug_only_s || sc.opts.debug_only_t)
+        mis = ctx.recp_spectral_pd;
+    else if (sc.opts.MIS)
+        mis = bdpt_mis_weight(sc, pool, svs, evs, s, t, cr) * ctx.recp_spectral_pd;
+    else
+        mis = 1.f / (float(s + t + 1) * ctx.k_density);
+    const stokes_t flux = cr.L * mis;
+    if (t > 1) return flux;
+    if (cr.has_element) {
+        film_splat_direct(sc, film, cr.element, flux, ctx.k);
+        if (ctr) ctr->light_splats++;
+    }
+    return stokes_zero();
+}
+
+// The (s,t) loop of plt_bdpt.cpp:105-146 for one sample, given both finished subpaths.
+WT_HD void bdpt_connect_all(const scene_t& sc, const fsd_pool_t& pool, const film_t& film, const vertex_store_t& svs, const vertex_store_t& evs, int nT,
+                            int nS, const sample_ctx_t& ctx, uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, bdpt_counters_t* ctr,
+                            bvh_counters_t* bctr) {
+    stokes_t L = stokes_zero();
+    for (int t = 0; t <= nT; ++t)
+        for (int s = 0; s <= nS; ++s) {
+            const int depth = t + s - 2;
+            if ((t == 1 && s == 1) || depth < 0) continue;
+            if (!sc.opts.emitter_direct && s == 1) continue;
+            if (!sc.opts.sensor_direct && t == 1) continue;
+            if (depth > sc.opts.max_depth) break;
+            if (sc.opts.debug_only_s && (int)sc.opts.debug_only_s - 1 != s) continue;
+            if (sc.opts.debug_only_t && (int)sc.opts.debug_only_t - 1 != t) continue;
+            L = L + bdpt_strategy(sc, pool, film, svs, evs, s, t, ctx, seed, sample_id, stack, ctr, bctr);
+        }
+    film_splat(sc, film, ctx.element, L, ctx.k);
+}
+
+}   // namespace wt

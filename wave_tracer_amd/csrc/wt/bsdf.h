@@ -1,0 +1,290 @@
+// wave_tracer_amd — flattened BSDF evaluation.
+//
+// Reference: include/wt/bsdf/bsdf.hpp:32-134, include/wt/bsdf/common.hpp:27-90,
+//            src/bsdf/diffuse.cpp:23-71, src/bsdf/dielectric.cpp:26-72 + include/wt/bsdf/dielectric.hpp,
+//            src/bsdf/surface_spm.cpp:28-201 + include/wt/bsdf/surface_spm.hpp,
+//            src/bsdf/two_sided.cpp:20-55, include/wt/bsdf/scale.hpp,
+//            include/wt/interaction/surface_profile/fractal.hpp:26-238, src/interaction/surface_profile/fractal.cpp:27-69,
+//            include/wt/interaction/surface_profile/dirac.hpp, include/wt/sampler/density.hpp (pdf tagging).
+//
+// The reference's virtual wrapper chain (two_sided -> scale -> leaf) is flattened into one material record
+// (scene.h: material_t); textures are constants in this round.
+#pragma once
+#include "beam.h"
+#include "rng.h"
+
+namespace wt {
+
+// ---- tagged probability densities (sampler/density.hpp): discrete mass stored as -mass ---------------
+WT_HD float pd_discrete(float mass) { return -mass; }
+WT_HD bool pd_is_discrete(float p) { return __builtin_signbit(p); }
+WT_HD float pd_density_or_zero(float p) { return pd_is_discrete(p) ? 0.f : p; }
+WT_HD float pd_mass(float p) { return -p; }
+
+constexpr uint32_t LOBE_SPECULAR = 0, LOBE_SCATTERED = 1;
+
+struct bsdf_sample_t {
+    vec3 wo;
+    float dpd;   // tagged
+    float eta;   // real part of the relative IOR crossed
+    mueller_t M;   // weighted bsdf (bsdf/pdf)
+    bool valid;
+};
+
+// ---- fractal surface profile ---------------------------------------------------------------------
+struct fractal_params_t {
+    float T;   // [mm^2]
+    float sigma2_norm;
+    float alpha;
+};
+WT_HD fractal_params_t fractal_params(const material_t& m, float k) {
+    const float meank = kTwoPi / 550e-6f;   // wavelen_to_wavenum(550nm) in 1/mm
+    const float max_GGX_alpha = .75f, maxT = sqr(70.f);
+    const float alpha2 = sqr(clampf(m.roughness, 0.f, max_GGX_alpha));
+    const float T = fminf_(maxT, (1.f - alpha2) / (4.f * sqr(meank) * alpha2));
+    const float x = 1.f + k * k * T;
+    const float p = m.gamma == 3.f ? x : powf(x, (m.gamma - 1.f) / 2.f);
+    return {T, 1.f / (1.f - 1.f / p), sqr(m.roughness / 9.f)};
+}
+// z: spatial frequency [1/mm]
+WT_HD float fractal_psd(const material_t& m, const fractal_params_t& pr, vec2 z, float k) {
+    const float x = 1.f + pr.T * dot(z, z);
+    const float p = m.gamma == 3.f ? x * x : powf(x, (m.gamma + 1.f) / 2.f);
+    return pr.sigma2_norm * (kInvTwoPi * k * k * (m.gamma - 1.f) * pr.T / p);
+}
+WT_HD float profile_alpha(const material_t& m, vec3 wi, vec3 wo, float k) {
+    if (m.profile == PROFILE_DIRAC) return 1.f;
+    const fractal_params_t pr = fractal_params(m, k);
+    const float a = sqr((fabsf(wi.z) + fabsf(wo.z)) * k) * pr.alpha;
+    return expf(-a);
+}
+WT_HD bool profile_is_delta_only(const material_t& m) { return m.profile == PROFILE_DIRAC || m.roughness == 0.f; }
+WT_HD float profile_psd(const material_t& m, vec3 wi, vec3 wo, float k) {
+    if (m.profile == PROFILE_DIRAC) return 0.f;
+    const fractal_params_t pr = fractal_params(m, k);
+    const vec2 z = k * (vec2{wi.x, wi.y} + vec2{wo.x, wo.y});
+    return fractal_psd(m, pr, z, k);
+}
+WT_HD float profile_pdf(const material_t& m, vec3 wi, vec3 wo, float k) {
+    if (m.profile == PROFILE_DIRAC) return 0.f;
+    const fractal_params_t pr = fractal_params(m, k);
+    const vec2 zeta_k = vec2{wi.x, wi.y} + vec2{wo.x, wo.y};
+    const float f_k = length(zeta_k);
+    const float s = sqrtf(fmaxf_(0.f, 1.f - sqr(wi.z)));
+    const float phi_max = (f_k == 0.f || s == 0.f) ? kPi : acosf(clampf((sqr(f_k) + sqr(s) - 1.f) / (2.f * f_k * s), -1.f, 1.f));
+    const float psd = fractal_psd(m, pr, zeta_k * k, k);
+    const float w = kInvPi * phi_max;
+    return w > 1e-2f ? 1.f / w * fabsf(wo.z) * psd : 0.f;
+}
+struct profile_sample_t {
+    vec3 wo;
+    float pdf, psd, weight;
+};
+// fractal.cpp:27-69 (Holzschuch & Pacanowski importance sampling)
+WT_HD profile_sample_t profile_sample(const material_t& m, vec3 wi, float k, sampler_t& sampler) {
+    if (m.profile == PROFILE_DIRAC) return {{0, 0, 1}, 0.f, 0.f, 0.f};
+    const fractal_params_t pr = fractal_params(m, k);
+    const float s = sqrtf(fmaxf_(0.f, 1.f - sqr(wi.z)));
+    const float phi_i = s > 0.f ? atan2f(wi.y, wi.x) : 0.f;
+    const float sqrtT = sqrtf(pr.T);
+    const vec2 u2 = sampler_r2(sampler);
+    const float k2T = sqr(k) * pr.T;
+    const float g = m.gamma;
+    const float M = 1.f - powf(1.f + k2T * sqr(1.f + s), -(g - 1.f) / 2.f);
+    const float f = sqrtf(powf(1.f - M * u2.x, -2.f / (g - 1.f)) - 1.f) / sqrtT;   // [1/mm]
+    const float f_k = f / k;
+    const float phi_max = (f == 0.f || s == 0.f) ? kPi : acosf(clampf((sqr(f_k) + sqr(s) - 1.f) / (2.f * f_k * s), -1.f, 1.f));
+    const float phi_f = phi_i + (2.f * u2.y - 1.f) * phi_max;
+    const vec2 zeta = f * vec2{cosf(phi_f), sinf(phi_f)};
+    const vec2 zeta_k = zeta / k;
+    const vec2 wo = zeta_k - vec2{wi.x, wi.y};
+    const float z = sqrtf(fmaxf_(0.f, 1.f - dot(wo, wo)));
+    const float psd = fractal_psd(m, pr, zeta, k);
+    const float w = kInvPi * phi_max;
+    const float pdf = w > 1e-2f ? z * psd / w : 0.f;
+    return {vec3{wo.x, wo.y, wi.z >= 0.f ? z : -z}, pdf, psd, w};
+}
+
+// ---- leaf BSDFs -----------------------------------------------------------------------------------
+WT_HD vec3 two_sided_flip(vec3 w, float z) { return z >= 0.f ? w : vec3{w.x, w.y, -w.z}; }
+
+WT_HD cplx material_IOR(const scene_t& sc, const material_t& m, float k) {
+    const cplx eta_1 = spectrum_value(sc, m.ext_ior_spec, k);
+    const cplx eta_2 = spectrum_value(sc, m.ior_spec, k);
+    return eta_1 / eta_2;
+}
+// surface_spm.cpp:28-38
+WT_HD vec3 spm_flip_wo(vec3 wo, float eta) {
+    const float scale = wo.z > 0.f ? eta : 1.f / eta;
+    const vec2 xy = vec2{wo.x, wo.y} * scale;
+    const float l2 = dot(xy, xy);
+    return l2 > 1.f ? vec3{1, 0, 0} : vec3{xy.x, xy.y, (wo.z > 0.f ? -1.f : 1.f) * sqrtf(fmaxf_(0.f, 1.f - l2))};
+}
+WT_HD bool IOR_has_transmission(cplx IOR) { return sqr(fabsf(IOR.im)) / cnorm(IOR) <= 1e-2f; }
+
+WT_HD bool material_is_delta_only(const scene_t& sc, int mat) {
+    const material_t m = sc.materials[mat];
+    if (m.type == MAT_DIFFUSE) return false;
+    if (m.type == MAT_DIELECTRIC) return true;
+    return profile_is_delta_only(m);
+}
+
+// bsdf_t::f — includes the cosine foreshortening; only non-delta lobes
+WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport) {
+    const material_t m = sc.materials[mat];
+    if (m.two_sided) {
+        const float z = wi.z;
+        wi = two_sided_flip(wi, z);
+        wo = two_sided_flip(wo, z);
+    }
+    mueller_t M = mueller_zero();
+    if (m.type == MAT_DIFFUSE) {
+        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale);
+        M = mueller_depolarizer((wi.z > 0.f && wo.z > 0.f) ? wo.z * kInvPi * refl : 0.f);
+    } else if (m.type == MAT_SURFACE_SPM) {
+        const bool is_scatter = !profile_is_delta_only(m);
+        const bool is_reflection = wi.z * wo.z >= 0.f;
+        const cplx eta_12 = material_IOR(sc, m, k);
+        const bool has_transmission = IOR_has_transmission(eta_12);
+        if (!(wi.z == 0.f || wo.z == 0.f || !is_scatter || (!is_reflection && !has_transmission))) {
+            const vec3 abs_wo = is_reflection ? wo : spm_flip_wo(wo, eta_12.re);
+            const float alpha = profile_alpha(m, wi, abs_wo, k);
+            float J = 1.f;
+            if (!is_reflection && transport == TRANSPORT_BACKWARD) J = sqr(wi.z < 0.f ? 1.f / eta_12.re : eta_12.re);
+            const float scale = is_reflection ? m.refl_scale : m.trans_scale;
+            const vec3 h = wi + abs_wo;
+            const vec3 mm = normalize(wi.z < 0.f ? -h : h);
+            // NB: f() evaluates Fresnel with Re(eta) only (surface_spm.cpp:66), sample() with the complex eta.
+            const mueller_t F = mueller_fresnel_rt(cplx{eta_12.re, 0.f}, is_reflection, wi, mm);
+            const float psd = profile_psd(m, wi, abs_wo, k);
+            M = ((1.f - alpha) * J * fabsf(wo.z) * psd * scale) * F;
+        }
+    }
+    // dielectric: delta only -> 0
+    if (m.scale != 1.f) M = M * m.scale;
+    return M;
+}
+
+WT_HD float material_pdf(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport) {
+    const material_t m = sc.materials[mat];
+    if (m.two_sided) {
+        const float z = wi.z;
+        wi = two_sided_flip(wi, z);
+        wo = two_sided_flip(wo, z);
+    }
+    if (m.type == MAT_DIFFUSE) return (wi.z > 0.f && wo.z > 0.f) ? cosine_hemisphere_pdf(wo.z) : 0.f;
+    if (m.type == MAT_DIELECTRIC) return 0.f;
+    const bool is_reflection = wi.z * wo.z >= 0.f;
+    const cplx eta_12 = material_IOR(sc, m, k);
+    const bool has_transmission = IOR_has_transmission(eta_12);
+    if (wi.z == 0.f || wo.z == 0.f || (!is_reflection && !has_transmission)) return 0.f;
+    const vec3 abs_wo = is_reflection ? wo : spm_flip_wo(wo, eta_12.re);
+    const float alpha = profile_alpha(m, wi, wi, k);
+    const float pdf_specular = alpha;
+    const fresnel_t f = fresnel(cplx{eta_12.re, 0.f}, wi, vec3{0, 0, 1});
+    const float pdf_transmission = (f.Ts + f.Tp) / 2.f;
+    return (1.f - pdf_specular) * profile_pdf(m, wi, abs_wo, k) * (is_reflection ? 1.f - pdf_transmission : pdf_transmission);
+}
+
+WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, float k, uint32_t transport, sampler_t& sampler) {
+    const material_t m = sc.materials[mat];
+    bsdf_sample_t r;
+    r.valid = false;
+    r.wo = {0, 0, 1};
+    r.dpd = 0.f;
+    r.eta = 1.f;
+    r.M = mueller_zero();
+    const float flipz = wi_in.z;
+    const vec3 wi = m.two_sided ? two_sided_flip(wi_in, flipz) : wi_in;
+
+    if (m.type == MAT_DIFFUSE) {
+        if (wi.z <= 0.f) return r;
+        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale);
+        r.wo = cosine_hemisphere(sampler_r2(sampler));
+        r.dpd = cosine_hemisphere_pdf(r.wo.z);
+        r.M = mueller_depolarizer(refl);
+        r.valid = true;
+    } else if (m.type == MAT_DIELECTRIC) {
+        // dielectric.cpp:26-72 — IOR() returns Re(eta_1/eta_2)
+        const float eta_12 = material_IOR(sc, m, k).re;
+        const fresnel_t f = fresnel(cplx{eta_12, 0.f}, wi, vec3{0, 0, 1});
+        const float T = (f.Ts + f.Tp) / 2.f;
+        const bool is_reflection = sampler_r(sampler) >= T;
+        const vec3 wo = is_reflection ? reflect_z(wi) : f.t;
+        const float pdf = is_reflection ? 1.f - T : T;
+        const float scale = is_reflection ? m.refl_scale : m.trans_scale;
+        if (scale == 0.f) return r;
+        mueller_t M;
+        if (is_reflection)
+            M = scale * mueller_fresnel(f.rs, f.rp);
+        else {
+            M = (f.Z * scale) * mueller_fresnel(f.ts, f.tp);
+            if (transport == TRANSPORT_BACKWARD) M = M * sqr(f.eta_12.re);
+        }
+        r.wo = wo;
+        r.dpd = pd_discrete(1.f);
+        r.eta = f.eta_12.re;
+        r.M = M * (1.f / pdf);
+        r.valid = true;
+    } else {
+        // surface_spm.cpp:75-157
+        const float alpha = profile_alpha(m, wi, wi, k);
+        const bool has_specular = alpha > 0.f;
+        const bool has_scatter = alpha < 1.f;
+        const cplx eta_12 = material_IOR(sc, m, k);
+        const bool has_transmission = IOR_has_transmission(eta_12);
+        if (wi.z == 0.f || (!has_specular && !has_scatter)) return r;
+        float pdf = 1.f;
+        bool is_specular = has_specular;
+        if (has_specular && has_scatter) {
+            const float pdf_specular = alpha;
+            is_specular = pdf_specular == 1.f || sampler_r(sampler) < pdf_specular;
+            pdf = is_specular ? pdf_specular : 1.f - pdf_specular;
+        }
+        float J = 1.f;
+        const fresnel_t f = fresnel(eta_12, wi, vec3{0, 0, 1});
+        const float pdf_transmission = (f.Ts + f.Tp) / 2.f;
+        bool is_reflection = true;
+        if (has_transmission) {
+            is_reflection = sampler_r(sampler) >= pdf_transmission;
+            pdf *= is_reflection ? 1.f - pdf_transmission : pdf_transmission;
+        }
+        if (!is_reflection && transport == TRANSPORT_BACKWARD) J = sqr(f.eta_12.re);
+        const float scale = is_reflection ? m.refl_scale : m.trans_scale;
+        if (scale == 0.f || (!is_reflection && !has_transmission)) return r;
+        if (is_specular) {
+            const vec3 wo = is_reflection ? reflect_z(wi) : f.t;
+            const mueller_t F = mueller_fresnel_rt(eta_12, is_reflection, wi, vec3{0, 0, 1});
+            r.wo = wo;
+            r.dpd = pd_discrete(pdf);
+            r.eta = is_reflection ? 1.f : f.eta_12.re;
+            r.M = F * (alpha * J * scale / pdf);
+            r.valid = true;
+        } else {
+            const profile_sample_t ps = profile_sample(m, wi, k, sampler);
+            const vec3 h = wi + ps.wo;
+            const vec3 mm = normalize(wi.z < 0.f ? -h : h);
+            const mueller_t F = mueller_fresnel_rt(eta_12, is_reflection, wi, mm);
+            const vec3 wo = is_reflection ? ps.wo : spm_flip_wo(ps.wo, eta_12.re);
+            pdf *= ps.pdf;
+            r.wo = wo;
+            r.dpd = pdf;
+            r.eta = is_reflection ? 1.f : f.eta_12.re;
+            r.M = F * ((1.f - alpha) * J * fabsf(wo.z) * ps.psd * scale / pdf);
+            r.valid = true;
+        }
+    }
+    if (r.valid) {
+        if (m.two_sided) r.wo = two_sided_flip(r.wo, flipz);
+        if (m.scale != 1.f) r.M = r.M * m.scale;
+    }
+    return r;
+}
+
+// integrator/common.hpp:21-33
+WT_HD float shading_normals_correction_scale(uint32_t transport, float wig, float wog, float wis, float wos) {
+    if (transport == TRANSPORT_FORWARD) return fminf_(fabsf(wis * wog / (wos * wig)), 1e+2f);
+    return 1.f;
+}
+
+}   // namespace wt

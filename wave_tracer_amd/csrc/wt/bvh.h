@@ -1,0 +1,373 @@
+// wave_tracer_amd — 8-wide BVH ray / cone traversal and the ballistic<->diffusive traversal policy
+// (SURVEY.md §8 rows a6, a7).
+//
+// Reference: src/ads/bvh8w.cpp:45-57 (child sort), 123-185 (cone leaf test), 187-230 (cone x 8 AABB),
+//            232-318 (cone traversal), 394-452 (ray leaf test), 454-467 (ray x 8 AABB),
+//            469-554 (ray traversal), 556-603 (closest / any hit);
+//            include/wt/ads/traversal_common.hpp:62-88 (search_range), 116-149 (record assembly);
+//            include/wt/integrator/traversal.hpp:26-57, 94-172, 319-333.
+//
+// The traversal stack is addressed through a (pointer, stride) pair so that a HIP kernel can keep it
+// in LDS, interleaved across the lanes of a wavefront (entry i of lane l at lds[i*blockDim + l]: every
+// lane owns its own bank column, ds_read_b64 / ds_write_b64 are conflict-free), while the CPU checker
+// passes a plain local array with stride 1.
+#pragma once
+#include "cone.h"
+#include "scene.h"
+
+namespace wt {
+
+struct stack_entry_t {
+    float t;
+    int32_t ptr;
+};
+// Two-segment stack: entries [0,n_fast) live at p[i*stride] (LDS, lane-interleaved, on the device), entries
+// [n_fast,cap) in a private spill array q (scratch).  The CPU checker uses n_fast = cap, q = nullptr.
+struct stack_ref_t {
+    stack_entry_t* p;
+    uint32_t stride;
+    uint32_t cap;
+    uint32_t n_fast;
+    stack_entry_t* q;
+    WT_HD stack_entry_t& operator[](int i) const { return (uint32_t)i < n_fast ? p[(size_t)i * stride] : q[(uint32_t)i - n_fast]; }
+};
+WT_HD stack_ref_t make_flat_stack(stack_entry_t* p, uint32_t cap) { return stack_ref_t{p, 1, cap, cap, nullptr}; }
+
+struct uint_list_t {   // bounded output list with the same (pointer,stride) addressing
+    uint32_t* p;
+    uint32_t stride;
+    uint32_t cap;
+    WT_HD uint32_t& operator[](uint32_t i) const { return p[(size_t)i * stride]; }
+};
+
+constexpr int kRayLeafShortcut = 16;   // src/ads/bvh8w.cpp:29
+
+// insertion sort, far-first (descending tmin) (bvh8w.cpp:45-57)
+WT_HD void stack_sort_desc(const stack_ref_t& s, int begin, int end) {
+    for (int i = begin + 1; i < end; ++i) {
+        const stack_entry_t p = s[i];
+        int j;
+        for (j = i - 1; j >= begin && p.t > s[j].t; --j) s[j + 1] = s[j];
+        s[j + 1] = p;
+    }
+}
+
+struct bvh_counters_t {
+    uint32_t nodes, leaves, tri_tests;
+};
+
+// ---- ray ---------------------------------------------------------------------------------------
+struct ray_hit_t {
+    float dist;   // +inf: none
+    uint32_t tuid;
+    float bx, by;
+    uint32_t front_face;
+};
+
+template <bool shadow>
+WT_HD bool ray_gather_tris(const scene_t& sc, vec3 ro, vec3 rd, uint32_t t0, uint32_t count, const range_t& range, ray_hit_t& rec,
+                           bvh_counters_t* ctr) {
+    bool intersects = false;
+    for (uint32_t t = 0; t < count; ++t) {
+        const tri_geo_t tri = sc.tri_geo[t0 + t];
+        if (ctr) ctr->tri_tests++;
+        if (shadow) {
+            if (test_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range)) {
+                rec.dist = range.min;
+                return true;
+            }
+            continue;
+        }
+        ray_tri_hit_t h;
+        if (intersect_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range, h) && h.dist < rec.dist) {
+            rec.dist = h.dist;
+            rec.bx = h.bx;
+            rec.by = h.by;
+            rec.tuid = t0 + t;
+            rec.front_face = dot(tri.n, rd) <= 0.f;
+            intersects = true;
+        }
+    }
+    return intersects;
+}
+
+// Closest-hit (shadow=false) or any-hit (shadow=true) ray traversal (bvh8w.cpp:469-554).
+// Box culling uses [range.min, min(range.max, closest)] instead of the reference's [0, closest]; the set of
+// accepted triangles is identical because the triangle test itself enforces `range`.
+template <bool shadow>
+WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack, ray_hit_t& rec,
+                            bvh_counters_t* ctr = nullptr) {
+    rec.dist = WT_INF;
+    rec.tuid = kInvalid;
+    rec.bx = rec.by = 0.f;
+    rec.front_face = 0;
+    if (sc.n_nodes == 0) return false;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+
+    int s = 1;
+    stack[0] = stack_entry_t{0.f, 1};
+    while (s > 0) {
+        const stack_entry_t top = stack[s - 1];
+        --s;
+        if (top.ptr < 0) {
+            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            if (ctr) ctr->leaves++;
+            const bool intr = ray_gather_tris<shadow>(sc, ro, rd, leaf.tris_ptr, leaf.count, range, rec, ctr);
+            if (intr) {
+                if (shadow) return true;
+                while (s > 0 && stack[s - 1].t >= rec.dist) --s;
+            }
+            continue;
+        }
+        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        if ((int)n.tris_count <= kRayLeafShortcut) {
+            const bool intr = ray_gather_tris<shadow>(sc, ro, rd, n.tris_start, n.tris_count, range, rec, ctr);
+            if (intr) {
+                if (shadow) return true;
+                while (s > 0 && stack[s - 1].t >= rec.dist) --s;
+            }
+            continue;
+        }
+        if (ctr) ctr->nodes++;
+        const float tfar = fminf_(rec.dist, range.max);
+        const int begin = s;
+        for (int i = 0; i < 8; ++i) {
+            const int32_t cp = n.child[i];
+            if (cp == 0) continue;
+            const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
+            const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
+            const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
+            const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
+            const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
+            const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
+            const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, range.min));
+            const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
+            if (rmin <= rmax && s < (int)stack.cap) stack[s++] = stack_entry_t{rmin, cp};
+        }
+        stack_sort_desc(stack, begin, s);
+    }
+    return rec.dist < WT_INF;
+}
+
+// ads_t::intersect(ray) + ray_work_to_intersection_record (traversal_common.hpp:94-113)
+WT_HD bool ads_intersect_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack, ray_hit_t& hit,
+                             bvh_counters_t* ctr = nullptr) {
+    bvh_traverse_ray<false>(sc, ro, rd, range, stack, hit, ctr);
+    if (!finitef(hit.dist) || hit.dist > range.max) {
+        hit.dist = WT_INF;
+        return false;
+    }
+    return true;
+}
+// ads_t::shadow(ray): TRUE if occluded (bvh8w.cpp:579-603)
+WT_HD bool ads_shadow_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack,
+                          bvh_counters_t* ctr = nullptr) {
+    ray_hit_t h;
+    bvh_traverse_ray<true>(sc, ro, rd, range, stack, h, ctr);
+    return h.dist < WT_INF;
+}
+
+// ---- cone --------------------------------------------------------------------------------------
+struct cone_hit_t {
+    float dist;   // closest intersection distance (+inf: none)
+    uint32_t front_face;
+    uint32_t ntris;      // triangles written to the list
+    uint32_t overflow;   // triangles dropped because the list was full
+};
+
+// intersection_record_work_t::search_range (traversal_common.hpp:76-83)
+WT_HD range_t cone_search_range(const cone_t& cone, const range_t& searchrange, float intr_dist, float z_scale) {
+    const float dist = fmaxf_(searchrange.min, intr_dist);
+    const float z_dist = cone_axes(cone, dist).x * z_scale;
+    range_t r{searchrange.min, fminf_(searchrange.max, dist + z_dist)};
+    return rand_(r, range_positive());
+}
+
+// Cone traversal (bvh8w.cpp:232-318): closest distance + every triangle hit inside the (shrinking) z-slab.
+WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack,
+                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr) {
+    rec.dist = WT_INF;
+    rec.front_face = 0;
+    rec.ntris = 0;
+    rec.overflow = 0;
+    if (sc.n_nodes == 0) return false;
+    const vec3 ro = cone.o, rd = cone.d;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    const float ta = cone.tan_alpha, ix = cone.x0;
+
+    range_t range = cone_search_range(cone, searchrange, rec.dist, z_scale);
+    int s = 1;
+    stack[0] = stack_entry_t{0.f, 1};
+    while (s > 0) {
+        const stack_entry_t top = stack[s - 1];
+        --s;
+        if (top.ptr < 0) {
+            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            if (ctr) ctr->leaves++;
+            bool found = false;
+            for (uint32_t t = 0; t < leaf.count; ++t) {
+                const uint32_t tuid = leaf.tris_ptr + t;
+                const tri_geo_t tri = sc.tri_geo[tuid];
+                if (ctr) ctr->tri_tests++;
+                const bool front_face = dot(tri.n, -rd) > 0.f;
+                cone_tri_hit_t h;
+                if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h)) {
+                    if (h.dist > range.max) continue;   // numerics (bvh8w.cpp:162)
+                    if (h.dist < rec.dist) {
+                        rec.dist = h.dist;
+                        rec.front_face = front_face;
+                    }
+                    found = true;
+                    if (rec.ntris < tris.cap)
+                        tris[rec.ntris++] = tuid;
+                    else
+                        rec.overflow++;
+                }
+            }
+            if (found) {
+                range = cone_search_range(cone, searchrange, rec.dist, z_scale);
+                while (s > 0 && stack[s - 1].t >= range.max) --s;
+            }
+            continue;
+        }
+        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        if (ctr) ctr->nodes++;
+        const int begin = s;
+        for (int i = 0; i < 8; ++i) {
+            const int32_t cp = n.child[i];
+            if (cp == 0) continue;
+            // cone_cluster_intersect (bvh8w.cpp:187-230): grow the box by the cone radius at its far z
+            float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
+            float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+            const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
+            const float dot_d_b = rd.x * bx + rd.y * by + rd.z * bz;
+            const float maxz = clampf(dot_d_b, 0.f, range.max);
+            const float enlr = fmaf(maxz, ta, ix);
+            ominx -= enlr;
+            ominy -= enlr;
+            ominz -= enlr;
+            omaxx += enlr;
+            omaxy += enlr;
+            omaxz += enlr;
+            const float dminx = (sx ? omaxx : ominx) * rinvd.x, dmaxx = (sx ? ominx : omaxx) * rinvd.x;
+            const float dminy = (sy ? omaxy : ominy) * rinvd.y, dmaxy = (sy ? ominy : omaxy) * rinvd.y;
+            const float dminz = (sz ? omaxz : ominz) * rinvd.z, dmaxz = (sz ? ominz : omaxz) * rinvd.z;
+            float tmin = 0.f, tmax = dmaxx;
+            tmin = fmaxf_(tmin, dminx);
+            tmax = fminf_(tmax, dmaxy);
+            tmin = fmaxf_(tmin, dminy);
+            tmax = fminf_(tmax, dmaxz);
+            tmin = fmaxf_(tmin, dminz);
+            const bool hit = tmin <= tmax && tmax >= range.min && tmin <= range.max;
+            if (!hit) continue;
+            if (tmin >= range.max) continue;
+            if (s < (int)stack.cap) stack[s++] = stack_entry_t{tmin, cp};
+        }
+        stack_sort_desc(stack, begin, s);
+    }
+    return rec.ntris > 0;
+}
+
+// ---- traversal policy (include/wt/integrator/traversal.hpp) -------------------------------------
+constexpr float kBallisticScale = 1.001f;      // traversal.hpp:26
+
+// traversal.hpp:39-57 (min_ballistic_distance is always 0 at the call sites: ray.o == envelope.o)
+WT_HD float max_ballistic_distance(float lambda_m, uint32_t segment, float min_ballistic_distance) {
+    const uint64_t max_segments = 16, seg_lambdas = 8, max_seg_lambdas = 1u << 16;
+    const float min_dist = min_ballistic_distance * 1.05f;
+    if (segment >= max_segments) return WT_INF;
+    const uint64_t sh = seg_lambdas << (2 * segment + 1);
+    const uint64_t B = sh < max_seg_lambdas ? sh : max_seg_lambdas;
+    return min_dist + lambda_m * float(B);
+}
+
+struct trav_result_t {
+    vec3 origin;
+    uint32_t empty;
+    uint32_t ballistic;
+    float dist;
+    float region_depth;
+    uint32_t front_face;
+    // ballistic (single ray hit)
+    uint32_t tuid;
+    float bx, by;
+    // diffusive
+    uint32_t ntris;
+    uint32_t overflow;
+    // statistics
+    uint32_t n_ray_queries, n_cone_queries;
+};
+
+// integrator::traverse (traversal.hpp:94-172). `envelope` already has its origin offset for self-intersection.
+WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
+                             const stack_ref_t& stack, const uint_list_t& tris, bvh_counters_t* ctr = nullptr) {
+    trav_result_t r;
+    r.origin = envelope.o;
+    r.empty = 1;
+    r.ballistic = 1;
+    r.dist = -WT_INF;
+    r.region_depth = 0.f;
+    r.front_face = 0;
+    r.tuid = kInvalid;
+    r.bx = r.by = 0.f;
+    r.ntris = 0;
+    r.overflow = 0;
+    r.n_ray_queries = r.n_cone_queries = 0;
+
+    const vec3 ro = envelope.o, rd = envelope.d;
+    ray_hit_t rh;
+    if (force_ray_tracing || cone_is_ray(envelope)) {
+        r.n_ray_queries++;
+        if (ads_intersect_ray(sc, ro, rd, range_t{0.f, distance}, stack, rh, ctr)) {
+            r.empty = 0;
+            r.dist = rh.dist;
+            r.tuid = rh.tuid;
+            r.bx = rh.bx;
+            r.by = rh.by;
+            r.front_face = rh.front_face;
+            r.ntris = 1;
+        }
+        return r;
+    }
+
+    const float min_ballistic_distance = 0.f;
+    float dist = 0.f;
+    for (uint32_t seg = 0;; ++seg) {
+        const float ballistic_dist = max_ballistic_distance(lambda_m, seg, min_ballistic_distance);
+        r.n_ray_queries++;
+        if (ads_intersect_ray(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, stack, rh, ctr)) {
+            r.empty = 0;
+            r.dist = rh.dist;
+            r.tuid = rh.tuid;
+            r.bx = rh.bx;
+            r.by = rh.by;
+            r.front_face = rh.front_face;
+            r.ntris = 1;
+            return r;
+        }
+        dist += ballistic_dist;
+        if (ballistic_dist == WT_INF || dist >= distance) return r;
+
+        // attempt diffusive propagation
+        const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
+        cone_hit_t ch;
+        r.n_cone_queries++;
+        bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr);
+        const bool df_empty = ch.ntris == 0;
+        if (df_empty || ch.dist - dist >= min_df_prog) {
+            r.ballistic = 0;
+            r.empty = df_empty;
+            r.dist = df_empty ? -WT_INF : ch.dist;
+            r.front_face = ch.front_face;
+            r.ntris = ch.ntris;
+            r.overflow = ch.overflow;
+            r.region_depth = df_empty ? 0.f : kMajorAxisToZScale * cone_axes(envelope, ch.dist).x;
+            return r;
+        }
+        // too short: continue the ballistic path
+    }
+}
+
+}   // namespace wt

@@ -1,0 +1,277 @@
+// wave_tracer_amd — Fraunhofer free-space diffraction (FSD) BSDF: aperture construction, ASF evaluation, LUT
+// importance sampling with rejection.
+//
+// Reference: include/wt/interaction/fsd/fraunhofer/fsd.hpp:20-185,
+//            include/wt/interaction/fsd/fraunhofer/free_space_diffraction.hpp:34-135,
+//            src/interaction/fsd/fraunhofer/free_space_diffraction.cpp:22-129,
+//            src/interaction/fsd/fraunhofer/fsd_sampler.cpp:38-156,
+//            include/wt/interaction/fsd/fraunhofer/fsd_lut.hpp:25-86.
+//
+// An aperture is a header + a bounded array of edge segments.  In the reference the per-edge amplitudes are
+// complex numbers whose imaginary (a_b) resp. real (iab_2) parts are identically zero (free_space_diffraction.cpp:
+// 66,72: `ca = a`), so they are stored as two real numbers here.
+#pragma once
+#include "beam.h"
+#include "gauss.h"
+#include "rng.h"
+
+namespace wt {
+
+constexpr float kFsdPA1 = 0.0049361075794549872500f;
+constexpr float kFsdPA2 = 0.21899789398059305541f;
+constexpr float kFsdP0Sigma = 0.288675134594813f / 4.f;
+constexpr float kFsdUnitM = 1e-3f;       // fsd_unit = 1 mm
+constexpr float kFsdWo2Cutoff = .85f;
+constexpr uint32_t kFsdMaxEdges = 48;    // per-aperture segment cap on the device (overflow is counted)
+
+struct fsd_edge_t {
+    vec2 e, v;    // edge vector, mid point (in fsd units = mm)
+    float ab;     // a_b   = ca - cb           (real)
+    float iab;    // iab_2 = i * (ca + cb)/2   -> stores (ca+cb)/2
+    float pdf;
+};
+struct fsd_aperture_t {
+    uint32_t n_edges;
+    float P0, P0_pdf, psi02, recp_I;
+    float k;
+    frame_t frame;
+    uint32_t overflow;
+};
+struct fsd_edges_ref_t {
+    fsd_edge_t* p;
+    uint32_t stride;
+    WT_HD fsd_edge_t get(uint32_t i) const {
+        fsd_edge_t e;
+        soa_load(reinterpret_cast<const uint32_t*>(p), stride, i, e);
+        return e;
+    }
+    WT_HD void set(uint32_t i, const fsd_edge_t& e) const { soa_store(reinterpret_cast<uint32_t*>(p), stride, i, e); }
+};
+
+WT_HD float fsd_alpha1(float x, float y) { return x == 0.f ? 0.f : kInvTwoPi * y / (x * (x * x + y * y)) * (cosf(x / 2.f) - sincf_(x / 2.f)); }
+WT_HD float fsd_alpha2(float x, float y) { return x == 0.f ? 0.f : kInvTwoPi * y / (x * x + y * y) * sincf_(x / 2.f); }
+WT_HD float fsd_chi_e(vec2 xi) {
+    const float chi = 0.830092714835359f;
+    const float t = 1.f + chi * dot(xi, xi);
+    const float t2 = t * t, t3 = t2 * t;
+    return fmaxf_(0.f, 1.f - (3.f / t2 - 2.f / t3));
+}
+WT_HD float fsd_chi_0(vec2 xi) {
+    xi = xi / kFsdP0Sigma;
+    return expf(-.5f * dot(xi, xi));
+}
+// zeta = xi * Xi, Xi = mat2(e, m), m = (e.y,-e.x)   (vec * mat: (dot(xi,e), dot(xi,m)))
+WT_HD vec2 fsd_zeta(const fsd_edge_t& e, vec2 xi) { return {dot(xi, e.e), xi.x * e.e.y - xi.y * e.e.x}; }
+WT_HD cplx fsd_Psi(const fsd_edge_t& e, vec2 xi) {
+    const vec2 z = fsd_zeta(e, xi);
+    const float a1 = e.ab * fsd_alpha1(z.x, z.y);
+    const float a2 = e.iab * fsd_alpha2(z.x, z.y);
+    const float ee2 = length2(e.e);
+    return cpolar(ee2, -dot(e.v, xi)) * cplx{a1, a2};
+}
+WT_HD float fsd_Psi2(const fsd_edge_t& e, vec2 xi) {
+    const vec2 z = fsd_zeta(e, xi);
+    const float a1 = e.ab * fsd_alpha1(z.x, z.y);
+    const float a2 = e.iab * fsd_alpha2(z.x, z.y);
+    return sqr(length2(e.e)) * (a1 * a1 + a2 * a2);
+}
+WT_HD float fsd_ASF_unclamped(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec2 xi) {
+    cplx amp{0.f, 0.f};
+    for (uint32_t i = 0; i < ap.n_edges; ++i) amp = amp + fsd_Psi(ed.get(i), xi);
+    return cnorm(amp);
+}
+WT_HD float fsd_ASF(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec2 xi) {
+    return fsd_ASF_unclamped(ap, ed, xi) * fsd_chi_e(xi) + ap.psi02 * fsd_chi_0(xi);
+}
+WT_HD float fsd_sampling_density(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec2 xi) {
+    float d = 0.f;
+    for (uint32_t i = 0; i < ap.n_edges; ++i) d += fsd_Psi2(ed.get(i), xi);
+    return d * fsd_chi_e(xi) + ap.P0 * kInvTwoPi / sqr(kFsdP0Sigma) * fsd_chi_0(xi);
+}
+WT_HD float fsd_Pj(const fsd_edge_t& e) {
+    const float l4 = sqr(length2(e.e));
+    return l4 * kFsdPA1 * sqr(e.ab) + l4 * kFsdPA2 * sqr(e.iab);
+}
+
+// free_space_diffraction_t ctor (free_space_diffraction.cpp:22-129).
+// `edge_ids`: the (deduplicated, sorted) ADS edge ids of the interaction region.  `sigma` = wavefront std-dev.
+template <class EdgeIdList>
+WT_HD void fsd_build_aperture(const scene_t& sc, const frame_t& frame, float k, float total_power, const cone_t& beam, const EdgeIdList& edge_ids,
+                              uint32_t n_edge_ids, vec2 sigma, fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
+    ap.k = k;
+    ap.frame = frame;
+    ap.n_edges = 0;
+    ap.overflow = 0;
+    const vec2 cse = sigma * kBeamEnvelope;   // wave_function.envelope()
+    const float r = fmaxf_(cse.x, cse.y);
+    const float max_edge_length = .33f * r;
+    ap.recp_I = total_power > 0.f ? 1.f / total_power : 0.f;
+    float P_total = 0.f;
+    for (uint32_t ei = 0; ei < n_edge_ids; ++ei) {
+        const edge_t edge = sc.edges[edge_ids[ei]];
+        // only the projected silhouette
+        if (dot(beam.d, edge.n1) * dot(beam.d, edge.n2) >= 0.f) continue;
+        const vec3 la = to_local(frame, edge.a - beam.o), lb = to_local(frame, edge.b - beam.o);
+        const vec2 u1{la.x, la.y}, u2{lb.x, lb.y};
+        float t1 = 0.f, t2 = 1.f;
+        const vec2 q1 = u1 / cse, q2 = u2 / cse;
+        if (!(dot(q1, q1) <= 1.f) || !(dot(q2, q2) <= 1.f)) {
+            const edge_ellipse_t intr = intersect_edge_ellipse(u1, u2, cse.x, cse.y);
+            if (intr.points == 0) continue;
+            t1 = fmaxf_(0.f, intr.t1);
+            t2 = fminf_(1.f, intr.t2);
+        }
+        const float len = length(mix2(u1, u2, t1) - mix2(u1, u2, t2));
+        // max(1, int(round(len/max_edge_length) + .5))
+        int segments = (int)(roundf(len / max_edge_length) + .5f);
+        if (segments < 1) segments = 1;
+        const float seg = 1.f / float(segments);
+        vec2 v1 = mix2(u1, u2, t1);
+        float a = sqrtf(wavefront_intensity(sigma, v1));
+        for (int i = 0; i < segments; ++i) {
+            const float tt = mixf(t1, t2, float(i + 1) * seg);
+            const vec2 v2 = mix2(u1, u2, tt);
+            const float b = sqrtf(wavefront_intensity(sigma, v2));
+            if (a > 0.f || b > 0.f) {
+                fsd_edge_t fe;
+                fe.v = ((v1 + v2) / 2.f) / kFsdUnitM;
+                fe.e = (v2 - v1) / kFsdUnitM;
+                fe.ab = a - b;
+                fe.iab = (a + b) / 2.f;
+                fe.pdf = fsd_Pj(fe);
+                if (fe.pdf > 0.f) {
+                    if (ap.n_edges < kFsdMaxEdges) {
+                        ed.set(ap.n_edges++, fe);
+                        P_total += fe.pdf;
+                    } else
+                        ap.overflow++;
+                }
+            }
+            v1 = v2;
+            a = b;
+        }
+    }
+    // power in the 0-th order lobe (8-point average on a circle of radius 3*P0_sigma)
+    const float psi0r = 3.f * kFsdP0Sigma;
+    const vec2 dirs[8] = {{-kInvSqrt2, -kInvSqrt2}, {-1, 0}, {-kInvSqrt2, kInvSqrt2}, {0, 1}, {kInvSqrt2, kInvSqrt2}, {1, 0}, {kInvSqrt2, -kInvSqrt2}, {0, -1}};
+    float acc = 0.f;
+    for (int i = 0; i < 8; ++i) acc += fsd_ASF_unclamped(ap, ed, psi0r * dirs[i]);
+    ap.psi02 = acc / 8.f;
+    ap.P0 = (kTwoPi * sqr(kFsdP0Sigma) * ap.psi02) / sqr(k * 1.f);   // k [1/mm] * fsd_unit [mm]
+    P_total += ap.P0;
+    if (P_total > 0.f) {
+        const float rp = 1.f / P_total;
+        ap.P0_pdf = ap.P0 * rp;
+        for (uint32_t i = 0; i < ap.n_edges; ++i) {
+            fsd_edge_t e = ed.get(i);
+            e.pdf *= rp;
+            ed.set(i, e);
+        }
+    } else {
+        ap.P0_pdf = 1.f;
+        ap.n_edges = 0;
+    }
+}
+
+// ---- LUT sampling (fsd_lut.hpp:36-69) ------------------------------------------------------------
+WT_HD float fsd_lut_lerp1(float x, const float* tbl, uint32_t S) {
+    x *= float(S - 1);
+    uint32_t l = (uint32_t)x;
+    if (l > S - 1) l = S - 1;
+    const uint32_t h = l + 1 < S ? l + 1 : S - 1;
+    const float f = fractf(x);
+    return f * tbl[h] + (1.f - f) * tbl[l];
+}
+WT_HD float fsd_lut_lerp2(float x, float rx, const float* tbl, uint32_t S) {
+    x *= float(S - 1);
+    uint32_t l = (uint32_t)x;
+    if (l > S - 1) l = S - 1;
+    const uint32_t h = l + 1 < S ? l + 1 : S - 1;
+    const float f = fractf(x);
+    return f * fsd_lut_lerp1(rx, tbl + (size_t)h * S, S) + (1.f - f) * fsd_lut_lerp1(rx, tbl + (size_t)l * S, S);
+}
+WT_HD vec2 fsd_lut_sample(const fsd_lut_t& lut, vec3 rand3, bool a1) {
+    const float* it = a1 ? lut.icdf_theta1 : lut.icdf_theta2;
+    const float* ic = a1 ? lut.icdf1 : lut.icdf2;
+    const float theta = fsd_lut_lerp1(rand3.x, it, lut.n_theta);
+    const float theta_fract = theta * 2.f / kPi;
+    const float r = fmaxf_(0.f, fsd_lut_lerp2(theta_fract, rand3.y, ic, lut.m));
+    vec2 zeta = r * vec2{cosf(theta), sinf(theta)};
+    int q = (int)(rand3.z * 4.f);
+    if (q > 3) q = 3;
+    zeta.x *= (((q + 1) / 2) % 2 == 0) ? 1.f : -1.f;
+    zeta.y *= ((q / 2) % 2 == 0) ? 1.f : -1.f;
+    return zeta;
+}
+// sampleN (fsd_sampler.cpp:55-70)
+WT_HD vec2 fsd_sampleN(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, sampler_t& sampler) {
+    // sampler.discrete<true>(n+1, ...): one uniform, linear scan
+    const float p = sampler_r(sampler);
+    float cdf = 0.f;
+    uint32_t sel = ap.n_edges;   // last
+    for (uint32_t i = 0; i < ap.n_edges; ++i) {
+        const float ep = i == 0 ? ap.P0_pdf : ed.get(i - 1).pdf;
+        cdf += ep;
+        if (p < cdf) {
+            sel = i;
+            break;
+        }
+    }
+    if (sel == 0) return kFsdP0Sigma * normal2d(sampler_r2(sampler));
+    const fsd_edge_t e = ed.get(sel - 1);
+    // sample1: pick alpha1 or alpha2 lobe  (discrete<2>({A,B}), un-normalised)
+    const float A = sqr(e.ab), B = sqr(e.iab);
+    const float pp = sampler_r(sampler) * (A + B);
+    const bool use_a1 = pp < A;
+    const vec2 zeta = fsd_lut_sample(sc.lut, sampler_r3(sampler), use_a1);
+    // zeta * inverse(Xi)
+    const mat2 Xi = mkmat2(e.e, vec2{e.e.y, -e.e.x});
+    return mul(zeta, inverse(Xi));
+}
+
+struct fsd_sample_t {
+    vec3 wo;
+    float dpd;   // solid-angle density (0: failed)
+    float weight;
+};
+// fsd_sampler_t::sample (rejection) + free_space_diffraction_t::sample
+WT_HD fsd_sample_t fsd_sample(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, sampler_t& sampler) {
+    const uint32_t edge_count = ap.n_edges;
+    const bool rejection = edge_count > 1;
+    const uint32_t max_tries = edge_count * 1024u;
+    const float recp_M = 1.f / float(edge_count);
+    vec2 xi{0, 0};
+    float pdf = 0.f, weight = 0.f;
+    for (uint32_t tr = 0; tr < max_tries; ++tr) {
+        const vec2 x = fsd_sampleN(sc, ap, ed, sampler);
+        const float g = fsd_sampling_density(ap, ed, x);
+        const float f = fsd_ASF(ap, ed, x);
+        const bool done = rejection ? sampler_r(sampler) * g < f * recp_M : true;
+        if (done) {
+            xi = x;
+            pdf = f * ap.recp_I;
+            weight = 1.f;
+            break;
+        }
+    }
+    const float scale = ap.k * 1.f;
+    if (pdf > 0.f) {
+        const vec2 zeta = xi / scale;
+        const vec2 wol{zeta.x / sqrtf(1.f + sqr(zeta.x)), zeta.y / sqrtf(1.f + sqr(zeta.y))};
+        const float wo2 = length2(wol);
+        if (wo2 < kFsdWo2Cutoff) return {vec3{wol.x, wol.y, sqrtf(1.f - wo2)}, pdf, weight};
+    }
+    return {vec3{0, 0, 1}, 0.f, 0.f};
+}
+// free_space_diffraction_t::pdf / f (free_space_diffraction.hpp:112-133)
+WT_HD float fsd_pdf(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec3 wolocal) {
+    const float wo2 = sqr(wolocal.x) + sqr(wolocal.y);
+    if (wolocal.z <= 0.f || wo2 >= kFsdWo2Cutoff) return 0.f;
+    const float scale = ap.k * 1.f;
+    const vec2 zeta{wolocal.x / sqrtf(1.f - sqr(wolocal.x)), wolocal.y / sqrtf(1.f - sqr(wolocal.y))};
+    const vec2 xi = scale * zeta;
+    const float pdf = fsd_ASF(ap, ed, xi) * ap.recp_I;
+    return (0.f <= pdf && pdf < 1e+2f) ? pdf : 0.f;
+}
+
+}   // namespace wt

@@ -1,0 +1,218 @@
+// wave_tracer_amd — flattened (struct-of-pointers) scene description consumed by the hot path.
+//
+// This is the drop-in boundary's payload: everything the per-sample
+// integrator dereferences, baked once on the host.  The same POD layout is used with host pointers
+// (CPU checker, scene baking) and with device pointers (HIP kernels); it contains no virtuals.
+//
+// Reference for the individual blocks:
+//   triangles/edges      include/wt/ads/common.hpp:37-72, src/ads/bvh8w_constructor.cpp:119-151
+//   BVH8 nodes           include/wt/ads/bvh8w/bvh8w_node.hpp:18-41, ads/bvh8w/common.hpp:29-43
+//   materials            include/wt/bsdf/*.hpp, src/bsdf/*.cpp (flattened wrappers two_sided/scale/composite)
+//   spectra              src/spectrum/*.cpp (baked to tables)
+//   emitters             include/wt/emitter/{spot,area}.hpp
+//   sensors / film       include/wt/sensor/sensor/{perspective,virtual_plane_sensor}.hpp, sensor/film/film.hpp
+//   sampling tables      src/scene/scene_build_sensor_sampling_data.cpp:40-150
+#pragma once
+#include "core.h"
+
+namespace wt {
+
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+struct tri_geo_t {   // 48 B
+    vec3 a, b, c, n;
+};
+struct tri_meta_t {   // 20 B
+    uint32_t shape_idx, shape_tri_idx;
+    uint32_t edge[3];   // edge_ab, edge_bc, edge_ca (kInvalid = none)
+};
+struct tri_shade_t {   // per triangle shading data (mesh/triangle.hpp), BVH order
+    vec3 n0, n1, n2;
+    vec2 uv0, uv1, uv2;
+    vec3 dpdu;
+    uint32_t has_uv;
+};
+struct edge_t {   // ads/common.hpp:53-72
+    vec3 a, b, e;
+    vec3 n1, t1, n2, t2;
+    float alpha;
+    uint32_t tri1, tri2;   // kInvalid = boundary edge
+};
+
+// 8-wide BVH node: child AABBs in SoA inside the node.
+// child ptr: 0 empty, >0 internal node index+1, <0 -(leaf index+1); root ptr = 1.
+struct bvh8_node_t {
+    float minx[8], miny[8], minz[8];
+    float maxx[8], maxy[8], maxz[8];
+    int32_t child[8];
+    uint32_t tris_start, tris_count;
+    uint32_t pad[6];   // 256 B
+};
+struct bvh8_leaf_t {
+    uint32_t tris_ptr, count;
+};
+
+struct shape_t {
+    int32_t material;
+    int32_t emitter;   // -1 none
+    float surface_area, recp_surface_area;
+    uint32_t tri_offset;   // into shape_tri_tuid / shape_tri_cdf
+    uint32_t tri_count;
+};
+
+// ---- spectra --------------------------------------------------------------------------------------
+enum spectrum_type_e : int32_t { SPEC_CONST = 0, SPEC_TABLE = 1, SPEC_DISCRETE = 2 };
+struct spectrum_t {
+    int32_t type;
+    float kmin, kmax;         // support [1/mm]; value 0 outside (table) / line position in kmin (discrete)
+    uint32_t offset, count;   // into spectra_data: count knots uniformly spaced in k over [kmin,kmax]
+    float c_re, c_im;         // constant value / discrete line value
+    uint32_t is_complex;      // table holds count re-values followed by count im-values
+};
+
+// ---- materials -----------------------------------------------------------------------------------
+enum material_type_e : int32_t { MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1, MAT_SURFACE_SPM = 2 };
+enum profile_type_e : int32_t { PROFILE_DIRAC = 0, PROFILE_FRACTAL = 1 };
+struct material_t {
+    int32_t type;
+    uint32_t two_sided;     // bsdf/two_sided wrapper
+    float scale;            // bsdf/scale wrapper (constant texture)
+    int32_t refl_spec;      // diffuse: reflectance spectrum
+    float refl_tex_scale;   // constant stand-in for texture modulation of reflectance
+    int32_t ior_spec;       // dielectric / surface_spm: interior IOR spectrum (complex)
+    int32_t ext_ior_spec;   // exterior IOR spectrum (-1 = 1)
+    int32_t profile;        // surface_spm: PROFILE_*
+    float roughness;        // fractal: perceptual roughness
+    float gamma;            // fractal: log-log slope
+    float refl_scale, trans_scale;
+};
+
+// ---- emitters ------------------------------------------------------------------------------------
+enum emitter_type_e : int32_t { EMIT_SPOT = 0, EMIT_AREA = 1 };
+struct emitter_t {
+    int32_t type;
+    int32_t spectrum;   // radiant intensity (spot) / radiance (area), value multiplies `scale`
+    float scale;
+    float phase_space_extent_scale;
+    // spot
+    vec3 position;
+    frame_t frame;   // to_world rotation: local z = mean direction
+    float cutoff, falloff, cos_cutoff, cos_falloff, recp_cutoff_range, max_tan_alpha;
+    float extent;   // <=0: default 10 lambda
+    // area
+    int32_t shape;
+    // sampling tables
+    float select_pmf;           // emitters_power_distribution.pdf
+    int32_t k_dist;             // index into kdists
+};
+
+// spectral sampling distribution per emitter (emission x sensitivity product)
+struct kdist_t {
+    int32_t discrete;          // 1: single line at kmin with mass 1
+    float kmin, kmax;
+    uint32_t offset, count;    // pdf knots (count), cdf knots (count) in kdist_data: pdf[0..count), cdf[0..count)
+};
+
+// ---- sensor / film ------------------------------------------------------------------------------
+enum sensor_type_e : int32_t { SENSOR_PERSPECTIVE = 0, SENSOR_VIRTUAL_PLANE = 1 };
+struct sensor_t {
+    int32_t type;
+    uint32_t width, height, channels;
+    uint32_t ray_trace_only;
+    // film reconstruction filter
+    float rfilter_sigma;   // in pixels (= .25 * rfilter_scale)
+    int32_t rf_radius;
+    uint32_t flip_x, flip_y;
+    // response: per-channel spectrum ids
+    int32_t response_spec[4];
+    // perspective
+    vec3 position;
+    frame_t frame;            // camera to world rotation (t = right, b = up, n = view dir)
+    float inv_cam[16];        // inverse(viewport * perspective), row-major 4x4
+    float cam[16];            // viewport * perspective, row-major
+    vec3 ddir_dx, ddir_dy;
+    float sensor_area;        // prod(snsr_extent) [m^2]
+    float element_extent_x;   // [m]
+    float sourcing_tan_alpha;
+    float phase_space_extent_scale;
+    // virtual plane
+    vec3 origin;              // sensor_origin (corner)
+    vec2 extent, element_extent;
+    float recp_area;
+    float requested_tan_alpha;   // <0: none (MUB)
+};
+
+struct integrator_opts_t {
+    int32_t max_depth;
+    uint32_t MIS, RR, FSD, sensor_direct, emitter_direct;
+    uint32_t force_ray_tracing;
+    // test hooks: evaluate a single (s,t) strategy with unit MIS weight (0 = all strategies; v>0 selects v-1)
+    uint32_t debug_only_s, debug_only_t;
+};
+
+// Fraunhofer FSD inverse-CDF LUT (interaction/fsd/fraunhofer/fsd_lut.hpp:27-69), regenerated on the host.
+struct fsd_lut_t {
+    uint32_t n_theta;   // Nsamples
+    uint32_t m;         // Msamples (square)
+    const float* icdf_theta1;
+    const float* icdf_theta2;
+    const float* icdf1;   // [m][m]
+    const float* icdf2;
+};
+
+struct scene_t {
+    // geometry
+    const tri_geo_t* tri_geo;
+    const tri_meta_t* tri_meta;
+    const tri_shade_t* tri_shade;
+    uint32_t n_tris;
+    const edge_t* edges;
+    uint32_t n_edges;
+    const bvh8_node_t* nodes;
+    uint32_t n_nodes;
+    const bvh8_leaf_t* leaves;
+    uint32_t n_leaves;
+    vec3 world_min, world_max;
+    // shapes
+    const shape_t* shapes;
+    uint32_t n_shapes;
+    const uint32_t* shape_tri_tuid;   // per shape: mesh tri index -> tuid
+    const float* shape_tri_cdf;       // per shape: area cdf (tri_count+1 entries each, concatenated with +shape index offset)
+    // materials & spectra
+    const material_t* materials;
+    uint32_t n_materials;
+    const spectrum_t* spectra;
+    uint32_t n_spectra;
+    const float* spectra_data;
+    // emitters
+    const emitter_t* emitters;
+    uint32_t n_emitters;
+    const float* emitter_cdf;   // n_emitters+1
+    const kdist_t* kdists;
+    const float* kdist_data;
+    // sensor
+    sensor_t sensor;
+    integrator_opts_t opts;
+    fsd_lut_t lut;
+};
+
+// ---- spectrum evaluation ---------------------------------------------------------------------
+WT_HD cplx spectrum_value(const scene_t& sc, int id, float k) {
+    if (id < 0) return {1.f, 0.f};
+    const spectrum_t s = sc.spectra[id];
+    if (s.type == SPEC_CONST) return {s.c_re, s.c_im};
+    if (s.type == SPEC_DISCRETE) return k == s.kmin ? cplx{s.c_re, s.c_im} : cplx{0.f, 0.f};
+    if (k < s.kmin || k > s.kmax) return {0.f, 0.f};
+    const float x = (k - s.kmin) / (s.kmax - s.kmin) * float(s.count - 1);
+    uint32_t l = (uint32_t)x;
+    if (l > s.count - 1) l = s.count - 1;
+    const uint32_t h = l + 1 < s.count ? l + 1 : s.count - 1;
+    const float f = x - float(l);
+    const float* d = sc.spectra_data + s.offset;
+    cplx r{d[l] * (1.f - f) + d[h] * f, 0.f};
+    if (s.is_complex) r.im = d[s.count + l] * (1.f - f) + d[s.count + h] * f;
+    return r;
+}
+WT_HD float spectrum_f(const scene_t& sc, int id, float k) { return spectrum_value(sc, id, k).re; }
+
+}   // namespace wt

@@ -1,0 +1,69 @@
+"""Host-side render loop: the counterpart of scene_renderer_t::render / render_context_t::develop
+(src/scene/render.cpp:381-579, 245-291).  Allocates the three linear film accumulators as torch tensors on the
+GPU, calls the HIP path through the C-ABI and develops the film.  Multi-GPU: samples are sharded by sample index
+(every rank renders all pixels for a disjoint sample range into its own film) and the films are summed with one
+RCCL reduce — no collective on the data path."""
+import ctypes as C
+
+import numpy as np
+
+from .api import Scene, load_library, _check
+
+
+def alloc_films(scene, device):
+    import torch
+    H, W, Cn = scene.height, scene.width, scene.channels
+    value = torch.zeros((H, W, Cn), dtype=torch.float64, device=device)
+    weight = torch.zeros((H, W), dtype=torch.float64, device=device)
+    light = torch.zeros((H, W, Cn), dtype=torch.float64, device=device)
+    return value, weight, light
+
+
+def develop(scene, value, weight, light, spe):
+    """pixel = value/weight (0 where weight==0) + light/spe  — film_storage.hpp:256-287."""
+    v = np.ascontiguousarray(value, dtype=np.float64)
+    w = np.ascontiguousarray(weight, dtype=np.float64)
+    l = np.ascontiguousarray(light, dtype=np.float64)
+    out = np.zeros(v.shape, dtype=np.float32)
+    _check(load_library().wtgpu_develop(scene.handle, v.ctypes.data, w.ctypes.data, l.ctypes.data, int(spe), out.ctypes.data))
+    return out
+
+
+def render(scene, spp, seed=1, device=0, sample_begin=0):
+    """Renders `spp` samples per element on one GPU; returns (value, weight, light) as numpy f64 arrays."""
+    import torch
+    if scene.device is None:
+        scene.upload(device)
+    dev = torch.device("cuda", scene.device)
+    with torch.cuda.device(dev):
+        value, weight, light = alloc_films(scene, dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        scene.render_into(value, weight, light, sample_begin, sample_begin + spp, seed, stream)
+        torch.cuda.synchronize(dev)
+    return value.cpu().numpy(), weight.cpu().numpy(), light.cpu().numpy()
+
+
+def shard_samples(spp, rank, world):
+    """Sample-index sharding: rank r renders [r*spp/world, (r+1)*spp/world)."""
+    b = (spp * rank) // world
+    e = (spp * (rank + 1)) // world
+    return b, e
+
+
+def render_distributed(scene, spp, seed=1, reduce_dst=0):
+    """One process per GPU (torch.distributed already initialised, backend nccl=RCCL on GPUs, gloo in CPU tests of the
+    sharding logic).  Each rank renders its sample shard; films are summed onto `reduce_dst`."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    b, e = shard_samples(spp, rank, world)
+    dev = torch.device("cuda", scene.device)
+    value, weight, light = alloc_films(scene, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    scene.render_into(value, weight, light, b, e, seed, stream)
+    for t in (value, weight, light):
+        dist.reduce(t, dst=reduce_dst, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize(dev)
+    if rank == reduce_dst:
+        return value.cpu().numpy(), weight.cpu().numpy(), light.cpu().numpy()
+    return None
