@@ -57,6 +57,13 @@ def load_library():
     if not os.path.exists(p):
         raise WtgpuError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          f"(hipcc --offload-arch=gfx950); wave_tracer_amd has no CPU fallback")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process leave the second one without
+    # devices.  Importing torch first makes the dynamic loader bind libwtgpu.so to the runtime torch already loaded, so
+    # that torch tensors / streams and our kernels share one HIP context.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     lib.wtgpu_scene_create_named.argtypes = [C.c_char_p, C.POINTER(SceneParams), C.POINTER(vp)]

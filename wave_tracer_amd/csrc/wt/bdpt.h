@@ -862,6 +862,10 @@ WT_HD void bdpt_connect_all(const scene_t& sc, const fsd_pool_t& pool, const fil
             if (sc.opts.debug_only_t && (int)sc.opts.debug_only_t - 1 != t) continue;
             L = L + bdpt_strategy(sc, pool, film, svs, evs, s, t, ctx, seed, sample_id, stack, ctr, bctr);
         }
+#if defined(WTGPU_DEBUG_PRINT) && defined(__HIP_DEVICE_COMPILE__)
+    if (ctx.element.x == 0 && ctx.element.y == 0)
+        printf("dbg3 L=%g nT=%d nS=%d ch=%u rfs=%g r=%d\n", L.s[0], nT, nS, sc.sensor.channels, sc.sensor.rfilter_sigma, sc.sensor.rf_radius);
+#endif
     film_splat(sc, film, ctx.element, L, ctx.k);
 }
 

@@ -47,7 +47,12 @@ WT_HD float clampf(float x, float a, float b) { return x < a ? a : (x > b ? b : 
 WT_HD float clamp01(float x) { return clampf(x, 0.f, 1.f); }
 WT_HD float signf(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }   // glm::sign
 WT_HD float mixf(float a, float b, float t) { return a * (1.f - t) + b * t; }   // glm::mix
-WT_HD bool finitef(float x) { return x - x == 0.f; }
+// bit test (an arithmetic test such as x-x==0 is broken by fma contraction: a*b - a*b becomes the rounding residual)
+WT_HD bool finitef(float x) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    return (u & 0x7f800000u) != 0x7f800000u;
+}
 WT_HD float fractf(float x) { return x - floorf(x); }
 
 // ---- error-free transforms (include/wt/math/eft/eft.hpp) ------------------------------------

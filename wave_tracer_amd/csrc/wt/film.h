@@ -72,6 +72,9 @@ WT_HD void film_splat(const scene_t& sc, const film_t& film, const sensor_elemen
     for (uint32_t c = 0; c < s.channels; ++c) {
         float v = sample.s[0] * spectrum_f(sc, s.response_spec[c], k);
         val[c] = (v >= 0.f && finitef(v)) ? v : 0.f;
+#if defined(WTGPU_DEBUG_PRINT) && defined(__HIP_DEVICE_COMPILE__)
+        if (el.x == 0 && el.y == 0) printf("dbg4 c=%u v=%g val=%g fin=%d ge=%d\n", c, v, val[c], (int)finitef(v), (int)(v >= 0.f));
+#endif
     }
     for (int dy = -r; dy <= r; ++dy) {
         const int y = (int)el.y + dy;

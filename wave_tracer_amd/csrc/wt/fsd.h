@@ -37,15 +37,12 @@ struct fsd_aperture_t {
     frame_t frame;
     uint32_t overflow;
 };
+// edges of one aperture: contiguous AoS (an aperture is read many times by the one lane that owns it)
 struct fsd_edges_ref_t {
     fsd_edge_t* p;
-    uint32_t stride;
-    WT_HD fsd_edge_t get(uint32_t i) const {
-        fsd_edge_t e;
-        soa_load(reinterpret_cast<const uint32_t*>(p), stride, i, e);
-        return e;
-    }
-    WT_HD void set(uint32_t i, const fsd_edge_t& e) const { soa_store(reinterpret_cast<uint32_t*>(p), stride, i, e); }
+    uint32_t stride;   // unused (kept 1)
+    WT_HD fsd_edge_t get(uint32_t i) const { return p[i]; }
+    WT_HD void set(uint32_t i, const fsd_edge_t& e) const { p[i] = e; }
 };
 
 WT_HD float fsd_alpha1(float x, float y) { return x == 0.f ? 0.f : kInvTwoPi * y / (x * (x * x + y * y)) * (cosf(x / 2.f) - sincf_(x / 2.f)); }

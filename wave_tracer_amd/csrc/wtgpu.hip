@@ -221,7 +221,27 @@ __global__ void __launch_bounds__(kBlock) k_connect(launch_args_t a) {
         stack_ref_t stack;
         lds_stack(lds, spill, stack);
         const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.fsd_counter, a.st.fsd_cap};
+#ifdef WTGPU_DEBUG_PRINT
+        if (i == 0)
+            printf("dbg k=%g recp=%g kd=%g el=(%u,%u) nT=%u nS=%u resp=%g %g %g spec0 type %d kmin %g kmax %g off %u cnt %u\n", ctx.k, ctx.recp_spectral_pd,
+                   ctx.k_density, ctx.element.x, ctx.element.y, nT, nS, spectrum_f(a.sc, a.sc.sensor.response_spec[0], ctx.k),
+                   spectrum_f(a.sc, a.sc.sensor.response_spec[1], ctx.k), spectrum_f(a.sc, a.sc.sensor.response_spec[2], ctx.k),
+                   a.sc.spectra[a.sc.sensor.response_spec[0]].type, a.sc.spectra[a.sc.sensor.response_spec[0]].kmin,
+                   a.sc.spectra[a.sc.sensor.response_spec[0]].kmax, a.sc.spectra[a.sc.sensor.response_spec[0]].offset,
+                   a.sc.spectra[a.sc.sensor.response_spec[0]].count);
+#endif
         bdpt_connect_all(a.sc, pool, a.film, svs, evs, (int)nT, (int)nS, ctx, a.seed, sample_id, stack, &ctr, nullptr);
+#ifdef WTGPU_DEBUG_PRINT
+        if (i == 0) {
+            connect_ret_t cr;
+            bdpt_connect(a.sc, pool, svs, evs, 0, 2, a.seed, sample_id, stack, cr, nullptr, nullptr);
+            vertex_t last;
+            svs.load(1, last);
+            printf("dbg2 L02=%g type %u emitter_of_shape %d beam scale %g rad0 %g k %g rr %g film.value[0]=%g weight[0]=%g ptrs %p %p %p\n", cr.L.s[0], last.type,
+                   last.emitter_of_shape, last.beam.scale, last.beam.rad[0], last.beam.k, last.rr_weight, a.film.value[0], a.film.weight[0], a.film.value,
+                   a.film.weight, a.film.light);
+        }
+#endif
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
@@ -375,7 +395,10 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     if (!s) return fail(WTGPU_ERR_INVALID, "null scene");
     if (s->uploaded) return fail(WTGPU_ERR_INVALID, "scene already uploaded");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(WTGPU_ERR_NO_DEVICE, "no HIP device present (there is no CPU fallback)");
+    const hipError_t dc = hipGetDeviceCount(&ndev);
+    if (dc != hipSuccess || ndev == 0)
+        return fail(WTGPU_ERR_NO_DEVICE, std::string("no HIP device present (there is no CPU fallback): hipGetDeviceCount -> ") + hipGetErrorString(dc) +
+                                             ", count " + std::to_string(ndev));
     if (device < 0 || device >= ndev) return fail(WTGPU_ERR_NO_DEVICE, "invalid device index");
     HIP_CHECK(hipSetDevice(device));
     s->device = device;
@@ -452,6 +475,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
     const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
     const uint64_t total = npix * (se - sb);
     launch_args_t a;
+    static_assert(sizeof(launch_args_t) <= 4096, "kernel argument too large");
     a.sc = s->dev;
     a.st = st;
     a.film = film_t{d_value, d_weight, d_light, h.sensor.width, h.sensor.height, h.sensor.channels};
@@ -470,6 +494,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
         HIP_CHECK(hipMemsetAsync(st.fsd_counter, 0, sizeof(uint32_t), stream));
         rec();
         hipLaunchKernelGGL(k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        HIP_CHECK(hipGetLastError());
         rec();
         // the first round's queue is the identity over both halves [0,nb) and [cap,cap+nb): materialise it only if nb<cap
         uint32_t n_active = 2 * nb;
@@ -490,8 +515,10 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
             const dim3 grid((n_active + kBlock - 1) / kBlock);
             rec();
             hipLaunchKernelGGL(k_trace, grid, dim3(kBlock), 0, stream, a, st.queue[cur], n_active, first ? 1 : 0);
+            HIP_CHECK(hipGetLastError());
             rec();
             hipLaunchKernelGGL(k_interact, grid, dim3(kBlock), 0, stream, a, st.queue[cur], n_active, first ? 1 : 0, st.queue[1 - cur], st.qcount + (1 - cur));
+            HIP_CHECK(hipGetLastError());
             rec();
             HIP_CHECK(hipMemcpyAsync(st.h_qcount, st.qcount + (1 - cur), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
