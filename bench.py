@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MI355X-native plt_bdpt hot path on BASELINE.json's headline workload.
+
+A *step* = one pass of the hot path over one batch of synthetic input = 1 sample per pixel of the cornell-box
+(stand-in) scene at 1440x1440, visible-spectrum wave mode (BDPT, max_depth 16, MIS, RR, Fraunhofer FSD): 2,073,600
+samples.  Inputs (flattened scene, BVH, LUTs) are resident in HBM before the timed region; film buffers are torch
+tensors on the GPU.  Multi-GPU: samples are sharded by sample index across ranks (weak scaling: every rank renders
+`steps` samples per pixel), no collective on the data path; one RCCL reduce of the film afterwards (outside the
+timed region it would be <2 ms; it is included in the timed region for honesty).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def cpu_baseline(scene_name, res, seconds_target=15.0):
+    """CPU checker (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload:
+    the same scene at reduced film resolution (Msamples/s of this path is resolution independent: every pixel does the
+    same work).  Only rank 0 at N=1 runs this."""
+    import numpy as np  # noqa: F401
+    from wave_tracer_amd.api import Scene
+    from oracle_util import oracle_render
+    cores = os.cpu_count() or 1
+    sc = Scene(scene_name, res=res, mesh_detail=1)
+    # calibrate
+    t = time.time()
+    oracle_render(sc, 0, 1, 123, threads=cores)
+    dt1 = max(1e-3, time.time() - t)
+    spp = max(1, min(64, int(seconds_target / dt1)))
+    t = time.time()
+    oracle_render(sc, 1, 1 + spp, 123, threads=cores)
+    dt = time.time() - t
+    n = sc.width * sc.height * spp
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{scene_name} res={res} spp={spp} ({n} samples, {dt:.1f}s) on all host cores; scalar fp32 restatement, baseline only"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell_box")
+    ap.add_argument("--res", type=int, default=1440)
+    ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-res", type=int, default=96)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.render import alloc_films
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    sc = Scene(args.scene, res=args.res, mesh_detail=1)
+    npix = sc.width * sc.height
+    sc.upload(local_rank, args.batch or npix)
+    value, weight, light = alloc_films(sc, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    K, Wm = args.steps, args.warmup
+    # weak scaling: every rank renders K (+W) samples per pixel on its own disjoint sample range
+    base = rank * (K + Wm)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for s in range(Wm):
+        sc.render_into(value, weight, light, base + s, base + s + 1, 1, stream)
+    sc.reset_counters()
+    for t in (value, weight, light):
+        t.zero_()
+    sync()
+    t0 = time.time()
+    tsum = {"generate_ms": 0.0, "trace_ms": 0.0, "trace_heavy_ms": 0.0, "interact_ms": 0.0, "connect_ms": 0.0, "rounds": 0, "trace_launches": 0}
+    for s in range(K):
+        sc.render_into(value, weight, light, base + Wm + s, base + Wm + s + 1, 1, stream)
+        tm = sc.timings()
+        for k in tsum:
+            tsum[k] += tm[k]
+    if distributed:
+        for t in (value, weight, light):
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+    sync()
+    dt = time.time() - t0
+    if distributed:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    counters = sc.counters()
+    if rank == 0:
+        samples_total = npix * K * world
+        msps = samples_total / dt / 1e6
+        # ---- roofline of the dominant kernel.  Algorithmic bytes per sample from SURVEY.md §8(d):
+        #   B = N_seg*2*S_path + N_vtx*S_vtx + N_conn*2*S_vtx + N_q*S_hit + B_film   with the measured per-sample counts.
+        ns = max(1, counters["samples"])
+        n_seg = counters["segments"] / ns
+        n_vtx = counters["vertices"] / ns
+        n_conn = counters["connections"] / ns
+        n_q = (counters["ray_queries"] + counters["cone_queries"] + counters["shadow_rays"]) / ns
+        n_light = counters["light_splats"] / ns
+        C = sc.channels
+        S_path = 200.0    # mean of backward (224 B) and forward (176 B) walk records
+        S_vtx, S_hit = 320.0, 32.0
+        b_film = 2 * (9 * C * 16) + n_light * 2 * (9 * C * 8)
+        bytes_per_sample = n_seg * 2 * S_path + n_vtx * S_vtx + n_conn * 2 * S_vtx + n_q * S_hit + b_film
+        kernels = {"k_trace": tsum["trace_ms"], "k_trace_heavy": tsum["trace_heavy_ms"], "k_interact": tsum["interact_ms"], "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
+        dom = max(kernels, key=kernels.get)
+        # bytes attributed to the dominant kernel per step (one step = npix samples)
+        share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
+                 "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
+        launches = {"k_trace": tsum["trace_launches"], "k_trace_heavy": tsum["trace_launches"], "k_interact": tsum["trace_launches"], "k_connect": K, "k_generate": K}[dom]
+        avg_ms = kernels[dom] / max(1, launches)
+        alg_bytes_per_launch = share * npix * K / max(1, launches)
+        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Msamples/sec (whole node), cornell-box 1440^2 wave-mode",
+            "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} stand-in (box.xml geometry, PLY meshes replaced by procedural stand-ins) res={args.res} "
+                                   f"plt_bdpt max_depth=16 MIS RR FSD, 1 spp per step", "samples_per_step": npix, "tris": int(sc.info.n_tris),
+                       "parallelism": f"sample-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "alg_bytes_per_launch": alg_bytes_per_launch,
+                         "alg_bytes_per_sample_all_kernels": bytes_per_sample,
+                         "kernel_ms_per_step": {k: v / K for k, v in kernels.items()}},
+            "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,
+                                    "cone_tri_overflow": counters["cone_tri_overflow"] / ns, "fsd_interactions": counters["fsd_interactions"] / ns,
+                                    "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_res)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,7 +99,8 @@ int wtgpu_get_counters(wtgpu_scene* scene, wtgpu_counters* out);
 int wtgpu_reset_counters(wtgpu_scene* scene);
 
 /* Average device time [ms] of each kernel of the last wtgpu_render call, measured with hipEvents on `stream`:
- * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact (sum), out[3]=connect, out[4]=number of rounds. */
+ * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact (sum), out[3]=connect, out[4]=number of rounds,
+ * out[5]=trace launches, out[6]=batches, out[7]=cooperative (heavy) trace (sum). */
 int wtgpu_last_render_timings(const wtgpu_scene* scene, float out[8]);
 
 /* Host-side film development (render_context_t::develop, src/scene/render.cpp:245-291):

@@ -31,8 +31,9 @@ constexpr uint32_t kMaxWalkIters = 96;   // must match kernels.hip (cap on trace
 struct sample_scratch_t {
     std::vector<uint32_t> svert, evert;   // vertex stores (stride 1)
     stack_entry_t stack[128];
-    uint32_t tris[kMaxConeTris];
+    std::vector<uint32_t> tris;   // unbounded in the reference (std::vector): 2^18 entries here
 };
+constexpr uint32_t kOracleConeTris = 1u << 18;
 
 void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
     unsigned long long* pa = reinterpret_cast<unsigned long long*>(&a);
@@ -43,7 +44,7 @@ void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
 void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream,
               sample_scratch_t& scr, bdpt_counters_t& ctr) {
     const stack_ref_t stack = make_flat_stack(scr.stack, 128);
-    const uint_list_t tris{scr.tris, 1, kMaxConeTris};
+    const uint_list_t tris{scr.tris.data(), 1, kOracleConeTris};
     for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
         const cone_t env = walk_trace_envelope(sc, w);
         const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
@@ -78,6 +79,7 @@ int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample
     // FSD aperture pool: per thread, reset per sample (apertures only live for one sample)
     auto worker = [&](int tid) {
         sample_scratch_t scr;
+        scr.tris.resize(kOracleConeTris);
         scr.svert.resize(kMaxVerts * kVertexWords);
         scr.evert.resize(kMaxVerts * kVertexWords);
         std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);

@@ -143,7 +143,7 @@ class Scene:
         t = (C.c_float * 8)()
         _check(load_library().wtgpu_last_render_timings(self._h, C.byref(t)))
         return {"generate_ms": t[0], "trace_ms": t[1], "interact_ms": t[2], "connect_ms": t[3], "rounds": int(t[4]),
-                "trace_launches": int(t[5]), "batches": int(t[6])}
+                "trace_launches": int(t[5]), "batches": int(t[6]), "trace_heavy_ms": t[7]}
 
     def close(self):
         if self._h:

@@ -243,24 +243,21 @@ mesh_t mesh_cylinder(dvec3 p0, dvec3 p1, double radius, int tess) {
     const dvec3 axis = dnorm(p1 - p0);
     const dvec3 ax = std::fabs(axis.x) > 0.9 ? dvec3{0, 1, 0} : dvec3{1, 0, 0};
     const dvec3 t = dnorm(dcross(ax, axis)), b = dcross(axis, t);
+    // src/mesh/cylinder.cpp: an open tube (no caps), two shared vertices per azimuth step
     mesh_t m;
+    const uint32_t verts = 2 * (uint32_t)tess;
     for (int i = 0; i < tess; ++i) {
-        const double a0 = 2 * M_PI * i / tess, a1 = 2 * M_PI * (i + 1) / tess;
-        const dvec3 n0 = t * std::cos(a0) + b * std::sin(a0), n1 = t * std::cos(a1) + b * std::sin(a1);
-        const uint32_t k = (uint32_t)m.verts.size();
-        m.verts.insert(m.verts.end(), {p0 + n0 * radius, p0 + n1 * radius, p1 + n1 * radius, p1 + n0 * radius});
-        m.normals.insert(m.normals.end(), {n0, n1, n1, n0});
-        m.uvs.insert(m.uvs.end(), {{(float)i / tess, 0}, {(float)(i + 1) / tess, 0}, {(float)(i + 1) / tess, 1}, {(float)i / tess, 1}});
-        m.tris.push_back({k, k + 1, k + 2});
-        m.tris.push_back({k + 2, k + 3, k});
-        // caps
-        const uint32_t c = (uint32_t)m.verts.size();
-        m.verts.insert(m.verts.end(), {p0, p0 + n1 * radius, p0 + n0 * radius, p1, p1 + n0 * radius, p1 + n1 * radius});
-        const dvec3 na = axis * -1.0;
-        m.normals.insert(m.normals.end(), {na, na, na, axis, axis, axis});
-        m.uvs.insert(m.uvs.end(), {{.5f, .5f}, {1, 0}, {0, 0}, {.5f, .5f}, {0, 1}, {1, 1}});
-        m.tris.push_back({c, c + 1, c + 2});
-        m.tris.push_back({c + 3, c + 4, c + 5});
+        const double a0 = 2 * M_PI * i / tess;
+        const dvec3 n0 = t * std::cos(a0) + b * std::sin(a0);
+        m.verts.push_back(p0 + n0 * radius);
+        m.verts.push_back(p1 + n0 * radius);
+        m.normals.push_back(n0);
+        m.normals.push_back(n0);
+        m.uvs.push_back({(float)i / tess, 0});
+        m.uvs.push_back({(float)i / tess, 1});
+        const uint32_t i0 = 2 * (uint32_t)i, i1 = i0 + 1, i2 = (i0 + 2) % verts, i3 = i2 + 1;
+        m.tris.push_back({i0, i2, i1});
+        m.tris.push_back({i1, i2, i3});
     }
     return m;
 }

@@ -22,7 +22,7 @@ namespace wt {
 
 constexpr uint32_t kMaxVerts = 18;       // max_depth(16) + 2
 constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
-constexpr uint32_t kMaxEdgeIds = 64;     // device cap of the de-duplicated edge set
+constexpr uint32_t kMaxEdgeIds = 96;     // cap of the de-duplicated edge set of one interaction region
 
 enum vertex_type_e : uint32_t { VT_SENSOR = 0, VT_EMITTER = 1, VT_SURFACE = 2, VT_MEDIUM = 3, VT_FSD = 4 };
 enum geo_kind_e : uint32_t { GEO_NONE = 0, GEO_POINT = 1, GEO_SURFACE = 2 };
@@ -396,7 +396,8 @@ WT_HD bool walk_continue(const scene_t& sc, walk_t& w, const vertex_store_t& vs,
 // Returns TRUE if the walk continues (another segment must be traced).
 template <class TriList>
 WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr, const TriList& tris, const vertex_store_t& vs,
-                          const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream, bdpt_counters_t* ctr) {
+                          const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream, bdpt_counters_t* ctr,
+                          const stack_ref_t* primary_query_stack = nullptr) {
     if (tr.empty) return false;   // no intersection (TODO in the reference: infinite emitters)
     sampler_t smp = make_sampler(seed, sample_id, stream, w.rng_draws);
     beam_t& beam = w.beam;
@@ -420,7 +421,25 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         phit.bx = tr.bx;
         phit.by = tr.by;
     } else {
-        // find_closest_triangle (plt_bdpt_detail.hpp:362-419)
+        // find_closest_triangle (plt_bdpt_detail.hpp:362-419).
+        // Device variant (primary_query_stack != nullptr): the cone query's triangle list is bounded on the device
+        // (kMaxConeTris) while the reference's is an unbounded std::vector; the triangle under the beam axis is therefore
+        // found with a BVH *ray* query over the same z-slab instead of scanning the list.  Whenever the list is complete both
+        // select the same triangle (closest axis hit inside the slab); the CPU checker keeps the reference's list scan.
+        if (primary_query_stack) {
+            const float wtol = cone_intersection_tolerance(origin_wp, sc.world_min, sc.world_max, sc.world_max);
+            ray_hit_t rh;
+            if (ads_intersect_ray(sc, origin_wp, beam.env.d, grow(izr, wtol), *primary_query_stack, rh)) {
+                const tri_geo_t g = sc.tri_geo[rh.tuid];
+                const float fptol = cone_intersection_tolerance(origin_wp, g.a, g.b, g.c);
+                if (contains(grow(izr, fptol), rh.dist)) {
+                    primary = rh.tuid;
+                    phit.dist = rh.dist;
+                    phit.bx = rh.bx;
+                    phit.by = rh.by;
+                }
+            }
+        } else
         for (uint32_t i = 0; i < tr.ntris; ++i) {
             const uint32_t tuid = tris[i];
             const tri_geo_t g = sc.tri_geo[tuid];

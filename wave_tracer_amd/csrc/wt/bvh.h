@@ -174,6 +174,7 @@ struct cone_hit_t {
     uint32_t front_face;
     uint32_t ntris;      // triangles written to the list
     uint32_t overflow;   // triangles dropped because the list was full
+    uint32_t aborted;    // work budget exceeded
 };
 
 // intersection_record_work_t::search_range (traversal_common.hpp:76-83)
@@ -185,12 +186,16 @@ WT_HD range_t cone_search_range(const cone_t& cone, const range_t& searchrange, 
 }
 
 // Cone traversal (bvh8w.cpp:232-318): closest distance + every triangle hit inside the (shrinking) z-slab.
+// `budget`: maximum number of cone-triangle tests; when exceeded the query stops and rec.aborted is set (the device
+// hands such heavy queries to the wavefront-cooperative traversal, wtgpu.hip: coop_cone).
 WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack,
-                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr) {
+                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr, uint32_t budget = 0xFFFFFFFFu) {
     rec.dist = WT_INF;
     rec.front_face = 0;
     rec.ntris = 0;
     rec.overflow = 0;
+    rec.aborted = 0;
+    uint32_t tests = 0;
     if (sc.n_nodes == 0) return false;
     const vec3 ro = cone.o, rd = cone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
@@ -207,6 +212,11 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
             if (ctr) ctr->leaves++;
             bool found = false;
+            tests += leaf.count;
+            if (tests > budget) {
+                rec.aborted = 1;
+                return false;
+            }
             for (uint32_t t = 0; t < leaf.count; ++t) {
                 const uint32_t tuid = leaf.tris_ptr + t;
                 const tri_geo_t tri = sc.tri_geo[tuid];
@@ -298,12 +308,14 @@ struct trav_result_t {
     uint32_t overflow;
     // statistics
     uint32_t n_ray_queries, n_cone_queries;
+    uint32_t aborted;   // device: the per-lane work budget was exceeded, redo cooperatively
 };
 
 // integrator::traverse (traversal.hpp:94-172). `envelope` already has its origin offset for self-intersection.
 WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
-                             const stack_ref_t& stack, const uint_list_t& tris, bvh_counters_t* ctr = nullptr) {
+                             const stack_ref_t& stack, const uint_list_t& tris, bvh_counters_t* ctr = nullptr, uint32_t cone_budget = 0xFFFFFFFFu) {
     trav_result_t r;
+    r.aborted = 0;
     r.origin = envelope.o;
     r.empty = 1;
     r.ballistic = 1;
@@ -354,7 +366,11 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;
-        bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr);
+        bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr, cone_budget);
+        if (ch.aborted) {
+            r.aborted = 1;
+            return r;
+        }
         const bool df_empty = ch.ntris == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;

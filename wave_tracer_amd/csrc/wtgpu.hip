@@ -23,6 +23,7 @@
 #include "../../include/wtgpu.h"
 #include "host/scene_builder.h"
 #include "wt/bdpt.h"
+#include "wt/coop.h"
 
 using namespace wt;
 
@@ -31,6 +32,7 @@ namespace {
 constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
 constexpr int kBlock = 128;
 constexpr int kLdsStack = 20;            // LDS-resident stack entries per lane
+constexpr uint32_t kConeBudget = 96;     // cone-triangle tests one lane may spend on a query before it is handed to a wavefront
 constexpr int kSpillStack = 44;          // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 thread_local std::string g_err;
@@ -54,6 +56,8 @@ struct device_state_t {
     uint32_t* tris = nullptr;     // [kMaxConeTris][2cap]
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* qcount = nullptr;   // [2] device
+    uint32_t* heavy_queue = nullptr;   // walks whose traversal exceeded the per-lane budget
+    uint32_t* heavy_count = nullptr;   // [0] = number queued, [1] = dequeue head
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
     uint32_t* fsd_counter = nullptr;
@@ -162,18 +166,59 @@ __global__ void __launch_bounds__(kBlock) k_trace(launch_args_t a, const uint32_
         const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
         const cone_t env = walk_trace_envelope(a.sc, wk);
         const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-        const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris);
-        soa_store(a.st.trav, W2, w, tr);
-        ctr.segments = 1;
-        ctr.ray_queries = tr.n_ray_queries;
-        ctr.cone_queries = tr.n_cone_queries;
-        ctr.cone_tri_overflow = tr.overflow;
+        const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris, nullptr, kConeBudget);
+        if (tr.aborted) {
+            a.st.heavy_queue[atomicAdd(a.st.heavy_count, 1u)] = w;
+        } else {
+            soa_store(a.st.trav, W2, w, tr);
+            ctr.segments = 1;
+            ctr.ray_queries = tr.n_ray_queries;
+            ctr.cone_queries = tr.n_cone_queries;
+            ctr.cone_tri_overflow = tr.overflow;
+        }
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
+// Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
+__global__ void __launch_bounds__(64) k_trace_heavy(launch_args_t a) {
+    __shared__ coop_shared_t sh;
+    __shared__ stack_entry_t lds[kLdsStack * 64];
+    __shared__ uint32_t s_item;
+    const uint32_t n = a.st.heavy_count[0];
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(a.st.heavy_count + 1, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.heavy_queue[item];
+        const size_t W2 = 2 * (size_t)a.st.cap;
+        walk_t wk;
+        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
+        stack_entry_t spill[kSpillStack];
+        stack_ref_t stack;
+        lds_stack(lds, spill, stack);
+        const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+        const cone_t env = walk_trace_envelope(a.sc, wk);
+        const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
+        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, sh, tris);
+        if (threadIdx.x == 0) {
+            soa_store(a.st.trav, W2, w, tr);
+            ctr.segments += 1;
+            ctr.ray_queries += tr.n_ray_queries;
+            ctr.cone_queries += tr.n_cone_queries;
+            ctr.cone_tri_overflow += tr.overflow;
+        }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
 __global__ void __launch_bounds__(kBlock) k_interact(launch_args_t a, const uint32_t* queue, uint32_t n, int first_round, uint32_t* next_queue,
                                                      uint32_t* next_count) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
     const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
@@ -193,7 +238,10 @@ __global__ void __launch_bounds__(kBlock) k_interact(launch_args_t a, const uint
         const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
         const vertex_store_t vs{a.st.verts, W2, w};
         const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.fsd_counter, a.st.fsd_cap};
-        const bool cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr);
+        stack_entry_t spill[kSpillStack];
+        stack_ref_t stack;
+        lds_stack(lds, spill, stack);
+        const bool cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack);
         wk.active = cont ? 1u : 0u;
         soa_store(a.st.walks, W2, w, wk);
         if (cont) next_queue[atomicAdd(next_count, 1u)] = w;
@@ -452,6 +500,8 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     if ((rc = dmalloc(s, &st.queue[0], W2))) return rc;
     if ((rc = dmalloc(s, &st.queue[1], W2))) return rc;
     if ((rc = dmalloc(s, &st.qcount, 2))) return rc;
+    if ((rc = dmalloc(s, &st.heavy_queue, W2))) return rc;
+    if ((rc = dmalloc(s, &st.heavy_count, 2))) return rc;
     st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
     if ((rc = dmalloc(s, &st.fsd_hdr, st.fsd_cap))) return rc;
     if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_cap * kFsdMaxEdges))) return rc;
@@ -459,7 +509,7 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     if ((rc = dmalloc(s, &st.counters, kNumCounters + 2))) return rc;
     HIP_CHECK(hipMemset(st.counters, 0, (kNumCounters + 2) * sizeof(unsigned long long)));
     HIP_CHECK(hipHostMalloc((void**)&st.h_qcount, 2 * sizeof(uint32_t), hipHostMallocDefault));
-    s->events.resize(2 * (2 * kMaxWalkIters + 4));
+    s->events.resize(4 * kMaxWalkIters + 8);
     for (auto& e : s->events) HIP_CHECK(hipEventCreate(&e));
     s->uploaded = true;
     return WTGPU_OK;
@@ -483,7 +533,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
     a.npix = (uint32_t)npix;
     a.sample_begin = sb;
     a.count_stats = 1;
-    float t_gen = 0, t_trace = 0, t_inter = 0, t_conn = 0;
+    float t_gen = 0, t_trace = 0, t_inter = 0, t_conn = 0, t_heavy = 0;
     uint32_t rounds_total = 0, n_trace_launches = 0;
     for (uint64_t j0 = 0; j0 < total; j0 += st.cap) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(st.cap, total - j0);
@@ -512,10 +562,17 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
         uint32_t round = 0;
         for (; round < kMaxWalkIters && n_active > 0; ++round) {
             HIP_CHECK(hipMemsetAsync(st.qcount + (1 - cur), 0, sizeof(uint32_t), stream));
+            HIP_CHECK(hipMemsetAsync(st.heavy_count, 0, 2 * sizeof(uint32_t), stream));
             const dim3 grid((n_active + kBlock - 1) / kBlock);
             rec();
             hipLaunchKernelGGL(k_trace, grid, dim3(kBlock), 0, stream, a, st.queue[cur], n_active, first ? 1 : 0);
             HIP_CHECK(hipGetLastError());
+            rec();
+            {
+                const uint32_t hb = std::min<uint32_t>(n_active, 256u * 16u);
+                hipLaunchKernelGGL(k_trace_heavy, dim3(hb), dim3(64), 0, stream, a);
+                HIP_CHECK(hipGetLastError());
+            }
             rec();
             hipLaunchKernelGGL(k_interact, grid, dim3(kBlock), 0, stream, a, st.queue[cur], n_active, first ? 1 : 0, st.queue[1 - cur], st.qcount + (1 - cur));
             HIP_CHECK(hipGetLastError());
@@ -541,8 +598,10 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
             hipEventElapsedTime(&ms, s->events[e], s->events[e + 1]);
             t_trace += ms;
             hipEventElapsedTime(&ms, s->events[e + 1], s->events[e + 2]);
+            t_heavy += ms;
+            hipEventElapsedTime(&ms, s->events[e + 2], s->events[e + 3]);
             t_inter += ms;
-            e += 3;
+            e += 4;
             ++n_trace_launches;
         }
         hipEventElapsedTime(&ms, s->events[e], s->events[e + 1]);
@@ -561,6 +620,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
     s->timings[4] = (float)rounds_total;
     s->timings[5] = (float)n_trace_launches;
     s->timings[6] = (float)((total + st.cap - 1) / st.cap);
+    s->timings[7] = t_heavy;
     return WTGPU_OK;
 }
 
