@@ -238,6 +238,9 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             }
             if (found) {
                 range = cone_search_range(cone, searchrange, rec.dist, z_scale);
+                // Bounded-list regime (device only; the CPU checker's list never saturates): once the triangle list is full
+                // nothing further can be recorded, so only triangles that can still lower the closest distance matter.
+                if (rec.overflow > 0) range.max = fminf_(range.max, rec.dist);
                 while (s > 0 && stack[s - 1].t >= range.max) --s;
             }
             continue;

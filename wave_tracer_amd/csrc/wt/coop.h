@@ -133,6 +133,7 @@ __device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const ra
                     rec.overflow += total - newn;
                     rec.ntris = newn;
                     range = cone_search_range(cone, searchrange, rec.dist, z_scale);
+                    if (rec.overflow > 0) range.max = fminf_(range.max, rec.dist);   // bounded-list regime, see bvh.h
                 }
             }
         } else {
