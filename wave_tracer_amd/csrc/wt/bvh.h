@@ -283,6 +283,65 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
     return rec.ntris > 0;
 }
 
+// Any-hit cone probe: TRUE if some triangle intersects the cone inside `range` (first hit terminates).
+// Used by the device's traverse(): a diffusive attempt is rejected whenever the closest cone hit lies within
+// [dist, dist + major_axis/2) (traversal.hpp:146,157), i.e. exactly when this probe over that thin slab succeeds;
+// probing first avoids the full (closest + triangle list) query whose result the reference computes and discards.
+WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t& range, const stack_ref_t& stack, uint32_t budget, bool& aborted) {
+    aborted = false;
+    if (sc.n_nodes == 0) return false;
+    const vec3 ro = cone.o, rd = cone.d;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    const float ta = cone.tan_alpha, ix = cone.x0;
+    uint32_t tests = 0;
+    int s = 1;
+    stack[0] = stack_entry_t{0.f, 1};
+    while (s > 0) {
+        const stack_entry_t top = stack[s - 1];
+        --s;
+        if (top.ptr < 0) {
+            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            tests += leaf.count;
+            if (tests > budget) {
+                aborted = true;
+                return false;
+            }
+            for (uint32_t t = 0; t < leaf.count; ++t) {
+                const tri_geo_t tri = sc.tri_geo[leaf.tris_ptr + t];
+                cone_tri_hit_t h;
+                if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max)) return true;
+            }
+            continue;
+        }
+        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        const int begin = s;
+        for (int i = 0; i < 8; ++i) {
+            const int32_t cp = n.child[i];
+            if (cp == 0) continue;
+            float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
+            float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+            const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
+            const float maxz = clampf(rd.x * bx + rd.y * by + rd.z * bz, 0.f, range.max);
+            const float enlr = fmaf(maxz, ta, ix);
+            ominx -= enlr; ominy -= enlr; ominz -= enlr;
+            omaxx += enlr; omaxy += enlr; omaxz += enlr;
+            const float dminx = (sx ? omaxx : ominx) * rinvd.x, dmaxx = (sx ? ominx : omaxx) * rinvd.x;
+            const float dminy = (sy ? omaxy : ominy) * rinvd.y, dmaxy = (sy ? ominy : omaxy) * rinvd.y;
+            const float dminz = (sz ? omaxz : ominz) * rinvd.z, dmaxz = (sz ? ominz : omaxz) * rinvd.z;
+            float tmin = 0.f, tmax = dmaxx;
+            tmin = fmaxf_(tmin, dminx);
+            tmax = fminf_(tmax, dmaxy);
+            tmin = fmaxf_(tmin, dminy);
+            tmax = fminf_(tmax, dmaxz);
+            tmin = fmaxf_(tmin, dminz);
+            if (tmin <= tmax && tmax >= range.min && tmin <= range.max && s < (int)stack.cap) stack[s++] = stack_entry_t{tmin, cp};
+        }
+        stack_sort_desc(stack, begin, s);
+    }
+    return false;
+}
+
 // ---- traversal policy (include/wt/integrator/traversal.hpp) -------------------------------------
 constexpr float kBallisticScale = 1.001f;      // traversal.hpp:26
 
@@ -316,7 +375,8 @@ struct trav_result_t {
 
 // integrator::traverse (traversal.hpp:94-172). `envelope` already has its origin offset for self-intersection.
 WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
-                             const stack_ref_t& stack, const uint_list_t& tris, bvh_counters_t* ctr = nullptr, uint32_t cone_budget = 0xFFFFFFFFu) {
+                             const stack_ref_t& stack, const uint_list_t& tris, bvh_counters_t* ctr = nullptr, uint32_t cone_budget = 0xFFFFFFFFu,
+                             bool probe_first = false) {
     trav_result_t r;
     r.aborted = 0;
     r.origin = envelope.o;
@@ -369,6 +429,15 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;
+        if (probe_first) {
+            bool ab;
+            const bool near_hit = bvh_cone_any_hit(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, stack, cone_budget, ab);
+            if (ab) {
+                r.aborted = 1;
+                return r;
+            }
+            if (near_hit) continue;   // closest hit would be < dist + min_df_prog: too short, continue the ballistic path
+        }
         bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr, cone_budget);
         if (ch.aborted) {
             r.aborted = 1;

@@ -161,6 +161,71 @@ __device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const ra
     }
 }
 
+// Wave-cooperative any-hit probe (see bvh_cone_any_hit).
+__device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh) {
+    const int lane = threadIdx.x & 63;
+    if (sc.n_nodes == 0) return false;
+    const vec3 ro = cone.o, rd = cone.d;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    const float ta = cone.tan_alpha, ix = cone.x0;
+    int s = 1;
+    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
+    __syncthreads();
+    bool found = false;
+    while (s > 0 && !found) {
+        const stack_entry_t top = sh.stack[s - 1];
+        --s;
+        __syncthreads();
+        uint32_t t0 = 0, cnt = 0;
+        bool brute = false;
+        const bvh8_node_t* node = nullptr;
+        if (top.ptr < 0) {
+            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            t0 = leaf.tris_ptr;
+            cnt = leaf.count;
+            brute = true;
+        } else {
+            node = &sc.nodes[top.ptr - 1];
+            if (node->tris_count <= kCoopLeafTris) {
+                t0 = node->tris_start;
+                cnt = node->tris_count;
+                brute = true;
+            }
+        }
+        if (brute) {
+            bool hit = false;
+            if ((uint32_t)lane < cnt) {
+                const tri_geo_t tri = sc.tri_geo[t0 + lane];
+                cone_tri_hit_t h;
+                hit = intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max);
+            }
+            if (__ballot(hit)) found = true;
+        } else {
+            bool h = false;
+            float tmin = 0.f;
+            int32_t cp = 0;
+            if (lane < 8) {
+                cp = node->child[lane];
+                if (cp != 0) h = cone_child_test(*node, lane, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
+            }
+            const unsigned mask = (unsigned)(__ballot(h) & 0xffull);
+            const int n = __popc(mask);
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float tj = __shfl(tmin, j, 64);
+                const bool hj = (mask >> j) & 1u;
+                if (hj && (tj > tmin || (tj == tmin && j < lane))) ++rank;
+            }
+            if (h && s + rank < kCoopStack) sh.stack[s + rank] = stack_entry_t{tmin, cp};
+            s = (s + n < kCoopStack) ? s + n : kCoopStack;
+        }
+        __syncthreads();
+    }
+    return found;
+}
+
 // integrator::traverse (traversal.hpp:94-172), wave-uniform.  `stack` is a per-lane stack for the (redundant) ray queries.
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
                                               const stack_ref_t& stack, coop_shared_t& sh, const uint_list_t& tris) {
@@ -211,6 +276,7 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;
+        if (coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh)) continue;   // too short (see bvh_cone_any_hit)
         coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch);
         const bool df_empty = ch.ntris == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {

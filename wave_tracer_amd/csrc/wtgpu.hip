@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -64,6 +66,7 @@ struct device_state_t {
     uint32_t fsd_cap = 0;
     unsigned long long* counters = nullptr;   // bdpt_counters_t + 2
     uint32_t* h_qcount = nullptr;             // pinned
+    uint32_t* dbg = nullptr;                  // debug records (WTGPU_DEBUG_HEAVY builds)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
 constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
@@ -101,6 +104,7 @@ struct launch_args_t {
     uint32_t npix;
     uint64_t sample_begin;
     uint32_t count_stats;
+    uint32_t cone_budget;
 };
 
 __device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s) {
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(launch_args_t a, const uint32_
         const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
         const cone_t env = walk_trace_envelope(a.sc, wk);
         const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-        const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris, nullptr, kConeBudget);
+        const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
         if (tr.aborted) {
             a.st.heavy_queue[atomicAdd(a.st.heavy_count, 1u)] = w;
         } else {
@@ -204,7 +208,27 @@ __global__ void __launch_bounds__(64) k_trace_heavy(launch_args_t a) {
         const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
         const cone_t env = walk_trace_envelope(a.sc, wk);
         const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
+#ifdef WTGPU_DEBUG_HEAVY
+        const long long t0 = wall_clock64();
+#endif
         const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, sh, tris);
+#ifdef WTGPU_DEBUG_HEAVY
+        const long long dt = wall_clock64() - t0;   // 100 MHz ticks
+        if (threadIdx.x == 0 && a.st.dbg) {
+            const uint32_t k = atomicAdd(a.st.dbg, 1u);
+            if (k < (1u << 20)) {
+                uint32_t* r = a.st.dbg + 4 + 8 * (size_t)k;
+                r[0] = w;
+                r[1] = (uint32_t)dt;
+                r[2] = tr.n_ray_queries | (tr.n_cone_queries << 8) | (tr.empty << 16) | (tr.ballistic << 17);
+                r[3] = tr.ntris + tr.overflow;
+                r[4] = __float_as_uint(env.x0);
+                r[5] = __float_as_uint(tr.dist);
+                r[6] = __float_as_uint(env.d.z);
+                r[7] = __float_as_uint(env.o.z);
+            }
+        }
+#endif
         if (threadIdx.x == 0) {
             soa_store(a.st.trav, W2, w, tr);
             ctr.segments += 1;
@@ -508,6 +532,10 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     if ((rc = dmalloc(s, &st.fsd_counter, 1))) return rc;
     if ((rc = dmalloc(s, &st.counters, kNumCounters + 2))) return rc;
     HIP_CHECK(hipMemset(st.counters, 0, (kNumCounters + 2) * sizeof(unsigned long long)));
+#ifdef WTGPU_DEBUG_HEAVY
+    if ((rc = dmalloc(s, &st.dbg, 4 + 8 * (size_t)(1u << 20)))) return rc;
+    HIP_CHECK(hipMemset(st.dbg, 0, 16));
+#endif
     HIP_CHECK(hipHostMalloc((void**)&st.h_qcount, 2 * sizeof(uint32_t), hipHostMallocDefault));
     s->events.resize(4 * kMaxWalkIters + 8);
     for (auto& e : s->events) HIP_CHECK(hipEventCreate(&e));
@@ -533,6 +561,9 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
     a.npix = (uint32_t)npix;
     a.sample_begin = sb;
     a.count_stats = 1;
+    a.cone_budget = kConeBudget;
+    if (const char* e = getenv("WTGPU_CONE_BUDGET")) a.cone_budget = (uint32_t)atoi(e);
+    if (const char* e = getenv("WTGPU_COUNT_STATS")) a.count_stats = (uint32_t)atoi(e);
     float t_gen = 0, t_trace = 0, t_inter = 0, t_conn = 0, t_heavy = 0;
     uint32_t rounds_total = 0, n_trace_launches = 0;
     for (uint64_t j0 = 0; j0 < total; j0 += st.cap) {
@@ -612,6 +643,28 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
         HIP_CHECK(hipMemcpy(&used, st.fsd_counter, 4, hipMemcpyDeviceToHost));
         (void)used;
     }
+#ifdef WTGPU_DEBUG_HEAVY
+    {
+        std::vector<uint32_t> d(4 + 8 * (size_t)(1u << 20));
+        HIP_CHECK(hipMemcpy(d.data(), st.dbg, d.size() * 4, hipMemcpyDeviceToHost));
+        const uint32_t n = std::min<uint32_t>(d[0], 1u << 20);
+        std::vector<uint32_t> idx(n);
+        for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return d[4 + 8 * x + 1] > d[4 + 8 * y + 1]; });
+        double tot = 0;
+        for (uint32_t i = 0; i < n; ++i) tot += d[4 + 8 * i + 1];
+        fprintf(stderr, "heavy items %u, total ticks %.3g (= %.1f wave-ms)\n", d[0], tot, tot / 1e5);
+        for (uint32_t q : {0u, n / 1000, n / 100, n / 10, n / 2}) if (q < n) fprintf(stderr, "  rank %u ticks %u\n", q, d[4 + 8 * idx[q] + 1]);
+        for (uint32_t i = 0; i < std::min<uint32_t>(n, 25); ++i) {
+            const uint32_t* r = &d[4 + 8 * idx[i]];
+            float x0, dist, dz, oz;
+            memcpy(&x0, r + 4, 4); memcpy(&dist, r + 5, 4); memcpy(&dz, r + 6, 4); memcpy(&oz, r + 7, 4);
+            fprintf(stderr, "  w=%u ms=%.2f nray=%u ncone=%u empty=%u ball=%u hits=%u x0=%g dist=%g dz=%g oz=%g\n", r[0], r[1] / 1e5, r[2] & 255, (r[2] >> 8) & 255,
+                    (r[2] >> 16) & 1, (r[2] >> 17) & 1, r[3], x0, dist, dz, oz);
+        }
+        HIP_CHECK(hipMemset(st.dbg, 0, 16));
+    }
+#endif
     s->samples_rendered += total;
     s->timings[0] = t_gen;
     s->timings[1] = t_trace;
