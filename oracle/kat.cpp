@@ -1,0 +1,153 @@
+// oracle/kat.cpp — C entry points exposing the restated physics primitives to the known-answer tests
+// (tests/test_kat.py).                                                           *** TEST INFRASTRUCTURE ***
+// Each wrapper just forwards to the function in wave_tracer_amd/csrc/wt/*.h that restates the cited reference code,
+// so that numpy / scipy / brute-force references can pin it.
+#include <cstring>
+
+#include "../wave_tracer_amd/csrc/wt/bdpt.h"
+
+using namespace wt;
+
+extern "C" {
+
+// K4: 2x2 SVD (math/linalg.hpp). A given column-major (a00,a01,a10,a11) glm style; out: Ucos,Usin,Vcos,Vsin,s1,s2
+void kat_svd2(const float* A, float* out) {
+    const svd_t s = svd2(mat2{A[0], A[1], A[2], A[3]});
+    out[0] = s.Ucos; out[1] = s.Usin; out[2] = s.Vcos; out[3] = s.Vsin; out[4] = s.sigma1; out[5] = s.sigma2;
+}
+// K2: Fresnel (interaction/fresnel.hpp).  out: rs,rp,ts,tp,Ts,Tp,Z,tx,ty,tz
+void kat_fresnel(float eta, const float* w, float* out) {
+    const fresnel_t f = fresnel(cplx{eta, 0.f}, vec3{w[0], w[1], w[2]}, vec3{0, 0, 1});
+    out[0] = f.rs.re; out[1] = f.rp.re; out[2] = f.ts.re; out[3] = f.tp.re; out[4] = f.Ts; out[5] = f.Tp; out[6] = f.Z;
+    out[7] = f.t.x; out[8] = f.t.y; out[9] = f.t.z;
+}
+void kat_fresnel_conductor(float eta_re, float eta_im, float cos_i, float* out) {
+    const float s = sqrtf(fmaxf_(0.f, 1.f - cos_i * cos_i));
+    const fresnel_conductor_t f = fresnel_reflection(cplx{eta_re, eta_im}, vec3{s, 0, cos_i}, vec3{0, 0, 1});
+    out[0] = f.rs.re; out[1] = f.rs.im; out[2] = f.rp.re; out[3] = f.rp.im;
+}
+// K3: Mueller algebra
+void kat_mueller_fresnel(float fs_re, float fs_im, float fp_re, float fp_im, float* out16) {
+    const mueller_t M = mueller_fresnel(cplx{fs_re, fs_im}, cplx{fp_re, fp_im});
+    std::memcpy(out16, M.m, sizeof(M.m));
+}
+void kat_mueller_rotation(float ax, float ay, float bx, float by, float* out16) {
+    const mueller_t M = mueller_rotation(vec2{ax, ay}, vec2{bx, by});
+    std::memcpy(out16, M.m, sizeof(M.m));
+}
+void kat_stokes_reorient(const float* S, const float* f0, const float* f1, float* out4) {
+    const frame_t a{{f0[0], f0[1], f0[2]}, {f0[3], f0[4], f0[5]}, {f0[6], f0[7], f0[8]}}, b{{f1[0], f1[1], f1[2]}, {f1[3], f1[4], f1[5]}, {f1[6], f1[7], f1[8]}};
+    const stokes_t r = stokes_reorient(stokes_t{{S[0], S[1], S[2], S[3]}}, a, b);
+    std::memcpy(out4, r.s, sizeof(r.s));
+}
+void kat_build_orthogonal_frame(const float* n, float* out9) {
+    const frame_t f = build_orthogonal_frame(vec3{n[0], n[1], n[2]});
+    const float v[9] = {f.t.x, f.t.y, f.t.z, f.b.x, f.b.y, f.b.z, f.n.x, f.n.y, f.n.z};
+    std::memcpy(out9, v, sizeof(v));
+}
+// K5: cone primitives.  cone: o(3) d(3) tan_alpha x0 ecc ; returns hit flag, dist in out[0]
+int kat_cone_tri(const float* c, const float* tri, float rmin, float rmax, float* out) {
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    const vec3 a{tri[0], tri[1], tri[2]}, b{tri[3], tri[4], tri[5]}, cc{tri[6], tri[7], tri[8]};
+    const vec3 n = normalize(cross(b - a, cc - a));
+    cone_tri_hit_t h;
+    const bool hit = intersect_cone_tri(cone, a, b, cc, n, range_t{rmin, rmax}, h);
+    out[0] = hit ? h.dist : -1.f;
+    return hit;
+}
+int kat_cone_contains(const float* c, const float* p) {
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    return cone_contains_local(cone, to_local(cone_frame(cone), vec3{p[0], p[1], p[2]} - cone.o), range_positive());
+}
+void kat_cone_local(const float* c, const float* p, float* out3) {
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    const vec3 l = to_local(cone_frame(cone), vec3{p[0], p[1], p[2]} - cone.o);
+    out3[0] = l.x; out3[1] = l.y; out3[2] = l.z;
+}
+int kat_ray_tri(const float* o, const float* d, const float* tri, float* out3) {
+    ray_tri_hit_t h;
+    const bool hit = intersect_ray_tri(vec3{o[0], o[1], o[2]}, vec3{d[0], d[1], d[2]}, vec3{tri[0], tri[1], tri[2]}, vec3{tri[3], tri[4], tri[5]},
+                                       vec3{tri[6], tri[7], tri[8]}, range_positive(), h);
+    out3[0] = h.dist; out3[1] = h.bx; out3[2] = h.by;
+    return hit;
+}
+// K6: minimum-uncertainty relations (beam_geometry.hpp)
+float kat_mub_tan_alpha(float len_m, float k) { return mub_tan_alpha_from_length(len_m, k); }
+float kat_mub_length(float tan_alpha, float k) { return mub_spatial_length_from_tan_alpha(tan_alpha, k); }
+// gaussian over triangle (gauss.h)
+float kat_gauss_triangle(const float* t) { return gauss_integrate_triangle_canonical(vec2{t[0], t[1]}, vec2{t[2], t[3]}, vec2{t[4], t[5]}); }
+// K7: fractal profile (surface_profile/fractal.hpp)
+float kat_fractal_psd(float roughness, float gamma, float k, const float* wi, const float* wo) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM; m.profile = PROFILE_FRACTAL; m.roughness = roughness; m.gamma = gamma;
+    return profile_psd(m, vec3{wi[0], wi[1], wi[2]}, vec3{wo[0], wo[1], wo[2]}, k);
+}
+float kat_fractal_pdf(float roughness, float gamma, float k, const float* wi, const float* wo) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM; m.profile = PROFILE_FRACTAL; m.roughness = roughness; m.gamma = gamma;
+    return profile_pdf(m, vec3{wi[0], wi[1], wi[2]}, vec3{wo[0], wo[1], wo[2]}, k);
+}
+float kat_fractal_alpha(float roughness, float gamma, float k, const float* wi, const float* wo) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM; m.profile = PROFILE_FRACTAL; m.roughness = roughness; m.gamma = gamma;
+    return profile_alpha(m, vec3{wi[0], wi[1], wi[2]}, vec3{wo[0], wo[1], wo[2]}, k);
+}
+void kat_fractal_sample(float roughness, float gamma, float k, const float* wi, uint64_t seed, uint32_t n, float* out /* n x {wo3,pdf,psd} */) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM; m.profile = PROFILE_FRACTAL; m.roughness = roughness; m.gamma = gamma;
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 0);
+        const profile_sample_t p = profile_sample(m, vec3{wi[0], wi[1], wi[2]}, k, s);
+        out[5 * i] = p.wo.x; out[5 * i + 1] = p.wo.y; out[5 * i + 2] = p.wo.z; out[5 * i + 3] = p.pdf; out[5 * i + 4] = p.psd;
+    }
+}
+// K8: Fraunhofer FSD kernel functions
+float kat_fsd_alpha1(float x, float y) { return fsd_alpha1(x, y); }
+float kat_fsd_alpha2(float x, float y) { return fsd_alpha2(x, y); }
+float kat_fsd_chi_e(float x, float y) { return fsd_chi_e(vec2{x, y}); }
+// K9: film reconstruction weights
+void kat_film_weights(float sigma, int radius, float ox, float oy, float* out /* wx[5], wy[5], recp_total */) {
+    sensor_t s{};
+    s.rfilter_sigma = sigma;
+    s.rf_radius = radius;
+    const rfilter_weights_t w = film_rfilter_weights(s, vec2{ox, oy});
+    std::memcpy(out, w.wx, 5 * sizeof(float));
+    std::memcpy(out + 5, w.wy, 5 * sizeof(float));
+    out[10] = w.recp_total;
+}
+// RNG
+void kat_philox(uint64_t seed, uint64_t sample_id, uint32_t stream, uint32_t n, float* out) {
+    sampler_t s = make_sampler(seed, sample_id, stream);
+    for (uint32_t i = 0; i < n; ++i) out[i] = sampler_r(s);
+}
+void kat_philox_raw(const uint32_t* ctr, const uint32_t* key, uint32_t* out) { philox4x32_10(ctr, key, out); }
+void kat_cosine_hemisphere(float u0, float u1, float* out3) {
+    const vec3 d = cosine_hemisphere(vec2{u0, u1});
+    out3[0] = d.x; out3[1] = d.y; out3[2] = d.z;
+}
+// eft
+float kat_diff_prod(float a, float b, float c, float d) { return diff_prod(a, b, c, d); }
+
+// scene-level: spectral sampling distribution checks
+float kat_kdist_pdf(const void* scene_host, int emitter, float k) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    return kdist_pdf(sc, sc.kdists[sc.emitters[emitter].k_dist], k);
+}
+float kat_kdist_sample(const void* scene_host, int emitter, float u, float* pdf_out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const wavenumber_sample_t w = kdist_sample(sc, sc.kdists[sc.emitters[emitter].k_dist], u);
+    *pdf_out = w.wpd;
+    return w.k;
+}
+float kat_spectrum(const void* scene_host, int id, float k, float* im) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const cplx v = spectrum_value(sc, id, k);
+    if (im) *im = v.im;
+    return v.re;
+}
+int kat_material_ior_spec(const void* scene_host, int material) { return static_cast<const scene_t*>(scene_host)->materials[material].ior_spec; }
+
+}   // extern "C"

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: libwtgpu.so loads, exports every symbol include/wtgpu.h declares, bakes the
+bundled scenes on the host, and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported(built):
+    from wave_tracer_amd.api import load_library, SYMBOLS
+    hdr = open(os.path.join(ROOT, "include", "wtgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(wtgpu_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/wtgpu.h but not exported by libwtgpu.so"
+    assert sorted(SYMBOLS) == declared
+
+
+def test_product_does_not_link_oracle(built):
+    import subprocess
+    from wave_tracer_amd.api import lib_path
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib_path()]).decode()
+    assert "oracle_" not in out and "kat_" not in out
+    needed = subprocess.check_output(["readelf", "-d", lib_path()]).decode()
+    assert "liboracle" not in needed
+
+
+@pytest.mark.parametrize("name,tris", [("double_slits", 10), ("furnace", 26), ("white_furnace", 12)])
+def test_named_scene_host_baking(built, name, tris):
+    from wave_tracer_amd import Scene
+    sc = Scene(name, res=64, lut=(64, 64))
+    assert sc.info.n_tris == tris
+    assert sc.info.n_nodes >= 1 and sc.info.n_leaves >= 1
+    if name == "double_slits":
+        assert (sc.width, sc.height, sc.channels) == (64, 16, 1)       # height = res/4, monochromatic (double_slits.xml:61-62)
+        assert sc.info.sensor_type == 1 and sc.info.n_emitters == 1
+        assert sc.info.n_edges == 19                                     # 5 rectangles: 5 diagonals (coplanar: dropped) ...
+    else:
+        assert sc.channels == 3
+
+
+def test_cornell_box_standin_baking(built):
+    from wave_tracer_amd import Scene
+    sc = Scene("cornell_box", res=32, mesh_detail=0, lut=(64, 64))
+    assert sc.info.n_shapes == 13 and sc.info.n_emitters == 3 and sc.info.max_depth == 16
+    st = sc.stats()
+    assert st["tris"] == sc.info.n_tris and st["nodes8"] == sc.info.n_nodes
+
+
+def test_unknown_scene_and_no_device_fail_loudly(built):
+    import torch
+    from wave_tracer_amd import Scene, WtgpuError
+    with pytest.raises(WtgpuError):
+        Scene("no_such_scene")
+    if not torch.cuda.is_available():
+        sc = Scene("furnace", res=8)
+        with pytest.raises(WtgpuError, match="no HIP device|no CPU fallback"):
+            sc.upload(0)
+
+
+def test_develop_matches_film_storage_semantics(built):
+    import numpy as np
+    from wave_tracer_amd import Scene, develop
+    sc = Scene("furnace", res=4)
+    v = np.arange(4 * 4 * 3, dtype=np.float64).reshape(4, 4, 3)
+    w = np.full((4, 4), 2.0)
+    w[0, 0] = 0.0
+    l = np.ones((4, 4, 3)) * 8.0
+    out = develop(sc, v, w, l, 4)
+    exp = np.where(w[..., None] != 0, v / np.where(w == 0, 1, w)[..., None], 0.0) + l / 4
+    assert np.allclose(out, exp)
