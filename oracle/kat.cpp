@@ -148,6 +148,12 @@ float kat_spectrum(const void* scene_host, int id, float k, float* im) {
     if (im) *im = v.im;
     return v.re;
 }
+// triangle soup of the flattened scene (BVH order): n_tris x {a,b,c,n} for brute-force ADS checks
+uint32_t kat_scene_tris(const void* scene_host, float* out12) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    if (out12) std::memcpy(out12, sc.tri_geo, sizeof(tri_geo_t) * sc.n_tris);
+    return sc.n_tris;
+}
 int kat_material_ior_spec(const void* scene_host, int material) { return static_cast<const scene_t*>(scene_host)->materials[material].ior_spec; }
 
 }   // extern "C"

@@ -131,6 +131,38 @@ class Scene:
         _check(load_library().wtgpu_render(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), int(sample_begin),
                                            int(sample_end), int(seed)))
 
+    def trace_rays(self, rays):
+        """rays: [n,8] f32 {o, d, tmin, tmax} (numpy) -> (dist, tuid, bary, front) numpy; device arrays are torch tensors."""
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        n = len(rays)
+        d_rays = torch.from_numpy(np.ascontiguousarray(rays, dtype=np.float32)).to(dev)
+        dist = torch.zeros(n, dtype=torch.float32, device=dev)
+        tuid = torch.zeros(n, dtype=torch.int32, device=dev)
+        bary = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+        front = torch.zeros(n, dtype=torch.int32, device=dev)
+        _check(load_library().wtgpu_trace_rays(self._h, None, d_rays.data_ptr(), n, dist.data_ptr(), tuid.data_ptr(), bary.data_ptr(), front.data_ptr()))
+        torch.cuda.synchronize(dev)
+        return dist.cpu().numpy(), tuid.cpu().numpy().view(np.uint32), bary.cpu().numpy(), front.cpu().numpy().view(np.uint32)
+
+    def traverse_cones(self, cones, cap=64):
+        """cones: [n,10] f32 {o, d, tan_alpha, x0, ecc, lambda_m} -> (dist, flags, ntris, tris[n,cap] sorted)."""
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        n = len(cones)
+        d_cones = torch.from_numpy(np.ascontiguousarray(cones, dtype=np.float32)).to(dev)
+        dist = torch.zeros(n, dtype=torch.float32, device=dev)
+        flags = torch.zeros(n, dtype=torch.int32, device=dev)
+        ntris = torch.zeros(n, dtype=torch.int32, device=dev)
+        tris = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        _check(load_library().wtgpu_traverse_cones(self._h, None, d_cones.data_ptr(), n, cap, dist.data_ptr(), flags.data_ptr(), ntris.data_ptr(),
+                                                   tris.data_ptr()))
+        torch.cuda.synchronize(dev)
+        return (dist.cpu().numpy(), flags.cpu().numpy().view(np.uint32), ntris.cpu().numpy().view(np.uint32),
+                tris.cpu().numpy().view(np.uint32))
+
     def counters(self):
         c = Counters()
         _check(load_library().wtgpu_get_counters(self._h, C.byref(c)))

@@ -50,20 +50,32 @@ def shard_samples(spp, rank, world):
     return b, e
 
 
-def render_distributed(scene, spp, seed=1, reduce_dst=0):
-    """One process per GPU (torch.distributed already initialised, backend nccl=RCCL on GPUs, gloo in CPU tests of the
-    sharding logic).  Each rank renders its sample shard; films are summed onto `reduce_dst`."""
+def _render_shard_hip(scene, begin, end, seed):
+    """Default shard renderer: the HIP path on the rank's GPU (fails loudly without one: there is no CPU fallback)."""
+    import torch
+    if scene.device is None:
+        raise RuntimeError("render_distributed: scene.upload(local_rank) first")
+    dev = torch.device("cuda", scene.device)
+    value, weight, light = alloc_films(scene, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    scene.render_into(value, weight, light, begin, end, seed, stream)
+    return value, weight, light
+
+
+def render_distributed(scene, spp, seed=1, reduce_dst=0, shard_renderer=None):
+    """One process per GPU (torch.distributed already initialised; backend nccl = RCCL on GPUs).  Each rank renders its
+    sample shard of every pixel into its own film; the films are summed onto `reduce_dst` with one reduce per buffer.
+    `shard_renderer(scene, begin, end, seed) -> (value, weight, light)` torch tensors is a seam for the CPU (gloo) tests of
+    the sharding / reduction logic; the product path is the default (HIP)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     b, e = shard_samples(spp, rank, world)
-    dev = torch.device("cuda", scene.device)
-    value, weight, light = alloc_films(scene, dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    scene.render_into(value, weight, light, b, e, seed, stream)
+    value, weight, light = (shard_renderer or _render_shard_hip)(scene, b, e, seed)
     for t in (value, weight, light):
         dist.reduce(t, dst=reduce_dst, op=dist.ReduceOp.SUM)
-    torch.cuda.synchronize(dev)
+    if value.is_cuda:
+        torch.cuda.synchronize(value.device)
     if rank == reduce_dst:
         return value.cpu().numpy(), weight.cpu().numpy(), light.cpu().numpy()
     return None
