@@ -22,25 +22,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def cpu_baseline(scene_name, res, seconds_target=15.0):
-    """CPU checker (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload:
-    the same scene at reduced film resolution (Msamples/s of this path is resolution independent: every pixel does the
-    same work).  Only rank 0 at N=1 runs this."""
-    import numpy as np  # noqa: F401
+    """CPU checker (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload: every n-th
+    24x24 block of the same full-size film (same pixel pitch => same beam footprints and per-sample work), for about
+    `seconds_target` seconds.  Only rank 0 at N=1 runs this."""
     from wave_tracer_amd.api import Scene
-    from oracle_util import oracle_render
-    cores = os.cpu_count() or 1
+    from oracle_util import oracle_render_tiles
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     sc = Scene(scene_name, res=res, mesh_detail=1)
-    # calibrate
+    n_tiles = ((sc.width + 23) // 24) * ((sc.height + 23) // 24)
+    # work unit of the checker = one 24x24 block (the reference's block size): keep >= 4 blocks per core in flight
+    stride = max(1, n_tiles // (4 * cores))
     t = time.time()
-    oracle_render(sc, 0, 1, 123, threads=cores)
+    _, _, _, _, n1, _ = oracle_render_tiles(sc, 0, 1, 123, stride, 0, threads=cores)      # calibration pass
     dt1 = max(1e-3, time.time() - t)
-    spp = max(1, min(64, int(seconds_target / dt1)))
+    spp = max(1, min(256, int(seconds_target / dt1)))
     t = time.time()
-    oracle_render(sc, 1, 1 + spp, 123, threads=cores)
+    _, _, _, _, n, _ = oracle_render_tiles(sc, 1, 1 + spp, 123, stride, 0, threads=cores)
     dt = time.time() - t
-    n = sc.width * sc.height * spp
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{scene_name} res={res} spp={spp} ({n} samples, {dt:.1f}s) on all host cores; scalar fp32 restatement, baseline only"}
+            "sample": f"{scene_name} res={res}: every {stride}th 24x24 block of the SAME {sc.width}x{sc.height} film, {spp} spp "
+                      f"({n} samples, {dt:.1f}s), {cores} threads; scalar fp32 restatement (oracle/), baseline only"}
 
 
 def main():
@@ -52,7 +53,7 @@ def main():
     ap.add_argument("--res", type=int, default=1440)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-res", type=int, default=96)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     import torch
@@ -153,7 +154,7 @@ def main():
                                     "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.cpu_res)
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.cpu_seconds)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -39,6 +39,8 @@ typedef struct wtgpu_scene_params {
     int32_t mesh_detail;       /* 0: low-poly stand-ins, 1: full tessellation */
     uint32_t lut_n_theta, lut_m; /* resolution of the regenerated Fraunhofer iCDF LUT (0: default) */
     uint32_t debug_only_s, debug_only_t; /* test hook: 0 = all strategies; v>0 evaluates only s (t) = v-1 with unit MIS weight */
+    uint32_t crop_of;          /* test hook (perspective sensors): 0 = off; v>0: the res x res film is the central crop of a v x v film
+                                * (same pixel pitch, hence the same beam footprints, as the full-size render) */
 } wtgpu_scene_params;
 
 typedef struct wtgpu_scene_info {

@@ -64,8 +64,10 @@ extern "C" {
 
 // Renders samples [sample_begin, sample_end) of every pixel into (value, weight, light) (accumulating).
 // `scene_host` points to a wt::scene_t whose pointers are host pointers.
-int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
-                  int n_threads, unsigned long long* counters_out /* sizeof(bdpt_counters_t)/8 entries or NULL */) {
+// `tile_stride`/`tile_offset`: only the 24x24 blocks with index % stride == offset are rendered (a bounded sample of a
+// full-size workload; stride 1 = everything).  Returns the number of samples rendered through *n_samples_out.
+static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
+                              int n_threads, unsigned long long* counters_out, uint32_t tile_stride, uint32_t tile_offset, uint64_t* n_samples_out) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
     const uint32_t W = sc.sensor.width, H = sc.sensor.height;
     film_t film{value, weight, light, W, H, sc.sensor.channels};
@@ -74,6 +76,7 @@ int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample
     const uint32_t B = 24;   // include/wt/wt_context.hpp:45
     const uint32_t bx = (W + B - 1) / B, by = (H + B - 1) / B;
     std::atomic<uint32_t> next{0};
+    std::atomic<uint64_t> n_done{0};
     std::vector<bdpt_counters_t> ctrs(n_threads);
     for (auto& c : ctrs) std::memset(&c, 0, sizeof(c));
     // FSD aperture pool: per thread, reset per sample (apertures only live for one sample)
@@ -91,10 +94,12 @@ int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample
         for (;;) {
             const uint32_t blk = next.fetch_add(1);
             if (blk >= bx * by) break;
+            if (tile_stride > 1 && blk % tile_stride != tile_offset) continue;
             const uint32_t x0 = (blk % bx) * B, y0 = (blk / bx) * B;
             for (uint32_t y = y0; y < std::min(H, y0 + B); ++y)
                 for (uint32_t x = x0; x < std::min(W, x0 + B); ++x)
                     for (uint64_t s = sample_begin; s < sample_end; ++s) {
+                        n_done.fetch_add(1, std::memory_order_relaxed);
                         const uint64_t pix = (uint64_t)y * W + x;
                         const uint64_t sample_id = (pix << 32) | (s & 0xFFFFFFFFull);
                         pool_counter = 0;
@@ -117,7 +122,18 @@ int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample
         for (auto& c : ctrs) add_counters(total, c);
         std::memcpy(counters_out, &total, sizeof(total));
     }
+    if (n_samples_out) *n_samples_out = n_done.load();
     return 0;
+}
+
+int oracle_render(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
+                  int n_threads, unsigned long long* counters_out /* sizeof(bdpt_counters_t)/8 entries or NULL */) {
+    return oracle_render_impl(scene_host, sample_begin, sample_end, seed, value, weight, light, n_threads, counters_out, 1, 0, nullptr);
+}
+int oracle_render_tiles(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
+                        int n_threads, unsigned long long* counters_out, uint32_t tile_stride, uint32_t tile_offset, uint64_t* n_samples_out) {
+    return oracle_render_impl(scene_host, sample_begin, sample_end, seed, value, weight, light, n_threads, counters_out, tile_stride, tile_offset,
+                              n_samples_out);
 }
 
 int oracle_counters_count() { return (int)(sizeof(bdpt_counters_t) / sizeof(unsigned long long)); }

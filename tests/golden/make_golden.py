@@ -23,7 +23,8 @@ CASES = {
     "furnace_fsd_r16": dict(scene="furnace", res=16, spp=4, seed=12, kw={"fsd": 1, "lut": (128, 128)}),
     "white_furnace_r12": dict(scene="white_furnace", res=12, spp=8, seed=13, kw={}),
     "double_slits_r96": dict(scene="double_slits", res=96, spp=8, seed=14, kw={"lut": (128, 128)}),
-    "cornell_box_r12": dict(scene="cornell_box", res=12, spp=2, seed=15, kw={"mesh_detail": 0, "lut": (128, 128)}),
+    # central 24x24 crop of the 1440x1440 film: the same pixel pitch (beam footprints) as the headline workload
+    "cornell_box_r12": dict(scene="cornell_box", res=24, spp=2, seed=15, kw={"mesh_detail": 0, "lut": (128, 128), "crop_of": 1440}),
 }
 COUNTER_KEYS = ["segments", "vertices", "connections", "surface_interactions", "fsd_interactions", "light_splats"]
 

@@ -17,6 +17,8 @@ def load_oracle():
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         lib = C.CDLL(p)
         lib.oracle_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.oracle_render_tiles.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_uint32, C.c_uint32, C.c_void_p]
         lib.oracle_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.oracle_traverse_cones.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
@@ -38,3 +40,24 @@ def oracle_render(scene, sample_begin, sample_end, seed, threads=0):
                            ctr.ctypes.data)
     assert rc == 0
     return value, weight, light, dict(zip(ORACLE_COUNTERS, [int(x) for x in ctr]))
+
+
+def oracle_render_tiles(scene, sample_begin, sample_end, seed, tile_stride, tile_offset=0, threads=0):
+    """Renders only the 24x24 blocks with index % tile_stride == tile_offset (a bounded sample of a full-size workload).
+    Returns (value, weight, light, counters, n_samples, tile_mask[H,W])."""
+    lib = load_oracle()
+    H, W, Cn = scene.height, scene.width, scene.channels
+    value = np.zeros((H, W, Cn), np.float64)
+    weight = np.zeros((H, W), np.float64)
+    light = np.zeros((H, W, Cn), np.float64)
+    ctr = np.zeros(lib.oracle_counters_count(), np.uint64)
+    n = C.c_uint64(0)
+    rc = lib.oracle_render_tiles(scene.host_desc(), sample_begin, sample_end, seed, value.ctypes.data, weight.ctypes.data, light.ctypes.data, threads,
+                                 ctr.ctypes.data, tile_stride, tile_offset, C.byref(n))
+    assert rc == 0
+    B = 24
+    bx = (W + B - 1) // B
+    ys, xs = np.mgrid[0:H, 0:W]
+    blk = (ys // B) * bx + xs // B
+    mask = (blk % tile_stride) == tile_offset if tile_stride > 1 else np.ones((H, W), bool)
+    return value, weight, light, dict(zip(ORACLE_COUNTERS, [int(x) for x in ctr])), int(n.value), mask

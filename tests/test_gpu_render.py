@@ -43,7 +43,8 @@ def test_image_parity_small(built, name, res, spp, kw):
     # wave-optics case: ~15 % of the vertices are free-space-diffraction interactions (rejection sampling, LUT inversion)
     ("double_slits", 96, 8, {"lut": (128, 128)}, 2e-2),
     # the headline scene (small film, coarse stand-in meshes): all BSDFs, spectra, both emitter types, dielectrics
-    ("cornell_box", 16, 4, {"mesh_detail": 0, "lut": (128, 128)}, 2e-2),
+    # (central crop of the 1440^2 film: same pixel pitch and hence the same beam footprints as the headline workload)
+    ("cornell_box", 32, 4, {"mesh_detail": 0, "lut": (128, 128), "crop_of": 1440}, 2e-2),
 ])
 def test_image_parity_scenes(built, name, res, spp, kw, tol):
     sc, gpu, cpu, gc, oc, gf, cf = _both(name, res, spp, 7, **kw)
@@ -60,7 +61,7 @@ def test_cornell_dense_mesh_parity(built):
     small film.  The CPU checker keeps the reference's unbounded triangle lists, so samples whose beam footprint covers
     more than kMaxConeTris triangles differ (DESIGN.md 'bounded lists'): tolerance 5 % relative L1 on the image, 1 % on
     event counts."""
-    sc, gpu, cpu, gc, oc, gf, cf = _both("cornell_box", 24, 2, 3, mesh_detail=1, lut=(128, 128))
+    sc, gpu, cpu, gc, oc, gf, cf = _both("cornell_box", 48, 2, 3, mesh_detail=1, lut=(128, 128), crop_of=1440)
     assert np.isfinite(gpu).all()
     assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
     assert _rel_l1(gpu, cpu) < 5e-2, _rel_l1(gpu, cpu)
@@ -153,9 +154,30 @@ def test_full_size_properties_1440(built):
         s = films[0][k] + films[1][k]
         assert torch.allclose(s, films[2][k], rtol=1e-7, atol=1e-30)
     assert c["samples"] == 2 * npix and c["walk_iteration_cap_hits"] == 0
+    # (5) sample-for-sample parity AT FULL SIZE on a bounded sample of the workload: the CPU checker renders every 97th 24x24
+    # block of the same 1440^2 film (38 blocks, 21,888 samples).  Pixels >= 1 px inside those blocks receive `value`/`weight`
+    # splats only from samples of their own block (3x3 reconstruction filter), so they are directly comparable; `light`
+    # (t<=1 splats from anywhere on the film) is not.  Tolerance: the bounded device lists make a few samples
+    # differ: relative L1 over the compared pixels < 5 %, weights to fp32 rounding.
+    from oracle_util import oracle_render_tiles
+    ov, ow, ol, oc5, n5, mask = oracle_render_tiles(sc, 0, 1, 5, 97)
+    inner = mask.copy()
+    inner[1:, :] &= mask[:-1, :]
+    inner[:-1, :] &= mask[1:, :]
+    inner[:, 1:] &= mask[:, :-1]
+    inner[:, :-1] &= mask[:, 1:]
+    inner[0, :] = inner[-1, :] = inner[:, 0] = inner[:, -1] = False
+    gv, gw = films[0][0].cpu().numpy(), films[0][1].cpu().numpy()
+    assert inner.sum() > 15000
+    assert np.allclose(gw[inner], ow[inner], rtol=1e-5, atol=1e-7)
+    rel = np.abs(gv[inner] - ov[inner]).sum() / np.abs(ov[inner]).sum()
+    assert rel < 5e-2, rel
+    frac_same = (np.abs(gv[inner] - ov[inner]).sum(axis=1) <= 1e-3 * np.abs(ov[inner]).sum(axis=1) + 1e-30).mean()
+    assert frac_same > 0.97, frac_same
     small = Scene("cornell_box", res=96, mesh_detail=1)
     _, _, _, oc = oracle_render(small, 0, 2, 5)
     n_small = 96 * 96 * 2
+    # sanity only: the 96^2 film has 15x wider pixel beams, hence more diffusive/diffractive events per sample
     for key in ("segments", "vertices", "connections"):
         a, b = c[key] / c["samples"], oc[key] / n_small
-        assert abs(a - b) < 0.03 * b, (key, a, b)
+        assert abs(a - b) < 0.25 * b, (key, a, b)

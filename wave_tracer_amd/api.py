@@ -17,7 +17,7 @@ class WtgpuError(RuntimeError):
 class SceneParams(C.Structure):
     _fields_ = [("res", C.c_uint32), ("max_depth", C.c_int32), ("fsd", C.c_int32), ("mis", C.c_int32), ("rr", C.c_int32),
                 ("force_ray_tracing", C.c_int32), ("mesh_detail", C.c_int32), ("lut_n_theta", C.c_uint32), ("lut_m", C.c_uint32),
-                ("debug_only_s", C.c_uint32), ("debug_only_t", C.c_uint32)]
+                ("debug_only_s", C.c_uint32), ("debug_only_t", C.c_uint32), ("crop_of", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
@@ -96,10 +96,10 @@ def _check(rc):
 class Scene:
     """Handle of a flattened scene (host-baked; optionally uploaded to one GPU)."""
 
-    def __init__(self, name, res=256, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, mesh_detail=1, lut=(0, 0), only_s=None, only_t=None):
+    def __init__(self, name, res=256, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, mesh_detail=1, lut=(0, 0), only_s=None, only_t=None, crop_of=0):
         lib = load_library()
         p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, mesh_detail, lut[0], lut[1],
-                        0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1)
+                        0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1, crop_of)
         h = C.c_void_p()
         _check(lib.wtgpu_scene_create_named(name.encode(), C.byref(p), C.byref(h)))
         self._h = h

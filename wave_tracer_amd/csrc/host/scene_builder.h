@@ -142,6 +142,7 @@ struct scene_params_t {
     int32_t mesh_detail;   // 0: low-poly stand-ins (tests), 1: full stand-in tessellation
     uint32_t lut_n_theta, lut_m;
     uint32_t debug_only_s, debug_only_t;
+    uint32_t crop_of;      // 0: off; else the film is the central res x res crop of a crop_of x crop_of film
 };
 // names: "double_slits", "cornell_box", "furnace" (diffuse box test scene)
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b);

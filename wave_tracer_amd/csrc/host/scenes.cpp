@@ -113,7 +113,8 @@ static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
     b.set_integrator(o);
     if (p.lut_m) b.set_fsd_lut_resolution(p.lut_n_theta, p.lut_m);
 
-    b.set_sensor_perspective(xform_t::lookat({0, 1 * cm, 6.8 * cm}, {0, 1 * cm, 0}, {0, 1, 0}), deg(19.75), p.res, p.res, 1.f, false);
+    const double fov = p.crop_of > p.res ? 2.0 * std::atan(std::tan(deg(19.75) / 2) * double(p.res) / double(p.crop_of)) : deg(19.75);
+    b.set_sensor_perspective(xform_t::lookat({0, 1 * cm, 6.8 * cm}, {0, 1 * cm, 0}, {0, 1, 0}), fov, p.res, p.res, 1.f, false);
     const float D55[3] = {0.95682f, 1.00000f, 0.92149f};
     b.set_response_rgb(D55);
 

@@ -22,7 +22,11 @@ namespace wt {
 
 constexpr uint32_t kMaxVerts = 18;       // max_depth(16) + 2
 constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
+#ifdef WT_ORACLE_UNBOUNDED
+constexpr uint32_t kMaxEdgeIds = 16384;  // CPU checker: effectively unbounded
+#else
 constexpr uint32_t kMaxEdgeIds = 96;     // cap of the de-duplicated edge set of one interaction region
+#endif
 
 enum vertex_type_e : uint32_t { VT_SENSOR = 0, VT_EMITTER = 1, VT_SURFACE = 2, VT_MEDIUM = 3, VT_FSD = 4 };
 enum geo_kind_e : uint32_t { GEO_NONE = 0, GEO_POINT = 1, GEO_SURFACE = 2 };

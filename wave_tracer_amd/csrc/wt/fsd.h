@@ -22,7 +22,11 @@ constexpr float kFsdPA2 = 0.21899789398059305541f;
 constexpr float kFsdP0Sigma = 0.288675134594813f / 4.f;
 constexpr float kFsdUnitM = 1e-3f;       // fsd_unit = 1 mm
 constexpr float kFsdWo2Cutoff = .85f;
+#ifdef WT_ORACLE_UNBOUNDED
+constexpr uint32_t kFsdMaxEdges = 4096;   // CPU checker: effectively unbounded, like the reference's std::vector
+#else
 constexpr uint32_t kFsdMaxEdges = 48;    // per-aperture segment cap on the device (overflow is counted)
+#endif
 
 struct fsd_edge_t {
     vec2 e, v;    // edge vector, mid point (in fsd units = mm)

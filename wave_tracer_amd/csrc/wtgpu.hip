@@ -415,6 +415,7 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
         p.lut_m = params->lut_m;
         p.debug_only_s = params->debug_only_s;
         p.debug_only_t = params->debug_only_t;
+        p.crop_of = params->crop_of;
         if (!wth::build_named_scene(name, p, *s->builder)) return fail(WTGPU_ERR_INVALID, std::string("unknown scene ") + name);
         s->host = s->builder->scene();
         s->stats = s->builder->stats();
