@@ -83,8 +83,8 @@ int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_sample
 /* Renders sample indices [sample_begin, sample_end) of every sensor element (the `spp` loop of
  * integrator_t::integrate for all pixels) and accumulates into the caller-owned DEVICE film buffers
  *     d_value  [height][width][channels] f64,  d_weight [height][width] f64,  d_light [height][width][channels] f64.
- * `stream` is a hipStream_t (NULL = default stream); the call is asynchronous w.r.t. the host except for the
- * small per-round queue-size readbacks.  RNG: Philox-4x32-10 keyed by `seed`, counter = (pixel, sample, stream). */
+ * `stream` is a hipStream_t (NULL = default stream).  The call only ENQUEUES work (internal streams that start after
+ * everything already on `stream`; `stream` continues after them): synchronise `stream` before reading the films.  RNG: Philox-4x32-10 keyed by `seed`, counter = (pixel, sample, stream). */
 int wtgpu_render(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin, uint64_t sample_end,
                  uint64_t seed);
 
@@ -100,10 +100,12 @@ int wtgpu_traverse_cones(wtgpu_scene* scene, void* stream, const float* d_cones,
 int wtgpu_get_counters(wtgpu_scene* scene, wtgpu_counters* out);
 int wtgpu_reset_counters(wtgpu_scene* scene);
 
-/* Average device time [ms] of each kernel of the last wtgpu_render call, measured with hipEvents on `stream`:
- * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact (sum), out[3]=connect, out[4]=number of rounds,
- * out[5]=trace launches, out[6]=batches, out[7]=cooperative (heavy) trace (sum). */
-int wtgpu_last_render_timings(const wtgpu_scene* scene, float out[8]);
+/* Device time [ms] per kernel, ACCUMULATED over all wtgpu_render calls since upload / the last wtgpu_reset_counters, measured
+ * with hipEvents on the internal streams the kernels are launched on (waits for the in-flight batches):
+ * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact (sum), out[3]=connect, out[4]=rounds with work,
+ * out[5]=trace launches with work, out[6]=batches, out[7]=cooperative (heavy) trace (sum).  Batches run concurrently on
+ * several streams, so the sums may exceed the wall time. */
+int wtgpu_last_render_timings(wtgpu_scene* scene, float out[8]);
 
 /* Host-side film development (render_context_t::develop, src/scene/render.cpp:245-291):
  * out[h][w][c] = value/weight (0 if weight==0) + light * (1/spe). */

@@ -136,6 +136,70 @@ int oracle_render_tiles(const void* scene_host, uint64_t sample_begin, uint64_t 
                               n_samples_out);
 }
 
+// Work profile of the device's traversal configuration (bounded 64-entry triangle list + pruning, any-hit probe first,
+// unlimited per-lane budget) on a tile subset: per traverse() call the BVH work split into ray / cone / probe parts.
+// out_calls: n x 8 uint32 {ray_nodes, ray_tris, cone_nodes, cone_tris, probe_nodes, probe_tris, n_ray_q | n_cone_q<<16, flags}
+// Returns the number of traverse() calls (<= cap rows are stored).  Diagnostic tool, not part of any parity claim.
+uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_t tile_stride, uint32_t* out_calls, uint64_t cap, int unbounded) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const uint32_t W = sc.sensor.width, H = sc.sensor.height, B = 24;
+    const uint32_t bx = (W + B - 1) / B, by = (H + B - 1) / B;
+    std::vector<double> value((size_t)W * H * sc.sensor.channels), weight((size_t)W * H), light((size_t)W * H * sc.sensor.channels);
+    film_t film{value.data(), weight.data(), light.data(), W, H, sc.sensor.channels};
+    sample_scratch_t scr;
+    scr.tris.resize(kOracleConeTris);
+    scr.svert.resize(kMaxVerts * kVertexWords);
+    scr.evert.resize(kMaxVerts * kVertexWords);
+    std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);
+    std::vector<fsd_edge_t> edges((2 * kMaxVerts + 8) * (size_t)kFsdMaxEdges);
+    uint32_t pool_counter = 0;
+    const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size()};
+    bdpt_counters_t ctr;
+    std::memset(&ctr, 0, sizeof(ctr));
+    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    uint64_t n_calls = 0;
+    for (uint32_t blk = 0; blk < bx * by; ++blk) {
+        if (tile_stride > 1 && blk % tile_stride != 0) continue;
+        const uint32_t x0 = (blk % bx) * B, y0 = (blk / bx) * B;
+        for (uint32_t y = y0; y < std::min(H, y0 + B); ++y)
+            for (uint32_t x = x0; x < std::min(W, x0 + B); ++x) {
+                const uint64_t pix = (uint64_t)y * W + x;
+                const uint64_t sample_id = (pix << 32);
+                pool_counter = 0;
+                sample_ctx_t ctx;
+                walk_t sw, ew;
+                const vertex_store_t svs{scr.svert.data(), 1, 0}, evs{scr.evert.data(), 1, 0};
+                bdpt_generate(sc, seed, sample_id, x, y, ctx, sw, ew, svs, evs);
+                for (int which = 0; which < 2; ++which) {
+                    walk_t& w = which ? ew : sw;
+                    const vertex_store_t& vs = which ? evs : svs;
+                    const uint_list_t tris{scr.tris.data(), 1, unbounded ? kOracleConeTris : kMaxConeTris};   // bounded like the device unless asked otherwise
+                    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+                        const cone_t env = walk_trace_envelope(sc, w);
+                        const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+                        bvh_counters_t bc;
+                        std::memset(&bc, 0, sizeof(bc));
+                        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris, &bc, 0xFFFFFFFFu, !unbounded);
+                        if (n_calls < cap) {
+                            uint32_t* o = out_calls + 8 * n_calls;
+                            o[0] = bc.nodes; o[1] = bc.tri_tests; o[2] = bc.cone_nodes; o[3] = bc.cone_tri_tests; o[4] = bc.probe_nodes; o[5] = bc.probe_tri_tests;
+                            o[6] = unbounded ? tr.ntris : (tr.n_ray_queries | (tr.n_cone_queries << 16));
+                            o[7] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (which ? 4u : 0u) | (it << 8);
+                        }
+                        ++n_calls;
+                        w.active = bdpt_walk_step(sc, w, tr, tris, vs, pool, seed, sample_id, which ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK, &ctr) ? 1u : 0u;
+                    }
+                }
+            }
+    }
+    return n_calls;
+}
+
+#ifdef WT_PROFILE_CONE_TRI
+void oracle_fsd_hist(unsigned long long* out) { std::memcpy(out, wt::g_fsd_hist, sizeof(wt::g_fsd_hist)); }
+void oracle_cone_tri_exits(unsigned long long* out) { std::memcpy(out, g_cone_tri_exits, sizeof(g_cone_tri_exits)); }
+#endif
+
 int oracle_counters_count() { return (int)(sizeof(bdpt_counters_t) / sizeof(unsigned long long)); }
 
 // ---- per-query entry points for the traversal parity tests ---------------------------------------------------

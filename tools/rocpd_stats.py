@@ -20,3 +20,14 @@ out = "\n".join(lines)
 print(out)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out + "\n")
+
+# optional per-dispatch dump (launch order): rocpd_stats.py results.db out.csv dispatches.csv
+if len(sys.argv) > 3:
+    rows = db.execute(f"""select s.kernel_name, d.start, d.end-d.start, d.grid_size_x, d.workgroup_size_x from {kd} d join {ks} s on d.kernel_id=s.id
+                          order by d.start""").fetchall()
+    t0 = rows[0][1] if rows else 0
+    with open(sys.argv[3], "w") as f:
+        f.write("kernel,start_ms,dur_ms,grid,workgroup\n")
+        for r in rows:
+            name = r[0].replace("(anonymous namespace)::", "").split("(")[0][-40:]
+            f.write(f"{name},{(r[1]-t0)/1e6:.3f},{r[2]/1e6:.4f},{r[3]},{r[4]}\n")

@@ -397,11 +397,19 @@ WT_HD bool walk_continue(const scene_t& sc, walk_t& w, const vertex_store_t& vs,
 }
 
 // One random-walk step after the beam has been traced (plt_bdpt_detail.hpp:421-526 minus the traverse() call).
+// Hand-over record of a Fraunhofer-FSD rejection loop that a device lane could not finish within kFsdInlineTries (fsd.h):
+// pending = the step returned early, nothing committed; resolved = the wavefront found the outcome, re-run the step with it.
+struct fsd_defer_t {
+    uint32_t pending, resolved;
+    uint32_t slot, base, next_try, end_draws;
+    fsd_sample_t fs;
+};
+
 // Returns TRUE if the walk continues (another segment must be traced).
 template <class TriList>
 WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr, const TriList& tris, const vertex_store_t& vs,
                           const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream, bdpt_counters_t* ctr,
-                          const stack_ref_t* primary_query_stack = nullptr) {
+                          const stack_ref_t* primary_query_stack = nullptr, fsd_defer_t* defer = nullptr) {
     if (tr.empty) return false;   // no intersection (TODO in the reference: infinite emitters)
     sampler_t smp = make_sampler(seed, sample_id, stream, w.rng_draws);
     beam_t& beam = w.beam;
@@ -430,7 +438,9 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         // (kMaxConeTris) while the reference's is an unbounded std::vector; the triangle under the beam axis is therefore
         // found with a BVH *ray* query over the same z-slab instead of scanning the list.  Whenever the list is complete both
         // select the same triangle (closest axis hit inside the slab); the CPU checker keeps the reference's list scan.
-        if (primary_query_stack) {
+        // The BVH query is only needed when the list was actually truncated (tr.overflow > 0, a few per cent of the segments);
+        // a complete list is scanned like the reference does (a handful of ray-triangle tests instead of a tree traversal).
+        if (primary_query_stack && tr.overflow > 0) {
             const float wtol = cone_intersection_tolerance(origin_wp, sc.world_min, sc.world_max, sc.world_max);
             ray_hit_t rh;
             if (ads_intersect_ray(sc, origin_wp, beam.env.d, grow(izr, wtol), *primary_query_stack, rh)) {
@@ -553,21 +563,49 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         if (n_edge_ids > 0) {
             // ---- sample_fraunhofer_fsd_interaction (plt_bdpt_detail.hpp:287-346)
             const float I = 1.f - integrated_flux;
-            const uint32_t slot = fsd_pool_alloc(pool);
+            const bool resume = defer && defer->resolved;   // second pass of a deferred FSD interaction: the aperture exists already
+            const uint32_t slot = resume ? defer->slot : fsd_pool_alloc(pool);
             if (slot >= pool.cap) {
                 if (ctr) ctr->fsd_pool_overflow++;
                 ok = false;
             } else {
                 fsd_aperture_t ap;
                 const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
-                fsd_build_aperture(sc, beam_frame, beam.k, I, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
-                pool.hdr[slot] = ap;
-                if (ctr && ap.overflow) ctr->fsd_edge_overflow += ap.overflow;
+                if (resume) {
+                    ap = pool.hdr[slot];
+                } else {
+                    fsd_build_aperture(sc, beam_frame, beam.k, I, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
+                    pool.hdr[slot] = ap;
+                    if (ctr && ap.overflow) ctr->fsd_edge_overflow += ap.overflow;
+                }
                 if (ap.n_edges == 0) {
                     beam_transform_restart(beam, interaction_wp, beam_dist);
                     do_RR = false;
                 } else {
-                    const fsd_sample_t fs = fsd_sample(sc, ap, ed, smp);
+                    fsd_sample_t fs;
+                    if (!defer) {
+                        fs = fsd_sample(sc, ap, ed, smp);
+                    } else if (resume) {
+                        fs = defer->fs;
+                        sampler_seek(smp, defer->end_draws);
+                    } else {
+                        // device: a lane runs the first kFsdInlineTries tries of the rejection loop itself; if none is accepted the
+                        // rest is finished by its whole wavefront (64 tries per step) and this step is re-entered with the result.
+                        const uint32_t max_tries = fsd_max_tries(ap), base = fsd_tries_base(smp);
+                        const uint32_t t1 = max_tries < kFsdInlineTries ? max_tries : kFsdInlineTries;
+                        fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
+                        const uint32_t t = fsd_run_tries(sc, ap, ed, smp, base, 0, t1, r);
+                        if (t == 0xFFFFFFFFu && t1 < max_tries) {
+                            defer->pending = 1;
+                            defer->slot = slot;
+                            defer->base = base;
+                            defer->next_try = t1;
+                            return false;   // nothing has been committed; the caller re-runs the step once `defer` is resolved
+                        }
+                        const bool accepted = t != 0xFFFFFFFFu;
+                        sampler_seek(smp, fsd_draws_after(base, accepted ? t : max_tries - 1u));
+                        fs = fsd_finalize(ap, accepted, r.x, r.f);
+                    }
                     ok = !(fs.dpd == 0.f || fs.weight == 0.f);
                     if (ok) {
                         if (ctr) ctr->fsd_interactions++;

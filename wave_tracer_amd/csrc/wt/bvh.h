@@ -52,8 +52,12 @@ WT_HD void stack_sort_desc(const stack_ref_t& s, int begin, int end) {
     }
 }
 
+constexpr uint32_t kNodeBudgetCost = 2;   // budget units charged per node visit of a cone query (1 unit = 1 triangle test)
+
 struct bvh_counters_t {
-    uint32_t nodes, leaves, tri_tests;
+    uint32_t nodes, leaves, tri_tests;                  // ray queries
+    uint32_t cone_nodes, cone_leaves, cone_tri_tests;   // full cone queries
+    uint32_t probe_nodes, probe_tri_tests;              // any-hit cone probes
 };
 
 // ---- ray ---------------------------------------------------------------------------------------
@@ -210,7 +214,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
         --s;
         if (top.ptr < 0) {
             const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
-            if (ctr) ctr->leaves++;
+            if (ctr) ctr->cone_leaves++;
             bool found = false;
             tests += leaf.count;
             if (tests > budget) {
@@ -220,7 +224,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             for (uint32_t t = 0; t < leaf.count; ++t) {
                 const uint32_t tuid = leaf.tris_ptr + t;
                 const tri_geo_t tri = sc.tri_geo[tuid];
-                if (ctr) ctr->tri_tests++;
+                if (ctr) ctr->cone_tri_tests++;
                 const bool front_face = dot(tri.n, -rd) > 0.f;
                 cone_tri_hit_t h;
                 if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h)) {
@@ -246,7 +250,12 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             continue;
         }
         const bvh8_node_t& n = sc.nodes[top.ptr - 1];
-        if (ctr) ctr->nodes++;
+        if (ctr) ctr->cone_nodes++;
+        tests += kNodeBudgetCost;   // an 8-wide node visit costs a lane about as much as a few triangle tests
+        if (tests > budget) {
+            rec.aborted = 1;
+            return false;
+        }
         const int begin = s;
         for (int i = 0; i < 8; ++i) {
             const int32_t cp = n.child[i];
@@ -287,7 +296,8 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
 // Used by the device's traverse(): a diffusive attempt is rejected whenever the closest cone hit lies within
 // [dist, dist + major_axis/2) (traversal.hpp:146,157), i.e. exactly when this probe over that thin slab succeeds;
 // probing first avoids the full (closest + triangle list) query whose result the reference computes and discards.
-WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t& range, const stack_ref_t& stack, uint32_t budget, bool& aborted) {
+WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t& range, const stack_ref_t& stack, uint32_t budget, bool& aborted,
+                             bvh_counters_t* ctr = nullptr) {
     aborted = false;
     if (sc.n_nodes == 0) return false;
     const vec3 ro = cone.o, rd = cone.d;
@@ -303,6 +313,7 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
         if (top.ptr < 0) {
             const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
             tests += leaf.count;
+            if (ctr) ctr->probe_tri_tests += leaf.count;
             if (tests > budget) {
                 aborted = true;
                 return false;
@@ -310,11 +321,17 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             for (uint32_t t = 0; t < leaf.count; ++t) {
                 const tri_geo_t tri = sc.tri_geo[leaf.tris_ptr + t];
                 cone_tri_hit_t h;
-                if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max)) return true;
+                if (intersect_cone_tri<true>(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max)) return true;
             }
             continue;
         }
         const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        if (ctr) ctr->probe_nodes++;
+        tests += kNodeBudgetCost;
+        if (tests > budget) {
+            aborted = true;
+            return false;
+        }
         const int begin = s;
         for (int i = 0; i < 8; ++i) {
             const int32_t cp = n.child[i];
@@ -431,7 +448,7 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
         r.n_cone_queries++;
         if (probe_first) {
             bool ab;
-            const bool near_hit = bvh_cone_any_hit(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, stack, cone_budget, ab);
+            const bool near_hit = bvh_cone_any_hit(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, stack, cone_budget, ab, ctr);
             if (ab) {
                 r.aborted = 1;
                 return r;

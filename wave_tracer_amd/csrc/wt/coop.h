@@ -21,11 +21,18 @@
 
 namespace wt {
 
-constexpr int kCoopStack = 192;
+constexpr int kCoopStack = 512;
 constexpr uint32_t kCoopLeafTris = 64;
+constexpr uint32_t kCoopTriBuf = 64 + 8 * kCoopLeafTris;   // buffered triangle ids: < 64 pending + 8 entries x <= 64 triangles
+
+constexpr uint32_t kCoopFlushAt = 12;
+constexpr uint32_t kCoopSurvCap = 128;   // candidates that passed the cheap filter and await the exact cone-triangle test
 
 struct coop_shared_t {
     stack_entry_t stack[kCoopStack];
+    uint32_t tri_buf[kCoopTriBuf];
+    uint32_t surv[kCoopSurvCap];
+    float hit_dist[64];   // cone-hit distance of every listed triangle (list capacity kMaxConeTris = 64)
 };
 
 __device__ inline float wave_min(float v) {
@@ -63,172 +70,355 @@ __device__ inline bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec
 }
 
 // One wavefront, one cone query.  Must be called by all 64 lanes of a 64-thread block with identical arguments.
-__device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
-                                 const uint_list_t& tris, cone_hit_t& rec) {
+//   * up to EIGHT stack entries are popped per step: lane l serves entry l/8, child l%8, so all 64 lanes run the cone x AABB
+//     test (bvh8w.cpp:187-230) at once; hits are pushed with ballot/popcount, the children of the nearest popped node on top,
+//     far-first within a node (the reference's order, bvh8w.cpp:45-57, is kept per node);
+//   * leaves (and subtrees with <= 64 triangles) are not tested one by one: their triangle ranges are buffered in LDS and
+//     tested 64 triangles per step, whatever leaf they came from (leaves hold ~4 triangles: testing them leaf by leaf would
+//     leave 60 lanes idle);
+//   * any_hit = false: closest distance by a wave min-reduce, hit triangles appended with ballot + prefix popcount, the
+//     search slab shrinks after every batch with hits exactly like intersection_record_work_t::search_range;
+//     any_hit = true : the any-hit probe (bvh_cone_any_hit): returns at the first batch with a hit.
+template <bool any_hit>
+__device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
+                                       const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr) {
     const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
     rec.dist = WT_INF;
     rec.front_face = 0;
     rec.ntris = 0;
     rec.overflow = 0;
     rec.aborted = 0;
-    if (sc.n_nodes == 0) return;
-    const vec3 ro = cone.o, rd = cone.d;
-    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
-    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
-    const float ta = cone.tan_alpha, ix = cone.x0;
-    range_t range = cone_search_range(cone, searchrange, rec.dist, z_scale);
-    int s = 1;
-    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
-    __syncthreads();
-    while (s > 0) {
-        const stack_entry_t top = sh.stack[s - 1];
-        --s;
-        __syncthreads();   // everyone has read the top before it may be overwritten
-        if (top.t >= range.max) continue;
-        uint32_t t0 = 0, cnt = 0;
-        bool brute = false;
-        const bvh8_node_t* node = nullptr;
-        if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
-            t0 = leaf.tris_ptr;
-            cnt = leaf.count;
-            brute = true;
-        } else {
-            node = &sc.nodes[top.ptr - 1];
-            if (node->tris_count <= kCoopLeafTris) {
-                t0 = node->tris_start;
-                cnt = node->tris_count;
-                brute = true;
-            }
-        }
-        if (brute) {
-            for (uint32_t base = 0; base < cnt; base += 64) {
-                bool hit = false;
-                float d = WT_INF;
-                bool ff = false;
-                const uint32_t ti = base + lane;
-                if (ti < cnt) {
-                    const tri_geo_t tri = sc.tri_geo[t0 + ti];
-                    ff = dot(tri.n, -rd) > 0.f;
-                    cone_tri_hit_t h;
-                    if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max)) {
-                        hit = true;
-                        d = h.dist;
-                    }
-                }
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    const float dm = wave_min(d);
-                    const unsigned long long m2 = __ballot(hit && d == dm);
-                    const int src = __ffsll((long long)m2) - 1;
-                    const int ffmin = __shfl((int)ff, src, 64);
-                    if (dm < rec.dist) {
-                        rec.dist = dm;
-                        rec.front_face = (uint32_t)ffmin;
-                    }
-                    const uint32_t pos = rec.ntris + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                    if (hit && pos < tris.cap) tris[pos] = t0 + ti;
-                    const uint32_t total = rec.ntris + (uint32_t)__popcll(mask);
-                    const uint32_t newn = total < tris.cap ? total : tris.cap;
-                    rec.overflow += total - newn;
-                    rec.ntris = newn;
-                    range = cone_search_range(cone, searchrange, rec.dist, z_scale);
-                    if (rec.overflow > 0) range.max = fminf_(range.max, rec.dist);   // bounded-list regime, see bvh.h
-                }
-            }
-        } else {
-            bool h = false;
-            float tmin = 0.f;
-            int32_t cp = 0;
-            if (lane < 8) {
-                cp = node->child[lane];
-                if (cp != 0) h = cone_child_test(*node, lane, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
-            }
-            const unsigned mask = (unsigned)(__ballot(h) & 0xffull);
-            const int n = __popc(mask);
-            // rank for a far-first (descending tmin) stable order
-            int rank = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float tj = __shfl(tmin, j, 64);
-                const bool hj = (mask >> j) & 1u;
-                if (hj && (tj > tmin || (tj == tmin && j < lane))) ++rank;
-            }
-            if (h && s + rank < kCoopStack) sh.stack[s + rank] = stack_entry_t{tmin, cp};
-            s = (s + n < kCoopStack) ? s + n : kCoopStack;
-        }
-        __syncthreads();
-    }
-}
-
-// Wave-cooperative any-hit probe (see bvh_cone_any_hit).
-__device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh) {
-    const int lane = threadIdx.x & 63;
     if (sc.n_nodes == 0) return false;
     const vec3 ro = cone.o, rd = cone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
     const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
     const float ta = cone.tan_alpha, ix = cone.x0;
+    range_t range = any_hit ? searchrange : cone_search_range(cone, searchrange, rec.dist, z_scale);
+    float slab_max = range.max;   // far end of the current interaction slab (list membership); range.max may be pruned below it
     int s = 1;
+    uint32_t leaf_total = 0, nsurv = 0;
     if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
     __syncthreads();
-    bool found = false;
-    while (s > 0 && !found) {
-        const stack_entry_t top = sh.stack[s - 1];
-        --s;
+    // Drops the listed triangles whose cone-hit distance lies beyond zmax.  The sequential traversal tests near triangles first
+    // and shrinks its slab at once, so its list holds (almost) only triangles inside the final slab [closest, closest + z_scale *
+    // axis]; a 64-wide batch is tested against the slab as it was before the batch.  Compacting whenever the slab shrinks keeps
+    // the list = the triangles that meet the cone inside the current interaction region (the sequential list may keep a few more
+    // that it saw before its slab shrank) and keeps the bounded list for the triangles that matter.
+    auto compact = [&](float zmax) {
+        if (rec.ntris == 0) return;
         __syncthreads();
-        uint32_t t0 = 0, cnt = 0;
-        bool brute = false;
-        const bvh8_node_t* node = nullptr;
-        if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
-            t0 = leaf.tris_ptr;
-            cnt = leaf.count;
-            brute = true;
-        } else {
-            node = &sc.nodes[top.ptr - 1];
-            if (node->tris_count <= kCoopLeafTris) {
-                t0 = node->tris_start;
-                cnt = node->tris_count;
-                brute = true;
-            }
+        const bool mine = (uint32_t)lane < rec.ntris;
+        const uint32_t val = mine ? tris[lane] : 0u;
+        const float dv = mine ? sh.hit_dist[lane] : 0.f;
+        const bool keep = mine && !(dv > zmax);
+        const unsigned long long km = __ballot(keep);
+        __syncthreads();
+        if (keep) {
+            const uint32_t np_ = (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+            tris[np_] = val;
+            sh.hit_dist[np_] = dv;
         }
-        if (brute) {
-            bool hit = false;
-            if ((uint32_t)lane < cnt) {
-                const tri_geo_t tri = sc.tri_geo[t0 + lane];
-                cone_tri_hit_t h;
-                hit = intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max);
+        rec.ntris = (uint32_t)__popcll(km);
+        __syncthreads();
+    };
+    // phase B2: exact cone-triangle test of the buffered survivors, a full wave at a time; TRUE = any-hit probe satisfied
+    auto flush = [&]() -> bool {
+        __syncthreads();
+        bool any = false;
+        for (uint32_t b2 = 0; b2 < nsurv && !any; b2 += 64) {
+            const uint32_t k2 = b2 + lane;
+            bool hit = false, ff = false;
+            float d = WT_INF;
+            uint32_t t2 = 0;
+            if (k2 < nsurv) {
+                t2 = sh.surv[k2];
+                const tri_geo_t tri = sc.tri_geo[t2];
+                ff = dot(tri.n, -rd) > 0.f;
+                cone_tri_hit_t ht;
+                if (intersect_cone_tri<any_hit>(cone, tri.a, tri.b, tri.c, tri.n, range, ht) && !(ht.dist > range.max)) {
+                    hit = true;
+                    d = ht.dist;
+                }
             }
-            if (__ballot(hit)) found = true;
-        } else {
-            bool h = false;
+            const unsigned long long mask = __ballot(hit);
+            if (!mask) continue;
+            if (any_hit) {
+                any = true;
+                break;
+            }
+            const float dm = wave_min(d);
+            if (dm < rec.dist) {
+                const unsigned long long m2 = __ballot(hit && d == dm);
+                const int src = __ffsll((long long)m2) - 1;
+                rec.front_face = (uint32_t)__shfl((int)ff, src, 64);
+                rec.dist = dm;
+                range = cone_search_range(cone, searchrange, rec.dist, z_scale);
+                slab_max = range.max;
+                compact(slab_max);   // the slab shrank: listed triangles beyond it leave (and make room)
+            }
+            const bool hit2 = hit && !(d > slab_max);   // this batch was tested against the slab as it was before it
+            const unsigned long long mask2 = __ballot(hit2);
+            const uint32_t pos = rec.ntris + (uint32_t)__popcll(mask2 & ((1ull << lane) - 1ull));
+            if (hit2 && pos < tris.cap) {
+                tris[pos] = t2;
+                sh.hit_dist[pos & 63u] = d;
+            }
+            const uint32_t total = rec.ntris + (uint32_t)__popcll(mask2);
+            const uint32_t newn = total < tris.cap ? total : tris.cap;
+            rec.overflow += total - newn;
+            rec.ntris = newn;
+            if (rec.overflow > 0) range.max = fminf_(range.max, rec.dist);   // bounded-list regime (traversal pruning only), see bvh.h
+        }
+        nsurv = 0;
+        __syncthreads();
+        return any;
+    };
+    for (;;) {
+        // ---- phase A: expand up to 8 stack entries per step until >= 64 triangles are buffered (or the stack is empty)
+        const long long ta0 = prof ? clock64() : 0;
+        while (s > 0 && leaf_total < 64u) {
+            const int np = s < 8 ? s : 8;
+            stack_entry_t e{0.f, 0};
+            if (grp < np) e = sh.stack[s - 1 - grp];
+            s -= np;
+            __syncthreads();   // everyone has read its entry before the slots are overwritten
+            const bool live = grp < np && (any_hit || e.t < range.max);
+            bool leafish = false, h = false;
+            uint32_t t0 = 0, cnt = 0;
             float tmin = 0.f;
             int32_t cp = 0;
-            if (lane < 8) {
-                cp = node->child[lane];
-                if (cp != 0) h = cone_child_test(*node, lane, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
+            if (live) {
+                if (e.ptr < 0) {
+                    const bvh8_leaf_t leaf = sc.leaves[-e.ptr - 1];
+                    t0 = leaf.tris_ptr;
+                    cnt = leaf.count;
+                    leafish = true;
+                } else {
+                    const bvh8_node_t& node = sc.nodes[e.ptr - 1];
+                    if (node.tris_count <= kCoopLeafTris) {
+                        t0 = node.tris_start;
+                        cnt = node.tris_count;
+                        leafish = true;
+                    } else {
+                        cp = node.child[sub];
+                        if (cp != 0) h = cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
+                    }
+                }
             }
-            const unsigned mask = (unsigned)(__ballot(h) & 0xffull);
-            const int n = __popc(mask);
-            int rank = 0;
+            // push the child hits: group 0 served the top (nearest) entry, its children go on top
+            const unsigned long long hm = __ballot(h);
+            if (hm) {
+                const uint32_t gbits = (uint32_t)(hm >> (grp * 8)) & 0xffu;
+                int rank = 0;   // far-first within the node
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float tj = __shfl(tmin, j, 64);
-                const bool hj = (mask >> j) & 1u;
-                if (hj && (tj > tmin || (tj == tmin && j < lane))) ++rank;
+                for (int j = 0; j < 8; ++j) {
+                    const float tj = __shfl(tmin, (lane & ~7) + j, 64);
+                    if (((gbits >> j) & 1u) && (tj > tmin || (tj == tmin && j < sub))) ++rank;
+                }
+                const int above = grp < 7 ? __popcll(hm >> ((grp + 1) * 8)) : 0;   // hits of the groups serving deeper entries
+                const int pos = s + above + rank;
+                if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+                const int total = s + __popcll(hm);
+                s = total < kCoopStack ? total : kCoopStack;
             }
-            if (h && s + rank < kCoopStack) sh.stack[s + rank] = stack_entry_t{tmin, cp};
-            s = (s + n < kCoopStack) ? s + n : kCoopStack;
+            // buffer the leaf ranges
+            const unsigned long long lm = __ballot(leafish && sub == 0 && cnt > 0);
+            unsigned long long m = lm;
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                uint32_t c = (uint32_t)__shfl((int)cnt, src, 64);
+                const uint32_t t = (uint32_t)__shfl((int)t0, src, 64);
+                if (c > kCoopLeafTris) c = kCoopLeafTris;   // cannot happen with this builder (leaves hold <= MAX_LEAF triangles)
+                if ((uint32_t)lane < c) sh.tri_buf[leaf_total + lane] = t + lane;
+                leaf_total += c;
+            }
+            __syncthreads();
         }
+        if (prof) prof[5] += (unsigned long long)(clock64() - ta0);
+        const long long tb0 = prof ? clock64() : 0;
+        // ---- phase B1: cheap conservative filter (slab + lateral rejection, cone_tri_maybe) over the buffered candidates.  97 % of
+        // them fail it; testing them with the exact routine would make every 64-wide batch pay its ~20x more expensive
+        // plane/edge path for the 2-3 lanes that need it.  Survivors are compacted into an LDS list instead.
+        bool found_any = false;
+        for (uint32_t base = 0; base < leaf_total && !found_any; base += 64) {
+            const uint32_t k = base + lane;
+            bool pass = false;
+            uint32_t tuid = 0;
+            if (k < leaf_total) {
+                tuid = sh.tri_buf[k];
+                const tri_geo_t tri = sc.tri_geo[tuid];
+                pass = cone_tri_maybe(cone, tri.a, tri.b, tri.c, range);
+            }
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                const uint32_t pos = nsurv + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                if (pass && pos < kCoopSurvCap) sh.surv[pos] = tuid;
+                nsurv += (uint32_t)__popcll(pm);   // < 64 + 64 <= kCoopSurvCap: a full wave is flushed right away
+            }
+            if (nsurv >= 64u) found_any = flush();
+        }
+        leaf_total = 0;
+        // ---- phase B2 at the end of a round when the query is about to finish (stack empty) or enough survivors wait: one more
+        // round of expansion + filtering costs ~1/5 of an exact-test pass, so a handful of survivors is worth waiting for.
+        if (!found_any && nsurv > 0 && (s == 0 || nsurv >= kCoopFlushAt)) found_any = flush();
         __syncthreads();
+        if (prof) prof[6] += (unsigned long long)(clock64() - tb0);
+        if (any_hit && found_any) return true;
+        if (s == 0) break;
     }
-    return found;
+    return rec.ntris > 0;
 }
 
-// integrator::traverse (traversal.hpp:94-172), wave-uniform.  `stack` is a per-lane stack for the (redundant) ray queries.
+__device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
+                                 const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr) {
+    coop_cone_query<false>(sc, cone, searchrange, z_scale, sh, tris, rec, prof);
+}
+// Wave-cooperative any-hit probe (see bvh_cone_any_hit).
+__device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh, unsigned long long* prof = nullptr) {
+    cone_hit_t rec;
+    const uint_list_t none{nullptr, 0, 0};
+    return coop_cone_query<true>(sc, cone, range, 0.f, sh, none, rec, prof);
+}
+
+// One wavefront, one closest-hit ray query (bvh_traverse_ray<false> + ads_intersect_ray), same scheme as coop_cone_query:
+// 8 stack entries x 8 children per step, buffered leaves tested 64 triangles per step.  A serial per-lane traversal is a
+// chain of ~30 dependent loads (~1 us each at this occupancy); this one is ~10 steps.  Equal-distance ties (a ray through
+// a shared edge) are resolved towards the lowest buffered triangle instead of the first visited one.
+__device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, coop_shared_t& sh, ray_hit_t& rec) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
+    rec.dist = WT_INF;
+    rec.tuid = kInvalid;
+    rec.bx = rec.by = 0.f;
+    rec.front_face = 0;
+    if (sc.n_nodes == 0) return false;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    int s = 1;
+    uint32_t leaf_total = 0;
+    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
+    __syncthreads();
+    for (;;) {
+        while (s > 0 && leaf_total < 64u) {
+            const int np = s < 8 ? s : 8;
+            stack_entry_t e{0.f, 0};
+            if (grp < np) e = sh.stack[s - 1 - grp];
+            s -= np;
+            __syncthreads();
+            const bool live = grp < np && e.t < rec.dist;
+            bool leafish = false, h = false;
+            uint32_t t0 = 0, cnt = 0;
+            float tmin = 0.f;
+            int32_t cp = 0;
+            if (live) {
+                if (e.ptr < 0) {
+                    const bvh8_leaf_t leaf = sc.leaves[-e.ptr - 1];
+                    t0 = leaf.tris_ptr;
+                    cnt = leaf.count;
+                    leafish = true;
+                } else {
+                    const bvh8_node_t& n = sc.nodes[e.ptr - 1];
+                    if (n.tris_count <= kCoopLeafTris) {
+                        t0 = n.tris_start;
+                        cnt = n.tris_count;
+                        leafish = true;
+                    } else {
+                        cp = n.child[sub];
+                        if (cp != 0) {
+                            const int i = sub;
+                            const float tfar = fminf_(rec.dist, range.max);
+                            const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
+                            const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
+                            const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
+                            const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
+                            const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
+                            const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
+                            const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, range.min));
+                            const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
+                            h = rmin <= rmax;
+                            tmin = rmin;
+                        }
+                    }
+                }
+            }
+            const unsigned long long hm = __ballot(h);
+            if (hm) {
+                const uint32_t gbits = (uint32_t)(hm >> (grp * 8)) & 0xffu;
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float tj = __shfl(tmin, (lane & ~7) + j, 64);
+                    if (((gbits >> j) & 1u) && (tj > tmin || (tj == tmin && j < sub))) ++rank;
+                }
+                const int above = grp < 7 ? __popcll(hm >> ((grp + 1) * 8)) : 0;
+                const int pos = s + above + rank;
+                if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+                const int total = s + __popcll(hm);
+                s = total < kCoopStack ? total : kCoopStack;
+            }
+            const unsigned long long lm = __ballot(leafish && sub == 0 && cnt > 0);
+            unsigned long long m = lm;
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                uint32_t c = (uint32_t)__shfl((int)cnt, src, 64);
+                const uint32_t t = (uint32_t)__shfl((int)t0, src, 64);
+                if (c > kCoopLeafTris) c = kCoopLeafTris;   // cannot happen with this builder (leaves hold <= MAX_LEAF triangles)
+                if ((uint32_t)lane < c) sh.tri_buf[leaf_total + lane] = t + lane;
+                leaf_total += c;
+            }
+            __syncthreads();
+        }
+        if (leaf_total == 0) {
+            if (s == 0) break;
+            continue;
+        }
+        for (uint32_t base = 0; base < leaf_total; base += 64) {
+            const uint32_t k = base + lane;
+            bool hit = false;
+            float d = WT_INF;
+            uint32_t tuid = 0;
+            ray_tri_hit_t ht{WT_INF, 0.f, 0.f};
+            bool ff = false;
+            if (k < leaf_total) {
+                tuid = sh.tri_buf[k];
+                const tri_geo_t tri = sc.tri_geo[tuid];
+                if (intersect_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range, ht) && ht.dist < rec.dist) {
+                    hit = true;
+                    d = ht.dist;
+                    ff = dot(tri.n, rd) <= 0.f;
+                }
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const float dm = wave_min(d);
+                const unsigned long long m2 = __ballot(hit && d == dm);
+                const int src = __ffsll((long long)m2) - 1;
+                rec.dist = dm;
+                rec.tuid = (uint32_t)__shfl((int)tuid, src, 64);
+                rec.bx = __shfl(ht.bx, src, 64);
+                rec.by = __shfl(ht.by, src, 64);
+                rec.front_face = (uint32_t)__shfl((int)ff, src, 64);
+            }
+        }
+        leaf_total = 0;
+        __syncthreads();
+        if (s == 0) break;
+    }
+    if (!finitef(rec.dist) || rec.dist > range.max) {
+        rec.dist = WT_INF;
+        return false;
+    }
+    return true;
+}
+
+// integrator::traverse (traversal.hpp:94-172), wave-uniform.
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
-                                              const stack_ref_t& stack, coop_shared_t& sh, const uint_list_t& tris) {
+                                              coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr) {
+#define WT_COOP_PROF(i, t0_) \
+    if (prof) prof[i] += (unsigned long long)(clock64() - (t0_));
     trav_result_t r;
     r.aborted = 0;
     r.origin = envelope.o;
@@ -246,7 +436,7 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
     ray_hit_t rh;
     if (force_ray_tracing || cone_is_ray(envelope)) {
         r.n_ray_queries++;
-        if (ads_intersect_ray(sc, ro, rd, range_t{0.f, distance}, stack, rh)) {
+        if (coop_ray_query(sc, ro, rd, range_t{0.f, distance}, sh, rh)) {
             r.empty = 0;
             r.dist = rh.dist;
             r.tuid = rh.tuid;
@@ -261,7 +451,10 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
     for (uint32_t seg = 0;; ++seg) {
         const float ballistic_dist = max_ballistic_distance(lambda_m, seg, 0.f);
         r.n_ray_queries++;
-        if (ads_intersect_ray(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, stack, rh)) {
+        const long long tq0 = prof ? clock64() : 0;
+        const bool ray_hit = coop_ray_query(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, sh, rh);
+        WT_COOP_PROF(0, tq0)
+        if (ray_hit) {
             r.empty = 0;
             r.dist = rh.dist;
             r.tuid = rh.tuid;
@@ -276,8 +469,13 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;
-        if (coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh)) continue;   // too short (see bvh_cone_any_hit)
-        coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch);
+        const long long tp0 = prof ? clock64() : 0;
+        const bool near_hit = coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh, prof);
+        WT_COOP_PROF(1, tp0)
+        if (near_hit) continue;   // too short (see bvh_cone_any_hit)
+        const long long tc0 = prof ? clock64() : 0;
+        coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch, prof);
+        WT_COOP_PROF(2, tc0)
         const bool df_empty = ch.ntris == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;

@@ -230,39 +230,78 @@ WT_HD vec2 fsd_sampleN(const scene_t& sc, const fsd_aperture_t& ap, const fsd_ed
     return mul(zeta, inverse(Xi));
 }
 
+#ifdef WT_PROFILE_CONE_TRI
+inline unsigned long long g_fsd_hist[8][24] = {{0}};
+#endif
 struct fsd_sample_t {
     vec3 wo;
     float dpd;   // solid-angle density (0: failed)
     float weight;
 };
-// fsd_sampler_t::sample (rejection) + free_space_diffraction_t::sample
-WT_HD fsd_sample_t fsd_sample(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, sampler_t& sampler) {
-    const uint32_t edge_count = ap.n_edges;
-    const bool rejection = edge_count > 1;
-    const uint32_t max_tries = edge_count * 1024u;
-    const float recp_M = 1.f / float(edge_count);
-    vec2 xi{0, 0};
-    float pdf = 0.f, weight = 0.f;
-    for (uint32_t tr = 0; tr < max_tries; ++tr) {
-        const vec2 x = fsd_sampleN(sc, ap, ed, sampler);
-        const float g = fsd_sampling_density(ap, ed, x);
-        const float f = fsd_ASF(ap, ed, x);
-        const bool done = rejection ? sampler_r(sampler) * g < f * recp_M : true;
-        if (done) {
-            xi = x;
-            pdf = f * ap.recp_I;
-            weight = 1.f;
-            break;
+// ---- fsd_sampler_t::sample (rejection, fsd_sampler.cpp:72-110) + free_space_diffraction_t::sample ------------------------
+// Random-number layout (ours; the reference draws from a sequential engine): try t of a rejection loop owns the kFsdDrawsPerTry
+// draws starting at  base + t*kFsdDrawsPerTry  of the walk's Philox stream (base = the stream position at entry, rounded up to
+// a multiple of 4; a try uses 4 or 6 draws).  Tries are therefore independent of each other: the CPU checker runs them in
+// order, the device runs the first few per lane and the rest 64 at a time across a wavefront (wtgpu.hip: k_interact), and both
+// accept the same (lowest) try.  After the loop the stream continues behind the last try that was looked at.
+constexpr uint32_t kFsdDrawsPerTry = 8;
+constexpr uint32_t kFsdInlineTries = 8;   // device: tries a lane runs on its own before asking its wavefront for help
+
+struct fsd_try_t {
+    vec2 x;
+    float f;
+    uint32_t accept;
+};
+WT_HD uint32_t fsd_max_tries(const fsd_aperture_t& ap) { return ap.n_edges * 1024u; }
+WT_HD uint32_t fsd_tries_base(const sampler_t& s) { return (s.draws + 3u) & ~3u; }
+// one try; `s` positioned at the try's first draw
+WT_HD fsd_try_t fsd_try(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, sampler_t s) {
+    fsd_try_t r;
+    r.x = fsd_sampleN(sc, ap, ed, s);
+    const float g = fsd_sampling_density(ap, ed, r.x);
+    r.f = fsd_ASF(ap, ed, r.x);
+    r.accept = ap.n_edges > 1 ? (sampler_r(s) * g < r.f * (1.f / float(ap.n_edges)) ? 1u : 0u) : 1u;
+    return r;
+}
+// tries [t0,t1) in order; returns the index of the first accepted one (result in `out`) or 0xFFFFFFFF
+WT_HD uint32_t fsd_run_tries(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, const sampler_t& stream_sampler, uint32_t base,
+                             uint32_t t0, uint32_t t1, fsd_try_t& out) {
+    for (uint32_t t = t0; t < t1; ++t) {
+        const fsd_try_t r = fsd_try(sc, ap, ed, sampler_at(stream_sampler, base + t * kFsdDrawsPerTry));
+        if (r.accept) {
+            out = r;
+            return t;
         }
     }
+    return 0xFFFFFFFFu;
+}
+WT_HD uint32_t fsd_draws_after(uint32_t base, uint32_t last_try) { return base + (last_try + 1u) * kFsdDrawsPerTry; }
+WT_HD fsd_sample_t fsd_finalize(const fsd_aperture_t& ap, bool accepted, vec2 xi, float f) {
+    const float pdf = accepted ? f * ap.recp_I : 0.f;
     const float scale = ap.k * 1.f;
     if (pdf > 0.f) {
         const vec2 zeta = xi / scale;
         const vec2 wol{zeta.x / sqrtf(1.f + sqr(zeta.x)), zeta.y / sqrtf(1.f + sqr(zeta.y))};
         const float wo2 = length2(wol);
-        if (wo2 < kFsdWo2Cutoff) return {vec3{wol.x, wol.y, sqrtf(1.f - wo2)}, pdf, weight};
+        if (wo2 < kFsdWo2Cutoff) return {vec3{wol.x, wol.y, sqrtf(1.f - wo2)}, pdf, 1.f};
     }
     return {vec3{0, 0, 1}, 0.f, 0.f};
+}
+WT_HD fsd_sample_t fsd_sample(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, sampler_t& sampler) {
+    const uint32_t max_tries = fsd_max_tries(ap), base = fsd_tries_base(sampler);
+    fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
+    const uint32_t t = fsd_run_tries(sc, ap, ed, sampler, base, 0, max_tries, r);
+    const bool accepted = t != 0xFFFFFFFFu;
+#ifdef WT_PROFILE_CONE_TRI
+    {
+        const uint32_t tries = accepted ? t + 1 : max_tries;
+        int eb = 0; while ((1u << (eb + 1)) <= ap.n_edges && eb < 7) ++eb;
+        int tb = 0; while ((1u << (tb + 1)) <= tries && tb < 23) ++tb;
+        g_fsd_hist[eb][accepted ? tb : 23]++;
+    }
+#endif
+    sampler_seek(sampler, fsd_draws_after(base, accepted ? t : max_tries - 1u));
+    return fsd_finalize(ap, accepted, r.x, r.f);
 }
 // free_space_diffraction_t::pdf / f (free_space_diffraction.hpp:112-133)
 WT_HD float fsd_pdf(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec3 wolocal) {

@@ -73,6 +73,20 @@ WT_HD sampler_t make_sampler(uint64_t seed, uint64_t sample_id, uint32_t stream,
     }
     return s;
 }
+// Repositions a sampler at draw number `draws` of its stream (counter-based: any position is reachable in O(1)).
+WT_HD void sampler_seek(sampler_t& s, uint32_t draws) {
+    s.draws = draws;
+    if (draws & 3u) {
+        const uint32_t ctr[4] = {(uint32_t)s.sample_id, (uint32_t)(s.sample_id >> 32), s.stream, draws >> 2};
+        const uint32_t key[2] = {s.seed_lo, s.seed_hi};
+        philox4x32_10(ctr, key, s.buf);
+    }
+}
+WT_HD sampler_t sampler_at(const sampler_t& s, uint32_t draws) {
+    sampler_t r = s;
+    sampler_seek(r, draws);
+    return r;
+}
 // uniform float in [0,1): 24 random bits
 WT_HD float sampler_r(sampler_t& s) {
     const uint32_t lane = s.draws & 3u;

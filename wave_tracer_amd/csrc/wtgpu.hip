@@ -8,6 +8,11 @@
 //     k_interact one thread per queued walk : surface / Fraunhofer-FSD / null interaction, vertex append, RR,
 //                re-enqueue
 //   k_connect    one thread per sample : all (s,t) connections, shadow rays, MIS, film splats (f64 atomics)
+// Every round kernel is *persistent*: a fixed grid whose wavefronts grab 64 queue items at a time through a device-side head
+// counter and read the queue length from a device control block, so the host never reads anything back: a whole batch
+// (generate, kMaxWalkIters rounds, connect) is enqueued blindly, rounds after the queue ran empty cost a few us each.
+// Batches are round-robined over several state slices, each with its own HIP stream, so that the long tails of one batch
+// (a handful of slow walks) overlap with the bulk of the others; wtgpu_render is asynchronous w.r.t. the host.
 // All per-walk / per-sample state lives in HBM as word-interleaved SoA (wt::soa_load/soa_store) so that the 64
 // lanes of a wavefront touch 64 consecutive dwords per field.
 //
@@ -34,7 +39,7 @@ namespace {
 constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
 constexpr int kBlock = 128;
 constexpr int kLdsStack = 20;            // LDS-resident stack entries per lane
-constexpr uint32_t kConeBudget = 96;     // cone-triangle tests one lane may spend on a query before it is handed to a wavefront
+constexpr uint32_t kConeBudget = 48;     // cone-triangle tests one lane may spend on a query before it is handed to a wavefront
 constexpr int kSpillStack = 44;          // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 thread_local std::string g_err;
@@ -48,6 +53,10 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(WTGPU_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
+// control block of one state slice (device memory)
+enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
+                  CTL_ROUNDS = 7, CTL_WORDS = 16 };
+
 struct device_state_t {
     uint64_t cap = 0;   // samples per batch
     uint32_t max_verts = 0;
@@ -57,16 +66,12 @@ struct device_state_t {
     uint32_t* trav = nullptr;     // [kTravWords][2cap]
     uint32_t* tris = nullptr;     // [kMaxConeTris][2cap]
     uint32_t* queue[2] = {nullptr, nullptr};
-    uint32_t* qcount = nullptr;   // [2] device
     uint32_t* heavy_queue = nullptr;   // walks whose traversal exceeded the per-lane budget
-    uint32_t* heavy_count = nullptr;   // [0] = number queued, [1] = dequeue head
+    uint32_t* ctl = nullptr;           // [CTL_WORDS] queue sizes, dequeue heads, FSD pool bump counter, rounds done
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
-    uint32_t* fsd_counter = nullptr;
     uint32_t fsd_cap = 0;
-    unsigned long long* counters = nullptr;   // bdpt_counters_t + 2
-    uint32_t* h_qcount = nullptr;             // pinned
-    uint32_t* dbg = nullptr;                  // debug records (WTGPU_DEBUG_HEAVY builds)
+    unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
 constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
@@ -75,6 +80,12 @@ constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long l
 
 }   // namespace
 
+struct chunk_rec_t {
+    std::vector<hipEvent_t> ev;   // [0] start, [1] after generate, then 3 per round (trace, heavy, interact), last: after connect
+    uint32_t* h_ctl = nullptr;    // pinned snapshot of the slice's control block after the batch
+    bool busy = false;
+};
+
 struct wtgpu_scene {
     std::unique_ptr<wth::scene_builder_t> builder;   // owns the host arrays (named scenes)
     scene_t host{};                                  // host-pointer scene
@@ -82,13 +93,18 @@ struct wtgpu_scene {
     std::vector<void*> dev_allocs;
     int device = -1;
     bool uploaded = false;
-    device_state_t st;
+    std::vector<device_state_t> slices;              // per-batch path state, one slice per internal stream
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> ev_done;
+    hipEvent_t ev_begin = nullptr;
+    std::vector<chunk_rec_t> recs;                   // in-flight batch records (events + control block snapshot)
+    size_t rec_next = 0;
+    bool timing = true;
     std::string stats;
     double lut_power[2] = {0, 0};
-    float timings[8] = {0};
+    double acc[8] = {0};                             // accumulated timings since the last reset (see wtgpu_last_render_timings)
     uint64_t samples_rendered = 0;
     uint64_t cap_hits = 0;
-    std::vector<hipEvent_t> events;
 };
 
 // ================================================ kernels ============================================================
@@ -105,6 +121,7 @@ struct launch_args_t {
     uint64_t sample_begin;
     uint32_t count_stats;
     uint32_t cone_budget;
+    uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
 };
 
 __device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s) {
@@ -128,6 +145,12 @@ __device__ inline void flush_counters(unsigned long long* g, const bdpt_counters
 
 __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        uint32_t* ctl = a.st.ctl;
+        ctl[CTL_COUNT0] = 2 * a.nb;
+        ctl[CTL_COUNT1] = 0;
+        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+    }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
     const uint32_t pix = (uint32_t)(j % a.npix);
@@ -153,82 +176,103 @@ __device__ inline void walk_ident(const launch_args_t& a, uint32_t w, uint32_t& 
         stream = STREAM_EMITTER_WALK;
     }
 }
+// queue item -> walk id; the first round's queue is the identity over [0,nb) (sensor walks) and [cap,cap+nb) (emitter walks)
+__device__ inline uint32_t queue_walk(const launch_args_t& a, const uint32_t* queue, uint32_t qi, int first_round) {
+    if (!first_round) return queue[qi];
+    return qi < a.nb ? qi : (uint32_t)a.st.cap + (qi - a.nb);
+}
+// one wavefront grabs the next 64 queue items
+__device__ inline uint32_t wave_grab(uint32_t* head) {
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(head, 64u);
+    return (uint32_t)__shfl((int)base, 0, 64);
+}
+// wave-aggregated append of `w` (for lanes with `pred`) to a device queue
+__device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, uint32_t w) {
+    const unsigned long long m = __ballot(pred);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
+}
 
-__global__ void __launch_bounds__(kBlock) k_trace(launch_args_t a, const uint32_t* queue, uint32_t n, int first_round) {
+__global__ void __launch_bounds__(kBlock, 4) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_COUNT0 + in];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
+        ctl[CTL_HEAD_INTERACT] = 0;
+        if (n > 0) ctl[CTL_ROUNDS] = round + 1;
+    }
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
-    if (qi < n) {
-        const uint32_t w = first_round ? qi : queue[qi];
-        const size_t W2 = 2 * (size_t)a.st.cap;
-        walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);
-        stack_entry_t spill[kSpillStack];
-        stack_ref_t stack;
-        lds_stack(lds, spill, stack);
-        const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
-        const cone_t env = walk_trace_envelope(a.sc, wk);
-        const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-        const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
-        if (tr.aborted) {
-            a.st.heavy_queue[atomicAdd(a.st.heavy_count, 1u)] = w;
-        } else {
-            soa_store(a.st.trav, W2, w, tr);
-            ctr.segments = 1;
-            ctr.ray_queries = tr.n_ray_queries;
-            ctr.cone_queries = tr.n_cone_queries;
-            ctr.cone_tri_overflow = tr.overflow;
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
+    for (;;) {
+        const uint32_t qi = wave_grab(ctl + CTL_HEAD_TRACE) + (threadIdx.x & 63);
+        if (qi - (threadIdx.x & 63) >= n) break;
+        bool heavy = false;
+        uint32_t w = 0;
+        if (qi < n) {
+            w = queue_walk(a, a.st.queue[in], qi, first_round);
+            walk_t wk;
+            soa_load(a.st.walks, W2, w, wk);
+            const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+            const cone_t env = walk_trace_envelope(a.sc, wk);
+            const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
+            if (tr.aborted) {
+                heavy = true;
+            } else {
+                soa_store(a.st.trav, W2, w, tr);
+                ctr.segments += 1;
+                ctr.ray_queries += tr.n_ray_queries;
+                ctr.cone_queries += tr.n_cone_queries;
+                ctr.cone_tri_overflow += tr.overflow;
+            }
         }
+        wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
 // Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
-__global__ void __launch_bounds__(64) k_trace_heavy(launch_args_t a) {
+__global__ void __launch_bounds__(64, 4) k_trace_heavy(launch_args_t a) {
     __shared__ coop_shared_t sh;
-    __shared__ stack_entry_t lds[kLdsStack * 64];
     __shared__ uint32_t s_item;
-    const uint32_t n = a.st.heavy_count[0];
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_HEAVY_COUNT];
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(a.st.heavy_count + 1, 1u);
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_HEAVY_HEAD, 1u);
         __syncthreads();
         const uint32_t item = s_item;
         __syncthreads();
         if (item >= n) break;
         const uint32_t w = a.st.heavy_queue[item];
-        const size_t W2 = 2 * (size_t)a.st.cap;
         walk_t wk;
         soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
-        stack_entry_t spill[kSpillStack];
-        stack_ref_t stack;
-        lds_stack(lds, spill, stack);
         const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
         const cone_t env = walk_trace_envelope(a.sc, wk);
-        const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-#ifdef WTGPU_DEBUG_HEAVY
-        const long long t0 = wall_clock64();
-#endif
-        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, sh, tris);
-#ifdef WTGPU_DEBUG_HEAVY
-        const long long dt = wall_clock64() - t0;   // 100 MHz ticks
-        if (threadIdx.x == 0 && a.st.dbg) {
-            const uint32_t k = atomicAdd(a.st.dbg, 1u);
-            if (k < (1u << 20)) {
-                uint32_t* r = a.st.dbg + 4 + 8 * (size_t)k;
-                r[0] = w;
-                r[1] = (uint32_t)dt;
-                r[2] = tr.n_ray_queries | (tr.n_cone_queries << 8) | (tr.empty << 16) | (tr.ballistic << 17);
-                r[3] = tr.ntris + tr.overflow;
-                r[4] = __float_as_uint(env.x0);
-                r[5] = __float_as_uint(tr.dist);
-                r[6] = __float_as_uint(env.d.z);
-                r[7] = __float_as_uint(env.o.z);
-            }
+        unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const long long tt0 = a.profile ? clock64() : 0;
+        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr);
+        if (a.profile && threadIdx.x == 0) {
+            prof[3] = (unsigned long long)(clock64() - tt0);
+            for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
+            atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
+            atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
+            atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
         }
-#endif
         if (threadIdx.x == 0) {
             soa_store(a.st.trav, W2, w, tr);
             ctr.segments += 1;
@@ -240,35 +284,106 @@ __global__ void __launch_bounds__(64) k_trace_heavy(launch_args_t a) {
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-__global__ void __launch_bounds__(kBlock) k_interact(launch_args_t a, const uint32_t* queue, uint32_t n, int first_round, uint32_t* next_queue,
-                                                     uint32_t* next_count) {
+__global__ void __launch_bounds__(kBlock, 3) k_interact(launch_args_t a, int in, int first_round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_COUNT0 + in];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
+        ctl[CTL_HEAVY_HEAD] = 0;
+        ctl[CTL_HEAD_TRACE] = 0;
+    }
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
-    if (qi < n) {
-        const uint32_t w = first_round ? qi : queue[qi];
-        const size_t W2 = 2 * (size_t)a.st.cap;
-        uint32_t i, stream;
-        walk_ident(a, w, i, stream);
-        const uint64_t j = a.j0 + i;
-        const uint32_t pix = (uint32_t)(j % a.npix);
-        const uint64_t s = a.sample_begin + j / a.npix;
-        const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-        walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);
-        trav_result_t tr;
-        soa_load(a.st.trav, W2, w, tr);
-        const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
-        const vertex_store_t vs{a.st.verts, W2, w};
-        const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.fsd_counter, a.st.fsd_cap};
-        stack_entry_t spill[kSpillStack];
-        stack_ref_t stack;
-        lds_stack(lds, spill, stack);
-        const bool cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack);
-        wk.active = cont ? 1u : 0u;
-        soa_store(a.st.walks, W2, w, wk);
-        if (cont) next_queue[atomicAdd(next_count, 1u)] = w;
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
+    for (;;) {
+        const uint32_t qi = wave_grab(ctl + CTL_HEAD_INTERACT) + (threadIdx.x & 63);
+        if (qi - (threadIdx.x & 63) >= n) break;
+        bool cont = false;
+        uint32_t w = 0, stream = 0;
+        uint64_t sample_id = 0;
+        fsd_defer_t defer;
+        defer.pending = defer.resolved = 0;
+        defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
+        if (qi < n) {
+            w = queue_walk(a, a.st.queue[in], qi, first_round);
+            uint32_t i;
+            walk_ident(a, w, i, stream);
+            const uint64_t j = a.j0 + i;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t s = a.sample_begin + j / a.npix;
+            sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+            walk_t wk;
+            soa_load(a.st.walks, W2, w, wk);
+            trav_result_t tr;
+            soa_load(a.st.trav, W2, w, tr);
+            const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+            const vertex_store_t vs{a.st.verts, W2, w};
+            cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
+            if (!defer.pending) {
+                wk.active = cont ? 1u : 0u;
+                soa_store(a.st.walks, W2, w, wk);
+            }
+        }
+        // ---- Fraunhofer-FSD rejection loops that did not finish within kFsdInlineTries: the wavefront finishes them one after
+        // the other, 64 tries per step (tries are independent, fsd.h), then the owning lane re-runs its step with the outcome.
+        unsigned long long pm = __ballot(defer.pending != 0);
+        if (pm) {
+            const int lane = threadIdx.x & 63;
+            while (pm) {
+                const int L = __ffsll((long long)pm) - 1;
+                pm &= pm - 1;
+                const uint32_t slot = (uint32_t)__shfl((int)defer.slot, L, 64);
+                const uint32_t base = (uint32_t)__shfl((int)defer.base, L, 64);
+                const uint32_t t_first = (uint32_t)__shfl((int)defer.next_try, L, 64);
+                const uint32_t sid_lo = (uint32_t)__shfl((int)(uint32_t)sample_id, L, 64);
+                const uint32_t sid_hi = (uint32_t)__shfl((int)(uint32_t)(sample_id >> 32), L, 64);
+                const uint32_t strm = (uint32_t)__shfl((int)stream, L, 64);
+                const fsd_aperture_t ap = pool.hdr[slot];
+                const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
+                const uint32_t max_tries = fsd_max_tries(ap);
+                const sampler_t ss = make_sampler(a.seed, ((uint64_t)sid_hi << 32) | sid_lo, strm, 0);
+                bool acc = false;
+                uint32_t t_acc = 0;
+                float rx = 0.f, ry = 0.f, rf = 0.f;
+                for (uint32_t t0 = t_first; t0 < max_tries && !acc; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
+                    if (t < max_tries) r = fsd_try(a.sc, ap, ed, sampler_at(ss, base + t * kFsdDrawsPerTry));
+                    const unsigned long long am = __ballot(r.accept != 0);
+                    if (am) {
+                        const int wl = __ffsll((long long)am) - 1;   // lowest try wins, like the sequential loop
+                        rx = __shfl(r.x.x, wl, 64);
+                        ry = __shfl(r.x.y, wl, 64);
+                        rf = __shfl(r.f, wl, 64);
+                        t_acc = t0 + (uint32_t)wl;
+                        acc = true;
+                    }
+                }
+                if (lane == L) {
+                    defer.fs = fsd_finalize(ap, acc, vec2{rx, ry}, rf);
+                    defer.end_draws = fsd_draws_after(base, acc ? t_acc : max_tries - 1u);
+                    defer.resolved = 1;
+                }
+            }
+            if (defer.resolved) {
+                walk_t wk;
+                soa_load(a.st.walks, W2, w, wk);
+                trav_result_t tr;
+                soa_load(a.st.trav, W2, w, tr);
+                const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+                const vertex_store_t vs{a.st.verts, W2, w};
+                defer.pending = 0;
+                cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
+                wk.active = cont ? 1u : 0u;
+                soa_store(a.st.walks, W2, w, wk);
+            }
+        }
+        wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
@@ -292,7 +407,7 @@ __global__ void __launch_bounds__(kBlock) k_connect(launch_args_t a) {
         stack_entry_t spill[kSpillStack];
         stack_ref_t stack;
         lds_stack(lds, spill, stack);
-        const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.fsd_counter, a.st.fsd_cap};
+        const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
 #ifdef WTGPU_DEBUG_PRINT
         if (i == 0)
             printf("dbg k=%g recp=%g kd=%g el=(%u,%u) nT=%u nS=%u resp=%g %g %g spec0 type %d kmin %g kmax %g off %u cnt %u\n", ctx.k, ctx.recp_spectral_pd,
@@ -511,52 +626,101 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
 #undef UP
     s->dev = d;
 
-    // per-batch path state
-    device_state_t& st = s->st;
+    // per-batch path state: `n_slices` slices (one internal stream each) that together hold `max_batch` samples in flight
     const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
-    st.cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 20);
-    st.max_verts = (uint32_t)h.opts.max_depth + 2;
-    const size_t W2 = 2 * (size_t)st.cap;
-    if ((rc = dmalloc(s, &st.walks, kWalkWords * W2))) return rc;
-    if ((rc = dmalloc(s, &st.verts, (size_t)st.max_verts * kVertexWords * W2))) return rc;
-    if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
-    if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
-    if ((rc = dmalloc(s, &st.tris, (size_t)kMaxConeTris * W2))) return rc;
-    if ((rc = dmalloc(s, &st.queue[0], W2))) return rc;
-    if ((rc = dmalloc(s, &st.queue[1], W2))) return rc;
-    if ((rc = dmalloc(s, &st.qcount, 2))) return rc;
-    if ((rc = dmalloc(s, &st.heavy_queue, W2))) return rc;
-    if ((rc = dmalloc(s, &st.heavy_count, 2))) return rc;
-    st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
-    if ((rc = dmalloc(s, &st.fsd_hdr, st.fsd_cap))) return rc;
-    if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_cap * kFsdMaxEdges))) return rc;
-    if ((rc = dmalloc(s, &st.fsd_counter, 1))) return rc;
-    if ((rc = dmalloc(s, &st.counters, kNumCounters + 2))) return rc;
-    HIP_CHECK(hipMemset(st.counters, 0, (kNumCounters + 2) * sizeof(unsigned long long)));
-#ifdef WTGPU_DEBUG_HEAVY
-    if ((rc = dmalloc(s, &st.dbg, 4 + 8 * (size_t)(1u << 20)))) return rc;
-    HIP_CHECK(hipMemset(st.dbg, 0, 16));
-#endif
-    HIP_CHECK(hipHostMalloc((void**)&st.h_qcount, 2 * sizeof(uint32_t), hipHostMallocDefault));
-    s->events.resize(4 * kMaxWalkIters + 8);
-    for (auto& e : s->events) HIP_CHECK(hipEventCreate(&e));
+    const uint64_t total_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 20);
+    uint32_t n_slices = 6;
+    if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
+    n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, total_cap / 64));
+    if (const char* e = getenv("WTGPU_TIMING")) s->timing = atoi(e) != 0;
+    unsigned long long* counters = nullptr;
+    if ((rc = dmalloc(s, &counters, kNumCounters + 8))) return rc;
+    HIP_CHECK(hipMemset(counters, 0, (kNumCounters + 8) * sizeof(unsigned long long)));
+    s->slices.resize(n_slices);
+    s->streams.resize(n_slices);
+    s->ev_done.resize(n_slices);
+    for (uint32_t k = 0; k < n_slices; ++k) {
+        device_state_t& st = s->slices[k];
+        st.cap = (total_cap + n_slices - 1) / n_slices;
+        st.max_verts = (uint32_t)h.opts.max_depth + 2;
+        st.counters = counters;
+        const size_t W2 = 2 * (size_t)st.cap;
+        if ((rc = dmalloc(s, &st.walks, kWalkWords * W2))) return rc;
+        if ((rc = dmalloc(s, &st.verts, (size_t)st.max_verts * kVertexWords * W2))) return rc;
+        if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
+        if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
+        if ((rc = dmalloc(s, &st.tris, (size_t)kMaxConeTris * W2))) return rc;
+        if ((rc = dmalloc(s, &st.queue[0], W2))) return rc;
+        if ((rc = dmalloc(s, &st.queue[1], W2))) return rc;
+        if ((rc = dmalloc(s, &st.heavy_queue, W2))) return rc;
+        if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
+        HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
+        st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
+        if ((rc = dmalloc(s, &st.fsd_hdr, st.fsd_cap))) return rc;
+        if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_cap * kFsdMaxEdges))) return rc;
+        HIP_CHECK(hipStreamCreateWithFlags(&s->streams[k], hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&s->ev_done[k], hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&s->ev_begin, hipEventDisableTiming));
+    // in-flight batch records: events for per-kernel timings + pinned snapshot of the control block
+    s->recs.resize(4 * (size_t)n_slices);
+    for (auto& r : s->recs) {
+        r.ev.resize(s->timing ? 3 + 3 * (size_t)kMaxWalkIters : 1);
+        for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipHostMalloc((void**)&r.h_ctl, CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    }
     s->uploaded = true;
+    return WTGPU_OK;
+}
+
+// Waits for one in-flight batch record and folds its event timings / control-block snapshot into the accumulators.
+static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
+    if (!r.busy) return WTGPU_OK;
+    HIP_CHECK(hipEventSynchronize(r.ev.back()));
+    const uint32_t rounds = r.h_ctl[CTL_ROUNDS];
+    s->cap_hits += r.h_ctl[CTL_COUNT0 + (kMaxWalkIters & 1u)];   // walks still active after the last round
+    s->acc[4] += rounds;
+    s->acc[5] += rounds;
+    s->acc[6] += 1;
+    if (s->timing) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, r.ev[0], r.ev[1]);
+        s->acc[0] += ms;
+        size_t e = 1;
+        for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 3) {
+            hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
+            s->acc[1] += ms;
+            hipEventElapsedTime(&ms, r.ev[e + 1], r.ev[e + 2]);
+            s->acc[7] += ms;
+            hipEventElapsedTime(&ms, r.ev[e + 2], r.ev[e + 3]);
+            s->acc[2] += ms;
+        }
+        hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
+        s->acc[3] += ms;
+    }
+    r.busy = false;
+    return WTGPU_OK;
+}
+static int drain_all(wtgpu_scene* s) {
+    for (auto& r : s->recs) {
+        const int rc = drain_rec(s, r);
+        if (rc) return rc;
+    }
     return WTGPU_OK;
 }
 
 int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weight, double* d_light, uint64_t sb, uint64_t se, uint64_t seed) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     if (!d_value || !d_weight || !d_light || se < sb) return fail(WTGPU_ERR_INVALID, "bad film pointers / sample range");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
     HIP_CHECK(hipSetDevice(s->device));
     const scene_t& h = s->host;
-    device_state_t& st = s->st;
     const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
     const uint64_t total = npix * (se - sb);
+    if (total == 0) return WTGPU_OK;
     launch_args_t a;
     static_assert(sizeof(launch_args_t) <= 4096, "kernel argument too large");
     a.sc = s->dev;
-    a.st = st;
     a.film = film_t{d_value, d_weight, d_light, h.sensor.width, h.sensor.height, h.sensor.channels};
     a.seed = seed;
     a.npix = (uint32_t)npix;
@@ -565,129 +729,92 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
     a.cone_budget = kConeBudget;
     if (const char* e = getenv("WTGPU_CONE_BUDGET")) a.cone_budget = (uint32_t)atoi(e);
     if (const char* e = getenv("WTGPU_COUNT_STATS")) a.count_stats = (uint32_t)atoi(e);
-    float t_gen = 0, t_trace = 0, t_inter = 0, t_conn = 0, t_heavy = 0;
-    uint32_t rounds_total = 0, n_trace_launches = 0;
-    for (uint64_t j0 = 0; j0 < total; j0 += st.cap) {
-        const uint32_t nb = (uint32_t)std::min<uint64_t>(st.cap, total - j0);
+    a.profile = 0;
+    if (const char* e = getenv("WTGPU_PROFILE")) a.profile = (uint32_t)atoi(e);
+    // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
+    int n_cu = 256;
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
+    uint32_t heavy_waves_per_cu = 16;
+    if (const char* e = getenv("WTGPU_HEAVY_WAVES")) heavy_waves_per_cu = (uint32_t)std::max(1, atoi(e));
+    const uint32_t grid_round = (uint32_t)n_cu * 8u, grid_heavy = (uint32_t)n_cu * heavy_waves_per_cu;
+
+    // the internal streams start after everything already enqueued on the caller's stream ...
+    HIP_CHECK(hipEventRecord(s->ev_begin, caller));
+    const size_t n_slices = s->slices.size();
+    std::vector<char> used(n_slices, 0);
+    const uint64_t cap = s->slices[0].cap;
+    size_t chunk = 0;
+    for (uint64_t j0 = 0; j0 < total; j0 += cap, ++chunk) {
+        const size_t k = chunk % n_slices;
+        hipStream_t st_ = s->streams[k];
+        if (!used[k]) {
+            HIP_CHECK(hipStreamWaitEvent(st_, s->ev_begin, 0));
+            used[k] = 1;
+        }
+        chunk_rec_t& r = s->recs[s->rec_next];
+        s->rec_next = (s->rec_next + 1) % s->recs.size();
+        int rc = drain_rec(s, r);   // recycles the oldest record (blocks only when > recs.size() batches are in flight)
+        if (rc) return rc;
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(cap, total - j0);
+        a.st = s->slices[k];
         a.j0 = j0;
         a.nb = nb;
         size_t ev = 0;
-        auto rec = [&](void) { hipEventRecord(s->events[ev++], stream); };
-        HIP_CHECK(hipMemsetAsync(st.fsd_counter, 0, sizeof(uint32_t), stream));
+        const bool tm = s->timing;
+        auto rec = [&]() {
+            if (tm) hipEventRecord(r.ev[ev++], st_);
+        };
         rec();
-        hipLaunchKernelGGL(k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        rec();
+        const uint32_t g_full = std::min<uint32_t>(grid_round, (2 * nb + kBlock - 1) / kBlock);
+        for (uint32_t round = 0; round < kMaxWalkIters; ++round) {
+            const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
+            // the queue roughly halves every round and is normally empty after ~25: later rounds get smaller persistent grids
+            // (an empty launch costs its grid size; a grid that turns out too small only takes longer, the wavefronts loop)
+            const uint32_t shrink = round < 6 ? 1u : (round < 24 ? 4u : 32u);
+            const uint32_t g0 = std::max<uint32_t>(1u, g_full / shrink);
+            const uint32_t gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, 2 * nb) / (round < 24 ? 1u : 32u));
+            hipLaunchKernelGGL(k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+            rec();
+            hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
+            rec();
+            hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            rec();
+        }
+        hipLaunchKernelGGL(k_connect, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         HIP_CHECK(hipGetLastError());
-        rec();
-        // the first round's queue is the identity over both halves [0,nb) and [cap,cap+nb): materialise it only if nb<cap
-        uint32_t n_active = 2 * nb;
-        int cur = 0;
-        bool first = (nb == st.cap);
-        if (!first) {
-            std::vector<uint32_t> q(2 * (size_t)nb);
-            for (uint32_t i = 0; i < nb; ++i) {
-                q[i] = i;
-                q[nb + i] = (uint32_t)st.cap + i;
-            }
-            HIP_CHECK(hipMemcpyAsync(st.queue[0], q.data(), q.size() * 4, hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-        }
-        uint32_t round = 0;
-        for (; round < kMaxWalkIters && n_active > 0; ++round) {
-            HIP_CHECK(hipMemsetAsync(st.qcount + (1 - cur), 0, sizeof(uint32_t), stream));
-            HIP_CHECK(hipMemsetAsync(st.heavy_count, 0, 2 * sizeof(uint32_t), stream));
-            const dim3 grid((n_active + kBlock - 1) / kBlock);
-            rec();
-            hipLaunchKernelGGL(k_trace, grid, dim3(kBlock), 0, stream, a, st.queue[cur], n_active, first ? 1 : 0);
-            HIP_CHECK(hipGetLastError());
-            rec();
-            {
-                const uint32_t hb = std::min<uint32_t>(n_active, 256u * 16u);
-                hipLaunchKernelGGL(k_trace_heavy, dim3(hb), dim3(64), 0, stream, a);
-                HIP_CHECK(hipGetLastError());
-            }
-            rec();
-            hipLaunchKernelGGL(k_interact, grid, dim3(kBlock), 0, stream, a, st.queue[cur], n_active, first ? 1 : 0, st.queue[1 - cur], st.qcount + (1 - cur));
-            HIP_CHECK(hipGetLastError());
-            rec();
-            HIP_CHECK(hipMemcpyAsync(st.h_qcount, st.qcount + (1 - cur), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            n_active = st.h_qcount[0];
-            cur = 1 - cur;
-            first = false;
-        }
-        s->cap_hits += n_active;
-        rec();
-        hipLaunchKernelGGL(k_connect, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
-        rec();
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipGetLastError());
-        // timings
-        float ms = 0;
-        hipEventElapsedTime(&ms, s->events[0], s->events[1]);
-        t_gen += ms;
-        size_t e = 2;
-        for (uint32_t r = 0; r < round; ++r) {
-            hipEventElapsedTime(&ms, s->events[e], s->events[e + 1]);
-            t_trace += ms;
-            hipEventElapsedTime(&ms, s->events[e + 1], s->events[e + 2]);
-            t_heavy += ms;
-            hipEventElapsedTime(&ms, s->events[e + 2], s->events[e + 3]);
-            t_inter += ms;
-            e += 4;
-            ++n_trace_launches;
-        }
-        hipEventElapsedTime(&ms, s->events[e], s->events[e + 1]);
-        t_conn += ms;
-        rounds_total += round;
-        // fsd pool overflow check
-        uint32_t used = 0;
-        HIP_CHECK(hipMemcpy(&used, st.fsd_counter, 4, hipMemcpyDeviceToHost));
-        (void)used;
+        HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        hipEventRecord(r.ev[tm ? ev : 0], st_);
+        r.busy = true;
     }
-#ifdef WTGPU_DEBUG_HEAVY
-    {
-        std::vector<uint32_t> d(4 + 8 * (size_t)(1u << 20));
-        HIP_CHECK(hipMemcpy(d.data(), st.dbg, d.size() * 4, hipMemcpyDeviceToHost));
-        const uint32_t n = std::min<uint32_t>(d[0], 1u << 20);
-        std::vector<uint32_t> idx(n);
-        for (uint32_t i = 0; i < n; ++i) idx[i] = i;
-        std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return d[4 + 8 * x + 1] > d[4 + 8 * y + 1]; });
-        double tot = 0;
-        for (uint32_t i = 0; i < n; ++i) tot += d[4 + 8 * i + 1];
-        fprintf(stderr, "heavy items %u, total ticks %.3g (= %.1f wave-ms)\n", d[0], tot, tot / 1e5);
-        for (uint32_t q : {0u, n / 1000, n / 100, n / 10, n / 2}) if (q < n) fprintf(stderr, "  rank %u ticks %u\n", q, d[4 + 8 * idx[q] + 1]);
-        for (uint32_t i = 0; i < std::min<uint32_t>(n, 25); ++i) {
-            const uint32_t* r = &d[4 + 8 * idx[i]];
-            float x0, dist, dz, oz;
-            memcpy(&x0, r + 4, 4); memcpy(&dist, r + 5, 4); memcpy(&dz, r + 6, 4); memcpy(&oz, r + 7, 4);
-            fprintf(stderr, "  w=%u ms=%.2f nray=%u ncone=%u empty=%u ball=%u hits=%u x0=%g dist=%g dz=%g oz=%g\n", r[0], r[1] / 1e5, r[2] & 255, (r[2] >> 8) & 255,
-                    (r[2] >> 16) & 1, (r[2] >> 17) & 1, r[3], x0, dist, dz, oz);
+    // ... and the caller's stream continues after all of them
+    for (size_t k = 0; k < n_slices; ++k)
+        if (used[k]) {
+            HIP_CHECK(hipEventRecord(s->ev_done[k], s->streams[k]));
+            HIP_CHECK(hipStreamWaitEvent(caller, s->ev_done[k], 0));
         }
-        HIP_CHECK(hipMemset(st.dbg, 0, 16));
-    }
-#endif
     s->samples_rendered += total;
-    s->timings[0] = t_gen;
-    s->timings[1] = t_trace;
-    s->timings[2] = t_inter;
-    s->timings[3] = t_conn;
-    s->timings[4] = (float)rounds_total;
-    s->timings[5] = (float)n_trace_launches;
-    s->timings[6] = (float)((total + st.cap - 1) / st.cap);
-    s->timings[7] = t_heavy;
     return WTGPU_OK;
 }
 
-int wtgpu_last_render_timings(const wtgpu_scene* s, float out[8]) {
-    if (!s || !out) return fail(WTGPU_ERR_INVALID, "null argument");
-    std::memcpy(out, s->timings, sizeof(s->timings));
+int wtgpu_last_render_timings(wtgpu_scene* s, float out[8]) {
+    if (!s || !out || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
+    const int rc = drain_all(s);
+    if (rc) return rc;
+    for (int i = 0; i < 8; ++i) out[i] = (float)s->acc[i];
     return WTGPU_OK;
 }
 
 int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     if (!s || !out || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     bdpt_counters_t c;
-    HIP_CHECK(hipMemcpy(&c, s->st.counters, sizeof(c), hipMemcpyDeviceToHost));
+    {
+        const int rc = drain_all(s);
+        if (rc) return rc;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(&c, s->slices[0].counters, sizeof(c), hipMemcpyDeviceToHost));
     out->samples = s->samples_rendered;
     out->segments = c.segments;
     out->ray_queries = c.ray_queries;
@@ -704,13 +831,25 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     out->surface_interactions = c.surface_interactions;
     out->light_splats = c.light_splats;
     out->walk_iteration_cap_hits = s->cap_hits;
+    if (getenv("WTGPU_PROFILE")) {
+        unsigned long long p[8];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[wtgpu profile] heavy items %llu: clock ticks ray %llu probe %llu cone %llu total %llu (per item: ray %.0f probe %.0f cone %.0f total %.0f; cone+probe phase A %.0f phase B %.0f)\n", p[4], p[0],
+                p[1], p[2], p[3], p[4] ? double(p[0]) / p[4] : 0., p[4] ? double(p[1]) / p[4] : 0., p[4] ? double(p[2]) / p[4] : 0., p[4] ? double(p[3]) / p[4] : 0., p[4] ? double(p[5]) / p[4] : 0., p[4] ? double(p[6]) / p[4] : 0.);
+    }
     return WTGPU_OK;
 }
 int wtgpu_reset_counters(wtgpu_scene* s) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
-    HIP_CHECK(hipMemset(s->st.counters, 0, (kNumCounters + 2) * sizeof(unsigned long long)));
+    {
+        const int rc = drain_all(s);
+        if (rc) return rc;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemset(s->slices[0].counters, 0, (kNumCounters + 8) * sizeof(unsigned long long)));
     s->samples_rendered = 0;
     s->cap_hits = 0;
+    for (double& v : s->acc) v = 0;
     return WTGPU_OK;
 }
 
@@ -753,8 +892,14 @@ void wtgpu_scene_destroy(wtgpu_scene* s) {
     if (s->uploaded) {
         hipSetDevice(s->device);
         for (void* p : s->dev_allocs) hipFree(p);
-        if (s->st.h_qcount) hipHostFree(s->st.h_qcount);
-        for (auto& e : s->events) hipEventDestroy(e);
+        hipDeviceSynchronize();
+        for (auto& r : s->recs) {
+            for (auto& e : r.ev) hipEventDestroy(e);
+            if (r.h_ctl) hipHostFree(r.h_ctl);
+        }
+        for (auto& e : s->ev_done) hipEventDestroy(e);
+        if (s->ev_begin) hipEventDestroy(s->ev_begin);
+        for (auto& st_ : s->streams) hipStreamDestroy(st_);
     }
     delete s;
 }
