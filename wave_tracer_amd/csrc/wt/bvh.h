@@ -179,6 +179,7 @@ struct cone_hit_t {
     uint32_t ntris;      // triangles written to the list
     uint32_t overflow;   // triangles dropped because the list was full
     uint32_t aborted;    // work budget exceeded
+    uint32_t too_short;  // early exit: the closest hit is already known to lie within `min_progress` of the search start
 };
 
 // intersection_record_work_t::search_range (traversal_common.hpp:76-83)
@@ -193,12 +194,14 @@ WT_HD range_t cone_search_range(const cone_t& cone, const range_t& searchrange, 
 // `budget`: maximum number of cone-triangle tests; when exceeded the query stops and rec.aborted is set (the device
 // hands such heavy queries to the wavefront-cooperative traversal, wtgpu.hip: coop_cone).
 WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack,
-                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr, uint32_t budget = 0xFFFFFFFFu) {
+                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr, uint32_t budget = 0xFFFFFFFFu,
+                             float min_progress = -WT_INF) {
     rec.dist = WT_INF;
     rec.front_face = 0;
     rec.ntris = 0;
     rec.overflow = 0;
     rec.aborted = 0;
+    rec.too_short = 0;
     uint32_t tests = 0;
     if (sc.n_nodes == 0) return false;
     const vec3 ro = cone.o, rd = cone.d;
@@ -241,6 +244,12 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
                 }
             }
             if (found) {
+                // integrator::traverse discards a diffusive hit closer than `min_progress` to the start of the search
+                // (traversal.hpp:146,157); the closest distance only ever decreases, so the outcome is decided right here
+                if (rec.dist - searchrange.min < min_progress) {
+                    rec.too_short = 1;
+                    return true;
+                }
                 range = cone_search_range(cone, searchrange, rec.dist, z_scale);
                 // Bounded-list regime (device only; the CPU checker's list never saturates): once the triangle list is full
                 // nothing further can be recorded, so only triangles that can still lower the closest distance matter.
@@ -446,20 +455,15 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;
-        if (probe_first) {
-            bool ab;
-            const bool near_hit = bvh_cone_any_hit(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, stack, cone_budget, ab, ctr);
-            if (ab) {
-                r.aborted = 1;
-                return r;
-            }
-            if (near_hit) continue;   // closest hit would be < dist + min_df_prog: too short, continue the ballistic path
-        }
-        bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr, cone_budget);
+        // probe_first (device): stop the query as soon as its closest hit is known to be too near to be accepted (result-
+        // equivalent: the reference completes the query and then discards it, traversal.hpp:146,157)
+        bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr, cone_budget,
+                          probe_first ? min_df_prog : -WT_INF);
         if (ch.aborted) {
             r.aborted = 1;
             return r;
         }
+        if (ch.too_short) continue;
         const bool df_empty = ch.ntris == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;

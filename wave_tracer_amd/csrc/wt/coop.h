@@ -81,7 +81,7 @@ __device__ inline bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec
 //     any_hit = true : the any-hit probe (bvh_cone_any_hit): returns at the first batch with a hit.
 template <bool any_hit>
 __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
-                                       const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr) {
+                                       const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr, float min_progress = -WT_INF) {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
     rec.dist = WT_INF;
@@ -89,6 +89,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
     rec.ntris = 0;
     rec.overflow = 0;
     rec.aborted = 0;
+    rec.too_short = 0;
     if (sc.n_nodes == 0) return false;
     const vec3 ro = cone.o, rd = cone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
@@ -153,6 +154,11 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 const int src = __ffsll((long long)m2) - 1;
                 rec.front_face = (uint32_t)__shfl((int)ff, src, 64);
                 rec.dist = dm;
+                if (rec.dist - searchrange.min < min_progress) {   // decided: too near to be accepted (see bvh_traverse_cone)
+                    rec.too_short = 1;
+                    any = true;
+                    break;
+                }
                 range = cone_search_range(cone, searchrange, rec.dist, z_scale);
                 slab_max = range.max;
                 compact(slab_max);   // the slab shrank: listed triangles beyond it leave (and make room)
@@ -265,15 +271,15 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
         if (!found_any && nsurv > 0 && (s == 0 || nsurv >= kCoopFlushAt)) found_any = flush();
         __syncthreads();
         if (prof) prof[6] += (unsigned long long)(clock64() - tb0);
-        if (any_hit && found_any) return true;
+        if (found_any && (any_hit || rec.too_short)) return true;
         if (s == 0) break;
     }
     return rec.ntris > 0;
 }
 
 __device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
-                                 const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr) {
-    coop_cone_query<false>(sc, cone, searchrange, z_scale, sh, tris, rec, prof);
+                                 const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr, float min_progress = -WT_INF) {
+    coop_cone_query<false>(sc, cone, searchrange, z_scale, sh, tris, rec, prof, min_progress);
 }
 // Wave-cooperative any-hit probe (see bvh_cone_any_hit).
 __device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh, unsigned long long* prof = nullptr) {
@@ -469,13 +475,16 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;
+        // A thin-slab any-hit probe first: for wide beams it is far cheaper than letting the full (near-first, 8-wide) query find
+        // a too-near hit, which expands the whole cone's top levels before its first triangle batch (measured: 1.6x slower).
         const long long tp0 = prof ? clock64() : 0;
         const bool near_hit = coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh, prof);
         WT_COOP_PROF(1, tp0)
         if (near_hit) continue;   // too short (see bvh_cone_any_hit)
         const long long tc0 = prof ? clock64() : 0;
-        coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch, prof);
+        coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch, prof, min_df_prog);
         WT_COOP_PROF(2, tc0)
+        if (ch.too_short) continue;   // (boundary case of the probe's inclusive slab)
         const bool df_empty = ch.ntris == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;

@@ -55,7 +55,8 @@ int fail(int code, const std::string& msg) {
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_WORDS = 16 };
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_WORDS = 16 };
+constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
 
 struct device_state_t {
     uint64_t cap = 0;   // samples per batch
@@ -71,6 +72,10 @@ struct device_state_t {
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
     uint32_t fsd_cap = 0;
+    uint32_t* strat_items = nullptr;    // [kNumKeys][cap] sample indices bucketed by connection strategy (s,t)
+    uint32_t* strat_count = nullptr;    // [kNumKeys]
+    uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
+    double* lacc = nullptr;             // [4][cap] per-sample sum of the t>1 strategies' fluxes
     unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
@@ -388,49 +393,117 @@ __global__ void __launch_bounds__(kBlock, 3) k_interact(launch_args_t a, int in,
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-__global__ void __launch_bounds__(kBlock) k_connect(launch_args_t a) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+// ---- connections: strategy-major -------------------------------------------------------------------------------------
+// plt_bdpt.cpp:105-146 loops over all (s,t) pairs of a sample.  One thread per sample would leave a wavefront executing the
+// UNION of its 64 samples' pairs (~80 iterations with ~10 lanes' worth of work: subpath lengths are geometric).  Instead:
+//   k_connect_enum  : every sample appends its index to one bucket per valid (s,t) pair (wave-aggregated atomics),
+//   k_connect_scan  : prefix sum over the 19x19 bucket sizes,
+//   k_connect_strat : persistent; 64 consecutive items of the flattened bucket space = 64 samples with the SAME (s,t): uniform
+//                     control flow, coalesced vertex loads; the t>1 fluxes are summed per sample (f64 atomics), t<=1 strategies
+//                     splat into the light image directly,
+//   k_connect_splat : one film splat per sample with the summed flux (film.hpp:214-342).
+__device__ inline bool strategy_valid(const integrator_opts_t& o, int s, int t, int nS, int nT) {
+    const int depth = t + s - 2;
+    if (t > nT || s > nS) return false;
+    if ((t == 1 && s == 1) || depth < 0 || depth > o.max_depth) return false;
+    if (!o.emitter_direct && s == 1) return false;
+    if (!o.sensor_direct && t == 1) return false;
+    if (o.debug_only_s && (int)o.debug_only_s - 1 != s) return false;
+    if (o.debug_only_t && (int)o.debug_only_t - 1 != t) return false;
+    return true;
+}
+__device__ inline int wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_connect_enum(launch_args_t a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    int nT = -1, nS = -1;
+    if (i < a.nb) {
+        nT = (int)a.st.walks[WT_WALK_NVERTS_WORD * W2 + i];
+        nS = (int)a.st.walks[WT_WALK_NVERTS_WORD * W2 + a.st.cap + i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a.st.lacc[(size_t)c * a.st.cap + i] = 0.0;
+    }
+    const int mT = wave_max_i(nT), mS = wave_max_i(nS);
+    for (int t = 0; t <= mT; ++t)
+        for (int s = 0; s <= mS; ++s) {
+            const bool v = i < a.nb && strategy_valid(a.sc.opts, s, t, nS, nT);
+            const uint32_t key = (uint32_t)t * kKeyDim + (uint32_t)s;
+            wave_append(a.st.strat_items + (size_t)key * a.st.cap, a.st.strat_count + key, v, i);
+        }
+}
+__global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < kNumKeys; ++k) {
+            const uint32_t c = a.st.strat_count[k];
+            a.st.strat_prefix[k] = acc;
+            acc += c;
+            a.st.strat_count[k] = 0;   // ready for the next batch
+        }
+        a.st.strat_prefix[kNumKeys] = acc;
+        a.st.ctl[CTL_STRAT_HEAD] = 0;
+    }
+}
+__global__ void __launch_bounds__(kBlock, 3) k_connect_strat(launch_args_t a) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    __shared__ uint32_t s_prefix[kNumKeys + 1];
+    for (uint32_t k = threadIdx.x; k <= kNumKeys; k += blockDim.x) s_prefix[k] = a.st.strat_prefix[k];
+    __syncthreads();
+    const uint32_t total = s_prefix[kNumKeys];
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
-    if (i < a.nb) {
-        const size_t W2 = 2 * (size_t)a.st.cap;
-        const uint64_t j = a.j0 + i;
-        const uint32_t pix = (uint32_t)(j % a.npix);
-        const uint64_t s = a.sample_begin + j / a.npix;
-        const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-        sample_ctx_t ctx;
-        soa_load(a.st.ctx, (size_t)a.st.cap, i, ctx);
-        const vertex_store_t svs{a.st.verts, W2, i}, evs{a.st.verts, W2, (size_t)a.st.cap + i};
-        const uint32_t nT = a.st.walks[WT_WALK_NVERTS_WORD * W2 + i];
-        const uint32_t nS = a.st.walks[WT_WALK_NVERTS_WORD * W2 + a.st.cap + i];
-        stack_entry_t spill[kSpillStack];
-        stack_ref_t stack;
-        lds_stack(lds, spill, stack);
-        const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
-#ifdef WTGPU_DEBUG_PRINT
-        if (i == 0)
-            printf("dbg k=%g recp=%g kd=%g el=(%u,%u) nT=%u nS=%u resp=%g %g %g spec0 type %d kmin %g kmax %g off %u cnt %u\n", ctx.k, ctx.recp_spectral_pd,
-                   ctx.k_density, ctx.element.x, ctx.element.y, nT, nS, spectrum_f(a.sc, a.sc.sensor.response_spec[0], ctx.k),
-                   spectrum_f(a.sc, a.sc.sensor.response_spec[1], ctx.k), spectrum_f(a.sc, a.sc.sensor.response_spec[2], ctx.k),
-                   a.sc.spectra[a.sc.sensor.response_spec[0]].type, a.sc.spectra[a.sc.sensor.response_spec[0]].kmin,
-                   a.sc.spectra[a.sc.sensor.response_spec[0]].kmax, a.sc.spectra[a.sc.sensor.response_spec[0]].offset,
-                   a.sc.spectra[a.sc.sensor.response_spec[0]].count);
-#endif
-        bdpt_connect_all(a.sc, pool, a.film, svs, evs, (int)nT, (int)nS, ctx, a.seed, sample_id, stack, &ctr, nullptr);
-#ifdef WTGPU_DEBUG_PRINT
-        if (i == 0) {
-            connect_ret_t cr;
-            bdpt_connect(a.sc, pool, svs, evs, 0, 2, a.seed, sample_id, stack, cr, nullptr, nullptr);
-            vertex_t last;
-            svs.load(1, last);
-            printf("dbg2 L02=%g type %u emitter_of_shape %d beam scale %g rad0 %g k %g rr %g film.value[0]=%g weight[0]=%g ptrs %p %p %p\n", cr.L.s[0], last.type,
-                   last.emitter_of_shape, last.beam.scale, last.beam.rad[0], last.beam.k, last.rr_weight, a.film.value[0], a.film.weight[0], a.film.value,
-                   a.film.weight, a.film.light);
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
+    for (;;) {
+        const uint32_t idx = wave_grab(a.st.ctl + CTL_STRAT_HEAD) + (threadIdx.x & 63);
+        if (idx - (threadIdx.x & 63) >= total) break;
+        if (idx < total) {
+            // bucket of this item: last key with prefix <= idx
+            uint32_t lo = 0, hi = kNumKeys;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_prefix[mid] <= idx)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const uint32_t key = lo;
+            const int t = (int)(key / kKeyDim), s = (int)(key % kKeyDim);
+            const uint32_t i = a.st.strat_items[(size_t)key * a.st.cap + (idx - s_prefix[key])];
+            const uint64_t j = a.j0 + i;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t smp = a.sample_begin + j / a.npix;
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
+            sample_ctx_t ctx;
+            soa_load(a.st.ctx, (size_t)a.st.cap, i, ctx);
+            const vertex_store_t svs{a.st.verts, W2, i}, evs{a.st.verts, W2, (size_t)a.st.cap + i};
+            const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
+            if (t > 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
+            }
         }
-#endif
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+__global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nb) return;
+    sample_ctx_t ctx;
+    soa_load(a.st.ctx, (size_t)a.st.cap, i, ctx);
+    stokes_t L;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) L.s[c] = (float)a.st.lacc[(size_t)c * a.st.cap + i];
+    film_splat(a.sc, a.film, ctx.element, L, ctx.k);
 }
 
 // ---- per-query kernels (traversal parity tests) --------------------------------------------------------------------
@@ -658,6 +731,11 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
         if ((rc = dmalloc(s, &st.fsd_hdr, st.fsd_cap))) return rc;
         if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_cap * kFsdMaxEdges))) return rc;
+        if ((rc = dmalloc(s, &st.strat_items, (size_t)kNumKeys * st.cap))) return rc;
+        if ((rc = dmalloc(s, &st.strat_count, (size_t)kNumKeys))) return rc;
+        if ((rc = dmalloc(s, &st.strat_prefix, (size_t)kNumKeys + 1))) return rc;
+        if ((rc = dmalloc(s, &st.lacc, 4 * (size_t)st.cap))) return rc;
+        HIP_CHECK(hipMemset(st.strat_count, 0, kNumKeys * sizeof(uint32_t)));
         HIP_CHECK(hipStreamCreateWithFlags(&s->streams[k], hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&s->ev_done[k], hipEventDisableTiming));
     }
@@ -782,7 +860,10 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
         }
-        hipLaunchKernelGGL(k_connect, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        hipLaunchKernelGGL(k_connect_enum, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        hipLaunchKernelGGL(k_connect_scan, dim3(1), dim3(64), 0, st_, a);
+        hipLaunchKernelGGL(k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
+        hipLaunchKernelGGL(k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
         hipEventRecord(r.ev[tm ? ev : 0], st_);
