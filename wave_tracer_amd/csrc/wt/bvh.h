@@ -173,6 +173,28 @@ WT_HD bool ads_shadow_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& ra
 }
 
 // ---- cone --------------------------------------------------------------------------------------
+// Extra conservative culling of a child box against (cone ∩ z-slab), not in the reference (result-preserving: a culled box
+// cannot contain a point of the cone inside `range`).  The reference's test below grows the box by the cone radius at its far
+// z and slab-tests the AXIS against it, which for wide beams lets through everything beside a thin slab; these two tests bound
+// the box itself: (1) its extent along the axis must overlap the slab, (2) the lateral distance of its bounding sphere from
+// the axis must not exceed the cone's radius at the largest admissible z (containment x^2+(e y)^2 <= r(z)^2 with e >= 1
+// implies Euclidean lateral distance <= r(z) <= r(z_hi)).  b0/b1: box corners relative to the cone origin.
+WT_HD bool cone_box_outside(float b0x, float b0y, float b0z, float b1x, float b1y, float b1z, vec3 rd, float ta, float ix, const range_t& range) {
+    const float cx = 0.5f * (b0x + b1x), cy = 0.5f * (b0y + b1y), cz = 0.5f * (b0z + b1z);
+    const float hx = 0.5f * (b1x - b0x), hy = 0.5f * (b1y - b0y), hz = 0.5f * (b1z - b0z);
+    const float zc = cx * rd.x + cy * rd.y + cz * rd.z;
+    const float he = fabsf(rd.x) * hx + fabsf(rd.y) * hy + fabsf(rd.z) * hz;
+    const float slack = 1e-5f * (fabsf(zc) + he) + 1e-12f;
+    if (zc - he > range.max + slack || zc + he < range.min - slack) return true;
+    const float rho2 = fmaxf_(0.f, cx * cx + cy * cy + cz * cz - zc * zc);
+    const float rbox = sqrtf(hx * hx + hy * hy + hz * hz);
+    const float zhi = fminf_(range.max, zc + he);
+    const float rcone = fmaxf_(0.f, fmaf(zhi, ta, ix));
+    const float lim = (rcone + rbox) * 1.0005f + slack;
+    return finitef(lim) && rho2 > lim * lim;
+}
+
+
 struct cone_hit_t {
     float dist;   // closest intersection distance (+inf: none)
     uint32_t front_face;
@@ -272,6 +294,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             // cone_cluster_intersect (bvh8w.cpp:187-230): grow the box by the cone radius at its far z
             float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
             float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+            const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
             const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
             const float dot_d_b = rd.x * bx + rd.y * by + rd.z * bz;
             const float maxz = clampf(dot_d_b, 0.f, range.max);
@@ -294,6 +317,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             const bool hit = tmin <= tmax && tmax >= range.min && tmin <= range.max;
             if (!hit) continue;
             if (tmin >= range.max) continue;
+            if (cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) continue;
             if (s < (int)stack.cap) stack[s++] = stack_entry_t{tmin, cp};
         }
         stack_sort_desc(stack, begin, s);
@@ -347,6 +371,7 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             if (cp == 0) continue;
             float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
             float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+            const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
             const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
             const float maxz = clampf(rd.x * bx + rd.y * by + rd.z * bz, 0.f, range.max);
             const float enlr = fmaf(maxz, ta, ix);
@@ -361,7 +386,9 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             tmin = fmaxf_(tmin, dminy);
             tmax = fminf_(tmax, dmaxz);
             tmin = fmaxf_(tmin, dminz);
-            if (tmin <= tmax && tmax >= range.min && tmin <= range.max && s < (int)stack.cap) stack[s++] = stack_entry_t{tmin, cp};
+            if (tmin <= tmax && tmax >= range.min && tmin <= range.max && !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range) &&
+                s < (int)stack.cap)
+                stack[s++] = stack_entry_t{tmin, cp};
         }
         stack_sort_desc(stack, begin, s);
     }

@@ -46,6 +46,7 @@ __device__ inline bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec
                                        const range_t& range, float& tmin_out) {
     float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
     float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+    const bool outside = cone_box_outside(ominx, ominy, ominz, omaxx, omaxy, omaxz, rd, ta, ix, range);
     const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
     const float dot_d_b = rd.x * bx + rd.y * by + rd.z * bz;
     const float maxz = clampf(dot_d_b, 0.f, range.max);
@@ -66,7 +67,7 @@ __device__ inline bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec
     tmax = fminf_(tmax, dmaxz);
     tmin = fmaxf_(tmin, dminz);
     tmin_out = tmin;
-    return tmin <= tmax && tmax >= range.min && tmin <= range.max && !(tmin >= range.max);
+    return !outside && tmin <= tmax && tmax >= range.min && tmin <= range.max && !(tmin >= range.max);
 }
 
 // One wavefront, one cone query.  Must be called by all 64 lanes of a 64-thread block with identical arguments.
@@ -185,6 +186,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
         const long long ta0 = prof ? clock64() : 0;
         while (s > 0 && leaf_total < 64u) {
             const int np = s < 8 ? s : 8;
+            if (prof) prof[7] += 1ull + ((unsigned long long)np << 32);
             stack_entry_t e{0.f, 0};
             if (grp < np) e = sh.stack[s - 1 - grp];
             s -= np;
@@ -201,14 +203,17 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                     cnt = leaf.count;
                     leafish = true;
                 } else {
+                    // all loads of the node are issued before anything depends on them (one memory latency per step, not two)
                     const bvh8_node_t& node = sc.nodes[e.ptr - 1];
-                    if (node.tris_count <= kCoopLeafTris) {
-                        t0 = node.tris_start;
-                        cnt = node.tris_count;
+                    const uint32_t ntc = node.tris_count, nts = node.tris_start;
+                    cp = node.child[sub];
+                    const bool hc = cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
+                    if (ntc <= kCoopLeafTris) {
+                        t0 = nts;
+                        cnt = ntc;
                         leafish = true;
                     } else {
-                        cp = node.child[sub];
-                        if (cp != 0) h = cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
+                        h = hc && cp != 0;
                     }
                 }
             }
@@ -326,13 +331,14 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
                     leafish = true;
                 } else {
                     const bvh8_node_t& n = sc.nodes[e.ptr - 1];
-                    if (n.tris_count <= kCoopLeafTris) {
-                        t0 = n.tris_start;
-                        cnt = n.tris_count;
+                    const uint32_t ntc = n.tris_count, nts = n.tris_start;
+                    cp = n.child[sub];
+                    if (ntc <= kCoopLeafTris) {
+                        t0 = nts;
+                        cnt = ntc;
                         leafish = true;
                     } else {
-                        cp = n.child[sub];
-                        if (cp != 0) {
+                        {
                             const int i = sub;
                             const float tfar = fminf_(rec.dist, range.max);
                             const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
@@ -343,7 +349,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
                             const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
                             const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, range.min));
                             const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
-                            h = rmin <= rmax;
+                            h = rmin <= rmax && cp != 0;
                             tmin = rmin;
                         }
                     }

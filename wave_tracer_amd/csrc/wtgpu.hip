@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(64, 4) k_trace_heavy(launch_args_t a) {
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
             atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
             atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
+            atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
             atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
         }
         if (threadIdx.x == 0) {
@@ -915,8 +916,8 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     if (getenv("WTGPU_PROFILE")) {
         unsigned long long p[8];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[wtgpu profile] heavy items %llu: clock ticks ray %llu probe %llu cone %llu total %llu (per item: ray %.0f probe %.0f cone %.0f total %.0f; cone+probe phase A %.0f phase B %.0f)\n", p[4], p[0],
-                p[1], p[2], p[3], p[4] ? double(p[0]) / p[4] : 0., p[4] ? double(p[1]) / p[4] : 0., p[4] ? double(p[2]) / p[4] : 0., p[4] ? double(p[3]) / p[4] : 0., p[4] ? double(p[5]) / p[4] : 0., p[4] ? double(p[6]) / p[4] : 0.);
+        fprintf(stderr, "[wtgpu profile] heavy items %llu: clock ticks ray %llu probe %llu cone %llu total %llu (per item: ray %.0f probe %.0f cone %.0f total %.0f; cone+probe phase A %.0f phase B %.0f; phase-A steps %.1f entries %.1f)\n", p[4], p[0],
+                p[1], p[2], p[3], p[4] ? double(p[0]) / p[4] : 0., p[4] ? double(p[1]) / p[4] : 0., p[4] ? double(p[2]) / p[4] : 0., p[4] ? double(p[3]) / p[4] : 0., p[4] ? double(p[5]) / p[4] : 0., p[4] ? double(p[6]) / p[4] : 0., p[4] ? double(p[7] & 0xffffffffull) / p[4] : 0., p[4] ? double(p[7] >> 32) / p[4] : 0.);
     }
     return WTGPU_OK;
 }
