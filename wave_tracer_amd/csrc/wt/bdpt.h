@@ -400,11 +400,22 @@ WT_HD bool walk_continue(const scene_t& sc, walk_t& w, const vertex_store_t& vs,
 // Hand-over record of a Fraunhofer-FSD rejection loop that a device lane could not finish within kFsdInlineTries (fsd.h):
 // pending = the step returned early, nothing committed; resolved = the wavefront found the outcome, re-run the step with it.
 struct fsd_defer_t {
+    uint32_t split_no_primary, no_primary;   // in: defer walks without a primary triangle; out: this walk is one
+    uint32_t known_no_primary;               // in: the first pass already found no primary triangle (skip the search)
     uint32_t pending, resolved;
     uint32_t slot, base, next_try, end_draws;
     fsd_sample_t fs;
+#ifdef WTGPU_STEP_PROF
+    long long marks[8];
+#endif
 };
 
+#if defined(WTGPU_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define WT_STEP_MARK(i) \
+    if (defer) defer->marks[i] = clock64()   // profiling hook of debug builds (-DWTGPU_STEP_PROF)
+#else
+#define WT_STEP_MARK(i) ((void)0)
+#endif
 // Returns TRUE if the walk continues (another segment must be traced).
 template <class TriList>
 WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr, const TriList& tris, const vertex_store_t& vs,
@@ -440,7 +451,9 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         // select the same triangle (closest axis hit inside the slab); the CPU checker keeps the reference's list scan.
         // The BVH query is only needed when the list was actually truncated (tr.overflow > 0, a few per cent of the segments);
         // a complete list is scanned like the reference does (a handful of ray-triangle tests instead of a tree traversal).
-        if (primary_query_stack && tr.overflow > 0) {
+        if (defer && defer->known_no_primary) {
+            // second pass of a walk the first pass found no primary triangle for
+        } else if (primary_query_stack && tr.overflow > 0) {
             const float wtol = cone_intersection_tolerance(origin_wp, sc.world_min, sc.world_max, sc.world_max);
             ray_hit_t rh;
             if (ads_intersect_ray(sc, origin_wp, beam.env.d, grow(izr, wtol), *primary_query_stack, rh)) {
@@ -464,6 +477,14 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                 phit = h;
             }
         }
+        // Device, first pass (k_interact): the beam axis misses every listed triangle — what follows (footprint integrals over
+        // the whole list, edge gathering, aperture construction, FSD sampling) costs ~50x a surface interaction and concerns
+        // ~8 % of the walks; those are handed to a second pass (k_interact_b) so that they do not stall the other 63 lanes.
+        if (primary == kInvalid && defer && defer->split_no_primary) {
+            defer->no_primary = 1;
+            return false;   // nothing has been committed
+        }
+        WT_STEP_MARK(0);
         if (primary == kInvalid) {
             const float csz = centre(izr);
             for (uint32_t i = 0; i < tr.ntris; ++i) {
@@ -538,6 +559,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
             }
         }
     } else {
+        WT_STEP_MARK(1);
         // gather the ordered, de-duplicated edge set of the interaction region (traversal_common.hpp:124-148)
         uint32_t edge_ids[kMaxEdgeIds];
         uint32_t n_edge_ids = 0;
@@ -560,6 +582,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                 }
             }
         }
+        WT_STEP_MARK(2);
         if (n_edge_ids > 0) {
             // ---- sample_fraunhofer_fsd_interaction (plt_bdpt_detail.hpp:287-346)
             const float I = 1.f - integrated_flux;
@@ -575,6 +598,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                     ap = pool.hdr[slot];
                 } else {
                     fsd_build_aperture(sc, beam_frame, beam.k, I, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
+                    WT_STEP_MARK(3);
                     pool.hdr[slot] = ap;
                     if (ctr && ap.overflow) ctr->fsd_edge_overflow += ap.overflow;
                 }
@@ -638,8 +662,10 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
             if (ctr) ctr->null_interactions++;
         }
     }
+    WT_STEP_MARK(4);
     bool cont = false;
     if (ok) cont = walk_continue(sc, w, vs, do_RR, smp);
+    WT_STEP_MARK(5);
     w.rng_draws = smp.draws;
     return cont;
 }

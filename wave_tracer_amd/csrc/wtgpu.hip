@@ -55,7 +55,7 @@ int fail(int code, const std::string& msg) {
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_WORDS = 16 };
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_WORDS = 16 };
 constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
 
 struct device_state_t {
@@ -68,6 +68,7 @@ struct device_state_t {
     uint32_t* tris = nullptr;     // [kMaxConeTris][2cap]
     uint32_t* queue[2] = {nullptr, nullptr};
     uint32_t* heavy_queue = nullptr;   // walks whose traversal exceeded the per-lane budget
+    uint32_t* intb_queue = nullptr;    // walks whose interaction takes the expensive (no primary triangle) path
     uint32_t* ctl = nullptr;           // [CTL_WORDS] queue sizes, dequeue heads, FSD pool bump counter, rounds done
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         ctl[CTL_COUNT0] = 2 * a.nb;
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -211,6 +213,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_trace(launch_args_t a, int in, in
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
         ctl[CTL_HEAD_INTERACT] = 0;
+        ctl[CTL_INTB_COUNT] = 0;
+        ctl[CTL_INTB_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -290,11 +294,13 @@ __global__ void __launch_bounds__(64, 4) k_trace_heavy(launch_args_t a) {
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-__global__ void __launch_bounds__(kBlock, 3) k_interact(launch_args_t a, int in, int first_round) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+// Interaction step of the queued walks.  PASS_B = false: the queue of the round; walks whose beam axis misses every listed
+// triangle (expensive path, see bdpt_walk_step) are only appended to the pass-B queue.  PASS_B = true: that queue, full step.
+template <bool PASS_B>
+__device__ inline void interact_body(const launch_args_t& a, int in, int first_round, stack_entry_t* lds) {
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_COUNT0 + in];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in];
+    if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
         ctl[CTL_HEAD_TRACE] = 0;
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_interact(launch_args_t a, int in,
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
     for (;;) {
-        const uint32_t qi = wave_grab(ctl + CTL_HEAD_INTERACT) + (threadIdx.x & 63);
+        const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
         bool cont = false;
         uint32_t w = 0, stream = 0;
@@ -315,30 +321,44 @@ __global__ void __launch_bounds__(kBlock, 3) k_interact(launch_args_t a, int in,
         fsd_defer_t defer;
         defer.pending = defer.resolved = 0;
         defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
-        if (qi < n) {
-            w = queue_walk(a, a.st.queue[in], qi, first_round);
+        defer.split_no_primary = PASS_B ? 0u : 1u;
+        defer.known_no_primary = PASS_B ? 1u : 0u;
+        defer.no_primary = 0;
+        bool todo = qi < n;
+        if (todo) {
+            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round);
             uint32_t i;
             walk_ident(a, w, i, stream);
             const uint64_t j = a.j0 + i;
             const uint32_t pix = (uint32_t)(j % a.npix);
             const uint64_t s = a.sample_begin + j / a.npix;
             sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-            walk_t wk;
-            soa_load(a.st.walks, W2, w, wk);
-            trav_result_t tr;
-            soa_load(a.st.trav, W2, w, tr);
-            const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
-            const vertex_store_t vs{a.st.verts, W2, w};
-            cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
-            if (!defer.pending) {
-                wk.active = cont ? 1u : 0u;
-                soa_store(a.st.walks, W2, w, wk);
-            }
         }
-        // ---- Fraunhofer-FSD rejection loops that did not finish within kFsdInlineTries: the wavefront finishes them one after
-        // the other, 64 tries per step (tries are independent, fsd.h), then the owning lane re-runs its step with the outcome.
-        unsigned long long pm = __ballot(defer.pending != 0);
-        if (pm) {
+        // at most two executions of the step: the second only for lanes whose Fraunhofer-FSD rejection loop was finished by
+        // the wavefront in between (pass B)
+        for (int pass = 0; pass < (PASS_B ? 2 : 1); ++pass) {
+            if (todo) {
+                walk_t wk;
+                soa_load(a.st.walks, W2, w, wk);
+                trav_result_t tr;
+                soa_load(a.st.trav, W2, w, tr);
+                const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+                const vertex_store_t vs{a.st.verts, W2, w};
+                defer.pending = 0;
+                cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
+                if (!defer.pending) {
+                    todo = false;
+                    if (!defer.no_primary) {
+                        wk.active = cont ? 1u : 0u;
+                        soa_store(a.st.walks, W2, w, wk);
+                    }
+                }
+            }
+            if (!PASS_B) break;
+            // ---- Fraunhofer-FSD rejection loops that did not finish within kFsdInlineTries: the wavefront finishes them one after
+            // the other, 64 tries per step (tries are independent, fsd.h), then the owning lane re-runs its step with the outcome.
+            unsigned long long pm = __ballot(todo && defer.pending != 0);
+            if (!pm) break;
             const int lane = threadIdx.x & 63;
             while (pm) {
                 const int L = __ffsll((long long)pm) - 1;
@@ -376,22 +396,20 @@ __global__ void __launch_bounds__(kBlock, 3) k_interact(launch_args_t a, int in,
                     defer.resolved = 1;
                 }
             }
-            if (defer.resolved) {
-                walk_t wk;
-                soa_load(a.st.walks, W2, w, wk);
-                trav_result_t tr;
-                soa_load(a.st.trav, W2, w, tr);
-                const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
-                const vertex_store_t vs{a.st.verts, W2, w};
-                defer.pending = 0;
-                cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
-                wk.active = cont ? 1u : 0u;
-                soa_store(a.st.walks, W2, w, wk);
-            }
         }
+        if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
         wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
+__global__ void __launch_bounds__(kBlock, 4) k_interact(launch_args_t a, int in, int first_round) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    interact_body<false>(a, in, first_round, lds);
+}
+__global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int in) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    interact_body<true>(a, in, 0, lds);
 }
 
 // ---- connections: strategy-major -------------------------------------------------------------------------------------
@@ -727,6 +745,7 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         if ((rc = dmalloc(s, &st.queue[0], W2))) return rc;
         if ((rc = dmalloc(s, &st.queue[1], W2))) return rc;
         if ((rc = dmalloc(s, &st.heavy_queue, W2))) return rc;
+        if ((rc = dmalloc(s, &st.intb_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
         HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
         st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
@@ -859,6 +878,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
             hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / 4u)), dim3(kBlock), 0, st_, a, in);
             rec();
         }
         hipLaunchKernelGGL(k_connect_enum, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
@@ -913,6 +933,14 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     out->surface_interactions = c.surface_interactions;
     out->light_splats = c.light_splats;
     out->walk_iteration_cap_hits = s->cap_hits;
+#ifdef WTGPU_STEP_PROF
+    {
+        unsigned long long p[8];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[wtgpu step prof] pass-B walks %llu; mean ticks: scan %.0f integrals %.0f edges %.0f aperture %.0f sample+append %.0f continue %.0f\n", p[7],
+                double(p[0]) / p[7], double(p[1]) / p[7], double(p[2]) / p[7], double(p[3]) / p[7], double(p[4]) / p[7], double(p[5]) / p[7]);
+    }
+#endif
     if (getenv("WTGPU_PROFILE")) {
         unsigned long long p[8];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
