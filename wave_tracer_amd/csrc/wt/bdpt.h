@@ -333,6 +333,53 @@ WT_HD void bdpt_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, u
     walk_cache_prev(sc, ew, v);
 }
 
+// The part of walk_t the trace kernels need (19 of its 57 words), loaded field by field straight into registers.
+struct walk_trace_in_t {
+    cone_t env;
+    float k;
+    vec3 prev_ng;
+    uint32_t prev_offset_tuid;
+};
+template <class F>
+WT_HD F soa_word(const uint32_t* base, size_t stride, size_t idx, size_t word) {
+    static_assert(sizeof(F) == 4, "");
+    const uint32_t w = base[word * stride + idx];
+    F f;
+    __builtin_memcpy(&f, &w, 4);
+    return f;
+}
+#define WT_WALK_WORD(field) (offsetof(walk_t, field) / 4)
+WT_HD walk_trace_in_t walk_load_trace_in(const uint32_t* base, size_t stride, size_t idx) {
+    walk_trace_in_t r;
+    r.env.o = {soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.o.x)), soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.o.y)),
+               soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.o.z))};
+    r.env.d = {soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.d.x)), soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.d.y)),
+               soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.d.z))};
+    r.env.x = {soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.x.x)), soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.x.y)),
+               soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.x.z))};
+    r.env.x0 = soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.x0));
+    r.env.tan_alpha = soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.tan_alpha));
+    r.env.e = soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.e));
+    r.env.one_over_e = soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.one_over_e));
+    r.env.z_apex = soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.env.z_apex));
+    r.k = soa_word<float>(base, stride, idx, WT_WALK_WORD(beam.k));
+    r.prev_ng = {soa_word<float>(base, stride, idx, WT_WALK_WORD(prev_ng.x)), soa_word<float>(base, stride, idx, WT_WALK_WORD(prev_ng.y)),
+                 soa_word<float>(base, stride, idx, WT_WALK_WORD(prev_ng.z))};
+    r.prev_offset_tuid = soa_word<uint32_t>(base, stride, idx, WT_WALK_WORD(prev_offset_tuid));
+    return r;
+}
+WT_HD cone_t walk_trace_envelope(const scene_t& sc, const walk_trace_in_t& w) {
+    cone_t env = w.env;
+    if (w.prev_offset_tuid != kInvalid) {
+        const tri_geo_t g = sc.tri_geo[w.prev_offset_tuid];
+        const vec3 err = triangle_fp_errors(g.a, g.b, g.c, env.o);
+        const float offset_dist = dot(err, vabs(w.prev_ng));
+        const vec3 offset = offset_dist * w.prev_ng;
+        env.o = env.o + (dot(env.d, offset) >= 0.f ? offset : -offset);
+    }
+    return env;
+}
+
 // envelope used for tracing the next segment (traversal.hpp:276-288): origin offset away from the last surface
 WT_HD cone_t walk_trace_envelope(const scene_t& sc, const walk_t& w) {
     cone_t env = w.beam.env;

@@ -19,7 +19,8 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define WT_HD __host__ __device__ inline
+// always_inline: a real call on AMDGPU passes the big by-reference PODs (walk_t, vertex_t, ...) through scratch memory
+#define WT_HD __host__ __device__ inline __attribute__((always_inline))
 #define WT_D __device__ inline
 #else
 #define WT_HD inline

@@ -231,11 +231,10 @@ __global__ void __launch_bounds__(kBlock, 4) k_trace(launch_args_t a, int in, in
         uint32_t w = 0;
         if (qi < n) {
             w = queue_walk(a, a.st.queue[in], qi, first_round);
-            walk_t wk;
-            soa_load(a.st.walks, W2, w, wk);
-            const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
+            const uint_list_t tris{a.st.tris + (size_t)w * kMaxConeTris, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
             const cone_t env = walk_trace_envelope(a.sc, wk);
-            const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
+            const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
             if (tr.aborted) {
                 heavy = true;
             } else {
@@ -268,13 +267,12 @@ __global__ void __launch_bounds__(64, 4) k_trace_heavy(launch_args_t a) {
         __syncthreads();
         if (item >= n) break;
         const uint32_t w = a.st.heavy_queue[item];
-        walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
-        const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);   // uniform address: broadcast
+        const uint_list_t tris{a.st.tris + (size_t)w * kMaxConeTris, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
         const cone_t env = walk_trace_envelope(a.sc, wk);
         unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const long long tt0 = a.profile ? clock64() : 0;
-        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.beam.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr);
+        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr);
         if (a.profile && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
@@ -342,7 +340,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
                 soa_load(a.st.walks, W2, w, wk);
                 trav_result_t tr;
                 soa_load(a.st.trav, W2, w, tr);
-                const uint_list_t tris{a.st.tris + w, (uint32_t)W2, kMaxConeTris};
+                const uint_list_t tris{a.st.tris + (size_t)w * kMaxConeTris, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
                 const vertex_store_t vs{a.st.verts, W2, w};
                 defer.pending = 0;
                 cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
