@@ -130,15 +130,30 @@ def main():
         S_vtx, S_hit = 320.0, 32.0
         b_film = 2 * (9 * C * 16) + n_light * 2 * (9 * C * 8)
         bytes_per_sample = n_seg * 2 * S_path + n_vtx * S_vtx + n_conn * 2 * S_vtx + n_q * S_hit + b_film
-        kernels = {"k_trace": tsum["trace_ms"], "k_trace_heavy": tsum["trace_heavy_ms"], "k_interact": tsum["interact_ms"], "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
+        kernels = {"k_trace": tsum["trace_ms"], "k_trace_heavy": tsum["trace_heavy_ms"], "k_interact": tsum["interact_ms"],
+                   "k_interact_b": tsum["interact_b_ms"], "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
         dom = max(kernels, key=kernels.get)
-        # bytes attributed to the dominant kernel per step (one step = npix samples)
+        # bytes attributed to the dominant kernel per step (one step = npix samples); the two trace kernels split the segments
+        # (every segment is traced by exactly one of them), the two interaction passes split the vertices the same way: each is
+        # credited with the WHOLE term (an upper bound of its algorithmic bytes, hence of `achieved`)
         share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
-                 "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
-        launches = {"k_trace": tsum["trace_launches"], "k_trace_heavy": tsum["trace_launches"], "k_interact": tsum["trace_launches"], "k_connect": tsum["batches"], "k_generate": tsum["batches"]}[dom]
+                 "k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
+        rounds = tsum["trace_launches"]      # launches that had work (rounds of all batches); empty rounds are not counted
+        launches = {"k_trace": rounds, "k_trace_heavy": rounds, "k_interact": rounds, "k_interact_b": rounds, "k_connect": tsum["batches"],
+                    "k_generate": tsum["batches"]}[dom]
         avg_ms = kernels[dom] / max(1, launches)
         alg_bytes_per_launch = share * npix * K / max(1, launches)
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic of that kernel from the PMC passes of the same command (tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
+        # separate rocprofv3 --pmc runs, summary committed under profiles/); bytes per launch with work, like `achieved`
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if dom in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
+                traffic = pt["kernels"][dom]["hbm_bytes_per_launch_with_work"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Msamples/sec (whole node), cornell-box 1440^2 wave-mode",
             "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -147,7 +162,7 @@ def main():
             "config": {"workload": f"{args.scene} stand-in (box.xml geometry, PLY meshes replaced by procedural stand-ins) res={args.res} "
                                    f"plt_bdpt max_depth=16 MIS RR FSD, 1 spp per step", "samples_per_step": npix, "tris": int(sc.info.n_tris),
                        "parallelism": f"sample-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "alg_bytes_per_launch": alg_bytes_per_launch,
                          "alg_bytes_per_sample_all_kernels": bytes_per_sample,
                          "kernel_ms_per_step": {k: v / K for k, v in kernels.items()}},

@@ -96,16 +96,21 @@ int wtgpu_trace_rays(wtgpu_scene* scene, void* stream, const float* d_rays, uint
 int wtgpu_traverse_cones(wtgpu_scene* scene, void* stream, const float* d_cones, uint32_t n, uint32_t cap, float* d_dist, uint32_t* d_flags,
                          uint32_t* d_ntris, uint32_t* d_tris);
 
+/* Profiling aid: `repeats` launches of a streaming copy of n_dwords 32-bit words (one dword per lane, coalesced: the access width
+ * of the SoA path state) with a known byte count, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/profile_round.sh). */
+int wtgpu_calibrate_copy(uint64_t n_dwords, int repeats);
+
 /* Accumulated device counters since upload / last reset. */
 int wtgpu_get_counters(wtgpu_scene* scene, wtgpu_counters* out);
 int wtgpu_reset_counters(wtgpu_scene* scene);
 
 /* Device time [ms] per kernel, ACCUMULATED over all wtgpu_render calls since upload / the last wtgpu_reset_counters, measured
  * with hipEvents on the internal streams the kernels are launched on (waits for the in-flight batches):
- * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact (sum), out[3]=connect, out[4]=rounds with work,
- * out[5]=trace launches with work, out[6]=batches, out[7]=cooperative (heavy) trace (sum).  Batches run concurrently on
+ * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact first pass (sum), out[3]=connect (4 kernels), out[4]=rounds with work,
+ * out[5]=trace launches with work, out[6]=batches, out[7]=cooperative (heavy) trace (sum), out[8]=second interaction pass (sum),
+ * out[9..11] reserved.  Batches run concurrently on
  * several streams, so the sums may exceed the wall time. */
-int wtgpu_last_render_timings(wtgpu_scene* scene, float out[8]);
+int wtgpu_last_render_timings(wtgpu_scene* scene, float out[12]);
 
 /* Host-side film development (render_context_t::develop, src/scene/render.cpp:245-291):
  * out[h][w][c] = value/weight (0 if weight==0) + light * (1/spe). */

@@ -19,4 +19,17 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_IN
   find /tmp/prof_pmc_$N -name "*counter_collection.csv" -exec cp {} $OUT/${TAG}_pmc_${N}_raw.csv \;
   python $R/tools/pmc_summary.py /tmp/prof_pmc_$N $OUT/${TAG}_pmc_${N}.csv > /dev/null 2>> $OUT/${TAG}_pmc_${N}.log
 done
+# calibration of FETCH_SIZE / WRITE_SIZE on a known byte count with the SoA access width (one dword per lane)
+NDW=268435456; REP=4
+echo "{\"n_dwords\": $NDW, \"repeats\": $REP}" > $OUT/${TAG}_calib.json
+for N in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_cal_$N
+  timeout 300 rocprofv3 --pmc $N --kernel-trace --output-format csv -d /tmp/prof_cal_$N -o pmc -- python -c "
+import sys; sys.path.insert(0, '$R')
+import ctypes, torch
+from wave_tracer_amd.api import load_library
+lib = load_library(); lib.wtgpu_calibrate_copy.argtypes = [ctypes.c_uint64, ctypes.c_int]
+torch.cuda.init(); assert lib.wtgpu_calibrate_copy($NDW, $REP) == 0" > $OUT/${TAG}_calib_${N}.log 2>&1
+  python $R/tools/pmc_summary.py /tmp/prof_cal_$N $OUT/${TAG}_calib_${N}.csv > /dev/null 2>> $OUT/${TAG}_calib_${N}.log
+done
 ls -la $OUT

@@ -48,7 +48,7 @@ class Counters(C.Structure):
 SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_scene_get_info", "wtgpu_scene_host_desc",
            "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
            "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
-           "wtgpu_scene_stats_json"]
+           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy"]
 
 _lib = None
 
@@ -85,7 +85,7 @@ def load_library():
     lib.wtgpu_traverse_cones.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, vp]
     lib.wtgpu_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.wtgpu_reset_counters.argtypes = [vp]
-    lib.wtgpu_last_render_timings.argtypes = [vp, C.POINTER(C.c_float * 8)]
+    lib.wtgpu_last_render_timings.argtypes = [vp, C.POINTER(C.c_float * 12)]
     lib.wtgpu_develop.argtypes = [vp, vp, vp, vp, u64, vp]
     lib.wtgpu_scene_destroy.argtypes = [vp]
     lib.wtgpu_scene_destroy.restype = None
@@ -180,10 +180,10 @@ class Scene:
         _check(load_library().wtgpu_reset_counters(self._h))
 
     def timings(self):
-        t = (C.c_float * 8)()
+        t = (C.c_float * 12)()
         _check(load_library().wtgpu_last_render_timings(self._h, C.byref(t)))
         return {"generate_ms": t[0], "trace_ms": t[1], "interact_ms": t[2], "connect_ms": t[3], "rounds": int(t[4]),
-                "trace_launches": int(t[5]), "batches": int(t[6]), "trace_heavy_ms": t[7]}
+                "trace_launches": int(t[5]), "batches": int(t[6]), "trace_heavy_ms": t[7], "interact_b_ms": t[8]}
 
     def close(self):
         if self._h:

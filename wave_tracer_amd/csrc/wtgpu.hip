@@ -108,7 +108,7 @@ struct wtgpu_scene {
     bool timing = true;
     std::string stats;
     double lut_power[2] = {0, 0};
-    double acc[8] = {0};                             // accumulated timings since the last reset (see wtgpu_last_render_timings)
+    double acc[12] = {0};                             // accumulated timings since the last reset (see wtgpu_last_render_timings)
     uint64_t samples_rendered = 0;
     uint64_t cap_hits = 0;
 };
@@ -206,7 +206,7 @@ __device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, 
     if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
+__global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_COUNT0 + in];
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_trace(launch_args_t a, int in, in
 }
 
 // Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
-__global__ void __launch_bounds__(64, 4) k_trace_heavy(launch_args_t a) {
+__global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
     __shared__ coop_shared_t sh;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
@@ -523,6 +523,12 @@ __global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
     film_splat(a.sc, a.film, ctx.element, L, ctx.k);
 }
 
+// ---- PMC calibration: a streaming copy with the access width of the SoA state (one dword per lane, fully coalesced) and a known
+// byte count, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled to bytes for THIS access pattern (tools/profile_round.sh)
+__global__ void __launch_bounds__(256) k_calib_copy(const uint32_t* in, uint32_t* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i] + 1u;
+}
+
 // ---- per-query kernels (traversal parity tests) --------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_trace_rays(scene_t sc, const float* rays, uint32_t n, float* dist, uint32_t* tuid, float* bary, uint32_t* front) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
@@ -761,7 +767,7 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     // in-flight batch records: events for per-kernel timings + pinned snapshot of the control block
     s->recs.resize(4 * (size_t)n_slices);
     for (auto& r : s->recs) {
-        r.ev.resize(s->timing ? 3 + 3 * (size_t)kMaxWalkIters : 1);
+        r.ev.resize(s->timing ? 3 + 4 * (size_t)kMaxWalkIters : 1);
         for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipHostMalloc((void**)&r.h_ctl, CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     }
@@ -783,13 +789,15 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
         hipEventElapsedTime(&ms, r.ev[0], r.ev[1]);
         s->acc[0] += ms;
         size_t e = 1;
-        for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 3) {
+        for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 4) {
             hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
             s->acc[1] += ms;
             hipEventElapsedTime(&ms, r.ev[e + 1], r.ev[e + 2]);
             s->acc[7] += ms;
             hipEventElapsedTime(&ms, r.ev[e + 2], r.ev[e + 3]);
             s->acc[2] += ms;
+            hipEventElapsedTime(&ms, r.ev[e + 3], r.ev[e + 4]);
+            s->acc[8] += ms;
         }
         hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
         s->acc[3] += ms;
@@ -876,6 +884,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
             hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            rec();
             hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / 4u)), dim3(kBlock), 0, st_, a, in);
             rec();
         }
@@ -898,11 +907,11 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
     return WTGPU_OK;
 }
 
-int wtgpu_last_render_timings(wtgpu_scene* s, float out[8]) {
+int wtgpu_last_render_timings(wtgpu_scene* s, float out[12]) {
     if (!s || !out || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     const int rc = drain_all(s);
     if (rc) return rc;
-    for (int i = 0; i < 8; ++i) out[i] = (float)s->acc[i];
+    for (int i = 0; i < 12; ++i) out[i] = (float)s->acc[i];
     return WTGPU_OK;
 }
 
@@ -979,6 +988,18 @@ int wtgpu_traverse_cones(wtgpu_scene* s, void* stream_, const float* d_cones, ui
     hipError_t e = hipStreamSynchronize(stream);
     hipFree(scratch);
     HIP_CHECK(e);
+    return WTGPU_OK;
+}
+
+int wtgpu_calibrate_copy(uint64_t n_dwords, int repeats) {
+    uint32_t *in = nullptr, *out = nullptr;
+    HIP_CHECK(hipMalloc((void**)&in, n_dwords * 4));
+    HIP_CHECK(hipMalloc((void**)&out, n_dwords * 4));
+    HIP_CHECK(hipMemset(in, 1, n_dwords * 4));
+    for (int r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_calib_copy, dim3(256 * 32), dim3(256), 0, 0, in, out, (size_t)n_dwords);
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipFree(in));
+    HIP_CHECK(hipFree(out));
     return WTGPU_OK;
 }
 
