@@ -318,7 +318,12 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             if (!hit) continue;
             if (tmin >= range.max) continue;
             if (cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) continue;
-            if (s < (int)stack.cap) stack[s++] = stack_entry_t{tmin, cp};
+            if (s < (int)stack.cap) {
+                stack[s++] = stack_entry_t{tmin, cp};
+            } else if (budget != 0xFFFFFFFFu) {
+                rec.aborted = 1;   // device: the 64-entry per-lane stack is full -> the wave-cooperative query (512 entries) takes over
+                return false;
+            }
         }
         stack_sort_desc(stack, begin, s);
     }
@@ -386,9 +391,14 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             tmin = fmaxf_(tmin, dminy);
             tmax = fminf_(tmax, dmaxz);
             tmin = fmaxf_(tmin, dminz);
-            if (tmin <= tmax && tmax >= range.min && tmin <= range.max && !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range) &&
-                s < (int)stack.cap)
-                stack[s++] = stack_entry_t{tmin, cp};
+            if (tmin <= tmax && tmax >= range.min && tmin <= range.max && !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) {
+                if (s < (int)stack.cap) {
+                    stack[s++] = stack_entry_t{tmin, cp};
+                } else if (budget != 0xFFFFFFFFu) {
+                    aborted = true;
+                    return false;
+                }
+            }
         }
         stack_sort_desc(stack, begin, s);
     }
