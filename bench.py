@@ -138,7 +138,9 @@ def main():
         # credited with the WHOLE term (an upper bound of its algorithmic bytes, hence of `achieved`)
         share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
-        rounds = tsum["trace_launches"]      # launches that had work (rounds of all batches); empty rounds are not counted
+        # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once):
+        # the same launch count rocprofv3 --kernel-trace --stats averages over (profiles/r01_kernel_stats_1440.csv)
+        rounds = 96 * tsum["batches"]
         launches = {"k_trace": rounds, "k_trace_heavy": rounds, "k_interact": rounds, "k_interact_b": rounds, "k_connect": tsum["batches"],
                     "k_generate": tsum["batches"]}[dom]
         avg_ms = kernels[dom] / max(1, launches)
@@ -151,7 +153,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
                 pt = json.load(f)
             if dom in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
-                traffic = pt["kernels"][dom]["hbm_bytes_per_launch_with_work"]
+                traffic = pt["kernels"][dom]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -163,7 +165,8 @@ def main():
                                    f"plt_bdpt max_depth=16 MIS RR FSD, 1 spp per step", "samples_per_step": npix, "tris": int(sc.info.n_tris),
                        "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "alg_bytes_per_launch": alg_bytes_per_launch,
+                         "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "round_launches_with_work": tsum["trace_launches"],
+                         "alg_bytes_per_launch": alg_bytes_per_launch,
                          "alg_bytes_per_sample_all_kernels": bytes_per_sample,
                          "kernel_ms_per_step": {k: v / K for k, v in kernels.items()}},
             "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,

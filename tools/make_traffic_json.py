@@ -35,12 +35,11 @@ for k in fetch:
         continue
     fb = fetch[k][0] * 1024.0 * kf
     wb = write.get(k, (0.0, 0))[0] * 1024.0 * kw
-    per_round = k in ("k_trace", "k_trace_heavy", "k_interact", "k_interact_b")
-    n_work = rounds if per_round else batches
     kernels[k] = {"fetch_bytes_per_step": fb, "write_bytes_per_step": wb, "dispatches": fetch[k][1],
-                  "hbm_bytes_per_launch_with_work": (fb + wb) / max(1.0, n_work)}
+                  "hbm_bytes_per_launch": (fb + wb) / max(1, fetch[k][1])}
 json.dump({"workload": {"scene": scene, "res": res, "steps": 1}, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0",
            "calibration": {"known_bytes_each_way": known, "FETCH_SIZE_KiB": cal_f[0], "WRITE_SIZE_KiB": cal_w[0], "fetch_factor": kf, "write_factor": kw,
                            "note": "factor = true bytes / (counter * 1024) for a one-dword-per-lane coalesced streaming copy"},
-           "launches_with_work_per_step": {"rounds": rounds, "batches": batches}, "kernels": kernels}, open(out, "w"), indent=1)
+           "note": "per launch = per step / dispatches of that kernel in one step (96 rounds x 6 batches for the round kernels, most of them empty)",
+           "kernels": kernels}, open(out, "w"), indent=1)
 print(json.dumps({"fetch_factor": kf, "write_factor": kw, "total_GB_per_step": sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in kernels.values()) / 1e9}))
