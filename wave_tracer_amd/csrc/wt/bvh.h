@@ -124,7 +124,9 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
             }
             continue;
         }
-        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+        // one per child field); the unrolled child loop then runs from registers
+        const bvh8_node_t n = sc.nodes[top.ptr - 1];
         if ((int)n.tris_count <= kRayLeafShortcut) {
             const bool intr = ray_gather_tris<shadow>(sc, ro, rd, n.tris_start, n.tris_count, range, rec, ctr);
             if (intr) {
@@ -136,6 +138,7 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
         if (ctr) ctr->nodes++;
         const float tfar = fminf_(rec.dist, range.max);
         const int begin = s;
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int32_t cp = n.child[i];
             if (cp == 0) continue;
@@ -280,7 +283,9 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             }
             continue;
         }
-        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+        // one per child field); the unrolled child loop then runs from registers
+        const bvh8_node_t n = sc.nodes[top.ptr - 1];
         if (ctr) ctr->cone_nodes++;
         tests += kNodeBudgetCost;   // an 8-wide node visit costs a lane about as much as a few triangle tests
         if (tests > budget) {
@@ -288,6 +293,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
             return false;
         }
         const int begin = s;
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int32_t cp = n.child[i];
             if (cp == 0) continue;
@@ -363,7 +369,9 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             }
             continue;
         }
-        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
+        // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+        // one per child field); the unrolled child loop then runs from registers
+        const bvh8_node_t n = sc.nodes[top.ptr - 1];
         if (ctr) ctr->probe_nodes++;
         tests += kNodeBudgetCost;
         if (tests > budget) {
@@ -371,6 +379,7 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             return false;
         }
         const int begin = s;
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int32_t cp = n.child[i];
             if (cp == 0) continue;

@@ -19,7 +19,7 @@ namespace wt {
 
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;
 
-struct tri_geo_t {   // 48 B
+struct alignas(16) tri_geo_t {   // 48 B, 3 x 16-B loads
     vec3 a, b, c, n;
 };
 struct tri_meta_t {   // 20 B
@@ -41,7 +41,7 @@ struct edge_t {   // ads/common.hpp:53-72
 
 // 8-wide BVH node: child AABBs in SoA inside the node.
 // child ptr: 0 empty, >0 internal node index+1, <0 -(leaf index+1); root ptr = 1.
-struct bvh8_node_t {
+struct alignas(16) bvh8_node_t {
     float minx[8], miny[8], minz[8];
     float maxx[8], maxy[8], maxz[8];
     int32_t child[8];
