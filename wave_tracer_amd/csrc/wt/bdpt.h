@@ -532,23 +532,6 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
             return false;   // nothing has been committed
         }
         WT_STEP_MARK(0);
-        if (primary == kInvalid) {
-            const float csz = centre(izr);
-            for (uint32_t i = 0; i < tr.ntris; ++i) {
-                const tri_geo_t g = sc.tri_geo[tris[i]];
-                const bool front_face = dot(g.n, -beam.env.d) > 0.f;
-                if (front_face != (tr.front_face != 0)) continue;
-                const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
-                                                      to_local(beam_frame, g.c - envelope.o), izr);
-                for (int t = 0; t < ct.tris; ++t) {
-                    vec3 a, b, c;
-                    clip_tri_get(ct, t, a, b, c);
-                    const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz),
-                               pc = cone_project_local(envelope, c, csz);
-                    integrated_flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
-                }
-            }
-        }
     }
 
     bool do_RR = true;
@@ -632,8 +615,28 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         WT_STEP_MARK(2);
         if (n_edge_ids > 0) {
             // ---- sample_fraunhofer_fsd_interaction (plt_bdpt_detail.hpp:287-346)
-            const float I = 1.f - integrated_flux;
             const bool resume = defer && defer->resolved;   // second pass of a deferred FSD interaction: the aperture exists already
+            // Fraction of the beam's power the listed triangles intercept (find_closest_triangle, plt_bdpt_detail.hpp:391-416).
+            // The reference computes it whenever the beam axis misses every triangle; its only consumer is the aperture built
+            // right below, so it is evaluated here, i.e. not for null interactions (3/4 of these walks) — same value, no RNG.
+            if (!resume) {
+                const float csz = centre(izr);
+                for (uint32_t i = 0; i < tr.ntris; ++i) {
+                    const tri_geo_t g = sc.tri_geo[tris[i]];
+                    const bool front_face = dot(g.n, -beam.env.d) > 0.f;
+                    if (front_face != (tr.front_face != 0)) continue;
+                    const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
+                                                          to_local(beam_frame, g.c - envelope.o), izr);
+                    for (int t = 0; t < ct.tris; ++t) {
+                        vec3 a, b, c;
+                        clip_tri_get(ct, t, a, b, c);
+                        const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz),
+                                   pc = cone_project_local(envelope, c, csz);
+                        integrated_flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
+                    }
+                }
+            }
+            const float I = 1.f - integrated_flux;
             const uint32_t slot = resume ? defer->slot : fsd_pool_alloc(pool);
             if (slot >= pool.cap) {
                 if (ctr) ctr->fsd_pool_overflow++;
