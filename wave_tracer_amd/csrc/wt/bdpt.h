@@ -464,7 +464,9 @@ struct fsd_defer_t {
 #define WT_STEP_MARK(i) ((void)0)
 #endif
 // Returns TRUE if the walk continues (another segment must be traced).
-template <class TriList>
+// MODE 0: everything (CPU checker).  Device: MODE 1 compiles only the surface-interaction branch (k_interact; walks without a
+// primary triangle leave through `defer`), MODE 2 only the no-primary branch (k_interact_b) — smaller kernels, smaller frames.
+template <int MODE = 0, class TriList>
 WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr, const TriList& tris, const vertex_store_t& vs,
                           const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream, bdpt_counters_t* ctr,
                           const stack_ref_t* primary_query_stack = nullptr, fsd_defer_t* defer = nullptr) {
@@ -536,7 +538,10 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
 
     bool do_RR = true;
     bool ok = true;
+    bool took_surface = false;
+    if constexpr (MODE != 2) {
     if (primary != kInvalid) {
+        took_surface = true;
         // ---- sample_surface_interaction (plt_bdpt_detail.hpp:192-270)
         const tri_geo_t g = sc.tri_geo[primary];
         const vec3 sampled_tri_wp = origin_wp + envelope.d * phit.dist;
@@ -588,7 +593,10 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                 }
             }
         }
-    } else {
+    }
+    }
+    if constexpr (MODE != 1) {
+    if (!took_surface) {
         WT_STEP_MARK(1);
         // gather the ordered, de-duplicated edge set of the interaction region (traversal_common.hpp:124-148)
         uint32_t edge_ids[kMaxEdgeIds];
@@ -711,6 +719,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
             beam_transform_restart(beam, interaction_wp, beam_dist);
             if (ctr) ctr->null_interactions++;
         }
+    }
     }
     WT_STEP_MARK(4);
     bool cont = false;

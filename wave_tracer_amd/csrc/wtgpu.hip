@@ -343,7 +343,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
                 const uint_list_t tris{a.st.tris + (size_t)w * kMaxConeTris, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
                 const vertex_store_t vs{a.st.verts, W2, w};
                 defer.pending = 0;
-                cont = bdpt_walk_step(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
+                cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
                 if (!defer.pending) {
                     todo = false;
                     if (!defer.no_primary) {
