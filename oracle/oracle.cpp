@@ -173,18 +173,22 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
                 for (int which = 0; which < 2; ++which) {
                     walk_t& w = which ? ew : sw;
                     const vertex_store_t& vs = which ? evs : svs;
-                    const uint_list_t tris{scr.tris.data(), 1, unbounded ? kOracleConeTris : kMaxConeTris};   // bounded like the device unless asked otherwise
+                    const uint_list_t tris{scr.tris.data(), 1, unbounded == 1 ? kOracleConeTris : kMaxConeTris};   // bounded like the device unless asked otherwise
                     for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
                         const cone_t env = walk_trace_envelope(sc, w);
                         const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
                         bvh_counters_t bc;
                         std::memset(&bc, 0, sizeof(bc));
-                        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris, &bc, 0xFFFFFFFFu, !unbounded);
+                        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris, &bc, 0xFFFFFFFFu, unbounded != 1);
                         if (n_calls < cap) {
                             uint32_t* o = out_calls + 8 * n_calls;
                             o[0] = bc.nodes; o[1] = bc.tri_tests; o[2] = bc.cone_nodes; o[3] = bc.cone_tri_tests; o[4] = bc.probe_nodes; o[5] = bc.probe_tri_tests;
-                            o[6] = unbounded ? tr.ntris : (tr.n_ray_queries | (tr.n_cone_queries << 16));
+                            o[6] = unbounded == 1 ? tr.ntris : (tr.n_ray_queries | (tr.n_cone_queries << 16));
                             o[7] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (which ? 4u : 0u) | (it << 8);
+                            if (unbounded == 2) {   // beam-width study: overwrite the ray columns with the envelope's x0 / tan_alpha
+                                std::memcpy(&o[0], &env.x0, 4);
+                                std::memcpy(&o[1], &env.tan_alpha, 4);
+                            }
                         }
                         ++n_calls;
                         w.active = bdpt_walk_step(sc, w, tr, tris, vs, pool, seed, sample_id, which ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK, &ctr) ? 1u : 0u;
