@@ -181,16 +181,30 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
         __syncthreads();
         return any;
     };
+#ifdef WTGPU_COOP_PROF
+    long long cp_t = clock64();
+#define CP(k)                                              \
+    do {                                                   \
+        const long long n_ = clock64();                    \
+        if (prof) prof[k] += (unsigned long long)(n_ - cp_t); \
+        cp_t = n_;                                         \
+    } while (0)
+#else
+#define CP(k) ((void)0)
+#endif
     for (;;) {
         // ---- phase A: expand up to 8 stack entries per step until >= 64 triangles are buffered (or the stack is empty)
         const long long ta0 = prof ? clock64() : 0;
         while (s > 0 && leaf_total < 64u) {
             const int np = s < 8 ? s : 8;
+#ifndef WTGPU_COOP_PROF
             if (prof) prof[7] += 1ull + ((unsigned long long)np << 32);
+#endif
             stack_entry_t e{0.f, 0};
             if (grp < np) e = sh.stack[s - 1 - grp];
             s -= np;
             __syncthreads();   // everyone has read its entry before the slots are overwritten
+            CP(0);
             const bool live = grp < np && (any_hit || e.t < range.max);
             bool leafish = false, h = false;
             uint32_t t0 = 0, cnt = 0;
@@ -217,6 +231,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                     }
                 }
             }
+            CP(1);
             // push the child hits: group 0 served the top (nearest) entry, its children go on top
             const unsigned long long hm = __ballot(h);
             if (hm) {
@@ -233,6 +248,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }
+            CP(2);
             // buffer the leaf ranges
             const unsigned long long lm = __ballot(leafish && sub == 0 && cnt > 0);
             unsigned long long m = lm;
@@ -246,6 +262,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 leaf_total += c;
             }
             __syncthreads();
+            CP(3);
         }
         if (prof) prof[5] += (unsigned long long)(clock64() - ta0);
         const long long tb0 = prof ? clock64() : 0;
@@ -268,12 +285,16 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 if (pass && pos < kCoopSurvCap) sh.surv[pos] = tuid;
                 nsurv += (uint32_t)__popcll(pm);   // < 64 + 64 <= kCoopSurvCap: a full wave is flushed right away
             }
+            CP(7);
             if (nsurv >= 64u) found_any = flush();
+            CP(6);
         }
         leaf_total = 0;
         // ---- phase B2 at the end of a round when the query is about to finish (stack empty) or enough survivors wait: one more
         // round of expansion + filtering costs ~1/5 of an exact-test pass, so a handful of survivors is worth waiting for.
+        CP(7);
         if (!found_any && nsurv > 0 && (s == 0 || nsurv >= kCoopFlushAt)) found_any = flush();
+        CP(6);
         __syncthreads();
         if (prof) prof[6] += (unsigned long long)(clock64() - tb0);
         if (found_any && (any_hit || rec.too_short)) return true;
@@ -429,8 +450,12 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
 // integrator::traverse (traversal.hpp:94-172), wave-uniform.
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
                                               coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr) {
+#ifdef WTGPU_COOP_PROF
+#define WT_COOP_PROF(i, t0_)
+#else
 #define WT_COOP_PROF(i, t0_) \
     if (prof) prof[i] += (unsigned long long)(clock64() - (t0_));
+#endif
     trav_result_t r;
     r.aborted = 0;
     r.origin = envelope.o;

@@ -275,7 +275,11 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
         const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr);
         if (a.profile && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
+#ifdef WTGPU_COOP_PROF
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
+#else
+            for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
+#endif
             atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
             atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
             atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
@@ -946,6 +950,15 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
         fprintf(stderr, "[wtgpu step prof] pass-B walks %llu; mean ticks: scan %.0f integrals %.0f edges %.0f aperture %.0f sample+append %.0f continue %.0f\n", p[7],
                 double(p[0]) / p[7], double(p[1]) / p[7], double(p[2]) / p[7], double(p[3]) / p[7], double(p[4]) / p[7], double(p[5]) / p[7]);
+    }
+#endif
+#ifdef WTGPU_COOP_PROF
+    if (getenv("WTGPU_PROFILE")) {
+        unsigned long long p[8];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        const double n = p[4] ? double(p[4]) : 1.;
+        fprintf(stderr, "[coop prof] items %llu; per item ticks: A.pop %.0f A.node+test %.0f A.push %.0f A.leafappend %.0f B1.filter %.0f flush %.0f\n", p[4], p[0] / n, p[1] / n,
+                p[2] / n, p[3] / n, p[7] / n, p[6] / n);
     }
 #endif
     if (getenv("WTGPU_PROFILE")) {
