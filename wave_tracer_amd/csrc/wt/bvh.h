@@ -506,7 +506,12 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
         bvh_traverse_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, stack, tris, ch, ctr, cone_budget,
                           probe_first ? min_df_prog : -WT_INF);
         if (ch.aborted) {
+            // hand-over state for the cooperative kernel: every query before this one is settled (rays missed, diffusive attempts
+            // were too short); it resumes with the cone query of segment `seg` at distance `dist`
             r.aborted = 1;
+            r.dist = dist;
+            r.ntris = seg;
+            r.n_cone_queries--;   // recounted by whoever completes it
             return r;
         }
         if (ch.too_short) continue;

@@ -449,7 +449,8 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
 
 // integrator::traverse (traversal.hpp:94-172), wave-uniform.
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
-                                              coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr) {
+                                              coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr, bool resume = false,
+                                              uint32_t seg0 = 0, float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0) {
 #ifdef WTGPU_COOP_PROF
 #define WT_COOP_PROF(i, t0_)
 #else
@@ -484,13 +485,22 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         }
         return r;
     }
-    float dist = 0.f;
-    for (uint32_t seg = 0;; ++seg) {
+    // resume = the per-lane kernel already settled every query before the cone query of segment seg0 (bvh.h: traverse())
+    float dist = resume ? dist0 : 0.f;
+    if (resume) {
+        r.n_ray_queries = nray0;
+        r.n_cone_queries = ncone0;
+    }
+    for (uint32_t seg = resume ? seg0 : 0u;; ++seg) {
         const float ballistic_dist = max_ballistic_distance(lambda_m, seg, 0.f);
-        r.n_ray_queries++;
-        const long long tq0 = prof ? clock64() : 0;
-        const bool ray_hit = coop_ray_query(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, sh, rh);
-        WT_COOP_PROF(0, tq0)
+        const bool skip_ray = resume && seg == seg0;   // that segment's ray query missed already; `dist` is past it
+        bool ray_hit = false;
+        if (!skip_ray) {
+            r.n_ray_queries++;
+            const long long tq0 = prof ? clock64() : 0;
+            ray_hit = coop_ray_query(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, sh, rh);
+            WT_COOP_PROF(0, tq0)
+        }
         if (ray_hit) {
             r.empty = 0;
             r.dist = rh.dist;
@@ -501,8 +511,10 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
             r.ntris = 1;
             return r;
         }
-        dist += ballistic_dist;
-        if (ballistic_dist == WT_INF || dist >= distance) return r;
+        if (!skip_ray) {
+            dist += ballistic_dist;
+            if (ballistic_dist == WT_INF || dist >= distance) return r;
+        }
         const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
         cone_hit_t ch;
         r.n_cone_queries++;

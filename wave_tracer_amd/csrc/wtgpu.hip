@@ -82,6 +82,7 @@ struct device_state_t {
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
 constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
 constexpr size_t kTravWords = sizeof(trav_result_t) / 4;
+#define WT_TRAV_WORD(field) (offsetof(trav_result_t, field) / 4)
 constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long long);
 
 }   // namespace
@@ -237,6 +238,11 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
             const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
             if (tr.aborted) {
                 heavy = true;
+                // resume state for k_trace_heavy (traverse(): dist / ntris = segment / query counts so far)
+                a.st.trav[WT_TRAV_WORD(dist) * W2 + w] = __float_as_uint(tr.dist);
+                a.st.trav[WT_TRAV_WORD(ntris) * W2 + w] = tr.ntris;
+                a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = tr.n_ray_queries;
+                a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = tr.n_cone_queries;
             } else {
                 soa_store(a.st.trav, W2, w, tr);
                 ctr.segments += 1;
@@ -272,7 +278,10 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
         const cone_t env = walk_trace_envelope(a.sc, wk);
         unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const long long tt0 = a.profile ? clock64() : 0;
-        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr);
+        const float dist0 = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
+        const uint32_t seg0 = a.st.trav[WT_TRAV_WORD(ntris) * W2 + w];
+        const uint32_t nray0 = a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w], ncone0 = a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w];
+        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr, true, seg0, dist0, nray0, ncone0);
         if (a.profile && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
 #ifdef WTGPU_COOP_PROF
