@@ -51,8 +51,9 @@ def cpu_baseline(scene_name, res, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    # passes pipeline on the GPU (a pass is in flight for ~0.25 s): with few steps the ramp-up and drain of that pipeline weigh in
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--res", type=int, default=1440)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
@@ -99,9 +100,11 @@ def main():
         t.zero_()
     sync()
     t0 = time.time()
-    # wtgpu_render only enqueues: consecutive steps pipeline on the GPU, everything is complete at the closing sync
+    # wtgpu_render_async only enqueues and does not make `stream` wait: consecutive steps (more samples into the same film
+    # accumulators) pipeline on the GPU; the join + closing sync below complete all K steps inside the timed region
     for s in range(K):
-        sc.render_into(value, weight, light, base + Wm + s, base + Wm + s + 1, 1, stream)
+        sc.render_async_into(value, weight, light, base + Wm + s, base + Wm + s + 1, 1, stream)
+    sc.join(stream)
     if distributed:
         for t in (value, weight, light):
             dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)

@@ -88,6 +88,14 @@ int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_sample
 int wtgpu_render(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin, uint64_t sample_end,
                  uint64_t seed);
 
+/* The two halves of wtgpu_render.  wtgpu_render_async enqueues the work behind everything already on `stream` but does not make
+ * `stream` wait for it, so consecutive calls (more samples into the same accumulators) pipeline on the GPU; wtgpu_join makes
+ * `stream` continue after everything enqueued so far.  Nothing may read or overwrite the films between an async render and its
+ * join. */
+int wtgpu_render_async(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin,
+                       uint64_t sample_end, uint64_t seed);
+int wtgpu_join(wtgpu_scene* scene, void* stream);
+
 /* Per-query ADS entry points (ads_t::intersect(ray) / integrator::traverse(cone), include/wt/ads/ads.hpp:71-113,
  * include/wt/integrator/traversal.hpp:94-172) on device-resident arrays; used by the traversal parity tests.
  * rays:  n x {ox,oy,oz, dx,dy,dz, tmin,tmax}            cones: n x {ox,oy,oz, dx,dy,dz, tan_alpha, x0, ecc, lambda_m} */

@@ -120,6 +120,24 @@ def test_batched_render_equals_unbatched(built):
     assert np.allclose(va, vb, rtol=1e-9, atol=1e-30) and np.allclose(wa, wb, rtol=1e-12) and np.allclose(la, lb, rtol=1e-9, atol=1e-30)
 
 
+def test_async_renders_pipeline_and_join(built):
+    """wtgpu_render_async + wtgpu_join: several un-joined renders into the same accumulators equal one joined render."""
+    import torch
+    from wave_tracer_amd import Scene, render
+    from wave_tracer_amd.render import alloc_films
+    sc = Scene("furnace", res=32, lut=(32, 32))
+    ref = render(sc, 6, seed=21)
+    dev = torch.device("cuda", 0)
+    v, w, l = alloc_films(sc, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for s in range(6):
+        sc.render_async_into(v, w, l, s, s + 1, 21, st)
+    sc.join(st)
+    torch.cuda.synchronize(dev)
+    for a, b in zip((v, w, l), ref):
+        assert np.allclose(a.cpu().numpy(), b, rtol=1e-9, atol=1e-30)
+
+
 def test_empty_sample_range_is_a_noop(built):
     from wave_tracer_amd import Scene, render
     sc = Scene("furnace", res=16, lut=(32, 32))

@@ -48,7 +48,7 @@ class Counters(C.Structure):
 SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_scene_get_info", "wtgpu_scene_host_desc",
            "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
            "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
-           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy"]
+           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join"]
 
 _lib = None
 
@@ -81,6 +81,8 @@ def load_library():
     lib.wtgpu_scene_host_desc.restype = vp
     lib.wtgpu_scene_upload.argtypes = [vp, i32, u64]
     lib.wtgpu_render.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64]
+    lib.wtgpu_render_async.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64]
+    lib.wtgpu_join.argtypes = [vp, vp]
     lib.wtgpu_trace_rays.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     lib.wtgpu_traverse_cones.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, vp]
     lib.wtgpu_get_counters.argtypes = [vp, C.POINTER(Counters)]
@@ -138,6 +140,16 @@ class Scene:
         sp = C.c_void_p(stream) if stream else None
         _check(load_library().wtgpu_render(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), int(sample_begin),
                                            int(sample_end), int(seed)))
+
+    def render_async_into(self, value, weight, light, sample_begin, sample_end, seed, stream=None):
+        """Like render_into, but `stream` does not wait for the work: consecutive calls pipeline on the GPU.  Call join(stream)
+        before anything reads or overwrites the films."""
+        sp = C.c_void_p(stream) if stream else None
+        _check(load_library().wtgpu_render_async(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), int(sample_begin),
+                                                 int(sample_end), int(seed)))
+
+    def join(self, stream=None):
+        _check(load_library().wtgpu_join(self._h, C.c_void_p(stream) if stream else None))
 
     def trace_rays(self, rays):
         """rays: [n,8] f32 {o, d, tmin, tmax} (numpy) -> (dist, tuid, bary, front) numpy; device arrays are torch tensors."""

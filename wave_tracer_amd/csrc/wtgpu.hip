@@ -826,7 +826,23 @@ static int drain_all(wtgpu_scene* s) {
     return WTGPU_OK;
 }
 
+int wtgpu_join(wtgpu_scene* s, void* stream_) {
+    if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
+    hipStream_t caller = static_cast<hipStream_t>(stream_);
+    HIP_CHECK(hipSetDevice(s->device));
+    for (size_t k = 0; k < s->slices.size(); ++k) {
+        HIP_CHECK(hipEventRecord(s->ev_done[k], s->streams[k]));
+        HIP_CHECK(hipStreamWaitEvent(caller, s->ev_done[k], 0));
+    }
+    return WTGPU_OK;
+}
+
 int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weight, double* d_light, uint64_t sb, uint64_t se, uint64_t seed) {
+    const int rc = wtgpu_render_async(s, stream_, d_value, d_weight, d_light, sb, se, seed);
+    return rc ? rc : wtgpu_join(s, stream_);
+}
+
+int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d_weight, double* d_light, uint64_t sb, uint64_t se, uint64_t seed) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     if (!d_value || !d_weight || !d_light || se < sb) return fail(WTGPU_ERR_INVALID, "bad film pointers / sample range");
     hipStream_t caller = static_cast<hipStream_t>(stream_);
@@ -910,12 +926,7 @@ int wtgpu_render(wtgpu_scene* s, void* stream_, double* d_value, double* d_weigh
         hipEventRecord(r.ev[tm ? ev : 0], st_);
         r.busy = true;
     }
-    // ... and the caller's stream continues after all of them
-    for (size_t k = 0; k < n_slices; ++k)
-        if (used[k]) {
-            HIP_CHECK(hipEventRecord(s->ev_done[k], s->streams[k]));
-            HIP_CHECK(hipStreamWaitEvent(caller, s->ev_done[k], 0));
-        }
+    // (wtgpu_join makes the caller's stream continue after all of them)
     s->samples_rendered += total;
     return WTGPU_OK;
 }
