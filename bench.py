@@ -16,7 +16,7 @@ import os
 import sys
 import time
 
-# The renderer pipelines batches over 6 HIP streams; the ROCm runtime reads this when libamdhip64 is loaded (import torch), its
+# The renderer pipelines batches over 4 HIP streams (plus the caller's); the ROCm runtime reads this when libamdhip64 is loaded (import torch), its
 # default of 4 hardware queues makes streams share queues and serialise (see wave_tracer_amd/api.py).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

@@ -738,7 +738,7 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     // per-batch path state: `n_slices` slices (one internal stream each) that together hold `max_batch` samples in flight
     const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
     const uint64_t total_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 20);
-    uint32_t n_slices = 6;
+    uint32_t n_slices = 4;
     if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
     n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, total_cap / 64));
     if (const char* e = getenv("WTGPU_TIMING")) s->timing = atoi(e) != 0;
