@@ -120,6 +120,23 @@ def test_batched_render_equals_unbatched(built):
     assert np.allclose(va, vb, rtol=1e-9, atol=1e-30) and np.allclose(wa, wb, rtol=1e-12) and np.allclose(la, lb, rtol=1e-9, atol=1e-30)
 
 
+def test_exact_regions_mode(built, monkeypatch):
+    """WTGPU_EXACT_REGIONS=1: interaction regions that overflow the bounded triangle list are gathered by a wavefront (k_gather);
+    the dense-mesh crop must stay within the same tolerances and its diffraction-interaction count must not move away from
+    the CPU checker's (unbounded lists)."""
+    args = ("cornell_box", 48, 2, 3)
+    kw = dict(mesh_detail=1, lut=(128, 128), crop_of=1440)
+    _, gpu0, cpu, gc0, oc, _, _ = _both(*args, **kw)
+    monkeypatch.setenv("WTGPU_EXACT_REGIONS", "1")
+    _, gpu1, _, gc1, _, gf, cf = _both(*args, **kw)
+    assert np.isfinite(gpu1).all()
+    assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
+    assert _rel_l1(gpu1, cpu) < 5e-2
+    assert abs(gc1["fsd_interactions"] - oc["fsd_interactions"]) <= abs(gc0["fsd_interactions"] - oc["fsd_interactions"]) + 3
+    for key in ("segments", "vertices", "connections"):
+        assert abs(gc1[key] - oc[key]) <= 1e-2 * oc[key]
+
+
 def test_async_renders_pipeline_and_join(built):
     """wtgpu_render_async + wtgpu_join: several un-joined renders into the same accumulators equal one joined render."""
     import torch

@@ -449,6 +449,11 @@ WT_HD bool walk_continue(const scene_t& sc, walk_t& w, const vertex_store_t& vs,
 struct fsd_defer_t {
     uint32_t split_no_primary, no_primary;   // in: defer walks without a primary triangle; out: this walk is one
     uint32_t known_no_primary;               // in: the first pass already found no primary triangle (skip the search)
+    // in: a wavefront already walked an interaction region too large for the bounded triangle list (coop_gather, coop.h):
+    // intercepted power fraction and the sorted classified-edge set of the WHOLE region
+    uint32_t has_gather, gather_n_edges, gather_edge_overflow;
+    float gather_flux;
+    const uint32_t* gather_edges;
     uint32_t pending, resolved;
     uint32_t slot, base, next_try, end_draws;
     fsd_sample_t fs;
@@ -601,7 +606,11 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         // gather the ordered, de-duplicated edge set of the interaction region (traversal_common.hpp:124-148)
         uint32_t edge_ids[kMaxEdgeIds];
         uint32_t n_edge_ids = 0;
-        if (sc.opts.FSD && !is_ballistic) {
+        if (sc.opts.FSD && !is_ballistic && defer && defer->has_gather) {
+            n_edge_ids = defer->gather_n_edges < kMaxEdgeIds ? defer->gather_n_edges : kMaxEdgeIds;
+            for (uint32_t i = 0; i < n_edge_ids; ++i) edge_ids[i] = defer->gather_edges[i];
+            if (ctr) ctr->edge_overflow += defer->gather_edge_overflow;
+        } else if (sc.opts.FSD && !is_ballistic) {
             for (uint32_t i = 0; i < tr.ntris; ++i) {
                 const tri_meta_t m = sc.tri_meta[tris[i]];
                 for (int e = 0; e < 3; ++e) {
@@ -627,7 +636,9 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
             // Fraction of the beam's power the listed triangles intercept (find_closest_triangle, plt_bdpt_detail.hpp:391-416).
             // The reference computes it whenever the beam axis misses every triangle; its only consumer is the aperture built
             // right below, so it is evaluated here, i.e. not for null interactions (3/4 of these walks) — same value, no RNG.
-            if (!resume) {
+            if (!resume && defer && defer->has_gather) {
+                integrated_flux = defer->gather_flux;
+            } else if (!resume) {
                 const float csz = centre(izr);
                 for (uint32_t i = 0; i < tr.ntris; ++i) {
                     const tri_geo_t g = sc.tri_geo[tris[i]];

@@ -18,6 +18,7 @@
 #pragma once
 #if defined(__HIPCC__)
 #include "bvh.h"
+#include "gauss.h"
 
 namespace wt {
 
@@ -33,6 +34,7 @@ struct coop_shared_t {
     uint32_t tri_buf[kCoopTriBuf];
     uint32_t surv[kCoopSurvCap];
     float hit_dist[64];   // cone-hit distance of every listed triangle (list capacity kMaxConeTris = 64)
+    uint32_t edge_ids[96];   // coop_gather: sorted classified-edge set of an interaction region (capacity kMaxEdgeIds)
 };
 
 __device__ inline float wave_min(float v) {
@@ -312,6 +314,186 @@ __device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, cons
     cone_hit_t rec;
     const uint_list_t none{nullptr, 0, 0};
     return coop_cone_query<true>(sc, cone, range, 0.f, sh, none, rec, prof);
+}
+
+// ---- interaction-region gather for beams whose footprint holds more triangles than the bounded list (kMaxConeTris) -----------
+// The interaction step needs three things from the triangle list of a diffusive hit (bdpt_walk_step): the triangle under the beam
+// axis (a BVH ray query when the list overflowed), the fraction of the beam's power the front-facing triangles intercept, and the
+// set of classified (silhouette) edges.  The last two are sums / unions over the list, so for a region that does not fit the list
+// one wavefront walks the region once more — every triangle that meets the traced cone inside the final slab — and accumulates
+// them directly: the result is that of an unbounded list (the reference's std::vector), whatever the triangle count.
+struct gather_out_t {
+    float flux;
+    uint32_t n_edges, edge_overflow;
+};
+__device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
+                                           const range_t& izr, vec2 sigma, bool want_front, coop_shared_t& sh, bool do_flux, bool do_edges) {
+    uint32_t* edges = sh.edge_ids;
+    const uint32_t edge_cap = 96;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
+    gather_out_t out{0.f, 0u, 0u};
+    if (sc.n_nodes == 0) return out;
+    const vec3 ro = tcone.o, rd = tcone.d;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    const float ta = tcone.tan_alpha, ix = tcone.x0;
+    const float csz = centre(izr);
+    int s = 1;
+    uint32_t leaf_total = 0, nsurv = 0;
+    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
+    __syncthreads();
+    auto flush = [&]() {
+        __syncthreads();
+        for (uint32_t b2 = 0; b2 < nsurv; b2 += 64) {
+            const uint32_t k2 = b2 + lane;
+            float contrib = 0.f;
+            uint32_t eid[3] = {kInvalid, kInvalid, kInvalid};
+            if (k2 < nsurv) {
+                const uint32_t t2 = sh.surv[k2];
+                const tri_geo_t tri = sc.tri_geo[t2];
+                cone_tri_hit_t ht;
+                if (intersect_cone_tri(tcone, tri.a, tri.b, tri.c, tri.n, slab, ht) && !(ht.dist > slab.max)) {
+                    if (do_edges) {
+                        const tri_meta_t m = sc.tri_meta[t2];
+                        eid[0] = m.edge[0];
+                        eid[1] = m.edge[1];
+                        eid[2] = m.edge[2];
+                    }
+                    if (do_flux && (dot(tri.n, -rd) > 0.f) == want_front) {   // find_closest_triangle's footprint integral (bdpt.h)
+                        const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, tri.a - envelope.o), to_local(beam_frame, tri.b - envelope.o),
+                                                              to_local(beam_frame, tri.c - envelope.o), izr);
+                        for (int t = 0; t < ct.tris; ++t) {
+                            vec3 a, b, c;
+                            clip_tri_get(ct, t, a, b, c);
+                            contrib += wavefront_integrate_triangle(sigma, cone_project_local(envelope, a, csz), cone_project_local(envelope, b, csz),
+                                                                    cone_project_local(envelope, c, csz));
+                        }
+                    }
+                }
+            }
+            // sum in lane order (deterministic)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float o = __shfl_up(contrib, off, 64);
+                if (lane >= off) contrib += o;
+            }
+            out.flux += __shfl(contrib, 63, 64);
+            // classified edges are rare (a few hundred in a 170K-triangle scene): insert them one by one into the sorted LDS
+            // list, all lanes cooperating on the search
+            unsigned long long em = __ballot(eid[0] != kInvalid || eid[1] != kInvalid || eid[2] != kInvalid);
+            while (em) {
+                const int src = __ffsll((long long)em) - 1;
+                em &= em - 1;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const uint32_t id = (uint32_t)__shfl((int)eid[e], src, 64);
+                    if (id == kInvalid) continue;
+                    // position = number of entries smaller than id; present = some entry equals id   (entries lane, lane+64, ...)
+                    uint32_t less = 0;
+                    bool present = false;
+                    for (uint32_t j = (uint32_t)lane; j < out.n_edges; j += 64) {
+                        const uint32_t v = edges[j];
+                        less += v < id ? 1u : 0u;
+                        present = present || v == id;
+                    }
+                    if (__ballot(present)) continue;
+                    if (out.n_edges >= edge_cap) {
+                        out.edge_overflow++;
+                        continue;
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) less += (uint32_t)__shfl_xor((int)less, off, 64);
+                    // shift the tail up by one (read everything first), then insert
+                    uint32_t mv[2];
+                    int nm = 0;
+                    for (uint32_t j = less + (uint32_t)lane; j < out.n_edges && nm < 2; j += 64) mv[nm++] = edges[j];
+                    __syncthreads();
+                    nm = 0;
+                    for (uint32_t j = less + (uint32_t)lane; j < out.n_edges && nm < 2; j += 64) edges[j + 1] = mv[nm++];
+                    if (lane == 0) edges[less] = id;
+                    out.n_edges++;
+                    __syncthreads();
+                }
+            }
+        }
+        nsurv = 0;
+        __syncthreads();
+    };
+    for (;;) {
+        while (s > 0 && leaf_total < 64u) {
+            const int np = s < 8 ? s : 8;
+            stack_entry_t e{0.f, 0};
+            if (grp < np) e = sh.stack[s - 1 - grp];
+            s -= np;
+            __syncthreads();
+            const bool live = grp < np;
+            bool leafish = false, h = false;
+            uint32_t t0 = 0, cnt = 0;
+            float tmin = 0.f;
+            int32_t cp = 0;
+            if (live) {
+                if (e.ptr < 0) {
+                    const bvh8_leaf_t leaf = sc.leaves[-e.ptr - 1];
+                    t0 = leaf.tris_ptr;
+                    cnt = leaf.count;
+                    leafish = true;
+                } else {
+                    const bvh8_node_t& node = sc.nodes[e.ptr - 1];
+                    const uint32_t ntc = node.tris_count, nts = node.tris_start;
+                    cp = node.child[sub];
+                    const bool hc = cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, slab, tmin);
+                    if (ntc <= kCoopLeafTris) {
+                        t0 = nts;
+                        cnt = ntc;
+                        leafish = true;
+                    } else {
+                        h = hc && cp != 0;
+                    }
+                }
+            }
+            const unsigned long long hm = __ballot(h);
+            if (hm) {
+                const int pos = s + __popcll(hm & ((1ull << lane) - 1ull));   // order is irrelevant here
+                if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+                const int total = s + __popcll(hm);
+                s = total < kCoopStack ? total : kCoopStack;
+            }
+            unsigned long long m = __ballot(leafish && sub == 0 && cnt > 0);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                uint32_t c = (uint32_t)__shfl((int)cnt, src, 64);
+                const uint32_t t = (uint32_t)__shfl((int)t0, src, 64);
+                if (c > kCoopLeafTris) c = kCoopLeafTris;
+                if ((uint32_t)lane < c) sh.tri_buf[leaf_total + lane] = t + lane;
+                leaf_total += c;
+            }
+            __syncthreads();
+        }
+        for (uint32_t base = 0; base < leaf_total; base += 64) {
+            const uint32_t k = base + lane;
+            bool pass = false;
+            uint32_t tuid = 0;
+            if (k < leaf_total) {
+                tuid = sh.tri_buf[k];
+                const tri_geo_t tri = sc.tri_geo[tuid];
+                pass = cone_tri_maybe(tcone, tri.a, tri.b, tri.c, slab);
+            }
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+                const uint32_t pos = nsurv + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                if (pass && pos < kCoopSurvCap) sh.surv[pos] = tuid;
+                nsurv += (uint32_t)__popcll(pm);
+            }
+            if (nsurv >= 64u) flush();
+        }
+        leaf_total = 0;
+        if (nsurv > 0 && s == 0) flush();
+        __syncthreads();
+        if (s == 0) break;
+    }
+    return out;
 }
 
 // One wavefront, one closest-hit ray query (bvh_traverse_ray<false> + ads_intersect_ray), same scheme as coop_cone_query:
