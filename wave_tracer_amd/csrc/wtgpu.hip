@@ -980,7 +980,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             rec();
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
-            hipLaunchKernelGGL(k_gather, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
+            if (a.exact_regions) hipLaunchKernelGGL(k_gather, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / 4u)), dim3(kBlock), 0, st_, a, in);
             rec();
         }
