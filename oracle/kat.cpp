@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "../wave_tracer_amd/csrc/wt/bdpt.h"
+#include "../wave_tracer_amd/csrc/wt/path.h"
 
 using namespace wt;
 
@@ -155,5 +156,67 @@ uint32_t kat_scene_tris(const void* scene_host, float* out12) {
     return sc.n_tris;
 }
 int kat_material_ior_spec(const void* scene_host, int material) { return static_cast<const scene_t*>(scene_host)->materials[material].ior_spec; }
+
+// K1: UTD transition function and wedge diffraction coefficients (interaction/fsd/utd.hpp)
+void kat_utd_F(float x, float* out2) {
+    const cplx f = utd_F(x);
+    out2[0] = f.re;
+    out2[1] = f.im;
+}
+// wedge: {v3, l, nff3, tff3, nbf3, alpha}; out: Ds.re, Ds.im, Dh.re, Dh.im
+void kat_wedge_UTD(const float* wd, float k, const float* wi, const float* wo, float ro, float* out4) {
+    utd_wedge_t w{{wd[0], wd[1], wd[2]}, wd[3], {wd[4], wd[5], wd[6]}, {wd[7], wd[8], wd[9]}, {wd[10], wd[11], wd[12]}, wd[13], 0u};
+    const utd_ret_t r = wedge_UTD(w, k, vec3{wi[0], wi[1], wi[2]}, vec3{wo[0], wo[1], wo[2]}, ro);
+    out4[0] = r.Ds.re; out4[1] = r.Ds.im; out4[2] = r.Dh.re; out4[3] = r.Dh.im;
+}
+int kat_wedge_diffraction_point(const float* wd, const float* src, const float* dst, float* out3) {
+    utd_wedge_t w{{wd[0], wd[1], wd[2]}, wd[3], {wd[4], wd[5], wd[6]}, {wd[7], wd[8], wd[9]}, {wd[10], wd[11], wd[12]}, wd[13], 0u};
+    vec3 p{0, 0, 0};
+    const bool ok = wedge_diffraction_point(w, vec3{src[0], src[1], src[2]}, vec3{dst[0], dst[1], dst[2]}, p);
+    out3[0] = p.x; out3[1] = p.y; out3[2] = p.z;
+    return ok ? 1 : 0;
+}
+int kat_wedge_diffraction_point_dir(const float* wd, const float* src, const float* wo, float* out3) {
+    utd_wedge_t w{{wd[0], wd[1], wd[2]}, wd[3], {wd[4], wd[5], wd[6]}, {wd[7], wd[8], wd[9]}, {wd[10], wd[11], wd[12]}, wd[13], 0u};
+    vec3 p{0, 0, 0};
+    const bool ok = wedge_diffraction_point_dir(w, vec3{src[0], src[1], src[2]}, vec3{wo[0], wo[1], wo[2]}, p);
+    out3[0] = p.x; out3[1] = p.y; out3[2] = p.z;
+    return ok ? 1 : 0;
+}
+void kat_edge_ellipsoid(const float* p0, const float* p1, const float* c, const float* x, const float* y, const float* axes, float* out2) {
+    const vec2 t = intersect_edge_ellipsoid(vec3{p0[0], p0[1], p0[2]}, vec3{p1[0], p1[1], p1[2]}, vec3{c[0], c[1], c[2]}, vec3{x[0], x[1], x[2]},
+                                            vec3{y[0], y[1], y[2]}, vec3{axes[0], axes[1], axes[2]});
+    out2[0] = t.x;
+    out2[1] = t.y;
+}
+// UTD aperture of the given scene edges seen from `src` through the region at `wp`: samples n directions and returns per sample
+// {wo3, weight, is_direct, pdf(wo)}; the total field |ts|^2,|th|^2 (no occlusion tests) towards dst in out_field
+uint32_t kat_utd_aperture(const void* scene_host, const uint32_t* edge_ids, uint32_t n_ids, const float* wp, const float* frame9, const float* size3,
+                          const float* src, float k, uint64_t seed, uint32_t n, float* out /* n x 6 */) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    static utd_edge_rec_t recs[kUtdMaxEdges];
+    utd_aperture_t ap;
+    const frame_t fr{{frame9[0], frame9[1], frame9[2]}, {frame9[3], frame9[4], frame9[5]}, {frame9[6], frame9[7], frame9[8]}};
+    const vec3 s{src[0], src[1], src[2]}, p{wp[0], wp[1], wp[2]};
+    utd_build_aperture(sc, p, fr, vec3{size3[0], size3[1], size3[2]}, normalize(s - p), k, edge_ids, n_ids, ap, utd_edges_ref_t{recs, 1});
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t smp = make_sampler(seed, i, 7);
+        const utd_sample_t us = utd_sample(sc, ap, utd_edges_ref_t{recs, 1}, s, smp);
+        float* o = out + 6 * i;
+        o[0] = us.wo.x; o[1] = us.wo.y; o[2] = us.wo.z; o[3] = us.weight; o[4] = (float)us.is_direct;
+        o[5] = us.weight > 0.f && !us.is_direct ? utd_pdf(sc, ap, utd_edges_ref_t{recs, 1}, s, us.wo) : 0.f;
+    }
+    return ap.n_edges;
+}
+uint32_t kat_scene_edges(const void* scene_host, uint32_t first, uint32_t n, float* out /* n x {a3,b3,n1 3,n2 3,alpha} */) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    for (uint32_t i = 0; i < n && first + i < sc.n_edges; ++i) {
+        const edge_t e = sc.edges[first + i];
+        float* o = out + 13 * i;
+        o[0] = e.a.x; o[1] = e.a.y; o[2] = e.a.z; o[3] = e.b.x; o[4] = e.b.y; o[5] = e.b.z;
+        o[6] = e.n1.x; o[7] = e.n1.y; o[8] = e.n1.z; o[9] = e.n2.x; o[10] = e.n2.y; o[11] = e.n2.z; o[12] = e.alpha;
+    }
+    return sc.n_edges;
+}
 
 }   // extern "C"

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../wave_tracer_amd/csrc/wt/bdpt.h"
+#include "../wave_tracer_amd/csrc/wt/path.h"
 
 using namespace wt;
 
@@ -58,6 +59,29 @@ void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_
     w.active = 0;
 }
 
+
+// plt_path: src/integrator/plt_path.cpp:39-50 + plt_path_detail.hpp:772-828 — one walk per sample
+void run_path_sample(const scene_t& sc, const film_t& film, uint64_t seed, uint64_t sample_id, uint32_t x, uint32_t y, sample_scratch_t& scr,
+                     std::vector<utd_edge_rec_t>& utd, bdpt_counters_t& ctr) {
+    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    const uint_list_t tris{scr.tris.data(), 1, kOracleConeTris};
+    const utd_edges_ref_t utd_edges{utd.data(), 1};
+    const uint32_t stream = sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
+    const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+    path_walk_t pw;
+    path_generate(sc, seed, sample_id, x, y, pw);
+    for (uint32_t it = 0; it < kMaxWalkIters && pw.w.active; ++it) {
+        const cone_t env = walk_trace_envelope(sc, pw.w);
+        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(pw.w.beam.k), WT_INF, rt, stack, tris);
+        ctr.segments++;
+        ctr.ray_queries += tr.n_ray_queries;
+        ctr.cone_queries += tr.n_cone_queries;
+        ctr.cone_tri_overflow += tr.overflow;
+        pw.w.active = path_walk_step(sc, pw, tr, tris, utd_edges, film, seed, sample_id, stream, stack, &ctr) ? 1u : 0u;
+    }
+    path_finish(sc, film, pw);
+}
+
 }   // namespace
 
 extern "C" {
@@ -91,6 +115,7 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
         const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size()};
         bdpt_counters_t& ctr = ctrs[tid];
         const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+        std::vector<utd_edge_rec_t> utd(kUtdMaxEdges);
         for (;;) {
             const uint32_t blk = next.fetch_add(1);
             if (blk >= bx * by) break;
@@ -102,6 +127,10 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
                         n_done.fetch_add(1, std::memory_order_relaxed);
                         const uint64_t pix = (uint64_t)y * W + x;
                         const uint64_t sample_id = (pix << 32) | (s & 0xFFFFFFFFull);
+                        if (sc.opts.integrator != INTEGRATOR_BDPT) {
+                            run_path_sample(sc, film, seed, sample_id, x, y, scr, utd, ctr);
+                            continue;
+                        }
                         pool_counter = 0;
                         sample_ctx_t ctx;
                         walk_t sw, ew;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -454,6 +455,49 @@ int scene_builder_t::add_emitter_spot(const xform_t& to_world, int spectrum, flo
     e.shape = -1;
     emitters_.push_back(e);
     return (int)emitters_.size() - 1;
+}
+int scene_builder_t::add_emitter_point(dvec3 position, int spectrum, float scale, float extent_m, float pse_scale) {
+    emitter_t e{};
+    e.type = EMIT_POINT;
+    e.spectrum = spectrum;
+    e.scale = scale;
+    e.phase_space_extent_scale = pse_scale;
+    e.position = tof(position);
+    e.frame = frame_t{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    e.extent = extent_m;
+    e.shape = -1;
+    emitters_.push_back(e);
+    return (int)emitters_.size() - 1;
+}
+// ITU-R P.2040-2 table 3 (src/spectrum/util/spectrum_from_ITU.cpp:26-52,78-200): eps_r = a f^b, sigma = c f^d [S/m] (f in GHz),
+// IOR = sqrt(eps_r - i sigma / (eps0 omega)).  Outside a material's frequency range the reference returns 0.
+int scene_builder_t::spectrum_itu(const std::string& material, float wavelength_mm) {
+    struct itu_t {
+        const char* name;
+        double a, b, c, d, fmin_ghz, fmax_ghz;
+    };
+    static const itu_t table[] = {{"vacuum", 1, 0, 0, 0, 0, 1e30},
+                                  {"concrete", 5.24, 0, 0.0462, 0.7822, 1, 100},
+                                  {"brick", 3.91, 0, 0.0238, 0.16, 1, 40},
+                                  {"plasterboard", 2.73, 0, 0.0085, 0.9395, 1, 100},
+                                  {"wood", 1.99, 0, 0.0047, 1.0718, 0.001, 100},
+                                  {"chipboard", 2.58, 0, 0.0217, 0.7800, 1, 100},
+                                  {"plywood", 2.71, 0, 0.33, 0, 1, 40},
+                                  {"marble", 7.074, 0, 0.0055, 0.9262, 1, 60},
+                                  {"metal", 1, 0, 1e7, 0, 1, 100}};
+    const double c0 = 299792458.0, mu0 = 1.25663706212e-6;
+    const double f_hz = c0 / (wavelength_mm * 1e-3), f_ghz = f_hz * 1e-9;
+    for (const auto& t : table) {
+        if (material != t.name) continue;
+        if (f_ghz < t.fmin_ghz || f_ghz > t.fmax_ghz) return spectrum_const(0.f, 0.f);
+        const double eps_r = t.a * (t.b != 0 ? std::pow(f_ghz, t.b) : 1.0);
+        const double sigma = t.c * (t.d != 0 ? std::pow(f_ghz, t.d) : 1.0);
+        const double eps0 = 1.0 / (mu0 * c0 * c0);
+        const double omega = 2.0 * M_PI * f_hz;
+        const std::complex<double> ior = std::sqrt(std::complex<double>(eps_r, -sigma / (eps0 * omega)));
+        return spectrum_const((float)ior.real(), (float)ior.imag());
+    }
+    throw std::runtime_error("unknown ITU material " + material);
 }
 int scene_builder_t::add_emitter_area(int shape, int spectrum, float scale, float pse_scale) {
     emitter_t e{};
@@ -956,6 +1000,8 @@ void scene_builder_t::build_sampling_tables() {
         double geom = 1.0;
         if (e.type == EMIT_SPOT)
             geom = kTwoPi * (1.0 - .5 * (e.cos_cutoff + e.cos_falloff));   // spot_solid_angle
+        else if (e.type == EMIT_POINT)
+            geom = 4.0 * M_PI;   // point.hpp:60-69
         else {
             double area = 0;
             const auto& r = shape_recs_[e.shape];
@@ -1088,7 +1134,7 @@ const scene_t& scene_builder_t::finalize() {
     build_bvh();
     build_edges();
     build_sampling_tables();
-    if (sc_.opts.FSD && !sc_.opts.force_ray_tracing) build_fsd_lut();
+    if (sc_.opts.FSD && !sc_.opts.force_ray_tracing && sc_.opts.integrator == INTEGRATOR_BDPT) build_fsd_lut();   // plt_path diffracts with UTD
 
     sensor_t& s = sc_.sensor;
     s.rfilter_sigma = .25f * rfilter_scale_;

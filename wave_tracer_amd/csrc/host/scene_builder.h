@@ -64,6 +64,9 @@ public:
     int add_shape(const mesh_t& mesh, const xform_t& to_world, int material, bool face_normals = false);
     int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);
     int add_emitter_area(int shape, int spectrum, float scale, float pse_scale);
+    int add_emitter_point(dvec3 position, int spectrum, float scale, float extent_m, float pse_scale);
+    // ITU-R P.2040 material IOR at one wavelength (src/spectrum/util/spectrum_from_ITU.cpp): a constant complex spectrum
+    int spectrum_itu(const std::string& material, float wavelength_mm);
 
     void set_sensor_perspective(const xform_t& to_world, double fov_rad, uint32_t w, uint32_t h, float pse_scale, bool ray_trace_only);
     void set_sensor_virtual_plane(const xform_t& to_world, double extent_x, double extent_y, uint32_t w, uint32_t h, float tan_alpha);
@@ -144,7 +147,8 @@ struct scene_params_t {
     uint32_t debug_only_s, debug_only_t;
     uint32_t crop_of;      // 0: off; else the film is the central res x res crop of a crop_of x crop_of film
 };
-// names: "double_slits", "cornell_box", "furnace" (diffuse box test scene)
+// names: "double_slits", "cornell_box", "furnace" (diffuse box test scene), "white_furnace", "etoile" (plt_path forward + UTD),
+// "furnace_path" (plt_path backward in the furnace scene)
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b);
 
 }   // namespace wth

@@ -212,8 +212,85 @@ static void build_white_furnace(const scene_params_t& p, scene_builder_t& b) {
     b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
 }
 
+// ---- scenes/sionna_etoile/etoile.xml (stand-in) -----------------------------------------------------------------
+// Integrator (plt_path forward, max_depth 16, no RR), sensor "coverage" (virtual_plane 840 m x 630 m at z = 1 mm, alpha .001 deg,
+// film res x .75 res, rfilter_scale .1, monochromatic), the first `point` emitter (80.1, 193.8, 21) m with
+// phase_space_extent_scale .75 and the ITU materials follow the XML with -Dwavelength=10GHz (BASELINE.json configs[3]); the other
+// emitters have no spectral overlap with the 10 GHz sensor.  The Sionna PLY meshes are Git-LFS assets that are absent: the
+// ground plane, the Arc de Triomphe and the building blocks between the twelve avenues are procedural boxes (marble walls,
+// metal roofs, concrete ground) laid out so that the transmitter stands in an avenue like in the original.
+static void build_etoile(const scene_params_t& p, scene_builder_t& b) {
+    const double wavelength_mm = 299792458.0 / 10e9 * 1e3;
+    integrator_opts_t o{};
+    o.integrator = INTEGRATOR_PATH_FORWARD;
+    o.max_depth = 16;
+    o.RR = 0;
+    o.FSD = 1;
+    o.MIS = o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    const uint32_t w = p.res, h = std::max(1u, p.res * 3 / 4);
+    b.set_sensor_virtual_plane(xform_t::translate(0, 0, 1 * mm) * xform_t::scale(1, -1, 1), 840.0, 630.0, w, h, (float)std::tan(deg(.001)));
+    b.set_film_rfilter_scale(.1f);
+    b.set_response_mono_discrete((float)wavelength_mm);
+    b.add_emitter_point({80.1, 193.8, 21.0}, b.spectrum_discrete((float)wavelength_mm, 1.f), 1.f, -1.f, .75f);
+
+    auto itu = [&](const char* name) {
+        material_t m = mat_spm(b.spectrum_itu(name, (float)wavelength_mm), false, 0.f, 3.f, true, 1.f);
+        m.trans_scale = 0.f;   // <spectrum name="transmission_scale" constant="0"/>
+        return b.add_material(m);
+    };
+    const int m_concrete = itu("concrete"), m_marble = itu("marble"), m_metal = itu("metal"), m_brick = itu("brick"), m_wood = itu("wood");
+    auto box = [&](double cx, double cy, double z0, double z1, double sx, double sy, double rot_deg, int mat) {
+        const xform_t X = xform_t::rotate(0, 0, 1, deg(rot_deg)) * xform_t::translate(cx, cy, (z0 + z1) / 2) * xform_t::scale(sx, sy, z1 - z0);
+        b.add_shape(mesh_cube(1.0), X, mat, true);
+    };
+    // ground ("mesh-Plane", concrete)
+    b.add_shape(mesh_rectangle({-600, -600, 0}, {1200, 0, 0}, {0, 1200, 0}), xform_t::identity(), m_concrete, true);
+    // Arc de Triomphe: two piers, the attic on top (marble), a metal cap and wooden doors
+    box(-16, 0, -1, 30, 14, 22, 0, m_marble);
+    box(16, 0, -1, 30, 14, 22, 0, m_marble);
+    box(0, 0, 30, 49, 46, 22, 0, m_marble);
+    box(0, 0, 49, 49.6, 44, 20, 0, m_metal);
+    box(-16, -11.2, 0, 4, 3, .4, 0, m_wood);
+    box(16, 11.2, 0, 4, 3, .4, 0, m_wood);
+    // twelve blocks between the avenues (avenue centres at 7.5 deg + 30 deg i; the transmitter stands in the one at 67.5 deg)
+    const int n_bays = p.mesh_detail > 0 ? 6 : 0;
+    for (int i = 0; i < 12; ++i) {
+        const double ang = 22.5 + 30.0 * i;
+        const double hgt = 24.0 + 3.0 * ((i * 7) % 5);
+        const int wall = (i % 3 == 2) ? m_brick : m_marble;
+        box(240, 0, -1, hgt, 180, 60, ang, wall);
+        box(240, 0, hgt, hgt + .5, 176, 56, ang, m_metal);
+        // facade relief on the avenue sides: protruding bays (more wedges per interaction region)
+        for (int k = 0; k < n_bays; ++k) {
+            const double x = 165 + 150.0 * (k + .5) / n_bays;
+            box(x, 30.6, 3, hgt - 3, 12, 1.2, ang, wall);
+            box(x, -30.6, 3, hgt - 3, 12, 1.2, ang, wall);
+        }
+    }
+}
+
+// plt_path (backward transport) variants of the test scenes: "<scene>_path"
+static void set_path_backward(scene_builder_t& b) {
+    integrator_opts_t o = b.scene().opts;
+    o.integrator = INTEGRATOR_PATH_BACKWARD;
+    b.set_integrator(o);
+}
+
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
-    if (name == "double_slits")
+    if (name == "etoile")
+        build_etoile(p, b);
+    else if (name == "furnace_path") {
+        build_furnace(p, b);
+        set_path_backward(b);
+    } else if (name == "white_furnace_path") {
+        build_white_furnace(p, b);
+        set_path_backward(b);
+    } else if (name == "cornell_box_path") {
+        build_cornell_box(p, b);
+        set_path_backward(b);
+    } else if (name == "double_slits")
         build_double_slits(p, b);
     else if (name == "cornell_box")
         build_cornell_box(p, b);

@@ -1,0 +1,462 @@
+// wave_tracer_amd — the unidirectional PLT integrator `plt_path` (forward: from the emitters, backward: from the sensor) with
+// next-event estimation and UTD free-space diffraction evaluated at the next vertex.
+//
+// Reference: src/integrator/plt_path.cpp:39-50 (per-sample loop),
+//            include/wt/integrator/plt_path/plt_path_detail.hpp:33-143 (walk data), 152-242 (interactions),
+//            256-280 (find_closest_triangle), 303-346 (MIS, do_fsd), 349-472 (nee_backward, emission), 474-549 (nee_forward,
+//            sensing), 551-770 (random_walk), 772-828 (integrate_backward / integrate_forward).
+//
+// The reference's recursion becomes an explicit walk state (path_walk_t) advanced one segment at a time: the trace kernels
+// (wtgpu.hip: k_trace / k_trace_heavy) only read its walk_t prefix; path_walk_step below is everything after traverse().
+// The std::unique_ptr<free_space_diffraction_t> of the walk becomes a per-walk slot of compact wedge records (utd.h).
+#pragma once
+#include "bdpt.h"
+#include "utd.h"
+
+namespace wt {
+
+struct path_walk_t {
+    walk_t w;   // MUST be first.  beam, from_previous_dpd (pdf_from_prev), throughput, depth (nverts), active, rng_draws,
+                // prev_vert_geo (prev_wp, prev_ng, prev_on_surface, prev_offset_tuid)
+    beam_t prev_beam;   // prev_vert_beam
+    uint32_t has_prev_beam;
+    uint32_t sampled_fsd;
+    uint32_t has_fsd;   // fsd_bsdf != nullptr: aperture header `ap` + the walk's wedge records
+    utd_aperture_t ap;
+    float L[4];   // backward transport: radiance gathered so far (Stokes)
+    float recp_spectral_pd;
+    sensor_element_t element;   // backward transport: the sampled sensor element
+};
+constexpr size_t kPathWalkWords = sizeof(path_walk_t) / 4;
+static_assert(offsetof(path_walk_t, w) == 0, "trace kernels read the walk_t prefix");
+
+// vertex_geo_variant_t restricted to what shadow()/offseted_ray_origin() consume
+enum path_geo_kind_e : uint32_t { PGEO_POINT = 0, PGEO_SURFACE = 1, PGEO_EDGE = 2 };
+struct path_geo_t {
+    vec3 wp;
+    uint32_t kind;
+    vec3 ng;         // surface
+    uint32_t tuid;   // surface: triangle (kInvalid: no offset); edge: edge id
+};
+WT_HD path_geo_t path_geo_point(vec3 p) { return path_geo_t{p, PGEO_POINT, vec3{0, 0, 1}, kInvalid}; }
+WT_HD path_geo_t path_geo_surface(const surface_t& s) { return path_geo_t{s.wp, PGEO_SURFACE, s.geo.n, s.tuid}; }
+WT_HD path_geo_t path_geo_edge(uint32_t edge, vec3 p) { return path_geo_t{p, PGEO_EDGE, vec3{0, 0, 1}, edge}; }
+WT_HD path_geo_t path_geo_prev(const walk_t& w) {
+    return path_geo_t{w.prev_wp, w.prev_offset_tuid != kInvalid ? PGEO_SURFACE : PGEO_POINT, w.prev_ng, w.prev_offset_tuid};
+}
+// intersection_{surface,edge}_t::offseted_ray_origin (src/interaction/intersection.cpp:148-211)
+WT_HD vec3 path_geo_offseted_origin(const scene_t& sc, const path_geo_t& g, vec3 ro, vec3 rd) {
+    if (g.kind == PGEO_SURFACE) {
+        if (g.tuid == kInvalid) return ro;
+        const tri_geo_t t = sc.tri_geo[g.tuid];
+        const vec3 err = triangle_fp_errors(t.a, t.b, t.c, ro);
+        const float offset_dist = dot(err, vabs(g.ng));
+        const vec3 offset = offset_dist * g.ng;
+        return ro + (dot(rd, offset) >= 0.f ? offset : -offset);
+    }
+    if (g.kind == PGEO_EDGE) {
+        const edge_t ed = sc.edges[g.tuid];
+        // offset away from the wedge
+        vec3 dir;
+        if (ed.tri2 == kInvalid)
+            dir = -ed.t1;
+        else {
+            const vec3 v = ed.t1 + ed.t2;
+            dir = length2(v) > 1e-14f ? -normalize(v) : -ed.t2;
+        }
+        const tri_geo_t t1 = sc.tri_geo[ed.tri1];
+        float d = dot(triangle_fp_errors(t1.a, t1.b, t1.c, ro), vabs(ed.t1));
+        if (ed.tri2 != kInvalid) {
+            const tri_geo_t t2 = sc.tri_geo[ed.tri2];
+            d = fmaxf_(d, dot(triangle_fp_errors(t2.a, t2.b, t2.c, ro), vabs(ed.t2)));
+        }
+        return ro + d * dir;
+    }
+    return ro;
+}
+// integrator::shadow (traversal.hpp:319-333): TRUE if occluded
+WT_HD bool path_shadow(const scene_t& sc, const path_geo_t& a, const path_geo_t& b, const stack_ref_t& stack, bdpt_counters_t* ctr) {
+    const vec3 rd = normalize(b.wp - a.wp);
+    const vec3 o = path_geo_offseted_origin(sc, a, a.wp, rd);
+    const vec3 t = path_geo_offseted_origin(sc, b, b.wp, -rd);
+    const float dist = length(t - o);
+    const vec3 d = (t - o) / dist;
+    if (ctr) ctr->shadow_rays++;
+    return ads_shadow_ray(sc, o, d, range_t{0.f, dist}, stack);
+}
+
+// elliptic_cone_t::contains (elliptic_cone.hpp:158-172)
+WT_HD bool cone_contains(const cone_t& c, vec3 p) {
+    const vec3 l = to_local(cone_frame(c), p - c.o);
+    return l.z >= 0.f && c.z_apex <= l.z && sqr(l.x) + sqr(c.e * l.y) <= sqr(l.z * c.tan_alpha + c.x0);
+}
+
+// power MIS heuristic (plt_path_detail.hpp:303-308)
+WT_HD float path_mis(float pd1, float pd2) {
+    if (pd2 == 0.f) return 1.f;
+    return pd1 * pd1 / (pd1 * pd1 + pd2 * pd2);
+}
+
+// beam_t::operator+= (beam.hpp:95-98 forward, 200-203 backward [the addend's scale is not applied there], 482-485)
+WT_HD void beam_add(beam_t& b, const beam_t& o) {
+    if (b.transport == TRANSPORT_FORWARD) {
+        const stokes_t S = beam_S(b) + stokes_reorient(beam_S(o), o.frame, b.frame);
+        for (int i = 0; i < 4; ++i) b.rad[i] = S.s[i];
+    } else {
+        beam_set_M(b, beam_M(b) + mueller_change_incident_frame(beam_M(o), o.frame, b.frame));
+    }
+}
+
+struct cpair_t {
+    cplx ts, th;
+};
+// do_fsd (plt_path_detail.hpp:311-346): coherent sum of the diffracted fields of the aperture's wedges (+ the direct path)
+WT_HD cpair_t path_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const path_geo_t& src_geo, vec3 dst, const utd_aperture_t& ap,
+                          const utd_edges_ref_t& edges, float k, const stack_ref_t& stack, bdpt_counters_t* ctr) {
+    const vec3 src = cone_from_src.o;
+    const path_geo_t dst_geo = path_geo_point(dst);
+    cplx ts{0.f, 0.f}, th{0.f, 0.f};
+    for (uint32_t i = 0; i < ap.n_edges; ++i) {
+        utd_diffracting_edge_t f;
+        if (!utd_f_edge(sc, ap, edges[i], src, dst, f)) continue;
+        const path_geo_t eintr = path_geo_edge(f.edge, f.p);
+        if (path_shadow(sc, eintr, src_geo, stack, ctr) || path_shadow(sc, eintr, dst_geo, stack, ctr)) continue;
+        const float d = f.ro + f.ri;
+        const cplx phase = cpolar(1.f, -k_times_len(k, d));
+        ts = ts + phase * f.utd.Ds;
+        th = th + phase * f.utd.Dh;
+    }
+    if (cone_contains(cone_from_src, dst)) {
+        if (!path_shadow(sc, src_geo, dst_geo, stack, ctr)) {
+            // direct path
+            const float d = length(dst - src);
+            const cplx phase = cpolar(1.f, -k_times_len(k, d));
+            ts = ts + phase;
+            th = th + phase;
+        }
+    }
+    return cpair_t{ts, th};
+}
+
+// ordered, de-duplicated edge set of a triangle list (ads/traversal_common.hpp:124-148)
+template <class TriList>
+WT_HD uint32_t path_gather_edge_ids(const scene_t& sc, const TriList& tris, uint32_t ntris, uint32_t* edge_ids, bdpt_counters_t* ctr) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < ntris; ++i) {
+        const tri_meta_t m = sc.tri_meta[tris[i]];
+        for (int e = 0; e < 3; ++e) {
+            const uint32_t id = m.edge[e];
+            if (id == kInvalid) continue;
+            uint32_t pos = 0;
+            while (pos < n && edge_ids[pos] < id) ++pos;
+            if (pos < n && edge_ids[pos] == id) continue;
+            if (n == kMaxEdgeIds) {
+                if (ctr) ctr->edge_overflow++;
+                continue;
+            }
+            for (uint32_t j = n; j > pos; --j) edge_ids[j] = edge_ids[j - 1];
+            edge_ids[pos] = id;
+            ++n;
+        }
+    }
+    return n;
+}
+
+// integrate_forward / integrate_backward up to the first random_walk call (plt_path_detail.hpp:772-828)
+WT_HD void path_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, uint32_t px, uint32_t py, path_walk_t& pw) {
+    sampler_t smp = make_sampler(seed, sample_id, STREAM_SCENE);
+    walk_t& w = pw.w;
+    pw.has_prev_beam = 0;
+    pw.sampled_fsd = 0;
+    pw.has_fsd = 0;
+    pw.ap.n_edges = 0;
+    pw.ap.overflow = 0;
+    pw.ap.k = 0.f;
+    pw.ap.interaction_wp = vec3{0, 0, 0};
+    pw.L[0] = pw.L[1] = pw.L[2] = pw.L[3] = 0.f;
+    pw.element = sensor_element_t{0, 0, {0.f, 0.f}};
+    w.throughput = 1.f;
+    w.rr_weight = 1.f;
+    w.nverts = 1;   // depth
+    w.rng_draws = 0;
+    w.pdf_from_prev = pd_discrete(0.f);
+    w.prev_ng = vec3{0, 0, 1};
+    w.prev_on_surface = 0;
+    w.prev_offset_tuid = kInvalid;
+    w.active = sc.opts.max_depth > 0 ? 1u : 0u;
+    if (sc.opts.integrator == INTEGRATOR_PATH_FORWARD) {
+        const emitter_k_sample_t ek = scene_sample_emitter_and_spectrum(sc, smp);
+        const float k = ek.wavenumber.k;
+        const emitter_sample_t es = emitter_sample(sc, ek.emitter, k, smp);
+        pw.recp_spectral_pd = 1.f / scene_sum_spectral_pdf(sc, k);
+        w.beam = es.beam;
+        pw.prev_beam = es.beam;
+        w.prev_wp = es.beam.env.o;   // prev_vert_geo = the beam's origin (a point, also for area emitters)
+    } else {
+        const emitter_k_sample_t ek = scene_sample_emitter_and_spectrum(sc, smp);
+        const float k = ek.wavenumber.k;
+        const bool disc = pd_is_discrete(ek.wavenumber.wpd);
+        pw.recp_spectral_pd = disc ? 1.f / pd_mass(ek.wavenumber.wpd) : 1.f / scene_sum_spectral_pdf(sc, k);
+        const sensor_sample_t ss = sensor_sample(sc, px, py, k, smp);
+        pw.element = ss.element;
+        w.beam = ss.beam;
+        pw.prev_beam = ss.beam;
+        w.prev_wp = ss.beam.env.o;
+    }
+}
+
+// Terminates a walk: backward transport splats what it gathered (integrate_backward, plt_path_detail.hpp:800-801).
+WT_HD void path_finish(const scene_t& sc, const film_t& film, path_walk_t& pw) {
+    pw.w.active = 0;
+    if (sc.opts.integrator != INTEGRATOR_PATH_BACKWARD) return;
+    const stokes_t L{{pw.L[0] * pw.recp_spectral_pd, pw.L[1] * pw.recp_spectral_pd, pw.L[2] * pw.recp_spectral_pd, pw.L[3] * pw.recp_spectral_pd}};
+    film_splat(sc, film, pw.element, L, pw.w.beam.k);
+}
+
+// One step of plt_path::random_walk after traverse() (plt_path_detail.hpp:574-770).  Returns TRUE if the walk continues.
+// `tris`: the traversal's triangle list; also receives the list of the ballistic edge query (plt_path_detail.hpp:645-650).
+// `utd_edges`: the walk's wedge-record slot (kUtdMaxEdges entries).
+WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_t& tr, const uint_list_t& tris, const utd_edges_ref_t& utd_edges,
+                          const film_t& film, uint64_t seed, uint64_t sample_id, uint32_t stream, const stack_ref_t& stack, bdpt_counters_t* ctr) {
+    walk_t& w = pw.w;
+    if (tr.empty) return false;   // no intersection (TODO in the reference: infinite emitters)
+    const bool backward = sc.opts.integrator == INTEGRATOR_PATH_BACKWARD;
+    const int depth = (int)w.nverts;
+    sampler_t smp = make_sampler(seed, sample_id, stream, w.rng_draws);
+    beam_t& beam = w.beam;
+    const float k = beam.k;
+    const float dist_to_interaction = tr.dist;
+    const bool is_ballistic = tr.ballistic || beam_is_ray(beam);
+    const frame_t beam_frame = cone_frame(beam.env);
+    const cone_t envelope = beam.env;
+    const vec3 origin_wp = tr.origin;
+    const vec3 interaction_wp = origin_wp + dist_to_interaction * beam.env.d;
+    const bool force_rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+
+    // ---- evaluate fsd from the previous interaction (plt_path_detail.hpp:616-636)
+    if (pw.has_fsd) {
+        const cone_t prev_cone = pw.prev_beam.env;
+        const cpair_t fsd = path_do_fsd(sc, prev_cone, path_geo_prev(w), interaction_wp, pw.ap, utd_edges, k, stack, ctr);
+        pw.has_fsd = 0;
+        const float f = (cnorm(fsd.ts) + cnorm(fsd.th)) / 2.f;
+        if (pw.sampled_fsd)
+            beam_scale(beam, f);
+        else {
+            beam_transform_region_interaction(pw.prev_beam, origin_wp, length(origin_wp - prev_cone.o), beam.env.d, f);
+            beam_add(beam, pw.prev_beam);
+        }
+    }
+
+    // ---- the triangle under the interaction point, if any (plt_path_detail.hpp:639-681)
+    uint32_t primary = kInvalid;
+    ray_tri_hit_t phit{WT_INF, 0.f, 0.f};
+    if (is_ballistic) {
+        primary = tr.tuid;
+        phit.dist = tr.dist;
+        phit.bx = tr.bx;
+        phit.by = tr.by;
+    } else {
+        const range_t izr{dist_to_interaction, dist_to_interaction + tr.region_depth};
+        for (uint32_t i = 0; i < tr.ntris; ++i) {
+            const uint32_t tuid = tris[i];
+            const tri_geo_t g = sc.tri_geo[tuid];
+            const float fptol = cone_intersection_tolerance(origin_wp, g.a, g.b, g.c);
+            ray_tri_hit_t h;
+            if (intersect_ray_tri(origin_wp, beam.env.d, g.a, g.b, g.c, grow(izr, fptol), h) && h.dist < phit.dist) {
+                primary = tuid;
+                phit = h;
+            }
+        }
+    }
+    const float interaction_region_end = primary != kInvalid ? phit.dist : dist_to_interaction;
+    surface_t srf;
+    if (primary != kInvalid) {
+        const tri_geo_t g = sc.tri_geo[primary];
+        srf = make_surface(sc, primary, g.n, vec2{phit.bx, phit.by}, origin_wp + phit.dist * beam.env.d);
+        srf.footprint = beam_surface_footprint_static(beam, srf, dist_to_interaction);
+    }
+
+    // ---- edges of the interaction region (plt_path_detail.hpp:593, 684-689)
+    uint32_t edge_ids[kMaxEdgeIds];
+    uint32_t n_edge_ids = 0;
+    if (sc.opts.FSD && !is_ballistic) {
+        n_edge_ids = path_gather_edge_ids(sc, tris, tr.ntris, edge_ids, ctr);
+    } else if (is_ballistic && !beam_is_ray(beam) && !force_rt) {
+        // ballistic: find the edges around the intersection with a cone query over a slab of the region's depth
+        const float zdist = cone_axes(envelope, dist_to_interaction).x * kMajorAxisToZScale;
+        cone_hit_t ch;
+        bvh_traverse_cone(sc, envelope, range_t{dist_to_interaction - zdist / 2.f, dist_to_interaction + zdist / 2.f}, 1.f, stack, tris, ch);
+        if (ctr) {
+            ctr->cone_queries++;
+            ctr->cone_tri_overflow += ch.overflow;
+        }
+        n_edge_ids = path_gather_edge_ids(sc, tris, ch.ntris, edge_ids, ctr);
+    }
+
+    // ---- construct the fsd BSDF (plt_path_detail.hpp:692-709)
+    if (n_edge_ids > 0) {
+        const vec3 footprint = beam_footprint(beam, dist_to_interaction);
+        utd_build_aperture(sc, interaction_wp, beam_frame, footprint, -beam.env.d, k, edge_ids, n_edge_ids, pw.ap, utd_edges);
+        pw.has_fsd = pw.ap.n_edges > 0 ? 1u : 0u;
+        if (ctr) {
+            ctr->fsd_interactions++;
+            ctr->fsd_edge_overflow += pw.ap.overflow;
+        }
+    }
+
+    // ---- NEE
+    if (backward && depth < sc.opts.max_depth && primary != kInvalid) {
+        // nee_backward (plt_path_detail.hpp:349-425)
+        const int mat = sc.shapes[srf.shape].material;
+        if (!material_is_delta_only(sc, mat)) {
+            const emitter_direct_sample_t ds = scene_sample_emitter_direct(sc, srf.wp, k, smp);
+            if (beam_intensity(ds.beam) != 0.f) {
+                const vec3 wiworld = -beam.env.d, woworld = -ds.beam.env.d;
+                const vec3 ng = srf.geo.n;
+                const vec3 wi = to_local(srf.shading, wiworld), wo = to_local(srf.shading, woworld);
+                const float wig = dot(wiworld, ng), wog = dot(woworld, ng);
+                if (!(wi.z * wig <= 0.f || wo.z * wog <= 0.f)) {
+                    const mueller_t f = material_f(sc, mat, wi, wo, k, TRANSPORT_BACKWARD);
+                    if (mueller_mean_intensity(f) != 0.f) {
+                        const path_geo_t emitter_geo = ds.has_surface ? path_geo_surface(ds.surface) : path_geo_point(ds.beam.env.o);
+                        if (!path_shadow(sc, path_geo_surface(srf), emitter_geo, stack, ctr)) {
+                            beam_t nee_beam = beam;
+                            beam_transform_surface_interaction(nee_beam, srf, woworld, f, 1.f);
+                            const stokes_t sL = integrate_beams(nee_beam, ds.beam);
+                            float mis = 1.f;
+                            if (!pd_is_discrete(ds.dpd)) {
+                                const float pd_brdf = pd_density_or_zero(material_pdf(sc, mat, wi, wo, k, TRANSPORT_BACKWARD));
+                                const float pd_direct = ds.dpd * ds.emitter_pdf;
+                                mis = path_mis(pd_direct, pd_brdf);
+                            }
+                            if (ctr) ctr->connections++;
+                            for (int i = 0; i < 4; ++i) pw.L[i] += sL.s[i] * mis;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!backward && depth < sc.opts.max_depth && pw.has_fsd && sensor_is_virtual(sc.sensor)) {
+        // nee_forward (plt_path_detail.hpp:474-518): only on FSD, only towards virtual coverage sensors
+        const sensor_direct_sample_t sd = sensor_sample_direct(sc, interaction_wp, k, smp);
+        if ((pd_is_discrete(sd.dpd) || sd.dpd != 0.f) && beam_intensity(sd.beam) > 0.f) {
+            const cpair_t fsd = path_do_fsd(sc, beam.env, path_geo_prev(w), sd.beam.env.o, pw.ap, utd_edges, k, stack, ctr);
+            const float f = (cnorm(fsd.ts) + cnorm(fsd.th)) / 2.f;
+            if (f != 0.f) {
+                beam_t fsd_beam = beam;
+                beam_transform_region_interaction(fsd_beam, interaction_wp, dist_to_interaction, -sd.beam.env.d, f);
+                const stokes_t sL = integrate_beams(sd.beam, fsd_beam);
+                film_splat_direct(sc, film, sd.element, sL * pw.recp_spectral_pd, k);
+                if (ctr) {
+                    ctr->connections++;
+                    ctr->light_splats++;
+                }
+            }
+        }
+    }
+
+    // ---- organic connections
+    if (backward && primary != kInvalid) {
+        // emission (plt_path_detail.hpp:427-472)
+        const int ei = sc.shapes[srf.shape].emitter;
+        if (ei >= 0) {
+            const stokes_t sL = emitter_Li(sc, ei, beam, srf);
+            float mis = 1.f;
+            if (!pd_is_discrete(w.pdf_from_prev)) {
+                const float emitter_pm = sc.emitters[ei].select_pmf;
+                const float emitter_ppd = pd_density_or_zero(emitter_pdf_position(sc, ei));
+                const float dn = dot(-beam.env.d, srf.geo.n);
+                const float recp_dn = dn != 0.f ? 1.f / fabsf(dn) : 0.f;
+                const float l2 = length2(beam.env.o - srf.wp);
+                const float pd_nee = emitter_ppd * l2 * recp_dn;
+                mis = path_mis(w.pdf_from_prev, pd_nee * emitter_pm);
+            }
+            if (ctr) ctr->connections++;
+            for (int i = 0; i < 4; ++i) pw.L[i] += sL.s[i] * mis;
+        }
+    }
+    if (!backward && sensor_is_virtual(sc.sensor)) {
+        // sensing (plt_path_detail.hpp:520-549): does this segment cross the virtual sensor?
+        const float max_distance = interaction_region_end - fmaxf_(0.f, dot(beam.env.d, origin_wp - beam.env.o));
+        const sensor_direct_connection_t dc = vplane_Si(sc, beam, range_t{0.f, max_distance});
+        if (dc.valid) {
+            const stokes_t sL = integrate_beams(dc.beam, beam);
+            film_splat_direct(sc, film, dc.element, sL * pw.recp_spectral_pd, k);
+            if (ctr) ctr->light_splats++;
+        }
+    }
+
+    // ---- interactions
+    bool sampled_null = false;
+    if (primary != kInvalid) {
+        // sample_surface_interaction (plt_path_detail.hpp:152-201)
+        const int mat = sc.shapes[srf.shape].material;
+        const uint32_t transport = beam.transport;
+        const vec3 ng = srf.geo.n;
+        const vec3 wiworld = -beam.env.d;
+        const vec3 wi = to_local(srf.shading, wiworld);
+        const float wig = dot(wiworld, ng), wis = wi.z;
+        if (wig * wis <= 0.f) return false;
+        const bsdf_sample_t bs = material_sample(sc, mat, wi, k, transport, smp);
+        w.rng_draws = smp.draws;
+        if (!bs.valid || bs.dpd == 0.f) return false;
+        const vec3 wo = bs.wo;
+        const vec3 woworld = normalize(to_world(srf.shading, wo));
+        const float wog = dot(woworld, ng), wos = wo.z;
+        if (ctr) ctr->surface_interactions++;
+        if (wog * wos <= 0.f) return false;
+        // transform_surface_interaction (plt_path_detail.hpp:63-83)
+        w.pdf_from_prev = bs.dpd;
+        w.prev_wp = srf.wp;
+        w.prev_ng = srf.geo.n;
+        w.prev_on_surface = 1;
+        w.prev_offset_tuid = srf.tuid;
+        pw.prev_beam = beam;
+        pw.has_prev_beam = 1;
+        pw.sampled_fsd = 0;
+        beam_transform_surface_interaction(beam, srf, woworld, bs.M, 1.f);
+        w.throughput *= mueller_mean_intensity(bs.M);
+        if (bs.eta != 1.f) w.throughput /= sqr(bs.eta);
+    } else if (pw.has_fsd) {
+        // sample_fsd_interaction (plt_path_detail.hpp:217-235)
+        const utd_sample_t us = utd_sample(sc, pw.ap, utd_edges, w.prev_wp, smp);
+        // transform_fsd_interaction (plt_path_detail.hpp:104-119)
+        w.pdf_from_prev = pd_discrete(0.f);
+        w.prev_wp = interaction_wp;
+        w.prev_ng = vec3{0, 0, 1};
+        w.prev_on_surface = 0;
+        w.prev_offset_tuid = kInvalid;
+        pw.prev_beam = beam;
+        pw.has_prev_beam = 1;
+        pw.sampled_fsd = 1;
+        beam_transform_region_interaction(beam, interaction_wp, dist_to_interaction, us.wo, us.weight);
+        w.throughput *= us.weight;
+    } else {
+        // sample_null_interaction (plt_path_detail.hpp:203-215): trace restart, no vertex
+        sampled_null = true;
+        beam_transform_restart(beam, interaction_wp, dist_to_interaction);
+        if (ctr) ctr->null_interactions++;
+    }
+
+    // ---- continue_walk (plt_path_detail.hpp:125-143)
+    bool cont = true;
+    if (depth >= sc.opts.max_depth)
+        cont = false;
+    else if (beam_intensity(beam) == 0.f)
+        cont = false;
+    else if (!sampled_null && sc.opts.RR) {
+        const float r = w.throughput < 1.f ? fmaxf_(w.throughput, .5f) : 1.f;
+        if (sampler_r(smp) <= r) {
+            const float scale = 1.f / r;
+            beam_scale(beam, scale);
+            w.throughput *= scale;
+        } else
+            cont = false;
+    }
+    w.rng_draws = smp.draws;
+    if (cont && !sampled_null) w.nverts = (uint32_t)depth + 1u;
+    return cont;
+}
+
+}   // namespace wt

@@ -88,7 +88,7 @@ struct material_t {
 };
 
 // ---- emitters ------------------------------------------------------------------------------------
-enum emitter_type_e : int32_t { EMIT_SPOT = 0, EMIT_AREA = 1 };
+enum emitter_type_e : int32_t { EMIT_SPOT = 0, EMIT_AREA = 1, EMIT_POINT = 2 };
 struct emitter_t {
     int32_t type;
     int32_t spectrum;   // radiant intensity (spot) / radiance (area), value multiplies `scale`
@@ -142,8 +142,10 @@ struct sensor_t {
     float requested_tan_alpha;   // <0: none (MUB)
 };
 
+enum integrator_type_e : uint32_t { INTEGRATOR_BDPT = 0, INTEGRATOR_PATH_FORWARD = 1, INTEGRATOR_PATH_BACKWARD = 2 };
 struct integrator_opts_t {
     int32_t max_depth;
+    uint32_t integrator;   // INTEGRATOR_* (plt_bdpt, or plt_path with its transport direction)
     uint32_t MIS, RR, FSD, sensor_direct, emitter_direct;
     uint32_t force_ray_tracing;
     // test hooks: evaluate a single (s,t) strategy with unit MIS weight (0 = all strategies; v>0 selects v-1)

@@ -45,7 +45,7 @@ struct sensor_direct_sample_t {
 
 // ================================ emitters ==========================================================
 WT_HD bool emitter_is_area(const emitter_t& e) { return e.type == EMIT_AREA; }
-WT_HD bool emitter_is_delta_position(const emitter_t& e) { return e.type == EMIT_SPOT; }
+WT_HD bool emitter_is_delta_position(const emitter_t& e) { return e.type == EMIT_SPOT || e.type == EMIT_POINT; }
 WT_HD bool emitter_is_delta_direction(const emitter_t&) { return false; }
 
 // spot_t::compute_falloff (spot.hpp:65-70)
@@ -68,6 +68,20 @@ WT_HD sourcing_geometry_t area_sourcing_geometry(const emitter_t& e, float k) {
     const phase_space_extent_t se =
         pse_enlarge(sg_phase_space_extent(sg_source_mub_from_length(initial_spatial_extent, k)), e.phase_space_extent_scale);
     return sg_source(se);
+}
+// point_t::sourcing_geometry (point.hpp:74-86)
+WT_HD sourcing_geometry_t point_sourcing_geometry(const emitter_t& e, float k) {
+    const float initial_spatial_extent = e.extent > 0.f ? e.extent : 10.f * wavenum_to_wavelen_m(k);
+    const phase_space_extent_t se =
+        pse_enlarge(sg_phase_space_extent(sg_source_mub_from_length(initial_spatial_extent, k)), e.phase_space_extent_scale);
+    return sg_source(se);
+}
+// sampler_t::uniform_sphere (sampler.hpp:147-152)
+WT_HD vec3 uniform_sphere(vec2 u) {
+    const float z = 1.f - 2.f * u.x;
+    const float rr = sqrtf(fmaxf_(0.f, 1.f - sqr(z)));
+    const float phi = kTwoPi * u.y;
+    return vec3{rr * cosf(phi), rr * sinf(phi), z};
 }
 WT_HD float emitter_spectral_value(const scene_t& sc, const emitter_t& e, float k) { return spectrum_f(sc, e.spectrum, k) * e.scale; }
 
@@ -103,6 +117,13 @@ WT_HD emitter_sample_t emitter_sample(const scene_t& sc, int ei, float k, sample
         beam_scale(r.beam, w / dpd);
         r.ppd = pd_discrete(1.f);
         r.dpd = dpd;
+    } else if (e.type == EMIT_POINT) {
+        // point_t::sample (src/emitter/point.cpp:28-43)
+        const vec3 d = uniform_sphere(sampler_r2(sampler));
+        r.beam = make_forward_beam(e.position, d, emitter_spectral_value(sc, e, k), k, point_sourcing_geometry(e, k));
+        beam_scale(r.beam, 4.f * kPi);
+        r.ppd = pd_discrete(1.f);
+        r.dpd = kInvTwoPi * .5f;
     } else {
         float ppd;
         r.surface = shape_sample_position(sc, e.shape, sampler, ppd);
@@ -123,13 +144,14 @@ WT_HD emitter_sample_t emitter_sample(const scene_t& sc, int ei, float k, sample
 // emitter_t::pdf_position
 WT_HD float emitter_pdf_position(const scene_t& sc, int ei) {
     const emitter_t e = sc.emitters[ei];
-    if (e.type == EMIT_SPOT) return pd_discrete(1.f);
+    if (e.type == EMIT_SPOT || e.type == EMIT_POINT) return pd_discrete(1.f);
     return sc.shapes[e.shape].recp_surface_area;
 }
 // emitter_t::pdf_direction (solid-angle density)
 WT_HD float emitter_pdf_direction(const scene_t& sc, int ei, vec3 dir, const surface_t* surface) {
     const emitter_t e = sc.emitters[ei];
     if (e.type == EMIT_SPOT) return uniform_cone_pdf(kTwoPi * (1.f - e.cos_cutoff));
+    if (e.type == EMIT_POINT) return kInvTwoPi * .5f;   // point.hpp pdf_direction: uniform sphere
     const float dn = fmaxf_(0.f, dot(dir, surface->geo.n));
     return cosine_hemisphere_pdf(dn);
 }
@@ -156,6 +178,14 @@ WT_HD emitter_direct_sample_t emitter_sample_direct(const scene_t& sc, int ei, v
         const float w = spot_falloff(e, local_wo);
         r.beam = make_forward_beam(e.position, d, emitter_spectral_value(sc, e, k), k, spot_sourcing_geometry(e, k));
         beam_scale(r.beam, w * recp_dist2);
+        r.dpd = pd_discrete(1.f);
+    } else if (e.type == EMIT_POINT) {
+        // point_t::sample_direct (src/emitter/point.cpp:45-61)
+        const vec3 dl = wp - e.position;
+        const float recp_dist2 = 1.f / length2(dl);
+        const vec3 d = dl * sqrtf(recp_dist2);
+        r.beam = make_forward_beam(e.position, d, emitter_spectral_value(sc, e, k), k, point_sourcing_geometry(e, k));
+        beam_scale(r.beam, recp_dist2);
         r.dpd = pd_discrete(1.f);
     } else {
         float ppd;
