@@ -212,6 +212,13 @@ static void build_white_furnace(const scene_params_t& p, scene_builder_t& b) {
     b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
 }
 
+// plt_path (backward transport) variants of the test scenes: "<scene>_path"
+static void set_path_backward(scene_builder_t& b) {
+    integrator_opts_t o = b.scene().opts;
+    o.integrator = INTEGRATOR_PATH_BACKWARD;
+    b.set_integrator(o);
+}
+
 // ---- scenes/sionna_etoile/etoile.xml (stand-in) -----------------------------------------------------------------
 // Integrator (plt_path forward, max_depth 16, no RR), sensor "coverage" (virtual_plane 840 m x 630 m at z = 1 mm, alpha .001 deg,
 // film res x .75 res, rfilter_scale .1, monochromatic), the first `point` emitter (80.1, 193.8, 21) m with
@@ -219,7 +226,7 @@ static void build_white_furnace(const scene_params_t& p, scene_builder_t& b) {
 // emitters have no spectral overlap with the 10 GHz sensor.  The Sionna PLY meshes are Git-LFS assets that are absent: the
 // ground plane, the Arc de Triomphe and the building blocks between the twelve avenues are procedural boxes (marble walls,
 // metal roofs, concrete ground) laid out so that the transmitter stands in an avenue like in the original.
-static void build_etoile(const scene_params_t& p, scene_builder_t& b) {
+static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_ground_only = false) {
     const double wavelength_mm = 299792458.0 / 10e9 * 1e3;
     integrator_opts_t o{};
     o.integrator = INTEGRATOR_PATH_FORWARD;
@@ -247,6 +254,7 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b) {
     };
     // ground ("mesh-Plane", concrete)
     b.add_shape(mesh_rectangle({-600, -600, 0}, {1200, 0, 0}, {0, 1200, 0}), xform_t::identity(), m_concrete, true);
+    if (open_ground_only) return;   // "etoile_open": transmitter over bare ground (closed-form coverage test)
     // Arc de Triomphe: two piers, the attic on top (marble), a metal cap and wooden doors
     box(-16, 0, -1, 30, 14, 22, 0, m_marble);
     box(16, 0, -1, 30, 14, 22, 0, m_marble);
@@ -271,17 +279,22 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b) {
     }
 }
 
-// plt_path (backward transport) variants of the test scenes: "<scene>_path"
-static void set_path_backward(scene_builder_t& b) {
-    integrator_opts_t o = b.scene().opts;
-    o.integrator = INTEGRATOR_PATH_BACKWARD;
-    b.set_integrator(o);
-}
 
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
     if (name == "etoile")
         build_etoile(p, b);
-    else if (name == "furnace_path") {
+    else if (name == "etoile_open")
+        build_etoile(p, b, true);
+    else if (name == "etoile_bdpt") {   // the same scene under plt_bdpt (cross-validation of the two integrators)
+        build_etoile(p, b);
+        integrator_opts_t o = b.scene().opts;
+        o.integrator = INTEGRATOR_BDPT;
+        o.RR = 1;
+        b.set_integrator(o);
+    } else if (name == "etoile_path_backward") {
+        build_etoile(p, b);
+        set_path_backward(b);
+    } else if (name == "furnace_path") {
         build_furnace(p, b);
         set_path_backward(b);
     } else if (name == "white_furnace_path") {

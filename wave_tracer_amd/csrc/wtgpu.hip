@@ -31,6 +31,7 @@
 #include "host/scene_builder.h"
 #include "wt/bdpt.h"
 #include "wt/coop.h"
+#include "wt/path.h"
 
 using namespace wt;
 
@@ -80,6 +81,7 @@ struct device_state_t {
     uint32_t* strat_count = nullptr;    // [kNumKeys]
     uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
     double* lacc = nullptr;             // [4][cap] per-sample sum of the t>1 strategies' fluxes
+    utd_edge_rec_t* utd = nullptr;      // plt_path: [cap][kUtdMaxEdges] wedge records of each walk's UTD aperture
     unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
@@ -484,6 +486,82 @@ __global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int i
     interact_body<true>(a, in, 0, lds);
 }
 
+// ---- plt_path: one walk per sample; k_trace / k_trace_heavy are shared with plt_bdpt (they only read the walk_t
+// prefix of the walk record), the interaction step is path_walk_step (wt/path.h): UTD evaluation of the previous aperture (shadow
+// rays through the LDS stack), primary triangle, edge query, aperture construction, NEE / sensing splats (f64 atomics), sampling.
+__global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        uint32_t* ctl = a.st.ctl;
+        ctl[CTL_COUNT0] = a.nb;
+        ctl[CTL_COUNT1] = 0;
+        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = 0;
+    }
+    if (i >= a.nb) return;
+    const uint64_t j = a.j0 + i;
+    const uint32_t pix = (uint32_t)(j % a.npix);
+    const uint64_t s = a.sample_begin + j / a.npix;
+    const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+    path_walk_t pw;
+    path_generate(a.sc, a.seed, sample_id, pix % a.sc.sensor.width, pix / a.sc.sensor.width, pw);
+    soa_store(a.st.walks, 2 * (size_t)a.st.cap, i, pw);
+}
+
+__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_COUNT0 + in];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
+        ctl[CTL_HEAVY_HEAD] = 0;
+        ctl[CTL_HEAD_TRACE] = 0;
+    }
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const uint32_t stream = a.sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
+    for (;;) {
+        const uint32_t qi = wave_grab(ctl + CTL_HEAD_INTERACT) + (threadIdx.x & 63);
+        if (qi - (threadIdx.x & 63) >= n) break;
+        bool cont = false;
+        uint32_t w = 0;
+        if (qi < n) {
+            w = queue_walk(a, a.st.queue[in], qi, first_round);
+            const uint64_t j = a.j0 + w;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t s = a.sample_begin + j / a.npix;
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+            path_walk_t pw;
+            soa_load(a.st.walks, W2, w, pw);
+            trav_result_t tr;
+            soa_load(a.st.trav, W2, w, tr);
+            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
+            const utd_edges_ref_t utd{a.st.utd + (size_t)w * kUtdMaxEdges, 1};
+            cont = path_walk_step(a.sc, pw, tr, tris, utd, a.film, a.seed, sample_id, stream, stack, &ctr);
+            if (!cont) path_finish(a.sc, a.film, pw);
+            pw.w.active = cont ? 1u : 0u;
+            soa_store(a.st.walks, W2, w, pw);
+        }
+        wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+// walks still active after the last round (iteration cap): backward transport splats what they gathered
+__global__ void __launch_bounds__(kBlock) k_path_flush(launch_args_t a, int in) {
+    const uint32_t n = a.st.ctl[CTL_COUNT0 + in];
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < n; qi += gridDim.x * blockDim.x) {
+        const uint32_t w = a.st.queue[in][qi];
+        path_walk_t pw;
+        soa_load(a.st.walks, W2, w, pw);
+        path_finish(a.sc, a.film, pw);
+    }
+}
+
 // ---- connections: strategy-major -------------------------------------------------------------------------------------
 // plt_bdpt.cpp:105-146 loops over all (s,t) pairs of a sample.  One thread per sample would leave a wavefront executing the
 // UNION of its 64 samples' pairs (~80 iterations with ~10 lanes' worth of work: subpath lengths are geometric).  Instead:
@@ -815,8 +893,10 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         st.max_verts = (uint32_t)h.opts.max_depth + 2;
         st.counters = counters;
         const size_t W2 = 2 * (size_t)st.cap;
-        if ((rc = dmalloc(s, &st.walks, kWalkWords * W2))) return rc;
-        if ((rc = dmalloc(s, &st.verts, (size_t)st.max_verts * kVertexWords * W2))) return rc;
+        const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;   // plt_path: no vertex store / strategy buckets / Fraunhofer pool
+        if ((rc = dmalloc(s, &st.walks, (path_mode ? kPathWalkWords : kWalkWords) * W2))) return rc;
+        if ((rc = dmalloc(s, &st.utd, path_mode ? (size_t)st.cap * kUtdMaxEdges : 1))) return rc;
+        if ((rc = dmalloc(s, &st.verts, path_mode ? 1 : (size_t)st.max_verts * kVertexWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
         if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.tris, (size_t)kTriListWords * W2))) return rc;
@@ -827,10 +907,10 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         if ((rc = dmalloc(s, &st.gather_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
         HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
-        st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
+        st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing && !path_mode) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
         if ((rc = dmalloc(s, &st.fsd_hdr, st.fsd_cap))) return rc;
         if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_cap * kFsdMaxEdges))) return rc;
-        if ((rc = dmalloc(s, &st.strat_items, (size_t)kNumKeys * st.cap))) return rc;
+        if ((rc = dmalloc(s, &st.strat_items, path_mode ? 1 : (size_t)kNumKeys * st.cap))) return rc;
         if ((rc = dmalloc(s, &st.strat_count, (size_t)kNumKeys))) return rc;
         if ((rc = dmalloc(s, &st.strat_prefix, (size_t)kNumKeys + 1))) return rc;
         if ((rc = dmalloc(s, &st.lacc, 4 * (size_t)st.cap))) return rc;
@@ -964,30 +1044,47 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             if (tm) hipEventRecord(r.ev[ev++], st_);
         };
         rec();
-        hipLaunchKernelGGL(k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;
+        const uint32_t walks_per_sample = path_mode ? 1u : 2u;
+        int dbg_stage = 99;
+        if (const char* e = getenv("WTGPU_DEBUG_STAGE")) dbg_stage = atoi(e);
+        if (path_mode)
+            hipLaunchKernelGGL(k_path_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        else
+            hipLaunchKernelGGL(k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         rec();
-        const uint32_t g_full = std::min<uint32_t>(grid_round, (2 * nb + kBlock - 1) / kBlock);
+        const uint32_t g_full = std::min<uint32_t>(grid_round, (walks_per_sample * nb + kBlock - 1) / kBlock);
         for (uint32_t round = 0; round < kMaxWalkIters; ++round) {
             const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
             // the queue roughly halves every round and is normally empty after ~25: later rounds get smaller persistent grids
             // (an empty launch costs its grid size; a grid that turns out too small only takes longer, the wavefronts loop)
             const uint32_t shrink = round < 6 ? 1u : (round < 24 ? 4u : 32u);
             const uint32_t g0 = std::max<uint32_t>(1u, g_full / shrink);
-            const uint32_t gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, 2 * nb) / (round < 24 ? 1u : 32u));
-            hipLaunchKernelGGL(k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+            const uint32_t gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < 24 ? 1u : 32u));
+            if (dbg_stage >= 2 + 3 * (int)round) hipLaunchKernelGGL(k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
             rec();
-            hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
+            if (dbg_stage >= 3 + 3 * (int)round) hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
+            if (path_mode) {
+                if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+                rec();
+                rec();
+                continue;
+            }
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
             if (a.exact_regions) hipLaunchKernelGGL(k_gather, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / 4u)), dim3(kBlock), 0, st_, a, in);
             rec();
         }
-        hipLaunchKernelGGL(k_connect_enum, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
-        hipLaunchKernelGGL(k_connect_scan, dim3(1), dim3(64), 0, st_, a);
-        hipLaunchKernelGGL(k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
-        hipLaunchKernelGGL(k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        if (path_mode) {
+            hipLaunchKernelGGL(k_path_flush, dim3(64), dim3(kBlock), 0, st_, a, (int)(kMaxWalkIters & 1u));
+        } else {
+            hipLaunchKernelGGL(k_connect_enum, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+            hipLaunchKernelGGL(k_connect_scan, dim3(1), dim3(64), 0, st_, a);
+            hipLaunchKernelGGL(k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
+            hipLaunchKernelGGL(k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
         hipEventRecord(r.ev[tm ? ev : 0], st_);
