@@ -39,6 +39,8 @@ typedef struct wtgpu_scene_params {
     int32_t mesh_detail;       /* 0: low-poly stand-ins, 1: full tessellation */
     uint32_t lut_n_theta, lut_m; /* resolution of the regenerated Fraunhofer iCDF LUT (0: default) */
     uint32_t debug_only_s, debug_only_t; /* test hook: 0 = all strategies; v>0 evaluates only s (t) = v-1 with unit MIS weight */
+    int32_t polarimetric;      /* >0: polarimetric sensor — the film stores the 4 Stokes components per channel
+                                * (sensor `polarimetric` attribute, include/wt/sensor/sensor/perspective.hpp:185-330) */
     uint32_t crop_of;          /* test hook (perspective sensors): 0 = off; v>0: the res x res film is the central crop of a v x v film
                                 * (same pixel pitch, hence the same beam footprints, as the full-size render) */
 } wtgpu_scene_params;
@@ -50,6 +52,8 @@ typedef struct wtgpu_scene_info {
     uint32_t sensor_type; /* 0 perspective, 1 virtual_plane */
     double fsd_lut_power[2]; /* integrals of the regenerated LUT densities (compare: PA1, PA2 of fsd.hpp:59-61) */
     uint64_t bytes_per_sample_state; /* device bytes of per-sample path/vertex state */
+    uint32_t stokes;      /* film components per channel: 1 (intensity) or 4 (polarimetric sensor: I, Q, U, V) */
+    uint32_t integrator;  /* 0 plt_bdpt, 1 plt_path forward, 2 plt_path backward */
 } wtgpu_scene_info;
 
 /* Device counters (the reference's stat collectors: include/wt/integrator/stats.hpp:27-83, include/wt/ads/ads_stats.hpp),
@@ -82,7 +86,7 @@ int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_sample
 
 /* Renders sample indices [sample_begin, sample_end) of every sensor element (the `spp` loop of
  * integrator_t::integrate for all pixels) and accumulates into the caller-owned DEVICE film buffers
- *     d_value  [height][width][channels] f64,  d_weight [height][width] f64,  d_light [height][width][channels] f64.
+ *     d_value  [height][width][channels][stokes] f64,  d_weight [height][width] f64,  d_light [height][width][channels][stokes] f64.
  * `stream` is a hipStream_t (NULL = default stream).  The call only ENQUEUES work (internal streams that start after
  * everything already on `stream`; `stream` continues after them): synchronise `stream` before reading the films.  RNG: Philox-4x32-10 keyed by `seed`, counter = (pixel, sample, stream). */
 int wtgpu_render(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin, uint64_t sample_end,

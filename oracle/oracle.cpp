@@ -173,7 +173,7 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
     const uint32_t W = sc.sensor.width, H = sc.sensor.height, B = 24;
     const uint32_t bx = (W + B - 1) / B, by = (H + B - 1) / B;
-    std::vector<double> value((size_t)W * H * sc.sensor.channels), weight((size_t)W * H), light((size_t)W * H * sc.sensor.channels);
+    std::vector<double> value((size_t)W * H * film_planes(sc.sensor)), weight((size_t)W * H), light((size_t)W * H * film_planes(sc.sensor));
     film_t film{value.data(), weight.data(), light.data(), W, H, sc.sensor.channels};
     sample_scratch_t scr;
     scr.tris.resize(kOracleConeTris);

@@ -22,14 +22,14 @@ class WtgpuError(RuntimeError):
 class SceneParams(C.Structure):
     _fields_ = [("res", C.c_uint32), ("max_depth", C.c_int32), ("fsd", C.c_int32), ("mis", C.c_int32), ("rr", C.c_int32),
                 ("force_ray_tracing", C.c_int32), ("mesh_detail", C.c_int32), ("lut_n_theta", C.c_uint32), ("lut_m", C.c_uint32),
-                ("debug_only_s", C.c_uint32), ("debug_only_t", C.c_uint32), ("crop_of", C.c_uint32)]
+                ("debug_only_s", C.c_uint32), ("debug_only_t", C.c_uint32), ("polarimetric", C.c_int32), ("crop_of", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32), ("n_tris", C.c_uint32), ("n_edges", C.c_uint32),
                 ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_shapes", C.c_uint32), ("n_emitters", C.c_uint32),
                 ("n_materials", C.c_uint32), ("max_depth", C.c_int32), ("sensor_type", C.c_uint32), ("fsd_lut_power", C.c_double * 2),
-                ("bytes_per_sample_state", C.c_uint64)]
+                ("bytes_per_sample_state", C.c_uint64), ("stokes", C.c_uint32), ("integrator", C.c_uint32)]
 
 
 COUNTER_FIELDS = ["samples", "segments", "ray_queries", "cone_queries", "vertices", "connections", "shadow_rays", "cone_tri_overflow",
@@ -106,10 +106,11 @@ def _check(rc):
 class Scene:
     """Handle of a flattened scene (host-baked; optionally uploaded to one GPU)."""
 
-    def __init__(self, name, res=256, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, mesh_detail=1, lut=(0, 0), only_s=None, only_t=None, crop_of=0):
+    def __init__(self, name, res=256, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, mesh_detail=1, lut=(0, 0), only_s=None, only_t=None, crop_of=0,
+                 polarimetric=0):
         lib = load_library()
         p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, mesh_detail, lut[0], lut[1],
-                        0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1, crop_of)
+                        0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1, polarimetric, crop_of)
         h = C.c_void_p()
         _check(lib.wtgpu_scene_create_named(name.encode(), C.byref(p), C.byref(h)))
         self._h = h
@@ -117,7 +118,9 @@ class Scene:
         info = SceneInfo()
         _check(lib.wtgpu_scene_get_info(h, C.byref(info)))
         self.info = info
-        self.width, self.height, self.channels = info.width, info.height, info.channels
+        # `channels` = film planes per pixel: spectral channels x Stokes components (1, or 4 for polarimetric sensors)
+        self.spectral_channels, self.stokes = info.channels, info.stokes
+        self.width, self.height, self.channels = info.width, info.height, info.channels * info.stokes
         self.device = None
 
     @property

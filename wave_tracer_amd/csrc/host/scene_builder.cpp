@@ -456,6 +456,19 @@ int scene_builder_t::add_emitter_spot(const xform_t& to_world, int spectrum, flo
     emitters_.push_back(e);
     return (int)emitters_.size() - 1;
 }
+int scene_builder_t::add_emitter_directional(dvec3 dir_to_emitter, int spectrum, float scale, float solid_angle_sr, float pse_scale) {
+    emitter_t e{};
+    e.type = EMIT_DIRECTIONAL;
+    e.spectrum = spectrum;
+    e.scale = scale;
+    e.phase_space_extent_scale = pse_scale;
+    e.frame = build_orthogonal_frame(tof(dnorm(dir_to_emitter)));
+    // directional.hpp:86: tan(acos(1 - solid_angle / 2 pi))
+    e.tan_alpha_at_target = std::tan(std::acos(1.f - solid_angle_sr * kInvTwoPi));
+    e.shape = -1;
+    emitters_.push_back(e);   // position / target / far are set in finalize() from the world AABB (scene.cpp:50-58)
+    return (int)emitters_.size() - 1;
+}
 int scene_builder_t::add_emitter_point(dvec3 position, int spectrum, float scale, float extent_m, float pse_scale) {
     emitter_t e{};
     e.type = EMIT_POINT;
@@ -1002,6 +1015,8 @@ void scene_builder_t::build_sampling_tables() {
             geom = kTwoPi * (1.0 - .5 * (e.cos_cutoff + e.cos_falloff));   // spot_solid_angle
         else if (e.type == EMIT_POINT)
             geom = 4.0 * M_PI;   // point.hpp:60-69
+        else if (e.type == EMIT_DIRECTIONAL)
+            geom = e.target_area;   // directional.hpp:101-103: irradiance x target area
         else {
             double area = 0;
             const auto& r = shape_recs_[e.shape];
@@ -1133,6 +1148,28 @@ const scene_t& scene_builder_t::finalize() {
     if (sensitivity_spec_ < 0) throw std::runtime_error("sensor response not set");
     build_bvh();
     build_edges();
+    // infinite emitters need the world AABB (src/scene/scene.cpp:50-58, directional_t::set_world_aabb, directional.hpp:46-75)
+    {
+        vec3 mn{WT_INF, WT_INF, WT_INF}, mx{-WT_INF, -WT_INF, -WT_INF};
+        for (auto& g : tri_geo_) {
+            mn = vmin(mn, vmin(g.a, vmin(g.b, g.c)));
+            mx = vmax(mx, vmax(g.a, vmax(g.b, g.c)));
+        }
+        for (auto& e : emitters_) {
+            if (e.type != EMIT_DIRECTIONAL) continue;
+            e.position = (mn + mx) / 2.f;
+            const vec3 pr = (mx - mn) / 2.f;
+            float r2 = 0.f, zmax = 0.f;
+            for (int yz = 0; yz < 4; ++yz) {
+                const vec3 c = to_local(e.frame, vec3{-pr.x, (yz & 2) ? pr.y : -pr.y, (yz & 1) ? pr.z : -pr.z});
+                r2 = std::max(r2, c.x * c.x + c.y * c.y);
+                zmax = std::max(zmax, std::fabs(c.z));
+            }
+            e.target_radius = std::sqrt(r2);
+            e.target_area = kPi * r2;
+            e.far_dist = 1.01f * zmax;
+        }
+    }
     build_sampling_tables();
     if (sc_.opts.FSD && !sc_.opts.force_ray_tracing && sc_.opts.integrator == INTEGRATOR_BDPT) build_fsd_lut();   // plt_path diffracts with UTD
 

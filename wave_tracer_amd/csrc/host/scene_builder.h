@@ -65,12 +65,15 @@ public:
     int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);
     int add_emitter_area(int shape, int spectrum, float scale, float pse_scale);
     int add_emitter_point(dvec3 position, int spectrum, float scale, float extent_m, float pse_scale);
+    // directional (sun-like) emitter: `dir_to_emitter`, irradiance spectrum, solid angle subtended at the target (default: the sun's)
+    int add_emitter_directional(dvec3 dir_to_emitter, int spectrum, float scale, float solid_angle_sr, float pse_scale);
     // ITU-R P.2040 material IOR at one wavelength (src/spectrum/util/spectrum_from_ITU.cpp): a constant complex spectrum
     int spectrum_itu(const std::string& material, float wavelength_mm);
 
     void set_sensor_perspective(const xform_t& to_world, double fov_rad, uint32_t w, uint32_t h, float pse_scale, bool ray_trace_only);
     void set_sensor_virtual_plane(const xform_t& to_world, double extent_x, double extent_y, uint32_t w, uint32_t h, float tan_alpha);
     void set_film_rfilter_scale(float s);
+    void set_sensor_polarimetric(bool on) { sc_.sensor.polarimetric = on ? 1u : 0u; }
     // response: "RGB" (CIE colourspace, given white point XYZ) or monochromatic discrete line
     void set_response_rgb(const float white_xyz[3]);
     void set_response_mono_discrete(float wavelength_mm);
@@ -145,6 +148,7 @@ struct scene_params_t {
     int32_t mesh_detail;   // 0: low-poly stand-ins (tests), 1: full stand-in tessellation
     uint32_t lut_n_theta, lut_m;
     uint32_t debug_only_s, debug_only_t;
+    int32_t polarimetric;  // >0: polarimetric sensor (Stokes film)
     uint32_t crop_of;      // 0: off; else the film is the central res x res crop of a crop_of x crop_of film
 };
 // names: "double_slits", "cornell_box", "furnace" (diffuse box test scene), "white_furnace", "etoile" (plt_path forward + UTD),

@@ -212,6 +212,26 @@ static void build_white_furnace(const scene_params_t& p, scene_builder_t& b) {
     b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
 }
 
+// ---- test scene "sunlit": diffuse ground + a cube casting a shadow, lit by a `directional` emitter (the reference scenes use
+// directional emitters for their optical previews, e.g. double_slits.xml:138-159), perspective camera looking down.
+static void build_sunlit(const scene_params_t& p, scene_builder_t& b) {
+    integrator_opts_t o{};
+    o.max_depth = 3;
+    o.MIS = o.RR = 1;
+    o.FSD = 0;
+    o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    b.set_sensor_perspective(xform_t::lookat({0, 0, 3.0}, {0, 0, 0}, {0, 1, 0}), deg(40), p.res, p.res, 1.f, false);
+    const float E[3] = {1, 1, 1};
+    b.set_response_rgb(E);
+    const int grey = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    b.add_shape(mesh_rectangle({-2, -2, 0}, {4, 0, 0}, {0, 4, 0}), xform_t::identity(), grey, true);
+    b.add_shape(mesh_cube(.4), xform_t::translate(.5, 0, .2), grey, true);
+    // sun 30 degrees off the zenith towards +x
+    b.add_emitter_directional({std::sin(deg(30)), 0, std::cos(deg(30))}, b.spectrum_blackbody(5750.f, 1.f), 1e-6f, 6.794e-5f, 1.f);
+}
+
 // plt_path (backward transport) variants of the test scenes: "<scene>_path"
 static void set_path_backward(scene_builder_t& b) {
     integrator_opts_t o = b.scene().opts;
@@ -281,7 +301,12 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_
 
 
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
-    if (name == "etoile")
+    if (name == "sunlit")
+        build_sunlit(p, b);
+    else if (name == "sunlit_path") {
+        build_sunlit(p, b);
+        set_path_backward(b);
+    } else if (name == "etoile")
         build_etoile(p, b);
     else if (name == "etoile_open")
         build_etoile(p, b, true);
@@ -313,6 +338,7 @@ bool build_named_scene(const std::string& name, const scene_params_t& p, scene_b
         build_white_furnace(p, b);
     else
         return false;
+    if (p.polarimetric > 0) b.set_sensor_polarimetric(true);
     b.finalize();
     return true;
 }

@@ -149,6 +149,7 @@ WT_HD float vertex_pdf_next_from_emitter(const scene_t& sc, const vertex_t& v, c
     const float recp_dist2 = 1.f / length2(dl);
     const vec3 d = dl * sqrtf(recp_dist2);
     const int ei = vertex_get_emitter(v);
+    if (emitter_is_infinite(sc.emitters[ei])) return directional_pdf_target_position(sc.emitters[ei], vertex_wp(next));   // vertex.hpp:532-536
     const float dpdf = pd_density_or_zero(emitter_pdf_direction(sc, ei, d, vertex_has_real_surface(sc, v) ? &v.surf : nullptr));
     float ppdf = dpdf * recp_dist2;
     if (vertex_is_on_surface(sc, next)) ppdf *= fabsf(dot(vertex_ng(sc, next), d));

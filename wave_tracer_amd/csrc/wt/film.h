@@ -4,8 +4,9 @@
 //            include/wt/sensor/film/film_storage.hpp:196-252 (write_block, write_light_splat), 256-287 (develop),
 //            include/wt/math/distribution/gaussian1d.hpp:100-106 (filter integral).
 //
-// Layout: value[H][W][C] (sum of w*v), weight[H][W] (sum of w; the reference stores the same weight once per
-// channel), light[H][W][C] (sum of light-image splats).  All f64.  Accumulation is atomic: on gfx950
+// Layout: value[H][W][C][S] (sum of w*v), weight[H][W] (sum of w; the reference stores the same weight once per
+// channel), light[H][W][C][S] (sum of light-image splats); S = 1 (intensity) or, for polarimetric sensors, the 4 Stokes
+// components (FilmSampleT = vec4, film.hpp:214-286; one developed image per component, src/main.cpp:405-430).  All f64.  Accumulation is atomic: on gfx950
 // atomicAdd(double) is a single global_atomic_add_f64.
 #pragma once
 #include "sources.h"
@@ -18,6 +19,8 @@ struct film_t {
     double* light;
     uint32_t width, height, channels;
 };
+WT_HD uint32_t film_stokes(const sensor_t& s) { return s.polarimetric ? 4u : 1u; }
+WT_HD uint32_t film_planes(const sensor_t& s) { return s.channels * film_stokes(s); }
 
 WT_HD void film_add(double* p, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -67,14 +70,20 @@ WT_HD rfilter_weights_t film_rfilter_weights(const sensor_t& s, vec2 o) {
 WT_HD void film_splat(const scene_t& sc, const film_t& film, const sensor_element_t& el, const stokes_t& sample, float k) {
     const sensor_t& s = sc.sensor;
     const int r = s.rf_radius;
+    const uint32_t S = film_stokes(s), P = s.channels * S;
     const rfilter_weights_t rw = film_rfilter_weights(s, el.offset);
-    float val[4];
+    float val[16];
     for (uint32_t c = 0; c < s.channels; ++c) {
-        float v = sample.s[0] * spectrum_f(sc, s.response_spec[c], k);
-        val[c] = (v >= 0.f && finitef(v)) ? v : 0.f;
-#if defined(WTGPU_DEBUG_PRINT) && defined(__HIP_DEVICE_COMPILE__)
-        if (el.x == 0 && el.y == 0) printf("dbg4 c=%u v=%g val=%g fin=%d ge=%d\n", c, v, val[c], (int)finitef(v), (int)(v >= 0.f));
-#endif
+        const float f = spectrum_f(sc, s.response_spec[c], k);
+        // avoid NaNs, infs and negatives (of the intensity); cannot bail out on zero: the weights must be summed
+        bool ok = true;
+        for (uint32_t q = 0; q < S; ++q) {
+            val[c * S + q] = sample.s[q] * f;
+            ok = ok && finitef(val[c * S + q]);
+        }
+        ok = ok && val[c * S] >= 0.f;
+        if (!ok)
+            for (uint32_t q = 0; q < S; ++q) val[c * S + q] = 0.f;
     }
     for (int dy = -r; dy <= r; ++dy) {
         const int y = (int)el.y + dy;
@@ -85,7 +94,7 @@ WT_HD void film_splat(const scene_t& sc, const film_t& film, const sensor_elemen
             const float w = fmaxf_(0.f, rw.wx[dx + r] * rw.wy[dy + r]) * rw.recp_total;
             const size_t pix = (size_t)y * film.width + x;
             film_add(&film.weight[pix], (double)w);
-            for (uint32_t c = 0; c < s.channels; ++c) film_add(&film.value[pix * s.channels + c], (double)(w * val[c]));
+            for (uint32_t c = 0; c < P; ++c) film_add(&film.value[pix * P + c], (double)(w * val[c]));
         }
     }
 }
@@ -93,10 +102,17 @@ WT_HD void film_splat(const scene_t& sc, const film_t& film, const sensor_elemen
 WT_HD void film_splat_direct(const scene_t& sc, const film_t& film, const sensor_element_t& el, const stokes_t& sample, float k) {
     const sensor_t& s = sc.sensor;
     const int r = s.rf_radius;
+    const uint32_t S = film_stokes(s), P = s.channels * S;
     const rfilter_weights_t rw = film_rfilter_weights(s, el.offset);
     for (uint32_t c = 0; c < s.channels; ++c) {
-        const float val = sample.s[0] * spectrum_f(sc, s.response_spec[c], k);
-        if (val <= 0.f || !finitef(val)) continue;
+        const float f = spectrum_f(sc, s.response_spec[c], k);
+        float val[4];
+        bool ok = true;
+        for (uint32_t q = 0; q < S; ++q) {
+            val[q] = sample.s[q] * f;
+            ok = ok && finitef(val[q]);
+        }
+        if (!ok || val[0] <= 0.f) continue;
         for (int dy = -r; dy <= r; ++dy) {
             const int y = (int)el.y + dy;
             if (y < 0 || y >= (int)film.height) continue;
@@ -104,7 +120,7 @@ WT_HD void film_splat_direct(const scene_t& sc, const film_t& film, const sensor
                 const int x = (int)el.x + dx;
                 if (x < 0 || x >= (int)film.width) continue;
                 const float w = fmaxf_(0.f, rw.wx[dx + r] * rw.wy[dy + r]) * rw.recp_total;
-                film_add(&film.light[((size_t)y * film.width + x) * s.channels + c], (double)(w * val));
+                for (uint32_t q = 0; q < S; ++q) film_add(&film.light[((size_t)y * film.width + x) * P + c * S + q], (double)(w * val[q]));
             }
         }
     }

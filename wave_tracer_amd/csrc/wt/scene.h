@@ -88,7 +88,7 @@ struct material_t {
 };
 
 // ---- emitters ------------------------------------------------------------------------------------
-enum emitter_type_e : int32_t { EMIT_SPOT = 0, EMIT_AREA = 1, EMIT_POINT = 2 };
+enum emitter_type_e : int32_t { EMIT_SPOT = 0, EMIT_AREA = 1, EMIT_POINT = 2, EMIT_DIRECTIONAL = 3 };
 struct emitter_t {
     int32_t type;
     int32_t spectrum;   // radiant intensity (spot) / radiance (area), value multiplies `scale`
@@ -99,6 +99,9 @@ struct emitter_t {
     frame_t frame;   // to_world rotation: local z = mean direction
     float cutoff, falloff, cos_cutoff, cos_falloff, recp_cutoff_range, max_tan_alpha;
     float extent;   // <=0: default 10 lambda
+    // directional (infinite emitter): position = world centre, frame.n = direction TO the emitter; the target is the disk that
+    // bounds the world AABB projected along that direction (directional.hpp:46-75)
+    float target_radius, target_area, far_dist, tan_alpha_at_target;
     // area
     int32_t shape;
     // sampling tables
@@ -118,6 +121,7 @@ enum sensor_type_e : int32_t { SENSOR_PERSPECTIVE = 0, SENSOR_VIRTUAL_PLANE = 1 
 struct sensor_t {
     int32_t type;
     uint32_t width, height, channels;
+    uint32_t polarimetric;   // film stores the 4 Stokes components per channel (sensor_t<polarimetric>, film.hpp) instead of intensity
     uint32_t ray_trace_only;
     // film reconstruction filter
     float rfilter_sigma;   // in pixels (= .25 * rfilter_scale)

@@ -45,8 +45,9 @@ struct sensor_direct_sample_t {
 
 // ================================ emitters ==========================================================
 WT_HD bool emitter_is_area(const emitter_t& e) { return e.type == EMIT_AREA; }
-WT_HD bool emitter_is_delta_position(const emitter_t& e) { return e.type == EMIT_SPOT || e.type == EMIT_POINT; }
-WT_HD bool emitter_is_delta_direction(const emitter_t&) { return false; }
+WT_HD bool emitter_is_delta_position(const emitter_t& e) { return e.type == EMIT_SPOT || e.type == EMIT_POINT; }   // directional: false
+WT_HD bool emitter_is_delta_direction(const emitter_t& e) { return e.type == EMIT_DIRECTIONAL; }
+WT_HD bool emitter_is_infinite(const emitter_t& e) { return e.type == EMIT_DIRECTIONAL; }
 
 // spot_t::compute_falloff (spot.hpp:65-70)
 WT_HD float spot_falloff(const emitter_t& e, vec3 local_dir) {
@@ -75,6 +76,18 @@ WT_HD sourcing_geometry_t point_sourcing_geometry(const emitter_t& e, float k) {
     const phase_space_extent_t se =
         pse_enlarge(sg_phase_space_extent(sg_source_mub_from_length(initial_spatial_extent, k)), e.phase_space_extent_scale);
     return sg_source(se);
+}
+// directional_t::sourcing_geometry (directional.hpp:117-126): MUB sourced into the solid angle the emitter subtends at the target
+WT_HD sourcing_geometry_t directional_sourcing_geometry(const emitter_t& e, float k) {
+    const float len = mub_spatial_length_from_tan_alpha(e.tan_alpha_at_target, k);
+    sourcing_geometry_t g = sg_source_mub_from_length(len, k);
+    g.tan_alpha = e.tan_alpha_at_target;
+    return sg_source(pse_enlarge(sg_phase_space_extent(g), e.phase_space_extent_scale));
+}
+// directional_t::pdf_target_position (directional.hpp:176-184)
+WT_HD float directional_pdf_target_position(const emitter_t& e, vec3 wp) {
+    const vec3 l = to_local(e.frame, wp - e.position);
+    return l.x * l.x + l.y * l.y <= sqr(e.target_radius) ? 1.f / e.target_area : 0.f;
 }
 // sampler_t::uniform_sphere (sampler.hpp:147-152)
 WT_HD vec3 uniform_sphere(vec2 u) {
@@ -117,6 +130,14 @@ WT_HD emitter_sample_t emitter_sample(const scene_t& sc, int ei, float k, sample
         beam_scale(r.beam, w / dpd);
         r.ppd = pd_discrete(1.f);
         r.dpd = dpd;
+    } else if (e.type == EMIT_DIRECTIONAL) {
+        // directional_t::sample (src/emitter/directional.cpp:29-50): a point of the target disk, sourced from beyond the world
+        const vec2 p = concentric_disk(sampler_r2(sampler)) * e.target_radius;
+        const vec3 wp = e.position + to_world(e.frame, p);
+        r.beam = make_forward_beam(wp + e.far_dist * e.frame.n, -e.frame.n, emitter_spectral_value(sc, e, k), k, directional_sourcing_geometry(e, k));
+        beam_scale(r.beam, e.target_area);
+        r.ppd = 1.f / e.target_area;
+        r.dpd = pd_discrete(1.f);
     } else if (e.type == EMIT_POINT) {
         // point_t::sample (src/emitter/point.cpp:28-43)
         const vec3 d = uniform_sphere(sampler_r2(sampler));
@@ -145,6 +166,7 @@ WT_HD emitter_sample_t emitter_sample(const scene_t& sc, int ei, float k, sample
 WT_HD float emitter_pdf_position(const scene_t& sc, int ei) {
     const emitter_t e = sc.emitters[ei];
     if (e.type == EMIT_SPOT || e.type == EMIT_POINT) return pd_discrete(1.f);
+    if (e.type == EMIT_DIRECTIONAL) return 0.f;   // infinite emitters have no position density (vertex.hpp:557-558)
     return sc.shapes[e.shape].recp_surface_area;
 }
 // emitter_t::pdf_direction (solid-angle density)
@@ -152,6 +174,7 @@ WT_HD float emitter_pdf_direction(const scene_t& sc, int ei, vec3 dir, const sur
     const emitter_t e = sc.emitters[ei];
     if (e.type == EMIT_SPOT) return uniform_cone_pdf(kTwoPi * (1.f - e.cos_cutoff));
     if (e.type == EMIT_POINT) return kInvTwoPi * .5f;   // point.hpp pdf_direction: uniform sphere
+    if (e.type == EMIT_DIRECTIONAL) return pd_discrete(veq(dir, -e.frame.n) ? 1.f : 0.f);   // directional.hpp:192-199
     const float dn = fmaxf_(0.f, dot(dir, surface->geo.n));
     return cosine_hemisphere_pdf(dn);
 }
@@ -178,6 +201,15 @@ WT_HD emitter_direct_sample_t emitter_sample_direct(const scene_t& sc, int ei, v
         const float w = spot_falloff(e, local_wo);
         r.beam = make_forward_beam(e.position, d, emitter_spectral_value(sc, e, k), k, spot_sourcing_geometry(e, k));
         beam_scale(r.beam, w * recp_dist2);
+        r.dpd = pd_discrete(1.f);
+    } else if (e.type == EMIT_DIRECTIONAL) {
+        // directional_t::sample_direct (src/emitter/directional.cpp:52-73)
+        const vec3 l = to_local(e.frame, wp - e.position);
+        const vec2 p{l.x, l.y};
+        const float scale = dot(p, p) <= sqr(e.target_radius) ? 1.f : 0.f;
+        const vec3 targetwp = e.position + to_world(e.frame, p);
+        r.beam = make_forward_beam(targetwp + e.far_dist * e.frame.n, -e.frame.n, emitter_spectral_value(sc, e, k), k, directional_sourcing_geometry(e, k));
+        beam_scale(r.beam, scale);
         r.dpd = pd_discrete(1.f);
     } else if (e.type == EMIT_POINT) {
         // point_t::sample_direct (src/emitter/point.cpp:45-61)

@@ -779,6 +779,7 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
         p.debug_only_s = params->debug_only_s;
         p.debug_only_t = params->debug_only_t;
         p.crop_of = params->crop_of;
+        p.polarimetric = params->polarimetric;
         if (!wth::build_named_scene(name, p, *s->builder)) return fail(WTGPU_ERR_INVALID, std::string("unknown scene ") + name);
         s->host = s->builder->scene();
         s->stats = s->builder->stats();
@@ -808,6 +809,8 @@ int wtgpu_scene_get_info(const wtgpu_scene* s, wtgpu_scene_info* info) {
     info->width = h.sensor.width;
     info->height = h.sensor.height;
     info->channels = h.sensor.channels;
+    info->stokes = film_stokes(h.sensor);
+    info->integrator = h.opts.integrator;
     info->n_tris = h.n_tris;
     info->n_edges = h.n_edges;
     info->n_nodes = h.n_nodes;
@@ -1205,10 +1208,10 @@ int wtgpu_develop(const wtgpu_scene* s, const double* value, const double* weigh
     const sensor_t& sn = s->host.sensor;
     const double sl = spe > 0 ? 1.0 / double(spe) : 0.0;
     for (size_t p = 0; p < (size_t)sn.width * sn.height; ++p)
-        for (uint32_t c = 0; c < sn.channels; ++c) {
+        for (uint32_t c = 0, P = film_planes(sn); c < P; ++c) {
             const double w = weight[p];
-            const double v = w != 0 ? value[p * sn.channels + c] / w : 0.0;
-            out[p * sn.channels + c] = (float)(v + light[p * sn.channels + c] * sl);
+            const double v = w != 0 ? value[p * P + c] / w : 0.0;
+            out[p * P + c] = (float)(v + light[p * P + c] * sl);
         }
     return WTGPU_OK;
 }
