@@ -25,6 +25,11 @@ CASES = {
     "double_slits_r96": dict(scene="double_slits", res=96, spp=8, seed=14, kw={"lut": (128, 128)}),
     # central 24x24 crop of the 1440x1440 film: the same pixel pitch (beam footprints) as the headline workload
     "cornell_box_r12": dict(scene="cornell_box", res=24, spp=2, seed=15, kw={"mesh_detail": 0, "lut": (128, 128), "crop_of": 1440}),
+    # plt_path (forward: point transmitter + UTD diffraction, coverage sensor; backward: NEE + MIS), directional emitter, Stokes film
+    "etoile_r48": dict(scene="etoile", res=48, spp=8, seed=16, kw={"mesh_detail": 0}),
+    "white_furnace_path_r12": dict(scene="white_furnace_path", res=12, spp=8, seed=17, kw={}),
+    "sunlit_r16": dict(scene="sunlit", res=16, spp=4, seed=18, kw={}),
+    "cornell_box_stokes_r12": dict(scene="cornell_box", res=12, spp=2, seed=19, kw={"mesh_detail": 0, "lut": (128, 128), "crop_of": 1440, "polarimetric": 1}),
 }
 COUNTER_KEYS = ["segments", "vertices", "connections", "surface_interactions", "fsd_interactions", "light_splats"]
 

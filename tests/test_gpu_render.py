@@ -71,7 +71,8 @@ def test_cornell_dense_mesh_parity(built):
         assert abs(gc[key] - oc[key]) <= 1e-2 * oc[key], (key, gc[key], oc[key])
 
 
-@pytest.mark.parametrize("case", ["furnace_r16", "furnace_fsd_r16", "white_furnace_r12", "double_slits_r96", "cornell_box_r12"])
+@pytest.mark.parametrize("case", ["furnace_r16", "furnace_fsd_r16", "white_furnace_r12", "double_slits_r96", "cornell_box_r12", "etoile_r48",
+                                  "white_furnace_path_r12", "sunlit_r16", "cornell_box_stokes_r12"])
 def test_gpu_matches_committed_golden(built, case):
     import json
     import os

@@ -237,7 +237,8 @@ def test_double_slit_fraunhofer_fringes(built):
 
 
 # --------------------------------------------------------------------------------------------------- regression fixtures
-@pytest.mark.parametrize("case", ["furnace_r16", "furnace_fsd_r16", "white_furnace_r12", "double_slits_r96", "cornell_box_r12"])
+@pytest.mark.parametrize("case", ["furnace_r16", "furnace_fsd_r16", "white_furnace_r12", "double_slits_r96", "cornell_box_r12", "etoile_r48",
+                                  "white_furnace_path_r12", "sunlit_r16", "cornell_box_stokes_r12"])
 def test_oracle_matches_committed_golden(built, case):
     from golden.make_golden import CASES, run_case
     g = np.load(os.path.join(HERE, "golden", case + ".npz"))
