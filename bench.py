@@ -160,12 +160,15 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         out = {
-            "metric": "Msamples/sec (whole node), cornell-box 1440^2 wave-mode",
+            "metric": ("Msamples/sec (whole node), cornell-box 1440^2 wave-mode" if (args.scene, args.res) == ("cornell_box", 1440)
+                       else f"Msamples/sec (whole node), {args.scene} res={args.res}"),
             "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} stand-in (box.xml geometry, PLY meshes replaced by procedural stand-ins) res={args.res} "
-                                   f"plt_bdpt max_depth=16 MIS RR FSD, 1 spp per step", "samples_per_step": npix, "tris": int(sc.info.n_tris),
+            "config": {"workload": f"{args.scene} stand-in (the scene file's geometry, LFS meshes replaced by procedural stand-ins) res={args.res} "
+                                   f"{['plt_bdpt', 'plt_path forward', 'plt_path backward'][int(sc.info.integrator)]} max_depth={int(sc.info.max_depth)} "
+                                   f"{'MIS RR Fraunhofer-FSD' if int(sc.info.integrator) == 0 else 'UTD-FSD'}, 1 spp per step",
+                       "samples_per_step": npix, "tris": int(sc.info.n_tris),
                        "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "round_launches_with_work": tsum["trace_launches"],
