@@ -7,7 +7,9 @@ from oracle_util import oracle_render
 
 CASES = [("cornell_box", dict(res=24, mesh_detail=0, crop_of=1440, lut=(64, 64)), 8),
          ("etoile", dict(res=48, mesh_detail=0), 16),
-         ("furnace_path", dict(res=16), 4)]
+         ("furnace_path", dict(res=16), 4),
+         # BASELINE.json configs[4] stand-in: scenes/bidir_room/room.xml, polarimetric wave mode
+         ("bidir_room", dict(res=60, mesh_detail=0, lut=(128, 128)), 8)]
 
 
 def _planes(sc, v, w, l, spp):

@@ -347,6 +347,55 @@ int scene_builder_t::spectrum_from_wavelength_table(const float* vre, const floa
     spectra_.push_back(s);
     return (int)spectra_.size() - 1;
 }
+// spectrum::rgb_t (include/wt/spectrum/rgb.hpp:90-92): RGB_to_spectral::uplift (RGB_to_spectral.hpp:27-84, A. Weidlich's variant of
+// Smits' uplift): ten 34-nm bins over 380..720 nm, 0 outside.  Baked on 1-nm steps (the step edges are smoothed by the k-knot
+// resampling of SPEC_TABLE spectra).
+int scene_builder_t::spectrum_rgb(float r, float g, float bl) {
+    static const float white_I[11] = {1.0000f, 1.0000f, 0.9999f, 0.9993f, 0.9992f, 0.9998f, 1.0000f, 1.0000f, 1.0000f, 1.0000f, 0.f};
+    static const float cyan_I[11] = {0.9710f, 0.9426f, 1.0007f, 1.0007f, 1.0007f, 1.0007f, 0.1564f, 0.0000f, 0.0000f, 0.0000f, 0.f};
+    static const float magenta_I[11] = {1.0000f, 1.0000f, 0.968f, 0.22295f, 0.0000f, 0.0458f, 0.8369f, 1.0000f, 1.0000f, 0.9959f, 0.f};
+    static const float yellow_I[11] = {0.0001f, 0.0000f, 0.1088f, 0.6651f, 1.0000f, 1.0000f, 0.9996f, 0.9586f, 0.9685f, 0.9840f, 0.f};
+    static const float red_I[11] = {0.1012f, 0.0515f, 0.0000f, 0.0000f, 0.0000f, 0.0000f, 0.8325f, 1.0149f, 1.0149f, 1.014f, 0.f};
+    static const float green_I[11] = {0.0000f, 0.0000f, 0.0273f, 0.7937f, 1.0000f, 0.9418f, 0.1719f, 0.0000f, 0.0000f, 0.0025f, 0.f};
+    static const float blue_I[11] = {1.0000f, 1.0000f, 0.8916f, 0.3323f, 0.0000f, 0.0000f, 0.0003f, 0.0369f, 0.0483f, 0.0496f, 0.f};
+    const int N = 341;
+    std::vector<float> v(N);
+    for (int i = 0; i < N; ++i) {
+        const float lambda = 380.f + (float)i;
+        const int bin = std::min(10, (int)((lambda - 380.f) / (720.f - 380.f) * 10.f));
+        float I = 0.f;
+        if (r <= g && r <= bl) {
+            I += white_I[bin] * r;
+            if (g <= bl) {
+                I += cyan_I[bin] * (g - r);
+                I += blue_I[bin] * (bl - g);
+            } else {
+                I += cyan_I[bin] * (bl - r);
+                I += green_I[bin] * (g - bl);
+            }
+        } else if (g <= r && g <= bl) {
+            I += white_I[bin] * g;
+            if (r <= bl) {
+                I += magenta_I[bin] * (r - g);
+                I += blue_I[bin] * (bl - r);
+            } else {
+                I += magenta_I[bin] * (bl - g);
+                I += red_I[bin] * (r - bl);
+            }
+        } else {
+            I += white_I[bin] * bl;
+            if (r <= g) {
+                I += yellow_I[bin] * (r - bl);
+                I += green_I[bin] * (g - r);
+            } else {
+                I += yellow_I[bin] * (g - bl);
+                I += red_I[bin] * (r - g);
+            }
+        }
+        v[i] = I;
+    }
+    return spectrum_from_wavelength_table(v.data(), nullptr, N, 380.f, 1.f);
+}
 // src/spectrum/blackbody.cpp + colourspace/blackbody.hpp:24-50 (Planck, W/m^2/mm of wavelength), baked over the
 // wavelength range the bundled sensors see
 int scene_builder_t::spectrum_blackbody(float T, float scale) {

@@ -170,6 +170,79 @@ static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
     b.add_emitter_spot(spot_x, cfl, 2e-2f, (float)deg(55), (float)deg(1), -1.f, .25f);
 }
 
+// ---- scenes/bidir_room/room.xml (stand-in) ------------------------------------------------------------------------
+// Integrator (plt_bdpt, max_depth 10), camera (42 deg fov along x, to_world matrix, phase_space_extent_scale .25, film res x
+// round(res 17/30), RGB / D55), the two CFL spots above the screen (beam .2 / .4 deg with scale 3e2, and cutoff 13 deg with scale
+// 8.5e-2) and the materials (Room = .33 x diffuse rgb, Wood, Plastic*, Diffuse, Al fractal screen scaled .33) follow the XML.
+// The 46 PLY meshes and the bitmap textures are Git-LFS assets that are absent: the room shell, the furniture and the screen
+// (a plate with a slit-shaped aperture under the narrow spot, `screen=1` in the XML) are procedural stand-ins at the XML's
+// centimetre scale.  Rendered with a polarimetric sensor this is BASELINE.json's configs[4] workload.
+static void build_room(const scene_params_t& p, scene_builder_t& b) {
+    integrator_opts_t o{};
+    o.max_depth = 10;
+    o.MIS = o.RR = o.FSD = o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    if (p.lut_m) b.set_fsd_lut_resolution(p.lut_n_theta, p.lut_m);
+    const double cam[16] = {-0.00500708, -0.00467005, -0.999977, 12 * cm, 0, 0.999989, -0.00467011, 2.66 * cm,
+                            0.999987,    -2.34659e-005, -0.00502464, -0.5 * cm, 0, 0, 0, 1};
+    const uint32_t w = p.res, h = std::max(1u, (uint32_t)std::lround(p.res * 17.0 / 30.0));
+    // fov_axis = x: set_sensor_perspective takes the fov along x
+    b.set_sensor_perspective(xform_t::from_rows(cam), deg(42), w, h, .25f, false);
+    const float D55[3] = {0.95682f, 1.00000f, 0.92149f};
+    b.set_response_rgb(D55);
+
+    material_t room_m = mat_diffuse(b.spectrum_rgb(.39f, .425f, .375f), 1.f, true);
+    room_m.scale = .33f;
+    const int m_room = b.add_material(room_m);
+    const int m_diffuse = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    const int m_wood = b.add_material(mat_diffuse(b.spectrum_rgb(.32963f, .257976f, .150292f), 1.f, true));
+    const int m_plastic = b.add_material(mat_diffuse(b.spectrum_rgb(.2f, .2f, .2f), 1.f, true));
+    const int m_dark = b.add_material(mat_diffuse(b.spectrum_rgb(.025f, .0225f, .02f), 1.f, true));
+    const int m_black = b.add_material(mat_diffuse(b.spectrum_const(.005f), 1.f, true));
+    const int m_screen = b.add_material(mat_spm(b.spectrum_named("Al"), true, .025f, 3.f, true, .33f));
+
+    auto box = [&](double x0, double x1, double y0, double y1, double z0, double z1, int mat) {
+        b.add_shape(mesh_cube(1.0), xform_t::translate((x0 + x1) / 2 * cm, (y0 + y1) / 2 * cm, (z0 + z1) / 2 * cm) * xform_t::scale((x1 - x0) * cm, (y1 - y0) * cm, (z1 - z0) * cm),
+                    mat, true);
+    };
+    // room shell: floor y = 0, ceiling y = 5.4, x in [-14, 13], z in [-7, 7] (inward-facing two-sided walls)
+    b.add_shape(mesh_rectangle({-14 * cm, 0, -7 * cm}, {27 * cm, 0, 0}, {0, 0, 14 * cm}), xform_t::identity(), m_room, true);
+    b.add_shape(mesh_rectangle({-14 * cm, 5.4 * cm, -7 * cm}, {27 * cm, 0, 0}, {0, 0, 14 * cm}), xform_t::identity(), m_room, true);
+    b.add_shape(mesh_rectangle({-14 * cm, 0, -7 * cm}, {0, 5.4 * cm, 0}, {0, 0, 14 * cm}), xform_t::identity(), m_room, true);
+    b.add_shape(mesh_rectangle({13 * cm, 0, -7 * cm}, {0, 5.4 * cm, 0}, {0, 0, 14 * cm}), xform_t::identity(), m_room, true);
+    b.add_shape(mesh_rectangle({-14 * cm, 0, -7 * cm}, {27 * cm, 0, 0}, {0, 5.4 * cm, 0}), xform_t::identity(), m_room, true);
+    b.add_shape(mesh_rectangle({-14 * cm, 0, 7 * cm}, {27 * cm, 0, 0}, {0, 5.4 * cm, 0}), xform_t::identity(), m_room, true);
+    // table under the spots: top + 4 legs (wood); the screen plate rests above it
+    box(-5.3, .7, 1.55, 1.7, -2.2, 2.6, m_wood);
+    for (int i = 0; i < 4; ++i) box(i & 1 ? .3 : -5.2, i & 1 ? .6 : -4.9, 0, 1.55, i & 2 ? 2.2 : -2.1, i & 2 ? 2.5 : -1.8, m_wood);
+    // shelf against the far wall, books (plastic), a stool (cylinder), a picture frame, a lamp arm holding the spots
+    box(-13.9, -12.6, 0, 4.2, -5.5, 5.5, m_wood);
+    for (int i = 0; i < 7; ++i) box(-12.6, -12.1 + .05 * (i % 3), 2.1, 3.0 + .12 * (i % 4), -4.8 + 1.4 * i, -4.0 + 1.4 * i, i % 2 ? m_plastic : m_dark);
+    b.add_shape(mesh_cylinder({4.5 * cm, 0, 3.8 * cm}, {4.5 * cm, 1.3 * cm, 3.8 * cm}, .9 * cm, p.mesh_detail ? 48 : 12), xform_t::identity(), m_wood);
+    box(-13.95, -13.8, 2.2, 4.6, -2.0, 2.0, m_black);
+    box(-2.6, -1.9, 3.45, 3.6, 3.3, 6.9, m_dark);
+    // "bunny" stand-in on the floor beside the table (diffuse blob; dense for mesh_detail = 1)
+    b.add_shape(mesh_blob(1.0 * cm, p.mesh_detail ? 5 : 2, .12, 7, 23), xform_t::translate(3.0 * cm, .9 * cm, -3.2 * cm), m_diffuse);
+    // the screen: an Al plate in the plane z = .25 cm ... the XML rotates the plate's normal to +z... here: a horizontal plate under the
+    // spots (they look down the -z axis of their lookat, i.e. along world -z from z = 3.4 cm to 0): plate in the z = .25 cm plane
+    // spanning the spots' footprint, with a double slit (two .35 mm slits .65 mm apart) centred under the narrow spot
+    const double sx = -2.2807, sy = 2.6177, zp = .25, half = .6, slit = .035, sep = .065;
+    auto plate = [&](double x0, double x1, double y0, double y1) {
+        b.add_shape(mesh_rectangle({x0 * cm, y0 * cm, zp * cm}, {(x1 - x0) * cm, 0, 0}, {0, (y1 - y0) * cm, 0}), xform_t::identity(), m_screen, true);
+    };
+    plate(sx - half, sx - sep / 2 - slit / 2, sy - half, sy + half);
+    plate(sx - sep / 2 + slit / 2, sx + sep / 2 - slit / 2, sy - half, sy + half);
+    plate(sx + sep / 2 + slit / 2, sx + half, sy - half, sy + half);
+    // back plane the pattern falls on (z = 0 .. the XML's target): a white card
+    box(sx - 1.2, sx + 1.2, sy - 1.2, sy + 1.2, -.05, 0, m_diffuse);
+
+    const int cfl = b.spectrum_named("CFL2534");
+    const xform_t spot = xform_t::lookat({sx * cm, sy * cm, 3.4 * cm}, {sx * cm, sy * cm, 0}, {0, 1, 0});
+    b.add_emitter_spot(spot, cfl, 3e2f, (float)deg(.4), (float)deg(.2), -1.f, .25f);
+    b.add_emitter_spot(spot, cfl, 8.5e-2f, (float)deg(13), (float)deg(13 * .75), -1.f, .15f);   // no beam_width: .75 x cutoff (spot.cpp:120-121)
+}
+
 // ---- test scene: closed diffuse box with an area light -------------------------------------------------------------
 static void build_furnace(const scene_params_t& p, scene_builder_t& b) {
     integrator_opts_t o{};
@@ -301,7 +374,9 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_
 
 
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
-    if (name == "sunlit")
+    if (name == "bidir_room")
+        build_room(p, b);
+    else if (name == "sunlit")
         build_sunlit(p, b);
     else if (name == "sunlit_path") {
         build_sunlit(p, b);
