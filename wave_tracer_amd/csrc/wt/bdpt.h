@@ -455,6 +455,9 @@ struct fsd_defer_t {
     uint32_t has_gather, gather_n_edges, gather_edge_overflow;
     float gather_flux;
     const uint32_t* gather_edges;
+    // in (pass B): do not sample apertures that turn out to have edges, hand the walk to the sampling pass; out: this walk is one
+    // (its aperture is in pool slot `slot`).  in (pass C): the aperture of this walk exists already in `slot`
+    uint32_t defer_sampling, to_sampling_pass, have_aperture;
     uint32_t pending, resolved;
     uint32_t slot, base, next_try, end_draws;
     fsd_sample_t fs;
@@ -607,7 +610,10 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         // gather the ordered, de-duplicated edge set of the interaction region (traversal_common.hpp:124-148)
         uint32_t edge_ids[kMaxEdgeIds];
         uint32_t n_edge_ids = 0;
-        if (sc.opts.FSD && !is_ballistic && defer && defer->has_gather) {
+        const bool have_ap = defer && (defer->resolved || defer->have_aperture);   // built by an earlier execution of this step
+        if (have_ap) {
+            n_edge_ids = 1;
+        } else if (sc.opts.FSD && !is_ballistic && defer && defer->has_gather) {
             n_edge_ids = defer->gather_n_edges < kMaxEdgeIds ? defer->gather_n_edges : kMaxEdgeIds;
             for (uint32_t i = 0; i < n_edge_ids; ++i) edge_ids[i] = defer->gather_edges[i];
             if (ctr) ctr->edge_overflow += defer->gather_edge_overflow;
@@ -634,43 +640,56 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         if (n_edge_ids > 0) {
             // ---- sample_fraunhofer_fsd_interaction (plt_bdpt_detail.hpp:287-346)
             const bool resume = defer && defer->resolved;   // second pass of a deferred FSD interaction: the aperture exists already
-            // Fraction of the beam's power the listed triangles intercept (find_closest_triangle, plt_bdpt_detail.hpp:391-416).
-            // The reference computes it whenever the beam axis misses every triangle; its only consumer is the aperture built
-            // right below, so it is evaluated here, i.e. not for null interactions (3/4 of these walks) — same value, no RNG.
-            if (!resume && defer && defer->has_gather) {
-                integrated_flux = defer->gather_flux;
-            } else if (!resume) {
-                const float csz = centre(izr);
-                for (uint32_t i = 0; i < tr.ntris; ++i) {
-                    const tri_geo_t g = sc.tri_geo[tris[i]];
-                    const bool front_face = dot(g.n, -beam.env.d) > 0.f;
-                    if (front_face != (tr.front_face != 0)) continue;
-                    const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
-                                                          to_local(beam_frame, g.c - envelope.o), izr);
-                    for (int t = 0; t < ct.tris; ++t) {
-                        vec3 a, b, c;
-                        clip_tri_get(ct, t, a, b, c);
-                        const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz),
-                                   pc = cone_project_local(envelope, c, csz);
-                        integrated_flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
-                    }
-                }
-            }
-            const float I = 1.f - integrated_flux;
-            const uint32_t slot = resume ? defer->slot : fsd_pool_alloc(pool);
+            const uint32_t slot = have_ap ? defer->slot : fsd_pool_alloc(pool);
             if (slot >= pool.cap) {
                 if (ctr) ctr->fsd_pool_overflow++;
                 ok = false;
             } else {
                 fsd_aperture_t ap;
                 const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
-                if (resume) {
+                if (have_ap) {
                     ap = pool.hdr[slot];
                 } else {
-                    fsd_build_aperture(sc, beam_frame, beam.k, I, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
+                    fsd_build_aperture(sc, beam_frame, beam.k, 1.f, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
                     WT_STEP_MARK(3);
-                    pool.hdr[slot] = ap;
                     if (ctr && ap.overflow) ctr->fsd_edge_overflow += ap.overflow;
+                    pool.hdr[slot] = ap;
+                    // Device, pass B: one walk in eight of this pass ends up here with a real aperture; the intercepted-power
+                    // integrals and the rejection sampling are left to a pass of its own (k_interact_c) where all 64 lanes of a
+                    // wavefront do that work instead of a handful.
+                    if (ap.n_edges > 0 && defer && defer->defer_sampling) {
+                        defer->to_sampling_pass = 1;
+                        defer->slot = slot;
+                        return false;   // nothing has been committed
+                    }
+                }
+                // Fraction of the beam's power the listed triangles intercept (find_closest_triangle, plt_bdpt_detail.hpp:391-416).
+                // The reference computes it whenever the beam axis misses every triangle; its only consumer is the normalisation
+                // 1/I of this aperture's scattering function, so it is evaluated only when the aperture has edges (one in seven
+                // of the regions with classified edges; none of the null interactions) — same value, no RNG involved.
+                if (ap.n_edges > 0 && !resume) {
+                    if (defer && defer->has_gather) {
+                        integrated_flux = defer->gather_flux;
+                    } else {
+                        const float csz = centre(izr);
+                        for (uint32_t i = 0; i < tr.ntris; ++i) {
+                            const tri_geo_t g = sc.tri_geo[tris[i]];
+                            const bool front_face = dot(g.n, -beam.env.d) > 0.f;
+                            if (front_face != (tr.front_face != 0)) continue;
+                            const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
+                                                                  to_local(beam_frame, g.c - envelope.o), izr);
+                            for (int t = 0; t < ct.tris; ++t) {
+                                vec3 a, b, c;
+                                clip_tri_get(ct, t, a, b, c);
+                                const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz),
+                                           pc = cone_project_local(envelope, c, csz);
+                                integrated_flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
+                            }
+                        }
+                    }
+                    const float I = 1.f - integrated_flux;
+                    ap.recp_I = I > 0.f ? 1.f / I : 0.f;
+                    pool.hdr[slot] = ap;
                 }
                 if (ap.n_edges == 0) {
                     beam_transform_restart(beam, interaction_wp, beam_dist);

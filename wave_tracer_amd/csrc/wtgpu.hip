@@ -56,7 +56,7 @@ int fail(int code, const std::string& msg) {
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_WORDS = 16 };
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_WORDS = 16 };
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
@@ -73,6 +73,7 @@ struct device_state_t {
     uint32_t* heavy_queue = nullptr;   // walks whose traversal exceeded the per-lane budget
     uint32_t* intb_queue = nullptr;    // walks whose interaction takes the expensive (no primary triangle) path
     uint32_t* gather_queue = nullptr;  // ... of those, the ones whose triangle list overflowed (coop_gather first)
+    uint32_t* intc_queue = nullptr;    // ... and the ones that built a Fraunhofer aperture with edges (sampled in pass C)
     uint32_t* ctl = nullptr;           // [CTL_WORDS] queue sizes, dequeue heads, FSD pool bump counter, rounds done
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
@@ -134,6 +135,7 @@ struct launch_args_t {
     uint32_t count_stats;
     uint32_t cone_budget;
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
+    uint32_t pass_c;          // WTGPU_PASS_C=1: Fraunhofer apertures with edges are completed (power integrals, rejection sampling) in a third pass
     uint32_t exact_regions;   // WTGPU_EXACT_REGIONS=1: walk interaction regions that overflow the bounded triangle list again (k_gather)
 };
 
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         ctl[CTL_COUNT0] = 2 * a.nb;
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
-        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = 0;
+        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -224,6 +226,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
         ctl[CTL_INTB_HEAD] = 0;
         ctl[CTL_GATHER_COUNT] = 0;
         ctl[CTL_GATHER_HEAD] = 0;
+        ctl[CTL_INTC_COUNT] = 0;
+        ctl[CTL_INTC_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -313,12 +317,15 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-// Interaction step of the queued walks.  PASS_B = false: the queue of the round; walks whose beam axis misses every listed
-// triangle (expensive path, see bdpt_walk_step) are only appended to the pass-B queue.  PASS_B = true: that queue, full step.
-template <bool PASS_B>
+// Interaction step of the queued walks.  PASS 0 (A): the queue of the round; walks whose beam axis misses every listed triangle
+// (expensive path, see bdpt_walk_step) are only appended to the pass-B queue.  PASS 1 (B): that queue: edge set, Fraunhofer aperture,
+// null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue.  PASS 2 (C): rejection sampling
+// of those apertures + vertex append, with full wavefronts.
+template <int PASS>
 __device__ inline void interact_body(const launch_args_t& a, int in, int first_round, stack_entry_t* lds) {
+    constexpr bool PASS_B = PASS >= 1, PASS_C = PASS == 2;
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in];
+    const uint32_t n = PASS_C ? ctl[CTL_INTC_COUNT] : (PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in]);
     if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
@@ -332,7 +339,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
     for (;;) {
-        const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
+        const uint32_t qi = wave_grab(ctl + (PASS_C ? CTL_INTC_HEAD : (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT))) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
         bool cont = false;
         uint32_t w = 0, stream = 0;
@@ -340,6 +347,9 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         fsd_defer_t defer;
         defer.pending = defer.resolved = 0;
         defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
+        defer.defer_sampling = (PASS == 1 && a.pass_c) ? 1u : 0u;
+        defer.to_sampling_pass = 0;
+        defer.have_aperture = PASS_C ? 1u : 0u;
         defer.split_no_primary = PASS_B ? 0u : 1u;
         defer.known_no_primary = PASS_B ? 1u : 0u;
         defer.no_primary = 0;
@@ -349,7 +359,8 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         bool need_gather = false;
         bool todo = qi < n;
         if (todo) {
-            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round);
+            w = PASS_C ? a.st.intc_queue[qi] : (PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round));
+            if (PASS_C) defer.slot = a.st.trav[WT_TRAV_WORD(by) * W2 + w];   // left by pass B
             uint32_t i;
             walk_ident(a, w, i, stream);
             const uint64_t j = a.j0 + i;
@@ -359,7 +370,8 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         }
         // at most two executions of the step: the second only for lanes whose Fraunhofer-FSD rejection loop was finished by
         // the wavefront in between (pass B)
-        for (int pass = 0; pass < (PASS_B ? 2 : 1); ++pass) {
+        // (with pass C enabled only that pass samples apertures; otherwise pass B does everything)
+        for (int pass = 0; pass < ((PASS_C || (PASS_B && !a.pass_c)) ? 2 : 1); ++pass) {
             if (todo) {
                 walk_t wk;
                 soa_load(a.st.walks, W2, w, wk);
@@ -375,17 +387,34 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
                     defer.gather_edge_overflow = pass == 0 ? tr.n_cone_queries : 0u;
                     defer.gather_edges = a.st.tris + (size_t)w * kTriListWords;
                 }
+#ifdef WTGPU_STEP_PROF
+                const long long prof_t0 = clock64();
+                for (int q = 0; q < 8; ++q) defer.marks[q] = 0;
+#endif
                 cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
+                if (PASS == 1 && defer.to_sampling_pass) a.st.trav[WT_TRAV_WORD(by) * W2 + w] = defer.slot;
+#ifdef WTGPU_STEP_PROF
+                if (PASS_B) {   // debug builds: where the pass-B step spends its time (per lane; slot 6 = FSD walks, 7 = walks)
+                    long long prev = prof_t0;
+                    for (int q = 0; q < 6; ++q)
+                        if (defer.marks[q]) {
+                            atomicAdd(a.st.counters + kNumCounters + q, (unsigned long long)(defer.marks[q] - prev));
+                            prev = defer.marks[q];
+                        }
+                    atomicAdd(a.st.counters + kNumCounters + 7, 1ull);
+                    if (defer.marks[3]) atomicAdd(a.st.counters + kNumCounters + 6, 1ull);
+                }
+#endif
                 if (!PASS_B && a.exact_regions && defer.no_primary && tr.overflow > 0 && !tr.ballistic && a.sc.opts.FSD) need_gather = true;
                 if (!defer.pending) {
                     todo = false;
-                    if (!defer.no_primary) {
+                    if (!defer.no_primary && !defer.to_sampling_pass) {
                         wk.active = cont ? 1u : 0u;
                         soa_store(a.st.walks, W2, w, wk);
                     }
                 }
             }
-            if (!PASS_B) break;
+            if (!(PASS_C || (PASS_B && !a.pass_c))) break;
             // ---- Fraunhofer-FSD rejection loops that did not finish within kFsdInlineTries: the wavefront finishes them one after
             // the other, 64 tries per step (tries are independent, fsd.h), then the owning lane re-runs its step with the outcome.
             unsigned long long pm = __ballot(todo && defer.pending != 0);
@@ -430,6 +459,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         }
         if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
         if (!PASS_B) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
+        if (PASS == 1) wave_append(a.st.intc_queue, ctl + CTL_INTC_COUNT, defer.to_sampling_pass != 0, w);
         wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
@@ -479,11 +509,15 @@ __global__ void __launch_bounds__(64, 3) k_gather(launch_args_t a) {
 
 __global__ void __launch_bounds__(kBlock, 4) k_interact(launch_args_t a, int in, int first_round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    interact_body<false>(a, in, first_round, lds);
+    interact_body<0>(a, in, first_round, lds);
 }
 __global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int in) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    interact_body<true>(a, in, 0, lds);
+    interact_body<1>(a, in, 0, lds);
+}
+__global__ void __launch_bounds__(kBlock, 3) k_interact_c(launch_args_t a, int in) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    interact_body<2>(a, in, 0, lds);
 }
 
 // ---- plt_path: one walk per sample; k_trace / k_trace_heavy are shared with plt_bdpt (they only read the walk_t
@@ -496,7 +530,7 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
         ctl[CTL_COUNT0] = a.nb;
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
-        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = 0;
+        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -908,6 +942,7 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         if ((rc = dmalloc(s, &st.heavy_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.intb_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.gather_queue, W2))) return rc;
+        if ((rc = dmalloc(s, &st.intc_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
         HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
         st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing && !path_mode) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
@@ -1013,12 +1048,20 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     // +0.2 % identical pixels); on, the device treats them like the reference's unbounded lists
     a.exact_regions = 0;
     if (const char* e = getenv("WTGPU_EXACT_REGIONS")) a.exact_regions = (uint32_t)atoi(e);
+    // Off by default (measured 194.7 -> 201.5 ms per pass): compacting the one walk in eight of pass B whose aperture has edges into
+    // a pass of its own gives full wavefronts for the power integrals and the rejection sampling, but re-loading the walk state and
+    // the extra 96 launches per batch cost more than the divergence they remove
+    a.pass_c = 0;
+    if (const char* e = getenv("WTGPU_PASS_C")) a.pass_c = (uint32_t)atoi(e);
     // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
     int n_cu = 256;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
     uint32_t heavy_waves_per_cu = 16;
     if (const char* e = getenv("WTGPU_HEAVY_WAVES")) heavy_waves_per_cu = (uint32_t)std::max(1, atoi(e));
     const uint32_t grid_round = (uint32_t)n_cu * 8u, grid_heavy = (uint32_t)n_cu * heavy_waves_per_cu;
+    uint32_t grid_div_b = 4, grid_div_c = 16;   // persistent grids of the two expensive-interaction passes relative to the round's
+    if (const char* e = getenv("WTGPU_GRID_B")) grid_div_b = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("WTGPU_GRID_C")) grid_div_c = (uint32_t)std::max(1, atoi(e));
 
     // the internal streams start after everything already enqueued on the caller's stream ...
     HIP_CHECK(hipEventRecord(s->ev_begin, caller));
@@ -1077,7 +1120,8 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
             if (a.exact_regions) hipLaunchKernelGGL(k_gather, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
-            hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / 4u)), dim3(kBlock), 0, st_, a, in);
+            hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
+            if (a.pass_c) hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, g0 / grid_div_c)), dim3(kBlock), 0, st_, a, in);
             rec();
         }
         if (path_mode) {
@@ -1135,8 +1179,8 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     {
         unsigned long long p[8];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[wtgpu step prof] pass-B walks %llu; mean ticks: scan %.0f integrals %.0f edges %.0f aperture %.0f sample+append %.0f continue %.0f\n", p[7],
-                double(p[0]) / p[7], double(p[1]) / p[7], double(p[2]) / p[7], double(p[3]) / p[7], double(p[4]) / p[7], double(p[5]) / p[7]);
+        fprintf(stderr, "[wtgpu step prof] pass-B walks %llu (with aperture %llu); total Mticks: scan %.1f pre %.1f edges %.1f integrals+aperture %.1f sample+append %.1f continue %.1f\n", p[7], p[6],
+                double(p[0]) * 1e-6, double(p[1]) * 1e-6, double(p[2]) * 1e-6, double(p[3]) * 1e-6, double(p[4]) * 1e-6, double(p[5]) * 1e-6);
     }
 #endif
 #ifdef WTGPU_COOP_PROF
