@@ -83,7 +83,14 @@ WT_HD fsd_edges_ref_t fsd_pool_edges(const fsd_pool_t& p, uint32_t slot) {
 }
 WT_HD uint32_t fsd_pool_alloc(const fsd_pool_t& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(p.counter, 1u);
+    // one atomic per wavefront: the lanes that allocate together (the active lanes of this divergent branch) share it
+    const unsigned long long m = __ballot(1);
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(p.counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 #else
     return __atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED);
 #endif

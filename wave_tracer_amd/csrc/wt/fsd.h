@@ -96,29 +96,38 @@ WT_HD float fsd_Pj(const fsd_edge_t& e) {
 
 // free_space_diffraction_t ctor (free_space_diffraction.cpp:22-129).
 // `edge_ids`: the (deduplicated, sorted) ADS edge ids of the interaction region.  `sigma` = wavefront std-dev.
-template <class EdgeIdList>
-WT_HD void fsd_build_aperture(const scene_t& sc, const frame_t& frame, float k, float total_power, const cone_t& beam, const EdgeIdList& edge_ids,
-                              uint32_t n_edge_ids, vec2 sigma, fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
+struct fsd_build_state_t {
+    vec2 cse;   // wave_function.envelope()
+    float max_edge_length;
+    float P_total;
+};
+WT_HD fsd_build_state_t fsd_build_begin(const frame_t& frame, float k, float total_power, vec2 sigma, fsd_aperture_t& ap) {
     ap.k = k;
     ap.frame = frame;
     ap.n_edges = 0;
     ap.overflow = 0;
-    const vec2 cse = sigma * kBeamEnvelope;   // wave_function.envelope()
-    const float r = fmaxf_(cse.x, cse.y);
-    const float max_edge_length = .33f * r;
     ap.recp_I = total_power > 0.f ? 1.f / total_power : 0.f;
-    float P_total = 0.f;
-    for (uint32_t ei = 0; ei < n_edge_ids; ++ei) {
-        const edge_t edge = sc.edges[edge_ids[ei]];
+    fsd_build_state_t st;
+    st.cse = sigma * kBeamEnvelope;
+    st.max_edge_length = .33f * fmaxf_(st.cse.x, st.cse.y);
+    st.P_total = 0.f;
+    return st;
+}
+WT_HD void fsd_build_add_edge(const scene_t& sc, const frame_t& frame, const cone_t& beam, vec2 sigma, fsd_build_state_t& st, uint32_t edge_id,
+                              fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
+    const vec2 cse = st.cse;
+    const float max_edge_length = st.max_edge_length;
+    {
+        const edge_t edge = sc.edges[edge_id];
         // only the projected silhouette
-        if (dot(beam.d, edge.n1) * dot(beam.d, edge.n2) >= 0.f) continue;
+        if (dot(beam.d, edge.n1) * dot(beam.d, edge.n2) >= 0.f) return;
         const vec3 la = to_local(frame, edge.a - beam.o), lb = to_local(frame, edge.b - beam.o);
         const vec2 u1{la.x, la.y}, u2{lb.x, lb.y};
         float t1 = 0.f, t2 = 1.f;
         const vec2 q1 = u1 / cse, q2 = u2 / cse;
         if (!(dot(q1, q1) <= 1.f) || !(dot(q2, q2) <= 1.f)) {
             const edge_ellipse_t intr = intersect_edge_ellipse(u1, u2, cse.x, cse.y);
-            if (intr.points == 0) continue;
+            if (intr.points == 0) return;
             t1 = fmaxf_(0.f, intr.t1);
             t2 = fminf_(1.f, intr.t2);
         }
@@ -143,7 +152,7 @@ WT_HD void fsd_build_aperture(const scene_t& sc, const frame_t& frame, float k, 
                 if (fe.pdf > 0.f) {
                     if (ap.n_edges < kFsdMaxEdges) {
                         ed.set(ap.n_edges++, fe);
-                        P_total += fe.pdf;
+                        st.P_total += fe.pdf;
                     } else
                         ap.overflow++;
                 }
@@ -152,6 +161,17 @@ WT_HD void fsd_build_aperture(const scene_t& sc, const frame_t& frame, float k, 
             a = b;
         }
     }
+}
+WT_HD void fsd_build_finish(float k, fsd_build_state_t& st, fsd_aperture_t& ap, const fsd_edges_ref_t& ed);
+template <class EdgeIdList>
+WT_HD void fsd_build_aperture(const scene_t& sc, const frame_t& frame, float k, float total_power, const cone_t& beam, const EdgeIdList& edge_ids,
+                              uint32_t n_edge_ids, vec2 sigma, fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
+    fsd_build_state_t st = fsd_build_begin(frame, k, total_power, sigma, ap);
+    for (uint32_t ei = 0; ei < n_edge_ids; ++ei) fsd_build_add_edge(sc, frame, beam, sigma, st, edge_ids[ei], ap, ed);
+    fsd_build_finish(k, st, ap, ed);
+}
+WT_HD void fsd_build_finish(float k, fsd_build_state_t& st, fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
+    float P_total = st.P_total;
     // power in the 0-th order lobe (8-point average on a circle of radius 3*P0_sigma)
     const float psi0r = 3.f * kFsdP0Sigma;
     const vec2 dirs[8] = {{-kInvSqrt2, -kInvSqrt2}, {-1, 0}, {-kInvSqrt2, kInvSqrt2}, {0, 1}, {kInvSqrt2, kInvSqrt2}, {1, 0}, {kInvSqrt2, -kInvSqrt2}, {0, -1}};
