@@ -10,6 +10,9 @@
  * quantities film_storage_t holds (include/wt/sensor/film/film_storage.hpp:196-252), from which
  *     pixel = value/weight + light/spe        (film_storage.hpp:256-287, src/scene/render.cpp:245-291).
  *
+ * The integrator is part of the flattened scene: plt_bdpt (src/integrator/plt_bdpt.cpp:43-148) or plt_path in either transport
+ * direction (src/integrator/plt_path.cpp:39-50); polarimetric sensors get four Stokes planes per channel.
+ *
  * Plain C types only; opaque handles; int status returns (0 = ok); no exceptions cross the boundary.
  * One wtgpu_scene may be uploaded to one device per process (one process per GPU).
  */

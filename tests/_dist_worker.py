@@ -19,7 +19,8 @@ def main():
     from wave_tracer_amd import Scene
     from wave_tracer_amd.render import render_distributed, shard_samples
     from oracle_util import oracle_render
-    sc = Scene("furnace", res=16, lut=(32, 32))
+    name = sys.argv[4] if len(sys.argv) > 4 else "furnace"
+    sc = Scene(name, res=16, lut=(32, 32), mesh_detail=0)
     rank, world = dist.get_rank(), dist.get_world_size()
 
     def cpu_shard(scene, b, e, s):
