@@ -1092,7 +1092,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         rec();
         const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;
         const uint32_t walks_per_sample = path_mode ? 1u : 2u;
-        int dbg_stage = 99;
+        int dbg_stage = 1 << 30;   // WTGPU_DEBUG_STAGE: bring-up aid, stops launching the round kernels after stage n (invalid results)
         if (const char* e = getenv("WTGPU_DEBUG_STAGE")) dbg_stage = atoi(e);
         if (path_mode)
             hipLaunchKernelGGL(k_path_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
