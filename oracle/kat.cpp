@@ -105,6 +105,22 @@ void kat_fractal_sample(float roughness, float gamma, float k, const float* wi, 
         out[5 * i] = p.wo.x; out[5 * i + 1] = p.wo.y; out[5 * i + 2] = p.wo.z; out[5 * i + 3] = p.pdf; out[5 * i + 4] = p.psd;
     }
 }
+// gaussian profile (surface_profile/gaussian.hpp); what: 0 psd, 1 pdf, 2 alpha
+float kat_gaussian(int what, float roughness, float sigma, float k, const float* wi, const float* wo) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM; m.profile = PROFILE_GAUSSIAN; m.roughness = roughness; m.gauss_sigma = sigma; m.gamma = 3.f;
+    const vec3 a{wi[0], wi[1], wi[2]}, b{wo[0], wo[1], wo[2]};
+    return what == 0 ? profile_psd(m, a, b, k) : (what == 1 ? profile_pdf(m, a, b, k) : profile_alpha(m, a, b, k));
+}
+void kat_gaussian_sample(float roughness, float sigma, float k, const float* wi, uint64_t seed, uint32_t n, float* out /* n x {wo3,pdf,psd} */) {
+    material_t m{};
+    m.type = MAT_SURFACE_SPM; m.profile = PROFILE_GAUSSIAN; m.roughness = roughness; m.gauss_sigma = sigma; m.gamma = 3.f;
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 0);
+        const profile_sample_t p = profile_sample(m, vec3{wi[0], wi[1], wi[2]}, k, s);
+        out[5 * i] = p.wo.x; out[5 * i + 1] = p.wo.y; out[5 * i + 2] = p.wo.z; out[5 * i + 3] = p.pdf; out[5 * i + 4] = p.psd;
+    }
+}
 // K8: Fraunhofer FSD kernel functions
 float kat_fsd_alpha1(float x, float y) { return fsd_alpha1(x, y); }
 float kat_fsd_alpha2(float x, float y) { return fsd_alpha2(x, y); }

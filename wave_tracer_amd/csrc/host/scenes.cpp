@@ -244,7 +244,7 @@ static void build_room(const scene_params_t& p, scene_builder_t& b) {
 }
 
 // ---- test scene: closed diffuse box with an area light -------------------------------------------------------------
-static void build_furnace(const scene_params_t& p, scene_builder_t& b) {
+static void build_furnace(const scene_params_t& p, scene_builder_t& b, bool spm_occluders = false) {
     integrator_opts_t o{};
     o.max_depth = 8;
     o.MIS = o.RR = 1;
@@ -262,7 +262,21 @@ static void build_furnace(const scene_params_t& p, scene_builder_t& b) {
     const int q = b.add_shape(mesh_rectangle({-.25, .95, -.25}, {0, 0, .5}, {.5, 0, 0}), xform_t::identity(), lightm);
     b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
     // an occluder with silhouette edges in the middle of the room
-    b.add_shape(mesh_cube(.3), xform_t::translate(.2, -.3, -.2) * xform_t::rotate(0, 1, 0, deg(30)), grey);
+    if (!spm_occluders) {
+        b.add_shape(mesh_cube(.3), xform_t::translate(.2, -.3, -.2) * xform_t::rotate(0, 1, 0, deg(30)), grey);
+    } else {
+        // "furnace_spm": rough conductors instead — an Al cube with the Gaussian surface profile (roughness-parametrised) and a
+        // gold one with an explicit rms, next to a fractal-profile one (surface_profile/{gaussian,fractal}.hpp)
+        material_t g1 = mat_spm(b.spectrum_named("Al"), false, .15f, 3.f, true, 1.f);
+        g1.profile = PROFILE_GAUSSIAN;
+        material_t g2 = mat_spm(b.spectrum_named("Au"), false, 0.f, 3.f, true, 1.f);
+        g2.profile = PROFILE_GAUSSIAN;
+        g2.gauss_sigma = 1500.f;   // [1/mm]
+        const material_t f1 = mat_spm(b.spectrum_named("Al"), true, .2f, 3.f, true, 1.f);
+        b.add_shape(mesh_cube(.3), xform_t::translate(.2, -.3, -.2) * xform_t::rotate(0, 1, 0, deg(30)), b.add_material(g1));
+        b.add_shape(mesh_cube(.25), xform_t::translate(-.35, -.3, -.1) * xform_t::rotate(0, 1, 0, deg(-20)), b.add_material(g2));
+        b.add_shape(mesh_cube(.2), xform_t::translate(-.05, -.55, .25) * xform_t::rotate(1, 0, 0, deg(25)), b.add_material(f1));
+    }
 }
 
 // ---- test scene: "white furnace": closed cube whose inner faces are diffuse (albedo .5) area emitters.  The radiance
@@ -376,6 +390,8 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
     if (name == "bidir_room")
         build_room(p, b);
+    else if (name == "furnace_spm")
+        build_furnace(p, b, true);
     else if (name == "sunlit")
         build_sunlit(p, b);
     else if (name == "sunlit_path") {

@@ -52,21 +52,68 @@ WT_HD float fractal_psd(const material_t& m, const fractal_params_t& pr, vec2 z,
     const float p = m.gamma == 3.f ? x * x : powf(x, (m.gamma + 1.f) / 2.f);
     return pr.sigma2_norm * (kInvTwoPi * k * k * (m.gamma - 1.f) * pr.T / p);
 }
+// ---- gaussian profile (interaction/surface_profile/gaussian.hpp:25-255) -----------------------------------------------------
+struct gaussian_params_t {
+    float sigma2;   // [1/mm^2]
+    float sigma2_norm;
+    float alpha;
+};
+// gaussian_t::gaussian_params (gaussian.hpp:94-117)
+WT_HD gaussian_params_t gaussian_params(const material_t& m, float k) {
+    gaussian_params_t r;
+    if (m.gauss_sigma > 0.f) {
+        r.sigma2 = sqr(m.gauss_sigma);
+        r.alpha = r.sigma2;
+    } else {
+        const float meank = kTwoPi / 550e-6f;
+        const float max_GGX_alpha = .75f, maxT = sqr(70.f);
+        const float alpha2 = sqr(clampf(m.roughness, 0.f, max_GGX_alpha));
+        const float T = fminf_(maxT, (1.f - alpha2) / (4.f * sqr(meank) * alpha2));
+        r.sigma2 = 1.f / T;
+        r.alpha = sqr(m.roughness / 9.f);
+    }
+    r.sigma2_norm = 1.f / (1.f - expf(-(k * k / 2.f / r.sigma2)));
+    return r;
+}
+WT_HD float gaussian_psd(const gaussian_params_t& pr, vec2 z, float k) {
+    const float e = expf(-(dot(z, z) / 2.f / pr.sigma2));
+    return e <= FLT_EPSILON ? 0.f : pr.sigma2_norm * (kInvTwoPi / pr.sigma2 * k * k * e);
+}
+WT_HD float gaussian_max_phi(float r, float l) {
+    return (r < FLT_EPSILON || l < FLT_EPSILON) ? kPi : fmaxf_(1e-2f, acosf(clampf((sqr(r) + sqr(l) - 1.f) / (2.f * r * l), -1.f, 1.f)));
+}
+// detail::boxmueller_truncated_pdf (gaussian.hpp:55-75)
+WT_HD float boxmueller_truncated_pdf(vec2 wo, vec2 mean, float sigma2) {
+    const float l = sqrtf(fminf_(1.f, dot(mean, mean)));
+    const float coso = sqrtf(fmaxf_(0.f, 1.f - dot(mean, mean)));
+    wo = wo - mean;
+    const float r2 = dot(wo, wo);
+    const float x = expf(-.5f * r2 / sigma2);
+    const float max_phi = gaussian_max_phi(sqrtf(r2), l);
+    return .5f * x / (max_phi * sigma2) * coso;
+}
+
 WT_HD float profile_alpha(const material_t& m, vec3 wi, vec3 wo, float k) {
     if (m.profile == PROFILE_DIRAC) return 1.f;
+    if (m.profile == PROFILE_GAUSSIAN) return expf(-(sqr((fabsf(wi.z) + fabsf(wo.z)) * k) * gaussian_params(m, k).alpha));
     const fractal_params_t pr = fractal_params(m, k);
     const float a = sqr((fabsf(wi.z) + fabsf(wo.z)) * k) * pr.alpha;
     return expf(-a);
 }
-WT_HD bool profile_is_delta_only(const material_t& m) { return m.profile == PROFILE_DIRAC || m.roughness == 0.f; }
+WT_HD bool profile_is_delta_only(const material_t& m) {
+    if (m.profile == PROFILE_GAUSSIAN && m.gauss_sigma > 0.f) return false;
+    return m.profile == PROFILE_DIRAC || m.roughness == 0.f;
+}
 WT_HD float profile_psd(const material_t& m, vec3 wi, vec3 wo, float k) {
     if (m.profile == PROFILE_DIRAC) return 0.f;
+    if (m.profile == PROFILE_GAUSSIAN) return gaussian_psd(gaussian_params(m, k), k * (vec2{wi.x, wi.y} + vec2{wo.x, wo.y}), k);
     const fractal_params_t pr = fractal_params(m, k);
     const vec2 z = k * (vec2{wi.x, wi.y} + vec2{wo.x, wo.y});
     return fractal_psd(m, pr, z, k);
 }
 WT_HD float profile_pdf(const material_t& m, vec3 wi, vec3 wo, float k) {
     if (m.profile == PROFILE_DIRAC) return 0.f;
+    if (m.profile == PROFILE_GAUSSIAN) return boxmueller_truncated_pdf(vec2{wo.x, wo.y}, -vec2{wi.x, wi.y}, gaussian_params(m, k).sigma2 / (k * k));
     const fractal_params_t pr = fractal_params(m, k);
     const vec2 zeta_k = vec2{wi.x, wi.y} + vec2{wo.x, wo.y};
     const float f_k = length(zeta_k);
@@ -83,6 +130,26 @@ struct profile_sample_t {
 // fractal.cpp:27-69 (Holzschuch & Pacanowski importance sampling)
 WT_HD profile_sample_t profile_sample(const material_t& m, vec3 wi, float k, sampler_t& sampler) {
     if (m.profile == PROFILE_DIRAC) return {{0, 0, 1}, 0.f, 0.f, 0.f};
+    if (m.profile == PROFILE_GAUSSIAN) {
+        // gaussian_t::sample (gaussian.hpp:205-228) + detail::sample_boxmueller_truncated (gaussian.hpp:26-53)
+        const gaussian_params_t gp = gaussian_params(m, k);
+        const float s2 = gp.sigma2 / (k * k);
+        const vec2 mean = -vec2{wi.x, wi.y};
+        const vec2 u = sampler_r2(sampler);
+        const float l = sqrtf(fminf_(1.f, dot(mean, mean)));
+        const float coso = sqrtf(fmaxf_(0.f, 1.f - dot(mean, mean)));
+        const float phi_i = (mean.x != 0.f || mean.y != 0.f) ? atan2f(mean.y, mean.x) : 0.f;
+        const float sm = expf(-.5f * sqr(1.f + l) / s2);
+        const float x = (1.f - sm) * fmaxf_(FLT_EPSILON, u.x) + sm;
+        const float r = sqrtf(-2.f * s2 * logf(x));
+        const float max_phi = gaussian_max_phi(r, l);
+        const float phi = phi_i + kPi + max_phi * (2.f * u.y - 1.f);
+        const vec2 wo2 = r * vec2{cosf(phi), sinf(phi)} + mean;
+        const float pdf = .5f * x / (max_phi * s2) * coso;
+        const float psd = gaussian_psd(gp, k * (wo2 - mean), k);
+        const float z = sqrtf(fmaxf_(0.f, 1.f - dot(wo2, wo2)));
+        return {vec3{wo2.x, wo2.y, wi.z >= 0.f ? z : -z}, pdf, psd, psd / pdf};
+    }
     const fractal_params_t pr = fractal_params(m, k);
     const float s = sqrtf(fmaxf_(0.f, 1.f - sqr(wi.z)));
     const float phi_i = s > 0.f ? atan2f(wi.y, wi.x) : 0.f;

@@ -72,7 +72,7 @@ struct spectrum_t {
 
 // ---- materials -----------------------------------------------------------------------------------
 enum material_type_e : int32_t { MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1, MAT_SURFACE_SPM = 2 };
-enum profile_type_e : int32_t { PROFILE_DIRAC = 0, PROFILE_FRACTAL = 1 };
+enum profile_type_e : int32_t { PROFILE_DIRAC = 0, PROFILE_FRACTAL = 1, PROFILE_GAUSSIAN = 2 };
 struct material_t {
     int32_t type;
     uint32_t two_sided;     // bsdf/two_sided wrapper
@@ -84,6 +84,7 @@ struct material_t {
     int32_t profile;        // surface_spm: PROFILE_*
     float roughness;        // fractal: perceptual roughness
     float gamma;            // fractal: log-log slope
+    float gauss_sigma;      // gaussian: > 0: explicit rms `sigma` [1/mm]; otherwise parametrised by `roughness` like the fractal profile
     float refl_scale, trans_scale;
 };
 
