@@ -51,6 +51,16 @@ def test_directional_emitter_under_plt_path(built):
     assert none.sum() == 0
 
 
+def test_double_slits_optical_overview(built):
+    """scenes/diffraction_simple/double_slits.xml with -Doptical_overview=true: `ray_trace_only` perspective camera (no cone queries
+    at all), two directional emitters, composite materials resolved to their optical bins (floor rgb(.8,.5,.35): warm)."""
+    img, c = _img("double_slits_overview", 16, lut=(64, 64))
+    assert c["cone_queries"] == 0 and c["fsd_interactions"] == 0 and c["connections"] > 0
+    assert np.isfinite(img).all() and (img >= 0).all()
+    floor = img[20:, :, :].reshape(-1, 3).mean(axis=0)
+    assert floor[0] > floor[1] > floor[2] > 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,spp,kw", [("sunlit", 8, {}), ("sunlit", 8, {"max_depth": 1, "mis": 0, "only_s": 2, "only_t": 1}), ("sunlit_path", 8, {})])
 def test_directional_emitter_gpu_parity(built, name, spp, kw):

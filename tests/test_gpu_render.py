@@ -28,6 +28,8 @@ def _rel_l1(a, b):
     ("furnace", 24, 4, {"fsd": 1, "lut": (128, 128)}),
     # rough conductors with the Gaussian (roughness-parametrised and explicit rms) and the fractal surface profile
     ("furnace_spm", 32, 8, {}),
+    # double_slits.xml -Doptical_overview=true: ray-trace-only RGB camera, two directional emitters, RGB-uplifted reflectances
+    ("double_slits_overview", 32, 8, {"lut": (64, 64)}),
 ])
 def test_image_parity_small(built, name, res, spp, kw):
     """Same Philox streams on both sides => the images agree sample for sample up to fp contraction / libm ulps.

@@ -68,6 +68,45 @@ static void apply_opts(const scene_params_t& p, integrator_opts_t& o) {
 }
 
 // ---- scenes/diffraction_simple/double_slits.xml ---------------------------------------------------------------
+static void build_double_slits_geometry(scene_builder_t& b, int m_wall, int m_floor, int m_screen) {
+    const double L = -500, S = 50, D = 12, H = 20, Z = -15, W = .65, Wslit = .35;
+    const xform_t I = xform_t::identity();
+    // wall, floor (bits/geometry.xml)
+    b.add_shape(mesh_rectangle({-100 * mm, -H * mm, S * mm}, {200 * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_wall);
+    b.add_shape(mesh_rectangle({-100 * mm, -H * mm, (L - 100) * mm}, {200 * mm, 0, 0}, {0, 0, (S - L + 100) * mm}), I, m_floor);
+    // screen: three rectangles leaving two slits of width Wslit centred at +-W/2
+    b.add_shape(mesh_rectangle({-D / 2 * mm, -H * mm, Z * mm}, {(D / 2 - (W + Wslit) / 2) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+    b.add_shape(mesh_rectangle({(-W / 2 + Wslit / 2) * mm, -H * mm, Z * mm}, {(W - Wslit) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+    b.add_shape(mesh_rectangle({(W + Wslit) / 2 * mm, -H * mm, Z * mm}, {(D / 2 - (W + Wslit) / 2) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+}
+
+// double_slits.xml with -Doptical_overview=true: the "optical_sensor" (perspective, fov 35 deg, ray_trace_only, RGB / CIE D50) sees the
+// set-up under the two `directional` preview emitters (blackbody 5750 K x 1e-6 and 6500 K x 6e-5); the 50 um spot has no overlap with
+// the RGB sensitivity and drops out of the emitter sampling tables.  Composite BSDFs / spectra (bsdf/composite.hpp:26-140: dispatch by
+// wavenumber bin, nothing outside the bins) are resolved when the scene is baked: every shipped scene splits its bins into
+// "optical" (300 nm .. 800 nm) and "radio" (1 um .. 1 m) and every sensor is sensitive inside one of them only.  Optical bins here:
+// floor = diffuse rgb(.8,.5,.35), wall = diffuse rgb(.539479,.539479,.539480), screen = the same conductor.
+static void build_double_slits_overview(const scene_params_t& p, scene_builder_t& b) {
+    const double S = 50;
+    integrator_opts_t o{};
+    o.max_depth = 16;
+    o.MIS = o.RR = o.FSD = o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    if (p.lut_m) b.set_fsd_lut_resolution(p.lut_n_theta, p.lut_m);
+    b.set_sensor_perspective(xform_t::lookat({-50 * mm, 100 * mm, -100 * mm}, {0, -10 * mm, S / 2 * mm}, {0, 1, 0}), deg(35), p.res, p.res, 1.f, true);
+    const float D50[3] = {0.96422f, 1.00000f, 0.82521f};
+    b.set_response_rgb(D50);
+    // lookat(origin, target 0): the emission direction (0,0,-1)... mapped by to_world points from the origin towards the target, so
+    // the direction TO the emitter is origin - target (src/emitter/directional.cpp:118-120)
+    b.add_emitter_directional({-2, 3.5, -1}, b.spectrum_blackbody(5750.f, 1.f), 1e-6f, 6.794e-5f, 1.f);
+    b.add_emitter_directional({-1, 4, 1}, b.spectrum_blackbody(6500.f, 1.f), 6e-5f, 6.794e-5f, 1.f);
+    const int m_screen = b.add_material(mat_spm(b.spectrum_const(1.f, 100.f), true, .3f, 3.f, true, 1.f));
+    const int m_floor = b.add_material(mat_diffuse(b.spectrum_rgb(.8f, .5f, .35f), 1.f, true));
+    const int m_wall = b.add_material(mat_diffuse(b.spectrum_rgb(.539479f, .539479f, .539480f), 1.f, true));
+    build_double_slits_geometry(b, m_wall, m_floor, m_screen);
+}
+
 static void build_double_slits(const scene_params_t& p, scene_builder_t& b) {
     const double L = -500, Lscale = 1633, S = 50, E = 5, extent = 250, D = 12, H = 20, Z = -15, lambda = .05, W = .65, Wslit = .35;
     integrator_opts_t o{};
@@ -94,14 +133,7 @@ static void build_double_slits(const scene_params_t& p, scene_builder_t& b) {
     const int m_floor = b.add_material(mat_diffuse(b.spectrum_const(.1f), 1.f, true));
     const int m_wall = b.add_material(mat_diffuse(b.spectrum_const(.9f), 1.f, true));
 
-    const xform_t I = xform_t::identity();
-    // wall, floor (bits/geometry.xml)
-    b.add_shape(mesh_rectangle({-100 * mm, -H * mm, S * mm}, {200 * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_wall);
-    b.add_shape(mesh_rectangle({-100 * mm, -H * mm, (L - 100) * mm}, {200 * mm, 0, 0}, {0, 0, (S - L + 100) * mm}), I, m_floor);
-    // screen: three rectangles leaving two slits of width Wslit centred at +-W/2
-    b.add_shape(mesh_rectangle({-D / 2 * mm, -H * mm, Z * mm}, {(D / 2 - (W + Wslit) / 2) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
-    b.add_shape(mesh_rectangle({(-W / 2 + Wslit / 2) * mm, -H * mm, Z * mm}, {(W - Wslit) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
-    b.add_shape(mesh_rectangle({(W + Wslit) / 2 * mm, -H * mm, Z * mm}, {(D / 2 - (W + Wslit) / 2) * mm, 0, 0}, {0, 2 * H * mm, 0}), I, m_screen);
+    build_double_slits_geometry(b, m_wall, m_floor, m_screen);
 }
 
 // ---- scenes/cornell-box/box.xml (stand-in) ----------------------------------------------------------------------
@@ -390,6 +422,8 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
     if (name == "bidir_room")
         build_room(p, b);
+    else if (name == "double_slits_overview")
+        build_double_slits_overview(p, b);
     else if (name == "furnace_spm")
         build_furnace(p, b, true);
     else if (name == "sunlit")
