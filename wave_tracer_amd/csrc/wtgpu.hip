@@ -39,9 +39,12 @@ namespace {
 
 constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
 constexpr int kBlock = 128;
-constexpr int kLdsStack = 20;            // LDS-resident stack entries per lane
+#ifndef WTGPU_LDS_STACK
+#define WTGPU_LDS_STACK 20
+#endif
+constexpr int kLdsStack = WTGPU_LDS_STACK;   // LDS-resident stack entries per lane
 constexpr uint32_t kConeBudget = 48;     // cone-triangle tests one lane may spend on a query before it is handed to a wavefront
-constexpr int kSpillStack = 44;          // scratch spill entries per lane (total 64, the reference's ray stack size)
+constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
