@@ -43,6 +43,20 @@ def test_named_scene_host_baking(built, name, tris):
         assert sc.channels == 3
 
 
+def test_scene_info_reports_integrator_and_stokes(built):
+    """wtgpu_scene_info: integrator of the flattened scene (0 plt_bdpt, 1 plt_path forward, 2 plt_path backward) and film components."""
+    from wave_tracer_amd import Scene
+    for name, integ, kw, stokes in (("furnace", 0, {}, 1), ("etoile", 1, {"mesh_detail": 0}, 1), ("furnace_path", 2, {}, 1),
+                                    ("bidir_room", 0, {"mesh_detail": 0, "lut": (32, 32), "polarimetric": 1}, 4)):
+        sc = Scene(name, res=16, **kw)
+        assert (sc.info.integrator, sc.info.stokes) == (integ, stokes)
+        assert sc.channels == sc.spectral_channels * stokes
+    et = Scene("etoile", res=32, mesh_detail=0)
+    assert (et.width, et.height) == (32, 24) and et.info.sensor_type == 1 and et.info.n_emitters == 1 and et.info.max_depth == 16
+    room = Scene("bidir_room", res=60, mesh_detail=0, lut=(32, 32))
+    assert (room.width, room.height) == (60, 34) and room.info.max_depth == 10 and room.info.n_emitters == 2   # round(res 17/30)
+
+
 def test_cornell_box_standin_baking(built):
     from wave_tracer_amd import Scene
     sc = Scene("cornell_box", res=32, mesh_detail=0, lut=(64, 64))
