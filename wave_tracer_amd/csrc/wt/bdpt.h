@@ -451,6 +451,26 @@ WT_HD bool walk_continue(const scene_t& sc, walk_t& w, const vertex_store_t& vs,
     return false;
 }
 
+// Power of the beam's wavefront that one triangle of the interaction region intercepts (find_closest_triangle,
+// plt_bdpt_detail.hpp:391-416): clipped to the region's z-slab, projected to the cross-section at its centre, Gaussian integral.
+WT_HD float region_triangle_flux(const scene_t& sc, const frame_t& beam_frame, const cone_t& envelope, const range_t& izr, vec2 sigma, uint32_t tuid,
+                                 bool want_front) {
+    const tri_geo_t g = sc.tri_geo[tuid];
+    const bool front_face = dot(g.n, -envelope.d) > 0.f;
+    if (front_face != want_front) return 0.f;
+    const float csz = centre(izr);
+    const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
+                                          to_local(beam_frame, g.c - envelope.o), izr);
+    float flux = 0.f;
+    for (int t = 0; t < ct.tris; ++t) {
+        vec3 a, b, c;
+        clip_tri_get(ct, t, a, b, c);
+        const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz), pc = cone_project_local(envelope, c, csz);
+        flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
+    }
+    return flux;
+}
+
 // One random-walk step after the beam has been traced (plt_bdpt_detail.hpp:421-526 minus the traverse() call).
 // Hand-over record of a Fraunhofer-FSD rejection loop that a device lane could not finish within kFsdInlineTries (fsd.h):
 // pending = the step returned early, nothing committed; resolved = the wavefront found the outcome, re-run the step with it.
@@ -678,21 +698,8 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                     if (defer && defer->has_gather) {
                         integrated_flux = defer->gather_flux;
                     } else {
-                        const float csz = centre(izr);
-                        for (uint32_t i = 0; i < tr.ntris; ++i) {
-                            const tri_geo_t g = sc.tri_geo[tris[i]];
-                            const bool front_face = dot(g.n, -beam.env.d) > 0.f;
-                            if (front_face != (tr.front_face != 0)) continue;
-                            const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
-                                                                  to_local(beam_frame, g.c - envelope.o), izr);
-                            for (int t = 0; t < ct.tris; ++t) {
-                                vec3 a, b, c;
-                                clip_tri_get(ct, t, a, b, c);
-                                const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz),
-                                           pc = cone_project_local(envelope, c, csz);
-                                integrated_flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
-                            }
-                        }
+                        for (uint32_t i = 0; i < tr.ntris; ++i)
+                            integrated_flux += region_triangle_flux(sc, beam_frame, envelope, izr, sigma, tris[i], tr.front_face != 0);
                     }
                     const float I = 1.f - integrated_flux;
                     ap.recp_I = I > 0.f ? 1.f / I : 0.f;

@@ -138,7 +138,7 @@ struct launch_args_t {
     uint32_t count_stats;
     uint32_t cone_budget;
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
-    uint32_t pass_c;          // WTGPU_PASS_C=1: Fraunhofer apertures with edges are completed (power integrals, rejection sampling) in a third pass
+    uint32_t pass_c;          // Fraunhofer apertures with edges are completed (power integrals, rejection sampling) by k_interact_c (WTGPU_PASS_C=0: by pass B)
     uint32_t exact_regions;   // WTGPU_EXACT_REGIONS=1: walk interaction regions that overflow the bounded triangle list again (k_gather)
 };
 
@@ -322,13 +322,12 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
 
 // Interaction step of the queued walks.  PASS 0 (A): the queue of the round; walks whose beam axis misses every listed triangle
 // (expensive path, see bdpt_walk_step) are only appended to the pass-B queue.  PASS 1 (B): that queue: edge set, Fraunhofer aperture,
-// null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue.  PASS 2 (C): rejection sampling
-// of those apertures + vertex append, with full wavefronts.
+// null interactions; with pass C enabled the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
 template <int PASS>
 __device__ inline void interact_body(const launch_args_t& a, int in, int first_round, stack_entry_t* lds) {
-    constexpr bool PASS_B = PASS >= 1, PASS_C = PASS == 2;
+    constexpr bool PASS_B = PASS == 1;
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = PASS_C ? ctl[CTL_INTC_COUNT] : (PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in]);
+    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in];
     if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
@@ -342,7 +341,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
     for (;;) {
-        const uint32_t qi = wave_grab(ctl + (PASS_C ? CTL_INTC_HEAD : (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT))) + (threadIdx.x & 63);
+        const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
         bool cont = false;
         uint32_t w = 0, stream = 0;
@@ -352,7 +351,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
         defer.defer_sampling = (PASS == 1 && a.pass_c) ? 1u : 0u;
         defer.to_sampling_pass = 0;
-        defer.have_aperture = PASS_C ? 1u : 0u;
+        defer.have_aperture = 0;
         defer.split_no_primary = PASS_B ? 0u : 1u;
         defer.known_no_primary = PASS_B ? 1u : 0u;
         defer.no_primary = 0;
@@ -362,8 +361,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         bool need_gather = false;
         bool todo = qi < n;
         if (todo) {
-            w = PASS_C ? a.st.intc_queue[qi] : (PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round));
-            if (PASS_C) defer.slot = a.st.trav[WT_TRAV_WORD(by) * W2 + w];   // left by pass B
+            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round);
             uint32_t i;
             walk_ident(a, w, i, stream);
             const uint64_t j = a.j0 + i;
@@ -374,7 +372,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         // at most two executions of the step: the second only for lanes whose Fraunhofer-FSD rejection loop was finished by
         // the wavefront in between (pass B)
         // (with pass C enabled only that pass samples apertures; otherwise pass B does everything)
-        for (int pass = 0; pass < ((PASS_C || (PASS_B && !a.pass_c)) ? 2 : 1); ++pass) {
+        for (int pass = 0; pass < ((PASS_B && !a.pass_c) ? 2 : 1); ++pass) {
             if (todo) {
                 walk_t wk;
                 soa_load(a.st.walks, W2, w, wk);
@@ -417,7 +415,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
                     }
                 }
             }
-            if (!(PASS_C || (PASS_B && !a.pass_c))) break;
+            if (!(PASS_B && !a.pass_c)) break;
             // ---- Fraunhofer-FSD rejection loops that did not finish within kFsdInlineTries: the wavefront finishes them one after
             // the other, 64 tries per step (tries are independent, fsd.h), then the owning lane re-runs its step with the outcome.
             unsigned long long pm = __ballot(todo && defer.pending != 0);
@@ -518,9 +516,104 @@ __global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int i
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     interact_body<1>(a, in, 0, lds);
 }
-__global__ void __launch_bounds__(kBlock, 3) k_interact_c(launch_args_t a, int in) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    interact_body<2>(a, in, 0, lds);
+// Pass C (WTGPU_PASS_C): the walks of pass B whose Fraunhofer aperture has edges, ONE WAVEFRONT PER WALK.  What a single lane of pass B
+// would do serially is spread over the 64 lanes: the intercepted-power integrals (lane = triangle of the region, wave reduction)
+// and the rejection sampling (64 tries per step; tries own their random draws, the lowest accepted try wins like in the sequential
+// loop); lane 0 then re-enters bdpt_walk_step with the outcome (vertex append, beam transform, Russian roulette).
+__global__ void __launch_bounds__(64, 3) k_interact_c(launch_args_t a, int in) {
+    __shared__ uint32_t s_item;
+    __shared__ stack_entry_t lds[8];   // the resumed step does no BVH queries; lane 0's stack is a formality
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_INTC_COUNT];
+    const int lane = threadIdx.x;
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
+    for (;;) {
+        if (lane == 0) s_item = atomicAdd(ctl + CTL_INTC_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.intc_queue[item];
+        uint32_t i, stream;
+        walk_ident(a, w, i, stream);
+        const uint64_t j = a.j0 + i;
+        const uint32_t pix = (uint32_t)(j % a.npix);
+        const uint64_t sample_id = ((uint64_t)pix << 32) | ((a.sample_begin + j / a.npix) & 0xFFFFFFFFull);
+        walk_t wk;
+        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
+        trav_result_t tr;
+        soa_load(a.st.trav, W2, w, tr);
+        const uint32_t slot = a.st.trav[WT_TRAV_WORD(by) * W2 + w];   // left by pass B
+        fsd_aperture_t ap = pool.hdr[slot];
+        const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
+        // ---- intercepted power (bdpt_walk_step computes the same sum triangle by triangle)
+        float flux;
+        if (tr.tuid == kGatherMarker) {
+            flux = tr.bx;
+        } else {
+            const range_t izr{tr.dist, tr.dist + tr.region_depth};
+            const vec3 sd3 = beam_footprint(wk.beam, tr.dist) / kBeamEnvelope;
+            const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
+            flux = (uint32_t)lane < tr.ntris ? region_triangle_flux(a.sc, cone_frame(wk.beam.env), wk.beam.env, izr, vec2{sd3.x, sd3.y}, tl[lane], tr.front_face != 0) : 0.f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) flux += __shfl_xor(flux, off, 64);
+        }
+        const float I = 1.f - flux;
+        ap.recp_I = I > 0.f ? 1.f / I : 0.f;
+        if (lane == 0) pool.hdr[slot] = ap;
+        // ---- rejection sampling, 64 tries per step
+        const sampler_t ss = make_sampler(a.seed, sample_id, stream, 0);
+        const uint32_t base = fsd_tries_base(make_sampler(a.seed, sample_id, stream, wk.rng_draws));
+        const uint32_t max_tries = fsd_max_tries(ap);
+        bool acc = false;
+        uint32_t t_acc = 0;
+        float rx = 0.f, ry = 0.f, rf = 0.f;
+        for (uint32_t t0 = 0; t0 < max_tries && !acc; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
+            if (t < max_tries) r = fsd_try(a.sc, ap, ed, sampler_at(ss, base + t * kFsdDrawsPerTry));
+            const unsigned long long am = __ballot(r.accept != 0);
+            if (am) {
+                const int wl = __ffsll((long long)am) - 1;
+                rx = __shfl(r.x.x, wl, 64);
+                ry = __shfl(r.x.y, wl, 64);
+                rf = __shfl(r.f, wl, 64);
+                t_acc = t0 + (uint32_t)wl;
+                acc = true;
+            }
+        }
+        // ---- commit: lane 0 resumes the step with the outcome
+        bool cont = false;
+        if (lane == 0) {
+            fsd_defer_t defer;
+            defer.defer_sampling = defer.to_sampling_pass = 0;
+            defer.have_aperture = 1;
+            defer.split_no_primary = 0;
+            defer.known_no_primary = 1;
+            defer.no_primary = 0;
+            defer.has_gather = defer.gather_n_edges = defer.gather_edge_overflow = 0;
+            defer.gather_flux = 0.f;
+            defer.gather_edges = nullptr;
+            defer.pending = 0;
+            defer.resolved = 1;
+            defer.slot = slot;
+            defer.base = base;
+            defer.next_try = 0;
+            defer.fs = fsd_finalize(ap, acc, vec2{rx, ry}, rf);
+            defer.end_draws = fsd_draws_after(base, acc ? t_acc : max_tries - 1u);
+            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
+            const vertex_store_t vs{a.st.verts, W2, w};
+            stack_ref_t stack{lds, 1, 8, 8, nullptr};
+            cont = bdpt_walk_step<2>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
+            wk.active = cont ? 1u : 0u;
+            soa_store(a.st.walks, W2, w, wk);
+        }
+        wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
 // ---- plt_path: one walk per sample; k_trace / k_trace_heavy are shared with plt_bdpt (they only read the walk_t
@@ -1051,10 +1144,10 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     // +0.2 % identical pixels); on, the device treats them like the reference's unbounded lists
     a.exact_regions = 0;
     if (const char* e = getenv("WTGPU_EXACT_REGIONS")) a.exact_regions = (uint32_t)atoi(e);
-    // Off by default (measured 194.7 -> 201.5 ms per pass): compacting the one walk in eight of pass B whose aperture has edges into
-    // a pass of its own gives full wavefronts for the power integrals and the rejection sampling, but re-loading the walk state and
-    // the extra 96 launches per batch cost more than the divergence they remove
-    a.pass_c = 0;
+    // On by default (193.5 -> 185.5 ms per pass; WTGPU_PASS_C=0 turns it off): the one walk in eight of pass B whose aperture has
+    // edges is completed by a wavefront of its own (k_interact_c): a lane of pass B takes ~1 ms for the intercepted-power integrals
+    // over up to 64 triangles plus the rejection loop, during which the 56 other lanes of its wavefront idle
+    a.pass_c = 1;
     if (const char* e = getenv("WTGPU_PASS_C")) a.pass_c = (uint32_t)atoi(e);
     // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
     int n_cu = 256;
@@ -1062,7 +1155,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     uint32_t heavy_waves_per_cu = 16;
     if (const char* e = getenv("WTGPU_HEAVY_WAVES")) heavy_waves_per_cu = (uint32_t)std::max(1, atoi(e));
     const uint32_t grid_round = (uint32_t)n_cu * 8u, grid_heavy = (uint32_t)n_cu * heavy_waves_per_cu;
-    uint32_t grid_div_b = 4, grid_div_c = 16;   // persistent grids of the two expensive-interaction passes relative to the round's
+    uint32_t grid_div_b = 4, grid_div_c = 2;   // persistent grids of the two expensive-interaction passes relative to the round's
     if (const char* e = getenv("WTGPU_GRID_B")) grid_div_b = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("WTGPU_GRID_C")) grid_div_c = (uint32_t)std::max(1, atoi(e));
 
@@ -1124,7 +1217,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             rec();
             if (a.exact_regions) hipLaunchKernelGGL(k_gather, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
-            if (a.pass_c) hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, g0 / grid_div_c)), dim3(kBlock), 0, st_, a, in);
+            if (a.pass_c) hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
             rec();
         }
         if (path_mode) {
