@@ -208,7 +208,7 @@ WT_HD void path_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, u
 // Terminates a walk: backward transport splats what it gathered (integrate_backward, plt_path_detail.hpp:800-801).
 WT_HD void path_finish(const scene_t& sc, const film_t& film, path_walk_t& pw) {
     pw.w.active = 0;
-    if (sc.opts.integrator != INTEGRATOR_PATH_BACKWARD) return;
+    if (sc.opts.integrator != INTEGRATOR_PATH_BACKWARD || sc.opts.max_depth <= 0) return;   // max_depth 0: nothing at all (:776, :805)
     const stokes_t L{{pw.L[0] * pw.recp_spectral_pd, pw.L[1] * pw.recp_spectral_pd, pw.L[2] * pw.recp_spectral_pd, pw.L[3] * pw.recp_spectral_pd}};
     film_splat(sc, film, pw.element, L, pw.w.beam.k);
 }
@@ -219,7 +219,7 @@ WT_HD void path_finish(const scene_t& sc, const film_t& film, path_walk_t& pw) {
 WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_t& tr, const uint_list_t& tris, const utd_edges_ref_t& utd_edges,
                           const film_t& film, uint64_t seed, uint64_t sample_id, uint32_t stream, const stack_ref_t& stack, bdpt_counters_t* ctr) {
     walk_t& w = pw.w;
-    if (tr.empty) return false;   // no intersection (TODO in the reference: infinite emitters)
+    if (!w.active || tr.empty) return false;   // (inactive: max_depth 0)  no intersection (TODO in the reference: infinite emitters)
     const bool backward = sc.opts.integrator == INTEGRATOR_PATH_BACKWARD;
     const int depth = (int)w.nverts;
     sampler_t smp = make_sampler(seed, sample_id, stream, w.rng_draws);
