@@ -1169,9 +1169,11 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
     int n_cu = 256;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
-    uint32_t heavy_waves_per_cu = 16;
+    uint32_t heavy_waves_per_cu = 8;   // swept 6 / 8 / 10 / 12 / 16 / 24 / 32: 169.6 / 168.0 / 171.6 / 174.3 / 176 / 181 / 183 ms per pass (4 streams share the CUs)
     if (const char* e = getenv("WTGPU_HEAVY_WAVES")) heavy_waves_per_cu = (uint32_t)std::max(1, atoi(e));
-    const uint32_t grid_round = (uint32_t)n_cu * 8u, grid_heavy = (uint32_t)n_cu * heavy_waves_per_cu;
+    uint32_t round_blocks_per_cu = 8;
+    if (const char* e = getenv("WTGPU_ROUND_BLOCKS")) round_blocks_per_cu = (uint32_t)std::max(1, atoi(e));
+    const uint32_t grid_round = (uint32_t)n_cu * round_blocks_per_cu, grid_heavy = (uint32_t)n_cu * heavy_waves_per_cu;
     uint32_t grid_div_b = 4, grid_div_c = 2;   // persistent grids of the two expensive-interaction passes relative to the round's
     if (const char* e = getenv("WTGPU_GRID_B")) grid_div_b = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("WTGPU_GRID_C")) grid_div_c = (uint32_t)std::max(1, atoi(e));
