@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -55,6 +56,22 @@ def test_scene_info_reports_integrator_and_stokes(built):
     assert (et.width, et.height) == (32, 24) and et.info.sensor_type == 1 and et.info.n_emitters == 1 and et.info.max_depth == 16
     room = Scene("bidir_room", res=60, mesh_detail=0, lut=(32, 32))
     assert (room.width, room.height) == (60, 34) and room.info.max_depth == 10 and room.info.n_emitters == 2   # round(res 17/30)
+
+
+def test_scene_create_from_desc_wraps_a_flattened_scene(built):
+    """wtgpu_scene_create_from_desc: the entry point a port of the reference's loader would call with its own flattened scene.
+    Wrapping the host description of a baked scene gives the same scene (info, and sample-for-sample the same CPU-checker image)."""
+    from wave_tracer_amd import Scene
+    from oracle_util import oracle_render
+    for name, kw in (("furnace", {"lut": (32, 32)}), ("etoile", {"mesh_detail": 0})):
+        a = Scene(name, res=16, **kw)
+        b = Scene.from_desc(a.host_desc(), keepalive=a)
+        for f in ("width", "height", "channels", "n_tris", "n_edges", "n_nodes", "n_leaves", "n_shapes", "n_emitters", "n_materials", "max_depth",
+                  "sensor_type", "stokes", "integrator"):
+            assert getattr(a.info, f) == getattr(b.info, f), f
+        va, wa, la, ca = oracle_render(a, 0, 2, 5, threads=1)
+        vb, wb, lb, cb = oracle_render(b, 0, 2, 5, threads=1)
+        assert np.array_equal(va, vb) and np.array_equal(wa, wb) and np.array_equal(la, lb) and ca == cb
 
 
 def test_cornell_box_standin_baking(built):

@@ -161,6 +161,17 @@ def test_pass_c_mode_is_result_identical(built, monkeypatch):
         assert np.abs(va - vb).sum() <= 1e-5 * np.abs(va).sum() and np.abs(la - lb).sum() <= 1e-5 * max(np.abs(la).sum(), 1e-300)
 
 
+def test_scene_from_desc_renders_like_the_named_scene(built):
+    """wtgpu_scene_create_from_desc + upload + render == the named scene it was taken from."""
+    from wave_tracer_amd import Scene, render
+    a = Scene("furnace", res=24, lut=(32, 32))
+    b = Scene.from_desc(a.host_desc(), keepalive=a)
+    va, wa, la = render(a, 4, seed=6)
+    vb, wb, lb = render(b, 4, seed=6)
+    assert np.allclose(wa, wb, rtol=1e-12) and np.abs(va - vb).sum() <= 1e-9 * np.abs(va).sum() and np.abs(la - lb).sum() <= 1e-9 * max(np.abs(la).sum(), 1e-300)
+    assert a.counters() == b.counters()
+
+
 def test_async_renders_pipeline_and_join(built):
     """wtgpu_render_async + wtgpu_join: several un-joined renders into the same accumulators equal one joined render."""
     import torch

@@ -123,6 +123,25 @@ class Scene:
         self.width, self.height, self.channels = info.width, info.height, info.channels * info.stokes
         self.device = None
 
+    @classmethod
+    def from_desc(cls, desc_ptr, keepalive=None, name="<desc>"):
+        """Wraps an already flattened scene (pointer to a host `wt::scene_t`, wtgpu_scene_create_from_desc): the entry point a port of
+        the reference's own loader would use.  `keepalive`: the object owning the host arrays (they must outlive the handle)."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        _check(lib.wtgpu_scene_create_from_desc(C.c_void_p(desc_ptr), C.byref(h)))
+        self._h = h
+        self._keepalive = keepalive
+        self.name = name
+        info = SceneInfo()
+        _check(lib.wtgpu_scene_get_info(h, C.byref(info)))
+        self.info = info
+        self.spectral_channels, self.stokes = info.channels, info.stokes
+        self.width, self.height, self.channels = info.width, info.height, info.channels * info.stokes
+        self.device = None
+        return self
+
     @property
     def handle(self):
         return self._h
