@@ -26,7 +26,7 @@ def test_srgb_transfer_and_modes():
     lum = np.maximum(0, rgb @ np.array([.2126, .7152, .0722]))
     assert np.allclose(db[..., 1], tonemap_db(lum, -30, 0))
     t = colourmap(np.linspace(0, 1, 64))
-    assert t.shape == (64, 3) and (t >= 0).all() and (t <= 1).all() and t[0, 2] > t[0, 0] and t[-1, 0] > t[-1, 2]   # blue -> red
+    assert t.shape == (64, 3) and (t >= 0).all() and (t <= 1).all() and t[8, 2] > t[8, 0] and t[-4, 0] > t[-4, 2]   # blue -> red
 
 
 def test_image_writers_round_trip(tmp_path):
