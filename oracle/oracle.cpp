@@ -2,7 +2,8 @@
 //
 // What this is: a scalar, per-sample, per-pixel CPU rendering loop that follows the reference's control flow
 // (src/integrator/plt_bdpt.cpp:43-148: for each sample { spectral+emitter sample; sensor sample; sensor subpath;
-// emitter subpath; all (s,t) connections with MIS; splat }), parallelised over pixel tiles with std::thread like the
+// emitter subpath; all (s,t) connections with MIS; splat }; for plt_path scenes src/integrator/plt_path.cpp:39-50: one walk per
+// sample with next-event estimation and UTD diffraction), parallelised over pixel tiles with std::thread like the
 // reference's render loop (src/scene/render.cpp:99-172: 24x24-pixel blocks).  It is used ONLY by tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product path.
 //
@@ -12,7 +13,8 @@
 // citing the reference file:line it restates) with the HIP kernels; what it checks independently is the GPU
 // orchestration (wavefront scheduling, SoA state, LDS stacks, queues, atomics) — sample for sample, with identical
 // counter-based random numbers.  The physics primitives themselves are pinned by closed-form / numpy / scipy
-// known-answer tests in tests/test_kat.py and by the analytic double-slit fringe gate.
+// known-answer tests in tests/test_kat*.py, the analytic double-slit fringe gate and the closed forms of
+// tests/test_path_oracle.py (free-space coverage, white furnace).
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -27,7 +29,7 @@ using namespace wt;
 
 namespace {
 
-constexpr uint32_t kMaxWalkIters = 96;   // must match kernels.hip (cap on trace/interact rounds per subpath)
+constexpr uint32_t kMaxWalkIters = 96;   // must match wave_tracer_amd/csrc/wtgpu.hip (cap on trace/interact rounds per subpath)
 
 struct sample_scratch_t {
     std::vector<uint32_t> svert, evert;   // vertex stores (stride 1)

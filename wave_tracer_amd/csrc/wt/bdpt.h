@@ -9,7 +9,7 @@
 //
 // The reference's recursion / std::vector<vertex_t> / unique_ptr<fsd> arena become: an explicit walk state, a
 // strided vertex store (one SoA "plane" per vertex index) and a pool of fixed-capacity FSD apertures.  The
-// functions here are the building blocks shared by the HIP wavefront kernels (kernels.hip) and by the scalar
+// functions here are the building blocks shared by the HIP wavefront kernels (wtgpu.hip) and by the scalar
 // per-sample CPU loop of the checker (oracle/).
 #pragma once
 #include <cstddef>
