@@ -113,54 +113,57 @@ WT_HD fsd_build_state_t fsd_build_begin(const frame_t& frame, float k, float tot
     st.P_total = 0.f;
     return st;
 }
+// The aperture segments one scene edge contributes, in order, each passed to emit(fe) (free_space_diffraction.cpp:47-104): only
+// silhouette edges, clipped to the beam's envelope ellipse, cut into pieces no longer than a third of the envelope radius.
+template <class Emit>
+WT_HD void fsd_edge_segments(const scene_t& sc, const frame_t& frame, const cone_t& beam, vec2 sigma, vec2 cse, float max_edge_length, uint32_t edge_id,
+                             Emit&& emit) {
+    const edge_t edge = sc.edges[edge_id];
+    // only the projected silhouette
+    if (dot(beam.d, edge.n1) * dot(beam.d, edge.n2) >= 0.f) return;
+    const vec3 la = to_local(frame, edge.a - beam.o), lb = to_local(frame, edge.b - beam.o);
+    const vec2 u1{la.x, la.y}, u2{lb.x, lb.y};
+    float t1 = 0.f, t2 = 1.f;
+    const vec2 q1 = u1 / cse, q2 = u2 / cse;
+    if (!(dot(q1, q1) <= 1.f) || !(dot(q2, q2) <= 1.f)) {
+        const edge_ellipse_t intr = intersect_edge_ellipse(u1, u2, cse.x, cse.y);
+        if (intr.points == 0) return;
+        t1 = fmaxf_(0.f, intr.t1);
+        t2 = fminf_(1.f, intr.t2);
+    }
+    const float len = length(mix2(u1, u2, t1) - mix2(u1, u2, t2));
+    // max(1, int(round(len/max_edge_length) + .5))
+    int segments = (int)(roundf(len / max_edge_length) + .5f);
+    if (segments < 1) segments = 1;
+    const float seg = 1.f / float(segments);
+    vec2 v1 = mix2(u1, u2, t1);
+    float a = sqrtf(wavefront_intensity(sigma, v1));
+    for (int i = 0; i < segments; ++i) {
+        const float tt = mixf(t1, t2, float(i + 1) * seg);
+        const vec2 v2 = mix2(u1, u2, tt);
+        const float b = sqrtf(wavefront_intensity(sigma, v2));
+        if (a > 0.f || b > 0.f) {
+            fsd_edge_t fe;
+            fe.v = ((v1 + v2) / 2.f) / kFsdUnitM;
+            fe.e = (v2 - v1) / kFsdUnitM;
+            fe.ab = a - b;
+            fe.iab = (a + b) / 2.f;
+            fe.pdf = fsd_Pj(fe);
+            if (fe.pdf > 0.f) emit(fe);
+        }
+        v1 = v2;
+        a = b;
+    }
+}
 WT_HD void fsd_build_add_edge(const scene_t& sc, const frame_t& frame, const cone_t& beam, vec2 sigma, fsd_build_state_t& st, uint32_t edge_id,
                               fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
-    const vec2 cse = st.cse;
-    const float max_edge_length = st.max_edge_length;
-    {
-        const edge_t edge = sc.edges[edge_id];
-        // only the projected silhouette
-        if (dot(beam.d, edge.n1) * dot(beam.d, edge.n2) >= 0.f) return;
-        const vec3 la = to_local(frame, edge.a - beam.o), lb = to_local(frame, edge.b - beam.o);
-        const vec2 u1{la.x, la.y}, u2{lb.x, lb.y};
-        float t1 = 0.f, t2 = 1.f;
-        const vec2 q1 = u1 / cse, q2 = u2 / cse;
-        if (!(dot(q1, q1) <= 1.f) || !(dot(q2, q2) <= 1.f)) {
-            const edge_ellipse_t intr = intersect_edge_ellipse(u1, u2, cse.x, cse.y);
-            if (intr.points == 0) return;
-            t1 = fmaxf_(0.f, intr.t1);
-            t2 = fminf_(1.f, intr.t2);
-        }
-        const float len = length(mix2(u1, u2, t1) - mix2(u1, u2, t2));
-        // max(1, int(round(len/max_edge_length) + .5))
-        int segments = (int)(roundf(len / max_edge_length) + .5f);
-        if (segments < 1) segments = 1;
-        const float seg = 1.f / float(segments);
-        vec2 v1 = mix2(u1, u2, t1);
-        float a = sqrtf(wavefront_intensity(sigma, v1));
-        for (int i = 0; i < segments; ++i) {
-            const float tt = mixf(t1, t2, float(i + 1) * seg);
-            const vec2 v2 = mix2(u1, u2, tt);
-            const float b = sqrtf(wavefront_intensity(sigma, v2));
-            if (a > 0.f || b > 0.f) {
-                fsd_edge_t fe;
-                fe.v = ((v1 + v2) / 2.f) / kFsdUnitM;
-                fe.e = (v2 - v1) / kFsdUnitM;
-                fe.ab = a - b;
-                fe.iab = (a + b) / 2.f;
-                fe.pdf = fsd_Pj(fe);
-                if (fe.pdf > 0.f) {
-                    if (ap.n_edges < kFsdMaxEdges) {
-                        ed.set(ap.n_edges++, fe);
-                        st.P_total += fe.pdf;
-                    } else
-                        ap.overflow++;
-                }
-            }
-            v1 = v2;
-            a = b;
-        }
-    }
+    fsd_edge_segments(sc, frame, beam, sigma, st.cse, st.max_edge_length, edge_id, [&](const fsd_edge_t& fe) {
+        if (ap.n_edges < kFsdMaxEdges) {
+            ed.set(ap.n_edges++, fe);
+            st.P_total += fe.pdf;
+        } else
+            ap.overflow++;
+    });
 }
 WT_HD void fsd_build_finish(float k, fsd_build_state_t& st, fsd_aperture_t& ap, const fsd_edges_ref_t& ed);
 template <class EdgeIdList>
