@@ -172,6 +172,7 @@ uint32_t kat_scene_tris(const void* scene_host, float* out12) {
     return sc.n_tris;
 }
 int kat_material_ior_spec(const void* scene_host, int material) { return static_cast<const scene_t*>(scene_host)->materials[material].ior_spec; }
+int kat_material_refl_spec(const void* scene_host, int material) { return static_cast<const scene_t*>(scene_host)->materials[material].refl_spec; }
 
 // K1: UTD transition function and wedge diffraction coefficients (interaction/fsd/utd.hpp)
 void kat_utd_F(float x, float* out2) {
