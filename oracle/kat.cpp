@@ -236,4 +236,47 @@ uint32_t kat_scene_edges(const void* scene_host, uint32_t first, uint32_t n, flo
     return sc.n_edges;
 }
 
+// K10 (MIS weights sum to one) reduces to: every density a walk STORES when it samples equals the density the MIS code EVALUATES
+// for the same transition.  out: n x {sampled dpd (tagged), evaluated pdf, M00 * dpd, f00(wi, wo), wo.z}
+void kat_material_sample_consistency(const void* scene_host, int mat, const float* wi3, float k, uint32_t transport, uint64_t seed, uint32_t n, float* out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const vec3 wi{wi3[0], wi3[1], wi3[2]};
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 3);
+        const bsdf_sample_t bs = material_sample(sc, mat, wi, k, transport, s);
+        float* o = out + 5 * i;
+        o[0] = bs.valid ? bs.dpd : 0.f;
+        o[1] = bs.valid ? material_pdf(sc, mat, wi, bs.wo, k, transport) : 0.f;
+        o[2] = bs.valid ? bs.M.m[0] * bs.dpd : 0.f;
+        o[3] = bs.valid ? material_f(sc, mat, wi, bs.wo, k, transport).m[0] : 0.f;
+        o[4] = bs.wo.z;
+    }
+}
+// out: n x {sampled dpd, sensor_pdf_direction(dir), sampled ppd (tagged), sensor_pdf_position}
+void kat_sensor_sample_consistency(const void* scene_host, uint32_t px, uint32_t py, float k, uint64_t seed, uint32_t n, float* out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 4);
+        const sensor_sample_t ss = sensor_sample(sc, px, py, k, s);
+        float* o = out + 4 * i;
+        o[0] = ss.dpd;
+        o[1] = sensor_pdf_direction(sc, ss.beam.env.d);
+        o[2] = ss.ppd;
+        o[3] = sensor_pdf_position(sc);
+    }
+}
+// out: n x {sampled dpd (tagged), emitter_pdf_direction(dir), sampled ppd (tagged), emitter_pdf_position}
+void kat_emitter_sample_consistency(const void* scene_host, int ei, float k, uint64_t seed, uint32_t n, float* out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 5);
+        const emitter_sample_t es = emitter_sample(sc, ei, k, s);
+        float* o = out + 4 * i;
+        o[0] = es.dpd;
+        o[1] = emitter_pdf_direction(sc, ei, es.beam.env.d, es.has_surface ? &es.surface : nullptr);
+        o[2] = es.ppd;
+        o[3] = emitter_pdf_position(sc, ei);
+    }
+}
+
 }   // extern "C"
