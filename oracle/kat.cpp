@@ -279,4 +279,32 @@ void kat_emitter_sample_consistency(const void* scene_host, int ei, float k, uin
     }
 }
 
+// Fraunhofer aperture of ALL scene edges seen by a beam (cone6 = {o3, d3}, tan_alpha, x0) at distance `dist`: n samples,
+// out: n x {wo3 (aperture frame), sampled dpd, fsd_pdf(wo), weight}; returns the number of aperture segments
+uint32_t kat_fsd_sample_consistency(const void* scene_host, const float* cone6, float tan_alpha, float x0, float dist, float k, uint64_t seed, uint32_t n,
+                                    float* out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const vec3 d = normalize(vec3{cone6[3], cone6[4], cone6[5]});
+    const cone_t env = make_cone_iso(vec3{cone6[0], cone6[1], cone6[2]}, d, tan_alpha, x0);
+    const frame_t fr = cone_frame(env);
+    const vec2 ax = cone_axes(env, dist);
+    const vec2 sigma{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope};
+    static fsd_edge_t edges[kFsdMaxEdges];
+    static uint32_t ids[4096];
+    const uint32_t n_ids = sc.n_edges < 4096 ? sc.n_edges : 4096;
+    for (uint32_t i = 0; i < n_ids; ++i) ids[i] = i;
+    fsd_aperture_t ap;
+    const fsd_edges_ref_t ed{edges, 1};
+    cone_t beam = env;
+    beam.o = env.o + dist * d;   // the aperture is built in the frame at the interaction point (bdpt_walk_step passes the beam itself)
+    fsd_build_aperture(sc, fr, k, 1.f, env, ids, n_ids, sigma, ap, ed);
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 6);
+        const fsd_sample_t fs = fsd_sample(sc, ap, ed, s);
+        float* o = out + 6 * i;
+        o[0] = fs.wo.x; o[1] = fs.wo.y; o[2] = fs.wo.z; o[3] = fs.dpd; o[4] = fs.dpd > 0.f ? fsd_pdf(ap, ed, fs.wo) : 0.f; o[5] = fs.weight;
+    }
+    return ap.n_edges;
+}
+
 }   // extern "C"
