@@ -265,6 +265,18 @@ void kat_sensor_sample_consistency(const void* scene_host, uint32_t px, uint32_t
         o[3] = sensor_pdf_position(sc);
     }
 }
+// emitted flux estimate: mean over n emitter samples of the sourced beam's intensity (= flux / spectral unit); also returns the
+// emitter's spectral value at k through *value
+double kat_emitter_mean_flux(const void* scene_host, int ei, float k, uint64_t seed, uint32_t n, float* value) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    double acc = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 8);
+        acc += (double)beam_intensity(emitter_sample(sc, ei, k, s).beam);
+    }
+    if (value) *value = emitter_spectral_value(sc, sc.emitters[ei], k);
+    return acc / n;
+}
 // out: n x {sampled dpd (tagged), emitter_pdf_direction(dir), sampled ppd (tagged), emitter_pdf_position}
 void kat_emitter_sample_consistency(const void* scene_host, int ei, float k, uint64_t seed, uint32_t n, float* out) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);

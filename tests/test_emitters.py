@@ -71,3 +71,41 @@ def test_directional_emitter_gpu_parity(built, name, spp, kw):
     assert _rel_l1(gpu, cpu) < 1e-2, _rel_l1(gpu, cpu)
     for key in ("segments", "connections", "surface_interactions"):
         assert abs(gc[key] - oc[key]) <= 5e-3 * max(100, oc[key]), (key, gc[key], oc[key])
+
+
+def test_emitted_flux_of_every_emitter_type(built):
+    """E[intensity of a sourced beam] = the emitter's flux: spot: I x integral of the falloff over the cone (linear in the angle between
+    beam_width and cutoff, spot.hpp:65-70); area: radiance x pi x area; point: I x 4 pi; directional: irradiance x target area."""
+    import ctypes as C
+    import math
+    from scipy import integrate
+    from oracle_util import load_oracle
+    from wave_tracer_amd import Scene
+    lib = load_oracle()
+    lib.kat_emitter_mean_flux.restype = C.c_double
+    lib.kat_emitter_mean_flux.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    k = 2 * math.pi / 5.5e-4
+    n = 200000
+
+    def flux(sc, ei, kk=k):
+        v = C.c_float()
+        return lib.kat_emitter_mean_flux(C.c_void_p(sc.host_desc()), ei, C.c_float(kk), 3, n, C.byref(v)), v.value
+
+    # cornell stand-in: emitter 0 = area (cube source 3.1 x .04 x 3.1 of a .2 cm cube), 1 = spot 1/3 deg, 2 = spot 1/55 deg
+    sc = Scene("cornell_box", res=16, mesh_detail=0, lut=(32, 32))
+    f, v = flux(sc, 0)
+    sx, sy = .2e-2 * 3.1, .2e-2 * .04
+    area = 2 * (sx * sx + 2 * sx * sy)
+    assert abs(f / (v * math.pi * area) - 1) < 0.01
+    for ei, (falloff, cutoff) in ((1, (1.0, 3.0)), (2, (1.0, 55.0))):
+        f, v = flux(sc, ei)
+        a, b = math.radians(falloff), math.radians(cutoff)
+        solid = 2 * math.pi * (1 - math.cos(a)) + integrate.quad(lambda t: 2 * math.pi * math.sin(t) * (b - t) / (b - a), a, b)[0]
+        assert abs(f / (v * solid) - 1) < 0.01, (ei, f, v * solid)
+    et = Scene("etoile", res=16, mesh_detail=0)
+    f, v = flux(et, 0, 2 * math.pi / 29.9792458)
+    assert abs(f / (v * 4 * math.pi) - 1) < 1e-5
+    sun = Scene("sunlit", res=8)
+    f, v = flux(sun, 0)
+    r2 = (2 * math.cos(math.radians(30)) + .2 * math.sin(math.radians(30))) ** 2 + 2 ** 2     # farthest AABB corner from the axis
+    assert abs(f / (v * math.pi * r2) - 1) < 1e-4
