@@ -127,3 +127,28 @@ def test_fraunhofer_fsd_sampled_density_vs_evaluated_density(lib):
     assert low.sum() > 100 and high.sum() > 100
     assert np.allclose(o[low, 3], o[low, 4], rtol=2e-3)
     assert (o[high, 4] == 0).all()
+
+
+def test_dielectric_and_conductor_energy_balance(lib):
+    """E[sample weight] over the lobe choice: a lossless dielectric interface conserves energy in forward transport (R + T = 1,
+    dielectric.cpp:26-72; backward transport carries the eta^2 radiance scaling on transmission), a smooth conductor reflects
+    less than one, a Lambertian reflects its albedo."""
+    from wave_tracer_amd import Scene
+    sc = Scene("cornell_box", res=16, mesh_detail=0, lut=(32, 32))
+    h = C.c_void_p(sc.host_desc())
+    n = 20000
+    for th in (0.1, 0.7, 1.2):
+        for up in (1.0, -1.0):
+            wi = fa([math.sin(th), 0, up * math.cos(th)])
+            o = np.zeros((n, 5), np.float32)
+            lib.kat_material_sample_consistency(h, 4, p(wi), F(K), 0, 5, n, p(o))       # SF5 dielectric, forward transport
+            w = np.where(o[:, 0] != 0, o[:, 2] / np.where(o[:, 0] != 0, o[:, 0], 1), 0)
+            assert abs(w.mean() - 1) < 0.02, (th, up, w.mean())
+            if up > 0:
+                lib.kat_material_sample_consistency(h, 3, p(wi), F(K), 0, 5, n, p(o))   # gold, Dirac profile, lit from outside
+                w = np.where(o[:, 0] != 0, o[:, 2] / np.where(o[:, 0] != 0, o[:, 0], 1), 0)
+                assert 0.3 < w.mean() < 1.0
+    wi = fa([.3, .2, math.sqrt(1 - .13)])
+    o = np.zeros((n, 5), np.float32)
+    lib.kat_material_sample_consistency(h, 1, p(wi), F(K), 0, 5, n, p(o))               # right wall: diffuse .6
+    assert abs((o[:, 2] / o[:, 0]).mean() - .6) < 1e-3
