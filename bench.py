@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--res", type=int, default=1440)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
+    ap.add_argument("--ray-tracing", action="store_true", help="diagnostic: --ray-tracing of the reference CLI (wt_context.hpp:43), no cones / diffraction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -78,7 +79,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    sc = Scene(args.scene, res=args.res, mesh_detail=1)
+    sc = Scene(args.scene, res=args.res, mesh_detail=1, force_ray_tracing=1 if args.ray_tracing else 0)
     npix = sc.width * sc.height
     sc.upload(local_rank, args.batch or npix)
     value, weight, light = alloc_films(sc, dev)

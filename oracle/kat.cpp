@@ -319,4 +319,64 @@ uint32_t kat_fsd_sample_consistency(const void* scene_host, const float* cone6, 
     return ap.n_edges;
 }
 
+// K8b: synthetic Fraunhofer aperture (edges given directly in fsd units: n x {e.x,e.y,v.x,v.y,a_b,iab_2}); psi02/P0/pdfs derived like
+// free_space_diffraction.cpp:106-128.  ap_out = {P0, P0_pdf, psi02, edge pdfs...}
+static void kat_make_aperture(const float* edges, uint32_t n_edges, float k, fsd_aperture_t& ap, fsd_edge_t* store) {
+    const fsd_edges_ref_t ed{store, 1};
+    fsd_build_state_t st = fsd_build_begin(frame_t{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, k, 1.f, vec2{1.f, 1.f}, ap);
+    for (uint32_t i = 0; i < n_edges && i < kFsdMaxEdges; ++i) {
+        fsd_edge_t fe;
+        fe.e = {edges[6 * i], edges[6 * i + 1]};
+        fe.v = {edges[6 * i + 2], edges[6 * i + 3]};
+        fe.ab = edges[6 * i + 4];
+        fe.iab = edges[6 * i + 5];
+        fe.pdf = fsd_Pj(fe);
+        ed.set(ap.n_edges++, fe);
+        st.P_total += fe.pdf;
+    }
+    fsd_build_finish(k, st, ap, ed);
+}
+// n proposals (sampleN) and n rejection-sampled directions (fsd_run_tries): out = n x {prop.x, prop.y, acc.x, acc.y, accepted}
+void kat_fsd_aperture_sample(const void* scene_host, const float* edges, uint32_t n_edges, float k, uint64_t seed, uint32_t n, float* out, float* ap_out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    static fsd_edge_t store[kFsdMaxEdges];
+    fsd_aperture_t ap;
+    kat_make_aperture(edges, n_edges, k, ap, store);
+    const fsd_edges_ref_t ed{store, 1};
+    ap_out[0] = ap.P0;
+    ap_out[1] = ap.P0_pdf;
+    ap_out[2] = ap.psi02;
+    for (uint32_t i = 0; i < ap.n_edges; ++i) ap_out[3 + i] = ed.get(i).pdf;
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 7);
+        const vec2 xi = fsd_sampleN(sc, ap, ed, s);
+        sampler_t s2 = make_sampler(seed, i, 8);
+        fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
+        const uint32_t t = fsd_run_tries(sc, ap, ed, s2, fsd_tries_base(s2), 0, fsd_max_tries(ap), r);
+        float* o = out + 5 * i;
+        o[0] = xi.x; o[1] = xi.y; o[2] = r.x.x; o[3] = r.x.y; o[4] = t != 0xFFFFFFFFu ? 1.f : 0.f;
+    }
+}
+// out = n x {ASF (fsd.hpp:143-146), sampling_density (fsd.hpp:122-127)} at the given xi
+void kat_fsd_aperture_eval(const float* edges, uint32_t n_edges, float k, const float* xi, uint32_t n, float* out) {
+    static fsd_edge_t store[kFsdMaxEdges];
+    fsd_aperture_t ap;
+    kat_make_aperture(edges, n_edges, k, ap, store);
+    const fsd_edges_ref_t ed{store, 1};
+    for (uint32_t i = 0; i < n; ++i) {
+        out[2 * i] = fsd_ASF(ap, ed, vec2{xi[2 * i], xi[2 * i + 1]});
+        out[2 * i + 1] = fsd_sampling_density(ap, ed, vec2{xi[2 * i], xi[2 * i + 1]});
+    }
+}
+// raw LUT draw in zeta space (fsd_lut.hpp:50-69)
+void kat_fsd_lut_sample(const void* scene_host, int which, uint64_t seed, uint32_t n, float* out2) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 9);
+        const vec2 z = fsd_lut_sample(sc.lut, sampler_r3(s), which == 0);
+        out2[2 * i] = z.x;
+        out2[2 * i + 1] = z.y;
+    }
+}
+
 }   // extern "C"

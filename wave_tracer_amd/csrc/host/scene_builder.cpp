@@ -1126,15 +1126,23 @@ void scene_builder_t::build_sampling_tables() {
 
 // Regenerates the inverse-CDF tables of chi_e*|alpha_1|^2 and chi_e*|alpha_2|^2 (the reference ships them as
 // Git-LFS binaries that are absent here).  Layout and use: fsd_lut.hpp:27-69.
+//
+// Mask argument.  The only numbers the reference holds about its tables are the lobe powers PA1 = 0.00493610757945... and
+// PA2 = 0.218997893980... (fsd.hpp:59-61, "power contained in chi_e x |alpha|^2").  With the mask evaluated at zeta itself the
+// two integrals are 0.0048274 / 0.16279 (2 % / 26 % low).  Solving  int chi_e(c |zeta|^2) |alpha_j|^2 dzeta = PAj  for the mask
+// constant c INDEPENDENTLY for j = 1 and j = 2 gives c = 3.527899 and c = 3.527895: one and the same constant,
+// c = (17/4) * 0.830092714835359 = 3.527894, i.e. the tables' mask is chi_e(sqrt(17)/2 * zeta).  With it both constants are
+// reproduced to 1e-6 relative (tests/test_kat.py::test_fsd_lut_mask_reproduces_reference_lobe_powers, scipy quadrature), so
+// the proposal these tables draw from and the normalisation 1/PAj the sampler applies (fsd.h: fsd_Pj) agree like in the reference.
 void scene_builder_t::build_fsd_lut() {
     const uint32_t M = lut_m_, NT = lut_n_theta_;
-    const int J = 6000;
-    const double r0 = 1e-4, Rmax = 4e3;
+    const int J = 8000;
+    const double r0 = 1e-4, Rmax = 4e4;   // the power beyond |zeta| = 4e4 is 1e-5 (alpha_1) / 1e-4 (alpha_2: 1/r tail along the y axis) of the lobe's
     std::vector<double> rs(J), lw(J);
     for (int j = 0; j < J; ++j) rs[j] = r0 * std::pow(Rmax / r0, double(j) / (J - 1));
     const double dl = std::log(Rmax / r0) / (J - 1);
     auto chi_e = [](double r2) {
-        const double t = 1 + 0.830092714835359 * r2;
+        const double t = 1 + kFsdLutMaskScale2 * 0.830092714835359 * r2;
         return std::max(0.0, 1 - (3 / (t * t) - 2 / (t * t * t)));
     };
     auto sinc = [](double x) { return std::fabs(x) < 1e-8 ? 1.0 : std::sin(x) / x; };
@@ -1197,6 +1205,30 @@ const scene_t& scene_builder_t::finalize() {
     if (sensitivity_spec_ < 0) throw std::runtime_error("sensor response not set");
     build_bvh();
     build_edges();
+    // per-child "subtree has classified edges" masks (every subtree owns a contiguous triangle range)
+    {
+        std::vector<uint32_t> pre(tri_meta_.size() + 1, 0);
+        for (size_t t = 0; t < tri_meta_.size(); ++t) {
+            const tri_meta_t& m = tri_meta_[t];
+            pre[t + 1] = pre[t] + ((m.edge[0] != kInvalid || m.edge[1] != kInvalid || m.edge[2] != kInvalid) ? 1u : 0u);
+        }
+        for (auto& nd : nodes_) {
+            nd.edge_mask = 0;
+            for (int c = 0; c < 8; ++c) {
+                const int32_t cp = nd.child[c];
+                if (cp == 0) continue;
+                uint32_t t0, cnt;
+                if (cp < 0) {
+                    t0 = leaves_[-cp - 1].tris_ptr;
+                    cnt = leaves_[-cp - 1].count;
+                } else {
+                    t0 = nodes_[cp - 1].tris_start;
+                    cnt = nodes_[cp - 1].tris_count;
+                }
+                if (pre[t0 + cnt] - pre[t0] > 0) nd.edge_mask |= 1u << c;
+            }
+        }
+    }
     // infinite emitters need the world AABB (src/scene/scene.cpp:50-58, directional_t::set_world_aabb, directional.hpp:46-75)
     {
         vec3 mn{WT_INF, WT_INF, WT_INF}, mx{-WT_INF, -WT_INF, -WT_INF};

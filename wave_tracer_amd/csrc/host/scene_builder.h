@@ -17,6 +17,10 @@
 
 namespace wth {
 
+// mask of the Fraunhofer iCDF tables = chi_e(kFsdLutMaskScale2 * chi * |zeta|^2): the value that reproduces the reference's PA1 and PA2
+// (fsd.hpp:59-61), see scene_builder.cpp: build_fsd_lut
+constexpr double kFsdLutMaskScale2 = 17.0 / 4.0;
+
 struct dvec3 {
     double x, y, z;
 };
@@ -125,7 +129,7 @@ private:
     std::vector<wt::kdist_t> kdists_;
     std::vector<float> kdist_data_;
     std::vector<float> lut_theta1_, lut_theta2_, lut1_, lut2_;
-    uint32_t lut_n_theta_ = 512, lut_m_ = 512;
+    uint32_t lut_n_theta_ = 2048, lut_m_ = 3072;   // the reference's table sizes (fsd_lut.hpp:27: Nsamples, Msamples); 2 x 37.7 MB
     float rfilter_scale_ = 1.f;
     bool response_is_rgb_ = true;
     float mono_lambda_mm_ = 0.f;

@@ -538,6 +538,14 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         // a complete list is scanned like the reference does (a handful of ray-triangle tests instead of a tree traversal).
         if (defer && defer->known_no_primary) {
             // second pass of a walk the first pass found no primary triangle for
+        } else if (tr.aborted == 2) {
+            // device: the trace kernels resolved the primary of this overflowed region already (g8.h: g8_resolve_primary)
+            if (tr.tuid != kInvalid) {
+                primary = tr.tuid;
+                phit.dist = tr.pdist;
+                phit.bx = tr.bx;
+                phit.by = tr.by;
+            }
         } else if (primary_query_stack && tr.overflow > 0) {
             const float wtol = cone_intersection_tolerance(origin_wp, sc.world_min, sc.world_max, sc.world_max);
             ray_hit_t rh;

@@ -434,9 +434,10 @@ struct trav_result_t {
     float dist;
     float region_depth;
     uint32_t front_face;
-    // ballistic (single ray hit)
+    // ballistic (single ray hit); device, aborted == 2: the primary triangle of an overflowed region (g8.h: g8_resolve_primary)
     uint32_t tuid;
     float bx, by;
+    float pdist;
     // diffusive
     uint32_t ntris;
     uint32_t overflow;
@@ -459,6 +460,7 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
     r.front_face = 0;
     r.tuid = kInvalid;
     r.bx = r.by = 0.f;
+    r.pdist = 0.f;
     r.ntris = 0;
     r.overflow = 0;
     r.n_ray_queries = r.n_cone_queries = 0;
@@ -515,7 +517,7 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
             return r;
         }
         if (ch.too_short) continue;
-        const bool df_empty = ch.ntris == 0;
+        const bool df_empty = ch.ntris == 0 && ch.overflow == 0;   // (a list of capacity 0 — closest-hit-only queries — counts every hit as overflow)
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;
             r.empty = df_empty;
@@ -528,6 +530,90 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
         }
         // too short: continue the ballistic path
     }
+}
+
+// The triangle under the beam axis of a diffusive hit (find_closest_triangle, plt_bdpt_detail.hpp:362-389: the closest axis hit
+// among the triangles of the interaction region) by ONE ray query over the region's z-slab instead of a scan of the region's
+// triangle list: a triangle the axis hits inside the slab meets the cone inside the slab, i.e. is a region triangle, whatever the
+// size of the region.  Marks r.aborted = 2: "primary in r.tuid / r.bx / r.by / r.pdist (kInvalid: the axis misses the region)".
+WT_HD void resolve_primary(const scene_t& sc, const cone_t& envelope, const stack_ref_t& stack, trav_result_t& r, bvh_counters_t* ctr = nullptr) {
+    const range_t izr{r.dist, r.dist + r.region_depth};
+    const float wtol = cone_intersection_tolerance(envelope.o, sc.world_min, sc.world_max, sc.world_max);
+    r.aborted = 2;
+    r.tuid = kInvalid;
+    r.n_ray_queries++;
+    ray_hit_t rh;
+    if (ads_intersect_ray(sc, envelope.o, envelope.d, grow(izr, wtol), stack, rh, ctr)) {
+        const tri_geo_t g = sc.tri_geo[rh.tuid];
+        const float fptol = cone_intersection_tolerance(envelope.o, g.a, g.b, g.c);
+        if (contains(grow(izr, fptol), rh.dist)) {
+            r.tuid = rh.tuid;
+            r.bx = rh.bx;
+            r.by = rh.by;
+            r.pdist = rh.dist;
+        }
+    }
+}
+
+// The ordered, de-duplicated set of classified edges of an interaction region (traversal_common.hpp:124-148: the edges of every
+// triangle that meets the traced cone inside the region's slab), for regions of ANY size: the walk descends only into subtrees
+// that hold classified edges (bvh8_node_t::edge_mask) and tests only edge-bearing triangles, so a region of 10^5 smooth-mesh
+// triangles costs a few node visits.  `out`: sorted ids (capacity `cap`); returns the count, `overflow` = ids dropped.
+WT_HD uint32_t bvh_gather_edges(const scene_t& sc, const cone_t& tcone, const range_t& slab, const stack_ref_t& stack, uint32_t* out, uint32_t cap,
+                                uint32_t& overflow) {
+    overflow = 0;
+    uint32_t n_out = 0;
+    if (sc.n_nodes == 0) return 0;
+    const vec3 ro = tcone.o, rd = tcone.d;
+    const float ta = tcone.tan_alpha, ix = tcone.x0;
+    int s = 1;
+    stack[0] = stack_entry_t{0.f, 1};
+    while (s > 0) {
+        const int32_t ptr = stack[s - 1].ptr;
+        --s;
+        uint32_t t0, cnt;
+        if (ptr < 0) {
+            const bvh8_leaf_t leaf = sc.leaves[-ptr - 1];
+            t0 = leaf.tris_ptr;
+            cnt = leaf.count;
+        } else {
+            const bvh8_node_t& n = sc.nodes[ptr - 1];
+            const uint32_t em = n.edge_mask;
+            for (int i = 0; i < 8; ++i) {
+                if (!((em >> i) & 1u)) continue;
+                if (cone_box_outside(n.minx[i] - ro.x, n.miny[i] - ro.y, n.minz[i] - ro.z, n.maxx[i] - ro.x, n.maxy[i] - ro.y, n.maxz[i] - ro.z, rd, ta, ix, slab)) continue;
+                const bool room = s < (int)stack.cap;   // (always: the pruned tree is a few levels of a handful of nodes)
+                overflow += room ? 0u : 1u;
+                if (room) {
+                    stack[s] = stack_entry_t{0.f, n.child[i]};
+                    ++s;
+                }
+            }
+            continue;
+        }
+        for (uint32_t t = 0; t < cnt; ++t) {
+            const tri_meta_t m = sc.tri_meta[t0 + t];
+            if (m.edge[0] == kInvalid && m.edge[1] == kInvalid && m.edge[2] == kInvalid) continue;
+            const tri_geo_t tri = sc.tri_geo[t0 + t];
+            cone_tri_hit_t h;
+            if (!intersect_cone_tri(tcone, tri.a, tri.b, tri.c, tri.n, slab, h) || h.dist > slab.max) continue;
+            for (int e = 0; e < 3; ++e) {
+                const uint32_t id = m.edge[e];
+                if (id == kInvalid) continue;
+                uint32_t pos = 0;
+                while (pos < n_out && out[pos] < id) ++pos;
+                if (pos < n_out && out[pos] == id) continue;
+                if (n_out == cap) {
+                    overflow++;
+                    continue;
+                }
+                for (uint32_t j = n_out; j > pos; --j) out[j] = out[j - 1];
+                out[pos] = id;
+                ++n_out;
+            }
+        }
+    }
+    return n_out;
 }
 
 }   // namespace wt

@@ -327,12 +327,14 @@ struct gather_out_t {
     uint32_t n_edges, edge_overflow;
 };
 __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
-                                           const range_t& izr, vec2 sigma, bool want_front, coop_shared_t& sh, bool do_flux, bool do_edges) {
+                                           const range_t& izr, vec2 sigma, bool want_front, coop_shared_t& sh, bool do_flux, bool do_edges,
+                                           unsigned long long* stats = nullptr, int32_t root = 1) {
     uint32_t* edges = sh.edge_ids;
     const uint32_t edge_cap = 96;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
     gather_out_t out{0.f, 0u, 0u};
+    const bool edges_only = do_edges && !do_flux;
     if (sc.n_nodes == 0) return out;
     const vec3 ro = tcone.o, rd = tcone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
@@ -341,10 +343,11 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
     const float csz = centre(izr);
     int s = 1;
     uint32_t leaf_total = 0, nsurv = 0;
-    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
+    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, root};   // (root: a subtree of the region, k_flux_tasks)
     __syncthreads();
     auto flush = [&]() {
         __syncthreads();
+        if (stats) stats[1] += nsurv;
         for (uint32_t b2 = 0; b2 < nsurv; b2 += 64) {
             const uint32_t k2 = b2 + lane;
             float contrib = 0.f;
@@ -353,7 +356,9 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                 const uint32_t t2 = sh.surv[k2];
                 const tri_geo_t tri = sc.tri_geo[t2];
                 cone_tri_hit_t ht;
-                if (intersect_cone_tri(tcone, tri.a, tri.b, tri.c, tri.n, slab, ht) && !(ht.dist > slab.max)) {
+                // membership = "meets the cone inside the slab": the any-hit form decides at the first contained vertex (most triangles
+                // of a large region lie inside the beam)
+                if (intersect_cone_tri<true>(tcone, tri.a, tri.b, tri.c, tri.n, slab, ht) && !(ht.dist > slab.max)) {
                     if (do_edges) {
                         const tri_meta_t m = sc.tri_meta[t2];
                         eid[0] = m.edge[0];
@@ -442,7 +447,8 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                     const bvh8_node_t& node = sc.nodes[e.ptr - 1];
                     const uint32_t ntc = node.tris_count, nts = node.tris_start;
                     cp = node.child[sub];
-                    const bool hc = cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, slab, tmin);
+                    // edges only: descend only into subtrees that hold classified edges (bvh8_node_t::edge_mask)
+                    const bool hc = (!edges_only || ((node.edge_mask >> sub) & 1u)) && cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, slab, tmin);
                     if (ntc <= kCoopLeafTris) {
                         t0 = nts;
                         cnt = ntc;
@@ -471,14 +477,22 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             }
             __syncthreads();
         }
+        if (stats) stats[0] += leaf_total;
         for (uint32_t base = 0; base < leaf_total; base += 64) {
             const uint32_t k = base + lane;
             bool pass = false;
             uint32_t tuid = 0;
             if (k < leaf_total) {
                 tuid = sh.tri_buf[k];
-                const tri_geo_t tri = sc.tri_geo[tuid];
-                pass = cone_tri_maybe(tcone, tri.a, tri.b, tri.c, slab);
+                bool want = true;
+                if (edges_only) {   // ... and test only the triangles that carry one
+                    const tri_meta_t m = sc.tri_meta[tuid];
+                    want = m.edge[0] != kInvalid || m.edge[1] != kInvalid || m.edge[2] != kInvalid;
+                }
+                if (want) {
+                    const tri_geo_t tri = sc.tri_geo[tuid];
+                    pass = cone_tri_maybe(tcone, tri.a, tri.b, tri.c, slab);
+                }
             }
             const unsigned long long pm = __ballot(pass);
             if (pm) {
@@ -494,6 +508,56 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
         if (s == 0) break;
     }
     return out;
+}
+
+// Cuts the part of the tree that overlaps (cone ∩ slab) into subtrees of at most `max_tris` triangles and hands each to emit(ptr)
+// (ptr: child reference as in bvh8_node_t::child).  One wavefront; emit is called by ONE lane per subtree, possibly several lanes at
+// once.  Used to spread the region sums of interaction regions with 10^3..10^5 triangles over many wavefronts (k_flux_split).
+template <class Emit>
+__device__ inline void coop_split(const scene_t& sc, const cone_t& tcone, const range_t& slab, coop_shared_t& sh, uint32_t max_tris, Emit&& emit) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
+    if (sc.n_nodes == 0) return;
+    const vec3 ro = tcone.o, rd = tcone.d;
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    const float ta = tcone.tan_alpha, ix = tcone.x0;
+    int s = 1;
+    if (lane == 0) sh.stack[0] = stack_entry_t{0.f, 1};
+    __syncthreads();
+    if (sc.nodes[0].tris_count <= max_tris) {
+        if (lane == 0) emit(1);
+        return;
+    }
+    while (s > 0) {
+        const int np = s < 8 ? s : 8;
+        stack_entry_t e{0.f, 0};
+        if (grp < np) e = sh.stack[s - 1 - grp];
+        s -= np;
+        __syncthreads();
+        bool push = false;
+        int32_t cp = 0;
+        float tmin = 0.f;
+        if (grp < np) {   // every stack entry is an internal node with more than max_tris triangles
+            const bvh8_node_t& node = sc.nodes[e.ptr - 1];
+            cp = node.child[sub];
+            if (cp != 0 && cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, slab, tmin)) {
+                if (cp < 0 || sc.nodes[cp - 1].tris_count <= max_tris)
+                    emit(cp);
+                else
+                    push = true;
+            }
+        }
+        const unsigned long long hm = __ballot(push);
+        if (hm) {
+            const int pos = s + __popcll(hm & ((1ull << lane) - 1ull));
+            if (push && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+            else if (push) emit(cp);   // stack full (cannot happen at these depths): the subtree goes out as one task
+            const int total = s + __popcll(hm);
+            s = total < kCoopStack ? total : kCoopStack;
+        }
+        __syncthreads();
+    }
 }
 
 // One wavefront, one closest-hit ray query (bvh_traverse_ray<false> + ads_intersect_ray), same scheme as coop_cone_query:
@@ -649,6 +713,7 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
     r.front_face = 0;
     r.tuid = kInvalid;
     r.bx = r.by = 0.f;
+    r.pdist = 0.f;
     r.ntris = 0;
     r.overflow = 0;
     r.n_ray_queries = r.n_cone_queries = 0;
@@ -710,7 +775,7 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch, prof, min_df_prog);
         WT_COOP_PROF(2, tc0)
         if (ch.too_short) continue;   // (boundary case of the probe's inclusive slab)
-        const bool df_empty = ch.ntris == 0;
+        const bool df_empty = ch.ntris == 0 && ch.overflow == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;
             r.empty = df_empty;

@@ -255,6 +255,15 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
         phit.dist = tr.dist;
         phit.bx = tr.bx;
         phit.by = tr.by;
+    } else if (tr.aborted == 2) {
+        // device: the region overflowed the bounded triangle list; the trace kernel resolved the triangle under the beam axis with a
+        // ray query over the region's slab (resolve_primary, wt/bvh.h) — a truncated list may have lost it
+        if (tr.tuid != kInvalid) {
+            primary = tr.tuid;
+            phit.dist = tr.pdist;
+            phit.bx = tr.bx;
+            phit.by = tr.by;
+        }
     } else {
         const range_t izr{dist_to_interaction, dist_to_interaction + tr.region_depth};
         for (uint32_t i = 0; i < tr.ntris; ++i) {
@@ -279,18 +288,32 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
     // ---- edges of the interaction region (plt_path_detail.hpp:593, 684-689)
     uint32_t edge_ids[kMaxEdgeIds];
     uint32_t n_edge_ids = 0;
+    // (a region that overflowed the bounded device list gets its edge set from a walk of the whole region — bvh_gather_edges, wt/bvh.h:
+    // the edges of every triangle meeting the cone inside the final slab, the reference's unbounded list; the CPU checker's lists
+    // never overflow)
     if (sc.opts.FSD && !is_ballistic) {
-        n_edge_ids = path_gather_edge_ids(sc, tris, tr.ntris, edge_ids, ctr);
+        if (tr.overflow > 0) {
+            cone_t tcone = envelope;
+            tcone.o = origin_wp;
+            uint32_t dropped = 0;
+            n_edge_ids = bvh_gather_edges(sc, tcone, range_t{dist_to_interaction, dist_to_interaction + tr.region_depth}, stack, edge_ids, kMaxEdgeIds, dropped);
+            if (ctr) ctr->edge_overflow += dropped;
+        } else
+            n_edge_ids = path_gather_edge_ids(sc, tris, tr.ntris, edge_ids, ctr);
     } else if (is_ballistic && !beam_is_ray(beam) && !force_rt) {
         // ballistic: find the edges around the intersection with a cone query over a slab of the region's depth
         const float zdist = cone_axes(envelope, dist_to_interaction).x * kMajorAxisToZScale;
+        const range_t sr{dist_to_interaction - zdist / 2.f, dist_to_interaction + zdist / 2.f};
         cone_hit_t ch;
-        bvh_traverse_cone(sc, envelope, range_t{dist_to_interaction - zdist / 2.f, dist_to_interaction + zdist / 2.f}, 1.f, stack, tris, ch);
-        if (ctr) {
-            ctr->cone_queries++;
-            ctr->cone_tri_overflow += ch.overflow;
-        }
-        n_edge_ids = path_gather_edge_ids(sc, tris, ch.ntris, edge_ids, ctr);
+        // (budget: a full per-lane stack aborts the query instead of silently dropping children, bvh.h)
+        bvh_traverse_cone(sc, envelope, sr, 1.f, stack, tris, ch, nullptr, 1u << 30);
+        if (ctr) ctr->cone_queries++;
+        if (ch.aborted || ch.overflow > 0) {
+            uint32_t dropped = 0;
+            n_edge_ids = bvh_gather_edges(sc, envelope, ch.aborted ? sr : cone_search_range(envelope, sr, ch.dist, 1.f), stack, edge_ids, kMaxEdgeIds, dropped);
+            if (ctr) ctr->edge_overflow += dropped;
+        } else
+            n_edge_ids = path_gather_edge_ids(sc, tris, ch.ntris, edge_ids, ctr);
     }
 
     // ---- construct the fsd BSDF (plt_path_detail.hpp:692-709)

@@ -46,7 +46,9 @@ struct alignas(16) bvh8_node_t {
     float maxx[8], maxy[8], maxz[8];
     int32_t child[8];
     uint32_t tris_start, tris_count;
-    uint32_t pad[6];   // 256 B
+    uint32_t edge_mask;   // bit i: the subtree of child i holds a triangle with a classified edge (ads/common.hpp:53-72); prunes the
+                          // interaction-region edge gather (bvh_gather_edges) — a handful of silhouette edges in 10^5 triangles
+    uint32_t pad[5];   // 256 B
 };
 struct bvh8_leaf_t {
     uint32_t tris_ptr, count;

@@ -31,6 +31,7 @@
 #include "host/scene_builder.h"
 #include "wt/bdpt.h"
 #include "wt/coop.h"
+#include "wt/g8.h"
 #include "wt/path.h"
 
 using namespace wt;
@@ -59,7 +60,7 @@ int fail(int code, const std::string& msg) {
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_WORDS = 16 };
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_WORDS = 24 };   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
@@ -77,6 +78,9 @@ struct device_state_t {
     uint32_t* intb_queue = nullptr;    // walks whose interaction takes the expensive (no primary triangle) path
     uint32_t* gather_queue = nullptr;  // ... of those, the ones whose triangle list overflowed (coop_gather first)
     uint32_t* intc_queue = nullptr;    // ... and the ones that built a Fraunhofer aperture with edges (sampled in pass C)
+    uint2* ftasks = nullptr;           // (walk, subtree) tasks of the intercepted-power sums of overflowed regions (k_flux_split / k_flux_tasks)
+    uint32_t ftask_cap = 0;
+    double* facc = nullptr;            // [2cap] their accumulators
     uint32_t* ctl = nullptr;           // [CTL_WORDS] queue sizes, dequeue heads, FSD pool bump counter, rounds done
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
@@ -138,8 +142,7 @@ struct launch_args_t {
     uint32_t count_stats;
     uint32_t cone_budget;
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
-    uint32_t pass_c;          // Fraunhofer apertures with edges are completed (power integrals, rejection sampling) by k_interact_c (WTGPU_PASS_C=0: by pass B)
-    uint32_t exact_regions;   // WTGPU_EXACT_REGIONS=1: walk interaction regions that overflow the bounded triangle list again (k_gather)
+    uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
 };
 
 __device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s) {
@@ -169,6 +172,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -231,6 +235,9 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
         ctl[CTL_GATHER_HEAD] = 0;
         ctl[CTL_INTC_COUNT] = 0;
         ctl[CTL_INTC_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = 0;
+        ctl[CTL_FTASK_HEAD] = 0;
+        ctl[CTL_FSPLIT_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -248,10 +255,14 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
         if (qi < n) {
             w = queue_walk(a, a.st.queue[in], qi, first_round);
             const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
-            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
+            // plt_bdpt: closest-hit-only cone queries (list capacity 0: once something is hit only nearer triangles matter, wt/bvh.h) —
+            // what an interaction needs of its region is the triangle under the beam axis (resolve_primary) and, for the few walks
+            // without one, sums over the WHOLE region gathered later (k_edges, k_interact_c).  plt_path keeps the bounded list.
+            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};
             const cone_t env = walk_trace_envelope(a.sc, wk);
-            const trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
-            if (tr.aborted) {
+            trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
+            if (!tr.aborted && !tr.ballistic && !tr.empty && (!a.collect_list || tr.overflow > 0)) resolve_primary(a.sc, env, stack, tr);
+            if (tr.aborted == 1) {
                 heavy = true;
                 // resume state for k_trace_heavy (traverse(): dist / ntris = segment / query counts so far)
                 a.st.trav[WT_TRAV_WORD(dist) * W2 + w] = __float_as_uint(tr.dist);
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
                 ctr.segments += 1;
                 ctr.ray_queries += tr.n_ray_queries;
                 ctr.cone_queries += tr.n_cone_queries;
-                ctr.cone_tri_overflow += tr.overflow;
+                if (a.collect_list) ctr.cone_tri_overflow += tr.overflow;
             }
         }
         wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w);
@@ -277,27 +288,29 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_HEAVY_COUNT];
+    const uint32_t* hq = a.st.heavy_queue;
+    uint32_t* head = ctl + CTL_HEAVY_HEAD;
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
     const size_t W2 = 2 * (size_t)a.st.cap;
     const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_HEAVY_HEAD, 1u);
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
         __syncthreads();
         const uint32_t item = s_item;
         __syncthreads();
         if (item >= n) break;
-        const uint32_t w = a.st.heavy_queue[item];
+        const uint32_t w = hq[item];
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);   // uniform address: broadcast
-        const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
+        const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};   // see k_trace
         const cone_t env = walk_trace_envelope(a.sc, wk);
         unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const long long tt0 = a.profile ? clock64() : 0;
+        const long long tt0 = a.profile == 2 ? clock64() : 0;
         const float dist0 = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
         const uint32_t seg0 = a.st.trav[WT_TRAV_WORD(ntris) * W2 + w];
         const uint32_t nray0 = a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w], ncone0 = a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w];
-        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile ? prof : nullptr, true, seg0, dist0, nray0, ncone0);
-        if (a.profile && threadIdx.x == 0) {
+        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0);
+        if (a.profile == 2 && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
 #ifdef WTGPU_COOP_PROF
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
@@ -309,22 +322,42 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
             atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
             atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
         }
+        trav_result_t tr2 = tr;
+        if (!tr.ballistic && !tr.empty && (!a.collect_list || tr.overflow > 0)) {   // the triangle under the beam axis (resolve_primary, wt/bvh.h)
+            const range_t izr{tr.dist, tr.dist + tr.region_depth};
+            const float wtol = cone_intersection_tolerance(env.o, a.sc.world_min, a.sc.world_max, a.sc.world_max);
+            tr2.aborted = 2;
+            tr2.tuid = kInvalid;
+            tr2.n_ray_queries++;
+            ray_hit_t rh;
+            if (coop_ray_query(a.sc, env.o, env.d, grow(izr, wtol), sh, rh)) {
+                const tri_geo_t g = a.sc.tri_geo[rh.tuid];
+                if (contains(grow(izr, cone_intersection_tolerance(env.o, g.a, g.b, g.c)), rh.dist)) {
+                    tr2.tuid = rh.tuid;
+                    tr2.bx = rh.bx;
+                    tr2.by = rh.by;
+                    tr2.pdist = rh.dist;
+                }
+            }
+        }
         if (threadIdx.x == 0) {
-            soa_store(a.st.trav, W2, w, tr);
+            soa_store(a.st.trav, W2, w, tr2);
             ctr.segments += 1;
-            ctr.ray_queries += tr.n_ray_queries;
-            ctr.cone_queries += tr.n_cone_queries;
-            ctr.cone_tri_overflow += tr.overflow;
+            ctr.ray_queries += tr2.n_ray_queries;
+            ctr.cone_queries += tr2.n_cone_queries;
+            if (a.collect_list) ctr.cone_tri_overflow += tr2.overflow;
         }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-// Interaction step of the queued walks.  PASS 0 (A): the queue of the round; walks whose beam axis misses every listed triangle
-// (expensive path, see bdpt_walk_step) are only appended to the pass-B queue.  PASS 1 (B): that queue: edge set, Fraunhofer aperture,
-// null interactions; with pass C enabled the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
+// Interaction step of the queued walks.  PASS 0 (A): the queue of the round — surface interactions; walks whose beam axis misses
+// every triangle of the interaction region (8 % of them; what follows costs ~50x a surface interaction) are only appended to the
+// pass-B queue.  k_edges then gathers the classified-edge set of their regions.  PASS 1 (B): Fraunhofer aperture construction,
+// null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
+// No BVH query happens in these passes (the trace kernels resolved the primary triangle): they carry no traversal stack.
 template <int PASS>
-__device__ inline void interact_body(const launch_args_t& a, int in, int first_round, stack_entry_t* lds) {
+__device__ inline void interact_body(const launch_args_t& a, int in, int first_round) {
     constexpr bool PASS_B = PASS == 1;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in];
@@ -335,21 +368,17 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
     }
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
     for (;;) {
         const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
         bool cont = false;
-        uint32_t w = 0, stream = 0;
-        uint64_t sample_id = 0;
+        uint32_t w = 0;
         fsd_defer_t defer;
         defer.pending = defer.resolved = 0;
         defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
-        defer.defer_sampling = (PASS == 1 && a.pass_c) ? 1u : 0u;
+        defer.defer_sampling = PASS_B ? 1u : 0u;
         defer.to_sampling_pass = 0;
         defer.have_aperture = 0;
         defer.split_no_primary = PASS_B ? 0u : 1u;
@@ -359,117 +388,49 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         defer.gather_flux = 0.f;
         defer.gather_edges = nullptr;
         bool need_gather = false;
-        bool todo = qi < n;
-        if (todo) {
+        if (qi < n) {
             w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round);
-            uint32_t i;
+            uint32_t i, stream;
             walk_ident(a, w, i, stream);
             const uint64_t j = a.j0 + i;
             const uint32_t pix = (uint32_t)(j % a.npix);
             const uint64_t s = a.sample_begin + j / a.npix;
-            sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-        }
-        // at most two executions of the step: the second only for lanes whose Fraunhofer-FSD rejection loop was finished by
-        // the wavefront in between (pass B)
-        // (with pass C enabled only that pass samples apertures; otherwise pass B does everything)
-        for (int pass = 0; pass < ((PASS_B && !a.pass_c) ? 2 : 1); ++pass) {
-            if (todo) {
-                walk_t wk;
-                soa_load(a.st.walks, W2, w, wk);
-                trav_result_t tr;
-                soa_load(a.st.trav, W2, w, tr);
-                const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};   // one contiguous 256-B list per walk
-                const vertex_store_t vs{a.st.verts, W2, w};
-                defer.pending = 0;
-                if (PASS_B && tr.tuid == kGatherMarker) {   // the region was gathered by k_gather: edge ids + intercepted power
-                    defer.has_gather = 1;
-                    defer.gather_flux = tr.bx;
-                    defer.gather_n_edges = tr.n_ray_queries;
-                    defer.gather_edge_overflow = pass == 0 ? tr.n_cone_queries : 0u;
-                    defer.gather_edges = a.st.tris + (size_t)w * kTriListWords;
-                }
-#ifdef WTGPU_STEP_PROF
-                const long long prof_t0 = clock64();
-                for (int q = 0; q < 8; ++q) defer.marks[q] = 0;
-#endif
-                cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
-                if (PASS == 1 && defer.to_sampling_pass) a.st.trav[WT_TRAV_WORD(by) * W2 + w] = defer.slot;
-#ifdef WTGPU_STEP_PROF
-                if (PASS_B) {   // debug builds: where the pass-B step spends its time (per lane; slot 6 = FSD walks, 7 = walks)
-                    long long prev = prof_t0;
-                    for (int q = 0; q < 6; ++q)
-                        if (defer.marks[q]) {
-                            atomicAdd(a.st.counters + kNumCounters + q, (unsigned long long)(defer.marks[q] - prev));
-                            prev = defer.marks[q];
-                        }
-                    atomicAdd(a.st.counters + kNumCounters + 7, 1ull);
-                    if (defer.marks[3]) atomicAdd(a.st.counters + kNumCounters + 6, 1ull);
-                }
-#endif
-                if (!PASS_B && a.exact_regions && defer.no_primary && tr.overflow > 0 && !tr.ballistic && a.sc.opts.FSD) need_gather = true;
-                if (!defer.pending) {
-                    todo = false;
-                    if (!defer.no_primary && !defer.to_sampling_pass) {
-                        wk.active = cont ? 1u : 0u;
-                        soa_store(a.st.walks, W2, w, wk);
-                    }
-                }
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+            walk_t wk;
+            soa_load(a.st.walks, W2, w, wk);
+            trav_result_t tr;
+            soa_load(a.st.trav, W2, w, tr);
+            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
+            const vertex_store_t vs{a.st.verts, W2, w};
+            if (PASS_B && tr.tuid == kGatherMarker) {   // k_edges left the region's sorted classified-edge ids in the walk's list slot
+                defer.has_gather = 1;
+                defer.gather_n_edges = tr.n_ray_queries;
+                defer.gather_edge_overflow = tr.n_cone_queries;
+                defer.gather_edges = a.st.tris + (size_t)w * kTriListWords;
             }
-            if (!(PASS_B && !a.pass_c)) break;
-            // ---- Fraunhofer-FSD rejection loops that did not finish within kFsdInlineTries: the wavefront finishes them one after
-            // the other, 64 tries per step (tries are independent, fsd.h), then the owning lane re-runs its step with the outcome.
-            unsigned long long pm = __ballot(todo && defer.pending != 0);
-            if (!pm) break;
-            const int lane = threadIdx.x & 63;
-            while (pm) {
-                const int L = __ffsll((long long)pm) - 1;
-                pm &= pm - 1;
-                const uint32_t slot = (uint32_t)__shfl((int)defer.slot, L, 64);
-                const uint32_t base = (uint32_t)__shfl((int)defer.base, L, 64);
-                const uint32_t t_first = (uint32_t)__shfl((int)defer.next_try, L, 64);
-                const uint32_t sid_lo = (uint32_t)__shfl((int)(uint32_t)sample_id, L, 64);
-                const uint32_t sid_hi = (uint32_t)__shfl((int)(uint32_t)(sample_id >> 32), L, 64);
-                const uint32_t strm = (uint32_t)__shfl((int)stream, L, 64);
-                const fsd_aperture_t ap = pool.hdr[slot];
-                const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
-                const uint32_t max_tries = fsd_max_tries(ap);
-                const sampler_t ss = make_sampler(a.seed, ((uint64_t)sid_hi << 32) | sid_lo, strm, 0);
-                bool acc = false;
-                uint32_t t_acc = 0;
-                float rx = 0.f, ry = 0.f, rf = 0.f;
-                for (uint32_t t0 = t_first; t0 < max_tries && !acc; t0 += 64) {
-                    const uint32_t t = t0 + lane;
-                    fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
-                    if (t < max_tries) r = fsd_try(a.sc, ap, ed, sampler_at(ss, base + t * kFsdDrawsPerTry));
-                    const unsigned long long am = __ballot(r.accept != 0);
-                    if (am) {
-                        const int wl = __ffsll((long long)am) - 1;   // lowest try wins, like the sequential loop
-                        rx = __shfl(r.x.x, wl, 64);
-                        ry = __shfl(r.x.y, wl, 64);
-                        rf = __shfl(r.f, wl, 64);
-                        t_acc = t0 + (uint32_t)wl;
-                        acc = true;
-                    }
-                }
-                if (lane == L) {
-                    defer.fs = fsd_finalize(ap, acc, vec2{rx, ry}, rf);
-                    defer.end_draws = fsd_draws_after(base, acc ? t_acc : max_tries - 1u);
-                    defer.resolved = 1;
-                }
+            cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
+            if (PASS_B && defer.to_sampling_pass) a.st.trav[WT_TRAV_WORD(by) * W2 + w] = defer.slot;
+            // a region that did not fit the bounded list: its edge set comes from a walk of the whole region (k_edges)
+            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || !a.collect_list)) need_gather = true;
+            if (!defer.no_primary && !defer.to_sampling_pass) {
+                wk.active = cont ? 1u : 0u;
+                soa_store(a.st.walks, W2, w, wk);
             }
         }
         if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
         if (!PASS_B) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
-        if (PASS == 1) wave_append(a.st.intc_queue, ctl + CTL_INTC_COUNT, defer.to_sampling_pass != 0, w);
+        if (PASS_B) wave_append(a.st.intc_queue, ctl + CTL_INTC_COUNT, defer.to_sampling_pass != 0, w);
         wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-// Interaction regions that overflowed the bounded triangle list (5 % of the diffusive segments of the cornell workload, up to
-// 82,000 triangles): one wavefront walks the region again and leaves the intercepted power fraction and the classified-edge set
-// of the WHOLE region for k_interact_b (coop_gather, coop.h).
-__global__ void __launch_bounds__(64, 3) k_gather(launch_args_t a) {
+// The classified-edge set of the interaction regions that overflowed the bounded triangle list: the WHOLE region, whatever its
+// triangle count — the reference's unbounded std::vector (include/wt/ads/traversal_common.hpp:124-148).  One wavefront per walk
+// (coop_gather, edges only): only subtrees that hold classified edges are entered and only edge-bearing triangles are tested, 64 at
+// a time (a wide beam over the whole scene still meets ~10^3 of them: a single lane needs milliseconds for that).
+// Sorted ids -> the walk's list slot, marker + count -> its traversal record.
+__global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
     __shared__ coop_shared_t sh;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
@@ -483,41 +444,106 @@ __global__ void __launch_bounds__(64, 3) k_gather(launch_args_t a) {
         if (item >= n) break;
         const uint32_t w = a.st.gather_queue[item];
         walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);   // uniform address
+        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
+        const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
+        const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
+        const range_t izr{beam_dist, beam_dist + region_depth};
+        const cone_t tcone = walk_trace_envelope(a.sc, wk);
+        const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true);
+        __syncthreads();
+        uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
+        for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = sh.edge_ids[j];
+        if (threadIdx.x == 0) {
+            a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = kGatherMarker;
+            a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = g.n_edges;
+            a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = g.edge_overflow;
+            if (a.profile) {
+                atomicAdd(a.st.counters + kNumCounters + 5, 1ull);
+                atomicAdd(a.st.counters + kNumCounters + 6, (unsigned long long)g.n_edges);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock, 4) k_interact(launch_args_t a, int in, int first_round) { interact_body<0>(a, in, first_round); }
+__global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
+// Intercepted power of interaction regions that overflowed the bounded list (find_closest_triangle's sum over ALL region triangles,
+// plt_bdpt_detail.hpp:391-416) for the pass-C walks.  Such regions hold 10^3..10^5 triangles (a wide emitter beam over a finely
+// tessellated mesh), 5000 on average in the headline workload: one wavefront per region would leave the round waiting for the
+// largest one (measured: 27 ms for a 130,000-triangle region).  k_flux_split cuts the part of the tree that overlaps the region
+// into subtrees of <= kFluxTaskTris triangles, k_flux_tasks sums every subtree on whichever wavefront is free (f64 atomics).
+constexpr uint32_t kFluxTaskTris = 512;
+__global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
+    __shared__ coop_shared_t sh;
+    __shared__ uint32_t s_item;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_INTC_COUNT];
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSPLIT_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.intc_queue[item];
+        if (a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] == kGatherMarker) {   // block-uniform
+            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
+            const cone_t tcone = walk_trace_envelope(a.sc, wk);
+            const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
+            const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
+            if (threadIdx.x == 0) a.st.facc[w] = 0.0;
+            coop_split(a.sc, tcone, range_t{beam_dist, beam_dist + region_depth}, sh, kFluxTaskTris, [&](int32_t ptr) {
+                const uint32_t idx = atomicAdd(ctl + CTL_FTASK_COUNT, 1u);
+                if (idx < a.st.ftask_cap)
+                    a.st.ftasks[idx] = make_uint2(w, (uint32_t)ptr);
+                else
+                    atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_pool_overflow) / sizeof(unsigned long long), 1ull);   // reported; cannot happen below 4M tasks per batch
+            });
+        }
+    }
+}
+__global__ void __launch_bounds__(64, 3) k_flux_tasks(launch_args_t a) {
+    __shared__ coop_shared_t sh;
+    __shared__ uint32_t s_item;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = min(ctl[CTL_FTASK_COUNT], a.st.ftask_cap);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FTASK_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint2 task = a.st.ftasks[item];
+        const uint32_t w = task.x;
+        walk_t wk;
+        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
         const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
         const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
         const bool want_front = a.st.trav[WT_TRAV_WORD(front_face) * W2 + w] != 0;
         const range_t izr{beam_dist, beam_dist + region_depth};
         const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
-        // edges first (cheap): the intercepted power is only consumed when the region has classified edges (FSD aperture), which
-        // most giant regions — smooth dense meshes — do not
-        gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{sd3.x, sd3.y}, want_front, sh, false, true);
-        if (g.n_edges > 0)
-            g.flux = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{sd3.x, sd3.y}, want_front, sh, true, false).flux;
-        __syncthreads();
-        uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
-        for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = sh.edge_ids[j];
+        unsigned long long gst[2] = {0, 0};
+        const float flux = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{sd3.x, sd3.y}, want_front, sh, true, false,
+                                       a.profile ? gst : nullptr, (int32_t)task.y).flux;
         if (threadIdx.x == 0) {
-            a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = kGatherMarker;
-            a.st.trav[WT_TRAV_WORD(bx) * W2 + w] = __float_as_uint(g.flux);
-            a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = g.n_edges;
-            a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = g.edge_overflow;
+            if (flux != 0.f) unsafeAtomicAdd(&a.st.facc[w], (double)flux);
+            if (a.profile) {   // WTGPU_PROFILE=1: sizes of the gathered regions
+                atomicAdd(a.st.counters + kNumCounters + 0, 1ull);
+                atomicAdd(a.st.counters + kNumCounters + 1, gst[0]);
+                atomicAdd(a.st.counters + kNumCounters + 2, gst[1]);
+                atomicMax(a.st.counters + kNumCounters + 4, gst[0]);
+            }
         }
         __syncthreads();
     }
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_interact(launch_args_t a, int in, int first_round) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    interact_body<0>(a, in, first_round, lds);
-}
-__global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int in) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    interact_body<1>(a, in, 0, lds);
-}
-// Pass C (WTGPU_PASS_C): the walks of pass B whose Fraunhofer aperture has edges, ONE WAVEFRONT PER WALK.  What a single lane of pass B
-// would do serially is spread over the 64 lanes: the intercepted-power integrals (lane = triangle of the region, wave reduction)
+// Pass C: the walks of pass B whose Fraunhofer aperture has edges, ONE WAVEFRONT PER WALK.  What a single lane would do serially
+// is spread over the 64 lanes: the intercepted-power integral over every triangle of the interaction region (find_closest_triangle,
+// plt_bdpt_detail.hpp:391-416 — coop_gather walks the WHOLE region, however many triangles it holds: the reference's unbounded list)
 // and the rejection sampling (64 tries per step; tries own their random draws, the lowest accepted try wins like in the sequential
 // loop); lane 0 then re-enters bdpt_walk_step with the outcome (vertex append, beam transform, Russian roulette).
 __global__ void __launch_bounds__(64, 3) k_interact_c(launch_args_t a, int in) {
@@ -549,13 +575,14 @@ __global__ void __launch_bounds__(64, 3) k_interact_c(launch_args_t a, int in) {
         const uint32_t slot = a.st.trav[WT_TRAV_WORD(by) * W2 + w];   // left by pass B
         fsd_aperture_t ap = pool.hdr[slot];
         const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
-        // ---- intercepted power (bdpt_walk_step computes the same sum triangle by triangle)
+        // ---- intercepted power of the whole region (same z-slab, cone and facing as the reference's list-based sum)
+        const range_t izr{tr.dist, tr.dist + tr.region_depth};
+        const vec3 sd3 = beam_footprint(wk.beam, tr.dist) / kBeamEnvelope;
+        const cone_t tcone = walk_trace_envelope(a.sc, wk);
         float flux;
-        if (tr.tuid == kGatherMarker) {
-            flux = tr.bx;
-        } else {
-            const range_t izr{tr.dist, tr.dist + tr.region_depth};
-            const vec3 sd3 = beam_footprint(wk.beam, tr.dist) / kBeamEnvelope;
+        if (tr.tuid == kGatherMarker) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
+            flux = (float)a.st.facc[w];
+        } else {   // lane = triangle of the (complete) list, wave reduction (bdpt_walk_step computes the same sum triangle by triangle)
             const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
             flux = (uint32_t)lane < tr.ntris ? region_triangle_flux(a.sc, cone_frame(wk.beam.env), wk.beam.env, izr, vec2{sd3.x, sd3.y}, tl[lane], tr.front_face != 0) : 0.f;
 #pragma unroll
@@ -627,6 +654,7 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -845,6 +873,24 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(scene_t sc, const float* 
     bary[2 * i + 1] = h.by;
     front[i] = h.front_face;
 }
+constexpr int kG8Groups = kBlock / 8;
+// 8-lane-group variant (wt/g8.h): one ray per group, 16 groups per block
+__global__ void __launch_bounds__(kBlock) k_trace_rays_g8(scene_t sc, const float* rays, uint32_t n, float* dist, uint32_t* tuid, float* bary, uint32_t* front) {
+    __shared__ stack_entry_t lds[kG8Stack * (kBlock / 8)];
+    const uint32_t i = blockIdx.x * (kBlock / 8) + (threadIdx.x >> 3);
+    if (i >= n) return;
+    const g8_stack_t st{lds + kG8Stack * (threadIdx.x >> 3)};
+    const float* r = rays + 8 * (size_t)i;
+    ray_hit_t h;
+    g8_intersect_ray(sc, vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, range_t{r[6], r[7]}, st, h);
+    if ((threadIdx.x & 7u) == 0) {
+        dist[i] = h.dist;
+        tuid[i] = h.tuid;
+        bary[2 * i] = h.bx;
+        bary[2 * i + 1] = h.by;
+        front[i] = h.front_face;
+    }
+}
 __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
                                                            uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
@@ -866,6 +912,40 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
         if (!tr.empty) out_tris[(size_t)i * cap] = tr.tuid;
     } else {
         // insertion sort of the (short) list into the output
+        uint32_t m = 0;
+        for (uint32_t j = 0; j < tr.ntris; ++j) {
+            const uint32_t v = tris[j];
+            uint32_t pos = m < cap ? m : cap;
+            while (pos > 0 && out_tris[(size_t)i * cap + pos - 1] > v) {
+                if (pos < cap) out_tris[(size_t)i * cap + pos] = out_tris[(size_t)i * cap + pos - 1];
+                --pos;
+            }
+            if (pos < cap) out_tris[(size_t)i * cap + pos] = v;
+            if (m < cap) ++m;
+        }
+    }
+}
+
+// 8-lane-group variant of k_traverse_cones (one cone per group); lists come out in the sequential traversal's order
+__global__ void __launch_bounds__(kBlock) k_traverse_cones_g8(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
+                                                              uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
+    __shared__ stack_entry_t lds[kG8Stack * kG8Groups];
+    const uint32_t i = blockIdx.x * kG8Groups + (threadIdx.x >> 3);
+    if (i >= n) return;
+    const g8_stack_t st{lds + kG8Stack * (threadIdx.x >> 3)};
+    const float* c = cones + 10 * (size_t)i;
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    const uint_list_t tris{scratch_tris + (size_t)i * kMaxConeTris, 1u, kMaxConeTris};
+    const trav_result_t tr = g8_traverse(sc, env, c[9], WT_INF, false, st, tris, 0xFFFFFFFFu);
+    if ((threadIdx.x & 7u) != 0) return;
+    dist[i] = tr.dist;
+    flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
+    ntris[i] = tr.ballistic ? (tr.empty ? 0 : 1) : tr.ntris;
+    for (uint32_t j = 0; j < cap; ++j) out_tris[(size_t)i * cap + j] = kInvalid;
+    if (tr.ballistic) {
+        if (!tr.empty) out_tris[(size_t)i * cap] = tr.tuid;
+    } else {
         uint32_t m = 0;
         for (uint32_t j = 0; j < tr.ntris; ++j) {
             const uint32_t v = tris[j];
@@ -1056,6 +1136,9 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         if ((rc = dmalloc(s, &st.intb_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.gather_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.intc_queue, W2))) return rc;
+        st.ftask_cap = path_mode ? 1u : (1u << 22);
+        if ((rc = dmalloc(s, &st.ftasks, (size_t)st.ftask_cap))) return rc;
+        if ((rc = dmalloc(s, &st.facc, path_mode ? 1 : W2))) return rc;
         if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
         HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
         st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing && !path_mode) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
@@ -1157,15 +1240,10 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     if (const char* e = getenv("WTGPU_COUNT_STATS")) a.count_stats = (uint32_t)atoi(e);
     a.profile = 0;
     if (const char* e = getenv("WTGPU_PROFILE")) a.profile = (uint32_t)atoi(e);
-    // Off by default: regions of up to 82,000 triangles cost as much as the rest of the pass (measured 197 -> 420 ms per pass for
-    // +0.2 % identical pixels); on, the device treats them like the reference's unbounded lists
-    a.exact_regions = 0;
-    if (const char* e = getenv("WTGPU_EXACT_REGIONS")) a.exact_regions = (uint32_t)atoi(e);
-    // On by default (193.5 -> 185.5 ms per pass; WTGPU_PASS_C=0 turns it off): the one walk in eight of pass B whose aperture has
-    // edges is completed by a wavefront of its own (k_interact_c): a lane of pass B takes ~1 ms for the intercepted-power integrals
-    // over up to 64 triangles plus the rejection loop, during which the 56 other lanes of its wavefront idle
-    a.pass_c = 1;
-    if (const char* e = getenv("WTGPU_PASS_C")) a.pass_c = (uint32_t)atoi(e);
+    // Bounded triangle lists (64) are the fast path of an interaction region; a region that overflows its list is handled exactly by
+    // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_interact_c).
+    // WTGPU_NO_LISTS=1 (plt_bdpt, diagnostic): no lists at all, every region is gathered.
+    a.collect_list = (h.opts.integrator != INTEGRATOR_BDPT || !getenv("WTGPU_NO_LISTS")) ? 1u : 0u;
     // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
     int n_cu = 256;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
@@ -1174,7 +1252,8 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     uint32_t round_blocks_per_cu = 8;
     if (const char* e = getenv("WTGPU_ROUND_BLOCKS")) round_blocks_per_cu = (uint32_t)std::max(1, atoi(e));
     const uint32_t grid_round = (uint32_t)n_cu * round_blocks_per_cu, grid_heavy = (uint32_t)n_cu * heavy_waves_per_cu;
-    uint32_t grid_div_b = 4, grid_div_c = 2;   // persistent grids of the two expensive-interaction passes relative to the round's
+    uint32_t grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2;
+    if (const char* e = getenv("WTGPU_GRID_FLUX")) grid_mul_flux = (uint32_t)std::max(1, atoi(e));   // persistent grids of the two expensive-interaction passes relative to the round's
     if (const char* e = getenv("WTGPU_GRID_B")) grid_div_b = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("WTGPU_GRID_C")) grid_div_c = (uint32_t)std::max(1, atoi(e));
 
@@ -1234,9 +1313,11 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             }
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
-            if (a.exact_regions) hipLaunchKernelGGL(k_gather, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
+            hipLaunchKernelGGL(k_edges, dim3(gh), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
-            if (a.pass_c) hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
+            hipLaunchKernelGGL(k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
+            hipLaunchKernelGGL(k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
+            hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
             rec();
         }
         if (path_mode) {
@@ -1310,6 +1391,11 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     if (getenv("WTGPU_PROFILE")) {
         unsigned long long p[8];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[wtgpu profile] flux tasks: %llu, candidates %llu (max %llu per task), exact-tested %llu; k_edges: %llu walks, %llu edges\n", p[0], p[1], p[4], p[2], p[5], p[6]);
+    }
+    if (getenv("WTGPU_PROFILE_HEAVY")) {
+        unsigned long long p[8];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
         fprintf(stderr, "[wtgpu profile] heavy items %llu: clock ticks ray %llu probe %llu cone %llu total %llu (per item: ray %.0f probe %.0f cone %.0f total %.0f; cone+probe phase A %.0f phase B %.0f; phase-A steps %.1f entries %.1f)\n", p[4], p[0],
                 p[1], p[2], p[3], p[4] ? double(p[0]) / p[4] : 0., p[4] ? double(p[1]) / p[4] : 0., p[4] ? double(p[2]) / p[4] : 0., p[4] ? double(p[3]) / p[4] : 0., p[4] ? double(p[5]) / p[4] : 0., p[4] ? double(p[6]) / p[4] : 0., p[4] ? double(p[7] & 0xffffffffull) / p[4] : 0., p[4] ? double(p[7] >> 32) / p[4] : 0.);
     }
@@ -1332,7 +1418,11 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
 int wtgpu_trace_rays(wtgpu_scene* s, void* stream_, const float* d_rays, uint32_t n, float* d_dist, uint32_t* d_tuid, float* d_bary, uint32_t* d_front) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
+    static const bool per_lane = getenv("WTGPU_RAYS_PER_LANE") != nullptr;   // A/B switch of the query kernels (parity tests run both)
+    if (per_lane)
+        hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
+    else
+        hipLaunchKernelGGL(k_trace_rays_g8, dim3((n + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
     HIP_CHECK(hipGetLastError());
     return WTGPU_OK;
 }
@@ -1342,8 +1432,12 @@ int wtgpu_traverse_cones(wtgpu_scene* s, void* stream_, const float* d_cones, ui
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t* scratch = nullptr;
     HIP_CHECK(hipMalloc((void**)&scratch, (size_t)n * kMaxConeTris * 4));
-    hipLaunchKernelGGL(k_traverse_cones, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_cones, n, cap, d_dist, d_flags, d_ntris,
-                       d_tris, scratch);
+    if (getenv("WTGPU_RAYS_PER_LANE"))
+        hipLaunchKernelGGL(k_traverse_cones, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_cones, n, cap, d_dist, d_flags, d_ntris,
+                           d_tris, scratch);
+    else
+        hipLaunchKernelGGL(k_traverse_cones_g8, dim3((n + kG8Groups - 1) / kG8Groups), dim3(kBlock), 0, stream, s->dev, d_cones, n, cap, d_dist, d_flags,
+                           d_ntris, d_tris, scratch);
     hipError_t e = hipStreamSynchronize(stream);
     hipFree(scratch);
     HIP_CHECK(e);
