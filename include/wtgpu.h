@@ -111,6 +111,15 @@ int wtgpu_trace_rays(wtgpu_scene* scene, void* stream, const float* d_rays, uint
 int wtgpu_traverse_cones(wtgpu_scene* scene, void* stream, const float* d_cones, uint32_t n, uint32_t cap, float* d_dist, uint32_t* d_flags,
                          uint32_t* d_ntris, uint32_t* d_tris);
 
+/* Region summaries of n cone queries (same cone layout): the traversal policy's hit (dist, flags: 1 empty, 2 ballistic, 4 front face),
+ * the triangle under the beam axis (find_closest_triangle, plt_bdpt_detail.hpp:362-389; 0xFFFFFFFF: none) and — for diffusive hits — the
+ * interaction region [dist, dist + 2 x major axis] walked IN FULL, whatever its size (the reference's unbounded record,
+ * include/wt/ads/traversal_common.hpp:124-148): triangle count, number + sorted ids (first edge_cap) of its classified edges, and the
+ * fraction of a Gaussian beam (sigma = cross-section axes / 3) its triangles facing like the closest one intercept
+ * (plt_bdpt_detail.hpp:391-416).  Used by the parity tests of regions beyond the device's 64-triangle fast path. */
+int wtgpu_query_regions(wtgpu_scene* scene, void* stream, const float* d_cones, uint32_t n, uint32_t edge_cap, float* d_dist, uint32_t* d_flags,
+                        uint32_t* d_primary, uint32_t* d_ntris, uint32_t* d_nedges, uint32_t* d_edges, float* d_flux);
+
 /* Profiling aid: `repeats` launches of a streaming copy of n_dwords 32-bit words (one dword per lane, coalesced: the access width
  * of the SoA path state) with a known byte count, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE (tools/profile_round.sh). */
 int wtgpu_calibrate_copy(uint64_t n_dwords, int repeats);

@@ -306,6 +306,8 @@ uint32_t kat_fsd_sample_consistency(const void* scene_host, const float* cone6, 
     const uint32_t n_ids = sc.n_edges < 4096 ? sc.n_edges : 4096;
     for (uint32_t i = 0; i < n_ids; ++i) ids[i] = i;
     fsd_aperture_t ap;
+    ap.edge_offset = 0;
+    ap.edge_cap = kFsdMaxEdges;
     const fsd_edges_ref_t ed{edges, 1};
     cone_t beam = env;
     beam.o = env.o + dist * d;   // the aperture is built in the frame at the interaction point (bdpt_walk_step passes the beam itself)
@@ -323,6 +325,8 @@ uint32_t kat_fsd_sample_consistency(const void* scene_host, const float* cone6, 
 // free_space_diffraction.cpp:106-128.  ap_out = {P0, P0_pdf, psi02, edge pdfs...}
 static void kat_make_aperture(const float* edges, uint32_t n_edges, float k, fsd_aperture_t& ap, fsd_edge_t* store) {
     const fsd_edges_ref_t ed{store, 1};
+    ap.edge_offset = 0;
+    ap.edge_cap = kFsdMaxEdges;
     fsd_build_state_t st = fsd_build_begin(frame_t{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, k, 1.f, vec2{1.f, 1.f}, ap);
     for (uint32_t i = 0; i < n_edges && i < kFsdMaxEdges; ++i) {
         fsd_edge_t fe;

@@ -63,16 +63,21 @@ def test_image_parity_scenes(built, name, res, spp, kw, tol):
 
 
 def test_cornell_dense_mesh_parity(built):
-    """Bench geometry (170K triangles, bounded cone lists + any-hit probe + cooperative heavy-walk kernel all active) on a
-    small film.  The CPU checker keeps the reference's unbounded triangle lists, so samples whose beam footprint covers
-    more than kMaxConeTris triangles differ (DESIGN.md 'bounded lists'): tolerance 5 % relative L1 on the image, 1 % on
-    event counts."""
-    sc, gpu, cpu, gc, oc, gf, cf = _both("cornell_box", 48, 2, 3, mesh_detail=1, lut=(128, 128), crop_of=1440)
+    """Bench geometry (170K triangles: bounded lists, cooperative heavy-walk kernel, whole-region edge / power gathers all active) on
+    a small film.  Interaction regions are unbounded on both sides now (the device walks regions that overflow its 64-triangle list
+    once more: resolve_primary, k_edges, k_flux_*), so what remains are traversal-order details: the reference's (and the CPU
+    checker's) list of a region also holds triangles it met before the region's slab shrank, the device's gathers use the final slab.
+    Tolerance 2 % relative L1 on the image, 0.5 % on event counts, 1.5 % on the number of diffraction interactions."""
+    sc, gpu, cpu, gc, oc, gf, cf = _both("cornell_box", 64, 4, 3, mesh_detail=1, lut=(128, 128), crop_of=1440)
     assert np.isfinite(gpu).all()
     assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
-    assert _rel_l1(gpu, cpu) < 5e-2, _rel_l1(gpu, cpu)
+    print("dense crop: rel L1", _rel_l1(gpu, cpu), "fsd", gc["fsd_interactions"], oc["fsd_interactions"], "overflow counters",
+          {k: gc[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow")}, {k: oc[k] for k in ("edge_overflow", "fsd_edge_overflow")})
+    assert _rel_l1(gpu, cpu) < 2e-2, _rel_l1(gpu, cpu)
     for key in ("segments", "vertices", "connections"):
-        assert abs(gc[key] - oc[key]) <= 1e-2 * oc[key], (key, gc[key], oc[key])
+        assert abs(gc[key] - oc[key]) <= 5e-3 * oc[key], (key, gc[key], oc[key])
+    assert abs(gc["fsd_interactions"] - oc["fsd_interactions"]) <= 1.5e-2 * oc["fsd_interactions"] + 3, (gc["fsd_interactions"], oc["fsd_interactions"])
+    assert gc["fsd_pool_overflow"] == 0
 
 
 @pytest.mark.parametrize("case", ["furnace_r16", "furnace_fsd_r16", "white_furnace_r12", "double_slits_r96", "cornell_box_r12", "etoile_r48",
@@ -123,42 +128,6 @@ def test_batched_render_equals_unbatched(built):
     vb, wb, lb = render(b, 2, seed=4)
     assert b.timings()["batches"] >= 4
     assert np.allclose(va, vb, rtol=1e-9, atol=1e-30) and np.allclose(wa, wb, rtol=1e-12) and np.allclose(la, lb, rtol=1e-9, atol=1e-30)
-
-
-def test_exact_regions_mode(built, monkeypatch):
-    """WTGPU_EXACT_REGIONS=1: interaction regions that overflow the bounded triangle list are gathered by a wavefront (k_gather);
-    the dense-mesh crop must stay within the same tolerances and its diffraction-interaction count must not move away from
-    the CPU checker's (unbounded lists)."""
-    args = ("cornell_box", 48, 2, 3)
-    kw = dict(mesh_detail=1, lut=(128, 128), crop_of=1440)
-    _, gpu0, cpu, gc0, oc, _, _ = _both(*args, **kw)
-    monkeypatch.setenv("WTGPU_EXACT_REGIONS", "1")
-    _, gpu1, _, gc1, _, gf, cf = _both(*args, **kw)
-    assert np.isfinite(gpu1).all()
-    assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
-    assert _rel_l1(gpu1, cpu) < 5e-2
-    assert abs(gc1["fsd_interactions"] - oc["fsd_interactions"]) <= abs(gc0["fsd_interactions"] - oc["fsd_interactions"]) + 3
-    for key in ("segments", "vertices", "connections"):
-        assert abs(gc1[key] - oc[key]) <= 1e-2 * oc[key]
-
-
-def test_pass_c_mode_is_result_identical(built, monkeypatch):
-    """Pass C (default): Fraunhofer apertures with edges are completed — intercepted-power integrals, rejection sampling, vertex
-    append — by one wavefront per walk (k_interact_c) instead of by a single lane of pass B (WTGPU_PASS_C=0).  Same draws: event
-    counters identical, images equal to fp32 rounding (the wave reduction sums the triangle fluxes in a different order)."""
-    from wave_tracer_amd import Scene, render
-    for name, res, spp, kw in (("double_slits", 96, 4, {"lut": (128, 128)}), ("furnace", 24, 4, {"fsd": 1, "lut": (128, 128)})):
-        a = Scene(name, res=res, **kw)
-        va, wa, la = render(a, spp, seed=9)
-        ca = a.counters()
-        monkeypatch.setenv("WTGPU_PASS_C", "0")
-        b = Scene(name, res=res, **kw)
-        vb, wb, lb = render(b, spp, seed=9)
-        cb = b.counters()
-        monkeypatch.delenv("WTGPU_PASS_C")
-        assert ca["fsd_interactions"] > 0 and ca == cb
-        assert np.allclose(wa, wb, rtol=1e-12)
-        assert np.abs(va - vb).sum() <= 1e-5 * np.abs(va).sum() and np.abs(la - lb).sum() <= 1e-5 * max(np.abs(la).sum(), 1e-300)
 
 
 def test_scene_from_desc_renders_like_the_named_scene(built):
@@ -244,11 +213,15 @@ def test_full_size_properties_1440(built):
     assert inner.sum() > 15000
     assert np.allclose(gw[inner], ow[inner], rtol=1e-5, atol=1e-7)
     rel = np.abs(gv[inner] - ov[inner]).sum() / np.abs(ov[inner]).sum()
-    assert rel < 5e-2, rel
     frac_same = (np.abs(gv[inner] - ov[inner]).sum(axis=1) <= 1e-3 * np.abs(ov[inner]).sum(axis=1) + 1e-30).mean()
+    print("full size: rel L1", rel, "frac_same", frac_same, "counters", {k: c[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow", "fsd_interactions")},
+          "oracle tiles", {k: oc5[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_interactions")})
+    assert rel < 2e-2, rel
     # 5 % of the diffusive segments of this workload see more than kMaxConeTris = 64 triangles (CPU profile: p99 = 2400, max
-    # 82,000) and are truncated on the device: the pixels they touch differ, the others agree to fp32 rounding
-    assert frac_same > 0.93, frac_same
+    # 82,000): those regions are walked in full on the device, so all but a fraction of a per cent of the pixels agree
+    # with the CPU checker's unbounded lists to fp32 rounding
+    assert frac_same > 0.99, frac_same
+    assert c["fsd_pool_overflow"] == 0
     small = Scene("cornell_box", res=96, mesh_detail=1)
     _, _, _, oc = oracle_render(small, 0, 2, 5)
     n_small = 96 * 96 * 2

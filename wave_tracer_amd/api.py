@@ -48,7 +48,7 @@ class Counters(C.Structure):
 SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_scene_get_info", "wtgpu_scene_host_desc",
            "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
            "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
-           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join"]
+           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join", "wtgpu_query_regions"]
 
 _lib = None
 
@@ -85,6 +85,8 @@ def load_library():
     lib.wtgpu_join.argtypes = [vp, vp]
     lib.wtgpu_trace_rays.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     lib.wtgpu_traverse_cones.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    lib.wtgpu_query_regions.argtypes = [vp, vp, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+    lib.wtgpu_calibrate_copy.argtypes = [u64, i32]
     lib.wtgpu_get_counters.argtypes = [vp, C.POINTER(Counters)]
     lib.wtgpu_reset_counters.argtypes = [vp]
     lib.wtgpu_last_render_timings.argtypes = [vp, C.POINTER(C.c_float * 12)]
@@ -204,6 +206,24 @@ class Scene:
         torch.cuda.synchronize(dev)
         return (dist.cpu().numpy(), flags.cpu().numpy().view(np.uint32), ntris.cpu().numpy().view(np.uint32),
                 tris.cpu().numpy().view(np.uint32))
+
+    def query_regions(self, cones, edge_cap=96):
+        """cones: [n,10] f32 -> dict of numpy arrays: dist, flags, primary, ntris, nedges, edges[n,edge_cap] (sorted, 0xFFFFFFFF padded), flux."""
+        import numpy as np
+        import torch
+        dev = torch.device("cuda", self.device)
+        n = len(cones)
+        d_cones = torch.from_numpy(np.ascontiguousarray(cones, dtype=np.float32)).to(dev)
+        dist = torch.zeros(n, dtype=torch.float32, device=dev)
+        flux = torch.zeros(n, dtype=torch.float32, device=dev)
+        flags, primary, ntris, nedges = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4))
+        edges = torch.full((n, edge_cap), -1, dtype=torch.int32, device=dev)
+        _check(load_library().wtgpu_query_regions(self._h, None, d_cones.data_ptr(), n, edge_cap, dist.data_ptr(), flags.data_ptr(), primary.data_ptr(),
+                                                  ntris.data_ptr(), nedges.data_ptr(), edges.data_ptr(), flux.data_ptr()))
+        torch.cuda.synchronize(dev)
+        u = lambda t: t.cpu().numpy().view(np.uint32)
+        return {"dist": dist.cpu().numpy(), "flags": u(flags), "primary": u(primary), "ntris": u(ntris), "nedges": u(nedges), "edges": u(edges),
+                "flux": flux.cpu().numpy()}
 
     def counters(self):
         c = Counters()

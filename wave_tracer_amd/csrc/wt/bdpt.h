@@ -74,12 +74,39 @@ struct vertex_store_t {
 
 struct fsd_pool_t {
     fsd_aperture_t* hdr;
-    fsd_edge_t* edges;     // [cap][kFsdMaxEdges]
-    uint32_t* counter;     // bump allocator
+    fsd_edge_t* edges;     // segment records of all apertures (every aperture owns the range its header names)
+    uint32_t* counter;     // bump allocator of aperture slots
     uint32_t cap;
+    uint32_t* edge_counter;   // bump allocator of segment records (nullptr: every slot owns kFsdMaxEdges records — CPU checker)
+    uint32_t edge_cap;
 };
 WT_HD fsd_edges_ref_t fsd_pool_edges(const fsd_pool_t& p, uint32_t slot) {
-    return fsd_edges_ref_t{p.edges + (size_t)slot * kFsdMaxEdges, 1};
+    return fsd_edges_ref_t{p.edges + (size_t)p.hdr[slot].edge_offset, 1};
+}
+// storage for an aperture of up to `need` segments; FALSE: the segment pool is exhausted
+WT_HD bool fsd_pool_alloc_edges(const fsd_pool_t& p, uint32_t slot, uint32_t need, fsd_aperture_t& ap) {
+    if (!p.edge_counter) {
+        ap.edge_offset = slot * kFsdMaxEdges;
+        ap.edge_cap = kFsdMaxEdges;
+        return true;
+    }
+    if (need > kFsdMaxEdges) need = kFsdMaxEdges;
+    uint32_t off = 0;
+    if (need) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        off = atomicAdd(p.edge_counter, need);
+#else
+        off = __atomic_fetch_add(p.edge_counter, need, __ATOMIC_RELAXED);
+#endif
+    }
+    ap.edge_offset = off;
+    ap.edge_cap = need;
+    if ((size_t)off + need > p.edge_cap) {
+        ap.edge_offset = 0;
+        ap.edge_cap = 0;
+        return false;
+    }
+    return true;
 }
 WT_HD uint32_t fsd_pool_alloc(const fsd_pool_t& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -644,13 +671,15 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         WT_STEP_MARK(1);
         // gather the ordered, de-duplicated edge set of the interaction region (traversal_common.hpp:124-148)
         uint32_t edge_ids[kMaxEdgeIds];
+        const uint32_t* eids = edge_ids;
         uint32_t n_edge_ids = 0;
         const bool have_ap = defer && (defer->resolved || defer->have_aperture);   // built by an earlier execution of this step
         if (have_ap) {
             n_edge_ids = 1;
         } else if (sc.opts.FSD && !is_ballistic && defer && defer->has_gather) {
-            n_edge_ids = defer->gather_n_edges < kMaxEdgeIds ? defer->gather_n_edges : kMaxEdgeIds;
-            for (uint32_t i = 0; i < n_edge_ids; ++i) edge_ids[i] = defer->gather_edges[i];
+            // device: the sorted edge set of the WHOLE region, gathered by a wavefront (any length: used in place)
+            n_edge_ids = defer->gather_n_edges;
+            eids = defer->gather_edges;
             if (ctr) ctr->edge_overflow += defer->gather_edge_overflow;
         } else if (sc.opts.FSD && !is_ballistic) {
             for (uint32_t i = 0; i < tr.ntris; ++i) {
@@ -681,11 +710,21 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                 ok = false;
             } else {
                 fsd_aperture_t ap;
-                const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
                 if (have_ap) {
                     ap = pool.hdr[slot];
                 } else {
-                    fsd_build_aperture(sc, beam_frame, beam.k, 1.f, envelope, edge_ids, n_edge_ids, sigma, ap, ed);
+                    // size the aperture's storage first (the reference's is a std::vector): an upper bound of its segment count
+                    uint32_t need = 0;
+                    if (pool.edge_counter) {
+                        const vec2 cse = sigma * kBeamEnvelope;
+                        const float max_len = .33f * fmaxf_(cse.x, cse.y);
+                        for (uint32_t ei = 0; ei < n_edge_ids; ++ei) need += fsd_count_segments(sc, beam_frame, envelope, cse, max_len, eids[ei]);
+                    }
+                    if (!fsd_pool_alloc_edges(pool, slot, need, ap) && ctr) ctr->fsd_pool_overflow++;
+                }
+                const fsd_edges_ref_t ed{pool.edges + (size_t)ap.edge_offset, 1};
+                if (!have_ap) {
+                    fsd_build_aperture(sc, beam_frame, beam.k, 1.f, envelope, eids, n_edge_ids, sigma, ap, ed);
                     WT_STEP_MARK(3);
                     if (ctr && ap.overflow) ctr->fsd_edge_overflow += ap.overflow;
                     pool.hdr[slot] = ap;

@@ -37,6 +37,13 @@ struct uint_list_t {   // bounded output list with the same (pointer,stride) add
     uint32_t* p;
     uint32_t stride;
     uint32_t cap;
+    // optional: the cone-hit distance of every listed triangle (same addressing).  With it a cone query ends by dropping the
+    // triangles beyond its FINAL slab — `if (wt.dist > range.max) continue;`, include/wt/ads/traversal_common.hpp:131-135.  (In the
+    // reference that filter never fires: src/ads/bvh8w.cpp:175 records the triangle without its distance, so `wt.dist` is 0 and the
+    // record keeps whatever the traversal met while its slab was still wider — a set that depends on the visiting order, i.e. on
+    // the BVH builder.  d == nullptr reproduces that; everything here passes d: the record as traversal_common.hpp states it, which is
+    // also what the device's whole-region walks compute.)
+    float* d = nullptr;
     WT_HD uint32_t& operator[](uint32_t i) const { return p[(size_t)i * stride]; }
 };
 
@@ -262,9 +269,10 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
                         rec.front_face = front_face;
                     }
                     found = true;
-                    if (rec.ntris < tris.cap)
+                    if (rec.ntris < tris.cap) {
+                        if (tris.d) tris.d[(size_t)rec.ntris * tris.stride] = h.dist;
                         tris[rec.ntris++] = tuid;
-                    else
+                    } else
                         rec.overflow++;
                 }
             }
@@ -333,7 +341,20 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
         }
         stack_sort_desc(stack, begin, s);
     }
-    return rec.ntris > 0;
+    if (tris.d && rec.ntris > 0) {   // cone_work_to_intersection_record: remove the triangles beyond the final slab
+        const float zmax = cone_search_range(cone, searchrange, rec.dist, z_scale).max;
+        uint32_t m = 0;
+        for (uint32_t j = 0; j < rec.ntris; ++j) {
+            const float dj = tris.d[(size_t)j * tris.stride];
+            if (dj > zmax) continue;
+            const uint32_t tj = tris[j];
+            tris[m] = tj;
+            tris.d[(size_t)m * tris.stride] = dj;
+            ++m;
+        }
+        rec.ntris = m;
+    }
+    return rec.ntris + rec.overflow > 0;
 }
 
 // Any-hit cone probe: TRUE if some triangle intersects the cone inside `range` (first hit terminates).

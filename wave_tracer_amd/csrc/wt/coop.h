@@ -34,8 +34,10 @@ struct coop_shared_t {
     uint32_t tri_buf[kCoopTriBuf];
     uint32_t surv[kCoopSurvCap];
     float hit_dist[64];   // cone-hit distance of every listed triangle (list capacity kMaxConeTris = 64)
-    uint32_t edge_ids[96];   // coop_gather: sorted classified-edge set of an interaction region (capacity kMaxEdgeIds)
+    uint32_t edge_ids[96];   // coop_gather: sorted classified-edge set of an interaction region (scenes with more than kCoopEdgeBits edges)
+    uint32_t edge_bits[1024];   // coop_gather: the same set as a bitmap over the scene's edge ids (unbounded, sorted and de-duplicated for free)
 };
+constexpr uint32_t kCoopEdgeBits = 32768;
 
 __device__ inline float wave_min(float v) {
 #pragma unroll
@@ -325,6 +327,7 @@ __device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, cons
 struct gather_out_t {
     float flux;
     uint32_t n_edges, edge_overflow;
+    uint32_t n_tris;   // triangles of the region (met by the cone inside the slab)
 };
 __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
                                            const range_t& izr, vec2 sigma, bool want_front, coop_shared_t& sh, bool do_flux, bool do_edges,
@@ -333,8 +336,15 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
     const uint32_t edge_cap = 96;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
-    gather_out_t out{0.f, 0u, 0u};
+    gather_out_t out{0.f, 0u, 0u, 0u};
     const bool edges_only = do_edges && !do_flux;
+    // edge set as an LDS bitmap whenever the scene's edge ids fit (n_edges <= 32768): no capacity limit, ids come out sorted; the
+    // caller reads sh.edge_bits (coop_edge_count / coop_edge_write).  Larger scenes: the sorted 96-entry list (overflow counted).
+    const bool bitmap = do_edges && sc.n_edges <= kCoopEdgeBits;
+    if (bitmap) {
+        for (uint32_t j = threadIdx.x & 63; j < (sc.n_edges + 31u) / 32u; j += 64) sh.edge_bits[j] = 0u;
+        __syncthreads();
+    }
     if (sc.n_nodes == 0) return out;
     const vec3 ro = tcone.o, rd = tcone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
@@ -352,6 +362,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             const uint32_t k2 = b2 + lane;
             float contrib = 0.f;
             uint32_t eid[3] = {kInvalid, kInvalid, kInvalid};
+            bool member = false;
             if (k2 < nsurv) {
                 const uint32_t t2 = sh.surv[k2];
                 const tri_geo_t tri = sc.tri_geo[t2];
@@ -359,6 +370,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                 // membership = "meets the cone inside the slab": the any-hit form decides at the first contained vertex (most triangles
                 // of a large region lie inside the beam)
                 if (intersect_cone_tri<true>(tcone, tri.a, tri.b, tri.c, tri.n, slab, ht) && !(ht.dist > slab.max)) {
+                    member = true;
                     if (do_edges) {
                         const tri_meta_t m = sc.tri_meta[t2];
                         eid[0] = m.edge[0];
@@ -377,6 +389,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                     }
                 }
             }
+            out.n_tris += (uint32_t)__popcll(__ballot(member));
             // sum in lane order (deterministic)
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -386,7 +399,12 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             out.flux += __shfl(contrib, 63, 64);
             // classified edges are rare (a few hundred in a 170K-triangle scene): insert them one by one into the sorted LDS
             // list, all lanes cooperating on the search
-            unsigned long long em = __ballot(eid[0] != kInvalid || eid[1] != kInvalid || eid[2] != kInvalid);
+            if (bitmap) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (eid[e] != kInvalid) atomicOr(&sh.edge_bits[eid[e] >> 5], 1u << (eid[e] & 31u));
+            }
+            unsigned long long em = bitmap ? 0ull : __ballot(eid[0] != kInvalid || eid[1] != kInvalid || eid[2] != kInvalid);
             while (em) {
                 const int src = __ffsll((long long)em) - 1;
                 em &= em - 1;
@@ -508,6 +526,39 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
         if (s == 0) break;
     }
     return out;
+}
+
+// The bitmap edge set left in sh.edge_bits by coop_gather(do_edges): number of ids / the first `cap` ids in ascending order -> dst.
+__device__ inline uint32_t coop_edge_count(const scene_t& sc, coop_shared_t& sh) {
+    __syncthreads();
+    uint32_t c = 0;
+    for (uint32_t j = threadIdx.x & 63; j < (sc.n_edges + 31u) / 32u; j += 64) c += (uint32_t)__popc(sh.edge_bits[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+    return c;
+}
+__device__ inline void coop_edge_write(const scene_t& sc, coop_shared_t& sh, uint32_t* dst, uint32_t cap) {
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    const uint32_t nw = (sc.n_edges + 31u) / 32u;
+    for (uint32_t j0 = 0; j0 < nw && base < cap; j0 += 64) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        uint32_t bits = j < nw ? sh.edge_bits[j] : 0u;
+        uint32_t c = (uint32_t)__popc(bits), pre = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)pre, off, 64);
+            if (lane >= off) pre += o;
+        }
+        uint32_t pos = base + pre - c;
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            if (pos < cap) dst[pos] = j * 32u + (uint32_t)b;
+            ++pos;
+        }
+        base += (uint32_t)__shfl((int)pre, 63, 64);
+    }
 }
 
 // Cuts the part of the tree that overlaps (cone ∩ slab) into subtrees of at most `max_tris` triangles and hands each to emit(ptr)

@@ -22,11 +22,7 @@ constexpr float kFsdPA2 = 0.21899789398059305541f;
 constexpr float kFsdP0Sigma = 0.288675134594813f / 4.f;
 constexpr float kFsdUnitM = 1e-3f;       // fsd_unit = 1 mm
 constexpr float kFsdWo2Cutoff = .85f;
-#ifdef WT_ORACLE_UNBOUNDED
-constexpr uint32_t kFsdMaxEdges = 4096;   // CPU checker: effectively unbounded, like the reference's std::vector
-#else
-constexpr uint32_t kFsdMaxEdges = 48;    // per-aperture segment cap on the device (overflow is counted)
-#endif
+constexpr uint32_t kFsdMaxEdges = 4096;   // segments per aperture: effectively unbounded, like the reference's std::vector (overflow is counted)
 
 struct fsd_edge_t {
     vec2 e, v;    // edge vector, mid point (in fsd units = mm)
@@ -40,6 +36,7 @@ struct fsd_aperture_t {
     float k;
     frame_t frame;
     uint32_t overflow;
+    uint32_t edge_offset, edge_cap;   // this aperture's segment records: [edge_offset, edge_offset + edge_cap) of the pool's edge array
 };
 // edges of one aperture: contiguous AoS (an aperture is read many times by the one lane that owns it)
 struct fsd_edges_ref_t {
@@ -155,10 +152,29 @@ WT_HD void fsd_edge_segments(const scene_t& sc, const frame_t& frame, const cone
         a = b;
     }
 }
+// Upper bound of the number of segments fsd_edge_segments emits for one scene edge (its geometry part: silhouette test, clipping,
+// subdivision; segments whose beam amplitude vanishes are skipped there).  Sizes an aperture's storage before it is built.
+WT_HD uint32_t fsd_count_segments(const scene_t& sc, const frame_t& frame, const cone_t& beam, vec2 cse, float max_edge_length, uint32_t edge_id) {
+    const edge_t edge = sc.edges[edge_id];
+    if (dot(beam.d, edge.n1) * dot(beam.d, edge.n2) >= 0.f) return 0;
+    const vec3 la = to_local(frame, edge.a - beam.o), lb = to_local(frame, edge.b - beam.o);
+    const vec2 u1{la.x, la.y}, u2{lb.x, lb.y};
+    float t1 = 0.f, t2 = 1.f;
+    const vec2 q1 = u1 / cse, q2 = u2 / cse;
+    if (!(dot(q1, q1) <= 1.f) || !(dot(q2, q2) <= 1.f)) {
+        const edge_ellipse_t intr = intersect_edge_ellipse(u1, u2, cse.x, cse.y);
+        if (intr.points == 0) return 0;
+        t1 = fmaxf_(0.f, intr.t1);
+        t2 = fminf_(1.f, intr.t2);
+    }
+    const float len = length(mix2(u1, u2, t1) - mix2(u1, u2, t2));
+    const int segments = (int)(roundf(len / max_edge_length) + .5f);
+    return segments < 1 ? 1u : (uint32_t)segments;
+}
 WT_HD void fsd_build_add_edge(const scene_t& sc, const frame_t& frame, const cone_t& beam, vec2 sigma, fsd_build_state_t& st, uint32_t edge_id,
                               fsd_aperture_t& ap, const fsd_edges_ref_t& ed) {
     fsd_edge_segments(sc, frame, beam, sigma, st.cse, st.max_edge_length, edge_id, [&](const fsd_edge_t& fe) {
-        if (ap.n_edges < kFsdMaxEdges) {
+        if (ap.n_edges < ap.edge_cap) {
             ed.set(ap.n_edges++, fe);
             st.P_total += fe.pdf;
         } else

@@ -7,10 +7,10 @@
 //     step costs a wavefront 8 x 256 B of coalesced traffic instead of 64 x 256 B of scattered traffic;
 //   * the child hits are pushed far-first on a group-owned LDS stack with ranks computed by 8 cross-lane compares — the
 //     reference's stable insertion sort (src/ads/bvh8w.cpp:45-57), so the visiting order is that of the sequential traversal;
-//   * leaf triangles are tested one per lane (leaves hold <= 4, ray shortcut subtrees <= 16 triangles, bvh8w.cpp:29,512-526);
-//     the sequential loop updates its search range only after a whole leaf (bvh8w.cpp:134-179), so testing a leaf's triangles
-//     side by side against the same range is the same computation: closest hit, tie-breaks and (cone queries) the order of the
-//     triangle list are IDENTICAL to the per-lane / CPU traversal (wt/bvh.h), unlike the 64-wide variant in coop.h.
+//   * leaf triangles are tested one per lane (leaves hold <= 4, ray shortcut subtrees <= 16 triangles, bvh8w.cpp:29,512-526):
+//     closest hit and tie-breaks are IDENTICAL to the per-lane / CPU traversal (wt/bvh.h).
+// Measured: 1.2x the per-lane kernel on plain ray queries; the same scheme for cone queries (node test per lane, leaf
+// triangles 8 at a time) was 3x SLOWER than lane-per-walk in the pipeline (groups of a wavefront diverge and serialise) and is not kept.
 // All 8 lanes of a group must call with identical arguments; groups of a wavefront run independent queries (divergent control
 // flow between groups is fine: every cross-lane operation stays inside a group).
 #pragma once
@@ -157,204 +157,6 @@ __device__ inline bool g8_shadow_ray(const scene_t& sc, vec3 ro, vec3 rd, const 
     ray_hit_t h;
     g8_ray_query<true>(sc, ro, rd, range, st, h);
     return h.dist < WT_INF;
-}
-
-// Cone query (bvh_traverse_cone, wt/bvh.h; src/ads/bvh8w.cpp:232-318): closest distance + every triangle hit inside the shrinking
-// z-slab, in the sequential traversal's order.  `budget` in units of 1 per triangle test / kNodeBudgetCost per node, as in bvh.h.
-__device__ inline bool g8_cone_query(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const g8_stack_t& st,
-                                     const uint_list_t& tris, cone_hit_t& rec, uint32_t budget = 0xFFFFFFFFu, float min_progress = -WT_INF) {
-    const int sub = g8_sub();
-    rec.dist = WT_INF;
-    rec.front_face = 0;
-    rec.ntris = 0;
-    rec.overflow = 0;
-    rec.aborted = 0;
-    rec.too_short = 0;
-    uint32_t tests = 0;
-    if (sc.n_nodes == 0) return false;
-    const vec3 ro = cone.o, rd = cone.d;
-    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
-    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
-    const float ta = cone.tan_alpha, ix = cone.x0;
-    range_t range = cone_search_range(cone, searchrange, rec.dist, z_scale);
-    int s = 1;
-    if (sub == 0) st.p[0] = stack_entry_t{0.f, 1};
-    g8_fence();
-    while (s > 0) {
-        const stack_entry_t top = st.p[s - 1];
-        --s;
-        g8_fence();
-        if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
-            tests += leaf.count;
-            if (tests > budget) {
-                rec.aborted = 1;
-                return false;
-            }
-            bool found = false;
-            for (uint32_t b = 0; b < leaf.count; b += 8) {
-                const uint32_t t = b + (uint32_t)sub;
-                bool hit = false, ff = false;
-                float d = WT_INF;
-                if (t < leaf.count) {
-                    const tri_geo_t tri = sc.tri_geo[leaf.tris_ptr + t];
-                    ff = dot(tri.n, -rd) > 0.f;
-                    cone_tri_hit_t h;
-                    if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max)) {   // numerics (bvh8w.cpp:162)
-                        hit = true;
-                        d = h.dist;
-                    }
-                }
-                const uint32_t hb = g8_bits(__ballot(hit));
-                if (!hb) continue;
-                found = true;
-                const float dm = g8_min(d);
-                if (dm < rec.dist) {
-                    const uint32_t mb = g8_bits(__ballot(hit && d == dm));
-                    rec.dist = dm;
-                    rec.front_face = (uint32_t)g8_bcast((int)ff, __ffs((int)mb) - 1);
-                }
-                const uint32_t pos = rec.ntris + (uint32_t)__popc(hb & ((1u << sub) - 1u));
-                if (hit && pos < tris.cap) tris[pos] = leaf.tris_ptr + t;
-                const uint32_t total = rec.ntris + (uint32_t)__popc(hb);
-                const uint32_t newn = total < tris.cap ? total : tris.cap;
-                rec.overflow += total - newn;
-                rec.ntris = newn;
-            }
-            if (found) {
-                if (rec.dist - searchrange.min < min_progress) {   // traversal.hpp:146,157: decided, see bvh_traverse_cone
-                    rec.too_short = 1;
-                    return true;
-                }
-                range = cone_search_range(cone, searchrange, rec.dist, z_scale);
-                if (rec.overflow > 0) range.max = fminf_(range.max, rec.dist);   // bounded-list regime, see bvh_traverse_cone
-                while (s > 0 && st.p[s - 1].t >= range.max) --s;
-            }
-            continue;
-        }
-        const bvh8_node_t& n = sc.nodes[top.ptr - 1];
-        tests += kNodeBudgetCost;
-        if (tests > budget) {
-            rec.aborted = 1;
-            return false;
-        }
-        const int32_t cp = n.child[sub];
-        float tmin = 0.f;
-        const bool hc = cone_child_test(n, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, range, tmin);
-        bool ovf = false;
-        s = g8_push_sorted(st, s, hc && cp != 0, tmin, cp, ovf);
-        if (ovf && budget != 0xFFFFFFFFu) {
-            rec.aborted = 1;   // the 64-entry stack is full: the wave-cooperative query (512 entries) takes over
-            return false;
-        }
-    }
-    return rec.ntris > 0;
-}
-
-// integrator::traverse (traversal.hpp:94-172) for one group — the policy loop of wt::traverse (bvh.h) around the group queries.
-// Extra (device only): when an accepted diffusive hit overflowed the bounded triangle list, the triangle under the beam axis
-// (find_closest_triangle, plt_bdpt_detail.hpp:362-389: the closest axis hit among the region's triangles) is resolved right
-// here with one ray query over the region's z-slab, so that the interaction kernels need no BVH stack: r.aborted = 2 marks
-// "primary in r.tuid / r.bx / r.by / r.pdist (kInvalid: the axis misses the region)".
-// resume: an earlier kernel settled every query before the cone query of segment seg0 (rays missed, diffusive attempts were too short;
-// wt::traverse hand-over state): continue with that cone query at distance dist0.
-__device__ inline trav_result_t g8_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
-                                            const g8_stack_t& st, const uint_list_t& tris, uint32_t cone_budget, bool resume = false, uint32_t seg0 = 0,
-                                            float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0) {
-    trav_result_t r;
-    r.aborted = 0;
-    r.origin = envelope.o;
-    r.empty = 1;
-    r.ballistic = 1;
-    r.dist = -WT_INF;
-    r.region_depth = 0.f;
-    r.front_face = 0;
-    r.tuid = kInvalid;
-    r.bx = r.by = 0.f;
-    r.pdist = 0.f;
-    r.ntris = 0;
-    r.overflow = 0;
-    r.n_ray_queries = r.n_cone_queries = 0;
-    const vec3 ro = envelope.o, rd = envelope.d;
-    ray_hit_t rh;
-    if (force_ray_tracing || cone_is_ray(envelope)) {
-        r.n_ray_queries++;
-        if (g8_intersect_ray(sc, ro, rd, range_t{0.f, distance}, st, rh)) {
-            r.empty = 0;
-            r.dist = rh.dist;
-            r.tuid = rh.tuid;
-            r.bx = rh.bx;
-            r.by = rh.by;
-            r.front_face = rh.front_face;
-            r.ntris = 1;
-        }
-        return r;
-    }
-    float dist = resume ? dist0 : 0.f;
-    if (resume) {
-        r.n_ray_queries = nray0;
-        r.n_cone_queries = ncone0;
-    }
-    for (uint32_t seg = resume ? seg0 : 0u;; ++seg) {
-        const float ballistic_dist = max_ballistic_distance(lambda_m, seg, 0.f);
-        if (!(resume && seg == seg0)) {   // that segment's ray query missed already; `dist` is past it
-            r.n_ray_queries++;
-            if (g8_intersect_ray(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, st, rh)) {
-                r.empty = 0;
-                r.dist = rh.dist;
-                r.tuid = rh.tuid;
-                r.bx = rh.bx;
-                r.by = rh.by;
-                r.front_face = rh.front_face;
-                r.ntris = 1;
-                return r;
-            }
-            dist += ballistic_dist;
-            if (ballistic_dist == WT_INF || dist >= distance) return r;
-        }
-        const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
-        cone_hit_t ch;
-        r.n_cone_queries++;
-        g8_cone_query(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, st, tris, ch, cone_budget, min_df_prog);
-        if (ch.aborted) {   // hand-over state for the cooperative kernel, as in wt::traverse
-            r.aborted = 1;
-            r.dist = dist;
-            r.ntris = seg;
-            r.n_cone_queries--;
-            return r;
-        }
-        if (ch.too_short) continue;
-        const bool df_empty = ch.ntris == 0 && ch.overflow == 0;
-        if (df_empty || ch.dist - dist >= min_df_prog) {
-            r.ballistic = 0;
-            r.empty = df_empty;
-            r.dist = df_empty ? -WT_INF : ch.dist;
-            r.front_face = ch.front_face;
-            r.ntris = ch.ntris;
-            r.overflow = ch.overflow;
-            r.region_depth = df_empty ? 0.f : kMajorAxisToZScale * cone_axes(envelope, ch.dist).x;
-            return r;
-        }
-    }
-}
-
-// the primary triangle of an overflowed interaction region (see g8_traverse); `r` is an accepted diffusive result
-__device__ inline void g8_resolve_primary(const scene_t& sc, const cone_t& envelope, const g8_stack_t& st, trav_result_t& r) {
-    const range_t izr{r.dist, r.dist + r.region_depth};
-    const float wtol = cone_intersection_tolerance(envelope.o, sc.world_min, sc.world_max, sc.world_max);
-    r.aborted = 2;
-    r.tuid = kInvalid;
-    ray_hit_t rh;
-    if (g8_intersect_ray(sc, envelope.o, envelope.d, grow(izr, wtol), st, rh)) {
-        const tri_geo_t g = sc.tri_geo[rh.tuid];
-        const float fptol = cone_intersection_tolerance(envelope.o, g.a, g.b, g.c);
-        if (contains(grow(izr, fptol), rh.dist)) {
-            r.tuid = rh.tuid;
-            r.bx = rh.bx;
-            r.by = rh.by;
-            r.pdist = rh.dist;
-        }
-    }
 }
 
 }   // namespace wt

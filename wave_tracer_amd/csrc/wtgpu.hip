@@ -60,7 +60,7 @@ int fail(int code, const std::string& msg) {
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_WORDS = 24 };   // (CTL_GATHER_*: queue of k_edges)
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_WORDS = 24 };   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
@@ -81,10 +81,13 @@ struct device_state_t {
     uint2* ftasks = nullptr;           // (walk, subtree) tasks of the intercepted-power sums of overflowed regions (k_flux_split / k_flux_tasks)
     uint32_t ftask_cap = 0;
     double* facc = nullptr;            // [2cap] their accumulators
+    uint32_t* epool = nullptr;         // edge-id lists of the gathered regions of one round (bump allocator, k_edges)
+    uint32_t epool_cap = 0;
     uint32_t* ctl = nullptr;           // [CTL_WORDS] queue sizes, dequeue heads, FSD pool bump counter, rounds done
     fsd_aperture_t* fsd_hdr = nullptr;
     fsd_edge_t* fsd_edges = nullptr;
     uint32_t fsd_cap = 0;
+    uint32_t fsd_ecap = 0;            // segment records of all apertures of a batch (bump allocator)
     uint32_t* strat_items = nullptr;    // [kNumKeys][cap] sample indices bucketed by connection strategy (s,t)
     uint32_t* strat_count = nullptr;    // [kNumKeys]
     uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
-        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -238,6 +241,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
         ctl[CTL_FTASK_COUNT] = 0;
         ctl[CTL_FTASK_HEAD] = 0;
         ctl[CTL_FSPLIT_HEAD] = 0;
+        ctl[CTL_EPOOL_COUNT] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -258,7 +262,8 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
             // plt_bdpt: closest-hit-only cone queries (list capacity 0: once something is hit only nearer triangles matter, wt/bvh.h) —
             // what an interaction needs of its region is the triangle under the beam axis (resolve_primary) and, for the few walks
             // without one, sums over the WHOLE region gathered later (k_edges, k_interact_c).  plt_path keeps the bounded list.
-            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};
+            uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;   // 64 triangle ids + their 64 cone-hit distances
+            const uint_list_t tris{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
             const cone_t env = walk_trace_envelope(a.sc, wk);
             trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
             if (!tr.aborted && !tr.ballistic && !tr.empty && (!a.collect_list || tr.overflow > 0)) resolve_primary(a.sc, env, stack, tr);
@@ -369,7 +374,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
     const size_t W2 = 2 * (size_t)a.st.cap;
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
         const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
@@ -406,12 +411,14 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
                 defer.has_gather = 1;
                 defer.gather_n_edges = tr.n_ray_queries;
                 defer.gather_edge_overflow = tr.n_cone_queries;
-                defer.gather_edges = a.st.tris + (size_t)w * kTriListWords;
+                const uint32_t off = __float_as_uint(tr.bx);   // offset into the round's edge pool (0xFFFFFFFF: the list slot)
+                defer.gather_edges = off != 0xFFFFFFFFu ? a.st.epool + off : a.st.tris + (size_t)w * kTriListWords;
             }
             cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
             if (PASS_B && defer.to_sampling_pass) a.st.trav[WT_TRAV_WORD(by) * W2 + w] = defer.slot;
             // a region that did not fit the bounded list: its edge set comes from a walk of the whole region (k_edges)
-            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || !a.collect_list)) need_gather = true;
+            // (... or whose list holds more than kMaxEdgeIds / 3 triangles: the per-lane edge set of pass B is bounded)
+            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list)) need_gather = true;
             if (!defer.no_primary && !defer.to_sampling_pass) {
                 wk.active = cont ? 1u : 0u;
                 soa_store(a.st.walks, W2, w, wk);
@@ -451,15 +458,32 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
         const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true);
         __syncthreads();
-        uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
-        for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = sh.edge_ids[j];
+        // sorted ids -> the round's edge pool (unbounded lists: bitmap mode) or the walk's 128-word list slot (scenes with > 32768 edges)
+        const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
+        uint32_t n_edges = g.n_edges, dropped = g.edge_overflow, off = 0xFFFFFFFFu;
+        if (bitmap) {
+            n_edges = coop_edge_count(a.sc, sh);
+            if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
+            __syncthreads();
+            off = s_item;
+            __syncthreads();
+            if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported, cannot happen in the shipped scenes
+                dropped = n_edges;
+                n_edges = 0;
+            } else
+                coop_edge_write(a.sc, sh, a.st.epool + off, n_edges);
+        } else {
+            uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
+            for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = sh.edge_ids[j];
+        }
         if (threadIdx.x == 0) {
             a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = kGatherMarker;
-            a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = g.n_edges;
-            a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = g.edge_overflow;
+            a.st.trav[WT_TRAV_WORD(bx) * W2 + w] = off;
+            a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = n_edges;
+            a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = dropped;
             if (a.profile) {
                 atomicAdd(a.st.counters + kNumCounters + 5, 1ull);
-                atomicAdd(a.st.counters + kNumCounters + 6, (unsigned long long)g.n_edges);
+                atomicAdd(a.st.counters + kNumCounters + 6, (unsigned long long)n_edges);
             }
         }
         __syncthreads();
@@ -555,7 +579,7 @@ __global__ void __launch_bounds__(64, 3) k_interact_c(launch_args_t a, int in) {
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
     const size_t W2 = 2 * (size_t)a.st.cap;
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
         if (lane == 0) s_item = atomicAdd(ctl + CTL_INTC_HEAD, 1u);
         __syncthreads();
@@ -654,7 +678,7 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
-        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -697,7 +721,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, in
             soa_load(a.st.walks, W2, w, pw);
             trav_result_t tr;
             soa_load(a.st.trav, W2, w, tr);
-            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
+            uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
+            const uint_list_t tris{slot, 1u, kMaxConeTris, reinterpret_cast<float*>(slot + kMaxConeTris)};
             const utd_edges_ref_t utd{a.st.utd + (size_t)w * kUtdMaxEdges, 1};
             cont = path_walk_step(a.sc, pw, tr, tris, utd, a.film, a.seed, sample_id, stream, stack, &ctr);
             if (!cont) path_finish(a.sc, a.film, pw);
@@ -805,7 +830,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_connect_strat(launch_args_t a) {
     stack_ref_t stack;
     lds_stack(lds, spill, stack);
     const size_t W2 = 2 * (size_t)a.st.cap;
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap};
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap, a.st.ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
         const uint32_t idx = wave_grab(a.st.ctl + CTL_STRAT_HEAD) + (threadIdx.x & 63);
         if (idx - (threadIdx.x & 63) >= total) break;
@@ -902,7 +927,7 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
     const float* c = cones + 10 * (size_t)i;
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});
     const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
-    const uint_list_t tris{scratch_tris + i, n, kMaxConeTris};
+    const uint_list_t tris{scratch_tris + i, n, kMaxConeTris, reinterpret_cast<float*>(scratch_tris + (size_t)n * kMaxConeTris) + i};
     const trav_result_t tr = traverse(sc, env, c[9], WT_INF, false, stack, tris);
     dist[i] = tr.dist;
     flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
@@ -926,37 +951,49 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
     }
 }
 
-// 8-lane-group variant of k_traverse_cones (one cone per group); lists come out in the sequential traversal's order
-__global__ void __launch_bounds__(kBlock) k_traverse_cones_g8(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
-                                                              uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
-    __shared__ stack_entry_t lds[kG8Stack * kG8Groups];
-    const uint32_t i = blockIdx.x * kG8Groups + (threadIdx.x >> 3);
+// Region summaries of cone queries of ANY size (parity tests of the whole-region machinery): one wavefront per cone runs the
+// traversal policy with closest-hit-only cone queries, then — for a diffusive hit — resolves the triangle under the axis and walks
+// the region [dist, dist + 2 x major axis] for its triangle count, sorted classified-edge set and intercepted power (sigma = axes/3).
+__global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* cones, uint32_t n, uint32_t edge_cap, float* dist, uint32_t* flags,
+                                                      uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux) {
+    __shared__ coop_shared_t sh;
+    const uint32_t i = blockIdx.x;
     if (i >= n) return;
-    const g8_stack_t st{lds + kG8Stack * (threadIdx.x >> 3)};
     const float* c = cones + 10 * (size_t)i;
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});
     const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
-    const uint_list_t tris{scratch_tris + (size_t)i * kMaxConeTris, 1u, kMaxConeTris};
-    const trav_result_t tr = g8_traverse(sc, env, c[9], WT_INF, false, st, tris, 0xFFFFFFFFu);
-    if ((threadIdx.x & 7u) != 0) return;
-    dist[i] = tr.dist;
-    flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
-    ntris[i] = tr.ballistic ? (tr.empty ? 0 : 1) : tr.ntris;
-    for (uint32_t j = 0; j < cap; ++j) out_tris[(size_t)i * cap + j] = kInvalid;
+    const uint_list_t none{nullptr, 1u, 0u};
+    const trav_result_t tr = coop_traverse(sc, env, c[9], WT_INF, false, sh, none);
+    uint32_t prim = kInvalid;
+    gather_out_t ge{0.f, 0u, 0u, 0u}, gf{0.f, 0u, 0u, 0u};
     if (tr.ballistic) {
-        if (!tr.empty) out_tris[(size_t)i * cap] = tr.tuid;
-    } else {
-        uint32_t m = 0;
-        for (uint32_t j = 0; j < tr.ntris; ++j) {
-            const uint32_t v = tris[j];
-            uint32_t pos = m < cap ? m : cap;
-            while (pos > 0 && out_tris[(size_t)i * cap + pos - 1] > v) {
-                if (pos < cap) out_tris[(size_t)i * cap + pos] = out_tris[(size_t)i * cap + pos - 1];
-                --pos;
-            }
-            if (pos < cap) out_tris[(size_t)i * cap + pos] = v;
-            if (m < cap) ++m;
+        prim = tr.tuid;
+    } else if (!tr.empty) {
+        const range_t izr{tr.dist, tr.dist + tr.region_depth};
+        const float wtol = cone_intersection_tolerance(env.o, sc.world_min, sc.world_max, sc.world_max);
+        ray_hit_t rh;
+        if (coop_ray_query(sc, env.o, env.d, grow(izr, wtol), sh, rh)) {
+            const tri_geo_t g = sc.tri_geo[rh.tuid];
+            if (contains(grow(izr, cone_intersection_tolerance(env.o, g.a, g.b, g.c)), rh.dist)) prim = rh.tuid;
         }
+        const vec2 ax = cone_axes(env, tr.dist);
+        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, sh, false, true);
+        __syncthreads();
+        if (sc.n_edges <= kCoopEdgeBits) {
+            ge.n_edges = coop_edge_count(sc, sh);
+            coop_edge_write(sc, sh, edges + (size_t)i * edge_cap, edge_cap);
+        } else
+            for (uint32_t j = threadIdx.x; j < ge.n_edges && j < edge_cap; j += 64) edges[(size_t)i * edge_cap + j] = sh.edge_ids[j];
+        __syncthreads();
+        gf = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope}, tr.front_face != 0, sh, true, false);
+    }
+    if (threadIdx.x == 0) {
+        dist[i] = tr.dist;
+        flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
+        primary[i] = prim;
+        ntris[i] = gf.n_tris;
+        nedges[i] = ge.n_edges + ge.edge_overflow;
+        flux[i] = gf.flux;
     }
 }
 
@@ -1139,11 +1176,16 @@ int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
         st.ftask_cap = path_mode ? 1u : (1u << 22);
         if ((rc = dmalloc(s, &st.ftasks, (size_t)st.ftask_cap))) return rc;
         if ((rc = dmalloc(s, &st.facc, path_mode ? 1 : W2))) return rc;
+        st.epool_cap = path_mode ? 1u : (1u << 23);
+        if ((rc = dmalloc(s, &st.epool, (size_t)st.epool_cap))) return rc;
         if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
         HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
         st.fsd_cap = (h.opts.FSD && !h.opts.force_ray_tracing && !path_mode) ? (uint32_t)std::min<uint64_t>(W2, 1u << 22) : 1u;
         if ((rc = dmalloc(s, &st.fsd_hdr, st.fsd_cap))) return rc;
-        if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_cap * kFsdMaxEdges))) return rc;
+        // apertures own variable-size ranges of one segment pool: 64 records per sample in flight (measured mean of the headline
+        // workload: 1.6 per sample; an aperture holds up to kFsdMaxEdges = 4096)
+        st.fsd_ecap = st.fsd_cap > 1 ? (uint32_t)std::min<uint64_t>(64ull * st.cap + kFsdMaxEdges, 1ull << 28) : 1u;
+        if ((rc = dmalloc(s, &st.fsd_edges, (size_t)st.fsd_ecap))) return rc;
         if ((rc = dmalloc(s, &st.strat_items, path_mode ? 1 : (size_t)kNumKeys * st.cap))) return rc;
         if ((rc = dmalloc(s, &st.strat_count, (size_t)kNumKeys))) return rc;
         if ((rc = dmalloc(s, &st.strat_prefix, (size_t)kNumKeys + 1))) return rc;
@@ -1418,7 +1460,7 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
 int wtgpu_trace_rays(wtgpu_scene* s, void* stream_, const float* d_rays, uint32_t n, float* d_dist, uint32_t* d_tuid, float* d_bary, uint32_t* d_front) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const bool per_lane = getenv("WTGPU_RAYS_PER_LANE") != nullptr;   // A/B switch of the query kernels (parity tests run both)
+    static const bool per_lane = getenv("WTGPU_RAYS_G8") == nullptr;   // A/B switch: the pipeline's per-lane traversal (default) / 8-lane groups (wt/g8.h)
     if (per_lane)
         hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
     else
@@ -1431,16 +1473,22 @@ int wtgpu_traverse_cones(wtgpu_scene* s, void* stream_, const float* d_cones, ui
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     uint32_t* scratch = nullptr;
-    HIP_CHECK(hipMalloc((void**)&scratch, (size_t)n * kMaxConeTris * 4));
-    if (getenv("WTGPU_RAYS_PER_LANE"))
-        hipLaunchKernelGGL(k_traverse_cones, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_cones, n, cap, d_dist, d_flags, d_ntris,
-                           d_tris, scratch);
-    else
-        hipLaunchKernelGGL(k_traverse_cones_g8, dim3((n + kG8Groups - 1) / kG8Groups), dim3(kBlock), 0, stream, s->dev, d_cones, n, cap, d_dist, d_flags,
-                           d_ntris, d_tris, scratch);
+    HIP_CHECK(hipMalloc((void**)&scratch, (size_t)n * kMaxConeTris * 4 * 2));   // triangle ids + hit distances
+    hipLaunchKernelGGL(k_traverse_cones, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_cones, n, cap, d_dist, d_flags, d_ntris,
+                       d_tris, scratch);
     hipError_t e = hipStreamSynchronize(stream);
     hipFree(scratch);
     HIP_CHECK(e);
+    return WTGPU_OK;
+}
+
+int wtgpu_query_regions(wtgpu_scene* s, void* stream_, const float* d_cones, uint32_t n, uint32_t edge_cap, float* d_dist, uint32_t* d_flags,
+                        uint32_t* d_primary, uint32_t* d_ntris, uint32_t* d_nedges, uint32_t* d_edges, float* d_flux) {
+    if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
+    if (n == 0) return WTGPU_OK;
+    hipLaunchKernelGGL(k_query_regions, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream_), s->dev, d_cones, n, edge_cap, d_dist, d_flags, d_primary,
+                       d_ntris, d_nedges, d_edges, d_flux);
+    HIP_CHECK(hipGetLastError());
     return WTGPU_OK;
 }
 
