@@ -549,7 +549,9 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
     // primary triangle
     uint32_t primary = kInvalid;
     ray_tri_hit_t phit{WT_INF, 0.f, 0.f};
-    float integrated_flux = 0.f;
+    // summed in f64 (the reference sums in f32, plt_bdpt_detail.hpp:391-416): a beam over a dense mesh is almost entirely blocked, 1 - flux
+    // is small, and the f32 rounding of a sum of 10^3..10^4 terms (~1e-4) decides 1/I; an accurate sum is at least order-independent
+    double integrated_flux = 0.0;
     if (is_ballistic) {
         primary = tr.tuid;
         phit.dist = tr.dist;
@@ -748,7 +750,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
                         for (uint32_t i = 0; i < tr.ntris; ++i)
                             integrated_flux += region_triangle_flux(sc, beam_frame, envelope, izr, sigma, tris[i], tr.front_face != 0);
                     }
-                    const float I = 1.f - integrated_flux;
+                    const float I = (float)(1.0 - integrated_flux);
                     ap.recp_I = I > 0.f ? 1.f / I : 0.f;
                     pool.hdr[slot] = ap;
                 }

@@ -325,7 +325,7 @@ __device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, cons
 // one wavefront walks the region once more — every triangle that meets the traced cone inside the final slab — and accumulates
 // them directly: the result is that of an unbounded list (the reference's std::vector), whatever the triangle count.
 struct gather_out_t {
-    float flux;
+    double flux;   // f64 sum (see bdpt_walk_step)
     uint32_t n_edges, edge_overflow;
     uint32_t n_tris;   // triangles of the region (met by the cone inside the slab)
 };
@@ -336,7 +336,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
     const uint32_t edge_cap = 96;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
-    gather_out_t out{0.f, 0u, 0u, 0u};
+    gather_out_t out{0.0, 0u, 0u, 0u};
     const bool edges_only = do_edges && !do_flux;
     // edge set as an LDS bitmap whenever the scene's edge ids fit (n_edges <= 32768): no capacity limit, ids come out sorted; the
     // caller reads sh.edge_bits (coop_edge_count / coop_edge_write).  Larger scenes: the sorted 96-entry list (overflow counted).
@@ -390,13 +390,11 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                 }
             }
             out.n_tris += (uint32_t)__popcll(__ballot(member));
-            // sum in lane order (deterministic)
+            // f64 butterfly sum (order-independent to ~1e-16)
+            double csum = (double)contrib;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float o = __shfl_up(contrib, off, 64);
-                if (lane >= off) contrib += o;
-            }
-            out.flux += __shfl(contrib, 63, 64);
+            for (int off = 32; off > 0; off >>= 1) csum += __shfl_xor(csum, off, 64);
+            out.flux += csum;
             // classified edges are rare (a few hundred in a 170K-triangle scene): insert them one by one into the sorted LDS
             // list, all lanes cooperating on the search
             if (bitmap) {

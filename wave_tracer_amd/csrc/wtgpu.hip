@@ -550,10 +550,10 @@ __global__ void __launch_bounds__(64, 3) k_flux_tasks(launch_args_t a) {
         const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
         unsigned long long gst[2] = {0, 0};
-        const float flux = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{sd3.x, sd3.y}, want_front, sh, true, false,
-                                       a.profile ? gst : nullptr, (int32_t)task.y).flux;
+        const double flux = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{sd3.x, sd3.y}, want_front, sh, true, false,
+                                        a.profile ? gst : nullptr, (int32_t)task.y).flux;
         if (threadIdx.x == 0) {
-            if (flux != 0.f) unsafeAtomicAdd(&a.st.facc[w], (double)flux);
+            if (flux != 0.0) unsafeAtomicAdd(&a.st.facc[w], flux);
             if (a.profile) {   // WTGPU_PROFILE=1: sizes of the gathered regions
                 atomicAdd(a.st.counters + kNumCounters + 0, 1ull);
                 atomicAdd(a.st.counters + kNumCounters + 1, gst[0]);
@@ -603,16 +603,16 @@ __global__ void __launch_bounds__(64, 3) k_interact_c(launch_args_t a, int in) {
         const range_t izr{tr.dist, tr.dist + tr.region_depth};
         const vec3 sd3 = beam_footprint(wk.beam, tr.dist) / kBeamEnvelope;
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
-        float flux;
+        double flux;
         if (tr.tuid == kGatherMarker) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
-            flux = (float)a.st.facc[w];
+            flux = a.st.facc[w];
         } else {   // lane = triangle of the (complete) list, wave reduction (bdpt_walk_step computes the same sum triangle by triangle)
             const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
-            flux = (uint32_t)lane < tr.ntris ? region_triangle_flux(a.sc, cone_frame(wk.beam.env), wk.beam.env, izr, vec2{sd3.x, sd3.y}, tl[lane], tr.front_face != 0) : 0.f;
+            flux = (uint32_t)lane < tr.ntris ? (double)region_triangle_flux(a.sc, cone_frame(wk.beam.env), wk.beam.env, izr, vec2{sd3.x, sd3.y}, tl[lane], tr.front_face != 0) : 0.0;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) flux += __shfl_xor(flux, off, 64);
         }
-        const float I = 1.f - flux;
+        const float I = (float)(1.0 - flux);
         ap.recp_I = I > 0.f ? 1.f / I : 0.f;
         if (lane == 0) pool.hdr[slot] = ap;
         // ---- rejection sampling, 64 tries per step
@@ -965,7 +965,7 @@ __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* c
     const uint_list_t none{nullptr, 1u, 0u};
     const trav_result_t tr = coop_traverse(sc, env, c[9], WT_INF, false, sh, none);
     uint32_t prim = kInvalid;
-    gather_out_t ge{0.f, 0u, 0u, 0u}, gf{0.f, 0u, 0u, 0u};
+    gather_out_t ge{0.0, 0u, 0u, 0u}, gf{0.0, 0u, 0u, 0u};
     if (tr.ballistic) {
         prim = tr.tuid;
     } else if (!tr.empty) {
@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* c
         primary[i] = prim;
         ntris[i] = gf.n_tris;
         nedges[i] = ge.n_edges + ge.edge_overflow;
-        flux[i] = gf.flux;
+        flux[i] = (float)gf.flux;
     }
 }
 
