@@ -4,9 +4,10 @@
 A *step* = one pass of the hot path over one batch of synthetic input = 1 sample per pixel of the cornell-box
 (stand-in) scene at 1440x1440, visible-spectrum wave mode (BDPT, max_depth 16, MIS, RR, Fraunhofer FSD): 2,073,600
 samples.  Inputs (flattened scene, BVH, LUTs) are resident in HBM before the timed region; film buffers are torch
-tensors on the GPU.  Multi-GPU: samples are sharded by sample index across ranks (weak scaling: every rank renders
-`steps` samples per pixel), no collective on the data path; one RCCL reduce of the film afterwards (outside the
-timed region it would be <2 ms; it is included in the timed region for honesty).
+tensors on the GPU.  Multi-GPU: samples are sharded by sample index across ranks (weak scaling by default: every rank renders
+`steps` passes; --scaling strong: the ranks split the --spp-per-step samples of every step), no collective on the data path; one RCCL
+reduce of the film afterwards (outside the timed region it would be <2 ms; it is included in the timed region for honesty).
+`python bench.py --gpus N` without a launcher starts its N ranks itself (torch.distributed.run, 127.0.0.1).
 
 Prints ONE JSON line (rank 0).
 """
@@ -60,7 +61,22 @@ def main():
     ap.add_argument("--ray-tracing", action="store_true", help="diagnostic: --ray-tracing of the reference CLI (wt_context.hpp:43), no cones / diffraction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="film reduce: nccl = RCCL over xGMI (one GPU per rank); gloo: host reduce, ranks may share a GPU (launcher tests on 1-GPU boxes)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--spp-per-step", type=int, default=0, help="samples per element and step (default 1; strong scaling: the number of ranks)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become the launcher (one rank per GPU over RCCL, rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     import torch
     import torch.distributed as dist
@@ -74,8 +90,13 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank %= max(1, torch.cuda.device_count())
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, f"--gpus {args.gpus} but the launcher started {dist.get_world_size()} ranks"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -85,8 +106,13 @@ def main():
     value, weight, light = alloc_films(sc, dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     K, Wm = args.steps, args.warmup
-    # weak scaling: every rank renders K (+W) samples per pixel on its own disjoint sample range
-    base = rank * (K + Wm)
+    # one step = S samples per element over the whole job.  weak: every rank renders its own S per step (work per GPU fixed); strong:
+    # the ranks split the S samples of a step (total work fixed).  Sample indices are disjoint across ranks and steps.
+    S = args.spp_per_step or (world if args.scaling == "strong" else 1)
+    if args.scaling == "strong":
+        assert S % world == 0, "--spp-per-step must be a multiple of the number of ranks for strong scaling"
+    s_rank = S // world if args.scaling == "strong" else S          # samples per element this rank renders per step
+    base = rank * (K + Wm) * s_rank
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -95,7 +121,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     for s in range(Wm):
-        sc.render_into(value, weight, light, base + s, base + s + 1, 1, stream)
+        sc.render_into(value, weight, light, base + s * s_rank, base + (s + 1) * s_rank, 1, stream)
     sc.reset_counters()
     for t in (value, weight, light):
         t.zero_()
@@ -104,22 +130,28 @@ def main():
     # wtgpu_render_async only enqueues and does not make `stream` wait: consecutive steps (more samples into the same film
     # accumulators) pipeline on the GPU; the join + closing sync below complete all K steps inside the timed region
     for s in range(K):
-        sc.render_async_into(value, weight, light, base + Wm + s, base + Wm + s + 1, 1, stream)
+        sc.render_async_into(value, weight, light, base + (Wm + s) * s_rank, base + (Wm + s + 1) * s_rank, 1, stream)
     sc.join(stream)
     if distributed:
         for t in (value, weight, light):
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            if args.backend == "gloo":
+                torch.cuda.synchronize(dev)
+                h = t.cpu()
+                dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
     sync()
     dt = time.time() - t0
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     counters = sc.counters()
     tsum = sc.timings()      # HIP-event kernel times accumulated over the timed region (reset after the warm-up)
     if rank == 0:
-        samples_total = npix * K * world
+        samples_total = npix * K * s_rank * world
         msps = samples_total / dt / 1e6
         # ---- roofline of the dominant kernel.  Algorithmic bytes per sample from SURVEY.md §8(d):
         #   B = N_seg*2*S_path + N_vtx*S_vtx + N_conn*2*S_vtx + N_q*S_hit + B_film   with the measured per-sample counts.
@@ -142,19 +174,24 @@ def main():
         # credited with the WHOLE term (an upper bound of its algorithmic bytes, hence of `achieved`)
         share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
-        # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once):
-        # the same launch count rocprofv3 --kernel-trace --stats averages over (profiles/r01_kernel_stats_1440.csv)
+        # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once): `launches`
+        # is the count rocprofv3 --kernel-trace --stats averages over (profiles/r02_kernel_stats_*.csv), `launches_with_work` the rounds
+        # that had walks queued.  achieved = algorithmic bytes / the kernel's HIP-event time: the same for either count.
         rounds = 96 * tsum["batches"]
         launches = {"k_trace": rounds, "k_trace_heavy": rounds, "k_interact": rounds, "k_interact_b": rounds, "k_connect": tsum["batches"],
                     "k_generate": tsum["batches"]}[dom]
+        with_work = tsum["trace_launches"] if launches == rounds else launches
         avg_ms = kernels[dom] / max(1, launches)
-        alg_bytes_per_launch = share * npix * K / max(1, launches)
+        steps_rank = K * s_rank                                   # passes over the film this rank rendered
+        alg_bytes_per_launch = share * npix * steps_rank / max(1, launches)
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # whole path: all algorithmic bytes of a step over the wall time of a step
+        whole = bytes_per_sample * npix * s_rank / (dt / K) / 1e9
         # HBM traffic of that kernel from the PMC passes of the same command (tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
-        # separate rocprofv3 --pmc runs, summary committed under profiles/); bytes per launch with work, like `achieved`
+        # separate rocprofv3 --pmc runs, summary committed under profiles/), per launch like `achieved`
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pt = json.load(f)
             if dom in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
                 traffic = pt["kernels"][dom]["hbm_bytes_per_launch"]
@@ -164,18 +201,23 @@ def main():
             "metric": ("Msamples/sec (whole node), cornell-box 1440^2 wave-mode" if (args.scene, args.res) == ("cornell_box", 1440)
                        else f"Msamples/sec (whole node), {args.scene} res={args.res}"),
             "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} stand-in (the scene file's geometry, LFS meshes replaced by procedural stand-ins) res={args.res} "
                                    f"{['plt_bdpt', 'plt_path forward', 'plt_path backward'][int(sc.info.integrator)]} max_depth={int(sc.info.max_depth)} "
-                                   f"{'MIS RR Fraunhofer-FSD' if int(sc.info.integrator) == 0 else 'UTD-FSD'}, 1 spp per step",
-                       "samples_per_step": npix, "tris": int(sc.info.n_tris),
+                                   f"{'MIS RR Fraunhofer-FSD' if int(sc.info.integrator) == 0 else 'UTD-FSD'}, {S} spp per step; interaction regions exact "
+                                   f"(unbounded: regions beyond the 64-triangle fast path are walked in full, DESIGN.md §5)",
+                       "samples_per_step": npix * S, "tris": int(sc.info.n_tris),
                        "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "round_launches_with_work": tsum["trace_launches"],
+                         "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "launches_with_work": with_work,
+                         "avg_launch_ms_with_work": kernels[dom] / max(1, with_work),
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "alg_bytes_per_sample_all_kernels": bytes_per_sample,
-                         "kernel_ms_per_step": {k: v / K for k, v in kernels.items()}},
+                         "whole_path": {"alg_bytes_per_step": bytes_per_sample * npix * s_rank, "achieved": whole, "frac": whole / 8000.0},
+                         # HIP-event brackets on the 4 concurrent slice streams: each includes the time the kernel shares the GPU with the
+                         # other streams' kernels, so the sum exceeds ms_per_step (exclusive times: profiles/r02_kernel_stats_streams1.csv)
+                         "kernel_ms_per_step_stream_summed": {k: v / K for k, v in kernels.items()}},
             "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,
                                     "cone_tri_overflow": counters["cone_tri_overflow"] / ns, "fsd_interactions": counters["fsd_interactions"] / ns,
                                     "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns},

@@ -1,0 +1,209 @@
+/* wtgpu_scene.h — the flattened scene description consumed by wtgpu_scene_create_from_desc (include/wtgpu.h): plain C structs of
+ * host pointers and scalars, everything the per-sample integrators dereference.  A port of the reference's
+ * loader fills one wtgpu_scene_desc from scene_t / ads_t after `scene_bootstrap_t` finished (src/main.cpp:634-648) — see
+ * INTEGRATION.md for the field-by-field source in the reference.  All arrays are caller-owned and must outlive the handle
+ * (or at least wtgpu_scene_upload).
+ *
+ * GENERATED from wave_tracer_amd/csrc/wt/scene.h by tools/gen_public_scene_header.py (the library static_asserts that both layouts
+ * are identical: wave_tracer_amd/csrc/scene_abi_check.h).  Units: lengths in metres, wavenumbers k in 1/mm.
+ * Triangle / BVH conventions: include/wt/ads/common.hpp:37-72, include/wt/ads/bvh8w/bvh8w_node.hpp:18-41. */
+#ifndef WTGPU_SCENE_H
+#define WTGPU_SCENE_H
+#include <stdint.h>
+
+#define WTGPU_ALIGN16 __attribute__((aligned(16)))
+
+#define WTGPU_INVALID 0xFFFFFFFFu
+
+typedef struct wtgpu_vec2 { float x, y; } wtgpu_vec2;
+typedef struct wtgpu_vec3 { float x, y, z; } wtgpu_vec3;
+typedef struct wtgpu_frame { wtgpu_vec3 t, b, n; } wtgpu_frame;   /* orthonormal frame (math/frame.hpp) */
+
+typedef struct WTGPU_ALIGN16 wtgpu_tri_geo {   /* 48 B, 3 x 16-B loads */
+    wtgpu_vec3 a, b, c, n;
+} wtgpu_tri_geo;
+typedef struct wtgpu_tri_meta {   /* 20 B */
+    uint32_t shape_idx, shape_tri_idx;
+    uint32_t edge[3];   /* edge_ab, edge_bc, edge_ca (kInvalid = none) */
+} wtgpu_tri_meta;
+typedef struct wtgpu_tri_shade {   /* per triangle shading data (mesh/triangle.hpp), BVH order */
+    wtgpu_vec3 n0, n1, n2;
+    wtgpu_vec2 uv0, uv1, uv2;
+    wtgpu_vec3 dpdu;
+    uint32_t has_uv;
+} wtgpu_tri_shade;
+typedef struct wtgpu_edge {   /* ads/common.hpp:53-72 */
+    wtgpu_vec3 a, b, e;
+    wtgpu_vec3 n1, t1, n2, t2;
+    float alpha;
+    uint32_t tri1, tri2;   /* kInvalid = boundary edge */
+} wtgpu_edge;
+
+/* 8-wide BVH node: child AABBs in SoA inside the node. */
+/* child ptr: 0 empty, >0 internal node index+1, <0 -(leaf index+1); root ptr = 1. */
+typedef struct WTGPU_ALIGN16 wtgpu_bvh8_node {
+    float minx[8], miny[8], minz[8];
+    float maxx[8], maxy[8], maxz[8];
+    int32_t child[8];
+    uint32_t tris_start, tris_count;
+    uint32_t edge_mask;   /* bit i: the subtree of child i holds a triangle with a classified edge (ads/common.hpp:53-72); prunes the */
+                          /* interaction-region edge gather (bvh_gather_edges) — a handful of silhouette edges in 10^5 triangles */
+    uint32_t pad[5];   /* 256 B */
+} wtgpu_bvh8_node;
+typedef struct wtgpu_bvh8_leaf {
+    uint32_t tris_ptr, count;
+} wtgpu_bvh8_leaf;
+
+typedef struct wtgpu_shape {
+    int32_t material;
+    int32_t emitter;   /* -1 none */
+    float surface_area, recp_surface_area;
+    uint32_t tri_offset;   /* into shape_tri_tuid / shape_tri_cdf */
+    uint32_t tri_count;
+} wtgpu_shape;
+
+/* ---- spectra -------------------------------------------------------------------------------------- */
+enum { WTGPU_SPEC_CONST = 0, WTGPU_SPEC_TABLE = 1, WTGPU_SPEC_DISCRETE = 2 };   /* spectrum_type */
+typedef struct wtgpu_spectrum {
+    int32_t type;
+    float kmin, kmax;         /* support [1/mm]; value 0 outside (table) / line position in kmin (discrete) */
+    uint32_t offset, count;   /* into spectra_data: count knots uniformly spaced in k over [kmin,kmax] */
+    float c_re, c_im;         /* constant value / discrete line value */
+    uint32_t is_complex;      /* table holds count re-values followed by count im-values */
+} wtgpu_spectrum;
+
+/* ---- materials ----------------------------------------------------------------------------------- */
+enum { WTGPU_MAT_DIFFUSE = 0, WTGPU_MAT_DIELECTRIC = 1, WTGPU_MAT_SURFACE_SPM = 2 };   /* material_type */
+enum { WTGPU_PROFILE_DIRAC = 0, WTGPU_PROFILE_FRACTAL = 1, WTGPU_PROFILE_GAUSSIAN = 2 };   /* profile_type */
+typedef struct wtgpu_material {
+    int32_t type;
+    uint32_t two_sided;     /* bsdf/two_sided wrapper */
+    float scale;            /* bsdf/scale wrapper (constant texture) */
+    int32_t refl_spec;      /* diffuse: reflectance spectrum */
+    float refl_tex_scale;   /* constant stand-in for texture modulation of reflectance */
+    int32_t ior_spec;       /* dielectric / surface_spm: interior IOR spectrum (complex) */
+    int32_t ext_ior_spec;   /* exterior IOR spectrum (-1 = 1) */
+    int32_t profile;        /* surface_spm: PROFILE_* */
+    float roughness;        /* fractal: perceptual roughness */
+    float gamma;            /* fractal: log-log slope */
+    float gauss_sigma;      /* gaussian: > 0: explicit rms `sigma` [1/mm]; otherwise parametrised by `roughness` like the fractal profile */
+    float refl_scale, trans_scale;
+} wtgpu_material;
+
+/* ---- emitters ------------------------------------------------------------------------------------ */
+enum { WTGPU_EMIT_SPOT = 0, WTGPU_EMIT_AREA = 1, WTGPU_EMIT_POINT = 2, WTGPU_EMIT_DIRECTIONAL = 3 };   /* emitter_type */
+typedef struct wtgpu_emitter {
+    int32_t type;
+    int32_t spectrum;   /* radiant intensity (spot) / radiance (area), value multiplies `scale` */
+    float scale;
+    float phase_space_extent_scale;
+    /* spot */
+    wtgpu_vec3 position;
+    wtgpu_frame frame;   /* to_world rotation: local z = mean direction */
+    float cutoff, falloff, cos_cutoff, cos_falloff, recp_cutoff_range, max_tan_alpha;
+    float extent;   /* <=0: default 10 lambda */
+    /* directional (infinite emitter): position = world centre, frame.n = direction TO the emitter; the target is the disk that */
+    /* bounds the world AABB projected along that direction (directional.hpp:46-75) */
+    float target_radius, target_area, far_dist, tan_alpha_at_target;
+    /* area */
+    int32_t shape;
+    /* sampling tables */
+    float select_pmf;           /* emitters_power_distribution.pdf */
+    int32_t k_dist;             /* index into kdists */
+} wtgpu_emitter;
+
+/* spectral sampling distribution per emitter (emission x sensitivity product) */
+typedef struct wtgpu_kdist {
+    int32_t discrete;          /* 1: single line at kmin with mass 1 */
+    float kmin, kmax;
+    uint32_t offset, count;    /* pdf knots (count), cdf knots (count) in kdist_data: pdf[0..count), cdf[0..count) */
+} wtgpu_kdist;
+
+/* ---- sensor / film ------------------------------------------------------------------------------ */
+enum { WTGPU_SENSOR_PERSPECTIVE = 0, WTGPU_SENSOR_VIRTUAL_PLANE = 1 };   /* sensor_type */
+typedef struct wtgpu_sensor {
+    int32_t type;
+    uint32_t width, height, channels;
+    uint32_t polarimetric;   /* film stores the 4 Stokes components per channel (wtgpu_sensor<polarimetric>, film.hpp) instead of intensity */
+    uint32_t ray_trace_only;
+    /* film reconstruction filter */
+    float rfilter_sigma;   /* in pixels (= .25 * rfilter_scale) */
+    int32_t rf_radius;
+    uint32_t flip_x, flip_y;
+    /* response: per-channel spectrum ids */
+    int32_t response_spec[4];
+    /* perspective */
+    wtgpu_vec3 position;
+    wtgpu_frame frame;            /* camera to world rotation (t = right, b = up, n = view dir) */
+    float inv_cam[16];        /* inverse(viewport * perspective), row-major 4x4 */
+    float cam[16];            /* viewport * perspective, row-major */
+    wtgpu_vec3 ddir_dx, ddir_dy;
+    float sensor_area;        /* prod(snsr_extent) [m^2] */
+    float element_extent_x;   /* [m] */
+    float sourcing_tan_alpha;
+    float phase_space_extent_scale;
+    /* virtual plane */
+    wtgpu_vec3 origin;              /* sensor_origin (corner) */
+    wtgpu_vec2 extent, element_extent;
+    float recp_area;
+    float requested_tan_alpha;   /* <0: none (MUB) */
+} wtgpu_sensor;
+
+enum { WTGPU_INTEGRATOR_BDPT = 0, WTGPU_INTEGRATOR_PATH_FORWARD = 1, WTGPU_INTEGRATOR_PATH_BACKWARD = 2 };   /* integrator_type */
+typedef struct wtgpu_integrator_opts {
+    int32_t max_depth;
+    uint32_t integrator;   /* INTEGRATOR_* (plt_bdpt, or plt_path with its transport direction) */
+    uint32_t MIS, RR, FSD, sensor_direct, emitter_direct;
+    uint32_t force_ray_tracing;
+    /* test hooks: evaluate a single (s,t) strategy with unit MIS weight (0 = all strategies; v>0 selects v-1) */
+    uint32_t debug_only_s, debug_only_t;
+} wtgpu_integrator_opts;
+
+/* Fraunhofer FSD inverse-CDF LUT (interaction/fsd/fraunhofer/fsd_lut.hpp:27-69), regenerated on the host. */
+typedef struct wtgpu_fsd_lut {
+    uint32_t n_theta;   /* Nsamples */
+    uint32_t m;         /* Msamples (square) */
+    const float* icdf_theta1;
+    const float* icdf_theta2;
+    const float* icdf1;   /* [m][m] */
+    const float* icdf2;
+} wtgpu_fsd_lut;
+
+typedef struct wtgpu_scene_desc {
+    /* geometry */
+    const wtgpu_tri_geo* tri_geo;
+    const wtgpu_tri_meta* tri_meta;
+    const wtgpu_tri_shade* tri_shade;
+    uint32_t n_tris;
+    const wtgpu_edge* edges;
+    uint32_t n_edges;
+    const wtgpu_bvh8_node* nodes;
+    uint32_t n_nodes;
+    const wtgpu_bvh8_leaf* leaves;
+    uint32_t n_leaves;
+    wtgpu_vec3 world_min, world_max;
+    /* shapes */
+    const wtgpu_shape* shapes;
+    uint32_t n_shapes;
+    const uint32_t* shape_tri_tuid;   /* per shape: mesh tri index -> tuid */
+    const float* shape_tri_cdf;       /* per shape: area cdf (tri_count+1 entries each, concatenated with +shape index offset) */
+    /* materials & spectra */
+    const wtgpu_material* materials;
+    uint32_t n_materials;
+    const wtgpu_spectrum* spectra;
+    uint32_t n_spectra;
+    const float* spectra_data;
+    /* emitters */
+    const wtgpu_emitter* emitters;
+    uint32_t n_emitters;
+    const float* emitter_cdf;   /* n_emitters+1 */
+    const wtgpu_kdist* kdists;
+    const float* kdist_data;
+    /* sensor */
+    wtgpu_sensor sensor;
+    wtgpu_integrator_opts opts;
+    wtgpu_fsd_lut lut;
+} wtgpu_scene_desc;
+
+
+#endif /* WTGPU_SCENE_H */

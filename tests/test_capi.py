@@ -104,3 +104,23 @@ def test_develop_matches_film_storage_semantics(built):
     out = develop(sc, v, w, l, 4)
     exp = np.where(w[..., None] != 0, v / np.where(w == 0, 1, w)[..., None], 0.0) + l / 4
     assert np.allclose(out, exp)
+
+
+def test_c_host_program_is_built(built):
+    """wave_tracer_amd/csrc/smoke.c — a plain-C host compiled against include/ only — is built with the library (it runs in smoke() and in
+    the -m gpu suite); the public scene description is plain C (gcc -std=c11) and layout-identical to the internal one (static_asserts)."""
+    import subprocess
+    assert os.path.exists(os.path.join(ROOT, "wave_tracer_amd", "wtgpu_smoke"))
+    subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "wtgpu.h")])
+    hdr = open(os.path.join(ROOT, "include", "wtgpu.h")).read()
+    assert "debug_only" not in hdr and "crop_of" not in hdr          # test hooks live in csrc/wtgpu_test_hooks.h
+    assert "const void* scene_desc" not in hdr
+
+
+def test_public_scene_header_is_current(built):
+    """include/wtgpu_scene.h is generated from wt/scene.h (tools/gen_public_scene_header.py): regenerating must not change it."""
+    import subprocess
+    import sys
+    before = open(os.path.join(ROOT, "include", "wtgpu_scene.h")).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_public_scene_header.py")], stdout=subprocess.DEVNULL)
+    assert open(os.path.join(ROOT, "include", "wtgpu_scene.h")).read() == before

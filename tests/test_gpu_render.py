@@ -251,6 +251,100 @@ def test_rmse_far_below_monte_carlo_noise_floor(built):
     assert same < 3e-2 and same < floor / 20, (same, floor)
 
 
+def test_c_host_smoke_program(built):
+    """The plain-C host of the C-ABI (csrc/smoke.c): named scene + description round trip + progressive render + develop on the GPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([os.path.join(root, "wave_tracer_amd", "wtgpu_smoke")]).decode()
+    assert "smoke.c: furnace 24x24, 4 spp" in out and "4 progress calls" in out, out
+
+
+def test_progressive_render_progress_and_cancel(built):
+    """wtgpu_render_progressive / wtgpu_cancel (scene_renderer.hpp:42-62): the callback sees every chunk; stopping after chunk k leaves
+    exactly k chunks in the films (= the joined render of those samples); a cancel from another thread does the same."""
+    import threading
+    import torch
+    from wave_tracer_amd import Scene, render
+    from wave_tracer_amd.render import alloc_films
+    sc = Scene("furnace", res=32, lut=(32, 32))
+    sc.upload(0)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    seen = []
+    v, w, l = alloc_films(sc, dev)
+    cancelled, done = sc.render_progressive(v, w, l, 0, 6, 21, chunk_spp=2, progress=lambda d, t: seen.append((d, t)) or False, stream=st)
+    assert not cancelled and done == 6 and seen == [(2 * 1024, 6 * 1024), (4 * 1024, 6 * 1024), (6 * 1024, 6 * 1024)]
+    ref = render(sc, 6, seed=21)
+    assert np.allclose(v.cpu().numpy(), ref[0], rtol=1e-9, atol=1e-30)
+    # stop from the callback after the second chunk
+    v, w, l = alloc_films(sc, dev)
+    cancelled, done = sc.render_progressive(v, w, l, 0, 6, 21, chunk_spp=1, progress=lambda d, t: d >= 2 * 1024, stream=st)
+    assert cancelled and done == 2
+    ref2 = render(sc, 2, seed=21)
+    assert np.allclose(v.cpu().numpy(), ref2[0], rtol=1e-9, atol=1e-30) and np.allclose(w.cpu().numpy(), ref2[1], rtol=1e-12)
+    # cancel from another thread while a long render is running
+    v, w, l = alloc_films(sc, dev)
+    t = threading.Timer(0.05, sc.cancel)
+    t.start()
+    cancelled, done = sc.render_progressive(v, w, l, 0, 100000, 21, chunk_spp=1, stream=st)
+    t.join()
+    assert cancelled and 0 < done < 100000
+    wsum = float(w.sum())
+    assert abs(wsum - done * float(ref2[1].sum()) / 2) < 1e-6 * wsum          # exactly `done` complete chunks
+
+
+def test_rccl_film_reduce_world_size_1(built):
+    """wtgpu_comm_* / wtgpu_film_reduce (RCCL) at world size 1: the library's own collective path initialises and leaves the films
+    unchanged; render_distributed over torch.distributed's nccl backend gives the single-process render."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from wave_tracer_amd import Scene, render
+    from wave_tracer_amd.api import Comm
+    from wave_tracer_amd.render import alloc_films, render_distributed
+    sc = Scene("furnace", res=24, lut=(32, 32))
+    sc.upload(0)
+    ref = render(sc, 4, seed=3)
+    dev = torch.device("cuda", 0)
+    v, w, l = alloc_films(sc, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    sc.render_into(v, w, l, 0, 4, 3, st)
+    comm = Comm(1, 0, 0, Comm.unique_id())
+    comm.film_reduce(v, w, l, root=0, stream=st)
+    torch.cuda.synchronize(dev)
+    comm.close()
+    assert np.allclose(v.cpu().numpy(), ref[0], rtol=1e-9, atol=1e-30) and np.allclose(w.cpu().numpy(), ref[1], rtol=1e-12)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        out = render_distributed(sc, 4, seed=3)
+    finally:
+        dist.destroy_process_group()
+    assert np.allclose(out[0], ref[0], rtol=1e-9, atol=1e-30) and np.allclose(out[2], ref[2], rtol=1e-9, atol=1e-30)
+
+
+def test_bench_launches_its_own_ranks(built):
+    """`python bench.py --gpus N` with no launcher around it (the driver's N = 1 form, and what a user types) starts N ranks itself and
+    rank 0 prints ONE JSON line with n_gpus = N.  Two ranks share the box's single GPU here (--backend gloo: the film reduce goes over
+    the host; the RCCL path needs one GPU per rank)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                                   "--scene", "furnace", "--res", "64", "--no-cpu-baseline"], env=env, stderr=subprocess.DEVNULL).decode()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["samples_per_step"] == 64 * 64 and abs(d["value"] - 2 * 2 * 64 * 64 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * d["value"]
+    assert "roofline" in d and "whole_path" in d["roofline"]
+
+
 def test_converged_bias_dense_crop(built):
     """BASELINE.json's second metric: converged-image error against the CPU reference.  Dense-mesh crop of the headline film (same
     pixel pitch as the 1440^2 render).

@@ -22,7 +22,11 @@ class WtgpuError(RuntimeError):
 class SceneParams(C.Structure):
     _fields_ = [("res", C.c_uint32), ("max_depth", C.c_int32), ("fsd", C.c_int32), ("mis", C.c_int32), ("rr", C.c_int32),
                 ("force_ray_tracing", C.c_int32), ("mesh_detail", C.c_int32), ("lut_n_theta", C.c_uint32), ("lut_m", C.c_uint32),
-                ("debug_only_s", C.c_uint32), ("debug_only_t", C.c_uint32), ("polarimetric", C.c_int32), ("crop_of", C.c_uint32)]
+                ("polarimetric", C.c_int32)]
+
+
+class TestHooks(C.Structure):      # wave_tracer_amd/csrc/wtgpu_test_hooks.h (not part of the public C-ABI)
+    _fields_ = [("only_s", C.c_uint32), ("only_t", C.c_uint32), ("crop_of", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):
@@ -48,7 +52,9 @@ class Counters(C.Structure):
 SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_scene_get_info", "wtgpu_scene_host_desc",
            "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
            "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
-           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join", "wtgpu_query_regions"]
+           "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join", "wtgpu_query_regions", "wtgpu_render_progressive",
+           "wtgpu_cancel", "wtgpu_comm_unique_id", "wtgpu_comm_create", "wtgpu_film_reduce", "wtgpu_comm_destroy"]
+PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p)
 
 _lib = None
 
@@ -75,7 +81,15 @@ def load_library():
     lib = C.CDLL(p)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     lib.wtgpu_scene_create_named.argtypes = [C.c_char_p, C.POINTER(SceneParams), C.POINTER(vp)]
+    lib.wtgpu_scene_create_named_hooks.argtypes = [C.c_char_p, C.POINTER(SceneParams), C.POINTER(TestHooks), C.POINTER(vp)]
     lib.wtgpu_scene_create_from_desc.argtypes = [vp, C.POINTER(vp)]
+    lib.wtgpu_render_progressive.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64, u32, PROGRESS_CB, vp, C.POINTER(u64)]
+    lib.wtgpu_cancel.argtypes = [vp]
+    lib.wtgpu_comm_unique_id.argtypes = [vp]
+    lib.wtgpu_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    lib.wtgpu_film_reduce.argtypes = [vp, vp, vp, vp, vp, u64, u64, i32]
+    lib.wtgpu_comm_destroy.argtypes = [vp]
+    lib.wtgpu_comm_destroy.restype = None
     lib.wtgpu_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
     lib.wtgpu_scene_host_desc.argtypes = [vp]
     lib.wtgpu_scene_host_desc.restype = vp
@@ -111,10 +125,13 @@ class Scene:
     def __init__(self, name, res=256, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, mesh_detail=1, lut=(0, 0), only_s=None, only_t=None, crop_of=0,
                  polarimetric=0):
         lib = load_library()
-        p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, mesh_detail, lut[0], lut[1],
-                        0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1, polarimetric, crop_of)
+        p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, mesh_detail, lut[0], lut[1], polarimetric)
         h = C.c_void_p()
-        _check(lib.wtgpu_scene_create_named(name.encode(), C.byref(p), C.byref(h)))
+        if only_s is None and only_t is None and not crop_of:
+            _check(lib.wtgpu_scene_create_named(name.encode(), C.byref(p), C.byref(h)))
+        else:       # test hooks (single-strategy renders, crops of a larger film)
+            hooks = TestHooks(0 if only_s is None else only_s + 1, 0 if only_t is None else only_t + 1, crop_of)
+            _check(lib.wtgpu_scene_create_named_hooks(name.encode(), C.byref(p), C.byref(hooks), C.byref(h)))
         self._h = h
         self.name = name
         info = SceneInfo()
@@ -171,6 +188,23 @@ class Scene:
         sp = C.c_void_p(stream) if stream else None
         _check(load_library().wtgpu_render_async(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), int(sample_begin),
                                                  int(sample_end), int(seed)))
+
+    def render_progressive(self, value, weight, light, sample_begin, sample_end, seed, chunk_spp=1, progress=None, stream=None):
+        """Blocking render with the reference's control surface: progress(samples_done, samples_total) -> truthy to stop; cancel() from
+        any thread.  Returns (cancelled, samples_per_element_done)."""
+        sp = C.c_void_p(stream) if stream else None
+        cb = PROGRESS_CB((lambda d, t, u: 1 if progress(d, t) else 0) if progress else (lambda d, t, u: 0))
+        done = C.c_uint64(0)
+        lib = load_library()
+        rc = lib.wtgpu_render_progressive(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), int(sample_begin), int(sample_end),
+                                          int(seed), int(chunk_spp), cb, None, C.byref(done))
+        if rc == 6:      # WTGPU_CANCELLED
+            return True, int(done.value)
+        _check(rc)
+        return False, int(done.value)
+
+    def cancel(self):
+        _check(load_library().wtgpu_cancel(self._h))
 
     def join(self, stream=None):
         _check(load_library().wtgpu_join(self._h, C.c_void_p(stream) if stream else None))
@@ -242,6 +276,37 @@ class Scene:
     def close(self):
         if self._h:
             load_library().wtgpu_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator of the C-ABI (wtgpu_comm_*): one process per GPU, films summed onto a root rank."""
+
+    def __init__(self, world, rank, device, unique_id):
+        h = C.c_void_p()
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        _check(load_library().wtgpu_comm_create(int(world), int(rank), int(device), self._id, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(load_library().wtgpu_comm_unique_id(buf))
+        return buf.raw
+
+    def film_reduce(self, value, weight, light, root=0, stream=None):
+        sp = C.c_void_p(stream) if stream else None
+        _check(load_library().wtgpu_film_reduce(self._h, sp, value.data_ptr(), weight.data_ptr(), light.data_ptr(), value.numel(), weight.numel(), int(root)))
+
+    def close(self):
+        if self._h:
+            load_library().wtgpu_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):

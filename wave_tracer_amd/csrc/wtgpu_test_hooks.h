@@ -1,0 +1,15 @@
+/* Test hooks of the bundled scenes — NOT part of the public C-ABI (include/wtgpu.h); exported for tests/ only. */
+#pragma once
+#include "../../include/wtgpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct wtgpu_test_hooks {
+    uint32_t only_s, only_t; /* 0 = all strategies; v>0 evaluates only s (t) = v-1 with unit MIS weight */
+    uint32_t crop_of;        /* perspective sensors: 0 = off; v>0: the res x res film is the central crop of a v x v film (same pixel pitch,
+                              * hence the same beam footprints, as the full-size render) */
+} wtgpu_test_hooks;
+int wtgpu_scene_create_named_hooks(const char* name, const wtgpu_scene_params* params, const wtgpu_test_hooks* hooks, wtgpu_scene** out);
+#ifdef __cplusplus
+}
+#endif
