@@ -42,6 +42,7 @@ constexpr uint32_t kOracleConeTris = 1u << 18;
 // 1 (default): interaction records drop the triangles beyond their final slab (traversal_common.hpp:131-135 as written); 0: the
 // reference's executed behaviour (the distance is never recorded, the filter never fires) — to measure what that costs
 int g_region_filter = 1;
+int g_traverse_axis = 0;   // oracle_traverse_cones: run the device form of the traversal policy (wt::traverse_axis) instead of the reference's
 
 void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
     unsigned long long* pa = reinterpret_cast<unsigned long long*>(&a);
@@ -270,14 +271,15 @@ int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
     stack_entry_t st[128];
     const stack_ref_t stack = make_flat_stack(st, 128);
-    std::vector<uint32_t> tl(kMaxConeTris);
-    std::vector<float> dl(kMaxConeTris);
+    const uint32_t lcap = cap > kMaxConeTris ? cap : kMaxConeTris;   // the device's bounded list unless a larger one is asked for
+    std::vector<uint32_t> tl(lcap);
+    std::vector<float> dl(lcap);
     for (uint32_t i = 0; i < n; ++i) {
         const float* c = cones + 10 * i;
         const vec3 d = normalize(vec3{c[3], c[4], c[5]});
         const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
-        const uint_list_t tris{tl.data(), 1, kMaxConeTris, g_region_filter ? dl.data() : nullptr};
-        const trav_result_t tr = traverse(sc, env, c[9], WT_INF, false, stack, tris);
+        const uint_list_t tris{tl.data(), 1, lcap, g_region_filter ? dl.data() : nullptr};
+        const trav_result_t tr = g_traverse_axis ? traverse_axis(sc, env, c[9], WT_INF, false, stack, tris) : traverse(sc, env, c[9], WT_INF, false, stack, tris);
         out_dist[i] = tr.dist;
         out_flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
         out_ntris[i] = tr.ballistic ? (tr.empty ? 0 : 1) : tr.ntris;
@@ -294,6 +296,7 @@ int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n
 }
 
 void oracle_set_region_filter(int on) { g_region_filter = on; }
+void oracle_set_traverse_axis(int on) { g_traverse_axis = on; }
 
 // Region summaries of cone queries of any size: what the reference's unbounded intersection record yields (`list`: every triangle
 // the sequential traversal met, traversal_common.hpp:124-148) next to a brute-force scan of ALL scene triangles against the final

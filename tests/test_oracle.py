@@ -249,3 +249,22 @@ def test_oracle_matches_committed_golden(built, case):
     assert np.abs(img - ref).sum() <= 2e-3 * np.abs(ref).sum()
     for k, v in meta["counters"].items():
         assert abs(counters[k] - v) <= 2e-3 * max(50, v), (k, counters[k], v)
+
+
+def test_traverse_axis_equals_traverse(built):
+    """The device form of integrator::traverse (wt::traverse_axis: ONE closest hit of the beam axis instead of a ray query per
+    ballistic segment, used as an upper bound of every cone query) returns what the reference's form returns: distances, flags and the
+    (final-slab) triangle lists of 3000 cone queries of every width on the dense bench geometry, bit for bit."""
+    from test_gpu_traversal import region_cones
+    sc = _scene("cornell_box", res=16, mesh_detail=1, lut=(32, 32))
+    cones = np.concatenate([random_cones(1500, 31, -.015, .015) + np.array([0, .01, 0, 0, 0, 0, 0, 0, 0, 0], np.float32), region_cones(1500, 32)])
+    lib = load_oracle()
+    ref = oracle_cones(sc, cones, cap=32768)          # lists large enough for every region
+    lib.oracle_set_traverse_axis(1)
+    try:
+        dev = oracle_cones(sc, cones, cap=32768)
+    finally:
+        lib.oracle_set_traverse_axis(0)
+    assert np.array_equal(ref[1], dev[1]) and np.array_equal(ref[2], dev[2]) and np.array_equal(ref[3], dev[3])
+    assert np.array_equal(ref[0], dev[0], equal_nan=True)
+    assert ((ref[1] & 3) == 0).sum() > 500 and (ref[2] >= 64).sum() > 50 and ref[2].max() < 32768

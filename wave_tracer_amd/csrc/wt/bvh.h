@@ -553,6 +553,113 @@ WT_HD trav_result_t traverse(const scene_t& sc, const cone_t& envelope, float la
     }
 }
 
+// Upper bound of [closest cone hit + region depth] from the closest hit t of the beam AXIS: the axis lies inside the cone, so the
+// closest cone hit is not farther than t, and closest + 2 x axis(closest) grows with closest (slack: rounding of the two tests).
+WT_HD float cone_axis_bound(const cone_t& envelope, float t_axis) {
+    const float t = t_axis * 1.0001f + 1e-9f;
+    return t + kMajorAxisToZScale * cone_axes(envelope, t).x;
+}
+// The triangle under the beam axis from the axis hit (see resolve_primary): marks r.aborted = 2.
+WT_HD void primary_from_axis(const scene_t& sc, const cone_t& envelope, bool axis_hit, const ray_hit_t& ah, trav_result_t& r) {
+    r.aborted = 2;
+    r.tuid = kInvalid;
+    if (!axis_hit) return;
+    const range_t izr{r.dist, r.dist + r.region_depth};
+    const tri_geo_t g = sc.tri_geo[ah.tuid];
+    if (contains(grow(izr, cone_intersection_tolerance(envelope.o, g.a, g.b, g.c)), ah.dist)) {
+        r.tuid = ah.tuid;
+        r.bx = ah.bx;
+        r.by = ah.by;
+        r.pdist = ah.dist;
+    }
+}
+
+// integrator::traverse, device form — same results as traverse() above (tests/test_oracle.py::test_traverse_axis_equals_traverse),
+// less work:
+//   * ONE closest-hit query of the beam axis over the whole range replaces the ray query of every ballistic segment: the segments
+//     tile [0, distance) (traversal.hpp:39-57), so "segment k's ray query hits" == "the closest axis hit lies in segment k";
+//   * that hit bounds every cone query from above (cone_axis_bound): a beam wider than the BVH's leaf boxes gets no useful
+//     near-first order from its grown boxes and would otherwise test geometry far behind the surface it is about to hit;
+//   * and it IS the triangle under the beam axis of the interaction region (find_closest_triangle) whenever the region's bounded
+//     list overflowed (`primary_on_overflow`; a complete list is scanned like the reference does).
+// Hand-over when the cone query exceeds `cone_budget` (r.aborted = 1): r.dist / r.ntris = distance / segment of that query, and the
+// axis hit in r.tuid (kInvalid: none) / r.bx / r.by / r.pdist / r.front_face.
+WT_HD trav_result_t traverse_axis(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
+                                  const stack_ref_t& stack, const uint_list_t& tris, bvh_counters_t* ctr = nullptr, uint32_t cone_budget = 0xFFFFFFFFu,
+                                  bool probe_first = false, bool primary_always = false) {
+    trav_result_t r;
+    r.aborted = 0;
+    r.origin = envelope.o;
+    r.empty = 1;
+    r.ballistic = 1;
+    r.dist = -WT_INF;
+    r.region_depth = 0.f;
+    r.front_face = 0;
+    r.tuid = kInvalid;
+    r.bx = r.by = 0.f;
+    r.pdist = 0.f;
+    r.ntris = 0;
+    r.overflow = 0;
+    r.n_ray_queries = 1;
+    r.n_cone_queries = 0;
+    const vec3 ro = envelope.o, rd = envelope.d;
+    ray_hit_t ah;
+    const bool axis_hit = ads_intersect_ray(sc, ro, rd, range_t{0.f, distance}, stack, ah, ctr);
+    auto ballistic_hit = [&]() {
+        r.empty = 0;
+        r.dist = ah.dist;
+        r.tuid = ah.tuid;
+        r.bx = ah.bx;
+        r.by = ah.by;
+        r.front_face = ah.front_face;
+        r.ntris = 1;
+    };
+    if (force_ray_tracing || cone_is_ray(envelope)) {
+        if (axis_hit) ballistic_hit();
+        return r;
+    }
+    float dist = 0.f;
+    for (uint32_t seg = 0;; ++seg) {
+        const float ballistic_dist = max_ballistic_distance(lambda_m, seg, 0.f);
+        if (axis_hit && ah.dist <= fminf_(distance, dist + ballistic_dist * kBallisticScale)) {
+            ballistic_hit();
+            return r;
+        }
+        dist += ballistic_dist;
+        if (ballistic_dist == WT_INF || dist >= distance) return r;
+        const float min_df_prog = cone_axes(envelope, dist).x / 2.f;
+        cone_hit_t ch;
+        r.n_cone_queries++;
+        const float cone_max = axis_hit ? fminf_(distance, cone_axis_bound(envelope, ah.dist)) : distance;
+        bvh_traverse_cone(sc, envelope, range_t{dist, cone_max}, kMajorAxisToZScale, stack, tris, ch, ctr, cone_budget, probe_first ? min_df_prog : -WT_INF);
+        if (ch.aborted) {
+            r.aborted = 1;
+            r.dist = dist;
+            r.ntris = seg;
+            r.n_cone_queries--;   // recounted by whoever completes it
+            r.tuid = axis_hit ? ah.tuid : kInvalid;
+            r.bx = ah.bx;
+            r.by = ah.by;
+            r.pdist = ah.dist;
+            r.front_face = ah.front_face;
+            return r;
+        }
+        if (ch.too_short) continue;
+        const bool df_empty = ch.ntris == 0 && ch.overflow == 0;
+        if (df_empty || ch.dist - dist >= min_df_prog) {
+            r.ballistic = 0;
+            r.empty = df_empty;
+            r.dist = df_empty ? -WT_INF : ch.dist;
+            r.front_face = ch.front_face;
+            r.ntris = ch.ntris;
+            r.overflow = ch.overflow;
+            r.region_depth = df_empty ? 0.f : kMajorAxisToZScale * cone_axes(envelope, ch.dist).x;
+            if (!df_empty && (primary_always || ch.overflow > 0)) primary_from_axis(sc, envelope, axis_hit, ah, r);
+            return r;
+        }
+    }
+}
+
 // The triangle under the beam axis of a diffusive hit (find_closest_triangle, plt_bdpt_detail.hpp:362-389: the closest axis hit
 // among the triangles of the interaction region) by ONE ray query over the region's z-slab instead of a scan of the region's
 // triangle list: a triangle the axis hits inside the slab meets the cone inside the slab, i.e. is a region triangle, whatever the

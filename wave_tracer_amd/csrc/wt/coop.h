@@ -742,10 +742,14 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
     return true;
 }
 
-// integrator::traverse (traversal.hpp:94-172), wave-uniform.
+// integrator::traverse (traversal.hpp:94-172), wave-uniform — the device form of wt::traverse_axis (bvh.h): the closest hit of the beam
+// axis (`axis`, from the per-lane kernel's hand-over; computed here when nullptr) stands in for the per-segment ray queries, bounds
+// the cone queries and names the triangle under the axis of an overflowed region.  resume: continue with the cone query of segment
+// seg0 at distance dist0 (everything before is settled).
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
                                               coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr, bool resume = false,
-                                              uint32_t seg0 = 0, float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0) {
+                                              uint32_t seg0 = 0, float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0, const ray_hit_t* axis = nullptr,
+                                              bool primary_always = false) {
 #ifdef WTGPU_COOP_PROF
 #define WT_COOP_PROF(i, t0_)
 #else
@@ -765,49 +769,41 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
     r.pdist = 0.f;
     r.ntris = 0;
     r.overflow = 0;
-    r.n_ray_queries = r.n_cone_queries = 0;
+    r.n_ray_queries = resume ? nray0 : 0u;
+    r.n_cone_queries = resume ? ncone0 : 0u;
     const vec3 ro = envelope.o, rd = envelope.d;
-    ray_hit_t rh;
-    if (force_ray_tracing || cone_is_ray(envelope)) {
+    ray_hit_t ah;
+    bool axis_hit;
+    if (axis) {
+        ah = *axis;
+        axis_hit = ah.tuid != kInvalid;
+    } else {
         r.n_ray_queries++;
-        if (coop_ray_query(sc, ro, rd, range_t{0.f, distance}, sh, rh)) {
-            r.empty = 0;
-            r.dist = rh.dist;
-            r.tuid = rh.tuid;
-            r.bx = rh.bx;
-            r.by = rh.by;
-            r.front_face = rh.front_face;
-            r.ntris = 1;
-        }
+        const long long tq0 = prof ? clock64() : 0;
+        axis_hit = coop_ray_query(sc, ro, rd, range_t{0.f, distance}, sh, ah);
+        WT_COOP_PROF(0, tq0)
+    }
+    auto ballistic_hit = [&]() {
+        r.empty = 0;
+        r.dist = ah.dist;
+        r.tuid = ah.tuid;
+        r.bx = ah.bx;
+        r.by = ah.by;
+        r.front_face = ah.front_face;
+        r.ntris = 1;
+    };
+    if (force_ray_tracing || cone_is_ray(envelope)) {
+        if (axis_hit) ballistic_hit();
         return r;
     }
-    // resume = the per-lane kernel already settled every query before the cone query of segment seg0 (bvh.h: traverse())
     float dist = resume ? dist0 : 0.f;
-    if (resume) {
-        r.n_ray_queries = nray0;
-        r.n_cone_queries = ncone0;
-    }
     for (uint32_t seg = resume ? seg0 : 0u;; ++seg) {
         const float ballistic_dist = max_ballistic_distance(lambda_m, seg, 0.f);
-        const bool skip_ray = resume && seg == seg0;   // that segment's ray query missed already; `dist` is past it
-        bool ray_hit = false;
-        if (!skip_ray) {
-            r.n_ray_queries++;
-            const long long tq0 = prof ? clock64() : 0;
-            ray_hit = coop_ray_query(sc, ro, rd, range_t{dist, fminf_(distance, dist + ballistic_dist * kBallisticScale)}, sh, rh);
-            WT_COOP_PROF(0, tq0)
-        }
-        if (ray_hit) {
-            r.empty = 0;
-            r.dist = rh.dist;
-            r.tuid = rh.tuid;
-            r.bx = rh.bx;
-            r.by = rh.by;
-            r.front_face = rh.front_face;
-            r.ntris = 1;
-            return r;
-        }
-        if (!skip_ray) {
+        if (!(resume && seg == seg0)) {   // (that segment is settled already; `dist` is past it)
+            if (axis_hit && ah.dist <= fminf_(distance, dist + ballistic_dist * kBallisticScale)) {
+                ballistic_hit();
+                return r;
+            }
             dist += ballistic_dist;
             if (ballistic_dist == WT_INF || dist >= distance) return r;
         }
@@ -821,7 +817,8 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         WT_COOP_PROF(1, tp0)
         if (near_hit) continue;   // too short (see bvh_cone_any_hit)
         const long long tc0 = prof ? clock64() : 0;
-        coop_cone(sc, envelope, range_t{dist, distance}, kMajorAxisToZScale, sh, tris, ch, prof, min_df_prog);
+        const float cone_max = axis_hit ? fminf_(distance, cone_axis_bound(envelope, ah.dist)) : distance;
+        coop_cone(sc, envelope, range_t{dist, cone_max}, kMajorAxisToZScale, sh, tris, ch, prof, min_df_prog);
         WT_COOP_PROF(2, tc0)
         if (ch.too_short) continue;   // (boundary case of the probe's inclusive slab)
         const bool df_empty = ch.ntris == 0 && ch.overflow == 0;
@@ -833,6 +830,7 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
             r.ntris = ch.ntris;
             r.overflow = ch.overflow;
             r.region_depth = df_empty ? 0.f : kMajorAxisToZScale * cone_axes(envelope, ch.dist).x;
+            if (!df_empty && (primary_always || ch.overflow > 0)) primary_from_axis(sc, envelope, axis_hit, ah, r);
             return r;
         }
     }

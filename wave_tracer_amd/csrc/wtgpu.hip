@@ -296,15 +296,19 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
             uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;   // 64 triangle ids + their 64 cone-hit distances
             const uint_list_t tris{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
             const cone_t env = walk_trace_envelope(a.sc, wk);
-            trav_result_t tr = traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true);
-            if (!tr.aborted && !tr.ballistic && !tr.empty && (!a.collect_list || tr.overflow > 0)) resolve_primary(a.sc, env, stack, tr);
+            const trav_result_t tr = traverse_axis(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true, !a.collect_list);
             if (tr.aborted == 1) {
                 heavy = true;
-                // resume state for k_trace_heavy (traverse(): dist / ntris = segment / query counts so far)
+                // resume state for k_trace_heavy (traverse_axis(): dist / ntris = segment / query counts so far + the axis hit)
                 a.st.trav[WT_TRAV_WORD(dist) * W2 + w] = __float_as_uint(tr.dist);
                 a.st.trav[WT_TRAV_WORD(ntris) * W2 + w] = tr.ntris;
                 a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = tr.n_ray_queries;
                 a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = tr.n_cone_queries;
+                a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = tr.tuid;
+                a.st.trav[WT_TRAV_WORD(bx) * W2 + w] = __float_as_uint(tr.bx);
+                a.st.trav[WT_TRAV_WORD(by) * W2 + w] = __float_as_uint(tr.by);
+                a.st.trav[WT_TRAV_WORD(pdist) * W2 + w] = __float_as_uint(tr.pdist);
+                a.st.trav[WT_TRAV_WORD(front_face) * W2 + w] = tr.front_face;
             } else {
                 soa_store(a.st.trav, W2, w, tr);
                 ctr.segments += 1;
@@ -345,36 +349,21 @@ __global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
         const float dist0 = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
         const uint32_t seg0 = a.st.trav[WT_TRAV_WORD(ntris) * W2 + w];
         const uint32_t nray0 = a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w], ncone0 = a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w];
-        const trav_result_t tr = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0);
+        ray_hit_t axis;   // the closest hit of the beam axis, found by k_trace (traverse_axis, wt/bvh.h)
+        axis.tuid = a.st.trav[WT_TRAV_WORD(tuid) * W2 + w];
+        axis.bx = __uint_as_float(a.st.trav[WT_TRAV_WORD(bx) * W2 + w]);
+        axis.by = __uint_as_float(a.st.trav[WT_TRAV_WORD(by) * W2 + w]);
+        axis.dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(pdist) * W2 + w]);
+        axis.front_face = a.st.trav[WT_TRAV_WORD(front_face) * W2 + w];
+        const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
+                                                &axis, !a.collect_list);
         if (a.profile == 2 && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
-#ifdef WTGPU_COOP_PROF
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
-#else
-            for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
-#endif
             atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
             atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
             atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
             atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
-        }
-        trav_result_t tr2 = tr;
-        if (!tr.ballistic && !tr.empty && (!a.collect_list || tr.overflow > 0)) {   // the triangle under the beam axis (resolve_primary, wt/bvh.h)
-            const range_t izr{tr.dist, tr.dist + tr.region_depth};
-            const float wtol = cone_intersection_tolerance(env.o, a.sc.world_min, a.sc.world_max, a.sc.world_max);
-            tr2.aborted = 2;
-            tr2.tuid = kInvalid;
-            tr2.n_ray_queries++;
-            ray_hit_t rh;
-            if (coop_ray_query(a.sc, env.o, env.d, grow(izr, wtol), sh, rh)) {
-                const tri_geo_t g = a.sc.tri_geo[rh.tuid];
-                if (contains(grow(izr, cone_intersection_tolerance(env.o, g.a, g.b, g.c)), rh.dist)) {
-                    tr2.tuid = rh.tuid;
-                    tr2.bx = rh.bx;
-                    tr2.by = rh.by;
-                    tr2.pdist = rh.dist;
-                }
-            }
         }
         if (threadIdx.x == 0) {
             soa_store(a.st.trav, W2, w, tr2);
@@ -994,19 +983,14 @@ __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* c
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});
     const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
     const uint_list_t none{nullptr, 1u, 0u};
-    const trav_result_t tr = coop_traverse(sc, env, c[9], WT_INF, false, sh, none);
+    const trav_result_t tr = coop_traverse(sc, env, c[9], WT_INF, false, sh, none, nullptr, false, 0, 0.f, 0, 0, nullptr, true);
     uint32_t prim = kInvalid;
     gather_out_t ge{0.0, 0u, 0u, 0u}, gf{0.0, 0u, 0u, 0u};
     if (tr.ballistic) {
         prim = tr.tuid;
     } else if (!tr.empty) {
         const range_t izr{tr.dist, tr.dist + tr.region_depth};
-        const float wtol = cone_intersection_tolerance(env.o, sc.world_min, sc.world_max, sc.world_max);
-        ray_hit_t rh;
-        if (coop_ray_query(sc, env.o, env.d, grow(izr, wtol), sh, rh)) {
-            const tri_geo_t g = sc.tri_geo[rh.tuid];
-            if (contains(grow(izr, cone_intersection_tolerance(env.o, g.a, g.b, g.c)), rh.dist)) prim = rh.tuid;
-        }
+        prim = tr.tuid;   // primary_from_axis (kInvalid: the axis misses the region)
         const vec2 ax = cone_axes(env, tr.dist);
         ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, sh, false, true);
         __syncthreads();
