@@ -63,7 +63,7 @@ def test_image_parity_scenes(built, name, res, spp, kw, tol):
 
 
 def test_cornell_dense_mesh_parity(built):
-    """Bench geometry (170K triangles: bounded lists, cooperative heavy-walk kernel, whole-region edge / power gathers all active) on
+    """Bench geometry (283K triangles: bounded lists, cooperative heavy-walk kernel, whole-region edge / power gathers all active) on
     a small film.  Interaction regions are unbounded on both sides now (the device walks regions that overflow its 64-triangle list
     once more: resolve_primary, k_edges, k_flux_*), so what remains are traversal-order details: the reference's (and the CPU
     checker's) list of a region also holds triangles it met before the region's slab shrank, the device's gathers use the final slab.

@@ -45,7 +45,7 @@ def test_ray_queries_golden_and_oracle(built):
 
 
 def test_ray_queries_large_mesh(built):
-    """170K-triangle stand-in (the bench geometry): 20K random rays, CPU checker on the same rays."""
+    """283K-triangle stand-in (the bench geometry): 20K random rays, CPU checker on the same rays."""
     sc = _scene(res=16, mesh_detail=1, lut=(32, 32))
     rays = random_rays(20000, 5, -.02, .02)
     rays[:, 1] += .01
@@ -88,7 +88,7 @@ def test_cone_traversal_golden_and_oracle(built):
 
 
 def test_cone_traversal_large_mesh(built):
-    """List-based query kernel on the 170K-triangle bench geometry, beams of every width (no clamp): closest distance and flags must
+    """List-based query kernel on the 283K-triangle bench geometry, beams of every width (no clamp): closest distance and flags must
     agree for all of them; the sorted 64-triangle lists are compared where the region fits the list."""
     sc = _scene(res=16, mesh_detail=1, lut=(32, 32))
     cones = np.concatenate([random_cones(1000, 8, -.015, .015) + np.array([0, .01, 0, 0, 0, 0, 0, 0, 0, 0], np.float32), region_cones(1000, 8)])
@@ -133,7 +133,7 @@ def oracle_regions(sc, cones, edge_cap=96):
 def test_whole_region_queries_beyond_the_list_cap(built):
     """wtgpu_query_regions on the bench geometry with beams up to tan(alpha) = 0.16: interaction regions of up to 10^4 triangles, far
     beyond the 64-triangle fast path.  Against the CPU checker's UNBOUNDED sequential traversal record (`list`, final-slab filter of
-    traversal_common.hpp:131-135 applied) and a brute-force scan of all 170K triangles against the final slab (`slab`) — the two
+    traversal_common.hpp:131-135 applied) and a brute-force scan of all 283K triangles against the final slab (`slab`) — the two
     must be the same sets, and the device's whole-region walks must reproduce them:
       * closest distance / flags / triangle under the axis: like the list-based traversal (1e-5, exact, >= 99.8 %);
       * region triangle count == brute force (<= 1 % of the regions differ, by fp ties of the cone-triangle test);

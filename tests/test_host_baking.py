@@ -77,3 +77,46 @@ def test_directional_emitter_target_disk(built):
     half = np.array([2.0, 2.0, 0.2])
     r2 = max(np.sum((c * half - np.dot(c * half, d) * d) ** 2) for c in np.array(np.meshgrid([-1, 1], [-1, 1], [-1, 1])).T.reshape(-1, 3))
     assert 2.7 ** 2 < r2 < 2.9 ** 2
+
+
+@pytest.mark.parametrize("name,radius,R1c,R2c,thick,T", [("lens_a", 1.5e-3, -.01, -.06, .04e-3, 50), ("lens_b", 2e-3, .5, 0.0, 1e-3, 24),
+                                                         ("lens_c", 2e-3, .4, .3, .9e-3, 16)])
+def test_procedural_lens_shape(built, name, radius, R1c, R2c, thick, T):
+    """mesh_lens restates the reference's `lens` shape (src/mesh/lens.cpp:19-199) — used for box.xml's dragon_lens.  Pinned by the
+    geometry the generator promises: triangle count 2 T (T - 1) + 2 T per curved face (T for a planar one) + 2 T rim; a closed,
+    outward-oriented surface; every face vertex on its sphere of radius `radius / Rk` (or plane); rim radius `radius`; axial extent
+    = the faces' sags + edge thickness, with ET = thickness - sag1 - sag2 (lens.cpp:40: `thickness` is measured pole to pole)."""
+    from collections import Counter
+    from test_oracle import _tris
+    from wave_tracer_amd import Scene
+    sc = Scene(name, res=16)
+    Tm = _tris(sc).astype(np.float64)
+    lens = Tm[np.abs(Tm[:, :3, 0] - .02).max(axis=1) > 1e-6][:, :3]            # all but the emitter wall at x = 2 cm
+    faces = sum((2 * T * (T - 1) + T) if Rc != 0 else T for Rc in (R1c, R2c))
+    assert len(lens) == faces + 2 * T
+    a, b, c = lens[:, 0], lens[:, 1], lens[:, 2]
+    assert np.einsum("ij,ij->i", a, np.cross(b, c)).sum() > 0                   # outward orientation (positive signed volume)
+    cnt = Counter()
+    for tri in lens:
+        for i in range(3):
+            cnt[tuple(sorted((tuple(np.round(tri[i], 9)), tuple(np.round(tri[(i + 1) % 3], 9)))))] += 1
+    assert all(v == 2 for v in cnt.values())                                     # closed 2-manifold
+    P = lens.reshape(-1, 3)
+    rho = np.hypot(P[:, 1], P[:, 2])
+    assert abs(rho.max() - radius) < 1e-9
+    sag = [abs(radius / Rc) - math.sqrt((radius / Rc) ** 2 - radius ** 2) if Rc != 0 else 0.0 for Rc in (R1c, R2c)]
+    s1, s2 = (math.copysign(sag[0], R1c), math.copysign(sag[1], R2c))           # convex faces bulge outwards, concave ones inwards
+    ET = thick - s1 - s2
+    assert ET > 0
+    assert abs(P[:, 0].min() - min(0.0, -s1)) < 1e-9 and abs(P[:, 0].max() - (ET + max(0.0, s2))) < 1e-9
+    # vertices left of the rim plane x = 0 / right of x = ET lie on the face spheres
+    for side, Rc, x_rim in ((-1, R1c, 0.0), (+1, R2c, ET)):
+        if Rc == 0:
+            continue
+        R = radius / Rc
+        xc = x_rim - side * math.copysign(math.sqrt(R * R - radius * radius), R)
+        on_face = (P[:, 0] < -1e-12) if (side < 0 and Rc > 0) else (P[:, 0] > ET + 1e-12) if (side > 0 and Rc > 0) else None
+        if on_face is None:      # concave face: its vertices lie between the rim planes; take those strictly inside the rim radius
+            continue
+        d = np.sqrt((P[on_face, 0] - xc) ** 2 + rho[on_face] ** 2)
+        assert len(d) > 0 and np.abs(d - abs(R)).max() < 1e-8

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <complex>
 #include <cstring>
 #include <functional>
@@ -240,6 +241,88 @@ mesh_t mesh_blob(double r, int recursion, double bump, int freq, uint32_t seed) 
         });
     return m;
 }
+mesh_t mesh_blob_geodesic(double r, int n, double bump, int freq, uint32_t seed) {
+    std::vector<dvec3> iv;
+    std::vector<std::array<uint32_t, 3>> it;
+    icosahedron(iv, it);
+    const double ph0 = (seed % 97) * 0.13, ph1 = (seed % 89) * 0.29, ph2 = (seed % 83) * 0.41;
+    auto P = [&](dvec3 d) {
+        const double s = std::sin(freq * d.x + ph0) * std::sin(freq * d.y + ph1) * std::sin(freq * d.z + ph2) +
+                         0.5 * std::sin(2.3 * freq * d.x + ph1) * std::cos(1.7 * freq * d.y + ph2);
+        return d * (r * (1.0 + bump * s));
+    };
+    auto N = [&](dvec3 d) {
+        const dvec3 ax = std::fabs(d.x) > 0.9 ? dvec3{0, 1, 0} : dvec3{1, 0, 0};
+        const dvec3 t = dnorm(dcross(ax, d)), b = dcross(d, t);
+        const double h = 1e-4;
+        dvec3 nn = dnorm(dcross(P(dnorm(d + t * h)) - P(dnorm(d - t * h)), P(dnorm(d + b * h)) - P(dnorm(d - b * h))));
+        if (ddot(nn, d) < 0) nn = nn * -1.0;
+        return nn;
+    };
+    mesh_t m;
+    for (auto& t : it) {
+        const dvec3 A = iv[t[0]], B = iv[t[1]], C = iv[t[2]];
+        auto at = [&](int i, int j) { return dnorm(A * (double(n - i - j) / n) + B * (double(i) / n) + C * (double(j) / n)); };
+        auto put = [&](dvec3 d0, dvec3 d1, dvec3 d2) {
+            const uint32_t k = (uint32_t)m.verts.size();
+            const dvec3 ds[3] = {d0, d1, d2};
+            for (auto& d : ds) {
+                m.verts.push_back(P(d));
+                m.normals.push_back(N(d));
+                m.uvs.push_back(sphere_uv(d));
+            }
+            m.tris.push_back({k, k + 1, k + 2});
+        };
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n - i; ++j) {
+                put(at(i, j), at(i + 1, j), at(i, j + 1));
+                if (i + j < n - 1) put(at(i + 1, j), at(i + 1, j + 1), at(i, j + 1));
+            }
+    }
+    return m;
+}
+mesh_t mesh_star_plate(double R, double thickness, int s) {
+    mesh_t m;
+    const double ri = R / std::sqrt(3.0);
+    dvec3 ring[12];
+    for (int k = 0; k < 12; ++k) {
+        const double a = M_PI / 6 * k, rr = (k % 2 == 0) ? R : ri;
+        ring[k] = {0, rr * std::cos(a), rr * std::sin(a)};
+    }
+    const double hx = thickness / 2;
+    auto face_tri = [&](dvec3 a, dvec3 b, dvec3 c, double x, bool flip) {   // s^2 sub-triangles
+        auto at = [&](int i, int j) { return a * (double(s - i - j) / s) + b * (double(i) / s) + c * (double(j) / s) + dvec3{x, 0, 0}; };
+        auto put = [&](dvec3 p0, dvec3 p1, dvec3 p2) {
+            const uint32_t k = (uint32_t)m.verts.size();
+            m.verts.insert(m.verts.end(), {p0, flip ? p2 : p1, flip ? p1 : p2});
+            m.uvs.insert(m.uvs.end(), {{0, 0}, {1, 0}, {0, 1}});
+            m.tris.push_back({k, k + 1, k + 2});
+        };
+        for (int i = 0; i < s; ++i)
+            for (int j = 0; j < s - i; ++j) {
+                put(at(i, j), at(i + 1, j), at(i, j + 1));
+                if (i + j < s - 1) put(at(i + 1, j), at(i + 1, j + 1), at(i, j + 1));
+            }
+    };
+    for (int side = 0; side < 2; ++side) {
+        const double x = side ? hx : -hx;
+        const bool flip = side == 0;   // the +x face is counter-clockwise seen from +x
+        for (int k = 0; k < 12; k += 2) face_tri(ring[(k + 11) % 12], ring[k], ring[(k + 1) % 12], x, flip);          // the six tips
+        for (int k = 1; k < 12; k += 2) face_tri({0, 0, 0}, ring[k], ring[(k + 2) % 12], x, flip);                     // the inner hexagon
+    }
+    for (int k = 0; k < 12; ++k)   // rim: s quads per outline edge, matching the faces' subdivision (no T-junctions)
+        for (int i = 0; i < s; ++i) {
+            const dvec3 pa = ring[k] * (double(s - i) / s) + ring[(k + 1) % 12] * (double(i) / s);
+            const dvec3 pb = ring[k] * (double(s - i - 1) / s) + ring[(k + 1) % 12] * (double(i + 1) / s);
+            const dvec3 a0 = pa + dvec3{-hx, 0, 0}, a1 = pa + dvec3{hx, 0, 0}, b0 = pb + dvec3{-hx, 0, 0}, b1 = pb + dvec3{hx, 0, 0};
+            const uint32_t q = (uint32_t)m.verts.size();
+            m.verts.insert(m.verts.end(), {a0, b0, b1, a1});
+            m.uvs.insert(m.uvs.end(), {{0, 0}, {1, 0}, {1, 1}, {0, 1}});
+            m.tris.push_back({q, q + 1, q + 2});
+            m.tris.push_back({q + 2, q + 3, q});
+        }
+    return m;
+}
 mesh_t mesh_cylinder(dvec3 p0, dvec3 p1, double radius, int tess) {
     const dvec3 axis = dnorm(p1 - p0);
     const dvec3 ax = std::fabs(axis.x) > 0.9 ? dvec3{0, 1, 0} : dvec3{1, 0, 0};
@@ -260,6 +343,89 @@ mesh_t mesh_cylinder(dvec3 p0, dvec3 p1, double radius, int tess) {
         m.tris.push_back({i0, i2, i1});
         m.tris.push_back({i1, i2, i3});
     }
+    return m;
+}
+// The reference's procedural lens (src/mesh/lens.cpp:19-199; box.xml:253-266 "dragon_lens"): two spherical (or planar) faces of
+// curvature radius radius/Rk around the +x axis and, when the edge thickness is positive, a cylindrical rim.  Vertex rings sit at
+// heights radius * (i/T)^0.8 (lens.cpp:56,83), T rings of T azimuth steps per curved face, one ring for a planar face.
+mesh_t mesh_lens(dvec3 centre, double radius, double R1c, double R2c, double thickness, int T) {
+    mesh_t m;
+    const double inf = std::numeric_limits<double>::infinity();
+    const double R1 = R1c != 0 ? radius / R1c : inf, R2 = R2c != 0 ? radius / R2c : inf;
+    const bool c1 = std::isfinite(R1), c2 = std::isfinite(R2);
+    auto sgn = [](double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+    const double x1 = c1 ? sgn(R1) * std::sqrt(R1 * R1 - radius * radius) : 0.0;    // centres of curvature on the axis
+    const double x2 = c2 ? -sgn(R2) * std::sqrt(R2 * R2 - radius * radius) : 0.0;
+    double ET = x1 - x2 - (c1 ? R1 : 0.0) - (c2 ? R2 : 0.0) + thickness;            // edge thickness
+    if (thickness == 0 && R1c <= 0 && R2c <= 0) ET += radius / 1000;                 // faces of a double-concave lens must not touch
+    struct face_t {
+        uint32_t start;
+        int rings;
+    };
+    auto add_face = [&](bool curved, double R, double xc, double side, double shift) {
+        face_t f{(uint32_t)m.verts.size(), curved ? T : 1};
+        m.verts.push_back({0, 0, 0});   // pole (set by the caller)
+        m.normals.push_back({side, 0, 0});
+        m.uvs.push_back({0, 0});
+        for (int i = 0; i < f.rings; ++i) {
+            const double h = radius * std::min(1.0, std::pow((i + 1) / double(f.rings), 0.8));
+            for (int j = 0; j < T; ++j) {
+                const double phi = 2 * M_PI * j / T;
+                const dvec3 cp{0, std::cos(phi) * h, std::sin(phi) * h};
+                dvec3 pnt, n{side, 0, 0};
+                if (curved) {
+                    n = dnorm(cp - dvec3{xc, 0, 0});
+                    if (R < 0) n = n * -1.0;
+                    pnt = dvec3{xc, 0, 0} + n * R + dvec3{shift, 0, 0};
+                } else
+                    pnt = cp + dvec3{shift, 0, 0};
+                m.verts.push_back(pnt);
+                m.normals.push_back(n);
+                m.uvs.push_back({(float)(i + 1) / (T + 1), (float)j / T});
+            }
+        }
+        return f;
+    };
+    const face_t L = add_face(c1, R1, x1, -1.0, 0.0);
+    m.verts[L.start] = {x1 - (c1 ? R1 : 0.0), 0, 0};                                  // lens.cpp:51
+    const face_t Rf = add_face(c2, R2, x2, +1.0, ET);
+    m.verts[Rf.start] = {x2 + (c2 ? R2 : 0.0) + ET, 0, 0};                            // lens.cpp:78
+    const uint32_t E = (uint32_t)m.verts.size();
+    if (ET > 0)
+        for (int j = 0; j < T; ++j) {
+            const double phi = 2 * M_PI * j / T;
+            const dvec3 n{0, std::cos(phi), std::sin(phi)};
+            m.verts.push_back(n * radius);
+            m.verts.push_back(n * radius + dvec3{ET, 0, 0});
+            m.normals.push_back(n);
+            m.normals.push_back(n);
+            m.uvs.push_back({0, (float)j / T});
+            m.uvs.push_back({1, (float)j / T});
+        }
+    // fans around the poles, quad strips between rings; the two faces wind oppositely (outward normals)
+    auto tri_face = [&](const face_t& f, bool flip) {
+        auto put = [&](uint32_t a, uint32_t b, uint32_t c) { m.tris.push_back(flip ? std::array<uint32_t, 3>{a, c, b} : std::array<uint32_t, 3>{a, b, c}); };
+        for (int i = 0; i < f.rings; ++i)
+            for (int j = 0; j < T; ++j) {
+                const int jp = j > 0 ? j - 1 : T - 1;
+                const uint32_t ring = f.start + 1 + (uint32_t)i * T, inner = ring - T;
+                if (i == 0)
+                    put(f.start, ring + j, ring + jp);
+                else {
+                    put(inner + jp, inner + j, ring + jp);
+                    put(ring + jp, inner + j, ring + j);
+                }
+            }
+    };
+    tri_face(L, false);
+    tri_face(Rf, true);
+    if (ET > 0)
+        for (int j = 0; j < T; ++j) {
+            const uint32_t p0 = E + (j > 0 ? 2 * j - 2 : 2 * T - 2), p1 = p0 + 1, q0 = E + 2 * j, q1 = q0 + 1;
+            m.tris.push_back({p1, p0, q0});
+            m.tris.push_back({q1, p1, q0});
+        }
+    for (auto& v : m.verts) v = v + centre;
     return m;
 }
 // triangular prism: apex angle `angle`, side length `length` (extrusion along z), apex height `height`

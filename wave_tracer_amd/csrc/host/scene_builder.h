@@ -49,8 +49,14 @@ mesh_t mesh_rectangle_scaled(double length);
 mesh_t mesh_cube(double length);
 mesh_t mesh_sphere(dvec3 centre, double r, int tessellation);
 mesh_t mesh_blob(double r, int recursion, double bump, int freq, uint32_t seed);
+// the same surface on a geodesic grid of frequency n (20 n^2 triangles: any count, not only 20 x 4^k)
+mesh_t mesh_blob_geodesic(double r, int n, double bump, int freq, uint32_t seed);
+// hexagram ("star of David") plate in the yz-plane, thickness along x, 2 x 12 s^2 + 24 s triangles, face normals
+mesh_t mesh_star_plate(double outer_radius, double thickness, int s);
 mesh_t mesh_cylinder(dvec3 p0, dvec3 p1, double radius, int tessellation);
 mesh_t mesh_prism(double length, double height, double angle_rad);
+// `lens` shape (src/mesh/lens.cpp): optical axis +x; R1, R2 = face curvatures in units of 1/radius (0 planar, +-1 half sphere, > 0 convex)
+mesh_t mesh_lens(dvec3 centre, double radius, double R1c, double R2c, double thickness, int tessellation);
 
 class scene_builder_t {
 public:

@@ -173,22 +173,27 @@ static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
     b.add_shape(rect, M({0, 0, -2, 1 * cm, -1, 0, 0, 1 * cm, 0, 1, 0, 0, 0, 0, 0, 1}), right_wall);
     b.add_shape(rect, M({0, 0, 2, -1 * cm, -1, 0, 0, 1 * cm, 0, -1, 0, 0, 0, 0, 0, 1}), tiles);    // left wall
 
-    const int rec_big = p.mesh_detail ? 6 : 3;   // 81920 / 1280 triangles
+    // the three LFS meshes are replaced by procedural ones of 70 k / 200 k / 2 k triangles (geodesic grids of
+    // frequency 59 / 100: 20 n^2 triangles; mesh_detail = 0: 1280 each, for the CPU checker's small cases)
+    const int n_dragon = p.mesh_detail ? 59 : 8, n_bunny = p.mesh_detail ? 100 : 8;
     // "dragon" stand-in: gold blob, scale 4.8 x 1cm model units (~ +-0.4cm), rotated 150deg about y, translated
-    b.add_shape(mesh_blob(.1 * cm, rec_big, .12, 9, 17),
+    b.add_shape(mesh_blob_geodesic(.1 * cm, n_dragon, .12, 9, 17),
                 xform_t::translate(.05 * cm, .55 * cm, 0) * xform_t::scale(4.0, 5.2, 3.0) * xform_t::rotate(0, 1, 0, deg(150)), gold);
     // prism (length 6mm, height 1.2mm, 90deg), translate(-.705cm,.15cm,0)
     b.add_shape(mesh_prism(6 * mm, 1.2 * mm, deg(90)), xform_t::translate(-.705 * cm, .15 * cm, 0), sf5);
     // ball: sphere r=1.4mm at (-.65cm,.3cm,0), to_world scale y=.25
     b.add_shape(mesh_sphere({-.65 * cm, .3 * cm, 0}, 1.4 * mm, 32), xform_t::scale(1, .25, 1), sf11);
     // "bunny" stand-in: SF5 blob near (.50cm,.89cm,-.09cm)
-    b.add_shape(mesh_blob(.1 * cm, rec_big, .10, 6, 41),
+    b.add_shape(mesh_blob_geodesic(.1 * cm, n_bunny, .10, 6, 41),
                 xform_t::translate(.50 * cm, 1.19 * cm, -.09 * cm) * xform_t::rotate(0, 1, 0, deg(-35)) * xform_t::scale(2.6, 3.0, 2.2), sf5);
-    // "screen" stand-in for star_big.ply: thin plate, face normals, Al fractal (scaled .1), rotated about z, at x=-.425cm
-    b.add_shape(mesh_cube(1 * cm), xform_t::translate(-.425 * cm, 1 * cm, 0) * xform_t::scale(.01, .5, .45), screen, true);
-    // "dragon_lens" stand-in: oblate SF11 spheroid r=1.5mm at (.045,.65,3.5)cm, axis ~ rotate(-.2,1,0; 72deg)
-    b.add_shape(mesh_sphere({0, 0, 0}, 1.5 * mm, 48),
-                xform_t::translate(.045 * cm, .65 * cm, 3.5 * cm) * xform_t::rotate(-.2, 1, 0, deg(72)) * xform_t::scale(1, 1, .12), sf11);
+    // "screen" stand-in for star_big.ply ("star of david", box.xml:199-212): a thin hexagram plate (.1 mm) of 2 k triangles with face
+    // normals, Al fractal (scaled .1), at x = -.425 cm; outer radius 2.5 mm (y) x 2.25 mm (z), the footprint of the former box plate
+    b.add_shape(mesh_star_plate(2.5 * mm, .1 * mm, p.mesh_detail ? 9 : 2), xform_t::translate(-.425 * cm, 1 * cm, 0) * xform_t::scale(1, 1, .9), screen, true);
+    // dragon_lens (box.xml:253-266): the reference's procedural `lens` shape — radius 1.5 mm, R1 = -.01, R2 = -.06, thickness .04 mm,
+    // tessellation 50, SF11 — centred at (.045,.65,3.5) cm in its own frame, then to_world = rotate(-.2,1,0; 72 deg) about the origin
+    // (src/mesh/lens.cpp:24,190-193: translate(centre) first, the shape's world transform second).  (`lens` / `mag_lens` and its
+    // cylinder are commented out in box.xml:214-251.)
+    b.add_shape(mesh_lens({.045 * cm, .65 * cm, 3.5 * cm}, 1.5 * mm, -.01, -.06, .04 * mm, 50), xform_t::rotate(-.2, 1, 0, deg(72)), sf11);
     // pipe
     b.add_shape(mesh_cylinder({-1.1 * cm, 1 * cm, 0}, {-.97 * cm, 1 * cm, 0}, .033 * cm, 32), xform_t::identity(), pipe_m);
     // cube_source: length .20cm, scale(3.1,.04,3.1), translate(.05,.02,-.05)cm, diffuse .01, area emitter blackbody 7000K x 4e-5
@@ -331,6 +336,34 @@ static void build_white_furnace(const scene_params_t& p, scene_builder_t& b) {
     b.add_emitter_area(q, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
 }
 
+// ---- test scenes "lens_<k>": one procedural `lens` (src/mesh/lens.cpp) in front of a diffuse emitter wall — geometry KATs of the
+// shape generator (tests/test_host_baking.py) and a dielectric refraction path for the renderers.
+//   lens_a: the dragon_lens of box.xml:253-266 (double concave, R1 -.01, R2 -.06)   lens_b: plano-convex (R1 .5, R2 0, centre thickness 1 mm)
+//   lens_c: biconvex (R1 .4, R2 .3, centre thickness .9 mm)
+static void build_lens_test(const scene_params_t& p, scene_builder_t& b, int which) {
+    integrator_opts_t o{};
+    o.max_depth = 4;
+    o.MIS = o.RR = 1;
+    o.FSD = 0;
+    o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    b.set_sensor_perspective(xform_t::lookat({-.02, 0, 0}, {0, 0, 0}, {0, 1, 0}), deg(30), p.res, p.res, 1.f, false);
+    const float E[3] = {1, 1, 1};
+    b.set_response_rgb(E);
+    const int glass = b.add_material(mat_dielectric(b.spectrum_const(1.5f)));
+    const int grey = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    const double mm = 1e-3;
+    if (which == 0)
+        b.add_shape(mesh_lens({0, 0, 0}, 1.5 * mm, -.01, -.06, .04 * mm, 50), xform_t::identity(), glass);
+    else if (which == 1)
+        b.add_shape(mesh_lens({0, 0, 0}, 2 * mm, .5, 0, 1 * mm, 24), xform_t::identity(), glass);
+    else
+        b.add_shape(mesh_lens({0, 0, 0}, 2 * mm, .4, .3, .9 * mm, 16), xform_t::identity(), glass);
+    const int wall = b.add_shape(mesh_rectangle({.02, -.02, -.02}, {0, .04, 0}, {0, 0, .04}), xform_t::identity(), grey, true);
+    b.add_emitter_area(wall, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
+}
+
 // ---- test scene "sunlit": diffuse ground + a cube casting a shadow, lit by a `directional` emitter (the reference scenes use
 // directional emitters for their optical previews, e.g. double_slits.xml:138-159), perspective camera looking down.
 static void build_sunlit(const scene_params_t& p, scene_builder_t& b) {
@@ -422,6 +455,8 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b) {
     if (name == "bidir_room")
         build_room(p, b);
+    else if (name == "lens_a" || name == "lens_b" || name == "lens_c")
+        build_lens_test(p, b, name.back() - 'a');
     else if (name == "double_slits_overview")
         build_double_slits_overview(p, b);
     else if (name == "furnace_spm")

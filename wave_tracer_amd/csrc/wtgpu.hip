@@ -48,7 +48,7 @@ constexpr int kBlock = 128;
 #define WTGPU_LDS_STACK 20
 #endif
 constexpr int kLdsStack = WTGPU_LDS_STACK;   // LDS-resident stack entries per lane
-constexpr uint32_t kConeBudget = 48;     // cone-triangle tests one lane may spend on a query before it is handed to a wavefront
+constexpr uint32_t kConeBudget = 32;     // work units (1 per cone-triangle test, 2 per node) one lane may spend on a cone query before it is handed to a wavefront (swept 4..160 after the axis bound: 12 / 20 / 28 / 32 / 48 / 64 / 96 -> 211 / 192 / 181 / 183 / 189 / 196 / 207 ms per pass)
 constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 thread_local std::string g_err;
@@ -941,9 +941,12 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    stack_entry_t spill[kSpillStack];
+    // (the CPU checker's 128-entry stack: this kernel answers every query by itself — in the pipeline a lane whose 64-entry stack
+    // fills up hands the query to a wavefront, k_trace_heavy)
+    stack_entry_t spill[128 - kLdsStack];
     stack_ref_t stack;
     lds_stack(lds, spill, stack);
+    stack.cap = 128;
     const float* c = cones + 10 * (size_t)i;
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});
     const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
