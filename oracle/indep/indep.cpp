@@ -1,0 +1,677 @@
+// oracle/indep/indep.cpp — an INDEPENDENT restatement of the composition layer of plt_bdpt.            *** TEST INFRASTRUCTURE ***
+//
+// oracle/oracle.cpp and the HIP kernels compile the same headers (wave_tracer_amd/csrc/wt/*.h): a mistake in how those headers COMPOSE
+// the primitives into an estimate is invisible to every GPU-vs-checker test.  This file is that composition written a second time,
+// directly from the reference, sharing no header with wt/ (only oracle/indep/prims.h, a C view of the primitives):
+//   * per-sample recursion over std::vector<vertex> like the reference (plt_bdpt_detail.hpp:421-526), not an explicit walk state;
+//   * vertex bookkeeping in double precision: area-measure densities (vertex.hpp:224-243, 444-564), append_vertex / continue_walk
+//     (plt_bdpt_detail.hpp:95-121, 167-182);
+//   * vertex_t::interact (vertex.hpp:330-413), connect_subpaths (plt_bdpt_detail.hpp:747-923), connect_and_integrate (:722-745),
+//     integrate_beams (beam.hpp:562-603) with its own Stokes re-orientation (stokes.hpp:146-165);
+//   * bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720) and the (s,t) loop of plt_bdpt_t::integrate (plt_bdpt.cpp:54-147).
+// It consumes the same counter-based random streams in the reference's order, so it must agree with liboracle.so sample for sample
+// (tests/test_indep.py: images to 1e-4, event counters exactly) — any disagreement is a bug in one of the two compositions.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "prims.h"
+
+namespace {
+
+struct V3 {
+    double x, y, z;
+};
+V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+double len2(V3 a) { return dot(a, a); }
+V3 unit(V3 a) { return a * (1.0 / std::sqrt(len2(a))); }
+V3 from(const float* p) { return {p[0], p[1], p[2]}; }
+void to(V3 v, float* p) {
+    p[0] = (float)v.x;
+    p[1] = (float)v.y;
+    p[2] = (float)v.z;
+}
+// solid-angle sampling densities are "tagged": a negative value is a discrete probability mass (sampler/density.hpp)
+bool is_discrete(float pd) { return std::signbit(pd); }
+double density_or_zero(float pd) { return is_discrete(pd) ? 0.0 : (double)pd; }
+
+enum vtype_e { V_SENSOR, V_EMITTER, V_SURFACE, V_FSD };
+struct vertex {
+    vtype_e type;
+    bool backward;   // transport mode of the subpath this vertex belongs to (sensor subpath: backward)
+    bool delta = false, fraunhofer = false;
+    double pdf_fwd = -1, pdf_bwd = -1, rr_weight = 1;
+    int material = -1, emitter = -1, emitter_of_shape = -1, fsd_slot = -1;
+    bool has_surface = false;   // geometry variant: surface record / bare point
+    prim_surface surface;
+    V3 wp;
+    prim_beam beam;   // the beam ARRIVING at this vertex
+    double& pdf() { return backward ? pdf_bwd : pdf_fwd; }
+    double& pdf_reversed() { return backward ? pdf_fwd : pdf_bwd; }
+};
+
+struct ctx_t {
+    const void* sc;
+    int max_depth, MIS, RR, FSD, sensor_direct, emitter_direct, sensor_flags;
+    int only_s = 0, only_t = 0;   // test hook of the bundled scenes: evaluate one strategy (value - 1) with unit MIS weight
+    uint64_t seed, sid;
+    uint32_t st_sensor, st_emitter, st_connect;
+    bool virtual_sensor() const { return sensor_flags & 1; }
+    unsigned long long ctr[8] = {0};   // segments, vertices, connections, surface, fsd, null, light splats, shadow rays
+};
+
+// ---- vertex predicates (vertex.hpp:260-443) -----------------------------------------------------------------------------------
+bool emitter_is_area(const ctx_t& c, int e) { return prim_emitter_flags(c.sc, e) & 1; }
+bool on_surface(const ctx_t& c, const vertex& v) {
+    return v.type == V_SURFACE || (v.type == V_EMITTER && emitter_is_area(c, v.emitter)) || (v.type == V_SENSOR && v.has_surface);
+}
+bool real_surface(const ctx_t& c, const vertex& v) { return v.type == V_SURFACE || (v.type == V_EMITTER && emitter_is_area(c, v.emitter)); }
+void normals(const ctx_t& c, const vertex& v, V3& ng, V3& ns) {
+    ng = ns = V3{0, 0, 1};   // sensors report (0,0,1), vertex.hpp:271-287
+    if (!real_surface(c, v)) return;
+    float wp[3], g[3], s[3];
+    uint32_t tuid, shape;
+    prim_surface_info(&v.surface, wp, g, s, &tuid, &shape);
+    ng = from(g);
+    ns = from(s);
+}
+bool on_emitter(const vertex& v) { return v.type == V_EMITTER || (v.type == V_SURFACE && v.emitter_of_shape >= 0); }
+int emitter_of(const vertex& v) { return v.type == V_EMITTER ? v.emitter : v.emitter_of_shape; }
+bool connectible(const ctx_t& c, const vertex& v) {
+    switch (v.type) {
+    case V_FSD: return true;
+    case V_EMITTER: return !(prim_emitter_flags(c.sc, v.emitter) & 2);
+    case V_SENSOR: return !(c.sensor_flags & 2);
+    case V_SURFACE: return !prim_material_is_delta_only(c.sc, v.material);
+    }
+    return false;
+}
+bool delta_emitter(const ctx_t& c, const vertex& v) { return v.type == V_EMITTER && (prim_emitter_flags(c.sc, v.emitter) & 6); }
+bool delta_sensor(const ctx_t& c, const vertex& v) { return v.type == V_SENSOR && (c.sensor_flags & 6); }
+
+// ---- densities in area measure (vertex.hpp:224-243, 444-564) ---------------------------------------------------------------------
+double to_area(const ctx_t& c, float dpd, V3 p, const vertex& next) {
+    const double dens = density_or_zero(dpd);
+    if (dens == 0) return 0;
+    const V3 d = next.wp - p;
+    const double d2 = len2(d);
+    if (d2 == 0) return INFINITY;
+    double ppdf = dens / d2;
+    if (on_surface(c, next)) {
+        V3 ng, ns;
+        normals(c, next, ng, ns);
+        ppdf *= std::fabs(dot(ng, unit(d)));
+    }
+    return ppdf;
+}
+double pdf_next_from_sensor(const ctx_t& c, const vertex& v, const vertex& next) {
+    const V3 dl = next.wp - v.wp;
+    const double r2 = 1.0 / len2(dl);
+    const V3 d = dl * std::sqrt(r2);
+    float df[3];
+    to(d, df);
+    double ppdf = density_or_zero(prim_sensor_pdf_direction(c.sc, df)) * r2;
+    if (on_surface(c, next)) {
+        V3 ng, ns;
+        normals(c, next, ng, ns);
+        ppdf *= std::fabs(dot(ng, d));
+    }
+    return ppdf;
+}
+double pdf_sensor(const ctx_t& c) { return density_or_zero(prim_sensor_pdf_position(c.sc)); }
+double pdf_next_from_emitter(const ctx_t& c, const vertex& v, const vertex& next) {
+    const V3 dl = next.wp - v.wp;
+    const double r2 = 1.0 / len2(dl);
+    const V3 d = dl * std::sqrt(r2);
+    const int e = emitter_of(v);
+    float f[3];
+    if (prim_emitter_flags(c.sc, e) & 8) {
+        to(next.wp, f);
+        return prim_directional_pdf_target_position(c.sc, e, f);
+    }
+    to(d, f);
+    double ppdf = density_or_zero(prim_emitter_pdf_direction(c.sc, e, f, real_surface(c, v) ? &v.surface : nullptr)) * r2;
+    if (on_surface(c, next)) {
+        V3 ng, ns;
+        normals(c, next, ng, ns);
+        ppdf *= std::fabs(dot(ng, d));
+    }
+    return ppdf;
+}
+double pdf_emitter(const ctx_t& c, const vertex& v) {
+    const int e = emitter_of(v);
+    return (double)prim_emitter_select_pmf(c.sc, e) * density_or_zero(prim_emitter_pdf_position(c.sc, e));
+}
+float beam_k(const prim_beam& b) {
+    float o[3], d[3], k, I;
+    int tr;
+    prim_beam_info(&b, o, d, &k, &tr, &I);
+    return k;
+}
+double vertex_pdf(const ctx_t& c, const vertex& v, const vertex* prev, const vertex& next, bool mode_backward) {
+    if (v.type == V_EMITTER) return pdf_next_from_emitter(c, v, next);
+    if (v.type == V_SENSOR) return pdf_next_from_sensor(c, v, next);
+    const V3 wiw = unit(prev->wp - v.wp), wow = unit(next.wp - v.wp);
+    float pd = 0;
+    float a[3], b[3], wi[3], wo[3];
+    if (v.type == V_SURFACE) {
+        to(wiw, a);
+        to(wow, b);
+        prim_surface_to_local(&v.surface, a, wi);
+        prim_surface_to_local(&v.surface, b, wo);
+        pd = prim_material_pdf(c.sc, v.material, wi, wo, beam_k(v.beam), mode_backward ? 1 : 0);
+    } else if (v.fraunhofer) {
+        to(wow, b);
+        pd = prim_fsd_pdf(v.fsd_slot, b);
+    }
+    return to_area(c, pd, v.wp, next);
+}
+
+// ---- walk (plt_bdpt_detail.hpp:70-183, 421-526) ----------------------------------------------------------------------------------
+struct walk {
+    prim_beam beam;
+    bool backward;
+    float pdf_from_prev;   // tagged
+    double throughput = 1, rr_weight = 1;
+    std::vector<vertex>& verts;
+    uint32_t stream, draws = 0;
+};
+bool append_vertex(const ctx_t& c, walk& w, vertex& v, float pdf_fwd, float pdf_revr) {
+    vertex& prev = w.verts.back();
+    if (prev.wp.x == v.wp.x && prev.wp.y == v.wp.y && prev.wp.z == v.wp.z) return false;
+    v.pdf() = to_area(c, w.pdf_from_prev, prev.wp, v);
+    v.beam = w.beam;
+    prev.pdf_reversed() = to_area(c, pdf_revr, v.wp, prev);
+    w.pdf_from_prev = pdf_fwd;
+    w.verts.push_back(v);
+    return true;
+}
+bool continue_walk(ctx_t& c, walk& w, bool allow_rr) {
+    if ((int)w.verts.size() > c.max_depth + 1) return false;
+    if (!allow_rr || !c.RR) return true;
+    w.verts.back().rr_weight = w.rr_weight;
+    const double r = w.throughput < 1 ? std::fmax(w.throughput, .5) : 1.0;
+    if ((double)prim_uniform(c.seed, c.sid, w.stream, &w.draws) <= r) {
+        w.rr_weight *= 1 / r;
+        w.throughput *= 1 / r;
+        return true;
+    }
+    return false;
+}
+void random_walk(ctx_t& c, walk& w, int guard = 0) {
+    if (guard >= 96) return;   // the checker's iteration cap (oracle.cpp: kMaxWalkIters); never reached in the shipped scenes
+    const vertex& last = w.verts.back();
+    uint32_t off_tuid = 0xFFFFFFFFu;
+    float png[3] = {0, 0, 1};
+    if (last.has_surface) {   // vertex_geo_variant_t = surface: offset the origin (traversal.hpp:253-257)
+        float wp[3], ns[3];
+        uint32_t shape;
+        prim_surface_info(&last.surface, wp, png, ns, &off_tuid, &shape);
+        V3 ng, nsd;
+        normals(c, last, ng, nsd);
+        to(ng, png);
+    }
+    prim_trav tr;
+    prim_trace(c.sc, &w.beam, off_tuid, png, &tr);
+    c.ctr[0]++;
+    if (tr.empty) return;
+    prim_step st;
+    prim_step_sample(c.sc, &w.beam, &tr, c.seed, c.sid, w.stream, &w.draws, &st);
+    bool do_rr = true;
+    if (st.kind == 0) {
+        // (the reference counts a surface interaction before its wo-side check, plt_bdpt_detail.hpp:243; the checker's counter
+        // semantics are compared on vertices / connections, which are unaffected)
+        return;
+    }
+    if (st.kind == 3 || st.kind == 4) {
+        do_rr = false;
+        if (st.kind == 3) c.ctr[5]++;
+        prim_step_apply(&w.beam, &st);
+    } else {
+        vertex v;
+        v.backward = w.backward;
+        v.wp = from(st.wp);
+        if (st.kind == 1) {
+            v.type = V_SURFACE;
+            v.delta = st.is_delta != 0;
+            v.material = st.material;
+            v.emitter_of_shape = st.emitter_of_shape;
+            v.has_surface = true;
+            v.surface = st.surface;
+            float wp[3], g[3], s[3];
+            uint32_t tuid, shape;
+            prim_surface_info(&st.surface, wp, g, s, &tuid, &shape);
+            v.wp = from(wp);
+        } else {
+            v.type = V_FSD;
+            v.fraunhofer = true;
+            v.fsd_slot = st.fsd_slot;
+            const float n[3] = {0, 0, 1};
+            prim_dummy_surface(n, st.wp, &v.surface);
+        }
+        if (!append_vertex(c, w, v, st.dpd, st.pdf_revr)) return;
+        c.ctr[1]++;
+        c.ctr[st.kind == 1 ? 3 : 4]++;
+        prim_step_apply(&w.beam, &st);
+        w.throughput *= st.throughput_mult;
+    }
+    if (continue_walk(c, w, do_rr)) random_walk(c, w, guard + 1);
+}
+
+// ---- beams ------------------------------------------------------------------------------------------------------------------------
+struct stokes {
+    double s[4];
+};
+double intensity(const prim_beam& b) {
+    float o[3], d[3], k, I;
+    int tr;
+    prim_beam_info(&b, o, d, &k, &tr, &I);
+    return I;
+}
+V3 beam_dir(const prim_beam& b) {
+    float o[3], d[3], k, I;
+    int tr;
+    prim_beam_info(&b, o, d, &k, &tr, &I);
+    return from(d);
+}
+V3 beam_origin(const prim_beam& b) {
+    float o[3], d[3], k, I;
+    int tr;
+    prim_beam_info(&b, o, d, &k, &tr, &I);
+    return from(o);
+}
+// Stokes vector re-oriented from frame `cur` to frame `nw` (same normal): stokes.hpp:146-165
+stokes reorient(const stokes& S, const V3 cur[3], const V3 nw[3]) {
+    const double tx = dot(cur[0], nw[0]), ty = dot(cur[1], nw[0]);   // new tangent in the current frame
+    const double bx = dot(cur[0], nw[1]), by = dot(cur[1], nw[1]);
+    const double n = std::sqrt(tx * tx + ty * ty);
+    const double c = n > 0 ? tx / n : 1, s = n > 0 ? ty / n : 0;     // R = rotation taking (1,0) to the new tangent
+    auto R = [&](double x, double y, double& ox, double& oy) {
+        ox = c * x - s * y;
+        oy = s * x + c * y;
+    };
+    double q1, u1, q2, u2;
+    R(S.s[1], S.s[2], q1, u1);
+    R(q1, u1, q2, u2);
+    stokes r{{S.s[0], q2, u2, S.s[3]}};
+    double vx, vy;
+    R(0, 1, vx, vy);
+    if (vx * bx + vy * by < 0) {   // handedness flip
+        r.s[2] = -r.s[2];
+        r.s[3] = -r.s[3];
+    }
+    return r;
+}
+// integrate_beams (beam.hpp:562-603): Md.scale * Md.M(Sd.S, Sd.frame, Md.frame)
+stokes integrate_beams(const prim_beam& det, const prim_beam& rad) {
+    if (intensity(det) == 0 || intensity(rad) == 0) return {{0, 0, 0, 0}};
+    float Mr[16], Mf[9], Ms, Sr[16], Sf[9], Ss;
+    prim_beam_payload(&det, Mr, Mf, &Ms);
+    prim_beam_payload(&rad, Sr, Sf, &Ss);
+    stokes S{{Sr[0], Sr[1], Sr[2], Sr[3]}};
+    if (!(S.s[1] == 0 && S.s[2] == 0 && S.s[3] == 0)) {   // mueller.hpp:134-144: unpolarised light needs no alignment
+        const V3 cur[3] = {from(Sf), from(Sf + 3), from(Sf + 6)}, nw[3] = {from(Mf), from(Mf + 3), from(Mf + 6)};
+        S = reorient(S, cur, nw);
+    }
+    stokes r;
+    for (int i = 0; i < 4; ++i) {
+        double a = 0;
+        for (int j = 0; j < 4; ++j) a += (double)Mr[4 * i + j] * S.s[j];
+        r.s[i] = a * (double)Ms;
+    }
+    return r;
+}
+
+// vertex_t::interact (vertex.hpp:330-413): the beam arriving at v transformed towards `next`
+bool interact(const ctx_t& c, const vertex& v, const vertex& next, bool ignore_fsd, prim_beam& out) {
+    const V3 wiw = beam_dir(v.beam) * -1.0;
+    const float k = beam_k(v.beam);
+    const V3 wow = unit(next.wp - v.wp);
+    float wof[3];
+    to(wow, wof);
+    float f = 0;
+    if (v.fraunhofer && !ignore_fsd) f = prim_fsd_pdf(v.fsd_slot, wof);
+    if (v.type == V_SURFACE) {
+        float a[3], wi[3], wo[3];
+        to(wiw, a);
+        prim_surface_to_local(&v.surface, a, wi);
+        prim_surface_to_local(&v.surface, wof, wo);
+        V3 ng, ns;
+        normals(c, v, ng, ns);
+        const double wig = dot(wiw, ng), wog = dot(wow, ng), wis = wi[2], wos = wo[2];
+        if (wig * wis <= 0 || wog * wos <= 0) return false;
+        float M[16];
+        prim_material_f(c.sc, v.material, wi, wo, k, v.backward ? 1 : 0, M);
+        double scale = 1.0 / std::fabs(wos);
+        if (!(ns.x == ng.x && ns.y == ng.y && ns.z == ng.z) && !v.backward)   // integrator/common.hpp:21-33 (forward transport only)
+            scale *= std::fmin(std::fabs(wis * wog / (wos * wig)), 100.0);
+        for (float& m : M) m = (float)(m * scale);
+        if (f > 0) {
+            M[0] += f;
+            M[5] += f;
+            M[10] += f;
+            M[15] += f;
+        }
+        if (M[0] == 0) return false;
+        out = v.beam;
+        prim_beam_transform_surface(&out, &v.surface, wof, M, 1.f);
+        return true;
+    }
+    if (v.type == V_FSD) {
+        const double beam_dist = dot(v.wp - beam_origin(v.beam), beam_dir(v.beam));
+        float p[3];
+        to(v.wp, p);
+        out = v.beam;
+        prim_beam_transform_region(&out, p, (float)beam_dist, wof, f);
+        return true;
+    }
+    return false;
+}
+
+// integrator::shadow + connect_and_integrate (traversal.hpp:319-333, plt_bdpt_detail.hpp:722-745)
+stokes connect_and_integrate(ctx_t& c, const prim_beam& db, const vertex& dv, const prim_beam& eb, const vertex& ev) {
+    if (intensity(db) == 0 || intensity(eb) == 0) return {{0, 0, 0, 0}};
+    c.ctr[7]++;
+    float a[3], b[3], rd[3], nrd[3], o[3], t[3];
+    to(dv.wp, a);
+    to(ev.wp, b);
+    const V3 d = unit(ev.wp - dv.wp);
+    to(d, rd);
+    to(d * -1.0, nrd);
+    prim_offset_origin(c.sc, dv.has_surface ? &dv.surface : nullptr, a, rd, o);
+    prim_offset_origin(c.sc, ev.has_surface ? &ev.surface : nullptr, b, nrd, t);
+    const V3 ot = from(t) - from(o);
+    const double dist = std::sqrt(len2(ot));
+    float dd[3];
+    to(ot * (1.0 / dist), dd);
+    if (prim_shadow_ray(c.sc, o, dd, (float)dist)) return {{0, 0, 0, 0}};
+    return integrate_beams(db, eb);
+}
+
+struct connect_ret {
+    stokes L{{0, 0, 0, 0}};
+    vertex tmp;
+    bool has_tmp = false, has_element = false;
+    prim_element element;
+};
+vertex temp_vertex(vtype_e type, bool backward, int emitter, bool has_surface, const prim_surface& s, V3 p) {
+    vertex v;
+    v.type = type;
+    v.backward = backward;
+    v.emitter = emitter;
+    v.has_surface = has_surface;
+    v.wp = p;
+    if (has_surface) {
+        v.surface = s;
+        float wp[3], g[3], n[3];
+        uint32_t tuid, shape;
+        prim_surface_info(&s, wp, g, n, &tuid, &shape);
+        v.wp = from(wp);
+    } else {
+        const float n[3] = {0, 0, 1};
+        float pf[3];
+        to(p, pf);
+        prim_dummy_surface(n, pf, &v.surface);
+    }
+    return v;
+}
+// connect_subpaths (plt_bdpt_detail.hpp:747-923)
+connect_ret connect(ctx_t& c, std::vector<vertex>& sv, std::vector<vertex>& ev, int s, int t) {
+    connect_ret r;
+    c.ctr[2]++;
+    const uint32_t stream = c.st_connect + (uint32_t)t * 32u + (uint32_t)s;
+    uint32_t draws = 0;
+    if (s == 0) {
+        const vertex& last = sv[t - 1];
+        if (on_emitter(last)) {
+            prim_beam QE = last.beam;
+            prim_beam_scale(&QE, (float)last.rr_weight);
+            float L[4];
+            prim_emitter_Li(c.sc, emitter_of(last), &QE, &last.surface, L);
+            r.L = {{L[0], L[1], L[2], L[3]}};
+        }
+    } else if (t == 0) {
+        if (c.virtual_sensor()) {
+            const vertex &last = ev[s - 1], &cur = ev[s - 2];
+            const double dist = std::sqrt(len2(last.wp - beam_origin(last.beam)));
+            prim_si si;
+            prim_vplane_Si(c.sc, &last.beam, (float)dist, &si);
+            if (si.valid) {
+                r.element = si.element;
+                r.has_element = true;
+                double w = cur.rr_weight;
+                const V3 dbd = beam_dir(si.beam);
+                if (on_surface(c, cur) && (cur.type == V_SURFACE || cur.type == V_FSD) && !cur.delta) {
+                    V3 ng, ns;
+                    normals(c, cur, ng, ns);
+                    w /= std::fabs(dot(dbd, ns));
+                }
+                float wp[3], g[3], n[3];
+                uint32_t tuid, shape;
+                prim_surface_info(&si.surface, wp, g, n, &tuid, &shape);
+                w /= std::fabs(dot(dbd, from(g)));
+                prim_beam_scale(&si.beam, (float)w);
+                r.tmp = temp_vertex(V_SENSOR, true, -1, true, si.surface, beam_origin(si.beam));
+                r.has_tmp = true;
+                r.L = integrate_beams(si.beam, last.beam);
+            }
+        }
+    } else if (s == 1) {
+        const vertex& last = sv[t - 1];
+        if (connectible(c, last)) {
+            float wp[3];
+            to(last.wp, wp);
+            prim_edirect ed;
+            prim_sample_emitter_direct(c.sc, wp, beam_k(last.beam), c.seed, c.sid, stream, &draws, &ed);
+            if ((is_discrete(ed.dpd) || ed.dpd != 0) && intensity(ed.beam) > 0) {
+                double w = last.rr_weight;
+                if (on_surface(c, last)) {
+                    V3 ng, ns;
+                    normals(c, last, ng, ns);
+                    w *= std::fabs(dot(beam_dir(ed.beam), ns));
+                }
+                prim_beam_scale(&ed.beam, (float)w);
+                r.tmp = temp_vertex(V_EMITTER, false, ed.emitter, ed.has_surface != 0, ed.surface, beam_origin(ed.beam));
+                r.has_tmp = true;
+                prim_beam db;
+                if (interact(c, last, r.tmp, false, db)) r.L = connect_and_integrate(c, db, last, ed.beam, r.tmp);
+            }
+        }
+    } else if (t == 1) {
+        const vertex& last = ev[s - 1];
+        if ((c.virtual_sensor() || last.type != V_FSD) && connectible(c, last)) {
+            float wp[3];
+            to(last.wp, wp);
+            prim_sdirect sd;
+            prim_sensor_sample_direct(c.sc, wp, beam_k(last.beam), c.seed, c.sid, stream, &draws, &sd);
+            if ((is_discrete(sd.dpd) || sd.dpd != 0) && intensity(sd.beam) > 0) {
+                double w = last.rr_weight;
+                if (on_surface(c, last)) {
+                    V3 ng, ns;
+                    normals(c, last, ng, ns);
+                    w *= std::fabs(dot(beam_dir(sd.beam), ns));
+                }
+                prim_beam_scale(&sd.beam, (float)w);
+                r.tmp = temp_vertex(V_SENSOR, true, -1, sd.has_surface != 0, sd.surface, beam_origin(sd.beam));
+                r.has_tmp = true;
+                prim_beam eb;
+                if (interact(c, last, r.tmp, false, eb)) {
+                    r.L = connect_and_integrate(c, sd.beam, r.tmp, eb, last);
+                    r.element = sd.element;
+                    r.has_element = true;
+                }
+            }
+        }
+    } else {
+        const vertex &e = ev[s - 1], &v = sv[t - 1];
+        const V3 dl = e.wp - v.wp;
+        if (connectible(c, e) && connectible(c, v) && !(dl.x == 0 && dl.y == 0 && dl.z == 0)) {
+            prim_beam eb, db;
+            const bool heb = interact(c, e, v, true, eb), hdb = interact(c, v, e, true, db);
+            if (heb && hdb) {
+                const double r2 = 1.0 / len2(dl);
+                const V3 d = dl * std::sqrt(r2);
+                double wev = e.rr_weight, wsv = v.rr_weight * r2;
+                V3 ng, ns;
+                if (on_surface(c, v)) {
+                    normals(c, v, ng, ns);
+                    wev *= std::fabs(dot(ns, d));
+                }
+                if (on_surface(c, e)) {
+                    normals(c, e, ng, ns);
+                    wsv *= std::fabs(dot(ns, d));
+                }
+                prim_beam_scale(&db, (float)wsv);
+                prim_beam_scale(&eb, (float)wev);
+                r.L = connect_and_integrate(c, db, v, eb, e);
+            }
+        }
+    }
+    return r;
+}
+
+// bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720)
+double mis_weight(const ctx_t& c, const std::vector<vertex>& sv, const std::vector<vertex>& ev, int s, int t, const connect_ret& cr) {
+    if (s + t <= 2) return 1;
+    struct pdfs {
+        double pdf, rev;
+        bool delta;
+    };
+    std::vector<pdfs> sp(t), ep(s);
+    for (int i = 0; i < t; ++i) sp[i] = {sv[i].pdf_bwd, sv[i].pdf_fwd, sv[i].delta};
+    for (int i = 0; i < s; ++i) ep[i] = {ev[i].pdf_fwd, ev[i].pdf_bwd, ev[i].delta};
+    const vertex& tv = cr.tmp;
+    if (s == 0) {
+        sp[t - 1].rev = pdf_emitter(c, sv[t - 1]);
+        sp[t - 2].rev = pdf_next_from_emitter(c, sv[t - 1], sv[t - 2]);
+    } else if (t == 0) {
+        const vertex& last = c.virtual_sensor() ? tv : ev[s - 1];
+        ep[s - 1].rev = pdf_sensor(c);
+        ep[s - 2].rev = pdf_next_from_sensor(c, last, ev[s - 2]);
+    } else if (s == 1) {
+        sp[t - 1].rev = pdf_next_from_emitter(c, tv, sv[t - 1]);
+        ep.resize(1);
+        ep[0].rev = vertex_pdf(c, sv[t - 1], &sv[t - 2], tv, true);
+        ep[0].pdf = pdf_emitter(c, tv);
+        ep[0].delta = false;
+    } else if (t == 1) {
+        ep[s - 1].rev = pdf_next_from_sensor(c, tv, ev[s - 1]);
+        sp.resize(1);
+        sp[0].rev = vertex_pdf(c, ev[s - 1], &ev[s - 2], tv, false);
+        sp[0].pdf = pdf_sensor(c);
+        sp[0].delta = false;
+    } else {
+        const vertex &e = ev[s - 1], &v = sv[t - 1], &ep_ = ev[s - 2], &vp = sv[t - 2];
+        ep[s - 1].rev = vertex_pdf(c, v, &vp, e, true);
+        ep[s - 2].rev = vertex_pdf(c, e, &v, ep_, true);
+        sp[t - 1].rev = vertex_pdf(c, e, &ep_, v, false);
+        sp[t - 2].rev = vertex_pdf(c, v, &e, vp, false);
+    }
+    if (t > 0) sp[t - 1].delta = false;
+    if (s > 0) ep[s - 1].delta = false;
+    const bool de = s == 1 ? delta_emitter(c, tv) : (s > 1 ? delta_emitter(c, ev[0]) : true);
+    const bool ds = t == 1 ? delta_sensor(c, tv) : (t > 1 ? delta_sensor(c, sv[0]) : true);
+    // area_density_or_one: epsilon of the reference's f_t = float
+    auto one = [](double p) { return std::isfinite(p) && p > 1.1920929e-7 ? p : 1.0; };
+    double sum = 0, ri = 1;
+    for (int i = t - 1; i >= 0; --i) {
+        ri *= one(sp[i].rev) / one(sp[i].pdf);
+        if (!sp[i].delta && !(i > 0 ? sp[i - 1].delta : ds)) sum += ri;
+    }
+    ri = 1;
+    for (int i = s - 1; i >= 0; --i) {
+        ri *= one(ep[i].rev) / one(ep[i].pdf);
+        if (!ep[i].delta && !(i > 0 ? ep[i - 1].delta : de)) sum += ri;
+    }
+    return 1.0 / (1.0 + sum);
+}
+
+// plt_bdpt_t::integrate, one sample (plt_bdpt.cpp:54-147)
+void sample(ctx_t& c, uint32_t px, uint32_t py, double* value, double* weight, double* light) {
+    prim_pool_reset();
+    prim_gen g;
+    prim_generate(c.sc, c.seed, c.sid, px, py, &g);
+    std::vector<vertex> sv, ev;
+    {   // create_sensor / create_emitter (vertex.hpp:77-121)
+        vertex v = temp_vertex(V_SENSOR, true, -1, g.s_has_surface != 0, g.s_surface, beam_origin(g.sbeam));
+        v.pdf_bwd = density_or_zero(g.s_ppd);
+        v.beam = g.sbeam;
+        sv.push_back(v);
+        vertex e = temp_vertex(V_EMITTER, false, g.emitter, g.e_has_surface != 0, g.e_surface, beam_origin(g.ebeam));
+        e.pdf_fwd = density_or_zero(g.e_ppd) * (double)g.e_select_pdf;
+        e.beam = g.ebeam;
+        ev.push_back(e);
+    }
+    walk ws{g.sbeam, true, g.s_dpd, 1, 1, sv, c.st_sensor};
+    random_walk(c, ws);
+    walk we{g.ebeam, false, g.e_dpd, 1, 1, ev, c.st_emitter};
+    random_walk(c, we);
+    stokes L{{0, 0, 0, 0}};
+    for (int t = 0; t <= (int)sv.size(); ++t)
+        for (int s = 0; s <= (int)ev.size(); ++s) {
+            const int depth = t + s - 2;
+            if ((t == 1 && s == 1) || depth < 0) continue;
+            if (!c.emitter_direct && s == 1) continue;
+            if (!c.sensor_direct && t == 1) continue;
+            if (depth > c.max_depth) break;
+            if ((c.only_s && c.only_s - 1 != s) || (c.only_t && c.only_t - 1 != t)) continue;
+            const connect_ret cr = connect(c, sv, ev, s, t);
+            if (!(cr.L.s[0] > 0)) continue;
+            const double mis = (c.only_s || c.only_t) ? (double)g.recp_spectral_pd : c.MIS ? mis_weight(c, sv, ev, s, t, cr) * (double)g.recp_spectral_pd : 1.0 / ((double)(s + t + 1) * (double)g.k_density);
+            float f[4];
+            for (int i = 0; i < 4; ++i) f[i] = (float)(cr.L.s[i] * mis);
+            if (t > 1) {
+                for (int i = 0; i < 4; ++i) L.s[i] += f[i];
+            } else if (cr.has_element) {
+                prim_film_splat(c.sc, value, weight, light, &cr.element, f, g.k, 1);
+                c.ctr[6]++;
+            }
+        }
+    float f[4] = {(float)L.s[0], (float)L.s[1], (float)L.s[2], (float)L.s[3]};
+    prim_film_splat(c.sc, value, weight, light, &g.element, f, g.k, 0);
+}
+
+}   // namespace
+
+extern "C" {
+// Renders samples [sample_begin, sample_end) of every sensor element into the (caller-zeroed) films, single-threaded (the films are
+// plain arrays); counters: segments, vertices, connections, surface / fsd / null interactions, light splats, shadow rays.
+int indep_render(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
+                 unsigned long long* counters) {
+    int info[14];
+    prim_info(scene_host, info);
+    if (info[10] != 0) return 1;   // plt_bdpt only
+    uint32_t st[4];
+    prim_streams(st);
+    ctx_t c;
+    c.sc = scene_host;
+    c.max_depth = info[0];
+    c.MIS = info[1];
+    c.RR = info[2];
+    c.FSD = info[3];
+    c.sensor_direct = info[4];
+    c.emitter_direct = info[5];
+    c.sensor_flags = info[11];
+    c.only_s = info[12];
+    c.only_t = info[13];
+    c.seed = seed;
+    c.st_sensor = st[1];
+    c.st_emitter = st[2];
+    c.st_connect = st[3];
+    const uint32_t W = (uint32_t)info[6], H = (uint32_t)info[7];
+    for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x)
+            for (uint64_t s = sample_begin; s < sample_end; ++s) {
+                const uint64_t pix = (uint64_t)y * W + x;
+                c.sid = (pix << 32) | (s & 0xFFFFFFFFull);
+                sample(c, x, y, value, weight, light);
+            }
+    if (counters) std::memcpy(counters, c.ctr, sizeof(c.ctr));
+    return 0;
+}
+}

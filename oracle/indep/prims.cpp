@@ -1,0 +1,366 @@
+// oracle/indep/prims.cpp — the primitive layer behind oracle/indep/prims.h: thin wrappers over the restated physics in
+// wave_tracer_amd/csrc/wt/*.h (one primitive each) plus the SAMPLING half of an interaction (sample_surface_interaction /
+// sample_fraunhofer_fsd_interaction / sample_null_interaction / find_closest_triangle, plt_bdpt_detail.hpp:192-419), restated here a second
+// time.  Nothing in this file composes a path.                                                        *** TEST INFRASTRUCTURE ***
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../wave_tracer_amd/csrc/wt/bdpt.h"
+#include "prims.h"
+
+using namespace wt;
+
+namespace {
+static_assert(sizeof(beam_t) <= sizeof(prim_beam) && sizeof(surface_t) <= sizeof(prim_surface) && sizeof(sensor_element_t) <= sizeof(prim_element), "blob sizes");
+template <class T, class B>
+T get(const B* b) {
+    T t;
+    std::memcpy(&t, b->b, sizeof(T));
+    return t;
+}
+template <class T, class B>
+void put(B* b, const T& t) {
+    std::memset(b->b, 0, sizeof(b->b));
+    std::memcpy(b->b, &t, sizeof(T));
+}
+vec3 v3(const float* p) { return {p[0], p[1], p[2]}; }
+void o3(float* p, vec3 v) {
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+const scene_t& S(const void* sc) { return *static_cast<const scene_t*>(sc); }
+
+// per-thread scratch: traversal stack + unbounded triangle list of the last prim_trace, Fraunhofer apertures of the current sample
+struct tls_t {
+    stack_entry_t stack[128];
+    std::vector<uint32_t> tris = std::vector<uint32_t>(1u << 18);
+    std::vector<float> dists = std::vector<float>(1u << 18);
+    std::vector<fsd_aperture_t> hdr = std::vector<fsd_aperture_t>(64);
+    std::vector<fsd_edge_t> edges = std::vector<fsd_edge_t>(64 * (size_t)kFsdMaxEdges);
+    uint32_t n_ap = 0;
+};
+thread_local tls_t tls;
+stack_ref_t stack() { return make_flat_stack(tls.stack, 128); }
+}   // namespace
+
+extern "C" {
+
+void prim_info(const void* sc_, int out[14]) {
+    const scene_t& sc = S(sc_);
+    const int v[14] = {sc.opts.max_depth, (int)sc.opts.MIS, (int)sc.opts.RR, (int)sc.opts.FSD, (int)sc.opts.sensor_direct, (int)sc.opts.emitter_direct,
+                       (int)sc.sensor.width, (int)sc.sensor.height, (int)sc.sensor.channels, (int)film_stokes(sc.sensor), (int)sc.opts.integrator,
+                       (sensor_is_virtual(sc.sensor) ? 1 : 0) | (sensor_is_delta_direction(sc.sensor) ? 2 : 0) | (sensor_is_delta_position(sc.sensor) ? 4 : 0) |
+                           ((sc.sensor.ray_trace_only || sc.opts.force_ray_tracing) ? 8 : 0),
+                       (int)sc.opts.debug_only_s, (int)sc.opts.debug_only_t};
+    std::memcpy(out, v, sizeof(v));
+}
+void prim_streams(uint32_t out[4]) {
+    out[0] = STREAM_SCENE;
+    out[1] = STREAM_SENSOR_WALK;
+    out[2] = STREAM_EMITTER_WALK;
+    out[3] = STREAM_CONNECT;
+}
+void prim_pool_reset(void) { tls.n_ap = 0; }
+
+void prim_generate(const void* sc_, uint64_t seed, uint64_t sid, uint32_t px, uint32_t py, prim_gen* out) {
+    const scene_t& sc = S(sc_);
+    sampler_t smp = make_sampler(seed, sid, STREAM_SCENE);
+    const emitter_k_sample_t ek = scene_sample_emitter_and_spectrum(sc, smp);
+    const float k = ek.wavenumber.k;
+    const emitter_sample_t es = emitter_sample(sc, ek.emitter, k, smp);
+    const bool disc = pd_is_discrete(ek.wavenumber.wpd);
+    out->k = k;
+    out->recp_spectral_pd = disc ? 1.f / pd_mass(ek.wavenumber.wpd) : 1.f / scene_sum_spectral_pdf(sc, k);
+    out->k_density = disc ? pd_mass(ek.wavenumber.wpd) : ek.wavenumber.wpd;
+    const sensor_sample_t ss = sensor_sample(sc, px, py, k, smp);
+    put(&out->element, ss.element);
+    put(&out->sbeam, ss.beam);
+    out->s_dpd = ss.dpd;
+    out->s_ppd = ss.ppd;
+    out->s_has_surface = ss.has_surface;
+    put(&out->s_surface, ss.surface);
+    put(&out->ebeam, es.beam);
+    out->e_dpd = es.dpd;
+    out->e_ppd = es.ppd;
+    out->e_select_pdf = ek.emitter_pdf;
+    out->emitter = ek.emitter;
+    out->e_has_surface = es.has_surface;
+    put(&out->e_surface, es.surface);
+}
+
+// integrator::traverse (+ the self-intersection offset of the origin, traversal.hpp:276-288)
+void prim_trace(const void* sc_, const prim_beam* beam, uint32_t prev_offset_tuid, const float prev_ng[3], prim_trav* out) {
+    const scene_t& sc = S(sc_);
+    const beam_t b = get<beam_t>(beam);
+    cone_t env = b.env;
+    if (prev_offset_tuid != kInvalid) {
+        const tri_geo_t g = sc.tri_geo[prev_offset_tuid];
+        const vec3 ng = v3(prev_ng);
+        const vec3 err = triangle_fp_errors(g.a, g.b, g.c, env.o);
+        const vec3 offset = dot(err, vabs(ng)) * ng;
+        env.o = env.o + (dot(env.d, offset) >= 0.f ? offset : -offset);
+    }
+    const uint_list_t tris{tls.tris.data(), 1, (uint32_t)tls.tris.size(), tls.dists.data()};
+    const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+    const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(b.k), WT_INF, rt, stack(), tris);
+    out->empty = tr.empty;
+    out->ballistic = tr.ballistic;
+    out->dist = tr.dist;
+    out->region_depth = tr.region_depth;
+    out->front_face = tr.front_face;
+    out->tuid = tr.tuid;
+    out->bx = tr.bx;
+    out->by = tr.by;
+    out->ntris = tr.ntris;
+    o3(out->origin, tr.origin);
+}
+
+// The sampling half of one interaction (no vertex bookkeeping, no beam transform): plt_bdpt_detail.hpp:192-419.
+void prim_step_sample(const void* sc_, const prim_beam* beam_, const prim_trav* tr, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_step* out) {
+    const scene_t& sc = S(sc_);
+    const beam_t beam = get<beam_t>(beam_);
+    sampler_t smp = make_sampler(seed, sid, stream, *draws);
+    std::memset(out, 0, sizeof(*out));
+    out->fsd_slot = -1;
+    out->emitter_of_shape = -1;
+    const float beam_dist = tr->dist;
+    const range_t izr{beam_dist, beam_dist + tr->region_depth};
+    const bool ballistic = tr->ballistic || beam_is_ray(beam);
+    const vec3 origin = v3(tr->origin), dir = beam.env.d;
+    const vec3 interaction_wp = origin + izr.min * dir;
+    o3(out->wp, interaction_wp);
+    out->apply_dist = beam_dist;
+    const frame_t bf = cone_frame(beam.env);
+    const vec3 sd = beam_footprint(beam, beam_dist) / kBeamEnvelope;
+    const vec2 sigma{sd.x, sd.y};
+    // --- find_closest_triangle
+    uint32_t primary = kInvalid;
+    ray_tri_hit_t ph{WT_INF, 0.f, 0.f};
+    if (ballistic) {
+        primary = tr->tuid;
+        ph = {tr->dist, tr->bx, tr->by};
+    } else {
+        for (uint32_t i = 0; i < tr->ntris; ++i) {
+            const tri_geo_t g = sc.tri_geo[tls.tris[i]];
+            ray_tri_hit_t h;
+            if (intersect_ray_tri(origin, dir, g.a, g.b, g.c, grow(izr, cone_intersection_tolerance(origin, g.a, g.b, g.c)), h) && h.dist < ph.dist) {
+                primary = tls.tris[i];
+                ph = h;
+            }
+        }
+    }
+    if (primary != kInvalid) {
+        // --- sample_surface_interaction
+        const tri_geo_t g = sc.tri_geo[primary];
+        surface_t srf = make_surface(sc, primary, g.n, vec2{ph.bx, ph.by}, origin + dir * ph.dist);
+        srf.footprint = beam_surface_footprint_static(beam, srf, beam_dist);
+        const shape_t shp = sc.shapes[srf.shape];
+        const vec3 wiw = -dir, ng = srf.geo.n, ns = srf.shading.n;
+        const vec3 wi = to_local(srf.shading, wiw);
+        const float wig = dot(wiw, ng), wis = wi.z;
+        if (wig * wis <= 0.f) return;
+        const bsdf_sample_t bs = material_sample(sc, shp.material, wi, beam.k, beam.transport, smp);
+        *draws = smp.draws;
+        if (!bs.valid || bs.dpd == 0.f) return;
+        const vec3 wow = normalize(to_world(srf.shading, bs.wo));
+        const float wog = dot(wow, ng), wos = bs.wo.z;
+        if (wog * wos <= 0.f) return;
+        out->kind = 1;
+        put(&out->surface, srf);
+        out->material = shp.material;
+        out->emitter_of_shape = shp.emitter;
+        out->is_delta = pd_is_discrete(bs.dpd);
+        out->dpd = bs.dpd;
+        out->pdf_revr = material_pdf(sc, shp.material, bs.wo, wi, beam.k, flip_transport(beam.transport));
+        float w = 1.f;
+        if (!veq(ns, ng)) w *= shading_normals_correction_scale(beam.transport, wig, wog, wis, wos);
+        out->apply_w = w;
+        std::memcpy(out->apply_M, bs.M.m, sizeof(out->apply_M));
+        o3(out->apply_wo, wow);
+        out->throughput_mult = w * mueller_mean_intensity(bs.M);
+        if (beam.transport == TRANSPORT_BACKWARD && bs.eta != 1.f) out->throughput_mult /= sqr(bs.eta);
+        return;
+    }
+    // --- edges of the region (traversal_common.hpp:124-148)
+    std::vector<uint32_t> eids;
+    if (sc.opts.FSD && !ballistic)
+        for (uint32_t i = 0; i < tr->ntris; ++i)
+            for (int e = 0; e < 3; ++e) {
+                const uint32_t id = sc.tri_meta[tls.tris[i]].edge[e];
+                if (id != kInvalid) eids.push_back(id);
+            }
+    std::sort(eids.begin(), eids.end());
+    eids.erase(std::unique(eids.begin(), eids.end()), eids.end());
+    if (eids.empty()) {   // --- sample_null_interaction
+        out->kind = 3;
+        out->throughput_mult = 1.f;
+        return;
+    }
+    // --- sample_fraunhofer_fsd_interaction
+    if (tls.n_ap >= tls.hdr.size()) return;
+    const uint32_t slot = tls.n_ap++;
+    fsd_aperture_t ap;
+    ap.edge_offset = slot * kFsdMaxEdges;
+    ap.edge_cap = kFsdMaxEdges;
+    const fsd_edges_ref_t ed{tls.edges.data() + ap.edge_offset, 1};
+    fsd_build_aperture(sc, bf, beam.k, 1.f, beam.env, eids.data(), (uint32_t)eids.size(), sigma, ap, ed);
+    if (ap.n_edges == 0) {   // empty aperture: restart (do_RR = false), the slot stays unused
+        --tls.n_ap;
+        out->kind = 4;
+        out->throughput_mult = 1.f;
+        return;
+    }
+    double flux = 0;
+    for (uint32_t i = 0; i < tr->ntris; ++i) flux += region_triangle_flux(sc, bf, beam.env, izr, sigma, tls.tris[i], tr->front_face != 0);
+    const float I = (float)(1.0 - flux);
+    ap.recp_I = I > 0.f ? 1.f / I : 0.f;
+    tls.hdr[slot] = ap;
+    const fsd_sample_t fs = fsd_sample(sc, ap, ed, smp);
+    *draws = smp.draws;
+    if (fs.dpd == 0.f || fs.weight == 0.f) return;
+    out->kind = 2;
+    out->fsd_slot = (int)slot;
+    out->dpd = out->pdf_revr = fs.dpd;
+    out->apply_w = fs.weight;
+    o3(out->apply_wo, to_world(ap.frame, fs.wo));
+    out->throughput_mult = fs.weight;
+}
+void prim_step_apply(prim_beam* beam_, const prim_step* st) {
+    beam_t b = get<beam_t>(beam_);
+    if (st->kind == 1) {
+        mueller_t M;
+        std::memcpy(M.m, st->apply_M, sizeof(M.m));
+        beam_transform_surface_interaction(b, get<surface_t>(&st->surface), v3(st->apply_wo), M, st->apply_w);
+    } else if (st->kind == 2)
+        beam_transform_region_interaction(b, v3(st->wp), st->apply_dist, v3(st->apply_wo), st->apply_w);
+    else if (st->kind == 3 || st->kind == 4)
+        beam_transform_restart(b, v3(st->wp), st->apply_dist);
+    put(beam_, b);
+}
+float prim_uniform(uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws) {
+    sampler_t smp = make_sampler(seed, sid, stream, *draws);
+    const float u = sampler_r(smp);
+    *draws = smp.draws;
+    return u;
+}
+
+void prim_beam_info(const prim_beam* b_, float o[3], float d[3], float* k, int* transport, float* intensity) {
+    const beam_t b = get<beam_t>(b_);
+    o3(o, b.env.o);
+    o3(d, b.env.d);
+    *k = b.k;
+    *transport = (int)b.transport;
+    *intensity = beam_intensity(b);
+}
+void prim_beam_scale(prim_beam* b_, float f) {
+    beam_t b = get<beam_t>(b_);
+    beam_scale(b, f);
+    put(b_, b);
+}
+void prim_beam_payload(const prim_beam* b_, float rad[16], float frame[9], float* scale) {
+    const beam_t b = get<beam_t>(b_);
+    std::memcpy(rad, b.rad, sizeof(b.rad));
+    o3(frame, b.frame.t);
+    o3(frame + 3, b.frame.b);
+    o3(frame + 6, b.frame.n);
+    *scale = b.scale;
+}
+void prim_beam_transform_surface(prim_beam* b_, const prim_surface* s, const float wo[3], const float M_[16], float weight) {
+    beam_t b = get<beam_t>(b_);
+    mueller_t M;
+    std::memcpy(M.m, M_, sizeof(M.m));
+    beam_transform_surface_interaction(b, get<surface_t>(s), v3(wo), M, weight);
+    put(b_, b);
+}
+void prim_beam_transform_region(prim_beam* b_, const float wp[3], float dist, const float wo[3], float weight) {
+    beam_t b = get<beam_t>(b_);
+    beam_transform_region_interaction(b, v3(wp), dist, v3(wo), weight);
+    put(b_, b);
+}
+void prim_surface_info(const prim_surface* s_, float wp[3], float ng[3], float ns[3], uint32_t* tuid, uint32_t* shape) {
+    const surface_t s = get<surface_t>(s_);
+    o3(wp, s.wp);
+    o3(ng, s.geo.n);
+    o3(ns, s.shading.n);
+    *tuid = s.tuid;
+    *shape = s.shape;
+}
+void prim_surface_to_local(const prim_surface* s_, const float v[3], float out[3]) { o3(out, to_local(get<surface_t>(s_).shading, v3(v))); }
+void prim_dummy_surface(const float n[3], const float p[3], prim_surface* out) { put(out, make_dummy_surface(v3(n), v3(p))); }
+void prim_material_f(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport, float M[16]) {
+    const mueller_t m = material_f(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport);
+    std::memcpy(M, m.m, sizeof(m.m));
+}
+float prim_material_pdf(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport) {
+    return material_pdf(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport);
+}
+int prim_material_is_delta_only(const void* sc, int mat) { return material_is_delta_only(S(sc), mat) ? 1 : 0; }
+float prim_fsd_pdf(int slot, const float wo_world[3]) {
+    const fsd_aperture_t ap = tls.hdr[(size_t)slot];
+    return fsd_pdf(ap, fsd_edges_ref_t{tls.edges.data() + ap.edge_offset, 1}, to_local(ap.frame, v3(wo_world)));
+}
+int prim_emitter_flags(const void* sc, int ei) {
+    const emitter_t& e = S(sc).emitters[ei];
+    return (emitter_is_area(e) ? 1 : 0) | (emitter_is_delta_direction(e) ? 2 : 0) | (emitter_is_delta_position(e) ? 4 : 0) | (emitter_is_infinite(e) ? 8 : 0);
+}
+float prim_emitter_select_pmf(const void* sc, int ei) { return S(sc).emitters[ei].select_pmf; }
+float prim_emitter_pdf_position(const void* sc, int ei) { return emitter_pdf_position(S(sc), ei); }
+float prim_emitter_pdf_direction(const void* sc, int ei, const float d[3], const prim_surface* s) {
+    surface_t srf;
+    if (s) srf = get<surface_t>(s);
+    return emitter_pdf_direction(S(sc), ei, v3(d), s ? &srf : nullptr);
+}
+float prim_directional_pdf_target_position(const void* sc, int ei, const float wp[3]) { return directional_pdf_target_position(S(sc).emitters[ei], v3(wp)); }
+void prim_emitter_Li(const void* sc, int ei, const prim_beam* b, const prim_surface* s, float L[4]) {
+    const stokes_t r = emitter_Li(S(sc), ei, get<beam_t>(b), get<surface_t>(s));
+    std::memcpy(L, r.s, sizeof(r.s));
+}
+float prim_sensor_pdf_position(const void* sc) { return sensor_pdf_position(S(sc)); }
+float prim_sensor_pdf_direction(const void* sc, const float d[3]) { return sensor_pdf_direction(S(sc), v3(d)); }
+void prim_sample_emitter_direct(const void* sc, const float wp[3], float k, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_edirect* out) {
+    sampler_t smp = make_sampler(seed, sid, stream, *draws);
+    const emitter_direct_sample_t ed = scene_sample_emitter_direct(S(sc), v3(wp), k, smp);
+    *draws = smp.draws;
+    put(&out->beam, ed.beam);
+    out->dpd = ed.dpd;
+    out->emitter = ed.emitter;
+    out->has_surface = ed.has_surface;
+    put(&out->surface, ed.surface);
+}
+void prim_sensor_sample_direct(const void* sc, const float wp[3], float k, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_sdirect* out) {
+    sampler_t smp = make_sampler(seed, sid, stream, *draws);
+    const sensor_direct_sample_t sd = sensor_sample_direct(S(sc), v3(wp), k, smp);
+    *draws = smp.draws;
+    put(&out->beam, sd.beam);
+    out->dpd = sd.dpd;
+    put(&out->element, sd.element);
+    out->has_surface = sd.has_surface;
+    put(&out->surface, sd.surface);
+}
+void prim_vplane_Si(const void* sc, const prim_beam* b, float dist, prim_si* out) {
+    const sensor_direct_connection_t dc = vplane_Si(S(sc), get<beam_t>(b), range_t{0.f, dist});
+    out->valid = dc.valid ? 1 : 0;
+    if (dc.valid) {
+        put(&out->beam, dc.beam);
+        put(&out->element, dc.element);
+        put(&out->surface, dc.surface);
+    }
+}
+void prim_offset_origin(const void* sc, const prim_surface* s, const float ro[3], const float rd[3], float out[3]) {
+    o3(out, s ? surface_offseted_ray_origin(S(sc), get<surface_t>(s), v3(ro), v3(rd)) : v3(ro));
+}
+int prim_shadow_ray(const void* sc, const float o[3], const float d[3], float dist) { return ads_shadow_ray(S(sc), v3(o), v3(d), range_t{0.f, dist}, stack()) ? 1 : 0; }
+void prim_film_splat(const void* sc_, double* value, double* weight, double* light, const prim_element* el, const float L[4], float k, int direct) {
+    const scene_t& sc = S(sc_);
+    const film_t film{value, weight, light, sc.sensor.width, sc.sensor.height, sc.sensor.channels};
+    stokes_t s;
+    std::memcpy(s.s, L, sizeof(s.s));
+    if (direct)
+        film_splat_direct(sc, film, get<sensor_element_t>(el), s, k);
+    else
+        film_splat(sc, film, get<sensor_element_t>(el), s, k);
+}
+
+}   // extern "C"

@@ -1,0 +1,75 @@
+"""The independent composition checker (oracle/indep/: vertices, area-measure densities, Russian roulette, the (s,t) strategies, MIS and
+beam integration restated a second time from the reference, in double precision, sharing no header with wave_tracer_amd/csrc/wt/) against
+liboracle.so (the shared-header composition the GPU tests are checked against).  Both consume the same Philox streams in the reference's
+order, so they must agree SAMPLE FOR SAMPLE: event counters exactly, films to float rounding.  A bug in either composition — a wrong
+density conversion, a missing cosine, a MIS special case — shows up here; a bug in a primitive does not (those are pinned by the KATs)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_util import ROOT, oracle_render
+
+_lib = None
+
+
+def indep():
+    global _lib
+    if _lib is None:
+        p = os.path.join(ROOT, "oracle", "_build", "libindep.so")
+        if not os.path.exists(p):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        _lib = C.CDLL(p)
+        _lib.indep_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def indep_render(sc, b, e, seed):
+    H, W, Cn = sc.height, sc.width, sc.channels
+    v, w, l = np.zeros((H, W, Cn)), np.zeros((H, W)), np.zeros((H, W, Cn))
+    ctr = np.zeros(8, np.uint64)
+    assert indep().indep_render(sc.host_desc(), b, e, seed, v.ctypes.data, w.ctypes.data, l.ctypes.data, ctr.ctypes.data) == 0
+    return v, w, l, dict(zip(["segments", "vertices", "connections", "surface", "fsd_interactions", "null_interactions", "light_splats", "shadow_rays"],
+                             [int(x) for x in ctr]))
+
+
+CASES = [
+    # scene, res, spp, kwargs — every strategy class: s=0 (emitter hit), t=0 (virtual sensor), s=1 / t=1 (direct sampling), interior
+    ("furnace", 16, 4, {}),
+    ("white_furnace", 12, 6, {}),
+    ("furnace", 16, 4, {"fsd": 1, "lut": (64, 64)}),
+    ("furnace_spm", 16, 4, {}),
+    ("furnace", 12, 4, {"mis": 0}),                      # the non-MIS weight 1 / ((s+t+1) k_density), plt_bdpt.cpp:126
+    ("furnace", 12, 4, {"rr": 0}),
+    ("double_slits", 48, 4, {"lut": (64, 64)}),          # virtual_plane sensor: t = 0 strategy, Fraunhofer vertices, spot emitter
+    ("sunlit", 16, 4, {}),                               # directional (infinite) emitter
+    ("cornell_box", 16, 2, {"mesh_detail": 0, "lut": (64, 64), "crop_of": 1440}),
+    ("lens_b", 16, 4, {}),                               # dielectric (delta) vertices
+    ("bidir_room", 20, 2, {"mesh_detail": 0, "lut": (64, 64), "polarimetric": 1}),   # Stokes film: polarised beam integration
+]
+
+
+@pytest.mark.parametrize("name,res,spp,kw", CASES)
+def test_independent_composition_matches_the_checker(built, name, res, spp, kw):
+    from wave_tracer_amd import Scene
+    sc = Scene(name, res=res, **kw)
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 77, threads=1)
+    iv, iw, il, ic = indep_render(sc, 0, spp, 77)
+    for k in ("segments", "vertices", "connections", "fsd_interactions", "null_interactions", "light_splats", "shadow_rays"):
+        assert ic[k] == oc[k], (k, ic[k], oc[k])
+    assert np.allclose(iw, ow, rtol=1e-6, atol=1e-12)
+    # Pixel by pixel: float rounding, EXCEPT single samples through a Fraunhofer vertex whose aperture holds an edge that is exactly
+    # axis-aligned in the beam frame: alpha_1 / alpha_2 are defined as 0 at zeta.x == 0 (fsd.hpp:66-75) although their limit there is
+    # not, so psi_0^2 (the 8-point average of free_space_diffraction.cpp:106-118) jumps by 30x with the last bit of the beam frame —
+    # an instability of the formula (found with this test: the two compositions differ in FMA contraction only), also behind the
+    # rare discrete GPU-vs-CPU divergences.  Such samples change only MIS weights: <= 3 % of the pixels, image < 2 %.
+    tot_a = iv.sum(axis=2) + il.sum(axis=2)
+    tot_b = ov.sum(axis=2) + ol.sum(axis=2)
+    assert tot_b.sum() > 0
+    same = np.abs(tot_a - tot_b) <= 1e-4 * np.abs(tot_b) + 1e-12 * tot_b.max()
+    print(f"{name}: {same.mean():.4f} of the pixels agree to 1e-4, image rel. L1 {np.abs(tot_a - tot_b).sum() / tot_b.sum():.2e}")
+    fsd_scene = oc["fsd_interactions"] > 0
+    assert same.mean() >= (0.97 if fsd_scene else 1.0), same.mean()
+    assert np.abs(tot_a - tot_b).sum() <= (2e-2 if fsd_scene else 1e-5) * tot_b.sum()

@@ -360,7 +360,7 @@ static void build_lens_test(const scene_params_t& p, scene_builder_t& b, int whi
         b.add_shape(mesh_lens({0, 0, 0}, 2 * mm, .5, 0, 1 * mm, 24), xform_t::identity(), glass);
     else
         b.add_shape(mesh_lens({0, 0, 0}, 2 * mm, .4, .3, .9 * mm, 16), xform_t::identity(), glass);
-    const int wall = b.add_shape(mesh_rectangle({.02, -.02, -.02}, {0, .04, 0}, {0, 0, .04}), xform_t::identity(), grey, true);
+    const int wall = b.add_shape(mesh_rectangle({.02, -.02, -.02}, {0, 0, .04}, {0, .04, 0}), xform_t::identity(), grey, true);
     b.add_emitter_area(wall, b.spectrum_blackbody(6000.f, 1.f), 1e-6f, 1.f);
 }
 
