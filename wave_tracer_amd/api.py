@@ -12,7 +12,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def lib_path():
-    return os.path.join(_HERE, "libwtgpu.so")
+    # WTGPU_LIB: an alternative build of the library (A/B experiments with compile-time knobs)
+    return os.environ.get("WTGPU_LIB") or os.path.join(_HERE, "libwtgpu.so")
 
 
 class WtgpuError(RuntimeError):

@@ -42,6 +42,28 @@ using namespace wt;
 
 namespace {
 
+// Register budgets (second __launch_bounds__ argument = minimum waves per SIMD => 512 / n unified VGPRs per lane).
+#ifndef WTGPU_LB_TRACE
+#define WTGPU_LB_TRACE 3
+#endif
+#ifndef WTGPU_LB_HEAVY
+#define WTGPU_LB_HEAVY 3
+#endif
+#ifndef WTGPU_LB_INTERACT
+#define WTGPU_LB_INTERACT 4
+#endif
+#ifndef WTGPU_LB_INTERACT_B
+#define WTGPU_LB_INTERACT_B 3
+#endif
+#ifndef WTGPU_LB_INTERACT_C
+#define WTGPU_LB_INTERACT_C 3
+#endif
+#ifndef WTGPU_LB_FLUX
+#define WTGPU_LB_FLUX 3
+#endif
+#ifndef WTGPU_LB_CONNECT
+#define WTGPU_LB_CONNECT 3
+#endif
 constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
 constexpr int kBlock = 128;
 #ifndef WTGPU_LDS_STACK
@@ -256,7 +278,7 @@ __device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, 
     if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
 }
 
-__global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_COUNT0 + in];
@@ -323,7 +345,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_trace(launch_args_t a, int in, in
 }
 
 // Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
-__global__ void __launch_bounds__(64, 3) k_trace_heavy(launch_args_t a) {
+__global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_t a) {
     __shared__ coop_shared_t sh;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
@@ -510,8 +532,8 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
     }
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_interact(launch_args_t a, int in, int first_round) { interact_body<0>(a, in, first_round); }
-__global__ void __launch_bounds__(kBlock, 3) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT) k_interact(launch_args_t a, int in, int first_round) { interact_body<0>(a, in, first_round); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
 // Intercepted power of interaction regions that overflowed the bounded list (find_closest_triangle's sum over ALL region triangles,
 // plt_bdpt_detail.hpp:391-416) for the pass-C walks.  Such regions hold 10^3..10^5 triangles (a wide emitter beam over a finely
 // tessellated mesh), 5000 on average in the headline workload: one wavefront per region would leave the round waiting for the
@@ -547,7 +569,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
         }
     }
 }
-__global__ void __launch_bounds__(64, 3) k_flux_tasks(launch_args_t a) {
+__global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t a) {
     __shared__ coop_shared_t sh;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
@@ -590,7 +612,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_tasks(launch_args_t a) {
 // plt_bdpt_detail.hpp:391-416 — coop_gather walks the WHOLE region, however many triangles it holds: the reference's unbounded list)
 // and the rejection sampling (64 tries per step; tries own their random draws, the lowest accepted try wins like in the sequential
 // loop); lane 0 then re-enters bdpt_walk_step with the outcome (vertex append, beam transform, Russian roulette).
-__global__ void __launch_bounds__(64, 3) k_interact_c(launch_args_t a, int in) {
+__global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_args_t a, int in) {
     __shared__ uint32_t s_item;
     __shared__ stack_entry_t lds[8];   // the resumed step does no BVH queries; lane 0's stack is a formality
     uint32_t* ctl = a.st.ctl;
@@ -838,7 +860,7 @@ __global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
         a.st.ctl[CTL_STRAT_HEAD] = 0;
     }
 }
-__global__ void __launch_bounds__(kBlock, 3) k_connect_strat(launch_args_t a) {
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(launch_args_t a) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     __shared__ uint32_t s_prefix[kNumKeys + 1];
     for (uint32_t k = threadIdx.x; k <= kNumKeys; k += blockDim.x) s_prefix[k] = a.st.strat_prefix[k];
