@@ -20,14 +20,21 @@ def _scene(name="cornell_box", **kw):
     return sc
 
 
-def _cmp_rays(g, o):
+def _cmp_rays(g, o, ids=True):
+    """ids=False (committed fixtures): triangle ids are positions in the BVH's leaf order, and the builder's split decisions hinge on
+    last-ulp results of libm (sin/cos of the procedural meshes), which differ between host CPUs — the fixture's ids are only valid on
+    the machine that made it.  Hit/miss, distance and facing are compared with the fixture; ids with the checker run on this host."""
     gd, gt, gb, gf = g
     od, ot, ob, of = o
     hit = np.isfinite(od)
     assert (np.isfinite(gd) == hit).all()
-    same = gt == ot
     if not hit.any():
         return
+    if not ids:
+        assert np.allclose(gd[hit], od[hit], rtol=1e-5, atol=1e-7)
+        assert (gf[hit] == of[hit]).mean() > 0.998
+        return
+    same = gt == ot
     # a ray through a shared edge/vertex may legitimately report the neighbour: allow < 0.2 % of such ties, at equal distance
     assert same[hit].mean() > 0.998
     assert np.allclose(gd[hit], od[hit], rtol=1e-5, atol=1e-7)
@@ -40,7 +47,7 @@ def test_ray_queries_golden_and_oracle(built):
     sc = _scene(res=16, mesh_detail=0, lut=(32, 32))
     g = np.load(os.path.join(HERE, "golden", "cornell_traversal.npz"))
     res = sc.trace_rays(g["rays"])
-    _cmp_rays(res, (g["dist"], g["tuid"], g["bary"], g["front"]))
+    _cmp_rays(res, (g["dist"], g["tuid"], g["bary"], g["front"]), ids=False)
     _cmp_rays(res, oracle_trace(sc, g["rays"]))
 
 
@@ -66,13 +73,16 @@ def test_ray_queries_edge_cases(built):
     assert one[1][0] == res[1][50] and one[0][0] == res[0][50]
 
 
-def _cmp_cones(g, o):
+def _cmp_cones(g, o, ids=True):
     gd, gf, gn, gt = g
     od, of, on, ot = o
     same = (gf == of)
     assert same.mean() > 0.995                      # ballistic/diffusive decision and facing
     m = same & ((of & 1) == 0)
     assert np.allclose(gd[m], od[m], rtol=2e-5, atol=1e-7)
+    if not ids:   # committed fixture: list sizes only (see _cmp_rays)
+        assert (gn[m] == on[m]).mean() > 0.99
+        return
     agree = (gn[m] == on[m]) & (gt[m] == ot[m]).all(axis=1)
     # triangles grazing the cone boundary can flip with 1-ulp differences of the edge test: >= 99 % identical lists
     assert agree.mean() > 0.99, agree.mean()
@@ -82,7 +92,7 @@ def test_cone_traversal_golden_and_oracle(built):
     sc = _scene(res=16, mesh_detail=0, lut=(32, 32))
     g = np.load(os.path.join(HERE, "golden", "cornell_traversal.npz"))
     res = sc.traverse_cones(g["cones"])
-    _cmp_cones(res, (g["cdist"], g["cflags"], g["cntris"], g["ctris"]))
+    _cmp_cones(res, (g["cdist"], g["cflags"], g["cntris"], g["ctris"]), ids=False)
     _cmp_cones(res, oracle_cones(sc, g["cones"]))
     assert ((g["cflags"] & 2) != 0).sum() > 20 and ((g["cflags"] & 3) == 0).sum() > 20     # both regimes exercised
 

@@ -485,17 +485,8 @@ WT_HD float region_triangle_flux(const scene_t& sc, const frame_t& beam_frame, c
     const tri_geo_t g = sc.tri_geo[tuid];
     const bool front_face = dot(g.n, -envelope.d) > 0.f;
     if (front_face != want_front) return 0.f;
-    const float csz = centre(izr);
-    const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
-                                          to_local(beam_frame, g.c - envelope.o), izr);
-    float flux = 0.f;
-    for (int t = 0; t < ct.tris; ++t) {
-        vec3 a, b, c;
-        clip_tri_get(ct, t, a, b, c);
-        const vec2 pa = cone_project_local(envelope, a, csz), pb = cone_project_local(envelope, b, csz), pc = cone_project_local(envelope, c, csz);
-        flux += wavefront_integrate_triangle(sigma, pa, pb, pc);
-    }
-    return flux;
+    return region_local_triangle_flux(envelope, izr, centre(izr), sigma, to_local(beam_frame, g.a - envelope.o), to_local(beam_frame, g.b - envelope.o),
+                                      to_local(beam_frame, g.c - envelope.o));
 }
 
 // One random-walk step after the beam has been traced (plt_bdpt_detail.hpp:421-526 minus the traverse() call).

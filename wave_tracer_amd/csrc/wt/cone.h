@@ -7,6 +7,7 @@
 //            include/wt/math/intersect/cone_intersection_tolerance.hpp:23-41
 #pragma once
 #include "core.h"
+#include "gauss.h"
 
 namespace wt {
 
@@ -604,6 +605,26 @@ WT_HD clip_tri_t clip_triangle_z(vec3 a, vec3 b, vec3 c, const range_t& zr) {
     }
     ret.tris = idx < 3 ? 0 : (idx == 3 ? 1 : (idx == 4 ? 2 : 3));
     return ret;
+}
+
+// find_closest_triangle's footprint integral of ONE triangle given in the beam's local frame (plt_bdpt_detail.hpp:391-416): the part
+// of the triangle inside the interaction region's z-slab, projected along the envelope onto the cross-section at the slab's centre.
+// A triangle that lies wholly inside the slab — nearly all of a large region's — is what clip_triangle_z returns for it (one
+// triangle, the same vertices): integrated directly, without the clipper's 5-vertex array (scratch traffic on the device).
+WT_HD float region_local_triangle_flux(const cone_t& envelope, const range_t& izr, float csz, vec2 sigma, vec3 la, vec3 lb, vec3 lc) {
+    const bool inside = la.z >= izr.min && la.z <= izr.max && lb.z >= izr.min && lb.z <= izr.max && lc.z >= izr.min && lc.z <= izr.max;
+    if (inside)
+        return wavefront_integrate_triangle(sigma, cone_project_local(envelope, la, csz), cone_project_local(envelope, lb, csz),
+                                            cone_project_local(envelope, lc, csz));
+    const clip_tri_t ct = clip_triangle_z(la, lb, lc, izr);
+    float flux = 0.f;
+    for (int t = 0; t < ct.tris; ++t) {
+        vec3 a, b, c;
+        clip_tri_get(ct, t, a, b, c);
+        flux += wavefront_integrate_triangle(sigma, cone_project_local(envelope, a, csz), cone_project_local(envelope, b, csz),
+                                             cone_project_local(envelope, c, csz));
+    }
+    return flux;
 }
 
 // cone_intersection_tolerance.hpp:23-41

@@ -34,6 +34,10 @@ struct coop_shared_t {
     uint32_t tri_buf[kCoopTriBuf];
     uint32_t surv[kCoopSurvCap];
     float hit_dist[64];   // cone-hit distance of every listed triangle (list capacity kMaxConeTris = 64)
+};
+// LDS of the edge-collecting gather only (k_edges): kept out of coop_shared_t so that the traversal kernels, whose wavefronts wait on
+// memory most of the time, fit twice as many wavefronts per CU (LDS is what bounds their occupancy).
+struct coop_edges_t {
     uint32_t edge_ids[96];   // coop_gather: sorted classified-edge set of an interaction region (scenes with more than kCoopEdgeBits edges)
     uint32_t edge_bits[1024];   // coop_gather: the same set as a bitmap over the scene's edge ids (unbounded, sorted and de-duplicated for free)
 };
@@ -331,18 +335,18 @@ struct gather_out_t {
 };
 __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
                                            const range_t& izr, vec2 sigma, bool want_front, coop_shared_t& sh, bool do_flux, bool do_edges,
-                                           unsigned long long* stats = nullptr, int32_t root = 1) {
-    uint32_t* edges = sh.edge_ids;
+                                           unsigned long long* stats = nullptr, int32_t root = 1, coop_edges_t* eg = nullptr) {
+    uint32_t* edges = eg ? eg->edge_ids : nullptr;   // eg: required when do_edges
     const uint32_t edge_cap = 96;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
     gather_out_t out{0.0, 0u, 0u, 0u};
     const bool edges_only = do_edges && !do_flux;
     // edge set as an LDS bitmap whenever the scene's edge ids fit (n_edges <= 32768): no capacity limit, ids come out sorted; the
-    // caller reads sh.edge_bits (coop_edge_count / coop_edge_write).  Larger scenes: the sorted 96-entry list (overflow counted).
+    // caller reads eg->edge_bits (coop_edge_count / coop_edge_write).  Larger scenes: the sorted 96-entry list (overflow counted).
     const bool bitmap = do_edges && sc.n_edges <= kCoopEdgeBits;
     if (bitmap) {
-        for (uint32_t j = threadIdx.x & 63; j < (sc.n_edges + 31u) / 32u; j += 64) sh.edge_bits[j] = 0u;
+        for (uint32_t j = threadIdx.x & 63; j < (sc.n_edges + 31u) / 32u; j += 64) eg->edge_bits[j] = 0u;
         __syncthreads();
     }
     if (sc.n_nodes == 0) return out;
@@ -378,14 +382,8 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                         eid[2] = m.edge[2];
                     }
                     if (do_flux && (dot(tri.n, -rd) > 0.f) == want_front) {   // find_closest_triangle's footprint integral (bdpt.h)
-                        const clip_tri_t ct = clip_triangle_z(to_local(beam_frame, tri.a - envelope.o), to_local(beam_frame, tri.b - envelope.o),
-                                                              to_local(beam_frame, tri.c - envelope.o), izr);
-                        for (int t = 0; t < ct.tris; ++t) {
-                            vec3 a, b, c;
-                            clip_tri_get(ct, t, a, b, c);
-                            contrib += wavefront_integrate_triangle(sigma, cone_project_local(envelope, a, csz), cone_project_local(envelope, b, csz),
-                                                                    cone_project_local(envelope, c, csz));
-                        }
+                        contrib = region_local_triangle_flux(envelope, izr, csz, sigma, to_local(beam_frame, tri.a - envelope.o),
+                                                             to_local(beam_frame, tri.b - envelope.o), to_local(beam_frame, tri.c - envelope.o));
                     }
                 }
             }
@@ -400,7 +398,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             if (bitmap) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e)
-                    if (eid[e] != kInvalid) atomicOr(&sh.edge_bits[eid[e] >> 5], 1u << (eid[e] & 31u));
+                    if (eid[e] != kInvalid) atomicOr(&eg->edge_bits[eid[e] >> 5], 1u << (eid[e] & 31u));
             }
             unsigned long long em = bitmap ? 0ull : __ballot(eid[0] != kInvalid || eid[1] != kInvalid || eid[2] != kInvalid);
             while (em) {
@@ -527,7 +525,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
 }
 
 // The bitmap edge set left in sh.edge_bits by coop_gather(do_edges): number of ids / the first `cap` ids in ascending order -> dst.
-__device__ inline uint32_t coop_edge_count(const scene_t& sc, coop_shared_t& sh) {
+__device__ inline uint32_t coop_edge_count(const scene_t& sc, coop_edges_t& sh) {
     __syncthreads();
     uint32_t c = 0;
     for (uint32_t j = threadIdx.x & 63; j < (sc.n_edges + 31u) / 32u; j += 64) c += (uint32_t)__popc(sh.edge_bits[j]);
@@ -535,7 +533,7 @@ __device__ inline uint32_t coop_edge_count(const scene_t& sc, coop_shared_t& sh)
     for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
     return c;
 }
-__device__ inline void coop_edge_write(const scene_t& sc, coop_shared_t& sh, uint32_t* dst, uint32_t cap) {
+__device__ inline void coop_edge_write(const scene_t& sc, coop_edges_t& sh, uint32_t* dst, uint32_t cap) {
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
     const uint32_t nw = (sc.n_edges + 31u) / 32u;

@@ -294,11 +294,29 @@ struct fsd_try_t {
 WT_HD uint32_t fsd_max_tries(const fsd_aperture_t& ap) { return ap.n_edges * 1024u; }
 WT_HD uint32_t fsd_tries_base(const sampler_t& s) { return (s.draws + 3u) & ~3u; }
 // one try; `s` positioned at the try's first draw
+// fsd_sampling_density and fsd_ASF of the same point in ONE pass over the segments (same per-segment arithmetic; a try of the
+// rejection loop needs both, and the per-segment amplitudes alpha1 / alpha2 are what they cost)
+WT_HD void fsd_density_and_ASF(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec2 xi, float& g, float& f) {
+    cplx amp{0.f, 0.f};
+    float d = 0.f;
+    for (uint32_t i = 0; i < ap.n_edges; ++i) {
+        const fsd_edge_t e = ed.get(i);
+        const vec2 z = fsd_zeta(e, xi);
+        const float a1 = e.ab * fsd_alpha1(z.x, z.y);
+        const float a2 = e.iab * fsd_alpha2(z.x, z.y);
+        const float ee2 = length2(e.e);
+        amp = amp + cpolar(ee2, -dot(e.v, xi)) * cplx{a1, a2};
+        d += sqr(ee2) * (a1 * a1 + a2 * a2);
+    }
+    const float ce = fsd_chi_e(xi), c0 = fsd_chi_0(xi);
+    g = d * ce + ap.P0 * kInvTwoPi / sqr(kFsdP0Sigma) * c0;
+    f = cnorm(amp) * ce + ap.psi02 * c0;
+}
 WT_HD fsd_try_t fsd_try(const scene_t& sc, const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, sampler_t s) {
     fsd_try_t r;
     r.x = fsd_sampleN(sc, ap, ed, s);
-    const float g = fsd_sampling_density(ap, ed, r.x);
-    r.f = fsd_ASF(ap, ed, r.x);
+    float g;
+    fsd_density_and_ASF(ap, ed, r.x, g, r.f);
     r.accept = ap.n_edges > 1 ? (sampler_r(s) * g < r.f * (1.f / float(ap.n_edges)) ? 1u : 0u) : 1u;
     return r;
 }

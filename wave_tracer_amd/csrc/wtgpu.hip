@@ -35,6 +35,7 @@
 #include "host/scene_builder.h"
 #include "wt/bdpt.h"
 #include "wt/coop.h"
+#include "wt/coop_fsd.h"
 #include "wt/g8.h"
 #include "wt/path.h"
 
@@ -89,6 +90,10 @@ enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_I
                   CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_WORDS = 24 };   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
+// ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
+// C — or without (pass B commits the restart)
+constexpr uint32_t kApertureMarker = 0xFFFFFFFDu, kNullApertureMarker = 0xFFFFFFFCu;
+__host__ __device__ inline bool is_region_marker(uint32_t t) { return t == kGatherMarker || t == kApertureMarker; }
 constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
 
 struct device_state_t {
@@ -126,6 +131,7 @@ constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
 constexpr size_t kTravWords = sizeof(trav_result_t) / 4;
 #define WT_TRAV_WORD(field) (offsetof(trav_result_t, field) / 4)
 constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long long);
+constexpr size_t kProfSlots = 96;   // WTGPU_PROFILE scratch counters behind the public ones
 
 }   // namespace
 
@@ -160,7 +166,7 @@ struct wtgpu_scene {
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0;
-        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2;
+        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8;
         int dbg_stage = 1 << 30;
     } knobs;
 };
@@ -197,6 +203,7 @@ struct launch_args_t {
     uint64_t sample_begin;
     uint32_t count_stats;
     uint32_t cone_budget;
+    uint32_t coop_aperture_min;   // regions with at least this many classified edges get their aperture built by k_edges' wavefront
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
     uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
 };
@@ -449,6 +456,11 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
             soa_load(a.st.trav, W2, w, tr);
             const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
             const vertex_store_t vs{a.st.verts, W2, w};
+            const bool queued_for_c = PASS_B && tr.tuid == kApertureMarker;   // k_edges built the aperture and queued the walk for pass C
+            if (PASS_B && tr.tuid == kNullApertureMarker) {   // k_edges built the aperture: no segments (the step restarts the beam)
+                defer.have_aperture = 1;
+                defer.slot = __float_as_uint(tr.by);
+            }
             if (PASS_B && tr.tuid == kGatherMarker) {   // k_edges left the region's sorted classified-edge ids in the walk's list slot
                 defer.has_gather = 1;
                 defer.gather_n_edges = tr.n_ray_queries;
@@ -456,12 +468,18 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
                 const uint32_t off = __float_as_uint(tr.bx);   // offset into the round's edge pool (0xFFFFFFFF: the list slot)
                 defer.gather_edges = off != 0xFFFFFFFFu ? a.st.epool + off : a.st.tris + (size_t)w * kTriListWords;
             }
-            cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
+            const long long pb0 = PASS_B && a.profile == 3 ? clock64() : 0;
+            if (!queued_for_c) cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
             if (PASS_B && defer.to_sampling_pass) a.st.trav[WT_TRAV_WORD(by) * W2 + w] = defer.slot;
+            if (PASS_B && a.profile == 3) {   // pass-B cost by the number of gathered scene edges
+                const int bin = defer.has_gather ? 32 - __clz((int)defer.gather_n_edges) : 0;   // 0: no gather / none
+                atomicAdd(a.st.counters + kNumCounters + 56 + bin, 1ull);
+                atomicAdd(a.st.counters + kNumCounters + 72 + bin, (unsigned long long)(clock64() - pb0));
+            }
             // a region that did not fit the bounded list: its edge set comes from a walk of the whole region (k_edges)
             // (... or whose list holds more than kMaxEdgeIds / 3 triangles: the per-lane edge set of pass B is bounded)
             if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list)) need_gather = true;
-            if (!defer.no_primary && !defer.to_sampling_pass) {
+            if (!defer.no_primary && !defer.to_sampling_pass && !queued_for_c) {
                 wk.active = cont ? 1u : 0u;
                 soa_store(a.st.walks, W2, w, wk);
             }
@@ -481,10 +499,12 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
 // Sorted ids -> the walk's list slot, marker + count -> its traversal record.
 __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
     __shared__ coop_shared_t sh;
+    __shared__ coop_edges_t eg;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_GATHER_COUNT];
     const size_t W2 = 2 * (size_t)a.st.cap;
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
         __syncthreads();
@@ -498,13 +518,13 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
         const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
         const range_t izr{beam_dist, beam_dist + region_depth};
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
-        const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true);
+        const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
         __syncthreads();
         // sorted ids -> the round's edge pool (unbounded lists: bitmap mode) or the walk's 128-word list slot (scenes with > 32768 edges)
         const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
         uint32_t n_edges = g.n_edges, dropped = g.edge_overflow, off = 0xFFFFFFFFu;
         if (bitmap) {
-            n_edges = coop_edge_count(a.sc, sh);
+            n_edges = coop_edge_count(a.sc, eg);
             if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
             __syncthreads();
             off = s_item;
@@ -513,13 +533,40 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
                 dropped = n_edges;
                 n_edges = 0;
             } else
-                coop_edge_write(a.sc, sh, a.st.epool + off, n_edges);
+                coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
         } else {
             uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
-            for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = sh.edge_ids[j];
+            for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = eg.edge_ids[j];
+        }
+        // Regions with many edges: the aperture is built right here, by the whole wavefront (wt/coop_fsd.h), instead of by one lane of
+        // pass B; walks whose aperture has segments go straight to the pass-C queue.
+        uint32_t marker = kGatherMarker, slot = 0;
+        if (n_edges >= a.coop_aperture_min) {
+            const uint32_t* eids = off != 0xFFFFFFFFu ? a.st.epool + off : a.st.tris + (size_t)w * kTriListWords;
+            __syncthreads();   // the ids were written by other lanes
+            if (threadIdx.x == 0) s_item = fsd_pool_alloc(pool);
+            __syncthreads();
+            slot = s_item;
+            __syncthreads();
+            if (slot < pool.cap) {
+                fsd_aperture_t ap;
+                const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
+                const bool ok = coop_build_aperture(a.sc, cone_frame(wk.beam.env), wk.beam.k, wk.beam.env, eids, n_edges, vec2{sd3.x, sd3.y}, pool, slot, ap);
+                marker = ap.n_edges > 0 ? kApertureMarker : kNullApertureMarker;
+                if (threadIdx.x == 0) {
+                    pool.hdr[slot] = ap;
+                    if (marker == kApertureMarker) a.st.intc_queue[atomicAdd(ctl + CTL_INTC_COUNT, 1u)] = w;
+                    if (a.count_stats) {
+                        if (dropped) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, edge_overflow) / sizeof(unsigned long long), (unsigned long long)dropped);
+                        if (ap.overflow) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_edge_overflow) / sizeof(unsigned long long), (unsigned long long)ap.overflow);
+                        if (!ok) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_pool_overflow) / sizeof(unsigned long long), 1ull);
+                    }
+                }
+            }
         }
         if (threadIdx.x == 0) {
-            a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = kGatherMarker;
+            a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = marker;
+            a.st.trav[WT_TRAV_WORD(by) * W2 + w] = slot;
             a.st.trav[WT_TRAV_WORD(bx) * W2 + w] = off;
             a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = n_edges;
             a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = dropped;
@@ -553,7 +600,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
         __syncthreads();
         if (item >= n) break;
         const uint32_t w = a.st.intc_queue[item];
-        if (a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] == kGatherMarker) {   // block-uniform
+        if (is_region_marker(a.st.trav[WT_TRAV_WORD(tuid) * W2 + w])) {   // block-uniform
             const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
             const cone_t tcone = walk_trace_envelope(a.sc, wk);
             const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
@@ -641,12 +688,13 @@ __global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_a
         const uint32_t slot = a.st.trav[WT_TRAV_WORD(by) * W2 + w];   // left by pass B
         fsd_aperture_t ap = pool.hdr[slot];
         const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
+        const long long pc0 = a.profile == 3 ? clock64() : 0;
         // ---- intercepted power of the whole region (same z-slab, cone and facing as the reference's list-based sum)
         const range_t izr{tr.dist, tr.dist + tr.region_depth};
         const vec3 sd3 = beam_footprint(wk.beam, tr.dist) / kBeamEnvelope;
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
         double flux;
-        if (tr.tuid == kGatherMarker) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
+        if (is_region_marker(tr.tuid)) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
             flux = a.st.facc[w];
         } else {   // lane = triangle of the (complete) list, wave reduction (bdpt_walk_step computes the same sum triangle by triangle)
             const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
@@ -677,6 +725,12 @@ __global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_a
                 t_acc = t0 + (uint32_t)wl;
                 acc = true;
             }
+        }
+        if (a.profile == 3 && lane == 0) {   // WTGPU_PROFILE=3: pass-C cost by aperture size (bin = floor(log2(segments)))
+            const int bin = 31 - __clz((int)max(ap.n_edges, 1u));
+            atomicAdd(a.st.counters + kNumCounters + 8 + bin, 1ull);
+            atomicAdd(a.st.counters + kNumCounters + 24 + bin, (unsigned long long)(acc ? t_acc + 1u : max_tries));
+            atomicAdd(a.st.counters + kNumCounters + 40 + bin, (unsigned long long)(clock64() - pc0));
         }
         // ---- commit: lane 0 resumes the step with the outcome
         bool cont = false;
@@ -1002,6 +1056,7 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
 __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* cones, uint32_t n, uint32_t edge_cap, float* dist, uint32_t* flags,
                                                       uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux) {
     __shared__ coop_shared_t sh;
+    __shared__ coop_edges_t eg;
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
     const float* c = cones + 10 * (size_t)i;
@@ -1017,13 +1072,13 @@ __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* c
         const range_t izr{tr.dist, tr.dist + tr.region_depth};
         prim = tr.tuid;   // primary_from_axis (kInvalid: the axis misses the region)
         const vec2 ax = cone_axes(env, tr.dist);
-        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, sh, false, true);
+        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
         __syncthreads();
         if (sc.n_edges <= kCoopEdgeBits) {
-            ge.n_edges = coop_edge_count(sc, sh);
-            coop_edge_write(sc, sh, edges + (size_t)i * edge_cap, edge_cap);
+            ge.n_edges = coop_edge_count(sc, eg);
+            coop_edge_write(sc, eg, edges + (size_t)i * edge_cap, edge_cap);
         } else
-            for (uint32_t j = threadIdx.x; j < ge.n_edges && j < edge_cap; j += 64) edges[(size_t)i * edge_cap + j] = sh.edge_ids[j];
+            for (uint32_t j = threadIdx.x; j < ge.n_edges && j < edge_cap; j += 64) edges[(size_t)i * edge_cap + j] = eg.edge_ids[j];
         __syncthreads();
         gf = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope}, tr.front_face != 0, sh, true, false);
     }
@@ -1172,6 +1227,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.grid_div_b = std::max(1u, u("WTGPU_GRID_B", 4));
     k.grid_div_c = std::max(1u, u("WTGPU_GRID_C", 2));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
+    k.coop_aperture_min = u("WTGPU_COOP_APERTURE_MIN", 8);   // 0xFFFFFFFF: every aperture by a single lane of pass B
     if (const char* e = getenv("WTGPU_DEBUG_STAGE")) k.dbg_stage = atoi(e);   // bring-up aid: stops launching the round kernels after stage n (invalid results)
     if (const char* e = getenv("WTGPU_TIMING")) s->timing = atoi(e) != 0;
     // The renderer pipelines batches over several HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware
@@ -1230,8 +1286,8 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
     n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, total_cap / 64));
     unsigned long long* counters = nullptr;
-    if ((rc = dmalloc(s, &counters, kNumCounters + 8))) return rc;
-    HIP_CHECK(hipMemset(counters, 0, (kNumCounters + 8) * sizeof(unsigned long long)));
+    if ((rc = dmalloc(s, &counters, kNumCounters + kProfSlots))) return rc;
+    HIP_CHECK(hipMemset(counters, 0, (kNumCounters + kProfSlots) * sizeof(unsigned long long)));
     s->slices.resize(n_slices);
     s->streams.resize(n_slices);
     s->ev_done.resize(n_slices);
@@ -1361,6 +1417,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     a.count_stats = K.count_stats;
     a.cone_budget = K.cone_budget;
     a.profile = K.profile;
+    a.coop_aperture_min = K.coop_aperture_min;
     // Bounded triangle lists (64) are the fast path of an interaction region; a region that overflows its list is handled exactly by
     // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_flux_*).
     // WTGPU_NO_LISTS=1 (plt_bdpt, diagnostic): no lists at all, every region is gathered.
@@ -1508,6 +1565,16 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
         fprintf(stderr, "[wtgpu profile] flux tasks: %llu, candidates %llu (max %llu per task), exact-tested %llu; k_edges: %llu walks, %llu edges\n", p[0], p[1], p[4], p[2], p[5], p[6]);
     }
+    if (s->knobs.profile == 3) {
+        unsigned long long p[kProfSlots];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[wtgpu profile] pass C by aperture size (slice 0): bin=log2(segments) items tries/item kticks/item total-Mticks\n");
+        for (int b = 0; b < 16; ++b)
+            if (p[8 + b]) fprintf(stderr, "[wtgpu profile]   C %2d %8llu %10.1f %10.1f %10.1f\n", b, p[8 + b], double(p[24 + b]) / p[8 + b], double(p[40 + b]) / p[8 + b] * 1e-3, double(p[40 + b]) * 1e-6);
+        fprintf(stderr, "[wtgpu profile] pass B by gathered scene edges: bin items kticks/item total-Mticks\n");
+        for (int b = 0; b < 16; ++b)
+            if (p[56 + b]) fprintf(stderr, "[wtgpu profile]   B %2d %8llu %10.1f %10.1f\n", b, p[56 + b], double(p[72 + b]) / p[56 + b] * 1e-3, double(p[72 + b]) * 1e-6);
+    }
     if (s->knobs.profile == 2) {
         unsigned long long p[8];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
@@ -1523,7 +1590,7 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
         if (rc) return rc;
     }
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemset(s->slices[0].counters, 0, (kNumCounters + 8) * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(s->slices[0].counters, 0, (kNumCounters + kProfSlots) * sizeof(unsigned long long)));
     s->samples_rendered = 0;
     s->cap_hits = 0;
     for (double& v : s->acc) v = 0;
