@@ -167,19 +167,20 @@ def main():
         b_film = 2 * (9 * C * 16) + n_light * 2 * (9 * C * 8)
         bytes_per_sample = n_seg * 2 * S_path + n_vtx * S_vtx + n_conn * 2 * S_vtx + n_q * S_hit + b_film
         kernels = {"k_trace": tsum["trace_ms"], "k_trace_heavy": tsum["trace_heavy_ms"], "k_interact": tsum["interact_ms"],
-                   "k_interact_b": tsum["interact_b_ms"], "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
+                   "k_edges+k_interact_b": tsum["interact_b_ms"], "k_flux_split+k_flux_tasks": tsum["flux_ms"], "k_interact_c": tsum["interact_c_ms"],
+                   "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
         dom = max(kernels, key=kernels.get)
         # bytes attributed to the dominant kernel per step (one step = npix samples); the two trace kernels split the segments
         # (every segment is traced by exactly one of them), the two interaction passes split the vertices the same way: each is
         # credited with the WHOLE term (an upper bound of its algorithmic bytes, hence of `achieved`)
         share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
-                 "k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
+                 "k_edges+k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_flux_split+k_flux_tasks": n_seg * S_path + n_vtx * S_vtx,
+                 "k_interact_c": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
         # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once): `launches`
         # is the count rocprofv3 --kernel-trace --stats averages over (profiles/r02_kernel_stats_*.csv), `launches_with_work` the rounds
         # that had walks queued.  achieved = algorithmic bytes / the kernel's HIP-event time: the same for either count.
         rounds = 96 * tsum["batches"]
-        launches = {"k_trace": rounds, "k_trace_heavy": rounds, "k_interact": rounds, "k_interact_b": rounds, "k_connect": tsum["batches"],
-                    "k_generate": tsum["batches"]}[dom]
+        launches = {"k_connect": tsum["batches"], "k_generate": tsum["batches"]}.get(dom, rounds)
         with_work = tsum["trace_launches"] if launches == rounds else launches
         avg_ms = kernels[dom] / max(1, launches)
         steps_rank = K * s_rank                                   # passes over the film this rank rendered

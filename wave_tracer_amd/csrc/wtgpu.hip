@@ -131,7 +131,7 @@ constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
 constexpr size_t kTravWords = sizeof(trav_result_t) / 4;
 #define WT_TRAV_WORD(field) (offsetof(trav_result_t, field) / 4)
 constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long long);
-constexpr size_t kProfSlots = 96;   // WTGPU_PROFILE scratch counters behind the public ones
+constexpr size_t kProfSlots = 128;   // WTGPU_PROFILE scratch counters behind the public ones
 
 }   // namespace
 
@@ -670,6 +670,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_a
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
+        const long long pl0 = a.profile == 3 ? clock64() : 0;
         if (lane == 0) s_item = atomicAdd(ctl + CTL_INTC_HEAD, 1u);
         __syncthreads();
         const uint32_t item = s_item;
@@ -731,7 +732,9 @@ __global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_a
             atomicAdd(a.st.counters + kNumCounters + 8 + bin, 1ull);
             atomicAdd(a.st.counters + kNumCounters + 24 + bin, (unsigned long long)(acc ? t_acc + 1u : max_tries));
             atomicAdd(a.st.counters + kNumCounters + 40 + bin, (unsigned long long)(clock64() - pc0));
+            atomicAdd(a.st.counters + kNumCounters + 112 + bin, (unsigned long long)(pc0 - pl0));
         }
+        const long long pm0 = a.profile == 3 ? clock64() : 0;
         // ---- commit: lane 0 resumes the step with the outcome
         bool cont = false;
         if (lane == 0) {
@@ -757,6 +760,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_a
             cont = bdpt_walk_step<2>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
             wk.active = cont ? 1u : 0u;
             soa_store(a.st.walks, W2, w, wk);
+            if (a.profile == 3) atomicAdd(a.st.counters + kNumCounters + 96 + (31 - __clz((int)max(ap.n_edges, 1u))), (unsigned long long)(clock64() - pm0));
         }
         wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
     }
@@ -1335,7 +1339,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     // in-flight batch records: events for per-kernel timings + pinned snapshot of the control block
     s->recs.resize(4 * (size_t)n_slices);
     for (auto& r : s->recs) {
-        r.ev.resize(s->timing ? 3 + 4 * (size_t)kMaxWalkIters : 1);
+        r.ev.resize(s->timing ? 3 + 6 * (size_t)kMaxWalkIters : 1);
         for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipHostMalloc((void**)&r.h_ctl, CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     }
@@ -1357,15 +1361,12 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
         hipEventElapsedTime(&ms, r.ev[0], r.ev[1]);
         s->acc[0] += ms;
         size_t e = 1;
-        for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 4) {
-            hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
-            s->acc[1] += ms;
-            hipEventElapsedTime(&ms, r.ev[e + 1], r.ev[e + 2]);
-            s->acc[7] += ms;
-            hipEventElapsedTime(&ms, r.ev[e + 2], r.ev[e + 3]);
-            s->acc[2] += ms;
-            hipEventElapsedTime(&ms, r.ev[e + 3], r.ev[e + 4]);
-            s->acc[8] += ms;
+        for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 6) {
+            static const int slot[6] = {1, 7, 2, 8, 9, 10};   // trace, heavy trace, pass A, edges + pass B, region flux, pass C
+            for (int q = 0; q < 6; ++q) {
+                hipEventElapsedTime(&ms, r.ev[e + q], r.ev[e + q + 1]);
+                s->acc[slot[q]] += ms;
+            }
         }
         hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
         s->acc[3] += ms;
@@ -1480,14 +1481,18 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
                 if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
                 rec();
                 rec();
+                rec();
+                rec();
                 continue;
             }
             hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
             hipLaunchKernelGGL(k_edges, dim3(gh), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
+            rec();
             hipLaunchKernelGGL(k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
+            rec();
             hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
             rec();
         }
@@ -1570,7 +1575,7 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
         fprintf(stderr, "[wtgpu profile] pass C by aperture size (slice 0): bin=log2(segments) items tries/item kticks/item total-Mticks\n");
         for (int b = 0; b < 16; ++b)
-            if (p[8 + b]) fprintf(stderr, "[wtgpu profile]   C %2d %8llu %10.1f %10.1f %10.1f\n", b, p[8 + b], double(p[24 + b]) / p[8 + b], double(p[40 + b]) / p[8 + b] * 1e-3, double(p[40 + b]) * 1e-6);
+            if (p[8 + b]) fprintf(stderr, "[wtgpu profile]   C %2d %8llu %10.1f %10.1f %10.1f   fetch+load %.1f commit %.1f kticks/item\n", b, p[8 + b], double(p[24 + b]) / p[8 + b], double(p[40 + b]) / p[8 + b] * 1e-3, double(p[40 + b]) * 1e-6, double(p[112 + b]) / p[8 + b] * 1e-3, double(p[96 + b]) / p[8 + b] * 1e-3);
         fprintf(stderr, "[wtgpu profile] pass B by gathered scene edges: bin items kticks/item total-Mticks\n");
         for (int b = 0; b < 16; ++b)
             if (p[56 + b]) fprintf(stderr, "[wtgpu profile]   B %2d %8llu %10.1f %10.1f\n", b, p[56 + b], double(p[72 + b]) / p[56 + b] * 1e-3, double(p[72 + b]) * 1e-6);
