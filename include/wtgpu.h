@@ -80,6 +80,14 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
  * port of the reference's own loader calls. */
 int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_scene** out);
 
+/* Minimal reader of the reference's XML scene format: enough of the vocabulary for
+ * scenes/diffraction_simple/{double_slits,double_slits_and_reflectors}.xml + bits/geometry.xml as shipped — <default> defines and
+ * "$name" substitution, expressions with units, <include>, enabled=..., integrator / sensor + film / spot and directional emitters /
+ * twosided, surface_spm, diffuse and composite BSDFs / rectangle shapes.  `defines`: n_defines strings "name=value", the -D defines of the
+ * reference's command line (src/main.cpp:805-928).  params (may be NULL): res (becomes the define "res" unless given), max_depth / fsd /
+ * mis / rr / force_ray_tracing overrides, lut_* resolution, polarimetric.  Anything outside that vocabulary fails with a message. */
+int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, uint32_t n_defines, const wtgpu_scene_params* params, wtgpu_scene** out);
+
 int wtgpu_scene_get_info(const wtgpu_scene* scene, wtgpu_scene_info* info);
 
 /* The flattened description of a handle (for CPU-side checkers and tools). */

@@ -231,6 +231,84 @@ def test_full_size_properties_1440(built):
         assert abs(a - b) < 0.25 * b, (key, a, b)
 
 
+def test_xml_scene_renders_like_the_checker(built):
+    """A scene loaded by the minimal XML reader (tests/data/xml/single_slit.xml: spot + slit in a conducting screen + wall sensor) goes
+    through the same C-ABI: GPU == CPU checker on the same random numbers."""
+    import os
+    from wave_tracer_amd import Scene, render, develop
+    sc = Scene.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "xml", "single_slit.xml"), res=128, lut=(128, 128))
+    spp = 8
+    v, w, l = render(sc, spp, seed=21)
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 21)
+    gi, oi = develop(sc, v, w, l, spp).astype(np.float64), develop(sc, ov, ow, ol, spp).astype(np.float64)
+    assert oc["fsd_interactions"] > 100 and oi.sum() > 0
+    assert np.abs(gi - oi).sum() < 2e-2 * np.abs(oi).sum()
+    c = sc.counters()
+    assert abs(c["fsd_interactions"] - oc["fsd_interactions"]) <= 0.02 * oc["fsd_interactions"]
+
+
+def test_double_slits_full_size_1440(built):
+    """BASELINE.json configs[0] at its real size (scenes/diffraction_simple/double_slits.xml with res = 1440: virtual-plane film
+    1440 x 360, 518,400 samples per pass).  The scene is small enough for the CPU checker to render the whole film, so this is a
+    FULL parity test at full size, plus the size-independent properties:
+      (1) finite, non-negative; two 1-spp passes sum to the 2-spp pass (film linearity);
+      (2) GPU == CPU checker on the same random numbers: weights to fp32 rounding, developed image rel-L1 < 2e-2, event counters
+          within 0.5 %;
+      (3) physics at 32 spp: the column profile outside the geometric shadow boundary follows cos^2(pi d x / lambda L) sinc^2(a x /
+          lambda L) (correlation > 0.985), bright orders at +-4.6 / 14.7 / 24.8 mm, left-right symmetric within 5 %."""
+    import torch
+    from wave_tracer_amd import Scene, develop
+    from wave_tracer_amd.render import alloc_films
+    res = 1440
+    sc = Scene("double_slits", res=res)
+    assert (sc.width, sc.height) == (1440, 360)
+    sc.upload(0)
+    dev = torch.device("cuda", 0)
+    films = [alloc_films(sc, dev) for _ in range(4)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    sc.reset_counters()
+    sc.render_into(*films[0], 0, 1, 9, st)
+    sc.render_into(*films[1], 1, 2, 9, st)
+    torch.cuda.synchronize(dev)
+    c = sc.counters()
+    sc.render_into(*films[2], 0, 2, 9, st)
+    sc.render_into(*films[3], 0, 32, 10, st)
+    torch.cuda.synchronize(dev)
+    for v, w, l in films:
+        assert torch.isfinite(v).all() and torch.isfinite(w).all() and torch.isfinite(l).all()
+        assert (v >= 0).all() and (w >= 0).all() and (l >= 0).all()
+    for k in range(3):
+        assert torch.allclose(films[0][k] + films[1][k], films[2][k], rtol=1e-7, atol=1e-30)
+    assert c["samples"] == 2 * sc.width * sc.height and c["walk_iteration_cap_hits"] == 0
+    assert c["edge_overflow"] == 0 and c["fsd_edge_overflow"] == 0 and c["fsd_pool_overflow"] == 0
+    # (2) full-film parity
+    ov, ow, ol, oc = oracle_render(sc, 0, 2, 9)
+    g = [t.cpu().numpy() for t in films[2]]
+    assert np.allclose(g[1], ow, rtol=1e-5, atol=1e-7)
+    gi, oi = develop(sc, *g, 2).astype(np.float64), develop(sc, ov, ow, ol, 2).astype(np.float64)
+    rel = np.abs(gi - oi).sum() / np.abs(oi).sum()
+    print("double slits 1440x360: rel L1", rel, {k: (c[k], oc[k]) for k in ("segments", "vertices", "fsd_interactions", "light_splats")})
+    assert rel < 2e-2, rel
+    for k in ("segments", "vertices", "connections", "fsd_interactions", "light_splats"):
+        assert abs(c[k] - oc[k]) <= 5e-3 * max(oc[k], 200), (k, c[k], oc[k])
+    # (3) fringes
+    img = develop(sc, *[t.cpu().numpy() for t in films[3]], 32).astype(np.float64)
+    prof = img.sum(axis=(0, 2))
+    x = (np.arange(res) + .5 - res / 2) * 250.0 / res                   # mm on the wall
+    lamL, d, a = 3.25, .65, .35
+    ana = np.cos(np.pi * d * x / lamL) ** 2 * np.sinc(a * x / lamL) ** 2
+    m = (np.abs(x) > 2.8) & (np.abs(x) < 32)
+    # (columns are 0.17 mm wide here: smooth the Monte-Carlo noise of single columns over 1 mm before comparing shapes)
+    ker = np.ones(6) / 6
+    ps, as_ = np.convolve(prof, ker, "same"), np.convolve(ana, ker, "same")
+    assert np.corrcoef(ps[m] / ps[m].max(), as_[m] / as_[m].max())[0, 1] > 0.985
+    assert abs(prof[x > 0].sum() / prof[x < 0].sum() - 1) < 0.05
+    for lo, hi, centre in [(2.8, 8, 4.6), (12, 18, 14.7), (22, 28, 24.8)]:
+        for sgn in (1, -1):
+            w_ = (sgn * x > lo) & (sgn * x < hi)
+            assert abs(abs(x[w_][np.argmax(ps[w_])]) - centre) < 0.8
+
+
 def test_rmse_far_below_monte_carlo_noise_floor(built):
     """BASELINE.json's second metric is the image RMSE against the CPU reference.  With identical random numbers the GPU image
     differs from the CPU checker's by far less than two CPU renders with different seeds differ from each other (the Monte-Carlo

@@ -54,7 +54,7 @@ SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_sc
            "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
            "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
            "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join", "wtgpu_query_regions", "wtgpu_render_progressive",
-           "wtgpu_cancel", "wtgpu_comm_unique_id", "wtgpu_comm_create", "wtgpu_film_reduce", "wtgpu_comm_destroy"]
+           "wtgpu_cancel", "wtgpu_comm_unique_id", "wtgpu_comm_create", "wtgpu_film_reduce", "wtgpu_comm_destroy", "wtgpu_scene_create_from_xml"]
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p)
 
 _lib = None
@@ -84,6 +84,8 @@ def load_library():
     lib.wtgpu_scene_create_named.argtypes = [C.c_char_p, C.POINTER(SceneParams), C.POINTER(vp)]
     lib.wtgpu_scene_create_named_hooks.argtypes = [C.c_char_p, C.POINTER(SceneParams), C.POINTER(TestHooks), C.POINTER(vp)]
     lib.wtgpu_scene_create_from_desc.argtypes = [vp, C.POINTER(vp)]
+    lib.wtgpu_scene_create_from_xml.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(SceneParams), C.POINTER(vp)]
+    lib.wtgpu_scene_compare.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     lib.wtgpu_render_progressive.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64, u32, PROGRESS_CB, vp, C.POINTER(u64)]
     lib.wtgpu_cancel.argtypes = [vp]
     lib.wtgpu_comm_unique_id.argtypes = [vp]
@@ -161,6 +163,35 @@ class Scene:
         self.width, self.height, self.channels = info.width, info.height, info.channels * info.stokes
         self.device = None
         return self
+
+    @classmethod
+    def from_xml(cls, path, defines=None, res=0, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, lut=(0, 0), polarimetric=0):
+        """Loads a scene file of the reference's XML format with the minimal reader (wtgpu_scene_create_from_xml).  `defines`: dict of
+        the reference's -D command-line defines."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, 1, lut[0], lut[1], polarimetric)
+        d = [f"{k}={v}".encode() for k, v in (defines or {}).items()]
+        arr = (C.c_char_p * max(1, len(d)))(*d)
+        h = C.c_void_p()
+        _check(lib.wtgpu_scene_create_from_xml(str(path).encode(), arr, len(d), C.byref(p), C.byref(h)))
+        self._h = h
+        self.name = os.path.basename(str(path))
+        info = SceneInfo()
+        _check(lib.wtgpu_scene_get_info(h, C.byref(info)))
+        self.info = info
+        self.spectral_channels, self.stokes = info.channels, info.stokes
+        self.width, self.height, self.channels = info.width, info.height, info.channels * info.stokes
+        self.device = None
+        return self
+
+    def first_difference(self, other):
+        """Test hook (wtgpu_scene_compare): '' when the two flattened scenes are identical byte for byte, else the first differing array."""
+        buf = C.create_string_buffer(256)
+        rc = load_library().wtgpu_scene_compare(self._h, other._h, buf, 256)
+        if rc not in (0, 1):
+            _check(rc)
+        return buf.value.decode()
 
     @property
     def handle(self):

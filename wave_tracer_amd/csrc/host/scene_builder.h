@@ -165,5 +165,11 @@ struct scene_params_t {
 // names: "double_slits", "cornell_box", "furnace" (diffuse box test scene), "white_furnace", "etoile" (plt_path forward + UTD),
 // "furnace_path" (plt_path backward in the furnace scene)
 bool build_named_scene(const std::string& name, const scene_params_t& p, scene_builder_t& b);
+// material constructors / parameter overrides shared by the bundled scenes and the XML reader (host/scenes.cpp)
+wt::material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided);
+wt::material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, bool two_sided, float scale);
+void apply_opts(const scene_params_t& p, wt::integrator_opts_t& o);
+// minimal reader of the reference's XML scene format (host/xml_scene.cpp): `defines` = "name=value" (-D of the reference's CLI)
+void build_scene_from_xml(const std::string& path, const std::vector<std::string>& defines, const scene_params_t& p, scene_builder_t& b);
 
 }   // namespace wth

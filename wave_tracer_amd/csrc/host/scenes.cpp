@@ -20,7 +20,7 @@ using namespace wt;
 static const double cm = 1e-2, mm = 1e-3;
 static inline double deg(double d) { return d * M_PI / 180.0; }
 
-static material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided) {
+material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided) {
     material_t m{};
     m.type = MAT_DIFFUSE;
     m.two_sided = two_sided;
@@ -43,7 +43,7 @@ static material_t mat_dielectric(int ior_spec) {
     m.gamma = 3.f;
     return m;
 }
-static material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, bool two_sided, float scale) {
+material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, bool two_sided, float scale) {
     material_t m{};
     m.type = MAT_SURFACE_SPM;
     m.two_sided = two_sided;
@@ -57,7 +57,7 @@ static material_t mat_spm(int ior_spec, bool fractal, float roughness, float gam
     m.refl_scale = m.trans_scale = 1.f;
     return m;
 }
-static void apply_opts(const scene_params_t& p, integrator_opts_t& o) {
+void apply_opts(const scene_params_t& p, integrator_opts_t& o) {
     if (p.max_depth >= 0) o.max_depth = p.max_depth;
     if (p.fsd >= 0) o.FSD = p.fsd;
     if (p.mis >= 0) o.MIS = p.mis;

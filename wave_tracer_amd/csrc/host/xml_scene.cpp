@@ -1,0 +1,715 @@
+// wave_tracer_amd — a minimal reader of the reference's XML scene format ("next" row): enough of the format to
+// load scenes/diffraction_simple/double_slits.xml, double_slits_and_reflectors.xml and their bits/geometry.xml AS SHIPPED and bake
+// them through scene_builder_t.  Not a general loader.
+//
+// Reference behaviour restated (nothing is copied; the reference parses with pugixml, which is not available here):
+//   * <default name value> defines with command-line overrides ("-Dname=value"), textual "$name" substitution in attribute values
+//     (src/scene/loader/xml/loader.cpp, src/main.cpp:805-928);
+//   * attribute values are arithmetic / boolean expressions, optionally followed by a unit ("($S-.0001) mm", ".001°", "5750K"),
+//     comma-separated for vectors, "a .. b" for ranges, "(re,imi)" for complex constants (include/wt/util/unique_function… the
+//     reference evaluates them with its own expression parser + mp-units' stoq);
+//   * <include path> is relative to the including file and is spliced in place;
+//   * elements with <boolean name="enabled" value=…/> evaluating to false are skipped (sensors, shapes);
+//   * node vocabulary handled: integrator (plt_bdpt | plt_path + direction), sensor (virtual_plane | perspective) with film
+//     (array; response monochromatic/discrete line or RGB), emitter (spot | directional), bsdf (twosided, surface_spm with
+//     fractal/dirac profile, diffuse, composite bins), spectrum (constant, complex constant, discrete line, rgb, blackbody,
+//     composite bins), shape (rectangle) with <ref id>.
+// Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
+// sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
+// monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
+// of a line emitter's power; a far-infrared line against an RGB sensor: zero) is not added.
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+#include "scene_builder.h"
+
+namespace wth {
+using namespace wt;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- tiny XML DOM
+struct xnode_t {
+    std::string name;
+    std::vector<std::pair<std::string, std::string>> attrs;
+    std::vector<xnode_t> kids;
+    const std::string* attr(const char* n) const {
+        for (auto& a : attrs)
+            if (a.first == n) return &a.second;
+        return nullptr;
+    }
+    std::string get(const char* n, const std::string& def = "") const {
+        const std::string* a = attr(n);
+        return a ? *a : def;
+    }
+    // <type name="n" value=…> child
+    const xnode_t* named(const char* n) const {
+        for (auto& k : kids)
+            if (k.get("name") == n) return &k;
+        return nullptr;
+    }
+    const xnode_t* child(const char* element) const {
+        for (auto& k : kids)
+            if (k.name == element) return &k;
+        return nullptr;
+    }
+};
+
+struct xml_parser_t {
+    const std::string& s;
+    size_t i = 0;
+    std::string file;
+    explicit xml_parser_t(const std::string& text, std::string f) : s(text), file(std::move(f)) {}
+    [[noreturn]] void fail(const std::string& what) const {
+        size_t line = 1;
+        for (size_t k = 0; k < i && k < s.size(); ++k) line += s[k] == '\n';
+        throw std::runtime_error(file + ":" + std::to_string(line) + ": " + what);
+    }
+    void skip_ws() {
+        while (i < s.size() && std::isspace((unsigned char)s[i])) ++i;
+    }
+    bool starts(const char* t) const { return s.compare(i, std::strlen(t), t) == 0; }
+    void skip_misc() {   // whitespace, text, comments, processing instructions, doctype
+        for (;;) {
+            while (i < s.size() && s[i] != '<') ++i;
+            if (i >= s.size()) return;
+            if (starts("<!--")) {
+                const size_t e = s.find("-->", i + 4);
+                if (e == std::string::npos) fail("unterminated comment");
+                i = e + 3;
+            } else if (starts("<?")) {
+                const size_t e = s.find("?>", i + 2);
+                if (e == std::string::npos) fail("unterminated processing instruction");
+                i = e + 2;
+            } else if (starts("<!")) {
+                const size_t e = s.find('>', i);
+                if (e == std::string::npos) fail("unterminated declaration");
+                i = e + 1;
+            } else
+                return;
+        }
+    }
+    static std::string unescape(const std::string& v) {
+        std::string o;
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (v[k] == '&') {
+                static const std::pair<const char*, char> ent[] = {{"&amp;", '&'}, {"&lt;", '<'}, {"&gt;", '>'}, {"&quot;", '"'}, {"&apos;", '\''}};
+                bool done = false;
+                for (auto& e : ent)
+                    if (v.compare(k, std::strlen(e.first), e.first) == 0) {
+                        o += e.second;
+                        k += std::strlen(e.first) - 1;
+                        done = true;
+                        break;
+                    }
+                if (done) continue;   // a bare '&' (the shipped scenes write "a && b" unescaped) is kept
+            }
+            o += v[k];
+        }
+        return o;
+    }
+    std::string ident() {
+        const size_t b = i;
+        while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '-' || s[i] == ':' || s[i] == '.')) ++i;
+        if (i == b) fail("name expected");
+        return s.substr(b, i - b);
+    }
+    // parses one element at s[i] == '<'
+    xnode_t element() {
+        xnode_t n;
+        ++i;
+        n.name = ident();
+        for (;;) {
+            skip_ws();
+            if (i >= s.size()) fail("unterminated element <" + n.name + ">");
+            if (starts("/>")) {
+                i += 2;
+                return n;
+            }
+            if (s[i] == '>') {
+                ++i;
+                break;
+            }
+            const std::string an = ident();
+            skip_ws();
+            if (i >= s.size() || s[i] != '=') fail("'=' expected after attribute " + an);
+            ++i;
+            skip_ws();
+            if (i >= s.size() || (s[i] != '"' && s[i] != '\'')) fail("quoted value expected for attribute " + an);
+            const char q = s[i++];
+            const size_t e = s.find(q, i);
+            if (e == std::string::npos) fail("unterminated attribute value");
+            n.attrs.emplace_back(an, unescape(s.substr(i, e - i)));
+            i = e + 1;
+        }
+        for (;;) {
+            skip_misc();
+            if (i >= s.size()) fail("missing </" + n.name + ">");
+            if (starts("</")) {
+                i += 2;
+                const std::string cn = ident();
+                if (cn != n.name) fail("</" + cn + "> closes <" + n.name + ">");
+                skip_ws();
+                if (i >= s.size() || s[i] != '>') fail("'>' expected");
+                ++i;
+                return n;
+            }
+            n.kids.push_back(element());
+        }
+    }
+    // a document or a fragment: every top-level element
+    std::vector<xnode_t> top_level() {
+        std::vector<xnode_t> v;
+        for (;;) {
+            skip_misc();
+            if (i >= s.size()) return v;
+            v.push_back(element());
+        }
+    }
+};
+
+std::string read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+std::string dir_of(const std::string& path) {
+    const size_t p = path.find_last_of('/');
+    return p == std::string::npos ? std::string(".") : path.substr(0, p);
+}
+
+// ---------------------------------------------------------------------------------------------- expressions and quantities
+struct expr_t {
+    const std::string& s;
+    size_t i = 0;
+    explicit expr_t(const std::string& t) : s(t) {}
+    [[noreturn]] void fail(const std::string& w) const { throw std::runtime_error("expression \"" + s + "\": " + w); }
+    void ws() {
+        while (i < s.size() && std::isspace((unsigned char)s[i])) ++i;
+    }
+    bool eat(const char* t) {
+        ws();
+        const size_t n = std::strlen(t);
+        if (s.compare(i, n, t) == 0) {
+            i += n;
+            return true;
+        }
+        return false;
+    }
+    double primary() {
+        ws();
+        if (i >= s.size()) fail("operand expected");
+        if (s[i] == '(') {
+            ++i;
+            const double v = lor();
+            if (!eat(")")) fail("')' expected");
+            return v;
+        }
+        if (std::isalpha((unsigned char)s[i])) {
+            const size_t b = i;
+            while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_')) ++i;
+            const std::string w = s.substr(b, i - b);
+            if (w == "true") return 1.0;
+            if (w == "false") return 0.0;
+            fail("unknown identifier " + w);
+        }
+        const char* b = s.c_str() + i;
+        char* e = nullptr;
+        const double v = std::strtod(b, &e);
+        if (e == b) fail("number expected");
+        i += (size_t)(e - b);
+        return v;
+    }
+    double unary() {
+        ws();
+        if (eat("-")) return -unary();
+        if (eat("+")) return unary();
+        if (i < s.size() && s[i] == '!' && !(i + 1 < s.size() && s[i + 1] == '=')) {
+            ++i;
+            return unary() == 0.0 ? 1.0 : 0.0;
+        }
+        return primary();
+    }
+    double mul() {
+        double v = unary();
+        for (;;) {
+            if (eat("*"))
+                v *= unary();
+            else if (eat("/"))
+                v /= unary();
+            else
+                return v;
+        }
+    }
+    double add() {
+        double v = mul();
+        for (;;) {
+            ws();
+            if (eat("+"))
+                v += mul();
+            else if (i < s.size() && s[i] == '-') {
+                ++i;
+                v -= mul();
+            } else
+                return v;
+        }
+    }
+    double cmp() {
+        const double a = add();
+        if (eat("==")) return a == add() ? 1.0 : 0.0;
+        if (eat("!=")) return a != add() ? 1.0 : 0.0;
+        if (eat("<=")) return a <= add() ? 1.0 : 0.0;
+        if (eat(">=")) return a >= add() ? 1.0 : 0.0;
+        if (eat("<")) return a < add() ? 1.0 : 0.0;
+        if (eat(">")) return a > add() ? 1.0 : 0.0;
+        return a;
+    }
+    double land() {
+        double v = cmp();
+        while (eat("&&")) {
+            const double r = cmp();
+            v = (v != 0.0 && r != 0.0) ? 1.0 : 0.0;
+        }
+        return v;
+    }
+    double lor() {
+        double v = land();
+        while (eat("||")) {
+            const double r = land();
+            v = (v != 0.0 || r != 0.0) ? 1.0 : 0.0;
+        }
+        return v;
+    }
+    // evaluates a prefix of the string; `i` is left behind it
+    double prefix() { return lor(); }
+};
+
+std::string trim(const std::string& s) {
+    size_t b = 0, e = s.size();
+    while (b < e && std::isspace((unsigned char)s[b])) ++b;
+    while (e > b && std::isspace((unsigned char)s[e - 1])) --e;
+    return s.substr(b, e - b);
+}
+double eval_number(const std::string& s) {
+    expr_t e(s);
+    const double v = e.prefix();
+    e.ws();
+    if (e.i != s.size()) e.fail("trailing characters");
+    return v;
+}
+
+enum dim_e { DIM_NONE, DIM_LENGTH, DIM_ANGLE, DIM_TEMPERATURE };
+struct quantity_t {
+    double raw;      // the number as written
+    double factor;   // unit -> SI (metres, radians, kelvin)
+    bool degrees;
+    dim_e dim;
+    // (degrees: v * pi / 180 in this order, lengths: v * 1e-3 etc. — the operation order of host/scenes.cpp, so that a scene read from
+    // its XML is bit-identical to the hand-written builder)
+    double si() const { return degrees ? raw * M_PI / 180.0 : raw * factor; }
+    double in_mm() const { return factor == 1e-3 ? raw : raw * factor * 1e3; }
+};
+quantity_t parse_quantity(const std::string& text) {
+    const std::string s = trim(text);
+    expr_t e(s);
+    const double v = e.prefix();
+    const std::string unit = trim(s.substr(e.i));
+    static const struct {
+        const char* u;
+        double f;
+        dim_e d;
+    } units[] = {{"", 1, DIM_NONE},        {"m", 1, DIM_LENGTH},          {"mm", 1e-3, DIM_LENGTH},       {"cm", 1e-2, DIM_LENGTH},
+                 {"um", 1e-6, DIM_LENGTH}, {"\xC2\xB5m", 1e-6, DIM_LENGTH}, {"nm", 1e-9, DIM_LENGTH},       {"km", 1e3, DIM_LENGTH},
+                 {"rad", 1, DIM_ANGLE},    {"K", 1, DIM_TEMPERATURE}};
+    if (unit == "\xC2\xB0" || unit == "deg") return {v, M_PI / 180.0, true, DIM_ANGLE};
+    for (auto& u : units)
+        if (unit == u.u) return {v, u.f, false, u.d};
+    throw std::runtime_error("quantity \"" + text + "\": unknown unit \"" + unit + "\"");
+}
+quantity_t parse_q(const std::string& text, dim_e want, const char* what) {
+    const quantity_t q = parse_quantity(text);
+    if (q.dim != want) throw std::runtime_error(std::string(what) + " \"" + text + "\": wrong or missing unit");
+    return q;
+}
+double parse_dim(const std::string& text, dim_e want, const char* what) { return parse_q(text, want, what).si(); }
+// splits at top-level commas
+std::vector<std::string> split_list(const std::string& s) {
+    std::vector<std::string> out;
+    int depth = 0;
+    std::string cur;
+    for (char c : s) {
+        if (c == '(') ++depth;
+        if (c == ')') --depth;
+        if (c == ',' && depth == 0) {
+            out.push_back(cur);
+            cur.clear();
+        } else
+            cur += c;
+    }
+    out.push_back(cur);
+    return out;
+}
+dvec3 parse_point(const std::string& s, dim_e dim, const char* what) {
+    const auto p = split_list(s);
+    if (p.size() != 3) throw std::runtime_error(std::string(what) + " \"" + s + "\": three components expected");
+    return {parse_dim(p[0], dim, what), parse_dim(p[1], dim, what), parse_dim(p[2], dim, what)};
+}
+// "a .. b" (lengths) -> metres
+bool parse_length_range(const std::string& s, double& lo, double& hi) {
+    const size_t p = s.find("..");
+    if (p == std::string::npos) return false;
+    lo = parse_dim(s.substr(0, p), DIM_LENGTH, "range");
+    hi = parse_dim(s.substr(p + 2), DIM_LENGTH, "range");
+    return true;
+}
+// "(re,imi)" | "re"
+void parse_complex(const std::string& text, double& re, double& im) {
+    const std::string s = trim(text);
+    re = im = 0;
+    if (s.size() > 2 && s.front() == '(' && s.back() == ')') {
+        const auto p = split_list(s.substr(1, s.size() - 2));
+        if (p.size() == 2) {
+            std::string ims = trim(p[1]);
+            if (!ims.empty() && (ims.back() == 'i' || ims.back() == 'j')) {
+                ims.pop_back();
+                re = eval_number(p[0]);
+                im = eval_number(ims);
+                return;
+            }
+        }
+    }
+    re = eval_number(s);
+}
+
+// ---------------------------------------------------------------------------------------------- the loader
+struct loader_t {
+    std::map<std::string, std::string> defs;
+    scene_builder_t& b;
+    std::vector<xnode_t> items;   // the <scene>'s children with includes spliced in, substituted
+    // sensor sensitivity: a line (mono) or the visible band
+    bool mono = false;
+    double line_m = 0, line_mm = 0;    // monochromatic sensor: wavelength [m], [mm]
+    double band_lo = 0, band_hi = 0;   // RGB sensor: sensitivity band [m]
+    std::map<std::string, int> materials;
+
+    explicit loader_t(scene_builder_t& bb) : b(bb) {}
+
+    std::string subst(const std::string& v) const {
+        std::string o;
+        for (size_t i = 0; i < v.size(); ++i) {
+            if (v[i] == '$') {
+                size_t e = i + 1;
+                while (e < v.size() && (std::isalnum((unsigned char)v[e]) || v[e] == '_')) ++e;
+                const std::string n = v.substr(i + 1, e - i - 1);
+                const auto it = defs.find(n);
+                if (it == defs.end()) throw std::runtime_error("undefined $" + n);
+                o += it->second;
+                i = e - 1;
+            } else
+                o += v[i];
+        }
+        return o;
+    }
+    void subst_tree(xnode_t& n) const {
+        for (auto& a : n.attrs) a.second = subst(a.second);
+        for (auto& k : n.kids) subst_tree(k);
+    }
+    void splice(std::vector<xnode_t>&& nodes, const std::string& dir) {
+        for (auto& n : nodes) {
+            if (n.name == "default") {
+                const std::string name = n.get("name");
+                if (!defs.count(name)) defs[name] = subst(n.get("value"));   // command-line defines win
+            } else if (n.name == "include") {
+                const std::string path = dir + "/" + subst(n.get("path"));
+                const std::string text = read_file(path);
+                xml_parser_t p(text, path);
+                splice(p.top_level(), dir_of(path));
+            } else {
+                subst_tree(n);
+                items.push_back(std::move(n));
+            }
+        }
+    }
+    static bool enabled(const xnode_t& n) {
+        const xnode_t* e = n.named("enabled");
+        return !e || eval_number(e->get("value", "true")) != 0.0;
+    }
+    static xform_t to_world(const xnode_t& n, dvec3 default_up) {
+        const xnode_t* t = n.named("to_world");
+        if (!t) return xform_t::identity();
+        const xnode_t* la = t->child("lookat");
+        if (!la) throw std::runtime_error("<transform name=\"to_world\">: only <lookat> is supported");
+        const dvec3 o = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
+        const dvec3 up = la->attr("up") ? parse_point(la->get("up"), DIM_NONE, "lookat up") : default_up;
+        return xform_t::lookat(o, tg, up);
+    }
+    bool in_sensitivity(double lo, double hi) const {   // does [lo,hi] (metres) contain the sensor's sensitivity range?
+        return mono ? (lo <= line_m && line_m <= hi) : (lo <= band_lo && band_hi <= hi);
+    }
+    // picks the <bin> whose wavelength_range holds the sensor's sensitivity (composite BSDFs and spectra, bsdf/composite.hpp:26-140)
+    const xnode_t* pick_bin(const xnode_t& comp) const {
+        for (auto& k : comp.kids) {
+            if (k.name != "bin") continue;
+            double lo, hi;
+            if (!parse_length_range(k.get("wavelength_range"), lo, hi)) throw std::runtime_error("<bin>: wavelength_range expected");
+            if (in_sensitivity(lo, hi)) return &k;
+        }
+        return nullptr;
+    }
+    // real-valued spectrum node -> builder spectrum id (-2: no overlap with the sensor)
+    int spectrum(const xnode_t& n) {
+        if (n.get("type") == "composite") {
+            const xnode_t* bin = pick_bin(n);
+            if (!bin) return -2;
+            const xnode_t* s = bin->child("spectrum");
+            if (!s) throw std::runtime_error("composite spectrum: <bin> without <spectrum>");
+            return spectrum(*s);
+        }
+        double scale = 1.0;
+        if (const xnode_t* sc = n.named("scale")) scale = eval_number(sc->get("value"));
+        if (n.get("type") == "discrete") {
+            const quantity_t q = parse_q(n.get("wavelength"), DIM_LENGTH, "discrete spectrum wavelength");
+            const double wl = q.si();
+            const double val = n.attr("value") ? eval_number(n.get("value")) : 1.0;
+            if (mono ? std::fabs(wl - line_m) > 1e-9 * line_m : !(band_lo <= wl && wl <= band_hi)) return -2;
+            return b.spectrum_discrete((float)q.in_mm(), (float)(val * scale));
+        }
+        if (n.attr("constant")) {
+            double re, im;
+            parse_complex(n.get("constant"), re, im);
+            return b.spectrum_const((float)(re * scale), (float)(im * scale));
+        }
+        if (n.attr("rgb")) {
+            const auto c = split_list(n.get("rgb"));
+            if (c.size() != 3) throw std::runtime_error("rgb spectrum: three components expected");
+            if (mono) return -2;   // RGB uplift is defined over 380..720 nm
+            return b.spectrum_rgb((float)eval_number(c[0]), (float)eval_number(c[1]), (float)eval_number(c[2]));
+        }
+        if (n.attr("blackbody")) {
+            if (mono) return -2;   // continuous spectrum x line sensor: see the header of this file
+            return b.spectrum_blackbody((float)parse_dim(n.get("blackbody"), DIM_TEMPERATURE, "blackbody"), (float)scale);
+        }
+        throw std::runtime_error("<spectrum>: unsupported kind");
+    }
+    // bsdf node -> material (two_sided accumulated from the wrappers)
+    bool material(const xnode_t& n, bool two_sided, material_t& out) {
+        const std::string type = n.get("type");
+        if (type == "twosided") {
+            const xnode_t* in = n.child("bsdf");
+            if (!in) throw std::runtime_error("twosided bsdf without a nested <bsdf>");
+            return material(*in, true, out);
+        }
+        if (type == "composite") {
+            const xnode_t* bin = pick_bin(n);
+            if (!bin) return false;
+            const xnode_t* in = bin->child("bsdf");
+            if (!in) throw std::runtime_error("composite bsdf: <bin> without <bsdf>");
+            return material(*in, two_sided, out);
+        }
+        if (type == "diffuse") {
+            const xnode_t* r = n.named("reflectance");
+            if (!r) throw std::runtime_error("diffuse bsdf: reflectance expected");
+            const int s = spectrum(*r);
+            if (s == -2) return false;
+            out = mat_diffuse(s, 1.f, two_sided);
+            return true;
+        }
+        if (type == "surface_spm") {
+            const xnode_t* ior = n.named("IOR");
+            if (!ior) throw std::runtime_error("surface_spm bsdf: IOR expected");
+            const int s = spectrum(*ior);
+            bool fractal = false;
+            float roughness = 0.f, gamma = 3.f;
+            if (const xnode_t* sp = n.child("surface_profile")) {
+                if (sp->get("type") != "fractal") throw std::runtime_error("surface_profile: only fractal is supported");
+                fractal = true;
+                const xnode_t* ro = sp->named("roughness");
+                if (!ro || !ro->attr("constant")) throw std::runtime_error("fractal profile: constant roughness expected");
+                roughness = (float)eval_number(ro->get("constant"));
+                if (const xnode_t* g = sp->named("gamma")) gamma = (float)eval_number(g->get("value"));
+            }
+            out = mat_spm(s, fractal, roughness, gamma, two_sided, 1.f);
+            return true;
+        }
+        throw std::runtime_error("bsdf type \"" + type + "\" is not supported by the minimal reader");
+    }
+
+    void load(const std::string& path, const scene_params_t& prm) {
+        const std::string text = read_file(path);
+        xml_parser_t p(text, path);
+        std::vector<xnode_t> top = p.top_level();
+        if (top.size() != 1 || top[0].name != "scene") throw std::runtime_error(path + ": a single <scene> element expected");
+        splice(std::move(top[0].kids), dir_of(path));
+
+        // ---- integrator
+        integrator_opts_t o{};
+        o.max_depth = 1024;
+        o.MIS = o.RR = o.FSD = o.sensor_direct = o.emitter_direct = 1;
+        for (auto& n : items) {
+            if (n.name != "integrator") continue;
+            const std::string type = n.get("type");
+            if (type == "plt_bdpt")
+                o.integrator = INTEGRATOR_BDPT;
+            else if (type == "plt_path") {
+                const xnode_t* d = n.named("direction");
+                if (!d) throw std::runtime_error("(plt_path integrator loader) 'direction' must be specified");
+                const std::string dir = d->get("value");
+                if (dir != "forward" && dir != "backward") throw std::runtime_error("plt_path: direction forward | backward expected");
+                o.integrator = dir == "forward" ? INTEGRATOR_PATH_FORWARD : INTEGRATOR_PATH_BACKWARD;
+            } else
+                throw std::runtime_error("integrator type \"" + type + "\" is not supported");
+            if (const xnode_t* a = n.named("max_depth")) o.max_depth = (int32_t)eval_number(a->get("value"));
+            if (const xnode_t* a = n.named("MIS")) o.MIS = eval_number(a->get("value")) != 0.0;
+            if (const xnode_t* a = n.named("FSD")) o.FSD = eval_number(a->get("value")) != 0.0;
+            if (const xnode_t* a = n.named("russian_roulette")) o.RR = eval_number(a->get("value")) != 0.0;
+            if (const xnode_t* a = n.named("sensor_direct_sampling")) o.sensor_direct = eval_number(a->get("value")) != 0.0;
+            if (const xnode_t* a = n.named("emitter_direct_sampling")) o.emitter_direct = eval_number(a->get("value")) != 0.0;
+        }
+        apply_opts(prm, o);
+        b.set_integrator(o);
+        if (prm.lut_m) b.set_fsd_lut_resolution(prm.lut_n_theta, prm.lut_m);
+
+        // ---- the enabled sensor (exactly one: one wtgpu_scene renders one film)
+        const xnode_t* sensor = nullptr;
+        for (auto& n : items)
+            if (n.name == "sensor" && enabled(n)) {
+                if (sensor) throw std::runtime_error("more than one enabled sensor: select one with -D defines");
+                sensor = &n;
+            }
+        if (!sensor) throw std::runtime_error("no enabled sensor");
+        const xnode_t* film = sensor->child("film");
+        if (!film || film->get("type") != "array") throw std::runtime_error("sensor: <film type=\"array\"> expected");
+        const xnode_t *fw = film->named("width"), *fh = film->named("height");
+        if (!fw || !fh) throw std::runtime_error("film: width and height expected");
+        const uint32_t W = (uint32_t)eval_number(fw->get("value")), H = std::max(1u, (uint32_t)eval_number(fh->get("value")));
+        const xnode_t* resp = film->child("response");
+        if (!resp) throw std::runtime_error("film: <response> expected");
+        if (resp->get("type") == "monochromatic") {
+            const xnode_t* sp = resp->child("spectrum");
+            if (!sp || sp->get("type") != "discrete") throw std::runtime_error("monochromatic response: discrete spectrum expected");
+            mono = true;
+            const quantity_t q = parse_q(sp->get("wavelength"), DIM_LENGTH, "response wavelength");
+            line_m = q.si();
+            line_mm = q.in_mm();
+        } else if (resp->get("type") == "RGB") {
+            band_lo = 380e-9;
+            band_hi = 720e-9;
+        } else
+            throw std::runtime_error("response type \"" + resp->get("type") + "\" is not supported");
+        const std::string stype = sensor->get("type");
+        if (stype == "virtual_plane") {
+            const xnode_t* ext = sensor->named("extent");
+            if (!ext) throw std::runtime_error("virtual_plane sensor: extent expected");
+            const auto e2 = split_list(ext->get("value"));
+            if (e2.size() != 2) throw std::runtime_error("virtual_plane sensor: extent needs two components");
+            float tan_alpha = -1.f;
+            if (const xnode_t* a = sensor->named("alpha")) tan_alpha = (float)std::tan(parse_dim(a->get("value"), DIM_ANGLE, "alpha"));
+            b.set_sensor_virtual_plane(to_world(*sensor, {0, 1, 0}), parse_dim(e2[0], DIM_LENGTH, "extent"), parse_dim(e2[1], DIM_LENGTH, "extent"), W, H, tan_alpha);
+        } else if (stype == "perspective") {
+            const xnode_t* fov = sensor->named("fov");
+            if (!fov) throw std::runtime_error("perspective sensor: fov expected");
+            bool rto = false;
+            if (const xnode_t* r = sensor->named("ray_trace_only")) rto = eval_number(r->get("value")) != 0.0;
+            float pse = 1.f;
+            if (const xnode_t* r = sensor->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
+            b.set_sensor_perspective(to_world(*sensor, {0, 1, 0}), parse_dim(fov->get("value"), DIM_ANGLE, "fov"), W, H, pse, rto);
+        } else
+            throw std::runtime_error("sensor type \"" + stype + "\" is not supported");
+        if (const xnode_t* r = film->named("rfilter_scale")) b.set_film_rfilter_scale((float)eval_number(r->get("value")));
+        if (prm.polarimetric > 0) b.set_sensor_polarimetric(true);
+        if (mono)
+            b.set_response_mono_discrete((float)line_mm);
+        else {
+            std::string wp = "D65";
+            if (const xnode_t* w = resp->named("white_point")) wp = w->get("value");
+            const float D50[3] = {0.96422f, 1.00000f, 0.82521f}, D65[3] = {0.95047f, 1.00000f, 1.08883f};
+            if (wp != "D50" && wp != "D65") throw std::runtime_error("white point \"" + wp + "\" is not supported");
+            b.set_response_rgb(wp == "D50" ? D50 : D65);
+        }
+
+        // ---- emitters, materials, shapes, in file order
+        uint32_t n_emitters = 0;
+        for (auto& n : items) {
+            if (n.name == "emitter") {
+                if (!enabled(n)) continue;
+                const std::string type = n.get("type");
+                if (type == "spot") {
+                    const xnode_t* sp = n.named("radiant_intensity");
+                    if (!sp) throw std::runtime_error("spot emitter: radiant_intensity expected");
+                    const int s = spectrum(*sp);
+                    if (s == -2) continue;
+                    const xnode_t *bw = n.named("beam_width"), *co = n.named("cutoff_angle");
+                    if (!bw || !co) throw std::runtime_error("spot emitter: beam_width and cutoff_angle expected");
+                    float pse = 1.f;
+                    if (const xnode_t* r = n.named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
+                    b.add_emitter_spot(to_world(n, {0, 1, 0}), s, 1.f, (float)parse_dim(co->get("value"), DIM_ANGLE, "cutoff_angle"),
+                                       (float)parse_dim(bw->get("value"), DIM_ANGLE, "beam_width"), -1.f, pse);
+                    ++n_emitters;
+                } else if (type == "directional") {
+                    const xnode_t* sp = n.named("irradiance");
+                    if (!sp) throw std::runtime_error("directional emitter: irradiance expected");
+                    double scale = 1.0;
+                    if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
+                    xnode_t unscaled = *sp;   // the builder takes the scale separately (emitter_t::scale)
+                    unscaled.kids.clear();
+                    const int s = spectrum(unscaled);
+                    if (s == -2) continue;
+                    const xnode_t* t = n.named("to_world");
+                    const xnode_t* la = t ? t->child("lookat") : nullptr;
+                    if (!la) throw std::runtime_error("directional emitter: <lookat> expected");
+                    const dvec3 og = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
+                    // the emitter's local -z is mapped from origin towards target: the direction TO the emitter is origin - target
+                    // (src/emitter/directional.cpp:118-120)
+                    b.add_emitter_directional({og.x - tg.x, og.y - tg.y, og.z - tg.z}, s, (float)scale, 6.794e-5f, 1.f);
+                    ++n_emitters;
+                } else
+                    throw std::runtime_error("emitter type \"" + type + "\" is not supported by the minimal reader");
+            } else if (n.name == "bsdf") {
+                const std::string id = n.get("id");
+                material_t m{};
+                if (id.empty()) throw std::runtime_error("top-level <bsdf> without id");
+                if (material(n, false, m)) materials[id] = b.add_material(m);
+            } else if (n.name == "shape") {
+                if (!enabled(n)) continue;
+                if (n.get("type") != "rectangle") throw std::runtime_error("shape type \"" + n.get("type") + "\" is not supported by the minimal reader");
+                auto pt = [&](const char* name) {
+                    const xnode_t* q = n.named(name);
+                    if (!q) throw std::runtime_error(std::string("rectangle: point ") + name + " expected");
+                    return dvec3{parse_dim(q->get("x"), DIM_LENGTH, "point x"), parse_dim(q->get("y"), DIM_LENGTH, "point y"), parse_dim(q->get("z"), DIM_LENGTH, "point z")};
+                };
+                const xnode_t* ref = n.child("ref");
+                if (!ref) throw std::runtime_error("shape without <ref id=…>");
+                const auto it = materials.find(ref->get("id"));
+                if (it == materials.end()) throw std::runtime_error("shape refers to unknown or spectrally empty material \"" + ref->get("id") + "\"");
+                b.add_shape(mesh_rectangle(pt("p"), pt("x"), pt("y")), xform_t::identity(), it->second);
+            }
+        }
+        if (!n_emitters) throw std::runtime_error("(scene) no emitters overlap the sensor's sensitivity");
+    }
+};
+
+}   // namespace
+
+// `defines`: "name=value" strings (the reference's -D command-line defines).  prm: res (if non-zero) becomes the define "res" unless
+// given explicitly; max_depth / fsd / mis / rr / force_ray_tracing override the integrator element; lut_*: table resolution.
+void build_scene_from_xml(const std::string& path, const std::vector<std::string>& defines, const scene_params_t& prm, scene_builder_t& b) {
+    loader_t L(b);
+    for (auto& d : defines) {
+        const size_t e = d.find('=');
+        if (e == std::string::npos || e == 0) throw std::runtime_error("define \"" + d + "\": name=value expected");
+        L.defs[d.substr(0, e)] = d.substr(e + 1);
+    }
+    if (prm.res && !L.defs.count("res")) L.defs["res"] = std::to_string(prm.res);
+    L.load(path, prm);
+    b.finalize();
+}
+
+}   // namespace wth

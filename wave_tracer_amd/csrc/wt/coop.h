@@ -747,7 +747,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
                                               coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr, bool resume = false,
                                               uint32_t seg0 = 0, float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0, const ray_hit_t* axis = nullptr,
-                                              bool primary_always = false) {
+                                              bool primary_always = false, bool probe_resumed = true) {
 #ifdef WTGPU_COOP_PROF
 #define WT_COOP_PROF(i, t0_)
 #else
@@ -811,7 +811,9 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         // A thin-slab any-hit probe first: for wide beams it is far cheaper than letting the full (near-first, 8-wide) query find
         // a too-near hit, which expands the whole cone's top levels before its first triangle batch (measured: 1.6x slower).
         const long long tp0 = prof ? clock64() : 0;
-        const bool near_hit = coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh, prof);
+        // (probe_resumed = false: not for the query a per-lane attempt handed over — that attempt spent its budget near-first without
+        // meeting a too-near hit, so the full query, which also stops at the first too-near hit, rarely finds one)
+        const bool near_hit = (probe_resumed || !(resume && seg == seg0)) && coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh, prof);
         WT_COOP_PROF(1, tp0)
         if (near_hit) continue;   // too short (see bvh_cone_any_hit)
         const long long tc0 = prof ? clock64() : 0;

@@ -166,7 +166,7 @@ struct wtgpu_scene {
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0;
-        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8;
+        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1;
         int dbg_stage = 1 << 30;
     } knobs;
 };
@@ -203,6 +203,7 @@ struct launch_args_t {
     uint64_t sample_begin;
     uint32_t count_stats;
     uint32_t cone_budget;
+    uint32_t heavy_probe;   // k_trace_heavy: any-hit probe of the near slab before the handed-over cone query too
     uint32_t coop_aperture_min;   // regions with at least this many classified edges get their aperture built by k_edges' wavefront
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
     uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
         axis.dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(pdist) * W2 + w]);
         axis.front_face = a.st.trav[WT_TRAV_WORD(front_face) * W2 + w];
         const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
-                                                &axis, !a.collect_list);
+                                                &axis, !a.collect_list, a.heavy_probe != 0);
         if (a.profile == 2 && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
@@ -1159,6 +1160,112 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
     return wtgpu_scene_create_named_hooks(name, params, nullptr, out);
 }
 
+static void finish_built_scene(wtgpu_scene* s) {
+    s->host = s->builder->scene();
+    s->stats = s->builder->stats();
+    s->lut_power[0] = s->builder->fsd_lut_power(0);
+    s->lut_power[1] = s->builder->fsd_lut_power(1);
+}
+int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, uint32_t n_defines, const wtgpu_scene_params* params, wtgpu_scene** out) {
+    if (!path || !out || (n_defines && !defines)) return fail(WTGPU_ERR_INVALID, "null argument");
+    try {
+        auto s = std::make_unique<wtgpu_scene>();
+        s->builder = std::make_unique<wth::scene_builder_t>();
+        wth::scene_params_t p{};
+        p.max_depth = p.fsd = p.mis = p.rr = -1;
+        if (params) {
+            p.res = params->res;
+            p.max_depth = params->max_depth;
+            p.fsd = params->fsd;
+            p.mis = params->mis;
+            p.rr = params->rr;
+            p.force_ray_tracing = params->force_ray_tracing;
+            p.lut_n_theta = params->lut_n_theta;
+            p.lut_m = params->lut_m;
+            p.polarimetric = params->polarimetric;
+        }
+        std::vector<std::string> defs;
+        for (uint32_t i = 0; i < n_defines; ++i) {
+            if (!defines[i]) return fail(WTGPU_ERR_INVALID, "null define");
+            defs.emplace_back(defines[i]);
+        }
+        wth::build_scene_from_xml(path, defs, p, *s->builder);
+        finish_built_scene(s.get());
+        if ((uint32_t)s->host.opts.max_depth + 2 > kMaxVerts) return fail(WTGPU_ERR_INVALID, "max_depth exceeds the compiled vertex capacity (16)");
+        *out = s.release();
+        return WTGPU_OK;
+    } catch (const std::exception& e) {
+        return fail(WTGPU_ERR_INVALID, e.what());
+    }
+}
+
+// Test hook: field-by-field comparison of two flattened scenes (every array the description names, byte for byte).  0: identical;
+// 1: different — `what` names the first difference.
+int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, size_t n_what) {
+    if (!a || !b) return fail(WTGPU_ERR_INVALID, "null scene");
+    const scene_t &x = a->host, &y = b->host;
+    std::string diff;
+    auto cnt = [&](const char* name, uint64_t u, uint64_t v) {
+        if (diff.empty() && u != v) diff = std::string(name) + ": " + std::to_string(u) + " vs " + std::to_string(v);
+    };
+    auto arr = [&](const char* name, const void* u, const void* v, size_t bytes, size_t elem) {
+        if (!diff.empty() || bytes == 0) return;
+        if (!u || !v) {
+            if (u != v) diff = std::string(name) + ": missing array";
+            return;
+        }
+        if (std::memcmp(u, v, bytes) != 0) {
+            size_t k = 0;
+            while (k < bytes && ((const unsigned char*)u)[k] == ((const unsigned char*)v)[k]) ++k;
+            diff = std::string(name) + ": element " + std::to_string(k / elem) + ", byte " + std::to_string(k % elem);
+        }
+    };
+    cnt("n_tris", x.n_tris, y.n_tris);
+    cnt("n_edges", x.n_edges, y.n_edges);
+    cnt("n_nodes", x.n_nodes, y.n_nodes);
+    cnt("n_leaves", x.n_leaves, y.n_leaves);
+    cnt("n_shapes", x.n_shapes, y.n_shapes);
+    cnt("n_materials", x.n_materials, y.n_materials);
+    cnt("n_spectra", x.n_spectra, y.n_spectra);
+    cnt("n_emitters", x.n_emitters, y.n_emitters);
+    cnt("lut.n_theta", x.lut.n_theta, y.lut.n_theta);
+    cnt("lut.m", x.lut.m, y.lut.m);
+    arr("sensor", &x.sensor, &y.sensor, sizeof(sensor_t), sizeof(sensor_t));
+    arr("opts", &x.opts, &y.opts, sizeof(integrator_opts_t), sizeof(integrator_opts_t));
+    arr("world_min", &x.world_min, &y.world_min, sizeof(vec3), sizeof(vec3));
+    arr("world_max", &x.world_max, &y.world_max, sizeof(vec3), sizeof(vec3));
+    arr("tri_geo", x.tri_geo, y.tri_geo, sizeof(tri_geo_t) * x.n_tris, sizeof(tri_geo_t));
+    arr("tri_meta", x.tri_meta, y.tri_meta, sizeof(tri_meta_t) * x.n_tris, sizeof(tri_meta_t));
+    arr("tri_shade", x.tri_shade, y.tri_shade, sizeof(tri_shade_t) * x.n_tris, sizeof(tri_shade_t));
+    arr("edges", x.edges, y.edges, sizeof(edge_t) * x.n_edges, sizeof(edge_t));
+    arr("nodes", x.nodes, y.nodes, sizeof(bvh8_node_t) * x.n_nodes, sizeof(bvh8_node_t));
+    arr("leaves", x.leaves, y.leaves, sizeof(bvh8_leaf_t) * x.n_leaves, sizeof(bvh8_leaf_t));
+    arr("shapes", x.shapes, y.shapes, sizeof(shape_t) * x.n_shapes, sizeof(shape_t));
+    arr("materials", x.materials, y.materials, sizeof(material_t) * x.n_materials, sizeof(material_t));
+    arr("spectra", x.spectra, y.spectra, sizeof(spectrum_t) * x.n_spectra, sizeof(spectrum_t));
+    arr("emitters", x.emitters, y.emitters, sizeof(emitter_t) * x.n_emitters, sizeof(emitter_t));
+    arr("emitter_cdf", x.emitter_cdf, y.emitter_cdf, sizeof(float) * (x.n_emitters + 1), sizeof(float));
+    if (diff.empty()) {
+        size_t nsd = 0, nkd = 0, nk = 0;
+        for (uint32_t i = 0; i < x.n_spectra; ++i)
+            if (x.spectra[i].type != SPEC_CONST && x.spectra[i].type != SPEC_DISCRETE) nsd = std::max<size_t>(nsd, x.spectra[i].offset + (size_t)x.spectra[i].count * (x.spectra[i].is_complex ? 2 : 1));
+        arr("spectra_data", x.spectra_data, y.spectra_data, sizeof(float) * nsd, sizeof(float));
+        for (uint32_t i = 0; i < x.n_emitters; ++i) nk = std::max<size_t>(nk, (size_t)x.emitters[i].k_dist + 1);
+        arr("kdists", x.kdists, y.kdists, sizeof(kdist_t) * nk, sizeof(kdist_t));
+        for (size_t i = 0; i < nk && diff.empty(); ++i) nkd = std::max<size_t>(nkd, x.kdists[i].offset + 2 * (size_t)x.kdists[i].count);
+        arr("kdist_data", x.kdist_data, y.kdist_data, sizeof(float) * nkd, sizeof(float));
+        arr("lut.icdf_theta1", x.lut.icdf_theta1, y.lut.icdf_theta1, sizeof(float) * x.lut.n_theta, sizeof(float));
+        arr("lut.icdf_theta2", x.lut.icdf_theta2, y.lut.icdf_theta2, sizeof(float) * x.lut.n_theta, sizeof(float));
+        arr("lut.icdf1", x.lut.icdf1, y.lut.icdf1, sizeof(float) * (size_t)x.lut.m * x.lut.m, sizeof(float));
+        arr("lut.icdf2", x.lut.icdf2, y.lut.icdf2, sizeof(float) * (size_t)x.lut.m * x.lut.m, sizeof(float));
+    }
+    if (what && n_what) {
+        std::strncpy(what, diff.c_str(), n_what - 1);
+        what[n_what - 1] = 0;
+    }
+    return diff.empty() ? 0 : 1;
+}
+
 int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* desc, wtgpu_scene** out) {
     if (!desc || !out) return fail(WTGPU_ERR_INVALID, "null argument");
     auto s = std::make_unique<wtgpu_scene>();
@@ -1231,6 +1338,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.grid_div_b = std::max(1u, u("WTGPU_GRID_B", 4));
     k.grid_div_c = std::max(1u, u("WTGPU_GRID_C", 2));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
+    k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
     k.coop_aperture_min = u("WTGPU_COOP_APERTURE_MIN", 8);   // 0xFFFFFFFF: every aperture by a single lane of pass B
     if (const char* e = getenv("WTGPU_DEBUG_STAGE")) k.dbg_stage = atoi(e);   // bring-up aid: stops launching the round kernels after stage n (invalid results)
     if (const char* e = getenv("WTGPU_TIMING")) s->timing = atoi(e) != 0;
@@ -1419,6 +1527,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     a.cone_budget = K.cone_budget;
     a.profile = K.profile;
     a.coop_aperture_min = K.coop_aperture_min;
+    a.heavy_probe = K.heavy_probe;
     // Bounded triangle lists (64) are the fast path of an interaction region; a region that overflows its list is handled exactly by
     // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_flux_*).
     // WTGPU_NO_LISTS=1 (plt_bdpt, diagnostic): no lists at all, every region is gathered.
