@@ -73,7 +73,7 @@ typedef struct wtgpu_spectrum {
 } wtgpu_spectrum;
 
 /* ---- materials ----------------------------------------------------------------------------------- */
-enum { WTGPU_MAT_DIFFUSE = 0, WTGPU_MAT_DIELECTRIC = 1, WTGPU_MAT_SURFACE_SPM = 2 };   /* material_type */
+enum { WTGPU_MAT_DIFFUSE = 0, WTGPU_MAT_DIELECTRIC = 1, WTGPU_MAT_SURFACE_SPM = 2, WTGPU_MAT_COMPOSITE = 3, WTGPU_MAT_MASK = 4 };   /* material_type */
 enum { WTGPU_PROFILE_DIRAC = 0, WTGPU_PROFILE_FRACTAL = 1, WTGPU_PROFILE_GAUSSIAN = 2 };   /* profile_type */
 typedef struct wtgpu_material {
     int32_t type;
@@ -88,6 +88,13 @@ typedef struct wtgpu_material {
     float gamma;            /* fractal: log-log slope */
     float gauss_sigma;      /* gaussian: > 0: explicit rms `sigma` [1/mm]; otherwise parametrised by `roughness` like the fractal profile */
     float refl_scale, trans_scale;
+    /* composite (bsdf/composite.hpp:26-140): spectral bins [kmin, kmax) [1/mm] -> child material; no BSDF outside the bins */
+    uint32_t n_bins;
+    float bin_kmin[4], bin_kmax[4];   /* kMaxCompositeBins (wt/bsdf.h) */
+    int32_t bin_child[4];
+    /* mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha (constant texture: bitmaps are absent) */
+    int32_t nested;
+    float mask_alpha;
 } wtgpu_material;
 
 /* ---- emitters ------------------------------------------------------------------------------------ */

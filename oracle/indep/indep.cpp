@@ -87,7 +87,12 @@ bool connectible(const ctx_t& c, const vertex& v) {
     case V_FSD: return true;
     case V_EMITTER: return !(prim_emitter_flags(c.sc, v.emitter) & 2);
     case V_SENSOR: return !(c.sensor_flags & 2);
-    case V_SURFACE: return !prim_material_is_delta_only(c.sc, v.material);
+    case V_SURFACE: {
+        float o[3], d[3], k, inten;
+        int tr;
+        prim_beam_info(&v.beam, o, d, &k, &tr, &inten);
+        return !prim_material_is_delta_only(c.sc, v.material, k);
+    }
     }
     return false;
 }

@@ -296,7 +296,7 @@ void prim_material_f(const void* sc, int mat, const float wi[3], const float wo[
 float prim_material_pdf(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport) {
     return material_pdf(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport);
 }
-int prim_material_is_delta_only(const void* sc, int mat) { return material_is_delta_only(S(sc), mat) ? 1 : 0; }
+int prim_material_is_delta_only(const void* sc, int mat, float k) { return material_is_delta_only(S(sc), mat, k) ? 1 : 0; }
 float prim_fsd_pdf(int slot, const float wo_world[3]) {
     const fsd_aperture_t ap = tls.hdr[(size_t)slot];
     return fsd_pdf(ap, fsd_edges_ref_t{tls.edges.data() + ap.edge_offset, 1}, to_local(ap.frame, v3(wo_world)));

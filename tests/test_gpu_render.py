@@ -30,6 +30,11 @@ def _rel_l1(a, b):
     ("furnace_spm", 32, 8, {}),
     # double_slits.xml -Doptical_overview=true: ray-trace-only RGB camera, two directional emitters, RGB-uplifted reflectances
     ("double_slits_overview", 32, 8, {"lut": (64, 64)}),
+    # dispatching BSDF wrappers evaluated per sample on the device: composite bins on both sides of the 550 nm boundary, a bin gap
+    # (no BSDF), a stochastic mask with its null lobe (tests/test_wrappers.py has the semantics)
+    ("furnace_wall_composite", 24, 8, {}),
+    ("furnace_wall_composite_gap", 24, 8, {}),
+    ("furnace_wall_mask", 24, 8, {}),
 ])
 def test_image_parity_small(built, name, res, spp, kw):
     """Same Philox streams on both sides => the images agree sample for sample up to fp contraction / libm ulps.

@@ -9,10 +9,13 @@
 //                    oblate dielectric spheroid.  Everything else (walls, prism, ball, pipe, cube source, both
 //                    spots, camera, integrator options, materials, spectra) follows the XML.
 //   "furnace"      : closed diffuse box + small area light, perspective camera inside (test scene).
+#include <array>
 #include <cmath>
+#include <vector>
 #include <stdexcept>
 
 #include "scene_builder.h"
+#include "spectra_data.h"
 
 namespace wth {
 using namespace wt;
@@ -55,6 +58,37 @@ material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, boo
     m.roughness = roughness;
     m.gamma = gamma;
     m.refl_scale = m.trans_scale = 1.f;
+    return m;
+}
+// bsdf/composite.hpp: bins given as WAVELENGTH ranges [nm] like the scene files' wavelength_range; stored as left-inclusive wavenumber
+// ranges [2 pi / l_hi, 2 pi / l_lo) [1/mm]
+material_t mat_composite(const std::vector<std::array<double, 2>>& wavelength_ranges_nm, const std::vector<int>& children, bool two_sided) {
+    if (wavelength_ranges_nm.size() != children.size() || children.size() > 4) throw std::runtime_error("composite: 1..4 bins expected");
+    material_t m{};
+    m.type = MAT_COMPOSITE;
+    m.two_sided = two_sided;
+    m.scale = 1.f;
+    m.refl_spec = m.ior_spec = m.ext_ior_spec = -1;
+    m.refl_scale = m.trans_scale = 1.f;
+    m.nested = -1;
+    m.n_bins = (uint32_t)children.size();
+    for (size_t i = 0; i < children.size(); ++i) {
+        m.bin_kmin[i] = (float)(2 * M_PI / (wavelength_ranges_nm[i][1] * 1e-6));
+        m.bin_kmax[i] = (float)(2 * M_PI / (wavelength_ranges_nm[i][0] * 1e-6));
+        m.bin_child[i] = children[i];
+    }
+    return m;
+}
+// src/bsdf/mask.cpp with a constant mask texture
+material_t mat_mask(int nested, float alpha, bool two_sided) {
+    material_t m{};
+    m.type = MAT_MASK;
+    m.two_sided = two_sided;
+    m.scale = 1.f;
+    m.refl_spec = m.ior_spec = m.ext_ior_spec = -1;
+    m.refl_scale = m.trans_scale = 1.f;
+    m.nested = nested;
+    m.mask_alpha = alpha;
     return m;
 }
 void apply_opts(const scene_params_t& p, integrator_opts_t& o) {
@@ -281,7 +315,36 @@ static void build_room(const scene_params_t& p, scene_builder_t& b) {
 }
 
 // ---- test scene: closed diffuse box with an area light -------------------------------------------------------------
-static void build_furnace(const scene_params_t& p, scene_builder_t& b, bool spm_occluders = false) {
+// wall material variants of the furnace test scene (tests of the dispatching BSDF wrappers, tests/test_wrappers.py)
+enum furnace_wall_e { WALL_GREY = 0, WALL_COMPOSITE_SAME, WALL_COMPOSITE, WALL_STEP, WALL_COMPOSITE_GAP, WALL_STEP_GAP, WALL_MASK_ONE, WALL_MASK, WALL_MASK_EQUIV };
+static int furnace_wall_material(scene_builder_t& b, int wall) {
+    auto step_table = [&](float lo_value, float hi_value) {   // lo_value below 550 nm, hi_value above
+        std::vector<float> v(SPD_N);
+        for (int i = 0; i < SPD_N; ++i) v[i] = SPD_LAMBDA_MIN_NM + SPD_LAMBDA_STEP_NM * i < 550.f ? lo_value : hi_value;
+        return b.spectrum_from_wavelength_table(v.data(), nullptr, SPD_N, SPD_LAMBDA_MIN_NM, SPD_LAMBDA_STEP_NM);
+    };
+    switch (wall) {
+    case WALL_COMPOSITE_SAME: {
+        const int a = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, false)), c = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, false));
+        return b.add_material(mat_composite({{300, 550}, {550, 800}}, {a, c}, true));
+    }
+    case WALL_COMPOSITE: {
+        const int a = b.add_material(mat_diffuse(b.spectrum_const(.8f), 1.f, false)), c = b.add_material(mat_diffuse(b.spectrum_const(.2f), 1.f, false));
+        return b.add_material(mat_composite({{300, 550}, {550, 800}}, {a, c}, true));
+    }
+    case WALL_STEP: return b.add_material(mat_diffuse(step_table(.8f, .2f), 1.f, true));
+    case WALL_COMPOSITE_GAP: {
+        const int a = b.add_material(mat_diffuse(b.spectrum_const(.8f), 1.f, false));
+        return b.add_material(mat_composite({{300, 550}}, {a}, true));
+    }
+    case WALL_STEP_GAP: return b.add_material(mat_diffuse(step_table(.8f, 0.f), 1.f, true));
+    case WALL_MASK_ONE: return b.add_material(mat_mask(b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, false)), 1.f, true));
+    case WALL_MASK: return b.add_material(mat_mask(b.add_material(mat_diffuse(b.spectrum_const(.8f), 1.f, false)), .6f, true));
+    case WALL_MASK_EQUIV: return b.add_material(mat_diffuse(b.spectrum_const(.48f), 1.f, true));
+    default: return b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    }
+}
+static void build_furnace(const scene_params_t& p, scene_builder_t& b, bool spm_occluders = false, int wall = WALL_GREY) {
     integrator_opts_t o{};
     o.max_depth = 8;
     o.MIS = o.RR = 1;
@@ -293,7 +356,7 @@ static void build_furnace(const scene_params_t& p, scene_builder_t& b, bool spm_
     b.set_sensor_perspective(xform_t::lookat({0, 0, .9}, {0, 0, 0}, {0, 1, 0}), deg(60), p.res, p.res, 1.f, false);
     const float E[3] = {1, 1, 1};
     b.set_response_rgb(E);
-    const int grey = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    const int grey = furnace_wall_material(b, wall);
     const int lightm = b.add_material(mat_diffuse(b.spectrum_const(.0f), 1.f, false));
     b.add_shape(mesh_cube(2.0), xform_t::identity(), grey);
     const int q = b.add_shape(mesh_rectangle({-.25, .95, -.25}, {0, 0, .5}, {.5, 0, 0}), xform_t::identity(), lightm);
@@ -461,6 +524,14 @@ bool build_named_scene(const std::string& name, const scene_params_t& p, scene_b
         build_double_slits_overview(p, b);
     else if (name == "furnace_spm")
         build_furnace(p, b, true);
+    else if (name.rfind("furnace_wall_", 0) == 0) {   // furnace_wall_<variant>: wall material variants (BSDF wrapper tests)
+        static const char* names[] = {"grey", "composite_same", "composite", "step", "composite_gap", "step_gap", "mask_one", "mask", "mask_equiv"};
+        int wall = -1;
+        for (int i = 0; i < 9; ++i)
+            if (name.substr(13) == names[i]) wall = i;
+        if (wall < 0) return false;
+        build_furnace(p, b, false, wall);
+    }
     else if (name == "sunlit")
         build_sunlit(p, b);
     else if (name == "sunlit_path") {

@@ -149,7 +149,7 @@ WT_HD bool vertex_is_connectible(const scene_t& sc, const vertex_t& v) {
     case VT_FSD: return true;
     case VT_EMITTER: return !emitter_is_delta_direction(sc.emitters[v.ref]);
     case VT_SENSOR: return !sensor_is_delta_direction(sc.sensor);
-    case VT_SURFACE: return !material_is_delta_only(sc, v.ref);
+    case VT_SURFACE: return !material_is_delta_only(sc, v.ref, v.beam.k);
     default: return false;
     }
 }

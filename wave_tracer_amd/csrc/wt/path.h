@@ -331,7 +331,7 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
     if (backward && depth < sc.opts.max_depth && primary != kInvalid) {
         // nee_backward (plt_path_detail.hpp:349-425)
         const int mat = sc.shapes[srf.shape].material;
-        if (!material_is_delta_only(sc, mat)) {
+        if (!material_is_delta_only(sc, mat, k)) {
             const emitter_direct_sample_t ds = scene_sample_emitter_direct(sc, srf.wp, k, smp);
             if (beam_intensity(ds.beam) != 0.f) {
                 const vec3 wiworld = -beam.env.d, woworld = -ds.beam.env.d;

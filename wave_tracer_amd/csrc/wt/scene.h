@@ -73,7 +73,7 @@ struct spectrum_t {
 };
 
 // ---- materials -----------------------------------------------------------------------------------
-enum material_type_e : int32_t { MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1, MAT_SURFACE_SPM = 2 };
+enum material_type_e : int32_t { MAT_DIFFUSE = 0, MAT_DIELECTRIC = 1, MAT_SURFACE_SPM = 2, MAT_COMPOSITE = 3, MAT_MASK = 4 };
 enum profile_type_e : int32_t { PROFILE_DIRAC = 0, PROFILE_FRACTAL = 1, PROFILE_GAUSSIAN = 2 };
 struct material_t {
     int32_t type;
@@ -88,6 +88,13 @@ struct material_t {
     float gamma;            // fractal: log-log slope
     float gauss_sigma;      // gaussian: > 0: explicit rms `sigma` [1/mm]; otherwise parametrised by `roughness` like the fractal profile
     float refl_scale, trans_scale;
+    // composite (bsdf/composite.hpp:26-140): spectral bins [kmin, kmax) [1/mm] -> child material; no BSDF outside the bins
+    uint32_t n_bins;
+    float bin_kmin[4], bin_kmax[4];   // kMaxCompositeBins (wt/bsdf.h)
+    int32_t bin_child[4];
+    // mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha (constant texture: bitmaps are absent)
+    int32_t nested;
+    float mask_alpha;
 };
 
 // ---- emitters ------------------------------------------------------------------------------------
