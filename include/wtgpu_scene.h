@@ -53,6 +53,10 @@ typedef struct WTGPU_ALIGN16 wtgpu_bvh8_node {
 typedef struct wtgpu_bvh8_leaf {
     uint32_t tris_ptr, count;
 } wtgpu_bvh8_leaf;
+/* A child reference of an 8-wide node: 0 = none, > 0 = node index + 1, < 0 = a LEAF NAMED BY VALUE: -((tris_ptr << 3) | count), count in */
+/* 1..7.  (The reference's node points into a leaf array, bvh8w_node.hpp:27-41; here the triangles of a leaf follow from the reference */
+/* itself, which takes one dependent memory round trip out of every leaf visit of every traversal.  wtgpu_scene::leaves still lists the */
+/* leaves for hosts that want to iterate them; the traversals do not read it.) */
 
 typedef struct wtgpu_shape {
     int32_t material;

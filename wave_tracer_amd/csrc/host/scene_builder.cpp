@@ -1104,7 +1104,8 @@ void scene_builder_t::build_bvh() {
             nd.maxz[c] = b.box.mx[2];
             if (b.leaf) {
                 leaves_.push_back(bvh8_leaf_t{b.first, b.count});
-                nd.child[c] = -(int32_t)leaves_.size();
+                if (b.count == 0 || b.count > 7 || b.first >= (1u << 28)) throw std::runtime_error("BVH leaf does not fit the by-value child reference");
+                nd.child[c] = -(int32_t)((b.first << 3) | b.count);   // leaf named by value (wt/scene.h)
             } else
                 todo.push_back({(int)c, ch[c]});
         }
@@ -1385,8 +1386,8 @@ const scene_t& scene_builder_t::finalize() {
                 if (cp == 0) continue;
                 uint32_t t0, cnt;
                 if (cp < 0) {
-                    t0 = leaves_[-cp - 1].tris_ptr;
-                    cnt = leaves_[-cp - 1].count;
+                    t0 = (uint32_t)(-cp) >> 3;
+                    cnt = (uint32_t)(-cp) & 7u;
                 } else {
                     t0 = nodes_[cp - 1].tris_start;
                     cnt = nodes_[cp - 1].tris_count;

@@ -31,6 +31,10 @@ struct stack_ref_t {
     stack_entry_t* q;
     WT_HD stack_entry_t& operator[](int i) const { return (uint32_t)i < n_fast ? p[(size_t)i * stride] : q[(uint32_t)i - n_fast]; }
 };
+WT_HD bvh8_leaf_t bvh_leaf_of(int32_t child) {   // child < 0 (wt/scene.h: bvh8_leaf_t)
+    const uint32_t v = (uint32_t)(-child);
+    return bvh8_leaf_t{v >> 3, v & 7u};
+}
 WT_HD stack_ref_t make_flat_stack(stack_entry_t* p, uint32_t cap) { return stack_ref_t{p, 1, cap, cap, nullptr}; }
 
 struct uint_list_t {   // bounded output list with the same (pointer,stride) addressing
@@ -122,7 +126,7 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
         const stack_entry_t top = stack[s - 1];
         --s;
         if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
             if (ctr) ctr->leaves++;
             const bool intr = ray_gather_tris<shadow>(sc, ro, rd, leaf.tris_ptr, leaf.count, range, rec, ctr);
             if (intr) {
@@ -248,7 +252,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
         const stack_entry_t top = stack[s - 1];
         --s;
         if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
             if (ctr) ctr->cone_leaves++;
             bool found = false;
             tests += leaf.count;
@@ -376,7 +380,7 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
         const stack_entry_t top = stack[s - 1];
         --s;
         if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
             tests += leaf.count;
             if (ctr) ctr->probe_tri_tests += leaf.count;
             if (tests > budget) {
@@ -701,7 +705,7 @@ WT_HD uint32_t bvh_gather_edges(const scene_t& sc, const cone_t& tcone, const ra
         --s;
         uint32_t t0, cnt;
         if (ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-ptr - 1];
+            const bvh8_leaf_t leaf = bvh_leaf_of(ptr);
             t0 = leaf.tris_ptr;
             cnt = leaf.count;
         } else {

@@ -220,7 +220,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
             int32_t cp = 0;
             if (live) {
                 if (e.ptr < 0) {
-                    const bvh8_leaf_t leaf = sc.leaves[-e.ptr - 1];
+                    const bvh8_leaf_t leaf = bvh_leaf_of(e.ptr);
                     t0 = leaf.tris_ptr;
                     cnt = leaf.count;
                     leafish = true;
@@ -453,7 +453,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             int32_t cp = 0;
             if (live) {
                 if (e.ptr < 0) {
-                    const bvh8_leaf_t leaf = sc.leaves[-e.ptr - 1];
+                    const bvh8_leaf_t leaf = bvh_leaf_of(e.ptr);
                     t0 = leaf.tris_ptr;
                     cnt = leaf.count;
                     leafish = true;
@@ -639,7 +639,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
             int32_t cp = 0;
             if (live) {
                 if (e.ptr < 0) {
-                    const bvh8_leaf_t leaf = sc.leaves[-e.ptr - 1];
+                    const bvh8_leaf_t leaf = bvh_leaf_of(e.ptr);
                     t0 = leaf.tris_ptr;
                     cnt = leaf.count;
                     leafish = true;

@@ -82,7 +82,7 @@ __device__ inline bool g8_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const r
         g8_fence();
         uint32_t t0 = 0, cnt = 0;
         if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = sc.leaves[-top.ptr - 1];
+            const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
             t0 = leaf.tris_ptr;
             cnt = leaf.count;
         } else {

@@ -65,6 +65,7 @@ namespace {
 #ifndef WTGPU_LB_CONNECT
 #define WTGPU_LB_CONNECT 3
 #endif
+constexpr uint32_t kFluxTaskTris = 2048;   // default size of a region-sum task (k_flux_split / k_flux_tasks)
 constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
 constexpr int kBlock = 128;
 #ifndef WTGPU_LDS_STACK
@@ -166,7 +167,7 @@ struct wtgpu_scene {
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0;
-        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1;
+        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
     } knobs;
 };
@@ -203,6 +204,7 @@ struct launch_args_t {
     uint64_t sample_begin;
     uint32_t count_stats;
     uint32_t cone_budget;
+    uint32_t flux_task_tris;   // k_flux_split: largest subtree handed to one wavefront of k_flux_tasks
     uint32_t heavy_probe;   // k_trace_heavy: any-hit probe of the near slab before the handed-over cone query too
     uint32_t coop_aperture_min;   // regions with at least this many classified edges get their aperture built by k_edges' wavefront
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
@@ -586,8 +588,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(laun
 // plt_bdpt_detail.hpp:391-416) for the pass-C walks.  Such regions hold 10^3..10^5 triangles (a wide emitter beam over a finely
 // tessellated mesh), 5000 on average in the headline workload: one wavefront per region would leave the round waiting for the
 // largest one (measured: 27 ms for a 130,000-triangle region).  k_flux_split cuts the part of the tree that overlaps the region
-// into subtrees of <= kFluxTaskTris triangles, k_flux_tasks sums every subtree on whichever wavefront is free (f64 atomics).
-constexpr uint32_t kFluxTaskTris = 512;
+// into subtrees of <= kFluxTaskTris (2048; swept 128 / 512 / 2048: 247 / 216 / 208 ms per pass) triangles, k_flux_tasks sums every subtree on whichever wavefront is free (f64 atomics).
 __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     __shared__ coop_shared_t sh;
     __shared__ uint32_t s_item;
@@ -607,7 +608,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
             const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
             const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
             if (threadIdx.x == 0) a.st.facc[w] = 0.0;
-            coop_split(a.sc, tcone, range_t{beam_dist, beam_dist + region_depth}, sh, kFluxTaskTris, [&](int32_t ptr) {
+            coop_split(a.sc, tcone, range_t{beam_dist, beam_dist + region_depth}, sh, a.flux_task_tris, [&](int32_t ptr) {
                 const uint32_t idx = atomicAdd(ctl + CTL_FTASK_COUNT, 1u);
                 if (idx < a.st.ftask_cap)
                     a.st.ftasks[idx] = make_uint2(w, (uint32_t)ptr);
@@ -1339,6 +1340,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.grid_div_c = std::max(1u, u("WTGPU_GRID_C", 2));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
+    k.flux_task_tris = std::max(64u, u("WTGPU_FLUX_TASK_TRIS", kFluxTaskTris));
     k.coop_aperture_min = u("WTGPU_COOP_APERTURE_MIN", 8);   // 0xFFFFFFFF: every aperture by a single lane of pass B
     if (const char* e = getenv("WTGPU_DEBUG_STAGE")) k.dbg_stage = atoi(e);   // bring-up aid: stops launching the round kernels after stage n (invalid results)
     if (const char* e = getenv("WTGPU_TIMING")) s->timing = atoi(e) != 0;
@@ -1528,6 +1530,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     a.profile = K.profile;
     a.coop_aperture_min = K.coop_aperture_min;
     a.heavy_probe = K.heavy_probe;
+    a.flux_task_tris = K.flux_task_tris;
     // Bounded triangle lists (64) are the fast path of an interaction region; a region that overflows its list is handled exactly by
     // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_flux_*).
     // WTGPU_NO_LISTS=1 (plt_bdpt, diagnostic): no lists at all, every region is gathered.
