@@ -120,50 +120,59 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
     const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
 
+    // "while-while" form (Aila & Laine): every lane of a wavefront first descends through nodes until it holds a leaf (lanes that
+    // found theirs wait at the inner loop's exit), then all of them test their leaf's triangles together — instead of paying the node
+    // path AND the leaf path in every iteration because some lane needs each.  Per lane the order of visits is unchanged.
     int s = 1;
     stack[0] = stack_entry_t{0.f, 1};
     while (s > 0) {
-        const stack_entry_t top = stack[s - 1];
-        --s;
-        if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
-            if (ctr) ctr->leaves++;
-            const bool intr = ray_gather_tris<shadow>(sc, ro, rd, leaf.tris_ptr, leaf.count, range, rec, ctr);
-            if (intr) {
-                if (shadow) return true;
-                while (s > 0 && stack[s - 1].t >= rec.dist) --s;
+        bool have_leaf = false;
+        uint32_t lt0 = 0, lcnt = 0;
+        while (s > 0) {
+            const stack_entry_t top = stack[s - 1];
+            --s;
+            if (top.ptr < 0) {
+                const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
+                if (ctr) ctr->leaves++;
+                lt0 = leaf.tris_ptr;
+                lcnt = leaf.count;
+                have_leaf = true;
+                break;
             }
-            continue;
-        }
-        // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
-        // one per child field); the unrolled child loop then runs from registers
-        const bvh8_node_t n = sc.nodes[top.ptr - 1];
-        if ((int)n.tris_count <= kRayLeafShortcut) {
-            const bool intr = ray_gather_tris<shadow>(sc, ro, rd, n.tris_start, n.tris_count, range, rec, ctr);
-            if (intr) {
-                if (shadow) return true;
-                while (s > 0 && stack[s - 1].t >= rec.dist) --s;
+            // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+            // one per child field); the unrolled child loop then runs from registers
+            const bvh8_node_t n = sc.nodes[top.ptr - 1];
+            if ((int)n.tris_count <= kRayLeafShortcut) {
+                lt0 = n.tris_start;
+                lcnt = n.tris_count;
+                have_leaf = true;
+                break;
             }
-            continue;
-        }
-        if (ctr) ctr->nodes++;
-        const float tfar = fminf_(rec.dist, range.max);
-        const int begin = s;
+            if (ctr) ctr->nodes++;
+            const float tfar = fminf_(rec.dist, range.max);
+            const int begin = s;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int32_t cp = n.child[i];
-            if (cp == 0) continue;
-            const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
-            const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
-            const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
-            const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
-            const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
-            const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
-            const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, range.min));
-            const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
-            if (rmin <= rmax && s < (int)stack.cap) stack[s++] = stack_entry_t{rmin, cp};
+            for (int i = 0; i < 8; ++i) {
+                const int32_t cp = n.child[i];
+                if (cp == 0) continue;
+                const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
+                const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
+                const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
+                const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
+                const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
+                const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
+                const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, range.min));
+                const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
+                if (rmin <= rmax && s < (int)stack.cap) stack[s++] = stack_entry_t{rmin, cp};
+            }
+            stack_sort_desc(stack, begin, s);
         }
-        stack_sort_desc(stack, begin, s);
+        if (!have_leaf) break;
+        const bool intr = ray_gather_tris<shadow>(sc, ro, rd, lt0, lcnt, range, rec, ctr);
+        if (intr) {
+            if (shadow) return true;
+            while (s > 0 && stack[s - 1].t >= rec.dist) --s;
+        }
     }
     return rec.dist < WT_INF;
 }
@@ -248,11 +257,68 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
     range_t range = cone_search_range(cone, searchrange, rec.dist, z_scale);
     int s = 1;
     stack[0] = stack_entry_t{0.f, 1};
-    while (s > 0) {
-        const stack_entry_t top = stack[s - 1];
-        --s;
-        if (top.ptr < 0) {
-            const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
+    while (s > 0) {   // "while-while" form, see bvh_traverse_ray
+        int32_t leaf_ptr = 0;
+        while (s > 0 && leaf_ptr == 0) {
+            const stack_entry_t top = stack[s - 1];
+            --s;
+            if (top.ptr < 0) {
+                leaf_ptr = top.ptr;
+                continue;
+            }
+            // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+            // one per child field); the unrolled child loop then runs from registers
+            const bvh8_node_t n = sc.nodes[top.ptr - 1];
+            if (ctr) ctr->cone_nodes++;
+            tests += kNodeBudgetCost;   // an 8-wide node visit costs a lane about as much as a few triangle tests
+            if (tests > budget) {
+                rec.aborted = 1;
+                return false;
+            }
+            const int begin = s;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t cp = n.child[i];
+                if (cp == 0) continue;
+                // cone_cluster_intersect (bvh8w.cpp:187-230): grow the box by the cone radius at its far z
+                float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
+                float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+                const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
+                const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
+                const float dot_d_b = rd.x * bx + rd.y * by + rd.z * bz;
+                const float maxz = clampf(dot_d_b, 0.f, range.max);
+                const float enlr = fmaf(maxz, ta, ix);
+                ominx -= enlr;
+                ominy -= enlr;
+                ominz -= enlr;
+                omaxx += enlr;
+                omaxy += enlr;
+                omaxz += enlr;
+                const float dminx = (sx ? omaxx : ominx) * rinvd.x, dmaxx = (sx ? ominx : omaxx) * rinvd.x;
+                const float dminy = (sy ? omaxy : ominy) * rinvd.y, dmaxy = (sy ? ominy : omaxy) * rinvd.y;
+                const float dminz = (sz ? omaxz : ominz) * rinvd.z, dmaxz = (sz ? ominz : omaxz) * rinvd.z;
+                float tmin = 0.f, tmax = dmaxx;
+                tmin = fmaxf_(tmin, dminx);
+                tmax = fminf_(tmax, dmaxy);
+                tmin = fmaxf_(tmin, dminy);
+                tmax = fminf_(tmax, dmaxz);
+                tmin = fmaxf_(tmin, dminz);
+                const bool hit = tmin <= tmax && tmax >= range.min && tmin <= range.max;
+                if (!hit) continue;
+                if (tmin >= range.max) continue;
+                if (cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) continue;
+                if (s < (int)stack.cap) {
+                    stack[s++] = stack_entry_t{tmin, cp};
+                } else if (budget != 0xFFFFFFFFu) {
+                    rec.aborted = 1;   // device: the 64-entry per-lane stack is full -> the wave-cooperative query (512 entries) takes over
+                    return false;
+                }
+            }
+            stack_sort_desc(stack, begin, s);
+        }
+        if (leaf_ptr == 0) break;
+        {
+            const bvh8_leaf_t leaf = bvh_leaf_of(leaf_ptr);
             if (ctr) ctr->cone_leaves++;
             bool found = false;
             tests += leaf.count;
@@ -293,57 +359,7 @@ WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_
                 if (rec.overflow > 0) range.max = fminf_(range.max, rec.dist);
                 while (s > 0 && stack[s - 1].t >= range.max) --s;
             }
-            continue;
         }
-        // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
-        // one per child field); the unrolled child loop then runs from registers
-        const bvh8_node_t n = sc.nodes[top.ptr - 1];
-        if (ctr) ctr->cone_nodes++;
-        tests += kNodeBudgetCost;   // an 8-wide node visit costs a lane about as much as a few triangle tests
-        if (tests > budget) {
-            rec.aborted = 1;
-            return false;
-        }
-        const int begin = s;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int32_t cp = n.child[i];
-            if (cp == 0) continue;
-            // cone_cluster_intersect (bvh8w.cpp:187-230): grow the box by the cone radius at its far z
-            float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
-            float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
-            const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
-            const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
-            const float dot_d_b = rd.x * bx + rd.y * by + rd.z * bz;
-            const float maxz = clampf(dot_d_b, 0.f, range.max);
-            const float enlr = fmaf(maxz, ta, ix);
-            ominx -= enlr;
-            ominy -= enlr;
-            ominz -= enlr;
-            omaxx += enlr;
-            omaxy += enlr;
-            omaxz += enlr;
-            const float dminx = (sx ? omaxx : ominx) * rinvd.x, dmaxx = (sx ? ominx : omaxx) * rinvd.x;
-            const float dminy = (sy ? omaxy : ominy) * rinvd.y, dmaxy = (sy ? ominy : omaxy) * rinvd.y;
-            const float dminz = (sz ? omaxz : ominz) * rinvd.z, dmaxz = (sz ? ominz : omaxz) * rinvd.z;
-            float tmin = 0.f, tmax = dmaxx;
-            tmin = fmaxf_(tmin, dminx);
-            tmax = fminf_(tmax, dmaxy);
-            tmin = fmaxf_(tmin, dminy);
-            tmax = fminf_(tmax, dmaxz);
-            tmin = fmaxf_(tmin, dminz);
-            const bool hit = tmin <= tmax && tmax >= range.min && tmin <= range.max;
-            if (!hit) continue;
-            if (tmin >= range.max) continue;
-            if (cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) continue;
-            if (s < (int)stack.cap) {
-                stack[s++] = stack_entry_t{tmin, cp};
-            } else if (budget != 0xFFFFFFFFu) {
-                rec.aborted = 1;   // device: the 64-entry per-lane stack is full -> the wave-cooperative query (512 entries) takes over
-                return false;
-            }
-        }
-        stack_sort_desc(stack, begin, s);
     }
     if (tris.d && rec.ntris > 0) {   // cone_work_to_intersection_record: remove the triangles beyond the final slab
         const float zmax = cone_search_range(cone, searchrange, rec.dist, z_scale).max;
