@@ -194,19 +194,27 @@ constexpr int kMaxCompositeBins = (int)(sizeof(material_t::bin_child) / sizeof(i
 //   composite (bsdf/composite.hpp:84-135: the bin whose left-inclusive range [kmin,kmax) holds k; none -> no BSDF: f = 0, no sample,
 //   pdf = 0, is_delta_only = true), mask (src/bsdf/mask.cpp: the nested BSDF; `alpha` accumulates the mask opacity).
 // two_sided / scale of a wrapper apply to what it wraps.  FALSE: no BSDF at this wavenumber.
-WT_HD bool material_resolve(const scene_t& sc, int mat, float k, material_t& m, float& alpha, bool* mask_two_sided = nullptr) {
+struct material_wrap_t {
+    float alpha;      // mask opacity (1: none)
+    bool masked;      // a mask wrapper was passed
+    bool mask_two;    // ... under a two_sided wrapper: the mask sees the flipped directions
+};
+WT_HD bool material_resolve(const scene_t& sc, int mat, float k, material_t& m, material_wrap_t& wr) {
     m = sc.materials[mat];
+    wr.alpha = 1.f;
+    wr.masked = wr.mask_two = false;
+    if (m.type < MAT_COMPOSITE) return true;   // a leaf BSDF: the common case (only the fields the caller goes on to use are loaded)
     uint32_t two = 0;
     float scale = 1.f;
-    alpha = 1.f;
-    for (int depth = 0; depth < 4 && (m.type == MAT_COMPOSITE || m.type == MAT_MASK); ++depth) {
+    for (int depth = 0; depth < 4 && m.type >= MAT_COMPOSITE; ++depth) {
         two |= m.two_sided;
         scale *= m.scale;
         int child = -1;
         if (m.type == MAT_MASK) {
-            alpha *= clamp01(m.mask_alpha);
+            wr.alpha *= clamp01(m.mask_alpha);
+            wr.masked = true;
+            wr.mask_two = two != 0;
             child = m.nested;
-            if (mask_two_sided) *mask_two_sided = two != 0;   // a two_sided wrapper at or above the mask: the mask sees the flipped directions
         } else {
             for (uint32_t i = 0; i < m.n_bins && i < (uint32_t)kMaxCompositeBins; ++i)
                 if (m.bin_kmin[i] <= k && k < m.bin_kmax[i]) {
@@ -217,25 +225,16 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, material_t& m, 
         if (child < 0) return false;
         m = sc.materials[child];
     }
-    if (m.type == MAT_COMPOSITE || m.type == MAT_MASK) return false;   // nesting deeper than the flattener produces
+    if (m.type >= MAT_COMPOSITE) return false;   // nesting deeper than the flattener produces
     m.two_sided |= two;
     m.scale *= scale;
     return true;
 }
-WT_HD bool material_is_masked(const scene_t& sc, int mat) {
-    material_t m = sc.materials[mat];
-    for (int depth = 0; depth < 4; ++depth) {
-        if (m.type == MAT_MASK) return true;
-        if (m.type != MAT_COMPOSITE || m.n_bins == 0) return false;
-        m = sc.materials[m.bin_child[0]];   // (a mask inside a composite bin is not produced by the flattener; outside is)
-    }
-    return false;
-}
 
 WT_HD bool material_is_delta_only(const scene_t& sc, int mat, float k) {
     material_t m;
-    float mask_alpha;
-    if (!material_resolve(sc, mat, k, m, mask_alpha)) return true;
+    material_wrap_t wr;
+    if (!material_resolve(sc, mat, k, m, wr)) return true;
     if (m.type == MAT_DIFFUSE) return false;
     if (m.type == MAT_DIELECTRIC) return true;
     return profile_is_delta_only(m);
@@ -244,8 +243,8 @@ WT_HD bool material_is_delta_only(const scene_t& sc, int mat, float k) {
 // bsdf_t::f — includes the cosine foreshortening; only non-delta lobes
 WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport) {
     material_t m;
-    float mask_alpha;
-    if (!material_resolve(sc, mat, k, m, mask_alpha) || mask_alpha == 0.f) return mueller_zero();
+    material_wrap_t wr;
+    if (!material_resolve(sc, mat, k, m, wr) || wr.alpha == 0.f) return mueller_zero();
     if (m.two_sided) {
         const float z = wi.z;
         wi = two_sided_flip(wi, z);
@@ -276,25 +275,24 @@ WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k
     }
     // dielectric: delta only -> 0
     if (m.scale != 1.f) M = M * m.scale;
-    if (mask_alpha != 1.f) M = M * mask_alpha;   // mask.cpp:24-35
+    if (wr.masked) M = M * wr.alpha;   // mask.cpp:24-35
     return M;
 }
 
 WT_HD float material_pdf_leaf(const scene_t& sc, const material_t& m, vec3 wi, vec3 wo, float k, uint32_t transport);
 WT_HD float material_pdf(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport) {
     material_t m;
-    float mask_alpha;
-    bool mask_two = false;
-    if (!material_resolve(sc, mat, k, m, mask_alpha, &mask_two)) return 0.f;
-    if (mask_alpha != 1.f || material_is_masked(sc, mat)) {
+    material_wrap_t wr;
+    if (!material_resolve(sc, mat, k, m, wr)) return 0.f;
+    if (wr.masked) {
         // mask.cpp:79-92: no transmission through a masked BSDF; the nested density times the probability of not taking the null lobe
-        if (mask_two) {
+        if (wr.mask_two) {
             const float z = wi.z;
             wi = two_sided_flip(wi, z);
             wo = two_sided_flip(wo, z);
         }
         if (wi.z <= 0.f || wo.z <= 0.f) return 0.f;
-        return material_pdf_leaf(sc, m, wi, wo, k, transport) * mask_alpha;
+        return material_pdf_leaf(sc, m, wi, wo, k, transport) * wr.alpha;
     }
     return material_pdf_leaf(sc, m, wi, wo, k, transport);
 }
@@ -326,19 +324,18 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
     r.eta = 1.f;
     r.M = mueller_zero();
     material_t m;
-    float mask_alpha;
-    bool mask_two = false;
-    if (!material_resolve(sc, mat, k, m, mask_alpha, &mask_two)) return r;   // composite: no bin at this wavenumber
+    material_wrap_t wr;
+    if (!material_resolve(sc, mat, k, m, wr)) return r;   // composite: no bin at this wavenumber
     // mask.cpp:37-77 (every lobe is admitted by the integrators' queries: has_null = true): the null lobe passes the beam straight
     // through with probability 1 - alpha (always, from behind), the nested BSDF is sampled otherwise
     float not_null = 1.f;
-    if (mask_alpha != 1.f || material_is_masked(sc, mat)) {
-        const float pdf_null = (mask_two ? wi_in.z == 0.f : wi_in.z <= 0.f) ? 1.f : 1.f - mask_alpha;
+    if (wr.masked) {
+        const float pdf_null = (wr.mask_two ? wi_in.z == 0.f : wi_in.z <= 0.f) ? 1.f : 1.f - wr.alpha;
         const bool is_null = pdf_null == 0.f ? false : (pdf_null == 1.f ? true : sampler_r(sampler) < pdf_null);
         if (is_null) {
             r.wo = -wi_in;
             r.dpd = pd_discrete(pdf_null);
-            r.M = mueller_identity() * ((1.f - mask_alpha) / pdf_null);
+            r.M = mueller_identity() * ((1.f - wr.alpha) / pdf_null);
             r.valid = true;
             return r;
         }
@@ -427,9 +424,9 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
     if (r.valid) {
         if (m.two_sided) r.wo = two_sided_flip(r.wo, flipz);
         if (m.scale != 1.f) r.M = r.M * m.scale;
-        if (not_null != 1.f || mask_alpha != 1.f) {   // mask.cpp:72-75
+        if (wr.masked) {   // mask.cpp:72-75
             r.dpd *= not_null;   // (a discrete mass is stored negated: scaling keeps the flag)
-            r.M = r.M * (mask_alpha / not_null);
+            r.M = r.M * (wr.alpha / not_null);
         }
     }
     return r;
