@@ -21,6 +21,9 @@ pytestmark = pytest.mark.gpu
     ("furnace_path", 32, 4, {}, 1e-2),
     ("furnace_path", 24, 4, {"fsd": 1}, 2e-2),
     ("cornell_box_path", 24, 4, {"mesh_detail": 0, "crop_of": 1440}, 2e-2),
+    # the dense bench geometry (283 K triangles) under plt_path: regions beyond the 64-triangle list take the primary from the axis hit
+    # and their edge set from bvh_gather_edges (wt/path.h)
+    ("cornell_box_path", 24, 2, {"mesh_detail": 1, "crop_of": 1440}, 3e-2),
 ])
 def test_path_image_parity(built, name, res, spp, kw, tol):
     """Same Philox streams on both sides: the images agree sample for sample up to fp contraction / libm ulps (a handful of
