@@ -107,6 +107,11 @@ def test_reader_reports_errors(built, tmp_path):
     sphere.write_text(open(OWN).read().replace('<include path="parts/slit_geometry.xml"/>', '<shape type="sphere"><ref id="metal"/></shape>'))
     with pytest.raises(WtgpuError, match="not supported by the minimal reader"):
         Scene.from_xml(str(sphere))
+    loop = tmp_path / "loop.xml"
+    loop.write_text('<scene><include path="loop_part.xml"/></scene>')
+    (tmp_path / "loop_part.xml").write_text('<include path="loop_part.xml"/>')
+    with pytest.raises(WtgpuError, match="nested deeper"):
+        Scene.from_xml(str(loop))
     nodir = tmp_path / "nodir.xml"
     nodir.write_text("<scene><integrator type='plt_path'/></scene>")
     with pytest.raises(WtgpuError, match="direction"):

@@ -422,7 +422,8 @@ struct loader_t {
         for (auto& a : n.attrs) a.second = subst(a.second);
         for (auto& k : n.kids) subst_tree(k);
     }
-    void splice(std::vector<xnode_t>&& nodes, const std::string& dir) {
+    void splice(std::vector<xnode_t>&& nodes, const std::string& dir, int depth = 0) {
+        if (depth > 8) throw std::runtime_error("<include> nested deeper than 8 levels (a cycle?)");
         for (auto& n : nodes) {
             if (n.name == "default") {
                 const std::string name = n.get("name");
@@ -431,7 +432,7 @@ struct loader_t {
                 const std::string path = dir + "/" + subst(n.get("path"));
                 const std::string text = read_file(path);
                 xml_parser_t p(text, path);
-                splice(p.top_level(), dir_of(path));
+                splice(p.top_level(), dir_of(path), depth + 1);
             } else {
                 subst_tree(n);
                 items.push_back(std::move(n));

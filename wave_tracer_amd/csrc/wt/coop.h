@@ -26,7 +26,10 @@ constexpr int kCoopStack = 512;
 constexpr uint32_t kCoopLeafTris = 64;
 constexpr uint32_t kCoopTriBuf = 64 + 8 * kCoopLeafTris;   // buffered triangle ids: < 64 pending + 8 entries x <= 64 triangles
 
-constexpr uint32_t kCoopFlushAt = 12;
+#ifndef WTGPU_COOP_FLUSH_AT
+#define WTGPU_COOP_FLUSH_AT 12
+#endif
+constexpr uint32_t kCoopFlushAt = WTGPU_COOP_FLUSH_AT;   // survivors worth an exact-test pass before the stack is empty
 constexpr uint32_t kCoopSurvCap = 128;   // candidates that passed the cheap filter and await the exact cone-triangle test
 
 struct coop_shared_t {

@@ -1467,19 +1467,18 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     s->acc[5] += rounds;
     s->acc[6] += 1;
     if (s->timing) {
-        float ms = 0;
-        hipEventElapsedTime(&ms, r.ev[0], r.ev[1]);
-        s->acc[0] += ms;
+        // (an event pair that cannot be resolved contributes 0 ms: timings are diagnostics, the render itself has completed)
+        auto elapsed = [](hipEvent_t a, hipEvent_t b) {
+            float ms = 0.f;
+            return hipEventElapsedTime(&ms, a, b) == hipSuccess ? ms : 0.f;
+        };
+        s->acc[0] += elapsed(r.ev[0], r.ev[1]);
         size_t e = 1;
         for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 6) {
             static const int slot[6] = {1, 7, 2, 8, 9, 10};   // trace, heavy trace, pass A, edges + pass B, region flux, pass C
-            for (int q = 0; q < 6; ++q) {
-                hipEventElapsedTime(&ms, r.ev[e + q], r.ev[e + q + 1]);
-                s->acc[slot[q]] += ms;
-            }
+            for (int q = 0; q < 6; ++q) s->acc[slot[q]] += elapsed(r.ev[e + q], r.ev[e + q + 1]);
         }
-        hipEventElapsedTime(&ms, r.ev[e], r.ev[e + 1]);
-        s->acc[3] += ms;
+        s->acc[3] += elapsed(r.ev[e], r.ev[e + 1]);
     }
     r.busy = false;
     return WTGPU_OK;
