@@ -48,7 +48,7 @@ namespace {
 #define WTGPU_LB_TRACE 3
 #endif
 #ifndef WTGPU_LB_HEAVY
-#define WTGPU_LB_HEAVY 3
+#define WTGPU_LB_HEAVY 2   // 215 VGPRs, no spills, no scratch frame: as fast as 3 waves with 93 spilled registers, 27 GB per pass less HBM traffic
 #endif
 #ifndef WTGPU_LB_INTERACT
 #define WTGPU_LB_INTERACT 4
@@ -63,7 +63,7 @@ namespace {
 #define WTGPU_LB_FLUX 3
 #endif
 #ifndef WTGPU_LB_CONNECT
-#define WTGPU_LB_CONNECT 3
+#define WTGPU_LB_CONNECT 2   // 355 -> 105 spilled registers (the rest of its frame are the two vertices and beams of a connection)
 #endif
 constexpr uint32_t kFluxTaskTris = 2048;   // default size of a region-sum task (k_flux_split / k_flux_tasks)
 constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
