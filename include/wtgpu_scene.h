@@ -96,10 +96,33 @@ typedef struct wtgpu_material {
     uint32_t n_bins;
     float bin_kmin[4], bin_kmax[4];   /* kMaxCompositeBins (wt/bsdf.h) */
     int32_t bin_child[4];
-    /* mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha (constant texture: bitmaps are absent) */
+    /* mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha */
     int32_t nested;
-    float mask_alpha;
+    float mask_alpha;       /* constant mask, used when mask_tex == 0 */
+    /* textures (include/wt/texture/*.hpp): texture index + 1, 0 = none (so that a zero-initialised record has no textures) */
+    uint32_t refl_tex;      /* diffuse: reflectance = clamp01(spectrum * refl_tex_scale * texture) (scale.hpp wrapping a texture) */
+    uint32_t mask_tex;      /* mask: opacity texture (0: the constant mask_alpha) */
+    uint32_t normal_tex;    /* normalmap wrapper (bsdf/normalmap.hpp:48-62), flattened onto the material it wraps */
+    uint32_t normal_flip;
 } wtgpu_material;
+
+/* ---- textures (include/wt/texture/texture.hpp:29-90) ------------------------------------------------------------------------------ */
+/* A texture record is one of constant / checkerboard / bitmap, with the two generic wrappers folded in: `transform` (uv' = M uv + t, */
+/* texture/transform.hpp:35-44; identity when absent) applied before the lookup and `scale` by a constant (texture/scale.hpp:95-97; 1 */
+/* when absent) applied after it.  Bitmaps are float texels (linear, 1..4 channels: luminance, luminance+alpha, RGB, RGBA), rows from the */
+/* image's top; luminance textures are wavelength independent (bitmap.hpp:84-99), RGB ones are only read through get_RGBA (normal maps). */
+enum { WTGPU_TEX_CONSTANT = 0, WTGPU_TEX_CHECKERBOARD = 1, WTGPU_TEX_BITMAP = 2 };   /* texture_type */
+enum { WTGPU_WRAP_BLACK = 0, WTGPU_WRAP_WHITE = 1, WTGPU_WRAP_CLAMP = 2, WTGPU_WRAP_REPEAT = 3, WTGPU_WRAP_MIRROR = 4 };   /* texture_wrap */
+typedef struct wtgpu_texture {
+    int32_t type;
+    float rgba[4];        /* TEX_CONSTANT */
+    int32_t col1, col2;   /* TEX_CHECKERBOARD: the two nested textures */
+    float m[4], t[2];     /* transform: uv' = (m[0] u + m[1] v + t[0], m[2] u + m[3] v + t[1]) */
+    float scale;
+    uint32_t width, height, channels, offset;   /* TEX_BITMAP: texel (x, y) channel c = texture_data[offset + (y * width + x) * channels + c] */
+    uint32_t bilinear;    /* 0: nearest, 1: bilinear */
+    uint32_t uwrap, vwrap;
+} wtgpu_texture;
 
 /* ---- emitters ------------------------------------------------------------------------------------ */
 enum { WTGPU_EMIT_SPOT = 0, WTGPU_EMIT_AREA = 1, WTGPU_EMIT_POINT = 2, WTGPU_EMIT_DIRECTIONAL = 3 };   /* emitter_type */
@@ -204,6 +227,9 @@ typedef struct wtgpu_scene_desc {
     const wtgpu_spectrum* spectra;
     uint32_t n_spectra;
     const float* spectra_data;
+    const wtgpu_texture* textures;
+    uint32_t n_textures;
+    const float* texture_data;
     /* emitters */
     const wtgpu_emitter* emitters;
     uint32_t n_emitters;

@@ -169,7 +169,7 @@ double vertex_pdf(const ctx_t& c, const vertex& v, const vertex* prev, const ver
         to(wow, b);
         prim_surface_to_local(&v.surface, a, wi);
         prim_surface_to_local(&v.surface, b, wo);
-        pd = prim_material_pdf(c.sc, v.material, wi, wo, beam_k(v.beam), mode_backward ? 1 : 0);
+        pd = prim_material_pdf(c.sc, v.material, &v.surface, wi, wo, beam_k(v.beam), mode_backward ? 1 : 0);
     } else if (v.fraunhofer) {
         to(wow, b);
         pd = prim_fsd_pdf(v.fsd_slot, b);
@@ -351,7 +351,7 @@ bool interact(const ctx_t& c, const vertex& v, const vertex& next, bool ignore_f
         const double wig = dot(wiw, ng), wog = dot(wow, ng), wis = wi[2], wos = wo[2];
         if (wig * wis <= 0 || wog * wos <= 0) return false;
         float M[16];
-        prim_material_f(c.sc, v.material, wi, wo, k, v.backward ? 1 : 0, M);
+        prim_material_f(c.sc, v.material, &v.surface, wi, wo, k, v.backward ? 1 : 0, M);
         double scale = 1.0 / std::fabs(wos);
         if (!(ns.x == ng.x && ns.y == ng.y && ns.z == ng.z) && !v.backward)   // integrator/common.hpp:21-33 (forward transport only)
             scale *= std::fmin(std::fabs(wis * wog / (wos * wig)), 100.0);

@@ -161,7 +161,7 @@ void prim_step_sample(const void* sc_, const prim_beam* beam_, const prim_trav* 
         const vec3 wi = to_local(srf.shading, wiw);
         const float wig = dot(wiw, ng), wis = wi.z;
         if (wig * wis <= 0.f) return;
-        const bsdf_sample_t bs = material_sample(sc, shp.material, wi, beam.k, beam.transport, smp);
+        const bsdf_sample_t bs = material_sample(sc, shp.material, wi, beam.k, beam.transport, smp, srf.uv);
         *draws = smp.draws;
         if (!bs.valid || bs.dpd == 0.f) return;
         const vec3 wow = normalize(to_world(srf.shading, bs.wo));
@@ -173,7 +173,7 @@ void prim_step_sample(const void* sc_, const prim_beam* beam_, const prim_trav* 
         out->emitter_of_shape = shp.emitter;
         out->is_delta = pd_is_discrete(bs.dpd);
         out->dpd = bs.dpd;
-        out->pdf_revr = material_pdf(sc, shp.material, bs.wo, wi, beam.k, flip_transport(beam.transport));
+        out->pdf_revr = material_pdf(sc, shp.material, bs.wo, wi, beam.k, flip_transport(beam.transport), srf.uv);
         float w = 1.f;
         if (!veq(ns, ng)) w *= shading_normals_correction_scale(beam.transport, wig, wog, wis, wos);
         out->apply_w = w;
@@ -289,12 +289,12 @@ void prim_surface_info(const prim_surface* s_, float wp[3], float ng[3], float n
 }
 void prim_surface_to_local(const prim_surface* s_, const float v[3], float out[3]) { o3(out, to_local(get<surface_t>(s_).shading, v3(v))); }
 void prim_dummy_surface(const float n[3], const float p[3], prim_surface* out) { put(out, make_dummy_surface(v3(n), v3(p))); }
-void prim_material_f(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport, float M[16]) {
-    const mueller_t m = material_f(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport);
+void prim_material_f(const void* sc, int mat, const prim_surface* at, const float wi[3], const float wo[3], float k, int transport, float M[16]) {
+    const mueller_t m = material_f(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport, get<surface_t>(at).uv);
     std::memcpy(M, m.m, sizeof(m.m));
 }
-float prim_material_pdf(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport) {
-    return material_pdf(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport);
+float prim_material_pdf(const void* sc, int mat, const prim_surface* at, const float wi[3], const float wo[3], float k, int transport) {
+    return material_pdf(S(sc), mat, v3(wi), v3(wo), k, (uint32_t)transport, get<surface_t>(at).uv);
 }
 int prim_material_is_delta_only(const void* sc, int mat, float k) { return material_is_delta_only(S(sc), mat, k) ? 1 : 0; }
 float prim_fsd_pdf(int slot, const float wo_world[3]) {

@@ -48,8 +48,8 @@ void prim_beam_transform_region(prim_beam* b, const float wp[3], float dist, con
 void prim_surface_info(const prim_surface* s, float wp[3], float ng[3], float ns[3], uint32_t* tuid, uint32_t* shape);
 void prim_surface_to_local(const prim_surface* s, const float v[3], float out[3]);
 void prim_dummy_surface(const float n[3], const float p[3], prim_surface* out);
-void prim_material_f(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport, float M[16]);
-float prim_material_pdf(const void* sc, int mat, const float wi[3], const float wo[3], float k, int transport);
+void prim_material_f(const void* sc, int mat, const prim_surface* at, const float wi[3], const float wo[3], float k, int transport, float M[16]);   /* `at`: texture coordinates of the query */
+float prim_material_pdf(const void* sc, int mat, const prim_surface* at, const float wi[3], const float wo[3], float k, int transport);
 int prim_material_is_delta_only(const void* sc, int mat, float k);
 float prim_fsd_pdf(int slot, const float wo_world[3]);
 int prim_emitter_flags(const void* sc, int ei);   /* 1 area, 2 delta direction, 4 delta position, 8 infinite */

@@ -384,3 +384,6 @@ void kat_fsd_lut_sample(const void* scene_host, int which, uint64_t seed, uint32
 }
 
 }   // extern "C"
+
+// texture addressing (wt/scene.h: tex_wrap_coord) for tests/test_textures.py
+extern "C" int kat_tex_wrap(uint32_t mode, int c, int dim) { return wt::tex_wrap_coord(mode, c, dim); }

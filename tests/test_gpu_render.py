@@ -35,6 +35,12 @@ def _rel_l1(a, b):
     ("furnace_wall_composite", 24, 8, {}),
     ("furnace_wall_composite_gap", 24, 8, {}),
     ("furnace_wall_mask", 24, 8, {}),
+    # textures on the device: checkerboard reflectance under a uv transform, a bilinear bitmap, a textured mask, a normal map
+    # (tests/test_textures.py has the semantics)
+    ("tex_checker", 32, 8, {}),
+    ("tex_bilinear_ramp", 32, 8, {}),
+    ("tex_mask", 32, 8, {}),
+    ("tex_normal_tilt", 32, 8, {}),
 ])
 def test_image_parity_small(built, name, res, spp, kw):
     """Same Philox streams on both sides => the images agree sample for sample up to fp contraction / libm ulps.

@@ -596,6 +596,55 @@ float scene_builder_t::spectrum_eval(int id, float k) const {
     return spectrum_f(tmp, id, k);
 }
 
+static texture_t texture_base(int32_t type) {
+    texture_t t{};
+    t.type = type;
+    t.rgba[3] = 1.f;
+    t.col1 = t.col2 = -1;
+    t.m[0] = t.m[3] = 1.f;
+    t.scale = 1.f;
+    t.uwrap = t.vwrap = WRAP_REPEAT;
+    return t;
+}
+int scene_builder_t::add_texture_constant(float r, float g, float b, float a) {
+    texture_t t = texture_base(TEX_CONSTANT);
+    t.rgba[0] = r;
+    t.rgba[1] = g;
+    t.rgba[2] = b;
+    t.rgba[3] = a;
+    textures_.push_back(t);
+    return (int)textures_.size() - 1;
+}
+int scene_builder_t::add_texture_checkerboard(int tex1, int tex2) {
+    if (tex1 < 0 || tex2 < 0 || tex1 >= (int)textures_.size() || tex2 >= (int)textures_.size()) throw std::runtime_error("checkerboard: unknown nested texture");
+    texture_t t = texture_base(TEX_CHECKERBOARD);
+    t.col1 = tex1;
+    t.col2 = tex2;
+    textures_.push_back(t);
+    return (int)textures_.size() - 1;
+}
+int scene_builder_t::add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, bool bilinear, uint32_t uwrap, uint32_t vwrap) {
+    if (!width || !height || channels < 1 || channels > 4 || !texels) throw std::runtime_error("bitmap texture: width, height > 0 and 1..4 channels expected");
+    texture_t t = texture_base(TEX_BITMAP);
+    t.width = width;
+    t.height = height;
+    t.channels = channels;
+    t.offset = (uint32_t)texture_data_.size();
+    t.bilinear = bilinear ? 1u : 0u;
+    t.uwrap = uwrap;
+    t.vwrap = vwrap;
+    texture_data_.insert(texture_data_.end(), texels, texels + (size_t)width * height * channels);
+    textures_.push_back(t);
+    return (int)textures_.size() - 1;
+}
+void scene_builder_t::texture_set_transform(int tex, const float M[4], const float tr[2]) {
+    texture_t& t = textures_.at(tex);
+    for (int i = 0; i < 4; ++i) t.m[i] = M[i];
+    t.t[0] = tr[0];
+    t.t[1] = tr[1];
+}
+void scene_builder_t::texture_set_scale(int tex, float scale) { textures_.at(tex).scale = scale; }
+
 int scene_builder_t::add_material(const material_t& m) {
     materials_.push_back(m);
     return (int)materials_.size() - 1;
@@ -1452,6 +1501,9 @@ const scene_t& scene_builder_t::finalize() {
     sc_.spectra = spectra_.data();
     sc_.n_spectra = (uint32_t)spectra_.size();
     sc_.spectra_data = spectra_data_.data();
+    sc_.textures = textures_.data();
+    sc_.n_textures = (uint32_t)textures_.size();
+    sc_.texture_data = texture_data_.data();
     sc_.emitters = emitters_.data();
     sc_.n_emitters = (uint32_t)emitters_.size();
     sc_.emitter_cdf = emitter_cdf_.data();

@@ -72,6 +72,14 @@ public:
     float spectrum_eval(int id, float k) const;
 
     int add_material(const wt::material_t& m);
+    // textures (include/wt/texture/*.hpp); ids index scene_t::textures (materials store id + 1)
+    int add_texture_constant(float r, float g, float b, float a = 1.f);
+    int add_texture_checkerboard(int tex1, int tex2);
+    // float texels, rows from the image's top, 1..4 channels; wrap: wt::WRAP_*
+    int add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, bool bilinear, uint32_t uwrap, uint32_t vwrap);
+    void texture_set_transform(int tex, const float M[4], const float t[2]);   // uv' = M uv + t (texture/transform.hpp)
+    void texture_set_scale(int tex, float scale);                               // texture/scale.hpp with a constant scale
+    wt::material_t& material(int id) { return materials_[id]; }
     int add_shape(const mesh_t& mesh, const xform_t& to_world, int material, bool face_normals = false);
     int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);
     int add_emitter_area(int shape, int spectrum, float scale, float pse_scale);
@@ -130,6 +138,8 @@ private:
     std::vector<wt::material_t> materials_;
     std::vector<wt::spectrum_t> spectra_;
     std::vector<float> spectra_data_;
+    std::vector<wt::texture_t> textures_;
+    std::vector<float> texture_data_;
     std::vector<wt::emitter_t> emitters_;
     std::vector<float> emitter_cdf_;
     std::vector<wt::kdist_t> kdists_;
@@ -168,6 +178,7 @@ bool build_named_scene(const std::string& name, const scene_params_t& p, scene_b
 // material constructors / parameter overrides shared by the bundled scenes and the XML reader (host/scenes.cpp)
 wt::material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided);
 wt::material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, bool two_sided, float scale);
+wt::material_t mat_mask(int nested, float alpha, bool two_sided);
 void apply_opts(const scene_params_t& p, wt::integrator_opts_t& o);
 // minimal reader of the reference's XML scene format (host/xml_scene.cpp): `defines` = "name=value" (-D of the reference's CLI)
 void build_scene_from_xml(const std::string& path, const std::vector<std::string>& defines, const scene_params_t& p, scene_builder_t& b);

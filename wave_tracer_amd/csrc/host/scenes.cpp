@@ -447,6 +447,78 @@ static void build_sunlit(const scene_params_t& p, scene_builder_t& b) {
     b.add_emitter_directional({std::sin(deg(30)), 0, std::cos(deg(30))}, b.spectrum_blackbody(5750.f, 1.f), 1e-6f, 6.794e-5f, 1.f);
 }
 
+// ---- test scenes "tex_<variant>": a sunlit ground plane (uv in [0,1]^2) seen from above — textures (include/wt/texture/*.hpp) on the
+// reflectance, the mask wrapper and the normalmap wrapper (tests/test_textures.py)
+static void build_textured(const scene_params_t& p, scene_builder_t& b, const std::string& variant) {
+    integrator_opts_t o{};
+    o.max_depth = 3;
+    o.MIS = o.RR = 1;
+    o.FSD = 0;
+    o.sensor_direct = o.emitter_direct = 1;
+    apply_opts(p, o);
+    b.set_integrator(o);
+    b.set_sensor_perspective(xform_t::lookat({0, 0, 3.0}, {0, 0, 0}, {0, 1, 0}), deg(40), p.res, p.res, 1.f, false);
+    const float E[3] = {1, 1, 1};
+    b.set_response_rgb(E);
+    mesh_t ground = mesh_rectangle({-2, -2, 0}, {4, 0, 0}, {0, 4, 0});
+    bool face_normals = true;
+    const float S4[4] = {4, 0, 0, 4}, T0[2] = {0, 0};
+    auto checker = [&](float v1, float v2) {   // 4 x 4 checks over the plane
+        const int c = b.add_texture_checkerboard(b.add_texture_constant(v1, v1, v1), b.add_texture_constant(v2, v2, v2));
+        b.texture_set_transform(c, S4, T0);
+        return c;
+    };
+    int mat;
+    if (variant == "plain") {
+        mat = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    } else if (variant == "const") {
+        mat = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+        b.material(mat).refl_tex = 1 + b.add_texture_constant(1.f, 1.f, 1.f);
+    } else if (variant == "checker") {
+        mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
+        b.material(mat).refl_tex = 1 + checker(.8f, .2f);
+    } else if (variant == "bitmap") {   // the same pattern as a 4 x 4 nearest-filtered bitmap (rows from the top: v is flipped)
+        float tx[16];
+        for (int y = 0; y < 4; ++y)
+            for (int x = 0; x < 4; ++x) {
+                const int iu = x, iv = 3 - y;   // checkerboard.hpp: equal parities of int(u'), int(v') -> the first texture
+                tx[y * 4 + x] = ((iu % 2) == (iv % 2)) ? .8f : .2f;
+            }
+        mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
+        b.material(mat).refl_tex = 1 + b.add_texture_bitmap(4, 4, 1, tx, false, WRAP_REPEAT, WRAP_REPEAT);
+    } else if (variant == "bilinear_flat") {   // bilinear filtering of equal texels, scaled by 2 (texture/scale.hpp): 0.25 * 2 = the plain 0.5
+        const float tx[6] = {.25f, .25f, .25f, .25f, .25f, .25f};
+        mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
+        const int t = b.add_texture_bitmap(3, 2, 1, tx, true, WRAP_MIRROR, WRAP_CLAMP);
+        b.texture_set_scale(t, 2.f);
+        b.material(mat).refl_tex = 1 + t;
+    } else if (variant == "bilinear_ramp") {   // 2 x 1 texels 0.2 | 0.8, clamped: a linear ramp in u between the texel centres u = .25 and .75
+        const float tx[2] = {.2f, .8f};
+        mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
+        b.material(mat).refl_tex = 1 + b.add_texture_bitmap(2, 1, 1, tx, true, WRAP_CLAMP, WRAP_CLAMP);
+    } else if (variant == "mask") {   // holes: opacity 1 / 0 in a checkerboard
+        const int inner = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, false));
+        mat = b.add_material(mat_mask(inner, 1.f, true));
+        b.material(mat).mask_tex = 1 + checker(1.f, 0.f);
+    } else if (variant == "normal_flat" || variant == "normal_tilt" || variant == "normal_tilt_flipped") {
+        const double n[3] = {variant == "normal_flat" ? 0.0 : 0.3, 0.0, 1.0};
+        const double l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        const double sg = variant == "normal_tilt_flipped" ? -1.0 : 1.0;   // stored mirrored in x, y and read back with flip = true
+        mat = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+        b.material(mat).normal_tex = 1 + b.add_texture_constant((float)((sg * n[0] / l + 1) / 2), (float)((sg * n[1] / l + 1) / 2), (float)((n[2] / l + 1) / 2));
+        b.material(mat).normal_flip = sg < 0 ? 1u : 0u;
+    } else if (variant == "tilt_mesh") {   // the tilted normal as the mesh's shading normal
+        const double l = std::sqrt(.3 * .3 + 1.0);
+        ground.normals.assign(4, dvec3{.3 / l, 0, 1 / l});
+        face_normals = false;
+        mat = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, true));
+    } else
+        throw std::runtime_error("unknown textured test scene variant " + variant);
+    b.add_shape(ground, xform_t::identity(), mat, face_normals);
+    // sun 30 degrees off the zenith towards +x
+    b.add_emitter_directional({std::sin(deg(30)), 0, std::cos(deg(30))}, b.spectrum_blackbody(5750.f, 1.f), 1e-6f, 6.794e-5f, 1.f);
+}
+
 // plt_path (backward transport) variants of the test scenes: "<scene>_path"
 static void set_path_backward(scene_builder_t& b) {
     integrator_opts_t o = b.scene().opts;
@@ -522,6 +594,8 @@ bool build_named_scene(const std::string& name, const scene_params_t& p, scene_b
         build_lens_test(p, b, name.back() - 'a');
     else if (name == "double_slits_overview")
         build_double_slits_overview(p, b);
+    else if (name.rfind("tex_", 0) == 0)
+        build_textured(p, b, name.substr(4));
     else if (name == "furnace_spm")
         build_furnace(p, b, true);
     else if (name.rfind("furnace_wall_", 0) == 0) {   // furnace_wall_<variant>: wall material variants (BSDF wrapper tests)

@@ -203,7 +203,7 @@ WT_HD float vertex_pdf(const scene_t& sc, const fsd_pool_t& pool, const vertex_t
     float pdf = 0.f;
     if (v.type == VT_SURFACE) {
         const vec3 wi = to_local(v.surf.shading, wiworld), wo = to_local(v.surf.shading, woworld);
-        pdf = material_pdf(sc, v.ref, wi, wo, v.beam.k, mode);
+        pdf = material_pdf(sc, v.ref, wi, wo, v.beam.k, mode, v.surf.uv);
     } else if (v.type == VT_FSD) {
         const fsd_aperture_t ap = pool.hdr[v.fsd_slot];
         pdf = fsd_pdf(ap, fsd_pool_edges(pool, v.fsd_slot), to_local(ap.frame, woworld));
@@ -229,7 +229,7 @@ WT_HD bool vertex_interact(const scene_t& sc, const fsd_pool_t& pool, const vert
         const float wig = dot(wiworld, ng), wog = dot(woworld, ng);
         const float wis = wi.z, wos = wo.z;
         if (wig * wis <= 0.f || wog * wos <= 0.f) return false;
-        mueller_t M = material_f(sc, v.ref, wi, wo, k, v.transport);
+        mueller_t M = material_f(sc, v.ref, wi, wo, k, v.transport, v.surf.uv);
         float scale = 1.f / fabsf(wos);
         if (!veq(ns, ng)) scale *= shading_normals_correction_scale(v.transport, wig, wog, wis, wos);
         M = M * scale;
@@ -621,7 +621,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
         ok = wig * wis > 0.f;
         bsdf_sample_t bs;
         if (ok) {
-            bs = material_sample(sc, shp.material, wi, k, transport, smp);
+            bs = material_sample(sc, shp.material, wi, k, transport, smp, srf.uv);
             ok = bs.valid && bs.dpd != 0.f;
         }
         if (ok) {
@@ -632,7 +632,7 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
             if (ctr) ctr->surface_interactions++;
             ok = wog * wos > 0.f;
             if (ok) {
-                const float pdf_revr = material_pdf(sc, shp.material, wo, wi, k, flip_transport(transport));
+                const float pdf_revr = material_pdf(sc, shp.material, wo, wi, k, flip_transport(transport), srf.uv);
                 vertex_t v;
                 v.type = VT_SURFACE;
                 v.transport = transport;

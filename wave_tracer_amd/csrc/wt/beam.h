@@ -61,6 +61,17 @@ WT_HD surface_t make_surface(const scene_t& sc, uint32_t tuid, vec3 geo_n, vec2 
     const vec3 ns = normalize(sh.n0 * bary.x + sh.n1 * bary.y + sh.n2 * bz);
     s.geo = build_shading_frame(geo_n, sh.dpdu);
     s.shading = build_shading_frame(ns, sh.dpdu);
+    if (sc.n_textures) {   // (scene-uniform: scenes without textures skip the lookups)
+        // normalmap wrapper (bsdf/normalmap.hpp:48-62): the mapped normal, given in the shading frame, replaces the shading normal
+        const material_t& m = sc.materials[sc.shapes[s.shape].material];
+        const uint32_t nt = m.normal_tex;
+        if (nt) {
+            const rgba_t c = texture_rgba(sc, (int)nt - 1, s.uv);
+            const float sg = m.normal_flip ? -1.f : 1.f;
+            const vec3 n = normalize(vec3{(c.r * 2.f - 1.f) * sg, (c.g * 2.f - 1.f) * sg, c.b * 2.f - 1.f});
+            s.shading = build_shading_frame(to_world(s.shading, n), sh.dpdu);
+        }
+    }
     return s;
 }
 // intersection_surface_t(shape, mesh_tri_idx, bary): centre at the barycentric point (intersection.cpp:74-82)

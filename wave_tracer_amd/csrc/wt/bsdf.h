@@ -199,7 +199,7 @@ struct material_wrap_t {
     bool masked;      // a mask wrapper was passed
     bool mask_two;    // ... under a two_sided wrapper: the mask sees the flipped directions
 };
-WT_HD bool material_resolve(const scene_t& sc, int mat, float k, material_t& m, material_wrap_t& wr) {
+WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, material_t& m, material_wrap_t& wr) {
     m = sc.materials[mat];
     wr.alpha = 1.f;
     wr.masked = wr.mask_two = false;
@@ -211,7 +211,7 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, material_t& m, 
         scale *= m.scale;
         int child = -1;
         if (m.type == MAT_MASK) {
-            wr.alpha *= clamp01(m.mask_alpha);
+            wr.alpha *= clamp01(m.mask_tex ? texture_f(sc, (int)m.mask_tex - 1, uv) : m.mask_alpha);   // mask.cpp:27, 50: clamp01(mask->f(tquery).x)
             wr.masked = true;
             wr.mask_two = two != 0;
             child = m.nested;
@@ -234,17 +234,18 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, material_t& m, 
 WT_HD bool material_is_delta_only(const scene_t& sc, int mat, float k) {
     material_t m;
     material_wrap_t wr;
-    if (!material_resolve(sc, mat, k, m, wr)) return true;
+    if (!material_resolve(sc, mat, k, vec2{0.f, 0.f}, m, wr)) return true;   // (is_delta_only does not depend on the mask's value)
     if (m.type == MAT_DIFFUSE) return false;
     if (m.type == MAT_DIELECTRIC) return true;
     return profile_is_delta_only(m);
 }
 
 // bsdf_t::f — includes the cosine foreshortening; only non-delta lobes
-WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport) {
+// `uv`: the surface's texture coordinates (intersection_surface_t::texture_query), used by textured reflectances and masks
+WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport, vec2 uv = vec2{0.f, 0.f}) {
     material_t m;
     material_wrap_t wr;
-    if (!material_resolve(sc, mat, k, m, wr) || wr.alpha == 0.f) return mueller_zero();
+    if (!material_resolve(sc, mat, k, uv, m, wr) || wr.alpha == 0.f) return mueller_zero();
     if (m.two_sided) {
         const float z = wi.z;
         wi = two_sided_flip(wi, z);
@@ -252,7 +253,7 @@ WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k
     }
     mueller_t M = mueller_zero();
     if (m.type == MAT_DIFFUSE) {
-        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale);
+        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_f(sc, (int)m.refl_tex - 1, uv) : 1.f));
         M = mueller_depolarizer((wi.z > 0.f && wo.z > 0.f) ? wo.z * kInvPi * refl : 0.f);
     } else if (m.type == MAT_SURFACE_SPM) {
         const bool is_scatter = !profile_is_delta_only(m);
@@ -280,10 +281,10 @@ WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k
 }
 
 WT_HD float material_pdf_leaf(const scene_t& sc, const material_t& m, vec3 wi, vec3 wo, float k, uint32_t transport);
-WT_HD float material_pdf(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport) {
+WT_HD float material_pdf(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport, vec2 uv = vec2{0.f, 0.f}) {
     material_t m;
     material_wrap_t wr;
-    if (!material_resolve(sc, mat, k, m, wr)) return 0.f;
+    if (!material_resolve(sc, mat, k, uv, m, wr)) return 0.f;
     if (wr.masked) {
         // mask.cpp:79-92: no transmission through a masked BSDF; the nested density times the probability of not taking the null lobe
         if (wr.mask_two) {
@@ -316,7 +317,7 @@ WT_HD float material_pdf_leaf(const scene_t& sc, const material_t& m, vec3 wi, v
     return (1.f - pdf_specular) * profile_pdf(m, wi, abs_wo, k) * (is_reflection ? 1.f - pdf_transmission : pdf_transmission);
 }
 
-WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, float k, uint32_t transport, sampler_t& sampler) {
+WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, float k, uint32_t transport, sampler_t& sampler, vec2 uv = vec2{0.f, 0.f}) {
     bsdf_sample_t r;
     r.valid = false;
     r.wo = {0, 0, 1};
@@ -325,7 +326,7 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
     r.M = mueller_zero();
     material_t m;
     material_wrap_t wr;
-    if (!material_resolve(sc, mat, k, m, wr)) return r;   // composite: no bin at this wavenumber
+    if (!material_resolve(sc, mat, k, uv, m, wr)) return r;   // composite: no bin at this wavenumber
     // mask.cpp:37-77 (every lobe is admitted by the integrators' queries: has_null = true): the null lobe passes the beam straight
     // through with probability 1 - alpha (always, from behind), the nested BSDF is sampled otherwise
     float not_null = 1.f;
@@ -346,7 +347,7 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
 
     if (m.type == MAT_DIFFUSE) {
         if (wi.z <= 0.f) return r;
-        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale);
+        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_f(sc, (int)m.refl_tex - 1, uv) : 1.f));
         r.wo = cosine_hemisphere(sampler_r2(sampler));
         r.dpd = cosine_hemisphere_pdf(r.wo.z);
         r.M = mueller_depolarizer(refl);

@@ -339,7 +339,7 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
                 const vec3 wi = to_local(srf.shading, wiworld), wo = to_local(srf.shading, woworld);
                 const float wig = dot(wiworld, ng), wog = dot(woworld, ng);
                 if (!(wi.z * wig <= 0.f || wo.z * wog <= 0.f)) {
-                    const mueller_t f = material_f(sc, mat, wi, wo, k, TRANSPORT_BACKWARD);
+                    const mueller_t f = material_f(sc, mat, wi, wo, k, TRANSPORT_BACKWARD, srf.uv);
                     if (mueller_mean_intensity(f) != 0.f) {
                         const path_geo_t emitter_geo = ds.has_surface ? path_geo_surface(ds.surface) : path_geo_point(ds.beam.env.o);
                         if (!path_shadow(sc, path_geo_surface(srf), emitter_geo, stack, ctr)) {
@@ -348,7 +348,7 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
                             const stokes_t sL = integrate_beams(nee_beam, ds.beam);
                             float mis = 1.f;
                             if (!pd_is_discrete(ds.dpd)) {
-                                const float pd_brdf = pd_density_or_zero(material_pdf(sc, mat, wi, wo, k, TRANSPORT_BACKWARD));
+                                const float pd_brdf = pd_density_or_zero(material_pdf(sc, mat, wi, wo, k, TRANSPORT_BACKWARD, srf.uv));
                                 const float pd_direct = ds.dpd * ds.emitter_pdf;
                                 mis = path_mis(pd_direct, pd_brdf);
                             }
@@ -421,7 +421,7 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
         const vec3 wi = to_local(srf.shading, wiworld);
         const float wig = dot(wiworld, ng), wis = wi.z;
         if (wig * wis <= 0.f) return false;
-        const bsdf_sample_t bs = material_sample(sc, mat, wi, k, transport, smp);
+        const bsdf_sample_t bs = material_sample(sc, mat, wi, k, transport, smp, srf.uv);
         w.rng_draws = smp.draws;
         if (!bs.valid || bs.dpd == 0.f) return false;
         const vec3 wo = bs.wo;

@@ -96,9 +96,32 @@ struct material_t {
     uint32_t n_bins;
     float bin_kmin[4], bin_kmax[4];   // kMaxCompositeBins (wt/bsdf.h)
     int32_t bin_child[4];
-    // mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha (constant texture: bitmaps are absent)
+    // mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha
     int32_t nested;
-    float mask_alpha;
+    float mask_alpha;       // constant mask, used when mask_tex == 0
+    // textures (include/wt/texture/*.hpp): texture index + 1, 0 = none (so that a zero-initialised record has no textures)
+    uint32_t refl_tex;      // diffuse: reflectance = clamp01(spectrum * refl_tex_scale * texture) (scale.hpp wrapping a texture)
+    uint32_t mask_tex;      // mask: opacity texture (0: the constant mask_alpha)
+    uint32_t normal_tex;    // normalmap wrapper (bsdf/normalmap.hpp:48-62), flattened onto the material it wraps
+    uint32_t normal_flip;
+};
+
+// ---- textures (include/wt/texture/texture.hpp:29-90) ------------------------------------------------------------------------------
+// A texture record is one of constant / checkerboard / bitmap, with the two generic wrappers folded in: `transform` (uv' = M uv + t,
+// texture/transform.hpp:35-44; identity when absent) applied before the lookup and `scale` by a constant (texture/scale.hpp:95-97; 1
+// when absent) applied after it.  Bitmaps are float texels (linear, 1..4 channels: luminance, luminance+alpha, RGB, RGBA), rows from the
+// image's top; luminance textures are wavelength independent (bitmap.hpp:84-99), RGB ones are only read through get_RGBA (normal maps).
+enum texture_type_e : int32_t { TEX_CONSTANT = 0, TEX_CHECKERBOARD = 1, TEX_BITMAP = 2 };
+enum texture_wrap_e : uint32_t { WRAP_BLACK = 0, WRAP_WHITE = 1, WRAP_CLAMP = 2, WRAP_REPEAT = 3, WRAP_MIRROR = 4 };
+struct texture_t {
+    int32_t type;
+    float rgba[4];        // TEX_CONSTANT
+    int32_t col1, col2;   // TEX_CHECKERBOARD: the two nested textures
+    float m[4], t[2];     // transform: uv' = (m[0] u + m[1] v + t[0], m[2] u + m[3] v + t[1])
+    float scale;
+    uint32_t width, height, channels, offset;   // TEX_BITMAP: texel (x, y) channel c = texture_data[offset + (y * width + x) * channels + c]
+    uint32_t bilinear;    // 0: nearest, 1: bilinear
+    uint32_t uwrap, vwrap;
 };
 
 // ---- emitters ------------------------------------------------------------------------------------
@@ -204,6 +227,9 @@ struct scene_t {
     const spectrum_t* spectra;
     uint32_t n_spectra;
     const float* spectra_data;
+    const texture_t* textures;
+    uint32_t n_textures;
+    const float* texture_data;
     // emitters
     const emitter_t* emitters;
     uint32_t n_emitters;
@@ -234,5 +260,80 @@ WT_HD cplx spectrum_value(const scene_t& sc, int id, float k) {
     return r;
 }
 WT_HD float spectrum_f(const scene_t& sc, int id, float k) { return spectrum_value(sc, id, k).re; }
+
+// ---- texture evaluation ---------------------------------------------------------------------------------------------------------
+struct rgba_t {
+    float r, g, b, a;
+};
+WT_HD int tex_modulo(int a, int b) {
+    const int r = a % b;
+    return r < 0 ? r + b : r;
+}
+// bitmap/texture2d_storage.hpp:80-97 (-1: outside, constant texel)
+WT_HD int tex_wrap_coord(uint32_t wrap, int c, int dim) {
+    if (c >= 0 && c < dim) return c;
+    switch (wrap) {
+    case WRAP_CLAMP: return c < 0 ? 0 : (dim > 1 ? dim : 1) - 1;
+    case WRAP_REPEAT: return tex_modulo(c, dim);
+    case WRAP_MIRROR: {
+        const int m2 = tex_modulo(c, 2 * dim);
+        return m2 >= dim ? 2 * dim - 1 - m2 : m2;
+    }
+    default: return -1;
+    }
+}
+// texture2d.hpp:233-268
+WT_HD rgba_t tex_texel(const scene_t& sc, const texture_t& t, int x, int y) {
+    x = tex_wrap_coord(t.uwrap, x, (int)t.width);
+    y = tex_wrap_coord(t.vwrap, y, (int)t.height);
+    if (x < 0 || y < 0) {
+        const float v = (x < 0 ? t.uwrap : t.vwrap) == WRAP_BLACK ? 0.f : 1.f;
+        return {v, v, v, 1.f};
+    }
+    const float* p = sc.texture_data + t.offset + ((size_t)y * t.width + (size_t)x) * t.channels;
+    switch (t.channels) {
+    case 1: return {p[0], p[0], p[0], 1.f};
+    case 2: return {p[0], p[0], p[0], p[1]};
+    case 3: return {p[0], p[1], p[2], 1.f};
+    default: return {p[0], p[1], p[2], p[3]};
+    }
+}
+WT_HD rgba_t tex_mix(rgba_t a, rgba_t b, float f) { return {a.r + (b.r - a.r) * f, a.g + (b.g - a.g) * f, a.b + (b.b - a.b) * f, a.a + (b.a - a.a) * f}; }
+// texture2d.hpp:284-310, 356-392 (v is flipped: uv (0,0) is the image's bottom-left corner); filtered texels are clamped to be
+// non-negative (the default texel_clamp_mode)
+WT_HD rgba_t tex_bitmap(const scene_t& sc, const texture_t& t, vec2 uv) {
+    uv.y = 1.f - uv.y;
+    const float u = float(t.width) * uv.x - .5f, v = float(t.height) * uv.y - .5f;
+    rgba_t r;
+    if (!t.bilinear) {
+        r = tex_texel(sc, t, (int)roundf(u), (int)roundf(v));
+    } else {
+        const float fu = floorf(u), fv = floorf(v);
+        const int iu = (int)fu, iv = (int)fv;
+        const float fx = u - fu, fy = v - fv;
+        r = tex_mix(tex_mix(tex_texel(sc, t, iu, iv), tex_texel(sc, t, iu + 1, iv), fx), tex_mix(tex_texel(sc, t, iu, iv + 1), tex_texel(sc, t, iu + 1, iv + 1), fx), fy);
+    }
+    return {fmaxf_(0.f, r.r), fmaxf_(0.f, r.g), fmaxf_(0.f, r.b), fmaxf_(0.f, r.a)};
+}
+// texture_t::get_RGBA.  Checkerboards nest (checkerboard.hpp:72-79: the parity of the integer parts of u and v picks the nested
+// texture; its uv is the same query), at most 4 levels here.
+WT_HD rgba_t texture_rgba(const scene_t& sc, int id, vec2 uv) {
+    float scale = 1.f;
+    for (int depth = 0; depth < 4; ++depth) {
+        const texture_t t = sc.textures[id];
+        uv = vec2{t.m[0] * uv.x + t.m[1] * uv.y + t.t[0], t.m[2] * uv.x + t.m[3] * uv.y + t.t[1]};
+        scale *= t.scale;
+        if (t.type == TEX_CHECKERBOARD) {
+            const int x = 2 * tex_modulo((int)uv.x, 2) - 1, y = 2 * tex_modulo((int)uv.y, 2) - 1;
+            id = x * y == 1 ? t.col1 : t.col2;
+            continue;
+        }
+        const rgba_t c = t.type == TEX_BITMAP ? tex_bitmap(sc, t, uv) : rgba_t{t.rgba[0], t.rgba[1], t.rgba[2], t.rgba[3]};
+        return {c.r * scale, c.g * scale, c.b * scale, c.a};
+    }
+    return {0.f, 0.f, 0.f, 1.f};
+}
+// texture_t::f(query).x for luminance textures
+WT_HD float texture_f(const scene_t& sc, int id, vec2 uv) { return texture_rgba(sc, id, uv).r; }
 
 }   // namespace wt

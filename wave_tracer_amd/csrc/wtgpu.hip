@@ -1229,6 +1229,7 @@ int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, 
     cnt("n_materials", x.n_materials, y.n_materials);
     cnt("n_spectra", x.n_spectra, y.n_spectra);
     cnt("n_emitters", x.n_emitters, y.n_emitters);
+    cnt("n_textures", x.n_textures, y.n_textures);
     cnt("lut.n_theta", x.lut.n_theta, y.lut.n_theta);
     cnt("lut.m", x.lut.m, y.lut.m);
     arr("sensor", &x.sensor, &y.sensor, sizeof(sensor_t), sizeof(sensor_t));
@@ -1244,6 +1245,7 @@ int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, 
     arr("shapes", x.shapes, y.shapes, sizeof(shape_t) * x.n_shapes, sizeof(shape_t));
     arr("materials", x.materials, y.materials, sizeof(material_t) * x.n_materials, sizeof(material_t));
     arr("spectra", x.spectra, y.spectra, sizeof(spectrum_t) * x.n_spectra, sizeof(spectrum_t));
+    arr("textures", x.textures, y.textures, sizeof(texture_t) * x.n_textures, sizeof(texture_t));
     arr("emitters", x.emitters, y.emitters, sizeof(emitter_t) * x.n_emitters, sizeof(emitter_t));
     arr("emitter_cdf", x.emitter_cdf, y.emitter_cdf, sizeof(float) * (x.n_emitters + 1), sizeof(float));
     if (diff.empty()) {
@@ -1379,6 +1381,11 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     for (uint32_t i = 0; i < h.n_spectra; ++i)
         if (h.spectra[i].type == SPEC_TABLE) spec_words = std::max(spec_words, (size_t)h.spectra[i].offset + (size_t)h.spectra[i].count * (h.spectra[i].is_complex ? 2 : 1));
     UP(spectra_data, spec_words)
+    UP(textures, h.n_textures)
+    size_t tex_words = 0;
+    for (uint32_t i = 0; i < h.n_textures; ++i)
+        if (h.textures[i].type == TEX_BITMAP) tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width * h.textures[i].height * h.textures[i].channels);
+    UP(texture_data, tex_words)
     UP(emitters, h.n_emitters)
     UP(emitter_cdf, h.n_emitters + 1)
     UP(kdists, h.n_emitters)
