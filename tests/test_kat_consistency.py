@@ -34,7 +34,10 @@ def p(a):
 K = 2 * math.pi / 5.5e-4
 
 
-@pytest.mark.parametrize("scene,kw,mats", [("furnace_spm", {}, [0, 2, 3, 4]), ("cornell_box", {"mesh_detail": 0, "lut": (32, 32)}, [0, 1, 2])])
+@pytest.mark.parametrize("scene,kw,mats", [("furnace_spm", {}, [0, 2, 3, 4]), ("cornell_box", {"mesh_detail": 0, "lut": (32, 32)}, [0, 1, 2]),
+                                           # the dispatching wrappers: a two-bin composite (material 2; queried at its bin boundary), a
+                                           # two-sided mask of opacity 0.6 over a diffuse BSDF (material 1): nested density x alpha
+                                           ("furnace_wall_composite", {}, [2]), ("furnace_wall_mask", {}, [1])])
 @pytest.mark.parametrize("transport", [0, 1])
 def test_bsdf_sampled_density_equals_evaluated_density(lib, scene, kw, mats, transport):
     """Diffuse BSDFs: sampled density == evaluated density and weight == f/pdf, exactly.  Rough conductors (surface_spm without
@@ -77,7 +80,7 @@ def test_bsdf_sampled_density_equals_evaluated_density(lib, scene, kw, mats, tra
                 checked += int(cont.sum())
                 if eta is None:
                     assert np.allclose(o[cont, 2], o[cont, 3], rtol=1e-4, atol=1e-9)   # Lambertian: weight * pdf == f
-    assert checked > 1000
+    assert checked > (1000 if len(mats) > 1 else 300)
 
 
 def test_sensor_and_emitter_sampled_densities_equal_evaluated_densities(lib):

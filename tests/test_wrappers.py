@@ -72,3 +72,31 @@ def test_mask_scales_the_nested_bsdf_and_passes_the_rest_through(built):
     assert diff < 2.5 * noise
     plain, _ = _render("furnace_wall_grey", spp=64)
     assert abs(m.mean() / plain.mean() - 1) > 0.02                # and it is not the 0.5 box
+
+
+def test_composite_bins_are_left_inclusive_in_wavenumber(built):
+    """composite.hpp:33-36: ranges are left-inclusive in WAVENUMBER, i.e. a wavelength bin "300nm .. 550nm" is k in [2 pi / 550 nm,
+    2 pi / 300 nm): exactly at 550 nm the short-wavelength bin (albedo 0.8) answers, one ulp below in k the long-wavelength one (0.2);
+    outside 300 .. 800 nm no BSDF (no sample)."""
+    import ctypes as C
+    import math
+    from oracle_util import load_oracle
+    from wave_tracer_amd import Scene
+    lib = load_oracle()
+    F = C.c_float
+    lib.kat_material_sample_consistency.argtypes = [C.c_void_p, C.c_int, C.c_void_p, F, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
+    sc = Scene("furnace_wall_composite", res=8)
+    h = C.c_void_p(sc.host_desc())
+    wi = np.ascontiguousarray([0.3, 0.2, 0.9], np.float32)
+    wi /= np.linalg.norm(wi)
+
+    def albedo(k):
+        o = np.zeros((8, 5), np.float32)
+        lib.kat_material_sample_consistency(h, 2, wi.ctypes.data_as(C.c_void_p), F(k), 0, 3, 8, o.ctypes.data_as(C.c_void_p))
+        return o[:, 2] / o[:, 0] if (o[:, 0] > 0).all() else None     # (weight x density) / density: a Lambertian sample's weight is its reflectance; None: no sample
+
+    kb = np.float32(2 * math.pi / 550e-6)
+    assert np.allclose(albedo(float(kb)), 0.8)
+    assert np.allclose(albedo(float(np.nextafter(kb, np.float32(0)))), 0.2)
+    assert np.allclose(albedo(2 * math.pi / 400e-6), 0.8) and np.allclose(albedo(2 * math.pi / 700e-6), 0.2)
+    assert albedo(2 * math.pi / 900e-6) is None and albedo(2 * math.pi / 250e-6) is None
