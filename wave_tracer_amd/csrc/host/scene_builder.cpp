@@ -959,6 +959,11 @@ void scene_builder_t::build_bvh() {
     const float C_INT = 1.f, C_TRAV = 1.f;   // relative costs of the binary builder
     const uint32_t MAX_LEAF = 4;
     constexpr int BINS = 32;
+    // knobs (read when a scene is baked): ranges of at most this many triangles become leaves without a SAH test, and how binary
+    // subtrees are gathered into 8-wide nodes (see below)
+    // (measured on the 283 K-triangle workload, ms per pass: 3 binary levels per node, leaves <= 2: 202.0; SAH-optimal grouping: 199; with
+    // ranges of <= 4 triangles kept as leaves: 190.0 — `k_trace_heavy` 205 -> 189 ms, `k_trace` 185 -> 173 ms stream-summed)
+    const uint32_t force_leaf = getenv("WTGPU_BVH_FORCE_LEAF") ? (uint32_t)std::max(1, atoi(getenv("WTGPU_BVH_FORCE_LEAF"))) : 4u;
     std::function<int(uint32_t, uint32_t, uint32_t)> build = [&](uint32_t first, uint32_t count, uint32_t depth) -> int {
         const int id = (int)bn.size();
         bn.emplace_back();
@@ -972,7 +977,7 @@ void scene_builder_t::build_bvh() {
             cb.grow(vec3{cen[order[i]][0], cen[order[i]][1], cen[order[i]][2]});
         }
         bvh_max_depth_ = std::max(bvh_max_depth_, depth);
-        if (count <= 2) {
+        if (count <= std::min(force_leaf, 7u)) {
             bn[id].leaf = true;
             return id;
         }
@@ -1126,14 +1131,114 @@ void scene_builder_t::build_bvh() {
         extract(bn[n].left, depth - 1, out);
         extract(bn[n].right, depth - 1, out);
     };
+    // ---- which binary subtrees become the children of an 8-wide node.
+    // collapse mode 0: three binary levels per node (src/ads/bvh8w_constructor.cpp:27-103): 4.5 of the 8 slots used on average in the
+    //   283 K-triangle scene; mode 1: greedy (open the inner child with the largest box until 8); mode 2 (default): the SAH-optimal
+    //   grouping by dynamic programming (Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on GPUs through compressed
+    //   wide BVHs", §3.1): C(n, j) = cheapest way to cover the subtree of n with at most j roots,
+    //       C(n, 1) = min( leaf: A(n) P(n) c_prim  [P(n) <= max leaf],  inner: A(n) c_node + D(n, 8) ),
+    //       D(n, j) = min_k C(left, k) + C(right, j - k),        C(n, j >= 2) = min( C(n, 1), D(n, j) ),
+    //   which also decides where small subtrees are better kept as ONE leaf of up to `wide_max_leaf` triangles (their triangles are
+    //   contiguous).  The reference itself notes "bvh8w: create better trees" as a TODO; the tree only changes how fast a query is
+    //   answered, never the answer (same triangles, same order).
+    const int collapse_mode = getenv("WTGPU_BVH_COLLAPSE") ? atoi(getenv("WTGPU_BVH_COLLAPSE")) : 2;
+    const uint32_t wide_max_leaf = getenv("WTGPU_BVH_MAX_LEAF") ? (uint32_t)std::min(7, std::max(1, atoi(getenv("WTGPU_BVH_MAX_LEAF")))) : 4u;
+    const float c_node = 1.f, c_prim = getenv("WTGPU_BVH_CPRIM") ? (float)atof(getenv("WTGPU_BVH_CPRIM")) : .3f;
+    struct dp_t {
+        float c[9];        // c[j], j = 1..8
+        uint8_t k[9];      // k[j]: 0 = one root (see `as_leaf`), else the left share of D(n, j)
+        uint8_t as_leaf;   // C(n, 1) is the leaf alternative
+    };
+    std::vector<dp_t> dp;
+    if (collapse_mode == 2) {
+        dp.resize(bn.size());
+        std::function<void(int)> solve = [&](int n) {
+            dp_t& d = dp[n];
+            const float A = bn[n].box.area();
+            if (bn[n].leaf) {
+                for (int j = 1; j <= 8; ++j) {
+                    d.c[j] = A * float(bn[n].count) * c_prim;
+                    d.k[j] = 0;
+                }
+                d.as_leaf = 1;
+                return;
+            }
+            const int l = bn[n].left, r = bn[n].right;
+            solve(l);
+            solve(r);
+            float D[9];
+            uint8_t K[9];
+            for (int j = 2; j <= 8; ++j) {
+                D[j] = WT_INF;
+                K[j] = 1;
+                for (int k = 1; k < j; ++k) {
+                    const float v = dp[l].c[k] + dp[r].c[j - k];
+                    if (v < D[j]) {
+                        D[j] = v;
+                        K[j] = (uint8_t)k;
+                    }
+                }
+            }
+            const float inner = A * c_node + D[8];
+            const float leafc = bn[n].count <= wide_max_leaf ? A * float(bn[n].count) * c_prim : WT_INF;
+            d.as_leaf = leafc <= inner ? 1 : 0;
+            d.c[1] = d.as_leaf ? leafc : inner;
+            d.k[1] = 0;
+            for (int j = 2; j <= 8; ++j) {
+                if (D[j] < d.c[1]) {
+                    d.c[j] = D[j];
+                    d.k[j] = K[j];
+                } else {
+                    d.c[j] = d.c[1];
+                    d.k[j] = 0;
+                }
+            }
+            // the children of n, should n become an inner 8-wide node (the root always does)
+            d.k[0] = K[8];
+        };
+        solve(root);
+    }
+    // child list of the wide node rooted at binary node n: (binary node, is a leaf of the wide tree)
+    std::function<void(int, int, std::vector<std::pair<int, bool>>&)> gather = [&](int m, int j, std::vector<std::pair<int, bool>>& out) {
+        const dp_t& d = dp[m];
+        if (bn[m].leaf || d.k[j] == 0) {
+            out.push_back({m, bn[m].leaf || d.as_leaf != 0});
+            return;
+        }
+        gather(bn[m].left, d.k[j], out);
+        gather(bn[m].right, j - d.k[j], out);
+    };
     std::function<uint32_t(int)> emit = [&](int bnode) -> uint32_t {
         const uint32_t idx = (uint32_t)nodes_.size();
         nodes_.emplace_back();
-        std::vector<int> ch;
+        std::vector<std::pair<int, bool>> chl;
         if (bn[bnode].leaf)
-            ch.push_back(bnode);
-        else
-            extract(bnode, 3, ch);
+            chl.push_back({bnode, true});
+        else if (collapse_mode == 2) {
+            gather(bn[bnode].left, dp[bnode].k[0], chl);
+            gather(bn[bnode].right, 8 - dp[bnode].k[0], chl);
+        } else {
+            std::vector<int> ch;
+            if (collapse_mode == 0)
+                extract(bnode, 3, ch);
+            else {
+                ch = {bn[bnode].left, bn[bnode].right};
+                while (ch.size() < 8) {
+                    int best = -1;
+                    float best_area = -1.f;
+                    for (size_t i = 0; i < ch.size(); ++i)
+                        if (!bn[ch[i]].leaf && bn[ch[i]].box.area() > best_area) {
+                            best_area = bn[ch[i]].box.area();
+                            best = (int)i;
+                        }
+                    if (best < 0) break;
+                    const int n = ch[best];
+                    ch[best] = bn[n].left;                      // keeps the left-to-right (triangle) order of the children
+                    ch.insert(ch.begin() + best + 1, bn[n].right);
+                }
+            }
+            for (int c : ch) chl.push_back({c, bn[c].leaf});
+        }
         bvh8_node_t nd{};
         nd.tris_start = bn[bnode].first;
         nd.tris_count = bn[bnode].count;
@@ -1143,20 +1248,20 @@ void scene_builder_t::build_bvh() {
             nd.maxx[i] = nd.maxy[i] = nd.maxz[i] = -WT_INF;
         }
         std::vector<std::pair<int, int>> todo;
-        for (size_t c = 0; c < ch.size(); ++c) {
-            const bnode_t& b = bn[ch[c]];
+        for (size_t c = 0; c < chl.size(); ++c) {
+            const bnode_t& b = bn[chl[c].first];
             nd.minx[c] = b.box.mn[0];
             nd.miny[c] = b.box.mn[1];
             nd.minz[c] = b.box.mn[2];
             nd.maxx[c] = b.box.mx[0];
             nd.maxy[c] = b.box.mx[1];
             nd.maxz[c] = b.box.mx[2];
-            if (b.leaf) {
+            if (chl[c].second) {
                 leaves_.push_back(bvh8_leaf_t{b.first, b.count});
                 if (b.count == 0 || b.count > 7 || b.first >= (1u << 28)) throw std::runtime_error("BVH leaf does not fit the by-value child reference");
                 nd.child[c] = -(int32_t)((b.first << 3) | b.count);   // leaf named by value (wt/scene.h)
             } else
-                todo.push_back({(int)c, ch[c]});
+                todo.push_back({(int)c, chl[c].first});
         }
         nodes_[idx] = nd;
         for (auto& t : todo) {
