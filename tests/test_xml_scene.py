@@ -104,7 +104,7 @@ def test_reader_reports_errors(built, tmp_path):
     with pytest.raises(WtgpuError, match="broken.xml:3"):
         Scene.from_xml(str(broken))
     sphere = tmp_path / "sphere.xml"
-    sphere.write_text(open(OWN).read().replace('<include path="parts/slit_geometry.xml"/>', '<shape type="sphere"><ref id="metal"/></shape>'))
+    sphere.write_text(open(OWN).read().replace('<include path="parts/slit_geometry.xml"/>', '<shape type="torus"><ref id="metal"/></shape>'))
     with pytest.raises(WtgpuError, match="not supported by the minimal reader"):
         Scene.from_xml(str(sphere))
     loop = tmp_path / "loop.xml"
@@ -116,3 +116,70 @@ def test_reader_reports_errors(built, tmp_path):
     nodir.write_text("<scene><integrator type='plt_path'/></scene>")
     with pytest.raises(WtgpuError, match="direction"):
         Scene.from_xml(str(nodir))
+
+
+OBJ = os.path.join(HERE, "data", "xml", "objects.xml")
+
+
+def _write_ply(path, fmt):
+    """A unit tetrahedron with per-vertex normals and uvs, plus an extra element and an extra face property the reader must skip."""
+    import struct
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    n = np.array([[-1, -1, -1], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    uv = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], np.float32)
+    f = [(0, 2, 1), (0, 1, 3), (0, 3, 2), (1, 2, 3)]
+    hdr = ("ply\nformat %s 1.0\ncomment generated by tests/test_xml_scene.py\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+           "property float nx\nproperty float ny\nproperty float nz\nproperty float s\nproperty float t\n"
+           "element face 4\nproperty list uchar int vertex_indices\nproperty uchar flags\nelement extra 1\nproperty double w\nend_header\n") % fmt
+    with open(path, "wb") as fh:
+        fh.write(hdr.encode())
+        if fmt == "ascii":
+            for i in range(4):
+                fh.write((" ".join(f"{x:g}" for x in (*v[i], *n[i], *uv[i])) + "\n").encode())
+            for t in f:
+                fh.write(("3 %d %d %d 7\n" % t).encode())
+            fh.write(b"3.5\n")
+        else:
+            e = "<" if fmt == "binary_little_endian" else ">"
+            for i in range(4):
+                fh.write(struct.pack(e + "8f", *v[i], *n[i], *uv[i]))
+            for t in f:
+                fh.write(struct.pack(e + "B3iB", 3, *t, 7))
+            fh.write(struct.pack(e + "d", 3.5))
+
+
+def test_object_scene_shapes_transforms_and_materials(built, tmp_path):
+    from wave_tracer_amd import Scene
+    s = Scene.from_xml(OBJ, lut=(32, 32))
+    # rectangle 2 + sphere (icosphere, tessellation 12 -> 2 subdivisions: 320) + cylinder 8 -> 16 + prism 8 + lens + cube 12
+    assert s.info.n_shapes == 6 and s.info.n_emitters == 1 and s.info.max_depth == 6
+    assert s.info.n_materials == 3 + 4          # three named (matte, floor, mirror) + four nested in the enabled shapes
+    v, w, l, c = oracle_render(s, 0, 4, 7)
+    assert np.isfinite(v).all() and v.sum() > 0 and c["surface_interactions"] > 0
+    # the three PLY encodings give the same scene, and the mesh is where its transform puts it
+    scenes = []
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        p = tmp_path / (fmt + ".ply")
+        _write_ply(str(p), fmt)
+        scenes.append(Scene.from_xml(OBJ, defines={"mesh": str(p), "with_mesh": "true"}, lut=(32, 32)))
+        assert scenes[-1].info.n_shapes == 7 and scenes[-1].info.n_tris == s.info.n_tris + 4
+    assert scenes[0].first_difference(scenes[1]) == "" and scenes[0].first_difference(scenes[2]) == ""
+    # relative paths resolve against the scene file's directory
+    from wave_tracer_amd.api import WtgpuError
+    with pytest.raises(WtgpuError, match="cannot open .*tests/data/xml/none.ply"):
+        Scene.from_xml(OBJ, defines={"with_mesh": "true"})
+
+
+def test_ply_reader_rejects_what_the_reference_rejects(built, tmp_path):
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    quad = tmp_path / "quad.ply"
+    quad.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                    "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    with pytest.raises(WtgpuError, match="triangulation not supported"):
+        Scene.from_xml(OBJ, defines={"mesh": str(quad), "with_mesh": "true"})
+    bad = tmp_path / "bad.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nelement face 1\n"
+                   "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n3 0 1 5\n")
+    with pytest.raises(WtgpuError, match="index out of range"):
+        Scene.from_xml(OBJ, defines={"mesh": str(bad), "with_mesh": "true"})

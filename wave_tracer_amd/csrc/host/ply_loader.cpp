@@ -1,0 +1,195 @@
+// wave_tracer_amd — PLY mesh reader: what src/mesh/ply_loader.cpp:22-98 takes from a file through miniply —
+// vertex positions (x, y, z), vertex normals (nx, ny, nz) unless face normals are requested, texture coordinates (u, v | s, t |
+// texture_u, texture_v), triangle faces (vertex_indices | vertex_index; other polygons are rejected like the reference does:
+// "triangulation not supported") — from ascii, binary_little_endian and binary_big_endian files, scaled by `scale` (the shape's
+// <quantity name="scale">).  The shipped scenes' PLY files are Git-LFS assets that are absent from the checkout; this is for user scenes
+// and is tested with generated files (tests/test_ply_loader.py).
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "scene_builder.h"
+
+namespace wth {
+
+namespace {
+
+struct prop_t {
+    std::string name;
+    int type = 0;        // index into kTypes
+    bool list = false;
+    int count_type = 0;
+};
+struct element_t {
+    std::string name;
+    size_t count = 0;
+    std::vector<prop_t> props;
+};
+const struct {
+    const char* n;
+    int size;
+    char kind;   // i: signed, u: unsigned, f: float
+} kTypes[] = {{"char", 1, 'i'},  {"uchar", 1, 'u'},  {"short", 2, 'i'},  {"ushort", 2, 'u'},  {"int", 4, 'i'},   {"uint", 4, 'u'},   {"float", 4, 'f'},   {"double", 8, 'f'},
+              {"int8", 1, 'i'},  {"uint8", 1, 'u'},  {"int16", 2, 'i'},  {"uint16", 2, 'u'},  {"int32", 4, 'i'}, {"uint32", 4, 'u'}, {"float32", 4, 'f'}, {"float64", 8, 'f'}};
+int type_of(const std::string& s) {
+    for (int i = 0; i < (int)(sizeof(kTypes) / sizeof(kTypes[0])); ++i)
+        if (s == kTypes[i].n) return i;
+    throw std::runtime_error("(ply loader) unknown property type " + s);
+}
+
+struct reader_t {
+    std::istream& in;
+    int format;   // 0 ascii, 1 little endian, 2 big endian
+    double scalar(int type) {
+        if (format == 0) {
+            double v;
+            if (!(in >> v)) throw std::runtime_error("(ply loader) unexpected end of data");
+            return v;
+        }
+        unsigned char b[8];
+        const int n = kTypes[type].size;
+        in.read(reinterpret_cast<char*>(b), n);
+        if (in.gcount() != n) throw std::runtime_error("(ply loader) unexpected end of data");
+        if (format == 2)
+            for (int i = 0; i < n / 2; ++i) std::swap(b[i], b[n - 1 - i]);
+        switch (kTypes[type].kind) {
+        case 'f':
+            if (n == 4) {
+                float f;
+                std::memcpy(&f, b, 4);
+                return f;
+            } else {
+                double d;
+                std::memcpy(&d, b, 8);
+                return d;
+            }
+        case 'i': {
+            int64_t v = 0;
+            std::memcpy(&v, b, n);
+            if (n < 8 && (b[n - 1] & 0x80)) v |= ~((int64_t(1) << (8 * n)) - 1);   // sign-extend (little endian after the swap)
+            return (double)v;
+        }
+        default: {
+            uint64_t v = 0;
+            std::memcpy(&v, b, n);
+            return (double)v;
+        }
+        }
+    }
+};
+
+}   // namespace
+
+mesh_t load_ply(const std::string& path, bool face_normals, double scale) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("(ply loader) cannot open " + path);
+    std::string line;
+    if (!std::getline(f, line) || line.substr(0, 3) != "ply") throw std::runtime_error("(ply loader) " + path + ": not a PLY file");
+    int format = -1;
+    std::vector<element_t> elements;
+    for (;;) {
+        if (!std::getline(f, line)) throw std::runtime_error("(ply loader) " + path + ": header without end_header");
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ls(line);
+        std::string kw;
+        ls >> kw;
+        if (kw == "end_header") break;
+        if (kw == "comment" || kw == "obj_info" || kw.empty()) continue;
+        if (kw == "format") {
+            std::string fm;
+            ls >> fm;
+            format = fm == "ascii" ? 0 : fm == "binary_little_endian" ? 1 : fm == "binary_big_endian" ? 2 : -1;
+            if (format < 0) throw std::runtime_error("(ply loader) unknown format " + fm);
+        } else if (kw == "element") {
+            element_t e;
+            ls >> e.name >> e.count;
+            elements.push_back(e);
+        } else if (kw == "property") {
+            if (elements.empty()) throw std::runtime_error("(ply loader) property before element");
+            prop_t p;
+            std::string t;
+            ls >> t;
+            if (t == "list") {
+                std::string ct, it;
+                ls >> ct >> it >> p.name;
+                p.list = true;
+                p.count_type = type_of(ct);
+                p.type = type_of(it);
+            } else {
+                p.type = type_of(t);
+                ls >> p.name;
+            }
+            elements.back().props.push_back(p);
+        } else
+            throw std::runtime_error("(ply loader) unexpected header line: " + line);
+    }
+    if (format < 0) throw std::runtime_error("(ply loader) " + path + ": no format line");
+    reader_t rd{f, format};
+    mesh_t m;
+    bool got_verts = false, got_faces = false;
+    for (const element_t& e : elements) {
+        if (e.name == "vertex") {
+            int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
+            for (int i = 0; i < (int)e.props.size(); ++i) {
+                const std::string& n = e.props[i].name;
+                if (e.props[i].list) throw std::runtime_error("(ply loader) list property in the vertex element");
+                if (n == "x") ix = i;
+                else if (n == "y") iy = i;
+                else if (n == "z") iz = i;
+                else if (n == "nx") inx = i;
+                else if (n == "ny") iny = i;
+                else if (n == "nz") inz = i;
+                else if (n == "u" || n == "s" || n == "texture_u") iu = i;
+                else if (n == "v" || n == "t" || n == "texture_v") iv = i;
+            }
+            if (ix < 0 || iy < 0 || iz < 0) throw std::runtime_error("(ply loader) vertex element without x, y, z");
+            const bool has_n = !face_normals && inx >= 0 && iny >= 0 && inz >= 0, has_uv = iu >= 0 && iv >= 0;
+            std::vector<double> row(e.props.size());
+            for (size_t r = 0; r < e.count; ++r) {
+                for (size_t i = 0; i < e.props.size(); ++i) row[i] = rd.scalar(e.props[i].type);
+                m.verts.push_back({row[ix] * scale, row[iy] * scale, row[iz] * scale});
+                if (has_n) m.normals.push_back({row[inx], row[iny], row[inz]});
+                if (has_uv) m.uvs.push_back({(float)row[iu], (float)row[iv]});
+            }
+            got_verts = true;
+        } else if (e.name == "face") {
+            for (size_t r = 0; r < e.count; ++r)
+                for (const prop_t& p : e.props) {
+                    if (!p.list) {
+                        rd.scalar(p.type);
+                        continue;
+                    }
+                    const size_t n = (size_t)rd.scalar(p.count_type);
+                    const bool indices = p.name == "vertex_indices" || p.name == "vertex_index";
+                    if (indices && n != 3) throw std::runtime_error("(ply loader) triangulation not supported");
+                    uint32_t id[3] = {0, 0, 0};
+                    for (size_t k = 0; k < n; ++k) {
+                        const double v = rd.scalar(p.type);
+                        if (indices) id[k] = (uint32_t)v;
+                    }
+                    if (indices) m.tris.push_back({id[0], id[1], id[2]});
+                }
+            got_faces = true;
+        } else {   // skip unknown elements
+            for (size_t r = 0; r < e.count; ++r)
+                for (const prop_t& p : e.props) {
+                    if (!p.list) {
+                        rd.scalar(p.type);
+                        continue;
+                    }
+                    const size_t n = (size_t)rd.scalar(p.count_type);
+                    for (size_t k = 0; k < n; ++k) rd.scalar(p.type);
+                }
+        }
+        if (got_verts && got_faces) break;
+    }
+    if (!got_verts || !got_faces) throw std::runtime_error("(ply loader) bad PLY: failed reading vertices or faces");
+    for (auto& t : m.tris)
+        for (uint32_t i : t)
+            if (i >= m.verts.size()) throw std::runtime_error("(ply loader) face index out of range");
+    return m;
+}
+
+}   // namespace wth

@@ -57,6 +57,8 @@ mesh_t mesh_cylinder(dvec3 p0, dvec3 p1, double radius, int tessellation);
 mesh_t mesh_prism(double length, double height, double angle_rad);
 // `lens` shape (src/mesh/lens.cpp): optical axis +x; R1, R2 = face curvatures in units of 1/radius (0 planar, +-1 half sphere, > 0 convex)
 mesh_t mesh_lens(dvec3 centre, double radius, double R1c, double R2c, double thickness, int tessellation);
+// PLY file (host/ply_loader.cpp; src/mesh/ply_loader.cpp:22-98): positions x `scale`, vertex normals unless face_normals, uvs, triangles
+mesh_t load_ply(const std::string& path, bool face_normals, double scale);
 
 class scene_builder_t {
 public:
@@ -179,6 +181,7 @@ bool build_named_scene(const std::string& name, const scene_params_t& p, scene_b
 wt::material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided);
 wt::material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma, bool two_sided, float scale);
 wt::material_t mat_mask(int nested, float alpha, bool two_sided);
+wt::material_t mat_dielectric(int ior_spec);
 void apply_opts(const scene_params_t& p, wt::integrator_opts_t& o);
 // minimal reader of the reference's XML scene format (host/xml_scene.cpp): `defines` = "name=value" (-D of the reference's CLI)
 void build_scene_from_xml(const std::string& path, const std::vector<std::string>& defines, const scene_params_t& p, scene_builder_t& b);

@@ -35,7 +35,7 @@ material_t mat_diffuse(int refl_spec, float tex_scale, bool two_sided) {
     m.gamma = 3.f;
     return m;
 }
-static material_t mat_dielectric(int ior_spec) {
+material_t mat_dielectric(int ior_spec) {
     material_t m{};
     m.type = MAT_DIELECTRIC;
     m.scale = 1.f;

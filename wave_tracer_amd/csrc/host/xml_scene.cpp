@@ -13,7 +13,9 @@
 //   * node vocabulary handled: integrator (plt_bdpt | plt_path + direction), sensor (virtual_plane | perspective) with film
 //     (array; response monochromatic/discrete line or RGB), emitter (spot | directional), bsdf (twosided, surface_spm with
 //     fractal/dirac profile, diffuse, composite bins), spectrum (constant, complex constant, discrete line, rgb, blackbody,
-//     composite bins), shape (rectangle) with <ref id>.
+//     composite bins, dielectric, constant scale wrapper, named IOR / emission tables), shape (rectangle, cube, sphere, cylinder,
+//     prism, lens, ply: host/ply_loader.cpp) with <ref id> or a nested <bsdf>, general to_world transforms, area emitters on shapes.
+//     Textures in scene files (bitmap decoding) are not read.
 // Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
@@ -399,6 +401,7 @@ struct loader_t {
     double line_m = 0, line_mm = 0;    // monochromatic sensor: wavelength [m], [mm]
     double band_lo = 0, band_hi = 0;   // RGB sensor: sensitivity band [m]
     std::map<std::string, int> materials;
+    std::string base_dir;   // directory of the scene file: relative asset paths resolve against it
 
     explicit loader_t(scene_builder_t& bb) : b(bb) {}
 
@@ -443,14 +446,50 @@ struct loader_t {
         const xnode_t* e = n.named("enabled");
         return !e || eval_number(e->get("value", "true")) != 0.0;
     }
+    // x= y= z= attributes or value="a, b, c" (value="s": all three); missing components take `def`
+    static dvec3 read_vec3(const xnode_t& n, dim_e dim, double def, const char* what) {
+        if (n.attr("value")) {
+            const auto p = split_list(n.get("value"));
+            if (p.size() == 1) {
+                const double v = parse_dim(p[0], dim, what);
+                return {v, v, v};
+            }
+            return parse_point(n.get("value"), dim, what);
+        }
+        auto c = [&](const char* a) { return n.attr(a) ? parse_dim(n.get(a), dim, what) : def; };
+        return {c("x"), c("y"), c("z")};
+    }
+    // src/math/transform_loader.cpp:60-143: a <lookat> (exclusive), or matrix / rotate / translate / scale applied in file order (each
+    // multiplies from the left)
     static xform_t to_world(const xnode_t& n, dvec3 default_up) {
         const xnode_t* t = n.named("to_world");
         if (!t) return xform_t::identity();
-        const xnode_t* la = t->child("lookat");
-        if (!la) throw std::runtime_error("<transform name=\"to_world\">: only <lookat> is supported");
-        const dvec3 o = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
-        const dvec3 up = la->attr("up") ? parse_point(la->get("up"), DIM_NONE, "lookat up") : default_up;
-        return xform_t::lookat(o, tg, up);
+        if (const xnode_t* la = t->child("lookat")) {
+            const dvec3 o = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
+            const dvec3 up = la->attr("up") ? parse_point(la->get("up"), DIM_NONE, "lookat up") : default_up;
+            return xform_t::lookat(o, tg, up);
+        }
+        xform_t M = xform_t::identity();
+        for (auto& op : t->kids) {
+            if (op.name == "matrix") {
+                const auto v = split_list(op.get("value"));
+                if (v.size() != 16) throw std::runtime_error("<matrix>: 16 values expected");
+                double r[16];
+                for (int i = 0; i < 16; ++i) r[i] = parse_quantity(v[i]).si();   // (the translation column carries length units)
+                M = xform_t::from_rows(r) * M;
+            } else if (op.name == "rotate") {
+                const dvec3 ax = read_vec3(op, DIM_NONE, 0.0, "rotate axis");
+                M = xform_t::rotate(ax.x, ax.y, ax.z, parse_dim(op.get("angle"), DIM_ANGLE, "rotate angle")) * M;
+            } else if (op.name == "translate") {
+                const dvec3 tr = read_vec3(op, DIM_LENGTH, 0.0, "translate");
+                M = xform_t::translate(tr.x, tr.y, tr.z) * M;
+            } else if (op.name == "scale") {
+                const dvec3 sc = read_vec3(op, DIM_NONE, 1.0, "scale");
+                M = xform_t::scale(sc.x, sc.y, sc.z) * M;
+            } else
+                throw std::runtime_error("<transform>: unsupported element <" + op.name + ">");
+        }
+        return M;
     }
     bool in_sensitivity(double lo, double hi) const {   // does [lo,hi] (metres) contain the sensor's sensitivity range?
         return mono ? (lo <= line_m && line_m <= hi) : (lo <= band_lo && band_hi <= hi);
@@ -494,6 +533,13 @@ struct loader_t {
             if (mono) return -2;   // RGB uplift is defined over 380..720 nm
             return b.spectrum_rgb((float)eval_number(c[0]), (float)eval_number(c[1]), (float)eval_number(c[2]));
         }
+        if (n.attr("material")) return b.spectrum_named(n.get("material"));   // data/ior tables baked into the library (Al, Au, Ag, Cu, SF5, SF11, BK7)
+        if (n.attr("emitter")) {
+            const std::string e = n.get("emitter");
+            if (e != "2534_CFL_Tensor_Twister") throw std::runtime_error("emission spectrum \"" + e + "\" is not among the baked tables");
+            if (mono) return -2;
+            return b.spectrum_named("CFL2534");
+        }
         if (n.attr("blackbody")) {
             if (mono) return -2;   // continuous spectrum x line sensor: see the header of this file
             return b.spectrum_blackbody((float)parse_dim(n.get("blackbody"), DIM_TEMPERATURE, "blackbody"), (float)scale);
@@ -504,9 +550,30 @@ struct loader_t {
     bool material(const xnode_t& n, bool two_sided, material_t& out) {
         const std::string type = n.get("type");
         if (type == "twosided") {
+            if (const xnode_t* r = n.child("ref")) {   // <bsdf type="twosided"><ref id=…/></bsdf>: a two-sided copy of a named BSDF
+                const auto it = materials.find(r->get("id"));
+                if (it == materials.end()) return false;
+                out = b.material(it->second);
+                out.two_sided = 1;
+                return true;
+            }
             const xnode_t* in = n.child("bsdf");
             if (!in) throw std::runtime_error("twosided bsdf without a nested <bsdf>");
             return material(*in, true, out);
+        }
+        if (type.empty() && n.attr("scale")) {   // scale wrapper (bsdf/scale.hpp) with a constant
+            const xnode_t* in = n.child("bsdf");
+            if (!in) throw std::runtime_error("scale bsdf without a nested <bsdf>");
+            if (!material(*in, two_sided, out)) return false;
+            out.scale *= (float)eval_number(n.get("scale"));
+            return true;
+        }
+        if (type == "dielectric") {
+            const xnode_t* ior = n.named("IOR");
+            if (!ior) throw std::runtime_error("dielectric bsdf: IOR expected");
+            out = mat_dielectric(spectrum(*ior));
+            out.two_sided = two_sided;
+            return true;
         }
         if (type == "composite") {
             const xnode_t* bin = pick_bin(n);
@@ -548,7 +615,8 @@ struct loader_t {
         xml_parser_t p(text, path);
         std::vector<xnode_t> top = p.top_level();
         if (top.size() != 1 || top[0].name != "scene") throw std::runtime_error(path + ": a single <scene> element expected");
-        splice(std::move(top[0].kids), dir_of(path));
+        base_dir = dir_of(path);
+        splice(std::move(top[0].kids), base_dir);
 
         // ---- integrator
         integrator_opts_t o{};
@@ -680,17 +748,80 @@ struct loader_t {
                 if (material(n, false, m)) materials[id] = b.add_material(m);
             } else if (n.name == "shape") {
                 if (!enabled(n)) continue;
-                if (n.get("type") != "rectangle") throw std::runtime_error("shape type \"" + n.get("type") + "\" is not supported by the minimal reader");
-                auto pt = [&](const char* name) {
+                auto pt = [&](const char* name, bool required = true, dvec3 def = {0, 0, 0}) {
                     const xnode_t* q = n.named(name);
-                    if (!q) throw std::runtime_error(std::string("rectangle: point ") + name + " expected");
-                    return dvec3{parse_dim(q->get("x"), DIM_LENGTH, "point x"), parse_dim(q->get("y"), DIM_LENGTH, "point y"), parse_dim(q->get("z"), DIM_LENGTH, "point z")};
+                    if (!q) {
+                        if (required) throw std::runtime_error(std::string("shape: point ") + name + " expected");
+                        return def;
+                    }
+                    return read_vec3(*q, DIM_LENGTH, 0.0, name);
                 };
-                const xnode_t* ref = n.child("ref");
-                if (!ref) throw std::runtime_error("shape without <ref id=…>");
-                const auto it = materials.find(ref->get("id"));
-                if (it == materials.end()) throw std::runtime_error("shape refers to unknown or spectrally empty material \"" + ref->get("id") + "\"");
-                b.add_shape(mesh_rectangle(pt("p"), pt("x"), pt("y")), xform_t::identity(), it->second);
+                auto len = [&](const char* name, double def) {
+                    const xnode_t* q = n.named(name);
+                    return q ? parse_dim(q->get("value"), DIM_LENGTH, name) : def;
+                };
+                auto num = [&](const char* name, double def) {
+                    const xnode_t* q = n.named(name);
+                    return q ? eval_number(q->get("value")) : def;
+                };
+                // the shape's material: a nested <bsdf> or <ref id=…>
+                int mat = -1;
+                if (const xnode_t* inl = n.child("bsdf")) {
+                    material_t m{};
+                    if (!material(*inl, false, m)) throw std::runtime_error("shape: its bsdf has no bin for the sensor's sensitivity");
+                    mat = b.add_material(m);
+                } else if (const xnode_t* ref = n.child("ref")) {
+                    const auto it = materials.find(ref->get("id"));
+                    if (it == materials.end()) throw std::runtime_error("shape refers to unknown or spectrally empty material \"" + ref->get("id") + "\"");
+                    mat = it->second;
+                } else
+                    throw std::runtime_error("(shape loader) no bsdf found");
+                // defaults: src/scene/shape.cpp:196-380
+                const std::string type = n.get("type");
+                const xform_t M = to_world(n, {0, 1, 0});
+                bool face_normals = false;
+                if (const xnode_t* fn = n.named("face_normals")) face_normals = eval_number(fn->get("value")) != 0.0;
+                mesh_t mesh;
+                if (type == "rectangle") {
+                    if (n.named("p"))
+                        mesh = mesh_rectangle(pt("p"), pt("x"), pt("y"));
+                    else
+                        mesh = mesh_rectangle_scaled(len("length", 2.0));
+                } else if (type == "cube")
+                    mesh = mesh_cube(len("length", 2.0));
+                else if (type == "sphere")
+                    mesh = mesh_sphere(pt("center", false), len("radius", 1e-3), (int)num("tessellation", 32));
+                else if (type == "cylinder")
+                    mesh = mesh_cylinder(pt("p0"), pt("p1"), len("radius", 1e-3), (int)num("tessellation", 32));
+                else if (type == "prism") {
+                    const xnode_t* a = n.named("angle");
+                    mesh = mesh_prism(len("length", 1.0), len("height", 1.0), a ? parse_dim(a->get("value"), DIM_ANGLE, "angle") : M_PI / 2);
+                } else if (type == "lens")
+                    mesh = mesh_lens(pt("center", false), len("radius", 1e-3), num("R1", 0), num("R2", 0), len("thickness", 0.0), (int)num("tessellation", 50));
+                else if (type == "ply") {
+                    const xnode_t* pth = n.child("path");
+                    if (!pth) throw std::runtime_error("ply shape: <path value=…/> expected");
+                    const std::string file = pth->get("value");
+                    mesh = load_ply(file.size() && file[0] == '/' ? file : base_dir + "/" + file, face_normals, len("scale", 1.0));
+                } else
+                    throw std::runtime_error("shape type \"" + type + "\" is not supported by the minimal reader");
+                const int shape = b.add_shape(mesh, M, mat, face_normals);
+                if (const xnode_t* em = n.child("emitter")) {   // area emitter on this shape (src/scene/shape.cpp:150-168)
+                    if (em->get("type") != "area") throw std::runtime_error("(shape loader) emitter must be an area emitter");
+                    const xnode_t* sp = em->named("radiance");
+                    if (!sp) throw std::runtime_error("area emitter: radiance expected");
+                    double scale = 1.0;
+                    if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
+                    xnode_t unscaled = *sp;
+                    unscaled.kids.clear();
+                    const int spec = spectrum(unscaled);
+                    if (spec != -2) {
+                        float pse = 1.f;
+                        if (const xnode_t* r = em->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
+                        b.add_emitter_area(shape, spec, (float)scale, pse);
+                        ++n_emitters;
+                    }
+                }
             }
         }
         if (!n_emitters) throw std::runtime_error("(scene) no emitters overlap the sensor's sensitivity");
