@@ -958,7 +958,8 @@ void scene_builder_t::build_bvh() {
     bn.reserve(2 * N);
     const float C_INT = 1.f, C_TRAV = 1.f;   // relative costs of the binary builder
     const uint32_t MAX_LEAF = 4;
-    constexpr int BINS = 32;
+    constexpr int MAX_BINS = 256;
+    const int BINS = getenv("WTGPU_BVH_BINS") ? std::min(MAX_BINS, std::max(4, atoi(getenv("WTGPU_BVH_BINS")))) : 32;
     // knobs (read when a scene is baked): ranges of at most this many triangles become leaves without a SAH test, and how binary
     // subtrees are gathered into 8-wide nodes (see below)
     // (measured on the 283 K-triangle workload, ms per pass: 3 binary levels per node, leaves <= 2: 202.0; SAH-optimal grouping: 199; with
@@ -987,9 +988,9 @@ void scene_builder_t::build_bvh() {
         for (int ax = 0; ax < 3; ++ax) {
             const float lo = cb.mn[ax], hi = cb.mx[ax];
             if (!(hi > lo)) continue;
-            aabb_t bb[BINS];
-            uint32_t bc[BINS] = {0};
-            for (auto& b : bb) b.reset();
+            aabb_t bb[MAX_BINS];
+            uint32_t bc[MAX_BINS] = {0};
+            for (int b = 0; b < BINS; ++b) bb[b].reset();
             const float sc = BINS / (hi - lo);
             for (uint32_t i = first; i < first + count; ++i) {
                 int b = (int)((cen[order[i]][ax] - lo) * sc);
@@ -997,8 +998,8 @@ void scene_builder_t::build_bvh() {
                 bb[b].grow(tb[order[i]]);
                 bc[b]++;
             }
-            float la[BINS], ra[BINS];
-            uint32_t lc[BINS], rc[BINS];
+            float la[MAX_BINS], ra[MAX_BINS];
+            uint32_t lc[MAX_BINS], rc[MAX_BINS];
             aabb_t acc;
             acc.reset();
             uint32_t c = 0;
