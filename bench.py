@@ -169,11 +169,15 @@ def main():
         kernels = {"k_trace": tsum["trace_ms"], "k_trace_heavy": tsum["trace_heavy_ms"], "k_interact": tsum["interact_ms"],
                    "k_edges+k_interact_b": tsum["interact_b_ms"], "k_flux_split+k_flux_tasks": tsum["flux_ms"], "k_interact_c": tsum["interact_c_ms"],
                    "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
+        path_mode = int(sc.info.integrator) != 0
+        if path_mode:      # plt_path scenes: the interaction bracket is k_path_interact (the later passes do not exist)
+            kernels = {("k_path_interact" if k == "k_interact" else k): v for k, v in kernels.items()}
         dom = max(kernels, key=kernels.get)
         # bytes attributed to the dominant kernel per step (one step = npix samples); the two trace kernels split the segments
         # (every segment is traced by exactly one of them), the two interaction passes split the vertices the same way: each is
         # credited with the WHOLE term (an upper bound of its algorithmic bytes, hence of `achieved`)
         share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
+                 "k_path_interact": n_seg * 2 * S_path,
                  "k_edges+k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_flux_split+k_flux_tasks": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_c": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
         # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once): `launches`
@@ -192,7 +196,8 @@ def main():
         # separate rocprofv3 --pmc runs, summary committed under profiles/), per launch like `achieved`
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            # (one PMC summary per profiled workload: the headline cornell box and the etoile plt_path stand-in)
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if args.scene != "etoile" else "r02_pmc_traffic_etoile.json")) as f:
                 pt = json.load(f)
             if dom in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
                 traffic = pt["kernels"][dom]["hbm_bytes_per_launch"]
