@@ -23,7 +23,10 @@
 namespace wt {
 
 constexpr int kCoopStack = 512;
-constexpr uint32_t kCoopLeafTris = 64;
+#ifndef WTGPU_COOP_LEAF_TRIS
+#define WTGPU_COOP_LEAF_TRIS 64
+#endif
+constexpr uint32_t kCoopLeafTris = WTGPU_COOP_LEAF_TRIS;   // subtrees of at most this many triangles are tested whole, 64 triangles per step
 constexpr uint32_t kCoopTriBuf = 64 + 8 * kCoopLeafTris;   // buffered triangle ids: < 64 pending + 8 entries x <= 64 triangles
 
 #ifndef WTGPU_COOP_FLUSH_AT
