@@ -1,7 +1,7 @@
 mkdir -p gpurun_out/ab
-for V in base W X Y base; do
+for V in base X Z; do
   if [ $V = base ]; then unset WTGPU_LIB; else export WTGPU_LIB=$PWD/wave_tracer_amd/_v/libwtgpu_$V.so; fi
-  timeout 200 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/ab/$V.json 2> gpurun_out/ab/$V.err
+  timeout 60 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/ab/$V.json 2> gpurun_out/ab/$V.err
   python - <<PY
 import json
 try:

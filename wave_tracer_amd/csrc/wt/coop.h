@@ -24,9 +24,15 @@ namespace wt {
 
 constexpr int kCoopStack = 512;
 #ifndef WTGPU_COOP_LEAF_TRIS
-#define WTGPU_COOP_LEAF_TRIS 64
+#define WTGPU_COOP_LEAF_TRIS 256
 #endif
-constexpr uint32_t kCoopLeafTris = WTGPU_COOP_LEAF_TRIS;   // subtrees of at most this many triangles are tested whole, 64 triangles per step
+// Subtrees of at most this many triangles are tested whole, 64 triangles per step, instead of being descended into (measured,
+// k_trace_heavy stream-summed per pass: 16 / 32 / 64 / 128 / 256 -> 293 / 201 / 193 / 177 / 169 ms: the wide beams this kernel serves
+// meet most of such a subtree anyway and a batch of cheap filter tests costs less than the node steps it replaces).  The region walks
+// (coop_gather) keep 64: with `edges_only` they prune by edge_mask at node level, which a larger threshold would bypass (k_edges
+// 86 -> 102 ms at 128).
+constexpr uint32_t kCoopLeafTris = WTGPU_COOP_LEAF_TRIS;
+constexpr uint32_t kCoopGatherLeafTris = 64;
 constexpr uint32_t kCoopTriBuf = 64 + 8 * kCoopLeafTris;   // buffered triangle ids: < 64 pending + 8 entries x <= 64 triangles
 
 #ifndef WTGPU_COOP_FLUSH_AT
@@ -40,6 +46,12 @@ struct coop_shared_t {
     uint32_t tri_buf[kCoopTriBuf];
     uint32_t surv[kCoopSurvCap];
     float hit_dist[64];   // cone-hit distance of every listed triangle (list capacity kMaxConeTris = 64)
+};
+// the region walks' (coop_gather, coop_split) LDS: the same with the smaller candidate buffer their leaf threshold needs
+struct coop_gather_shared_t {
+    stack_entry_t stack[kCoopStack];
+    uint32_t tri_buf[64 + 8 * 64];
+    uint32_t surv[kCoopSurvCap];
 };
 // LDS of the edge-collecting gather only (k_edges): kept out of coop_shared_t so that the traversal kernels, whose wavefronts wait on
 // memory most of the time, fit twice as many wavefronts per CU (LDS is what bounds their occupancy).
@@ -272,7 +284,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 uint32_t c = (uint32_t)__shfl((int)cnt, src, 64);
                 const uint32_t t = (uint32_t)__shfl((int)t0, src, 64);
                 if (c > kCoopLeafTris) c = kCoopLeafTris;   // cannot happen with this builder (leaves hold <= MAX_LEAF triangles)
-                if ((uint32_t)lane < c) sh.tri_buf[leaf_total + lane] = t + lane;
+                for (uint32_t q = (uint32_t)lane; q < c; q += 64u) sh.tri_buf[leaf_total + q] = t + q;
                 leaf_total += c;
             }
             __syncthreads();
@@ -339,8 +351,9 @@ struct gather_out_t {
     uint32_t n_edges, edge_overflow;
     uint32_t n_tris;   // triangles of the region (met by the cone inside the slab)
 };
+template <class SH>
 __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
-                                           const range_t& izr, vec2 sigma, bool want_front, coop_shared_t& sh, bool do_flux, bool do_edges,
+                                           const range_t& izr, vec2 sigma, bool want_front, SH& sh, bool do_flux, bool do_edges,
                                            unsigned long long* stats = nullptr, int32_t root = 1, coop_edges_t* eg = nullptr) {
     uint32_t* edges = eg ? eg->edge_ids : nullptr;   // eg: required when do_edges
     const uint32_t edge_cap = 96;
@@ -469,7 +482,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                     cp = node.child[sub];
                     // edges only: descend only into subtrees that hold classified edges (bvh8_node_t::edge_mask)
                     const bool hc = (!edges_only || ((node.edge_mask >> sub) & 1u)) && cone_child_test(node, sub, ro, rd, rinvd, sx, sy, sz, ta, ix, slab, tmin);
-                    if (ntc <= kCoopLeafTris) {
+                    if (ntc <= kCoopGatherLeafTris) {
                         t0 = nts;
                         cnt = ntc;
                         leafish = true;
@@ -491,8 +504,8 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
                 m &= m - 1;
                 uint32_t c = (uint32_t)__shfl((int)cnt, src, 64);
                 const uint32_t t = (uint32_t)__shfl((int)t0, src, 64);
-                if (c > kCoopLeafTris) c = kCoopLeafTris;
-                if ((uint32_t)lane < c) sh.tri_buf[leaf_total + lane] = t + lane;
+                if (c > kCoopGatherLeafTris) c = kCoopGatherLeafTris;
+                for (uint32_t q = (uint32_t)lane; q < c; q += 64u) sh.tri_buf[leaf_total + q] = t + q;
                 leaf_total += c;
             }
             __syncthreads();
@@ -566,8 +579,8 @@ __device__ inline void coop_edge_write(const scene_t& sc, coop_edges_t& sh, uint
 // Cuts the part of the tree that overlaps (cone ∩ slab) into subtrees of at most `max_tris` triangles and hands each to emit(ptr)
 // (ptr: child reference as in bvh8_node_t::child).  One wavefront; emit is called by ONE lane per subtree, possibly several lanes at
 // once.  Used to spread the region sums of interaction regions with 10^3..10^5 triangles over many wavefronts (k_flux_split).
-template <class Emit>
-__device__ inline void coop_split(const scene_t& sc, const cone_t& tcone, const range_t& slab, coop_shared_t& sh, uint32_t max_tris, Emit&& emit) {
+template <class SH, class Emit>
+__device__ inline void coop_split(const scene_t& sc, const cone_t& tcone, const range_t& slab, SH& sh, uint32_t max_tris, Emit&& emit) {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
     if (sc.n_nodes == 0) return;
@@ -698,7 +711,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
                 uint32_t c = (uint32_t)__shfl((int)cnt, src, 64);
                 const uint32_t t = (uint32_t)__shfl((int)t0, src, 64);
                 if (c > kCoopLeafTris) c = kCoopLeafTris;   // cannot happen with this builder (leaves hold <= MAX_LEAF triangles)
-                if ((uint32_t)lane < c) sh.tri_buf[leaf_total + lane] = t + lane;
+                for (uint32_t q = (uint32_t)lane; q < c; q += 64u) sh.tri_buf[leaf_total + q] = t + q;
                 leaf_total += c;
             }
             __syncthreads();

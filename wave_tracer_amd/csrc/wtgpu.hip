@@ -501,7 +501,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
 // a time (a wide beam over the whole scene still meets ~10^3 of them: a single lane needs milliseconds for that).
 // Sorted ids -> the walk's list slot, marker + count -> its traversal record.
 __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
-    __shared__ coop_shared_t sh;
+    __shared__ coop_gather_shared_t sh;
     __shared__ coop_edges_t eg;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(laun
 // largest one (measured: 27 ms for a 130,000-triangle region).  k_flux_split cuts the part of the tree that overlaps the region
 // into subtrees of <= kFluxTaskTris (2048; swept 128 / 512 / 2048: 247 / 216 / 208 ms per pass) triangles, k_flux_tasks sums every subtree on whichever wavefront is free (f64 atomics).
 __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
-    __shared__ coop_shared_t sh;
+    __shared__ coop_gather_shared_t sh;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_INTC_COUNT];
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     }
 }
 __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t a) {
-    __shared__ coop_shared_t sh;
+    __shared__ coop_gather_shared_t sh;
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = min(ctl[CTL_FTASK_COUNT], a.st.ftask_cap);
@@ -1062,6 +1062,7 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
 __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* cones, uint32_t n, uint32_t edge_cap, float* dist, uint32_t* flags,
                                                       uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux) {
     __shared__ coop_shared_t sh;
+    __shared__ coop_gather_shared_t gsh;
     __shared__ coop_edges_t eg;
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
@@ -1078,7 +1079,7 @@ __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* c
         const range_t izr{tr.dist, tr.dist + tr.region_depth};
         prim = tr.tuid;   // primary_from_axis (kInvalid: the axis misses the region)
         const vec2 ax = cone_axes(env, tr.dist);
-        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
+        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, gsh, false, true, nullptr, 1, &eg);
         __syncthreads();
         if (sc.n_edges <= kCoopEdgeBits) {
             ge.n_edges = coop_edge_count(sc, eg);
@@ -1086,7 +1087,7 @@ __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* c
         } else
             for (uint32_t j = threadIdx.x; j < ge.n_edges && j < edge_cap; j += 64) edges[(size_t)i * edge_cap + j] = eg.edge_ids[j];
         __syncthreads();
-        gf = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope}, tr.front_face != 0, sh, true, false);
+        gf = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope}, tr.front_face != 0, gsh, true, false);
     }
     if (threadIdx.x == 0) {
         dist[i] = tr.dist;
