@@ -183,3 +183,27 @@ def test_ply_reader_rejects_what_the_reference_rejects(built, tmp_path):
                    "property list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n3 0 1 5\n")
     with pytest.raises(WtgpuError, match="index out of range"):
         Scene.from_xml(OBJ, defines={"mesh": str(bad), "with_mesh": "true"})
+
+
+def test_obj_meshes(built, tmp_path):
+    """OBJ: one vertex per face corner, v / v/vt / v//vn / v/vt/vn and negative indices, polygons fan-triangulated, inconsistent
+    attributes rejected (src/mesh/obj_loader.cpp:62-100)."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    base = Scene.from_xml(OBJ, lut=(32, 32))
+    a = tmp_path / "a.obj"
+    a.write_text("# a quad and a triangle\no thing\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+                 "s off\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -5/1/1 -4/2/1 -1/3/1\n")
+    s = Scene.from_xml(OBJ, defines={"obj": str(a), "with_obj": "true"}, lut=(32, 32))
+    assert s.info.n_shapes == base.info.n_shapes + 1 and s.info.n_tris == base.info.n_tris + 3     # quad -> 2 triangles, + 1
+    b = tmp_path / "b.obj"
+    b.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")                                    # positions only
+    assert Scene.from_xml(OBJ, defines={"obj": str(b), "with_obj": "true"}, lut=(32, 32)).info.n_tris == base.info.n_tris + 1
+    c = tmp_path / "c.obj"
+    c.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3\n")
+    with pytest.raises(WtgpuError, match="missing normal data"):
+        Scene.from_xml(OBJ, defines={"obj": str(c), "with_obj": "true"})
+    d = tmp_path / "d.obj"
+    d.write_text("v 0 0 0\nv 1 0 0\nf 1 2 7\n")
+    with pytest.raises(WtgpuError, match="d.obj:3: f: vertex index out of range"):
+        Scene.from_xml(OBJ, defines={"obj": str(d), "with_obj": "true"})

@@ -59,6 +59,8 @@ mesh_t mesh_prism(double length, double height, double angle_rad);
 mesh_t mesh_lens(dvec3 centre, double radius, double R1c, double R2c, double thickness, int tessellation);
 // PLY file (host/ply_loader.cpp; src/mesh/ply_loader.cpp:22-98): positions x `scale`, vertex normals unless face_normals, uvs, triangles
 mesh_t load_ply(const std::string& path, bool face_normals, double scale);
+// Wavefront OBJ (host/obj_loader.cpp; src/mesh/obj_loader.cpp:26-140): one vertex per face corner, polygons fan-triangulated
+mesh_t load_obj(const std::string& path, bool face_normals, double scale);
 
 class scene_builder_t {
 public:

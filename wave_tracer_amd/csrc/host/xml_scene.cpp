@@ -14,7 +14,7 @@
 //     (array; response monochromatic/discrete line or RGB), emitter (spot | directional), bsdf (twosided, surface_spm with
 //     fractal/dirac profile, diffuse, composite bins), spectrum (constant, complex constant, discrete line, rgb, blackbody,
 //     composite bins, dielectric, constant scale wrapper, named IOR / emission tables), shape (rectangle, cube, sphere, cylinder,
-//     prism, lens, ply: host/ply_loader.cpp) with <ref id> or a nested <bsdf>, general to_world transforms, area emitters on shapes.
+//     prism, lens, ply / obj: host/ply_loader.cpp, host/obj_loader.cpp) with <ref id> or a nested <bsdf>, general to_world transforms, area emitters on shapes.
 //     Textures in scene files (bitmap decoding) are not read.
 // Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
@@ -798,11 +798,12 @@ struct loader_t {
                     mesh = mesh_prism(len("length", 1.0), len("height", 1.0), a ? parse_dim(a->get("value"), DIM_ANGLE, "angle") : M_PI / 2);
                 } else if (type == "lens")
                     mesh = mesh_lens(pt("center", false), len("radius", 1e-3), num("R1", 0), num("R2", 0), len("thickness", 0.0), (int)num("tessellation", 50));
-                else if (type == "ply") {
+                else if (type == "ply" || type == "obj") {
                     const xnode_t* pth = n.child("path");
-                    if (!pth) throw std::runtime_error("ply shape: <path value=…/> expected");
+                    if (!pth) throw std::runtime_error(type + " shape: <path value=…/> expected");
                     const std::string file = pth->get("value");
-                    mesh = load_ply(file.size() && file[0] == '/' ? file : base_dir + "/" + file, face_normals, len("scale", 1.0));
+                    const std::string full = file.size() && file[0] == '/' ? file : base_dir + "/" + file;
+                    mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0));
                 } else
                     throw std::runtime_error("shape type \"" + type + "\" is not supported by the minimal reader");
                 const int shape = b.add_shape(mesh, M, mat, face_normals);
