@@ -207,3 +207,97 @@ def test_obj_meshes(built, tmp_path):
     d.write_text("v 0 0 0\nv 1 0 0\nf 1 2 7\n")
     with pytest.raises(WtgpuError, match="d.obj:3: f: vertex index out of range"):
         Scene.from_xml(OBJ, defines={"obj": str(d), "with_obj": "true"})
+
+
+_MINI = """<scene version="0.1.0">
+  <integrator type="plt_bdpt"><integer name="max_depth" value="4"/><boolean name="FSD" value="false"/></integrator>
+  <sensor type="perspective"><quantity name="fov" value="40°"/>
+    <transform name="to_world"><lookat origin="0m,0m,1m" target="0m,0m,0m" up="0,1,0"/></transform>
+    <film type="array"><integer name="width" value="8"/><integer name="height" value="8"/><response type="RGB"/></film></sensor>
+  <emitter type="spot"><transform name="to_world"><lookat origin="0.2m,0m,1m" target="0m,0m,0m" up="0,1,0"/></transform>
+    <quantity name="beam_width" value="10°"/><quantity name="cutoff_angle" value="20°"/>
+    <spectrum name="radiant_intensity" %s/></emitter>
+  <shape type="rectangle"><quantity name="length" value="1m"/>
+    <bsdf type="twosided"><bsdf type="surface_spm"><spectrum name="IOR" material="%s"/>
+      <surface_profile type="fractal"><spectrum name="roughness" constant=".4"/></surface_profile></bsdf></bsdf></shape>
+</scene>"""
+
+
+def _ior_of_first_material(sc, wavelengths_nm):
+    import ctypes as C
+    from oracle_util import load_oracle
+    lib = load_oracle()
+    lib.kat_spectrum.restype = C.c_float
+    lib.kat_spectrum.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    lib.kat_material_ior_spec.argtypes = [C.c_void_p, C.c_int]
+    h = C.c_void_p(sc.host_desc())
+    spec = lib.kat_material_ior_spec(h, 0)
+    out = []
+    for l in wavelengths_nm:
+        im = C.c_float()
+        re = lib.kat_spectrum(h, spec, C.c_float(2 * np.pi / (l * 1e-6)), C.byref(im))
+        out.append(complex(re, im.value))
+    return np.array(out)
+
+
+def test_spectrum_database_files(built, tmp_path, monkeypatch):
+    """data/ior-style files (refractiveindex.info YAML: tabulated nk, Sellmeier "formula 2") read at run time for names that are not
+    baked into the library (src/spectrum/util/spectrum_from_db.cpp:83-140), found under $WTGPU_DATA_DIR or `data/` next to the scene."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    d = tmp_path / "data" / "ior"
+    os.makedirs(d)
+    os.makedirs(tmp_path / "data" / "emission")
+    # Sellmeier glass (BK7's published coefficients), C_i given directly (formula 2)
+    B, Cc = [1.03961212, 0.231792344, 1.01046945], [0.00600069867, 0.0200179144, 103.560653]
+    (d / "Glass.yml").write_text("# generated\nREFERENCES: \"test\"\nDATA:\n  - type: formula 2\n    wavelength_range: 0.3 2.5\n    coefficients: 0 %g %g %g %g %g %g\n"
+                                 % (B[0], Cc[0], B[1], Cc[1], B[2], Cc[2]))
+    # a tabulated metal: n + i k piecewise linear in wavelength [um]
+    rows = [(0.30, 0.3, 3.0), (0.50, 0.8, 6.0), (0.70, 1.8, 8.0), (0.90, 2.5, 8.5)]
+    (d / "Metal.yml").write_text("DATA:\n  - type: tabulated nk\n    data: |\n" + "".join("        %g %g %g\n" % r for r in rows))
+    lam = np.array([400.0, 550.0, 633.0, 700.0])
+    xml = tmp_path / "s.xml"
+    xml.write_text(_MINI % ('blackbody="5000K"', "Glass"))
+    l2 = (lam * 1e-3) ** 2
+    expect = np.sqrt(1 + sum(b * l2 / (l2 - c) for b, c in zip(B, Cc)))
+    got = _ior_of_first_material(Scene.from_xml(str(xml)), lam)
+    assert np.allclose(got.real, expect, rtol=2e-6) and np.allclose(got.imag, 0)
+    xml.write_text(_MINI % ('blackbody="5000K"', "Metal"))
+    got = _ior_of_first_material(Scene.from_xml(str(xml)), lam)
+    t = np.array(rows)
+    assert np.allclose(got.real, np.interp(lam * 1e-3, t[:, 0], t[:, 1]), rtol=1e-4) and np.allclose(got.imag, np.interp(lam * 1e-3, t[:, 0], t[:, 2]), rtol=1e-4)
+    # $WTGPU_DATA_DIR wins over the scene's own data directory; unknown names fail with the path that was tried
+    other = tmp_path / "elsewhere"
+    os.makedirs(other / "ior")
+    (other / "ior" / "Metal.yml").write_text("DATA:\n  - type: tabulated nk\n    data: |\n        0.2 2 2\n        1.0 2 2\n")
+    monkeypatch.setenv("WTGPU_DATA_DIR", str(other))
+    got = _ior_of_first_material(Scene.from_xml(str(xml)), lam)
+    assert np.allclose(got, 2 + 2j)
+    monkeypatch.delenv("WTGPU_DATA_DIR")
+    xml.write_text(_MINI % ('blackbody="5000K"', "Unobtainium"))
+    with pytest.raises(WtgpuError, match="cannot open .*data/ior/Unobtainium.yml"):
+        Scene.from_xml(str(xml))
+    # an emission table by name
+    (tmp_path / "data" / "emission" / "Lamp.yml").write_text("DATA:\n  - type: tabulated\n    data: |\n        400 0\n        550 1\n        700 0\n")
+    xml.write_text(_MINI % ('emitter="Lamp"', "Metal"))
+    s = Scene.from_xml(str(xml))
+    assert s.info.n_emitters == 1
+    v, w, l, c = oracle_render(s, 0, 4, 3)
+    assert v.sum() + l.sum() > 0
+
+
+@needs_reference
+def test_database_file_equals_the_baked_table(built, tmp_path):
+    """The reference's data/ior/Al.yml read at run time gives the spectrum that tools/bake_spectra.py baked into the library from the same
+    file (the baked header keeps 8 significant digits)."""
+    import shutil
+    from wave_tracer_amd import Scene
+    os.makedirs(tmp_path / "data" / "ior")
+    shutil.copy("/root/reference/data/ior/Al.yml", tmp_path / "data" / "ior" / "AlFromFile.yml")
+    lam = np.linspace(360, 820, 47)
+    xml = tmp_path / "s.xml"
+    xml.write_text(_MINI % ('blackbody="5000K"', "AlFromFile"))
+    a = _ior_of_first_material(Scene.from_xml(str(xml)), lam)
+    xml.write_text(_MINI % ('blackbody="5000K"', "Al"))
+    b = _ior_of_first_material(Scene.from_xml(str(xml)), lam)
+    assert np.allclose(a, b, rtol=1e-6, atol=1e-7)

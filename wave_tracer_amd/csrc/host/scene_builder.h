@@ -71,7 +71,10 @@ public:
     int spectrum_from_wavelength_table(const float* values_re, const float* values_im, int n, float lmin_nm, float lstep_nm);
     int spectrum_blackbody(float T, float scale);
     int spectrum_rgb(float r, float g, float b);   // RGB uplift (include/wt/spectrum/colourspace/RGB/RGB_to_spectral.hpp), 380..720 nm
-    int spectrum_named(const std::string& name);   // "Al","Au","SF5","SF11","BK7","Ag","Cu","CFL2534","CMF_X/Y/Z"
+    int spectrum_named(const std::string& name);
+    // spectrum database files (host/spectrum_db.cpp; src/spectrum/util/spectrum_from_db.cpp:83-140): data/ior/*.yml, data/emission/*.yml
+    int spectrum_ior_from_file(const std::string& path);
+    int spectrum_emission_from_file(const std::string& path);   // "Al","Au","SF5","SF11","BK7","Ag","Cu","CFL2534","CMF_X/Y/Z"
     // real-valued spectrum evaluation on the host (for baking)
     float spectrum_eval(int id, float k) const;
 

@@ -21,6 +21,7 @@
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
 // of a line emitter's power; a far-infrared line against an RGB sensor: zero) is not added.
 #include <cctype>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -533,12 +534,24 @@ struct loader_t {
             if (mono) return -2;   // RGB uplift is defined over 380..720 nm
             return b.spectrum_rgb((float)eval_number(c[0]), (float)eval_number(c[1]), (float)eval_number(c[2]));
         }
-        if (n.attr("material")) return b.spectrum_named(n.get("material"));   // data/ior tables baked into the library (Al, Au, Ag, Cu, SF5, SF11, BK7)
+        // named database spectra (spectrum_from_db.cpp): the tables baked into the library (Al, Au, Ag, Cu, SF5, SF11, BK7; the CFL emission
+        // spectrum), else a file <data dir>/ior/<name>.yml resp. <data dir>/emission/<name>.yml (data dir: $WTGPU_DATA_DIR, or "data" next to
+        // the scene file)
+        auto data_file = [&](const char* sub, const std::string& name) {
+            const char* env = getenv("WTGPU_DATA_DIR");
+            return (env ? std::string(env) : base_dir + "/data") + "/" + sub + "/" + name + ".yml";
+        };
+        if (n.attr("material")) {
+            const std::string m = n.get("material");
+            for (const char* baked : {"Al", "Au", "Ag", "Cu", "SF5", "SF11", "BK7"})
+                if (m == baked) return b.spectrum_named(m);
+            return b.spectrum_ior_from_file(data_file("ior", m));
+        }
         if (n.attr("emitter")) {
             const std::string e = n.get("emitter");
-            if (e != "2534_CFL_Tensor_Twister") throw std::runtime_error("emission spectrum \"" + e + "\" is not among the baked tables");
             if (mono) return -2;
-            return b.spectrum_named("CFL2534");
+            if (e == "2534_CFL_Tensor_Twister") return b.spectrum_named("CFL2534");
+            return b.spectrum_emission_from_file(data_file("emission", e));
         }
         if (n.attr("blackbody")) {
             if (mono) return -2;   // continuous spectrum x line sensor: see the header of this file
