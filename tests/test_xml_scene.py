@@ -301,3 +301,40 @@ def test_database_file_equals_the_baked_table(built, tmp_path):
     xml.write_text(_MINI % ('blackbody="5000K"', "Al"))
     b = _ior_of_first_material(Scene.from_xml(str(xml)), lam)
     assert np.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+TEX = os.path.join(HERE, "data", "xml", "textured.xml")
+
+
+def _render_dev(sc, spp=4, seed=3):
+    from wave_tracer_amd import develop
+    v, w, l, c = oracle_render(sc, 0, spp, seed)
+    return develop(sc, v, w, l, spp).astype(np.float64), c
+
+
+def test_texture_nodes_in_scene_files(built, tmp_path):
+    """<texture> elements (constant spectra as colours, checkerboard, transform, bitmap), the mask and normalmap bsdfs and the expression
+    functions (sin, cos, pi): the textured ground plane of tests/test_textures.py described in XML renders exactly like the same
+    scene built by host/scenes.cpp (same random numbers; the unused materials of the XML only shift material indices)."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.imageio import write_pfm
+    ref, cr = _render_dev(Scene("tex_checker", res=32))
+    img, ci = _render_dev(Scene.from_xml(TEX, defines={"variant": 1}))
+    assert np.array_equal(img, ref) and ci == cr
+    # the same pattern as a 4 x 4 PFM bitmap (write_pfm stores rows bottom-up; the reader returns them from the top)
+    tx = np.array([[.8 if (x % 2) == ((3 - y) % 2) else .2 for x in range(4)] for y in range(4)], np.float32)      # rows from the top
+    write_pfm(str(tmp_path / "c.pfm"), tx)
+    img, _ = _render_dev(Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(tmp_path / "c.pfm")}))
+    assert np.array_equal(img, ref)
+    ref, cr = _render_dev(Scene("tex_mask", res=32))
+    img, ci = _render_dev(Scene.from_xml(TEX, defines={"variant": 3}))
+    assert np.array_equal(img, ref) and ci == cr
+    # normal map: a 1 x 1 RGB PFM holding ((n + 1) / 2) of the tilted normal
+    n = np.array([.3, 0, 1.0]) / np.sqrt(1.09)
+    write_pfm(str(tmp_path / "n.pfm"), ((n + 1) / 2).astype(np.float32).reshape(1, 1, 3))
+    ref, _ = _render_dev(Scene("tex_normal_tilt", res=32))
+    img, _ = _render_dev(Scene.from_xml(TEX, defines={"variant": 4, "bitmap": str(tmp_path / "n.pfm")}))
+    assert np.abs(img - ref).max() <= 1e-6 * ref.max()
+    from wave_tracer_amd.api import WtgpuError
+    with pytest.raises(WtgpuError, match="PFM files only"):
+        Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(tmp_path / "missing.png")})

@@ -192,4 +192,30 @@ mesh_t load_ply(const std::string& path, bool face_normals, double scale) {
     return m;
 }
 
+
+// Portable float map: "PF" (3 channels) | "Pf" (1), width height, scale (< 0: little endian), rows bottom-up
+std::vector<float> load_pfm(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("(bitmap loader) cannot open " + path + " (PFM files only: no image decoder is available)");
+    std::string magic;
+    double scale = 0;
+    f >> magic >> width >> height >> scale;
+    if ((magic != "PF" && magic != "Pf") || !width || !height || scale == 0) throw std::runtime_error("(bitmap loader) " + path + ": not a PFM file");
+    f.get();   // the single whitespace after the header
+    channels = magic == "PF" ? 3u : 1u;
+    const size_t n = (size_t)width * height * channels;
+    std::vector<float> raw(n), out(n);
+    f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)(n * 4));
+    if ((size_t)f.gcount() != n * 4) throw std::runtime_error("(bitmap loader) " + path + ": truncated");
+    if (scale > 0)   // big endian
+        for (float& v : raw) {
+            unsigned char* b = reinterpret_cast<unsigned char*>(&v);
+            std::swap(b[0], b[3]);
+            std::swap(b[1], b[2]);
+        }
+    const size_t row = (size_t)width * channels;
+    for (uint32_t y = 0; y < height; ++y) std::memcpy(&out[(size_t)y * row], &raw[(size_t)(height - 1 - y) * row], row * 4);
+    return out;
+}
+
 }   // namespace wth

@@ -644,6 +644,16 @@ void scene_builder_t::texture_set_transform(int tex, const float M[4], const flo
     t.t[1] = tr[1];
 }
 void scene_builder_t::texture_set_scale(int tex, float scale) { textures_.at(tex).scale = scale; }
+void scene_builder_t::texture_compose_transform(int tex, const float M[4], const float tr[2]) {
+    texture_t& t = textures_.at(tex);
+    const float a[4] = {t.m[0], t.m[1], t.m[2], t.m[3]}, ta[2] = {t.t[0], t.t[1]};
+    t.m[0] = a[0] * M[0] + a[1] * M[2];
+    t.m[1] = a[0] * M[1] + a[1] * M[3];
+    t.m[2] = a[2] * M[0] + a[3] * M[2];
+    t.m[3] = a[2] * M[1] + a[3] * M[3];
+    t.t[0] = a[0] * tr[0] + a[1] * tr[1] + ta[0];
+    t.t[1] = a[2] * tr[0] + a[3] * tr[1] + ta[1];
+}
 
 int scene_builder_t::add_material(const material_t& m) {
     materials_.push_back(m);

@@ -61,6 +61,8 @@ mesh_t mesh_lens(dvec3 centre, double radius, double R1c, double R2c, double thi
 mesh_t load_ply(const std::string& path, bool face_normals, double scale);
 // Wavefront OBJ (host/obj_loader.cpp; src/mesh/obj_loader.cpp:26-140): one vertex per face corner, polygons fan-triangulated
 mesh_t load_obj(const std::string& path, bool face_normals, double scale);
+// Portable float map (PF: RGB, Pf: grey; little or big endian), rows returned from the image's TOP (the file stores them bottom-up)
+std::vector<float> load_pfm(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels);
 
 class scene_builder_t {
 public:
@@ -86,6 +88,9 @@ public:
     int add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, bool bilinear, uint32_t uwrap, uint32_t vwrap);
     void texture_set_transform(int tex, const float M[4], const float t[2]);   // uv' = M uv + t (texture/transform.hpp)
     void texture_set_scale(int tex, float scale);                               // texture/scale.hpp with a constant scale
+    float texture_scale(int tex) const { return textures_.at(tex).scale; }
+    // wraps `tex` in another transform texture: uv' = M_tex (M uv + t) + t_tex
+    void texture_compose_transform(int tex, const float M[4], const float t[2]);
     wt::material_t& material(int id) { return materials_[id]; }
     int add_shape(const mesh_t& mesh, const xform_t& to_world, int material, bool face_normals = false);
     int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);

@@ -15,7 +15,7 @@
 //     fractal/dirac profile, diffuse, composite bins), spectrum (constant, complex constant, discrete line, rgb, blackbody,
 //     composite bins, dielectric, constant scale wrapper, named IOR / emission tables), shape (rectangle, cube, sphere, cylinder,
 //     prism, lens, ply / obj: host/ply_loader.cpp, host/obj_loader.cpp) with <ref id> or a nested <bsdf>, general to_world transforms, area emitters on shapes.
-//     Textures in scene files (bitmap decoding) are not read.
+//     Textures: constant, checkerboard, scale, transform, bitmap (PFM files) on diffuse reflectances, mask and normalmap bsdfs.
 // Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
@@ -222,6 +222,13 @@ struct expr_t {
             const std::string w = s.substr(b, i - b);
             if (w == "true") return 1.0;
             if (w == "false") return 0.0;
+            if (w == "pi") return M_PI;
+            if (w == "sin" || w == "cos" || w == "tan" || w == "sqrt" || w == "abs") {
+                if (!eat("(")) fail("'(' expected after " + w);
+                const double a = lor();
+                if (!eat(")")) fail("')' expected");
+                return w == "sin" ? std::sin(a) : w == "cos" ? std::cos(a) : w == "tan" ? std::tan(a) : w == "sqrt" ? std::sqrt(a) : std::fabs(a);
+            }
             fail("unknown identifier " + w);
         }
         const char* b = s.c_str() + i;
@@ -559,6 +566,85 @@ struct loader_t {
         }
         throw std::runtime_error("<spectrum>: unsupported kind");
     }
+    // ---- textures (src/texture/texture_loader.cpp:30-62): constant, checkerboard (colour1 / colour2: a texture or a constant spectrum,
+    // defaults 0 and 1), scale (constant `scale` spectrum x nested texture), transform (<matrix value="a,b,c,d"/>, <translate value="x,y"/>
+    // on the uv of a nested texture), bitmap (<path>: a PFM file — image decoding of other formats is not available here —, filter_type
+    // nearest | bilinear, wrap_mode[_u|_v] black | white | clamp | repeat | mirror).  Luminance (wavelength-independent) values; RGB bitmaps
+    // only for normal maps.  Returns the texture id.
+    static float const_of(const xnode_t& sp, const char* what) {
+        if (!sp.attr("constant")) throw std::runtime_error(std::string(what) + ": a constant spectrum is expected here");
+        return (float)eval_number(sp.get("constant"));
+    }
+    int texture_or_constant(const xnode_t& n) { return n.name == "spectrum" ? b.add_texture_constant(const_of(n, "texture colour"), const_of(n, "texture colour"), const_of(n, "texture colour")) : texture(n); }
+    static uint32_t wrap_of(const std::string& w) {
+        static const char* names[] = {"black", "white", "clamp", "repeat", "mirror"};
+        for (uint32_t i = 0; i < 5; ++i)
+            if (w == names[i]) return i;
+        throw std::runtime_error("unknown wrap mode \"" + w + "\"");
+    }
+    int texture(const xnode_t& n) {
+        std::string type = n.get("type");
+        if (type.empty() && n.attr("bitmap")) type = "bitmap";
+        if (type == "constant") {
+            const xnode_t* sp = n.child("spectrum");
+            if (!sp) throw std::runtime_error("(constant texture loader) A nested real spectrum must be provided");
+            const float v = const_of(*sp, "constant texture");
+            return b.add_texture_constant(v, v, v);
+        }
+        if (type == "checkerboard") {
+            const xnode_t *c1 = n.named("colour1"), *c2 = n.named("colour2");
+            const int t1 = c1 ? texture_or_constant(*c1) : b.add_texture_constant(0.f, 0.f, 0.f);
+            const int t2 = c2 ? texture_or_constant(*c2) : b.add_texture_constant(1.f, 1.f, 1.f);
+            return b.add_texture_checkerboard(t1, t2);
+        }
+        if (type == "scale") {
+            const xnode_t *sc = n.named("scale"), *in = n.child("texture");
+            if (!sc || !in) throw std::runtime_error("scale texture: a `scale` spectrum and a nested texture expected");
+            const int t = texture(*in);
+            b.texture_set_scale(t, b.texture_scale(t) * const_of(*sc, "scale texture"));
+            return t;
+        }
+        if (type == "transform") {
+            const xnode_t* in = n.child("texture");
+            if (!in) throw std::runtime_error("(transform texture loader) A nested texture must be provided");
+            float M[4] = {1, 0, 0, 1}, T[2] = {0, 0};
+            if (const xnode_t* m = n.child("matrix")) {
+                const auto v = split_list(m->get("value"));
+                if (v.size() != 4) throw std::runtime_error("transform texture: <matrix> needs 4 values");
+                for (int i = 0; i < 4; ++i) M[i] = (float)eval_number(v[i]);
+            }
+            if (const xnode_t* tr = n.child("translate")) {
+                const auto v = split_list(tr->get("value"));
+                if (v.size() != 2) throw std::runtime_error("transform texture: <translate> needs 2 values");
+                T[0] = (float)eval_number(v[0]);
+                T[1] = (float)eval_number(v[1]);
+            }
+            const int t = texture(*in);
+            b.texture_compose_transform(t, M, T);
+            return t;
+        }
+        if (type == "bitmap") {
+            const xnode_t* pth = n.child("path");
+            std::string file = pth ? pth->get("value") : n.get("bitmap");
+            if (file.empty()) throw std::runtime_error("(bitmap texture loader) path must be provided");
+            if (file[0] != '/') file = base_dir + "/" + file;
+            bool bilinear = true;
+            if (const xnode_t* f = n.named("filter_type")) {
+                const std::string v = f->get("value");
+                if (v != "nearest" && v != "bilinear") throw std::runtime_error("bitmap filter_type \"" + v + "\" is not supported (nearest | bilinear)");
+                bilinear = v == "bilinear";
+            }
+            uint32_t uw = WRAP_REPEAT, vw = WRAP_REPEAT;
+            if (const xnode_t* w = n.named("wrap_mode")) uw = vw = wrap_of(w->get("value"));
+            if (const xnode_t* w = n.named("wrap_mode_u")) uw = wrap_of(w->get("value"));
+            if (const xnode_t* w = n.named("wrap_mode_v")) vw = wrap_of(w->get("value"));
+            uint32_t W = 0, H = 0, C = 0;
+            const std::vector<float> px = load_pfm(file, W, H, C);
+            return b.add_texture_bitmap(W, H, C, px.data(), bilinear, uw, vw);
+        }
+        throw std::runtime_error("(texture loader) texture type \"" + type + "\" is not supported");
+    }
+
     // bsdf node -> material (two_sided accumulated from the wrappers)
     bool material(const xnode_t& n, bool two_sided, material_t& out) {
         const std::string type = n.get("type");
@@ -598,9 +684,44 @@ struct loader_t {
         if (type == "diffuse") {
             const xnode_t* r = n.named("reflectance");
             if (!r) throw std::runtime_error("diffuse bsdf: reflectance expected");
+            if (r->name == "texture") {
+                // reflectance = spectrum x luminance texture: a `scale` texture's spectrum carries the wavelength dependence
+                // (scenes/cornell-box/box.xml:34-41: scale 0.35 x bitmap), anything else is a grey texture
+                if (r->get("type") == "scale" || r->attr("scale")) {
+                    const xnode_t *sc = r->named("scale"), *in = r->child("texture");
+                    if (!sc || !in) throw std::runtime_error("scale texture: a `scale` spectrum and a nested texture expected");
+                    const int s = spectrum(*sc);
+                    if (s == -2) return false;
+                    out = mat_diffuse(s, 1.f, two_sided);
+                    out.refl_tex = 1 + (uint32_t)texture(*in);
+                } else {
+                    out = mat_diffuse(b.spectrum_const(1.f), 1.f, two_sided);
+                    out.refl_tex = 1 + (uint32_t)texture(*r);
+                }
+                return true;
+            }
             const int s = spectrum(*r);
             if (s == -2) return false;
             out = mat_diffuse(s, 1.f, two_sided);
+            return true;
+        }
+        if (type == "mask") {   // src/bsdf/mask.cpp:94-124: a `mask` texture (or constant spectrum) and a nested bsdf
+            const xnode_t *mk = n.named("mask"), *in = n.child("bsdf");
+            if (!mk) throw std::runtime_error("(mask bsdf loader) a real 'mask' spectrum must be provided");
+            if (!in) throw std::runtime_error("(mask bsdf loader) 'mask' bsdf must contain a nested bsdf");
+            material_t inner{};
+            if (!material(*in, false, inner)) return false;
+            const int nested = b.add_material(inner);
+            out = mat_mask(nested, mk->name == "spectrum" ? const_of(*mk, "mask") : 1.f, two_sided);
+            if (mk->name == "texture") out.mask_tex = 1 + (uint32_t)texture(*mk);
+            return true;
+        }
+        if (type == "normalmap") {   // bsdf/normalmap.hpp: the nested bsdf with a perturbed shading frame
+            const xnode_t *nm = n.named("normalmap"), *in = n.child("bsdf");
+            if (!nm || nm->name != "texture" || !in) throw std::runtime_error("normalmap bsdf: a `normalmap` texture and a nested bsdf expected");
+            if (!material(*in, two_sided, out)) return false;
+            out.normal_tex = 1 + (uint32_t)texture(*nm);
+            if (const xnode_t* f = n.named("flip")) out.normal_flip = eval_number(f->get("value")) != 0.0 ? 1u : 0u;
             return true;
         }
         if (type == "surface_spm") {
@@ -713,8 +834,9 @@ struct loader_t {
             std::string wp = "D65";
             if (const xnode_t* w = resp->named("white_point")) wp = w->get("value");
             const float D50[3] = {0.96422f, 1.00000f, 0.82521f}, D65[3] = {0.95047f, 1.00000f, 1.08883f};
-            if (wp != "D50" && wp != "D65") throw std::runtime_error("white point \"" + wp + "\" is not supported");
-            b.set_response_rgb(wp == "D50" ? D50 : D65);
+            const float E[3] = {1.f, 1.f, 1.f}, D55[3] = {0.95682f, 1.00000f, 0.92149f};
+            if (wp != "D50" && wp != "D55" && wp != "D65" && wp != "E") throw std::runtime_error("white point \"" + wp + "\" is not supported");
+            b.set_response_rgb(wp == "D50" ? D50 : wp == "D55" ? D55 : wp == "E" ? E : D65);
         }
 
         // ---- emitters, materials, shapes, in file order
