@@ -48,6 +48,68 @@ def test_reference_reflectors_variant_loads_as_forward_plt_path(built):
     assert np.isfinite(v).all() and np.isfinite(l).all() and ctr["segments"] > 0
 
 
+BOX = "/root/reference/scenes/cornell-box/box.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(BOX), reason="the reference checkout is not present on this machine")
+def test_reference_cornell_box_xml_is_the_bundled_scene(built):
+    """scenes/cornell-box/box.xml read where it lies (BASELINE.json configs[1]'s scene file).  Its three PLY meshes and its bitmap are
+    Git-LFS pointers in the checkout: the reader substitutes the stand-ins of the bundled `cornell_box` scene (host/scenes.cpp:
+    asset_standin_mesh; mid-grey for the bitmap).  Everything else — integrator, camera, film, white point, the wall / prism / ball /
+    lens / pipe / cube shapes and their transforms, the materials, the two spots and the area emitter IN THE REFERENCE LOADER'S ORDER —
+    comes from the XML, and must give the scene every cornell_box test and the benchmark use: the same geometry, the same sample paths
+    (every counter equal) and the same film, bit for bit."""
+    from wave_tracer_amd import Scene
+    a = Scene.from_xml(BOX, res=24, mesh_detail=0, lut=(64, 64))
+    b = Scene("cornell_box", res=24, mesh_detail=0, lut=(64, 64))
+    assert a.stats() == b.stats()
+    ia, ib = a.info, b.info
+    for f in ("width", "height", "channels", "n_tris", "n_edges", "n_nodes", "n_leaves", "n_shapes", "n_emitters", "max_depth", "sensor_type", "integrator"):
+        assert getattr(ia, f) == getattr(ib, f), f
+    assert (ia.n_tris, ia.n_shapes, ia.n_emitters, ia.max_depth) == (14078, 13, 3, 16)
+    va, wa, la, ca = oracle_render(a, 0, 4, 7)
+    vb, wb, lb, cb = oracle_render(b, 0, 4, 7)
+    assert ca == cb and ca["fsd_interactions"] > 0
+    assert np.array_equal(wa, wb)
+    assert np.array_equal(va, vb) and np.array_equal(la, lb)
+    assert [e["type"] for e in a.emitter_summary()] == ["spot", "spot", "area"]
+    # the full stand-in tessellation is the benchmark's 283 K-triangle scene
+    full = Scene.from_xml(BOX, res=8, lut=(32, 32))
+    assert full.info.n_tris == Scene("cornell_box", res=8, lut=(32, 32)).info.n_tris > 280000
+
+
+def test_emitter_order_follows_the_reference_loader(built, tmp_path):
+    """Free emitters are listed by element id (unnamed elements: "__unnamed_$<n>" in file order, compared as STRINGS, so $10 sorts before
+    $9), area emitters after them in shape order (src/scene/loader/loader.cpp:131-133,272-310)."""
+    from wave_tracer_amd import Scene
+    def scene(ids):
+        ems = "".join(f'''<emitter type="spot" {("id=" + chr(34) + i + chr(34)) if i else ""}>
+            <transform name="to_world"><lookat origin="0cm, 0cm, 1cm" target="0cm, 0cm, 0cm"/></transform>
+            <quantity name="beam_width" value="1°"/><quantity name="cutoff_angle" value="{c}°"/>
+            <spectrum name="radiant_intensity" constant="1"/></emitter>''' for i, c in ids)
+        return f'''<scene version="0.1.0"><integrator type="plt_bdpt"><integer name="max_depth" value="4"/></integrator>
+          <sensor type="perspective"><quantity name="fov" value="20°"/>
+            <transform name="to_world"><lookat origin="0cm, 1cm, 5cm" target="0cm, 0cm, 0cm"/></transform>
+            <film type="array"><integer name="width" value="8"/><integer name="height" value="8"/><response type="RGB"/></film></sensor>
+          <shape type="cube"><quantity name="length" value="1mm"/><bsdf type="diffuse"><spectrum name="reflectance" constant=".5"/></bsdf>
+            <emitter type="area"><spectrum name="radiance" constant="1"/></emitter></shape>
+          {ems}
+          <shape type="rectangle"><quantity name="length" value="4cm"/><bsdf type="diffuse"><spectrum name="reflectance" constant=".5"/></bsdf></shape>
+        </scene>'''
+    def cutoffs(ids):
+        f = tmp_path / "e.xml"
+        f.write_text(scene(ids))
+        s = Scene.from_xml(str(f), lut=(32, 32))
+        return s.emitter_summary()
+    # ids given: sorted by id; the area emitter (declared first) comes last
+    assert [e["type"] for e in cutoffs([("b", 5), ("a", 7)])] == ["spot", "spot", "area"]
+    got = cutoffs([("b", 5), ("a", 7)])
+    assert [round(e["cutoff_deg"]) for e in got[:2]] == [7, 5]
+    # unnamed: integrator $1, sensor $2, cube $3, spots $4.. — ten spots reach $13: "$10".."$13" sort before "$4"
+    got = cutoffs([("", 10 + i) for i in range(10)])
+    assert [round(e["cutoff_deg"]) for e in got[:-1]] == [16, 17, 18, 19, 10, 11, 12, 13, 14, 15] and got[-1]["type"] == "area"
+
+
 def test_own_scene_defaults(built):
     from wave_tracer_amd import Scene
     s = Scene.from_xml(OWN, lut=(32, 32))

@@ -165,12 +165,13 @@ class Scene:
         return self
 
     @classmethod
-    def from_xml(cls, path, defines=None, res=0, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, lut=(0, 0), polarimetric=0):
+    def from_xml(cls, path, defines=None, res=0, max_depth=-1, fsd=-1, mis=-1, rr=-1, force_ray_tracing=0, lut=(0, 0), polarimetric=0, mesh_detail=1):
         """Loads a scene file of the reference's XML format with the minimal reader (wtgpu_scene_create_from_xml).  `defines`: dict of
-        the reference's -D command-line defines."""
+        the reference's -D command-line defines.  mesh_detail: tessellation of the procedural stand-ins that replace Git-LFS pointer
+        files (0: low-poly, for the CPU checker)."""
         lib = load_library()
         self = cls.__new__(cls)
-        p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, 1, lut[0], lut[1], polarimetric)
+        p = SceneParams(res, max_depth, fsd, mis, rr, force_ray_tracing, mesh_detail, lut[0], lut[1], polarimetric)
         d = [f"{k}={v}".encode() for k, v in (defines or {}).items()]
         arr = (C.c_char_p * max(1, len(d)))(*d)
         h = C.c_void_p()
@@ -202,6 +203,10 @@ class Scene:
 
     def stats(self):
         return json.loads(load_library().wtgpu_scene_stats_json(self._h).decode())
+
+    def emitter_summary(self):
+        """The scene's emitters in selection order: [{type, cutoff_deg, shape, select_pmf}]."""
+        return self.stats()["emitter_list"]
 
     def upload(self, device=0, max_batch_samples=0):
         _check(load_library().wtgpu_scene_upload(self._h, int(device), int(max_batch_samples)))

@@ -562,16 +562,34 @@ int scene_builder_t::spectrum_rgb(float r, float g, float bl) {
     }
     return spectrum_from_wavelength_table(v.data(), nullptr, N, 380.f, 1.f);
 }
-// src/spectrum/blackbody.cpp + colourspace/blackbody.hpp:24-50 (Planck, W/m^2/mm of wavelength), baked over the
-// wavelength range the bundled sensors see
+// src/spectrum/blackbody.cpp:30-56 + colourspace/blackbody.hpp:24-49.  Planck's spectral radiance per mm of wavelength, TIMES 1e-10
+// ("to make values more inline with emitter db quantities", blackbody.hpp:47-48: without that factor a blackbody area emitter
+// outshines a database-spectrum spot by ten orders of magnitude and the emitter selection never picks the spot), sampled at the
+// reference's knots — 8 nm steps from 8 nm, 8 nm + lambda / 100 beyond 800 nm — and interpolated linearly in WAVENUMBER between
+// them, as the reference's piecewise-linear approximation does.  Baked over the wavelength range the bundled sensors see.
 int scene_builder_t::spectrum_blackbody(float T, float scale) {
-    std::vector<float> v(SPD_N);
     const double c = 299792458.0, h = 6.62607015e-34, kB = 1.380649e-23;
     const double c1 = 2 * h * c * c, c2 = h * c / kB;
+    auto planck = [&](double lnm) {
+        const double l = lnm * 1e-9;
+        const double Le = c1 / (std::pow(l, 5) * (std::exp(c2 / (l * T)) - 1.0));   // W/m^2/sr per m of wavelength
+        return (double)(float)(Le * 1e-3) * 1e-10 * scale;                          // per mm, (f_t)ret * 1e-10, x scale
+    };
+    std::vector<double> knot_l, knot_v;
+    const double lmax = SPD_LAMBDA_MIN_NM + SPD_LAMBDA_STEP_NM * (SPD_N - 1);
+    for (double l = 8.0; knot_l.empty() || knot_l.back() < lmax;) {
+        knot_l.push_back(l);
+        knot_v.push_back(planck(l));
+        l += l < 800.0 ? 8.0 : 8.0 + l / 100.0;
+    }
+    std::vector<float> v(SPD_N);
+    size_t seg = 0;
     for (int i = 0; i < SPD_N; ++i) {
-        const double l = (SPD_LAMBDA_MIN_NM + SPD_LAMBDA_STEP_NM * i) * 1e-9;
-        const double Le = c1 / (std::pow(l, 5) * (std::exp(c2 / (l * T)) - 1.0));   // W/m^2/m
-        v[i] = (float)(Le * 1e-3 * scale);                                          // per mm
+        const double l = SPD_LAMBDA_MIN_NM + SPD_LAMBDA_STEP_NM * i;
+        while (seg + 2 < knot_l.size() && knot_l[seg + 1] < l) ++seg;
+        const double k = 1.0 / l, k0 = 1.0 / knot_l[seg], k1 = 1.0 / knot_l[seg + 1];   // linear in k (the 2 pi cancels)
+        const double f = (k - k0) / (k1 - k0);
+        v[i] = (float)(knot_v[seg] * (1 - f) + knot_v[seg + 1] * f);
     }
     return spectrum_from_wavelength_table(v.data(), nullptr, SPD_N, SPD_LAMBDA_MIN_NM, SPD_LAMBDA_STEP_NM);
 }
@@ -785,6 +803,22 @@ int scene_builder_t::spectrum_itu(const std::string& material, float wavelength_
         return spectrum_const((float)ior.real(), (float)ior.imag());
     }
     throw std::runtime_error("unknown ITU material " + material);
+}
+// new_order[i] = the current index of the emitter that becomes emitter i (the reference lists a scene's free emitters first, ordered
+// by element id, then the area emitters in shape order: src/scene/loader/loader.cpp:272-310)
+void scene_builder_t::permute_emitters(const std::vector<int>& new_order) {
+    if (new_order.size() != emitters_.size()) throw std::runtime_error("permute_emitters: wrong length");
+    std::vector<emitter_t> out(emitters_.size());
+    std::vector<int> where(emitters_.size(), -1);
+    for (size_t i = 0; i < new_order.size(); ++i) {
+        const int from = new_order[i];
+        if (from < 0 || (size_t)from >= emitters_.size() || where[from] >= 0) throw std::runtime_error("permute_emitters: not a permutation");
+        out[i] = emitters_[from];
+        where[from] = (int)i;
+    }
+    emitters_.swap(out);
+    for (auto& r : shape_recs_)
+        if (r.emitter >= 0) r.emitter = where[r.emitter];
 }
 int scene_builder_t::add_emitter_area(int shape, int spectrum, float scale, float pse_scale) {
     emitter_t e{};
@@ -1639,7 +1673,14 @@ std::string scene_builder_t::stats() const {
     std::ostringstream o;
     o << "{\"tris\": " << tri_geo_.size() << ", \"edges\": " << edges_.size() << ", \"nodes8\": " << nodes_.size() << ", \"leaves\": " << leaves_.size()
       << ", \"shapes\": " << shapes_.size() << ", \"emitters\": " << emitters_.size() << ", \"binary_depth\": " << bvh_max_depth_
-      << ", \"fsd_lut_power\": [" << lut_power_[0] << ", " << lut_power_[1] << "]}";
+      << ", \"fsd_lut_power\": [" << lut_power_[0] << ", " << lut_power_[1] << "], \"emitter_list\": [";
+    static const char* names[] = {"spot", "area", "point", "directional"};
+    for (size_t i = 0; i < emitters_.size(); ++i) {
+        const emitter_t& e = emitters_[i];
+        o << (i ? ", " : "") << "{\"type\": \"" << names[e.type & 3] << "\", \"cutoff_deg\": " << e.cutoff * 180.0 / M_PI << ", \"shape\": " << e.shape
+          << ", \"select_pmf\": " << e.select_pmf << "}";
+    }
+    o << "]}";
     return o.str();
 }
 

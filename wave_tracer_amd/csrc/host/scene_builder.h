@@ -96,6 +96,7 @@ public:
     int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);
     int add_emitter_area(int shape, int spectrum, float scale, float pse_scale);
     int add_emitter_point(dvec3 position, int spectrum, float scale, float extent_m, float pse_scale);
+    void permute_emitters(const std::vector<int>& new_order);   // new_order[i]: current index of the emitter that becomes emitter i
     // directional (sun-like) emitter: `dir_to_emitter`, irradiance spectrum, solid angle subtended at the target (default: the sun's)
     int add_emitter_directional(dvec3 dir_to_emitter, int spectrum, float scale, float solid_angle_sr, float pse_scale);
     // ITU-R P.2040 material IOR at one wavelength (src/spectrum/util/spectrum_from_ITU.cpp): a constant complex spectrum
@@ -193,6 +194,9 @@ wt::material_t mat_spm(int ior_spec, bool fractal, float roughness, float gamma,
 wt::material_t mat_mask(int nested, float alpha, bool two_sided);
 wt::material_t mat_dielectric(int ior_spec);
 void apply_opts(const scene_params_t& p, wt::integrator_opts_t& o);
+// Procedural stand-ins for the reference's Git-LFS assets that are absent from its checkout: `file` as written
+// in scenes/cornell-box/box.xml.  The stand-in comes with its own to_world (the asset's model units are unknown).  FALSE: no stand-in.
+bool asset_standin_mesh(const std::string& file, int mesh_detail, mesh_t& mesh, xform_t& to_world, bool& face_normals);
 // minimal reader of the reference's XML scene format (host/xml_scene.cpp): `defines` = "name=value" (-D of the reference's CLI)
 void build_scene_from_xml(const std::string& path, const std::vector<std::string>& defines, const scene_params_t& p, scene_builder_t& b);
 

@@ -170,6 +170,38 @@ static void build_double_slits(const scene_params_t& p, scene_builder_t& b) {
     build_double_slits_geometry(b, m_wall, m_floor, m_screen);
 }
 
+// ---- stand-ins for the Git-LFS assets of scenes/cornell-box/box.xml ------------------------------------------------------
+// dragon_recon/dragon_vrip_res2.ply (box.xml:108-124), bunny/bun_zipper.ply (:154-167), star_big.ply (:199-212) are LFS pointers in
+// the reference's checkout.  Procedural meshes of the same triangle budgets (70 k / 200 k / 2 k: geodesic grids of frequency
+// 59 / 100, 20 n^2 triangles; mesh_detail = 0: 1280 each, for the CPU checker's small cases) stand in for them, placed where the
+// XML places the originals.
+bool asset_standin_mesh(const std::string& file, int mesh_detail, mesh_t& mesh, xform_t& M, bool& face_normals) {
+    auto ends_with = [&](const char* suffix) {
+        const std::string s(suffix);
+        return file.size() >= s.size() && file.compare(file.size() - s.size(), s.size(), s) == 0;
+    };
+    face_normals = false;
+    if (ends_with("dragon_vrip_res2.ply")) {   // gold blob, +-0.4 cm, rotated 150 deg about y
+        mesh = mesh_blob_geodesic(.1 * cm, mesh_detail ? 59 : 8, .12, 9, 17);
+        M = xform_t::translate(.05 * cm, .55 * cm, 0) * xform_t::scale(4.0, 5.2, 3.0) * xform_t::rotate(0, 1, 0, deg(150));
+        return true;
+    }
+    if (ends_with("bun_zipper.ply")) {         // blob near (.50, 1.19, -.09) cm
+        mesh = mesh_blob_geodesic(.1 * cm, mesh_detail ? 100 : 8, .10, 6, 41);
+        M = xform_t::translate(.50 * cm, 1.19 * cm, -.09 * cm) * xform_t::rotate(0, 1, 0, deg(-35)) * xform_t::scale(2.6, 3.0, 2.2);
+        return true;
+    }
+    if (ends_with("star_big.ply")) {
+        // "star of david": a thin hexagram plate (.1 mm) of 2 k triangles with face normals at x = -.425 cm; outer radius 2.5 mm (y)
+        // x 2.25 mm (z)
+        mesh = mesh_star_plate(2.5 * mm, .1 * mm, mesh_detail ? 9 : 2);
+        M = xform_t::translate(-.425 * cm, 1 * cm, 0) * xform_t::scale(1, 1, .9);
+        face_normals = true;
+        return true;
+    }
+    return false;
+}
+
 // ---- scenes/cornell-box/box.xml (stand-in) ----------------------------------------------------------------------
 static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
     integrator_opts_t o{};
@@ -207,22 +239,21 @@ static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
     b.add_shape(rect, M({0, 0, -2, 1 * cm, -1, 0, 0, 1 * cm, 0, 1, 0, 0, 0, 0, 0, 1}), right_wall);
     b.add_shape(rect, M({0, 0, 2, -1 * cm, -1, 0, 0, 1 * cm, 0, -1, 0, 0, 0, 0, 0, 1}), tiles);    // left wall
 
-    // the three LFS meshes are replaced by procedural ones of 70 k / 200 k / 2 k triangles (geodesic grids of
-    // frequency 59 / 100: 20 n^2 triangles; mesh_detail = 0: 1280 each, for the CPU checker's small cases)
-    const int n_dragon = p.mesh_detail ? 59 : 8, n_bunny = p.mesh_detail ? 100 : 8;
-    // "dragon" stand-in: gold blob, scale 4.8 x 1cm model units (~ +-0.4cm), rotated 150deg about y, translated
-    b.add_shape(mesh_blob_geodesic(.1 * cm, n_dragon, .12, 9, 17),
-                xform_t::translate(.05 * cm, .55 * cm, 0) * xform_t::scale(4.0, 5.2, 3.0) * xform_t::rotate(0, 1, 0, deg(150)), gold);
+    // the three LFS meshes are replaced by procedural ones (asset_standin_mesh above)
+    auto standin = [&](const char* file, int material) {
+        mesh_t m;
+        xform_t M = xform_t::identity();
+        bool fn = false;
+        asset_standin_mesh(file, p.mesh_detail, m, M, fn);
+        b.add_shape(m, M, material, fn);
+    };
+    standin("dragon_recon/dragon_vrip_res2.ply", gold);
     // prism (length 6mm, height 1.2mm, 90deg), translate(-.705cm,.15cm,0)
     b.add_shape(mesh_prism(6 * mm, 1.2 * mm, deg(90)), xform_t::translate(-.705 * cm, .15 * cm, 0), sf5);
     // ball: sphere r=1.4mm at (-.65cm,.3cm,0), to_world scale y=.25
     b.add_shape(mesh_sphere({-.65 * cm, .3 * cm, 0}, 1.4 * mm, 32), xform_t::scale(1, .25, 1), sf11);
-    // "bunny" stand-in: SF5 blob near (.50cm,.89cm,-.09cm)
-    b.add_shape(mesh_blob_geodesic(.1 * cm, n_bunny, .10, 6, 41),
-                xform_t::translate(.50 * cm, 1.19 * cm, -.09 * cm) * xform_t::rotate(0, 1, 0, deg(-35)) * xform_t::scale(2.6, 3.0, 2.2), sf5);
-    // "screen" stand-in for star_big.ply ("star of david", box.xml:199-212): a thin hexagram plate (.1 mm) of 2 k triangles with face
-    // normals, Al fractal (scaled .1), at x = -.425 cm; outer radius 2.5 mm (y) x 2.25 mm (z), the footprint of the former box plate
-    b.add_shape(mesh_star_plate(2.5 * mm, .1 * mm, p.mesh_detail ? 9 : 2), xform_t::translate(-.425 * cm, 1 * cm, 0) * xform_t::scale(1, 1, .9), screen, true);
+    standin("bunny/bun_zipper.ply", sf5);
+    standin("star_big.ply", screen);
     // dragon_lens (box.xml:253-266): the reference's procedural `lens` shape — radius 1.5 mm, R1 = -.01, R2 = -.06, thickness .04 mm,
     // tessellation 50, SF11 — centred at (.045,.65,3.5) cm in its own frame, then to_world = rotate(-.2,1,0; 72 deg) about the origin
     // (src/mesh/lens.cpp:24,190-193: translate(centre) first, the shape's world transform second).  (`lens` / `mag_lens` and its
@@ -232,13 +263,13 @@ static void build_cornell_box(const scene_params_t& p, scene_builder_t& b) {
     b.add_shape(mesh_cylinder({-1.1 * cm, 1 * cm, 0}, {-.97 * cm, 1 * cm, 0}, .033 * cm, 32), xform_t::identity(), pipe_m);
     // cube_source: length .20cm, scale(3.1,.04,3.1), translate(.05,.02,-.05)cm, diffuse .01, area emitter blackbody 7000K x 4e-5
     const int cube = b.add_shape(mesh_cube(.20 * cm), xform_t::translate(.05 * cm, .02 * cm, -.05 * cm) * xform_t::scale(3.1, .04, 3.1), cube_m);
-    b.add_emitter_area(cube, b.spectrum_blackbody(7000.f, 1.f), 4e-5f, 1.f);
-
-    // spots: both at (-.99cm,1cm,0) looking +x; CFL emission
+    // spots: both at (-.99cm,1cm,0) looking +x; CFL emission.  Emitter order as the reference's loader lists them (loader.cpp:272-310):
+    // the free emitters (ordered by element id: the two unnamed spots in file order), then the shapes' area emitters
     const int cfl = b.spectrum_named("CFL2534");
     const xform_t spot_x = xform_t::lookat({-.99 * cm, 1 * cm, 0}, {1 * cm, 1 * cm, 0}, {0, 1, 0});
     b.add_emitter_spot(spot_x, cfl, 1.5f, (float)deg(3), (float)deg(1), -1.f, .45f);
     b.add_emitter_spot(spot_x, cfl, 2e-2f, (float)deg(55), (float)deg(1), -1.f, .25f);
+    b.add_emitter_area(cube, b.spectrum_blackbody(7000.f, 1.f), 4e-5f, 1.f);
 }
 
 // ---- scenes/bidir_room/room.xml (stand-in) ------------------------------------------------------------------------

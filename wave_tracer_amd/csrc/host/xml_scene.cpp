@@ -20,6 +20,7 @@
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
 // of a line emitter's power; a far-infrared line against an RGB sensor: zero) is not added.
+#include <algorithm>
 #include <cctype>
 #include <cstdlib>
 #include <cmath>
@@ -400,6 +401,15 @@ void parse_complex(const std::string& text, double& re, double& im) {
 }
 
 // ---------------------------------------------------------------------------------------------- the loader
+// an asset that the checkout does not hold: a Git-LFS pointer (a short text file) in place of the binary
+static bool is_lfs_pointer(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.good()) return false;
+    char head[24] = {0};
+    f.read(head, 23);
+    return std::string(head).rfind("version https://git-lfs", 0) == 0;
+}
+
 struct loader_t {
     std::map<std::string, std::string> defs;
     scene_builder_t& b;
@@ -410,6 +420,7 @@ struct loader_t {
     double band_lo = 0, band_hi = 0;   // RGB sensor: sensitivity band [m]
     std::map<std::string, int> materials;
     std::string base_dir;   // directory of the scene file: relative asset paths resolve against it
+    int mesh_detail = 1;    // tessellation of the procedural stand-ins for Git-LFS assets (scene_params_t::mesh_detail)
 
     explicit loader_t(scene_builder_t& bb) : b(bb) {}
 
@@ -548,6 +559,8 @@ struct loader_t {
             const char* env = getenv("WTGPU_DATA_DIR");
             return (env ? std::string(env) : base_dir + "/data") + "/" + sub + "/" + name + ".yml";
         };
+        // tabulated spectra cannot fold a scale: the emitters pass theirs separately (emitter_t::scale), elsewhere it must be 1
+        if ((n.attr("material") || n.attr("emitter")) && scale != 1.0) throw std::runtime_error("<spectrum>: a scale on a database spectrum is supported for emitters only");
         if (n.attr("material")) {
             const std::string m = n.get("material");
             for (const char* baked : {"Al", "Au", "Ag", "Cu", "SF5", "SF11", "BK7"})
@@ -638,6 +651,12 @@ struct loader_t {
             if (const xnode_t* w = n.named("wrap_mode")) uw = vw = wrap_of(w->get("value"));
             if (const xnode_t* w = n.named("wrap_mode_u")) uw = wrap_of(w->get("value"));
             if (const xnode_t* w = n.named("wrap_mode_v")) vw = wrap_of(w->get("value"));
+            // a Git-LFS pointer in place of the image (scenes/cornell-box/textures/tiles2.png in the reference's checkout): mid-grey,
+            // as the bundled cornell_box scene uses
+            if (is_lfs_pointer(file)) {
+                std::fprintf(stderr, "wtgpu: %s is a Git-LFS pointer: mid-grey stands in for the image\n", file.c_str());
+                return b.add_texture_constant(.5f, .5f, .5f);
+            }
             uint32_t W = 0, H = 0, C = 0;
             const std::vector<float> px = load_pfm(file, W, H, C);
             return b.add_texture_bitmap(W, H, C, px.data(), bilinear, uw, vw);
@@ -750,6 +769,7 @@ struct loader_t {
         std::vector<xnode_t> top = p.top_level();
         if (top.size() != 1 || top[0].name != "scene") throw std::runtime_error(path + ": a single <scene> element expected");
         base_dir = dir_of(path);
+        mesh_detail = prm.mesh_detail;
         splice(std::move(top[0].kids), base_dir);
 
         // ---- integrator
@@ -840,22 +860,38 @@ struct loader_t {
         }
 
         // ---- emitters, materials, shapes, in file order
-        uint32_t n_emitters = 0;
+        // Emitter order (it decides which random numbers select which emitter): the reference lists the free emitters ordered by
+        // element id — unnamed elements are numbered "__unnamed_$<n>" over the enabled top-level elements, compared as strings —
+        // then the area emitters in shape order (src/scene/loader/loader.cpp:131-133,272-310)
+        uint32_t n_emitters = 0, unnamed_ids = 0;
+        struct emitter_key_t {
+            int cls;
+            std::string id;
+            int index;
+        };
+        std::vector<emitter_key_t> emitter_keys;
         for (auto& n : items) {
+            std::string element_id = n.get("id");
+            if (enabled(n) && element_id.empty()) element_id = "__unnamed_$" + std::to_string(++unnamed_ids);
             if (n.name == "emitter") {
                 if (!enabled(n)) continue;
                 const std::string type = n.get("type");
                 if (type == "spot") {
                     const xnode_t* sp = n.named("radiant_intensity");
                     if (!sp) throw std::runtime_error("spot emitter: radiant_intensity expected");
-                    const int s = spectrum(*sp);
+                    double scale = 1.0;
+                    if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
+                    xnode_t unscaled = *sp;   // the builder takes the scale separately (emitter_t::scale)
+                    unscaled.kids.clear();
+                    const int s = spectrum(unscaled);
                     if (s == -2) continue;
                     const xnode_t *bw = n.named("beam_width"), *co = n.named("cutoff_angle");
                     if (!bw || !co) throw std::runtime_error("spot emitter: beam_width and cutoff_angle expected");
                     float pse = 1.f;
                     if (const xnode_t* r = n.named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
-                    b.add_emitter_spot(to_world(n, {0, 1, 0}), s, 1.f, (float)parse_dim(co->get("value"), DIM_ANGLE, "cutoff_angle"),
+                    b.add_emitter_spot(to_world(n, {0, 1, 0}), s, (float)scale, (float)parse_dim(co->get("value"), DIM_ANGLE, "cutoff_angle"),
                                        (float)parse_dim(bw->get("value"), DIM_ANGLE, "beam_width"), -1.f, pse);
+                    emitter_keys.push_back({0, element_id, (int)n_emitters});
                     ++n_emitters;
                 } else if (type == "directional") {
                     const xnode_t* sp = n.named("irradiance");
@@ -873,6 +909,7 @@ struct loader_t {
                     // the emitter's local -z is mapped from origin towards target: the direction TO the emitter is origin - target
                     // (src/emitter/directional.cpp:118-120)
                     b.add_emitter_directional({og.x - tg.x, og.y - tg.y, og.z - tg.z}, s, (float)scale, 6.794e-5f, 1.f);
+                    emitter_keys.push_back({0, element_id, (int)n_emitters});
                     ++n_emitters;
                 } else
                     throw std::runtime_error("emitter type \"" + type + "\" is not supported by the minimal reader");
@@ -913,7 +950,7 @@ struct loader_t {
                     throw std::runtime_error("(shape loader) no bsdf found");
                 // defaults: src/scene/shape.cpp:196-380
                 const std::string type = n.get("type");
-                const xform_t M = to_world(n, {0, 1, 0});
+                xform_t M = to_world(n, {0, 1, 0});
                 bool face_normals = false;
                 if (const xnode_t* fn = n.named("face_normals")) face_normals = eval_number(fn->get("value")) != 0.0;
                 mesh_t mesh;
@@ -938,7 +975,14 @@ struct loader_t {
                     if (!pth) throw std::runtime_error(type + " shape: <path value=…/> expected");
                     const std::string file = pth->get("value");
                     const std::string full = file.size() && file[0] == '/' ? file : base_dir + "/" + file;
-                    mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0));
+                    xform_t Ms = M;
+                    bool fns = face_normals;
+                    if (is_lfs_pointer(full) && asset_standin_mesh(file, mesh_detail, mesh, Ms, fns)) {
+                        std::fprintf(stderr, "wtgpu: %s is a Git-LFS pointer: using the procedural stand-in\n", full.c_str());
+                        M = Ms;   // the stand-in is placed in world space (the asset's model units are unknown)
+                        face_normals = fns;
+                    } else
+                        mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0));
                 } else
                     throw std::runtime_error("shape type \"" + type + "\" is not supported by the minimal reader");
                 const int shape = b.add_shape(mesh, M, mat, face_normals);
@@ -955,12 +999,23 @@ struct loader_t {
                         float pse = 1.f;
                         if (const xnode_t* r = em->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
                         b.add_emitter_area(shape, spec, (float)scale, pse);
+                        emitter_keys.push_back({1, std::string(), (int)n_emitters});
                         ++n_emitters;
                     }
                 }
             }
         }
         if (!n_emitters) throw std::runtime_error("(scene) no emitters overlap the sensor's sensitivity");
+        std::stable_sort(emitter_keys.begin(), emitter_keys.end(), [](const emitter_key_t& x, const emitter_key_t& y) {
+            return x.cls != y.cls ? x.cls < y.cls : x.cls == 0 ? x.id < y.id : x.index < y.index;
+        });
+        std::vector<int> order;
+        bool reorder = false;
+        for (size_t i = 0; i < emitter_keys.size(); ++i) {
+            order.push_back(emitter_keys[i].index);
+            reorder |= emitter_keys[i].index != (int)i;
+        }
+        if (reorder) b.permute_emitters(order);
     }
 };
 

@@ -1175,6 +1175,7 @@ int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, ui
         s->builder = std::make_unique<wth::scene_builder_t>();
         wth::scene_params_t p{};
         p.max_depth = p.fsd = p.mis = p.rr = -1;
+        p.mesh_detail = 1;
         if (params) {
             p.res = params->res;
             p.max_depth = params->max_depth;
@@ -1184,6 +1185,7 @@ int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, ui
             p.force_ray_tracing = params->force_ray_tracing;
             p.lut_n_theta = params->lut_n_theta;
             p.lut_m = params->lut_m;
+            p.mesh_detail = params->mesh_detail;
             p.polarimetric = params->polarimetric;
         }
         std::vector<std::string> defs;
