@@ -1,6 +1,8 @@
 """Emitters beyond the headline scene's spot / area lights: `point` (src/emitter/point.cpp, pinned by the
 free-space coverage closed form in tests/test_path_oracle.py) and `directional` (src/emitter/directional.cpp, an infinite emitter
 with a delta direction).  CPU checks through the CPU checker; GPU parity is marked."""
+import math
+
 import numpy as np
 import pytest
 
@@ -109,3 +111,40 @@ def test_emitted_flux_of_every_emitter_type(built):
     f, v = flux(sun, 0)
     r2 = (2 * math.cos(math.radians(30)) + .2 * math.sin(math.radians(30))) ** 2 + 2 ** 2     # farthest AABB corner from the axis
     assert abs(f / (v * math.pi * r2) - 1) < 1e-4
+
+
+def test_emitter_selection_weights_follow_the_reference(built):
+    """scene_build_sensor_sampling_data.cpp:62-103: an emitter is selected with probability ∝ R0 x power(sensitivity range), R0 = the
+    overlap integral of the emission and sensitivity spectra NORMALISED over their own supports — i.e. ∝ ∫ s e dk x geometry x
+    [∫_range e dk / ∫_all e dk].  Checked on the cornell scene: (a) the two spots share a spectrum: their ratio is scale x solid angle;
+    (b) the bracket of the 7000 K blackbody (tabulated 8 nm .. 5 mm at the reference's knots, x 1e-10, piecewise linear in k,
+    blackbody.cpp:30-56) against an independent evaluation here; (c) the CFL lamp lies almost entirely inside 390..830 nm;
+    (d) the blackbody's 1e-10 normalisation: the area emitter must NOT dominate the selection (it did, with probability 0.999998,
+    before the factor was added)."""
+    from wave_tracer_amd import Scene
+    em = Scene("cornell_box", res=16, mesh_detail=0, lut=(32, 32)).emitter_summary()
+    assert [e["type"] for e in em] == ["spot", "spot", "area"]
+
+    def solid(falloff, cutoff):     # spot.hpp:65-70
+        a, b = math.radians(falloff), math.radians(cutoff)
+        return 2 * math.pi * (1 - .5 * (math.cos(a) + math.cos(b)))
+    want = (2e-2 * solid(1, 55)) / (1.5 * solid(1, 3))
+    assert abs(em[1]["select_pmf"] / em[0]["select_pmf"] / want - 1) < 1e-4
+    # (b) Planck at the reference's knots, integrated over k
+    T, h, c, kB = 7000.0, 6.62607015e-34, 299792458.0, 1.380649e-23
+    ls, l = [], 8.0
+    while l <= 5e6 + 8.0:
+        ls.append(l)
+        l += 8.0 if l < 800.0 else 8.0 + l / 100.0
+    ls = np.array(ls)
+    with np.errstate(over="ignore"):
+        B = 2 * h * c * c / ((ls * 1e-9) ** 5 * (np.exp(h * c / kB / (ls * 1e-9 * T)) - 1.0))
+    k = 1.0 / ls[::-1]
+    v = B[::-1]
+    total = np.trapezoid(v, k)
+    fine = np.linspace(1 / 830.0, 1 / 390.0, 200001)
+    inside = np.trapezoid(np.interp(fine, k, v), fine)
+    # 5e-3: the baked sensitivity table reaches zero half a nanometre outside 390 / 830 nm (0.5-nm grid), where the blackbody is strongest
+    assert abs(em[2]["in_range_fraction"] / (inside / total) - 1) < 5e-3
+    assert .98 < em[0]["in_range_fraction"] <= 1.0 and em[0]["in_range_fraction"] == em[1]["in_range_fraction"]
+    assert em[2]["select_pmf"] < .01 and abs(sum(e["select_pmf"] for e in em) - 1) < 1e-5

@@ -78,6 +78,22 @@ def test_reference_cornell_box_xml_is_the_bundled_scene(built):
     assert full.info.n_tris == Scene("cornell_box", res=8, lut=(32, 32)).info.n_tris > 280000
 
 
+@pytest.mark.skipif(not os.path.exists(BOX), reason="the reference checkout is not present on this machine")
+def test_reference_sphere_polarization_xml(built):
+    """scenes/cornell-box/sphere_polarization.xml read in place: a polarimetric perspective sensor (<sensor polarimetric="true">: four
+    Stokes planes per RGB channel), metre-scale walls, a 128-segment dielectric sphere, a blackbody area emitter."""
+    from wave_tracer_amd import Scene
+    s = Scene.from_xml(os.path.join(os.path.dirname(BOX), "sphere_polarization.xml"), res=16, lut=(32, 32))
+    assert (s.width, s.height, s.spectral_channels, s.stokes, s.channels) == (16, 16, 3, 4, 12)
+    assert s.info.max_depth == 8 and s.info.integrator == 0 and s.info.n_shapes == 7 and s.info.n_emitters == 1
+    v, w, l, c = oracle_render(s, 0, 2, 3)
+    assert v.shape == (16, 16, 12) and np.isfinite(v).all() and np.isfinite(l).all() and v[..., 0::4].sum() > 0
+    # Stokes: |Q|, |U|, |V| never exceed I in the accumulated film (every sample is a physical Stokes vector)
+    I = v[..., 0::4] + l[..., 0::4]
+    for q in (1, 2, 3):
+        assert (np.abs(v[..., q::4] + l[..., q::4]) <= I * (1 + 1e-6) + 1e-12).all()
+
+
 def test_emitter_order_follows_the_reference_loader(built, tmp_path):
     """Free emitters are listed by element id (unnamed elements: "__unnamed_$<n>" in file order, compared as STRINGS, so $10 sorts before
     $9), area emitters after them in shape order (src/scene/loader/loader.cpp:131-133,272-310)."""

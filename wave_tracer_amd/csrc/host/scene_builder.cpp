@@ -575,9 +575,9 @@ int scene_builder_t::spectrum_blackbody(float T, float scale) {
         const double Le = c1 / (std::pow(l, 5) * (std::exp(c2 / (l * T)) - 1.0));   // W/m^2/sr per m of wavelength
         return (double)(float)(Le * 1e-3) * 1e-10 * scale;                          // per mm, (f_t)ret * 1e-10, x scale
     };
+    // knots over the reference's whole range, 10 nm .. 5 mm (blackbody.cpp:95-98: "hardcoded max & min"), from max(8 nm, 10 nm - 8 nm)
     std::vector<double> knot_l, knot_v;
-    const double lmax = SPD_LAMBDA_MIN_NM + SPD_LAMBDA_STEP_NM * (SPD_N - 1);
-    for (double l = 8.0; knot_l.empty() || knot_l.back() < lmax;) {
+    for (double l = 8.0; l <= 5e6 + 8.0;) {
         knot_l.push_back(l);
         knot_v.push_back(planck(l));
         l += l < 800.0 ? 8.0 : 8.0 + l / 100.0;
@@ -591,7 +591,41 @@ int scene_builder_t::spectrum_blackbody(float T, float scale) {
         const double f = (k - k0) / (k1 - k0);
         v[i] = (float)(knot_v[seg] * (1 - f) + knot_v[seg + 1] * f);
     }
-    return spectrum_from_wavelength_table(v.data(), nullptr, SPD_N, SPD_LAMBDA_MIN_NM, SPD_LAMBDA_STEP_NM);
+    const int id = spectrum_from_wavelength_table(v.data(), nullptr, SPD_N, SPD_LAMBDA_MIN_NM, SPD_LAMBDA_STEP_NM);
+    auto& support = spectrum_support_knots_[id];
+    for (size_t j = knot_l.size(); j-- > 0;) support.push_back({2.0 * M_PI / (knot_l[j] * 1e-6), knot_v[j]});   // k in 1/mm, ascending
+    return id;
+}
+// Share of an emission spectrum's k-integral that lies inside [k_lo, k_hi]:  power(range) / power(all wavenumbers)  of
+// scene_build_sensor_sampling_data.cpp:79-80 (the spectrum is piecewise linear in k over its support, 0 outside).
+double scene_builder_t::emission_fraction_in_range(int spectrum, double k_lo, double k_hi) const {
+    std::vector<std::pair<double, double>> tmp;
+    const std::vector<std::pair<double, double>>* kn = nullptr;
+    const auto it = spectrum_support_knots_.find(spectrum);
+    if (it != spectrum_support_knots_.end())
+        kn = &it->second;
+    else {
+        const spectrum_t& sp = spectra_[spectrum];
+        if (sp.type != SPEC_TABLE) return 1.0;
+        const int N = 8192;
+        for (int i = 0; i < N; ++i) {
+            const double k = sp.kmin + (double(sp.kmax) - sp.kmin) * i / (N - 1);
+            tmp.push_back({k, (double)spectrum_eval(spectrum, (float)k)});
+        }
+        kn = &tmp;
+    }
+    double all = 0, in = 0;
+    for (size_t i = 0; i + 1 < kn->size(); ++i) {
+        const double k0 = (*kn)[i].first, k1 = (*kn)[i + 1].first, v0 = (*kn)[i].second, v1 = (*kn)[i + 1].second;
+        if (!(k1 > k0)) continue;
+        all += .5 * (v0 + v1) * (k1 - k0);
+        const double a = std::max(k0, k_lo), b = std::min(k1, k_hi);
+        if (b > a) {
+            const double va = v0 + (v1 - v0) * (a - k0) / (k1 - k0), vb = v0 + (v1 - v0) * (b - k0) / (k1 - k0);
+            in += .5 * (va + vb) * (b - a);
+        }
+    }
+    return all > 0 ? in / all : 1.0;
 }
 int scene_builder_t::spectrum_named(const std::string& name) {
     struct ent {
@@ -1423,6 +1457,24 @@ void scene_builder_t::build_sampling_tables() {
     std::vector<double> powers;
     const spectrum_t sens = spectra_[sensitivity_spec_];
     const int NK = 4096;
+    // the sensitivity spectrum's own support (sensitivity_spectrum().wavenumber_range(): the CMF data cover 390..830 nm, the baked table
+    // is zero-padded to 340..840 nm)
+    double sens_support_kmin = sens.kmin, sens_support_kmax = sens.kmax;
+    if (sens.type == SPEC_TABLE) {
+        const int N = 4096;
+        int first = -1, last = -1;
+        for (int i = 0; i < N; ++i) {
+            const double k = sens.kmin + (double(sens.kmax) - sens.kmin) * i / (N - 1);
+            if (spectrum_eval(sensitivity_spec_, (float)k) > 0.f) {
+                if (first < 0) first = i;
+                last = i;
+            }
+        }
+        if (first >= 0) {
+            sens_support_kmin = sens.kmin + (double(sens.kmax) - sens.kmin) * std::max(0, first - 1) / (N - 1);
+            sens_support_kmax = sens.kmin + (double(sens.kmax) - sens.kmin) * std::min(N - 1, last + 1) / (N - 1);
+        }
+    }
     for (auto& e : emitters_) {
         const spectrum_t es = spectra_[e.spectrum];
         double geom = 1.0;
@@ -1470,7 +1522,14 @@ void scene_builder_t::build_sampling_tables() {
             cdf[0] = 0;
             for (int i = 1; i < NK; ++i) cdf[i] = cdf[i - 1] + .5 * (pdf[i] + pdf[i - 1]) * dk;
             const double total = cdf[NK - 1];
-            power = total * e.scale * geom;
+            // The reference's weight is R0 x power(sensitivity range) with R0 = ∫ s^ e^ dk of the two spectra NORMALISED over their own
+            // supports (product_distribution.hpp:39-43): ∝ ∫ s e dk x [∫_range e dk / ∫_all e dk] x geometry; 1 / ∫ s is common to
+            // all emitters.  The bracket is 1 for a lamp spectrum inside the visible band and ~0.3 for a blackbody tabulated from
+            // 10 nm to 5 mm.
+            const double in_range = emission_fraction_in_range(e.spectrum, sens_support_kmin, sens_support_kmax);
+            emitter_in_range_.resize(&e - emitters_.data() + 1, 1.0);
+            emitter_in_range_.back() = in_range;
+            power = total * e.scale * geom * in_range;
             for (int i = 0; i < NK; ++i) kdist_data_.push_back(total > 0 ? (float)(pdf[i] / total) : 0.f);
             for (int i = 0; i < NK; ++i) kdist_data_.push_back(total > 0 ? (i == NK - 1 ? 1.f : (float)(cdf[i] / total)) : 0.f);
         }
@@ -1678,7 +1737,7 @@ std::string scene_builder_t::stats() const {
     for (size_t i = 0; i < emitters_.size(); ++i) {
         const emitter_t& e = emitters_[i];
         o << (i ? ", " : "") << "{\"type\": \"" << names[e.type & 3] << "\", \"cutoff_deg\": " << e.cutoff * 180.0 / M_PI << ", \"shape\": " << e.shape
-          << ", \"select_pmf\": " << e.select_pmf << "}";
+          << ", \"select_pmf\": " << e.select_pmf << ", \"in_range_fraction\": " << (i < emitter_in_range_.size() ? emitter_in_range_[i] : 1.0) << "}";
     }
     o << "]}";
     return o.str();

@@ -10,6 +10,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -167,6 +168,11 @@ private:
     bool finalized_ = false;
     uint32_t bvh_max_depth_ = 0;
     double lut_power_[2] = {0, 0};
+    // spectra whose support exceeds the baked table (blackbody: 8 nm .. 5 mm): (k [1/mm] ascending, value) knots of the reference's
+    // piecewise-linear spectrum, for the emitter-selection weights (build_sampling_tables)
+    std::map<int, std::vector<std::pair<double, double>>> spectrum_support_knots_;
+    double emission_fraction_in_range(int spectrum, double k_lo, double k_hi) const;
+    std::vector<double> emitter_in_range_;   // per emitter: that share (reported by stats())
 
 public:
     double fsd_lut_power(int which) const { return lut_power_[which]; }

@@ -847,7 +847,10 @@ struct loader_t {
         } else
             throw std::runtime_error("sensor type \"" + stype + "\" is not supported");
         if (const xnode_t* r = film->named("rfilter_scale")) b.set_film_rfilter_scale((float)eval_number(r->get("value")));
-        if (prm.polarimetric > 0) b.set_sensor_polarimetric(true);
+        // <sensor … polarimetric="true"> (src/sensor/sensor_loader.cpp:28-38: the sensor records Stokes vectors); the parameter overrides
+        bool polarimetric = sensor->attr("polarimetric") && eval_number(sensor->get("polarimetric")) != 0.0;
+        if (prm.polarimetric > 0) polarimetric = true;
+        if (polarimetric) b.set_sensor_polarimetric(true);
         if (mono)
             b.set_response_mono_discrete((float)line_mm);
         else {

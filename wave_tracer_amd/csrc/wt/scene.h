@@ -99,7 +99,7 @@ struct material_t {
     // mask (src/bsdf/mask.cpp:24-92): nested material seen through a mask of opacity alpha
     int32_t nested;
     float mask_alpha;       // constant mask, used when mask_tex == 0
-    // textures (include/wt/texture/*.hpp): texture index + 1, 0 = none (so that a zero-initialised record has no textures)
+    // textures (the headers under include/wt/texture): texture index + 1, 0 = none (so that a zero-initialised record has no textures)
     uint32_t refl_tex;      // diffuse: reflectance = clamp01(spectrum * refl_tex_scale * texture) (scale.hpp wrapping a texture)
     uint32_t mask_tex;      // mask: opacity texture (0: the constant mask_alpha)
     uint32_t normal_tex;    // normalmap wrapper (bsdf/normalmap.hpp:48-62), flattened onto the material it wraps
