@@ -416,3 +416,76 @@ def test_texture_nodes_in_scene_files(built, tmp_path):
     from wave_tracer_amd.api import WtgpuError
     with pytest.raises(WtgpuError, match="PFM files only"):
         Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(tmp_path / "missing.png")})
+
+
+def _radio_city_xml():
+    """The bundled `etoile` stand-in (host/scenes.cpp:build_etoile, mesh_detail = 0) written in the vocabulary of
+    scenes/sionna_etoile/etoile.xml: two integrators and three sensors toggled by boolean expressions, a frequency in place of a
+    wavelength, composite materials whose radio bin is an ITU surface with transmission_scale 0, a point transmitter."""
+    mats = ["concrete", "marble", "metal", "brick", "wood"]
+    bsdfs = "".join(f'''
+  <bsdf type="twosided" id="mat-itu_{m}"><bsdf type="composite">
+    <bin wavelength_range="300nm .. 800nm"><bsdf type="diffuse"><spectrum rgb="0.5, 0.4, 0.3" name="reflectance"/></bsdf></bin>
+    <bin wavelength_range=".1mm .. 1m"><bsdf type="surface_spm"><spectrum name="IOR" ITU="{m}"/>
+      <spectrum name="transmission_scale" constant="0"/></bsdf></bin>
+  </bsdf></bsdf>''' for m in mats)
+    shapes = []
+
+    def box(cx, cy, z0, z1, sx, sy, rot, mat):
+        shapes.append(f'''
+  <shape type="cube"><quantity name="length" value="1m"/><boolean name="face_normals" value="true"/><ref id="mat-itu_{mat}" name="bsdf"/>
+    <transform name="to_world"><scale x="{sx!r}" y="{sy!r}" z="{z1 - z0!r}"/><translate x="{cx!r}m" y="{cy!r}m" z="{(z0 + z1) / 2!r}m"/>
+      <rotate z="1" angle="{rot!r}°"/></transform></shape>''')
+    box(-16, 0, -1, 30, 14, 22, 0, "marble")
+    box(16, 0, -1, 30, 14, 22, 0, "marble")
+    box(0, 0, 30, 49, 46, 22, 0, "marble")
+    box(0, 0, 49, 49.6, 44, 20, 0, "metal")
+    box(-16, -11.2, 0, 4, 3, .4, 0, "wood")
+    box(16, 11.2, 0, 4, 3, .4, 0, "wood")
+    for i in range(12):
+        ang, hgt, wall = 22.5 + 30.0 * i, 24.0 + 3.0 * ((i * 7) % 5), "brick" if i % 3 == 2 else "marble"
+        box(240, 0, -1, hgt, 180, 60, ang, wall)
+        box(240, 0, hgt, hgt + .5, 176, 56, ang, "metal")
+    return f'''<scene version="0.1.0">
+  <default name="res" value="64"/><default name="wavelength" value="1GHz"/>
+  <default name="sensor_extent" value="840"/><default name="optical_preview" value="false"/><default name="masked_overview" value="false"/>
+  <integrator type="plt_path"><boolean name="enabled" value="($optical_preview==false)"/>
+    <integer name="max_depth" value="16"/><string name="direction" value="forward"/><boolean name="russian_roulette" value="false"/></integrator>
+  <integrator type="plt_path"><boolean name="enabled" value="($optical_preview==true || $masked_overview==true)"/>
+    <string name="direction" value="backward"/><integer name="max_depth" value="16"/></integrator>
+  <sensor type="virtual_plane" id="coverage"><boolean name="enabled" value="($optical_preview==false)"/>
+    <transform name="to_world"><rotate z="1" angle="0°"/><scale y="-1"/><translate z="1mm"/></transform>
+    <quantity name="alpha" value=".001°"/><quantity name="extent" value="($sensor_extent) m, ($sensor_extent * .75) m"/>
+    <film type="array"><integer name="width" value="$res"/><integer name="height" value="($res*.75)"/><float name="rfilter_scale" value=".1"/>
+      <response type="monochromatic"><spectrum type="discrete" wavelength="$wavelength"/></response></film></sensor>
+  <sensor type="perspective" id="camera_perspective"><boolean name="enabled" value="($optical_preview==false &amp;&amp; $masked_overview==true)"/>
+    <quantity name="fov" value="(atan($sensor_extent/2 / 1250)*2) rad"/>
+    <transform name="to_world"><lookat origin="0 m, 0 m, 1250 m" target="0 m, 0 m, 0 m" up="0,1,0"/></transform>
+    <film type="array"><integer name="width" value="$res"/><integer name="height" value="($res*.75)"/><response type="RGB"/></film></sensor>
+  <emitter type="point"><point name="position" value="80.1m, 193.8m, 21m"/>
+    <spectrum name="radiant_intensity" type="discrete" wavelength="$wavelength" value="1"/><float name="phase_space_extent_scale" value=".75"/></emitter>
+  <emitter type="directional"><transform name="to_world"><lookat target="0m,0m,0m" origin="2m,2.5m,-2m" up="1,0,0"/></transform>
+    <spectrum name="irradiance" blackbody="5500K"><float name="scale" value="5e-5"/></spectrum></emitter>
+  {bsdfs}
+  <shape type="rectangle" id="mesh-Plane"><point name="p" x="-600m" y="-600m" z="0m"/><point name="x" x="1200m" y="0m" z="0m"/>
+    <point name="y" x="0m" y="1200m" z="0m"/><boolean name="face_normals" value="true"/><ref id="mat-itu_concrete" name="bsdf"/></shape>
+  {"".join(shapes)}
+</scene>'''
+
+
+def test_radio_scene_vocabulary_bakes_to_the_bundled_etoile(built, tmp_path):
+    """-Dwavelength=10GHz: the XML bakes to the SAME flattened scene, byte for byte, as `etoile` (mesh_detail 0)."""
+    from wave_tracer_amd import Scene
+    f = tmp_path / "radio_city.xml"
+    f.write_text(_radio_city_xml())
+    a = Scene.from_xml(str(f), defines={"wavelength": "10GHz"}, res=64)
+    b = Scene("etoile", res=64, mesh_detail=0)
+    assert (a.width, a.height, a.channels) == (64, 48, 1) and a.info.integrator == 1 and a.info.n_emitters == 1 and a.info.n_materials == 5
+    assert a.first_difference(b) == ""
+    # the default 1 GHz differs (another line, other ITU values); an unknown ITU material is reported
+    c = Scene.from_xml(str(f), res=64)
+    assert c.first_difference(b) != ""
+    from wave_tracer_amd.api import WtgpuError
+    f.write_text(_radio_city_xml().replace('ITU="wood"', 'ITU="cheese"'))
+    with pytest.raises(WtgpuError, match="cheese"):
+        Scene.from_xml(str(f), res=64)

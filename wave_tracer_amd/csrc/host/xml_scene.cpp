@@ -351,6 +351,21 @@ quantity_t parse_q(const std::string& text, dim_e want, const char* what) {
     return q;
 }
 double parse_dim(const std::string& text, dim_e want, const char* what) { return parse_q(text, want, what).si(); }
+// a wavelength, or a frequency that stands for one (parse_quantity.hpp:308-315: "…Hz" -> freq_to_wavelen)
+quantity_t parse_wavelength(const std::string& text, const char* what) {
+    if (text.find("Hz") == std::string::npos) return parse_q(text, DIM_LENGTH, what);
+    const std::string s = trim(text);
+    expr_t e(s);
+    const double v = e.prefix();
+    const std::string unit = trim(s.substr(e.i));
+    static const std::pair<const char*, double> units[] = {{"Hz", 1.0}, {"kHz", 1e3}, {"MHz", 1e6}, {"GHz", 1e9}, {"THz", 1e12}};
+    for (auto& u : units)
+        if (unit == u.first) {
+            if (!(v > 0)) throw std::runtime_error(std::string(what) + " \"" + text + "\": a positive frequency expected");
+            return {299792458.0 / (v * u.second) * 1e3, 1e-3, false, DIM_LENGTH};   // millimetres (the operation order of host/scenes.cpp)
+        }
+    throw std::runtime_error(std::string(what) + " \"" + text + "\": unknown frequency unit \"" + unit + "\"");
+}
 // splits at top-level commas
 std::vector<std::string> split_list(const std::string& s) {
     std::vector<std::string> out;
@@ -427,7 +442,10 @@ struct loader_t {
     std::string subst(const std::string& v) const {
         std::string o;
         for (size_t i = 0; i < v.size(); ++i) {
-            if (v[i] == '$') {
+            if (v[i] == '\\' && i + 1 < v.size() && v[i + 1] == '$') {   // "\$": a literal dollar (regular expressions in sensor masks)
+                o += '$';
+                ++i;
+            } else if (v[i] == '$') {
                 size_t e = i + 1;
                 while (e < v.size() && (std::isalnum((unsigned char)v[e]) || v[e] == '_')) ++e;
                 const std::string n = v.substr(i + 1, e - i - 1);
@@ -535,7 +553,7 @@ struct loader_t {
         double scale = 1.0;
         if (const xnode_t* sc = n.named("scale")) scale = eval_number(sc->get("value"));
         if (n.get("type") == "discrete") {
-            const quantity_t q = parse_q(n.get("wavelength"), DIM_LENGTH, "discrete spectrum wavelength");
+            const quantity_t q = parse_wavelength(n.get("wavelength"), "discrete spectrum wavelength");
             const double wl = q.si();
             const double val = n.attr("value") ? eval_number(n.get("value")) : 1.0;
             if (mono ? std::fabs(wl - line_m) > 1e-9 * line_m : !(band_lo <= wl && wl <= band_hi)) return -2;
@@ -572,6 +590,11 @@ struct loader_t {
             if (mono) return -2;
             if (e == "2534_CFL_Tensor_Twister") return b.spectrum_named("CFL2534");
             return b.spectrum_emission_from_file(data_file("emission", e));
+        }
+        if (n.attr("ITU")) {   // ITU-R P.2040 building materials (src/spectrum/util/spectrum_from_ITU.cpp): radio frequencies, line sensors only
+            if (!mono) throw std::runtime_error("<spectrum ITU=…>: supported for monochromatic sensors only");
+            if (scale != 1.0) throw std::runtime_error("<spectrum ITU=…>: scale is not supported");
+            return b.spectrum_itu(n.get("ITU"), (float)line_mm);
         }
         if (n.attr("blackbody")) {
             if (mono) return -2;   // continuous spectrum x line sensor: see the header of this file
@@ -664,6 +687,13 @@ struct loader_t {
         throw std::runtime_error("(texture loader) texture type \"" + type + "\" is not supported");
     }
 
+    // extIOR, reflection_scale, transmission_scale of the two interface BSDFs (src/bsdf/dielectric.cpp:94-97, surface_spm.cpp:225-229);
+    // the scales are constants here
+    void interface_extras(const xnode_t& n, material_t& out) {
+        if (const xnode_t* e = n.named("extIOR")) out.ext_ior_spec = spectrum(*e);
+        if (const xnode_t* r = n.named("reflection_scale")) out.refl_scale = const_of(*r, "reflection_scale");
+        if (const xnode_t* t = n.named("transmission_scale")) out.trans_scale = const_of(*t, "transmission_scale");
+    }
     // bsdf node -> material (two_sided accumulated from the wrappers)
     bool material(const xnode_t& n, bool two_sided, material_t& out) {
         const std::string type = n.get("type");
@@ -691,6 +721,7 @@ struct loader_t {
             if (!ior) throw std::runtime_error("dielectric bsdf: IOR expected");
             out = mat_dielectric(spectrum(*ior));
             out.two_sided = two_sided;
+            interface_extras(n, out);
             return true;
         }
         if (type == "composite") {
@@ -747,17 +778,24 @@ struct loader_t {
             const xnode_t* ior = n.named("IOR");
             if (!ior) throw std::runtime_error("surface_spm bsdf: IOR expected");
             const int s = spectrum(*ior);
-            bool fractal = false;
+            // surface profiles (src/interaction/surface_profile/{dirac,fractal,gaussian}.cpp): the roughness-parametrised forms with a
+            // constant roughness (T / sigma_h resp. sigma textures are not supported)
+            bool fractal = false, gaussian = false;
             float roughness = 0.f, gamma = 3.f;
             if (const xnode_t* sp = n.child("surface_profile")) {
-                if (sp->get("type") != "fractal") throw std::runtime_error("surface_profile: only fractal is supported");
-                fractal = true;
-                const xnode_t* ro = sp->named("roughness");
-                if (!ro || !ro->attr("constant")) throw std::runtime_error("fractal profile: constant roughness expected");
-                roughness = (float)eval_number(ro->get("constant"));
-                if (const xnode_t* g = sp->named("gamma")) gamma = (float)eval_number(g->get("value"));
+                const std::string pt = sp->get("type");
+                if (pt == "fractal" || pt == "gaussian") {
+                    (pt == "fractal" ? fractal : gaussian) = true;
+                    const xnode_t* ro = sp->named("roughness");
+                    if (!ro || !ro->attr("constant")) throw std::runtime_error(pt + " profile: a constant `roughness` spectrum is expected");
+                    roughness = (float)eval_number(ro->get("constant"));
+                    if (const xnode_t* g = sp->named("gamma")) gamma = (float)eval_number(g->get("value"));
+                } else if (pt != "dirac")
+                    throw std::runtime_error("surface_profile type \"" + pt + "\" is not supported (dirac | fractal | gaussian)");
             }
             out = mat_spm(s, fractal, roughness, gamma, two_sided, 1.f);
+            if (gaussian) out.profile = PROFILE_GAUSSIAN;
+            interface_extras(n, out);
             return true;
         }
         throw std::runtime_error("bsdf type \"" + type + "\" is not supported by the minimal reader");
@@ -777,7 +815,7 @@ struct loader_t {
         o.max_depth = 1024;
         o.MIS = o.RR = o.FSD = o.sensor_direct = o.emitter_direct = 1;
         for (auto& n : items) {
-            if (n.name != "integrator") continue;
+            if (n.name != "integrator" || !enabled(n)) continue;
             const std::string type = n.get("type");
             if (type == "plt_bdpt")
                 o.integrator = INTEGRATOR_BDPT;
@@ -819,7 +857,7 @@ struct loader_t {
             const xnode_t* sp = resp->child("spectrum");
             if (!sp || sp->get("type") != "discrete") throw std::runtime_error("monochromatic response: discrete spectrum expected");
             mono = true;
-            const quantity_t q = parse_q(sp->get("wavelength"), DIM_LENGTH, "response wavelength");
+            const quantity_t q = parse_wavelength(sp->get("wavelength"), "response wavelength");
             line_m = q.si();
             line_mm = q.in_mm();
         } else if (resp->get("type") == "RGB") {
@@ -894,6 +932,23 @@ struct loader_t {
                     if (const xnode_t* r = n.named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
                     b.add_emitter_spot(to_world(n, {0, 1, 0}), s, (float)scale, (float)parse_dim(co->get("value"), DIM_ANGLE, "cutoff_angle"),
                                        (float)parse_dim(bw->get("value"), DIM_ANGLE, "beam_width"), -1.f, pse);
+                    emitter_keys.push_back({0, element_id, (int)n_emitters});
+                    ++n_emitters;
+                } else if (type == "point") {   // src/emitter/point.cpp: position, radiant_intensity, optional spatial_extent
+                    const xnode_t* sp = n.named("radiant_intensity");
+                    if (!sp) throw std::runtime_error("point emitter: radiant_intensity expected");
+                    double scale = 1.0;
+                    if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
+                    xnode_t unscaled = *sp;
+                    unscaled.kids.clear();
+                    const int s = spectrum(unscaled);
+                    if (s == -2) continue;
+                    const xnode_t* pos = n.named("position");
+                    if (!pos) throw std::runtime_error("point emitter: position expected");
+                    float pse = 1.f, extent = -1.f;
+                    if (const xnode_t* r = n.named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
+                    if (const xnode_t* r = n.named("spatial_extent")) extent = (float)parse_dim(r->get("value"), DIM_LENGTH, "spatial_extent");
+                    b.add_emitter_point(read_vec3(*pos, DIM_LENGTH, 0.0, "position"), s, (float)scale, extent, pse);
                     emitter_keys.push_back({0, element_id, (int)n_emitters});
                     ++n_emitters;
                 } else if (type == "directional") {
@@ -984,7 +1039,9 @@ struct loader_t {
                         std::fprintf(stderr, "wtgpu: %s is a Git-LFS pointer: using the procedural stand-in\n", full.c_str());
                         M = Ms;   // the stand-in is placed in world space (the asset's model units are unknown)
                         face_normals = fns;
-                    } else
+                    } else if (is_lfs_pointer(full))
+                        throw std::runtime_error(full + " is a Git-LFS pointer file: the asset is absent from this checkout and has no bundled stand-in");
+                    else
                         mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0));
                 } else
                     throw std::runtime_error("shape type \"" + type + "\" is not supported by the minimal reader");
