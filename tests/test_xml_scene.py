@@ -94,6 +94,26 @@ def test_reference_sphere_polarization_xml(built):
         assert (np.abs(v[..., q::4] + l[..., q::4]) <= I * (1 + 1e-6) + 1e-12).all()
 
 
+ROOM = "/root/reference/scenes/bidir_room/room.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(ROOM) or not os.path.isdir("/root/reference/data/ior"), reason="the reference checkout is not present on this machine")
+def test_reference_room_xml_header_is_the_bundled_room(built, monkeypatch):
+    """scenes/bidir_room/room.xml (BASELINE.json configs[4]): its 46 PLY meshes are Git-LFS pointers without stand-ins, so only what does not
+    depend on the geometry is compared with the bundled `bidir_room` (-Dwtgpu_missing_assets=skip leaves the meshes out): the sensor
+    record (matrix camera, 42 deg along x => the vertical field of view of a 30 : 17 film, phase-space extent scale), the integrator
+    options and the two CFL spots (position, direction, cutoff, the default falloff of .75 x cutoff, scales, selection weights)."""
+    from wave_tracer_amd import Scene
+    monkeypatch.setenv("WTGPU_DATA_DIR", "/root/reference/data")
+    a = Scene.from_xml(ROOM, defines={"wtgpu_missing_assets": "skip"}, res=60, lut=(32, 32))
+    b = Scene("bidir_room", res=60, mesh_detail=0, lut=(32, 32))
+    assert (a.width, a.height) == (b.width, b.height) == (60, 34)
+    assert a.first_difference(b, "sensor") == "" and a.first_difference(b, "opts") == ""
+    assert a.emitter_summary() == b.emitter_summary()
+    ems = a.emitter_summary()
+    assert [round(e["cutoff_deg"], 3) for e in ems] == [.4, 13.0] and [round(e["falloff_deg"], 3) for e in ems] == [.2, 9.75]
+
+
 def test_emitter_order_follows_the_reference_loader(built, tmp_path):
     """Free emitters are listed by element id (unnamed elements: "__unnamed_$<n>" in file order, compared as STRINGS, so $10 sorts before
     $9), area emitters after them in shape order (src/scene/loader/loader.cpp:131-133,272-310)."""

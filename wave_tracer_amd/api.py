@@ -86,6 +86,7 @@ def load_library():
     lib.wtgpu_scene_create_from_desc.argtypes = [vp, C.POINTER(vp)]
     lib.wtgpu_scene_create_from_xml.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(SceneParams), C.POINTER(vp)]
     lib.wtgpu_scene_compare.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
+    lib.wtgpu_scene_compare_part.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.c_size_t]
     lib.wtgpu_render_progressive.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64, u32, PROGRESS_CB, vp, C.POINTER(u64)]
     lib.wtgpu_cancel.argtypes = [vp]
     lib.wtgpu_comm_unique_id.argtypes = [vp]
@@ -186,10 +187,14 @@ class Scene:
         self.device = None
         return self
 
-    def first_difference(self, other):
-        """Test hook (wtgpu_scene_compare): '' when the two flattened scenes are identical byte for byte, else the first differing array."""
+    def first_difference(self, other, part=None):
+        """Test hook (wtgpu_scene_compare[_part]): '' when the two flattened scenes are identical byte for byte, else the first differing
+        array.  part: "sensor" | "opts" | "emitters" compares only that record."""
         buf = C.create_string_buffer(256)
-        rc = load_library().wtgpu_scene_compare(self._h, other._h, buf, 256)
+        if part:
+            rc = load_library().wtgpu_scene_compare_part(self._h, other._h, part.encode(), buf, 256)
+        else:
+            rc = load_library().wtgpu_scene_compare(self._h, other._h, buf, 256)
         if rc not in (0, 1):
             _check(rc)
         return buf.value.decode()

@@ -1737,7 +1737,10 @@ std::string scene_builder_t::stats() const {
     for (size_t i = 0; i < emitters_.size(); ++i) {
         const emitter_t& e = emitters_[i];
         o << (i ? ", " : "") << "{\"type\": \"" << names[e.type & 3] << "\", \"cutoff_deg\": " << e.cutoff * 180.0 / M_PI << ", \"shape\": " << e.shape
-          << ", \"select_pmf\": " << e.select_pmf << ", \"in_range_fraction\": " << (i < emitter_in_range_.size() ? emitter_in_range_[i] : 1.0) << "}";
+          << ", \"select_pmf\": " << e.select_pmf << ", \"in_range_fraction\": " << (i < emitter_in_range_.size() ? emitter_in_range_[i] : 1.0)
+          << ", \"falloff_deg\": " << e.falloff * 180.0 / M_PI << ", \"scale\": " << e.scale << ", \"phase_space_extent_scale\": " << e.phase_space_extent_scale
+          << ", \"position\": [" << e.position.x << ", " << e.position.y << ", " << e.position.z << "], \"direction\": [" << e.frame.n.x << ", " << e.frame.n.y
+          << ", " << e.frame.n.z << "]}";
     }
     o << "]}";
     return o.str();

@@ -289,8 +289,8 @@ static void build_room(const scene_params_t& p, scene_builder_t& b) {
     const double cam[16] = {-0.00500708, -0.00467005, -0.999977, 12 * cm, 0, 0.999989, -0.00467011, 2.66 * cm,
                             0.999987,    -2.34659e-005, -0.00502464, -0.5 * cm, 0, 0, 0, 1};
     const uint32_t w = p.res, h = std::max(1u, (uint32_t)std::lround(p.res * 17.0 / 30.0));
-    // fov_axis = x: set_sensor_perspective takes the fov along x
-    b.set_sensor_perspective(xform_t::from_rows(cam), deg(42), w, h, .25f, false);
+    // fov_axis = x: 42 deg is the HORIZONTAL field of view; set_sensor_perspective takes the vertical one (perspective.cpp:134-137)
+    b.set_sensor_perspective(xform_t::from_rows(cam), 2.0 * std::atan(std::tan(deg(42) / 2) / (double(w) / double(h))), w, h, .25f, false);
     const float D55[3] = {0.95682f, 1.00000f, 0.92149f};
     b.set_response_rgb(D55);
 

@@ -224,12 +224,32 @@ struct expr_t {
             if (w == "true") return 1.0;
             if (w == "false") return 0.0;
             if (w == "pi") return M_PI;
-            if (w == "sin" || w == "cos" || w == "tan" || w == "sqrt" || w == "abs") {
-                if (!eat("(")) fail("'(' expected after " + w);
-                const double a = lor();
-                if (!eat(")")) fail("')' expected");
-                return w == "sin" ? std::sin(a) : w == "cos" ? std::cos(a) : w == "tan" ? std::tan(a) : w == "sqrt" ? std::sqrt(a) : std::fabs(a);
-            }
+            static const std::pair<const char*, double (*)(double)> f1[] = {
+                {"sin", [](double a) { return std::sin(a); }},     {"cos", [](double a) { return std::cos(a); }},   {"tan", [](double a) { return std::tan(a); }},
+                {"asin", [](double a) { return std::asin(a); }},   {"acos", [](double a) { return std::acos(a); }}, {"atan", [](double a) { return std::atan(a); }},
+                {"sqrt", [](double a) { return std::sqrt(a); }},   {"abs", [](double a) { return std::fabs(a); }},  {"exp", [](double a) { return std::exp(a); }},
+                {"log", [](double a) { return std::log(a); }},     {"round", [](double a) { return std::round(a); }},
+                {"floor", [](double a) { return std::floor(a); }}, {"ceil", [](double a) { return std::ceil(a); }}};
+            static const std::pair<const char*, double (*)(double, double)> f2[] = {{"min", [](double a, double c) { return std::min(a, c); }},
+                                                                                     {"max", [](double a, double c) { return std::max(a, c); }},
+                                                                                     {"pow", [](double a, double c) { return std::pow(a, c); }},
+                                                                                     {"atan2", [](double a, double c) { return std::atan2(a, c); }}};
+            for (auto& f : f1)
+                if (w == f.first) {
+                    if (!eat("(")) fail("'(' expected after " + w);
+                    const double a = lor();
+                    if (!eat(")")) fail("')' expected");
+                    return f.second(a);
+                }
+            for (auto& f : f2)
+                if (w == f.first) {
+                    if (!eat("(")) fail("'(' expected after " + w);
+                    const double a = lor();
+                    if (!eat(",")) fail("',' expected in " + w + "(a, b)");
+                    const double c = lor();
+                    if (!eat(")")) fail("')' expected");
+                    return f.second(a, c);
+                }
             fail("unknown identifier " + w);
         }
         const char* b = s.c_str() + i;
@@ -716,6 +736,13 @@ struct loader_t {
             out.scale *= (float)eval_number(n.get("scale"));
             return true;
         }
+        if (type == "scale") {   // <bsdf type="scale"><spectrum name="scale" constant=…/><bsdf …/></bsdf> (src/bsdf/scale.cpp:50-57)
+            const xnode_t *sc = n.named("scale"), *in = n.child("bsdf");
+            if (!sc || !in) throw std::runtime_error("scale bsdf: a `scale` spectrum and a nested <bsdf> expected");
+            if (!material(*in, two_sided, out)) return false;
+            out.scale *= const_of(*sc, "scale bsdf");
+            return true;
+        }
         if (type == "dielectric") {
             const xnode_t* ior = n.named("IOR");
             if (!ior) throw std::runtime_error("dielectric bsdf: IOR expected");
@@ -881,7 +908,14 @@ struct loader_t {
             if (const xnode_t* r = sensor->named("ray_trace_only")) rto = eval_number(r->get("value")) != 0.0;
             float pse = 1.f;
             if (const xnode_t* r = sensor->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
-            b.set_sensor_perspective(to_world(*sensor, {0, 1, 0}), parse_dim(fov->get("value"), DIM_ANGLE, "fov"), W, H, pse, rto);
+            // `fov` is the VERTICAL field of view unless fov_axis = "x" (src/sensor/perspective.cpp:65,113-137)
+            double fov_y = parse_dim(fov->get("value"), DIM_ANGLE, "fov");
+            if (const xnode_t* ax = sensor->named("fov_axis")) {
+                const std::string v = ax->get("value");
+                if (v != "x" && v != "y") throw std::runtime_error("(perspective sensor loader) unsupported 'fov_axis'");
+                if (v == "x") fov_y = 2.0 * std::atan(std::tan(fov_y / 2) / (double(W) / double(H)));
+            }
+            b.set_sensor_perspective(to_world(*sensor, {0, 1, 0}), fov_y, W, H, pse, rto);
         } else
             throw std::runtime_error("sensor type \"" + stype + "\" is not supported");
         if (const xnode_t* r = film->named("rfilter_scale")) b.set_film_rfilter_scale((float)eval_number(r->get("value")));
@@ -927,11 +961,12 @@ struct loader_t {
                     const int s = spectrum(unscaled);
                     if (s == -2) continue;
                     const xnode_t *bw = n.named("beam_width"), *co = n.named("cutoff_angle");
-                    if (!bw || !co) throw std::runtime_error("spot emitter: beam_width and cutoff_angle expected");
+                    if (!co) throw std::runtime_error("spot emitter: cutoff_angle expected");
                     float pse = 1.f;
                     if (const xnode_t* r = n.named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
-                    b.add_emitter_spot(to_world(n, {0, 1, 0}), s, (float)scale, (float)parse_dim(co->get("value"), DIM_ANGLE, "cutoff_angle"),
-                                       (float)parse_dim(bw->get("value"), DIM_ANGLE, "beam_width"), -1.f, pse);
+                    const double cutoff = parse_dim(co->get("value"), DIM_ANGLE, "cutoff_angle");
+                    b.add_emitter_spot(to_world(n, {0, 1, 0}), s, (float)scale, (float)cutoff,
+                                       bw ? (float)parse_dim(bw->get("value"), DIM_ANGLE, "beam_width") : (float)(cutoff * .75) /* spot.cpp:120-121 */, -1.f, pse);
                     emitter_keys.push_back({0, element_id, (int)n_emitters});
                     ++n_emitters;
                 } else if (type == "point") {   // src/emitter/point.cpp: position, radiant_intensity, optional spatial_extent
@@ -1039,8 +1074,15 @@ struct loader_t {
                         std::fprintf(stderr, "wtgpu: %s is a Git-LFS pointer: using the procedural stand-in\n", full.c_str());
                         M = Ms;   // the stand-in is placed in world space (the asset's model units are unknown)
                         face_normals = fns;
-                    } else if (is_lfs_pointer(full))
+                    } else if (is_lfs_pointer(full)) {
+                        // -Dwtgpu_missing_assets=skip: leave such shapes out (to inspect what else a scene file describes)
+                        const auto sk = defs.find("wtgpu_missing_assets");
+                        if (sk != defs.end() && sk->second == "skip") {
+                            std::fprintf(stderr, "wtgpu: %s is a Git-LFS pointer: shape skipped\n", full.c_str());
+                            continue;
+                        }
                         throw std::runtime_error(full + " is a Git-LFS pointer file: the asset is absent from this checkout and has no bundled stand-in");
+                    }
                     else
                         mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0));
                 } else

@@ -1205,14 +1205,27 @@ int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, ui
 
 // Test hook: field-by-field comparison of two flattened scenes (every array the description names, byte for byte).  0: identical;
 // 1: different — `what` names the first difference.
-int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, size_t n_what) {
+// `only`: nullptr = everything, else one of "sensor", "opts", "emitters" (records that do not depend on the geometry: a scene file whose
+// meshes are absent can still be checked for what else it describes)
+static int scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, const char* only, char* what, size_t n_what) {
     if (!a || !b) return fail(WTGPU_ERR_INVALID, "null scene");
     const scene_t &x = a->host, &y = b->host;
     std::string diff;
+    const std::string part = only ? only : "";
+    auto wanted = [&](const char* name) {
+        if (part.empty()) return true;
+        const std::string n(name);
+        if (part == "sensor") return n == "sensor";
+        if (part == "opts") return n == "opts";
+        if (part == "emitters") return n == "n_emitters" || n == "emitters" || n == "emitter_cdf";
+        return false;
+    };
     auto cnt = [&](const char* name, uint64_t u, uint64_t v) {
+        if (!wanted(name)) return;
         if (diff.empty() && u != v) diff = std::string(name) + ": " + std::to_string(u) + " vs " + std::to_string(v);
     };
     auto arr = [&](const char* name, const void* u, const void* v, size_t bytes, size_t elem) {
+        if (!wanted(name)) return;
         if (!diff.empty() || bytes == 0) return;
         if (!u || !v) {
             if (u != v) diff = std::string(name) + ": missing array";
@@ -1251,7 +1264,7 @@ int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, 
     arr("textures", x.textures, y.textures, sizeof(texture_t) * x.n_textures, sizeof(texture_t));
     arr("emitters", x.emitters, y.emitters, sizeof(emitter_t) * x.n_emitters, sizeof(emitter_t));
     arr("emitter_cdf", x.emitter_cdf, y.emitter_cdf, sizeof(float) * (x.n_emitters + 1), sizeof(float));
-    if (diff.empty()) {
+    if (diff.empty() && part.empty()) {
         size_t nsd = 0, nkd = 0, nk = 0;
         for (uint32_t i = 0; i < x.n_spectra; ++i)
             if (x.spectra[i].type != SPEC_CONST && x.spectra[i].type != SPEC_DISCRETE) nsd = std::max<size_t>(nsd, x.spectra[i].offset + (size_t)x.spectra[i].count * (x.spectra[i].is_complex ? 2 : 1));
@@ -1270,6 +1283,11 @@ int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, 
         what[n_what - 1] = 0;
     }
     return diff.empty() ? 0 : 1;
+}
+int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, size_t n_what) { return scene_compare(a, b, nullptr, what, n_what); }
+int wtgpu_scene_compare_part(const wtgpu_scene* a, const wtgpu_scene* b, const char* part, char* what, size_t n_what) {
+    if (!part) return fail(WTGPU_ERR_INVALID, "null part");
+    return scene_compare(a, b, part, what, n_what);
 }
 
 int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* desc, wtgpu_scene** out) {

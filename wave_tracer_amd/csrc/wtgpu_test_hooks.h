@@ -12,6 +12,8 @@ typedef struct wtgpu_test_hooks {
 int wtgpu_scene_create_named_hooks(const char* name, const wtgpu_scene_params* params, const wtgpu_test_hooks* hooks, wtgpu_scene** out);
 /* field-by-field (byte-for-byte) comparison of two flattened scenes: 0 identical, 1 different (`what`: the first difference) */
 int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, size_t n_what);
+/* the same restricted to one part: "sensor", "opts" or "emitters" (records that do not depend on the geometry) */
+int wtgpu_scene_compare_part(const wtgpu_scene* a, const wtgpu_scene* b, const char* part, char* what, size_t n_what);
 #ifdef __cplusplus
 }
 #endif
