@@ -114,6 +114,23 @@ def test_reference_room_xml_header_is_the_bundled_room(built, monkeypatch):
     assert [round(e["cutoff_deg"], 3) for e in ems] == [.4, 13.0] and [round(e["falloff_deg"], 3) for e in ems] == [.2, 9.75]
 
 
+ETOILE = "/root/reference/scenes/sionna_etoile/etoile.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(ETOILE), reason="the reference checkout is not present on this machine")
+def test_reference_etoile_xml_header_is_the_bundled_etoile(built):
+    """scenes/sionna_etoile/etoile.xml -Dwavelength=10GHz (BASELINE.json configs[3]), its 40 Git-LFS meshes left out: the coverage sensor
+    (virtual plane 840 m x 630 m, alpha .001 deg, rfilter_scale .1, 10 GHz line), the enabled integrator (forward plt_path, depth 16,
+    no Russian roulette) and the transmitter are those of the bundled `etoile`, byte for byte resp. field by field; the D65 / D55
+    preview emitters have no overlap with a 10 GHz line and are dropped."""
+    from wave_tracer_amd import Scene
+    a = Scene.from_xml(ETOILE, defines={"wtgpu_missing_assets": "skip", "wavelength": "10GHz"}, res=64)
+    b = Scene("etoile", res=64, mesh_detail=0)
+    assert (a.width, a.height, a.channels, a.info.integrator) == (64, 48, 1, 1)
+    assert a.first_difference(b, "sensor") == "" and a.first_difference(b, "opts") == ""
+    assert a.emitter_summary() == b.emitter_summary() and a.emitter_summary()[0]["type"] == "point"
+
+
 def test_emitter_order_follows_the_reference_loader(built, tmp_path):
     """Free emitters are listed by element id (unnamed elements: "__unnamed_$<n>" in file order, compared as STRINGS, so $10 sorts before
     $9), area emitters after them in shape order (src/scene/loader/loader.cpp:131-133,272-310)."""
