@@ -526,3 +526,48 @@ def test_radio_scene_vocabulary_bakes_to_the_bundled_etoile(built, tmp_path):
     f.write_text(_radio_city_xml().replace('ITU="wood"', 'ITU="cheese"'))
     with pytest.raises(WtgpuError, match="cheese"):
         Scene.from_xml(str(f), res=64)
+
+
+def test_surface_profiles_in_scene_files(built, tmp_path):
+    """dirac / fractal / gaussian (roughness or explicit rms `sigma`) surface profiles, written like the reference's scene files: the
+    XML twin of the bundled `furnace_spm` renders the same film bit for bit."""
+    from wave_tracer_amd import Scene
+    xml = '''<scene version="0.1.0">
+  <integrator type="plt_bdpt"><integer name="max_depth" value="8"/><boolean name="FSD" value="false"/></integrator>
+  <sensor type="perspective"><quantity name="fov" value="60°"/>
+    <transform name="to_world"><lookat origin="0m, 0m, .9m" target="0m, 0m, 0m" up="0, 1, 0"/></transform>
+    <film type="array"><integer name="width" value="$res"/><integer name="height" value="$res"/>
+      <response type="RGB"><string name="white_point" value="E"/></response></film></sensor>
+  <bsdf type="twosided" id="grey"><bsdf type="diffuse"><spectrum name="reflectance" constant=".5"/></bsdf></bsdf>
+  <shape type="cube"><quantity name="length" value="2m"/><ref id="grey"/></shape>
+  <shape type="rectangle"><point name="p" x="-.25m" y=".95m" z="-.25m"/><point name="x" x="0m" y="0m" z=".5m"/><point name="y" x=".5m" y="0m" z="0m"/>
+    <bsdf type="diffuse"><spectrum name="reflectance" constant="0"/></bsdf>
+    <emitter type="area"><spectrum name="radiance" blackbody="6000K"><float name="scale" value="1e-6"/></spectrum></emitter></shape>
+  <shape type="cube"><quantity name="length" value=".3m"/>
+    <transform name="to_world"><rotate y="1" angle="30°"/><translate x=".2m" y="-.3m" z="-.2m"/></transform>
+    <bsdf type="twosided"><bsdf type="surface_spm"><spectrum name="IOR" material="Al"/>
+      <surface_profile type="gaussian"><spectrum name="roughness" constant=".15"/></surface_profile></bsdf></bsdf></shape>
+  <shape type="cube"><quantity name="length" value=".25m"/>
+    <transform name="to_world"><rotate y="1" angle="-20°"/><translate x="-.35m" y="-.3m" z="-.1m"/></transform>
+    <bsdf type="twosided"><bsdf type="surface_spm"><spectrum name="IOR" material="Au"/>
+      <surface_profile type="gaussian"><quantity name="sigma" value="1.5 1/um"/></surface_profile></bsdf></bsdf></shape>
+  <shape type="cube"><quantity name="length" value=".2m"/>
+    <transform name="to_world"><rotate x="1" angle="25°"/><translate x="-.05m" y="-.55m" z=".25m"/></transform>
+    <bsdf type="twosided"><bsdf type="surface_spm"><spectrum name="IOR" material="Al"/>
+      <surface_profile type="fractal"><spectrum name="roughness" constant=".2"/></surface_profile></bsdf></bsdf></shape>
+</scene>'''
+    f = tmp_path / "furnace_spm.xml"
+    f.write_text(xml)
+    a = Scene.from_xml(str(f), res=16, lut=(32, 32))
+    b = Scene("furnace_spm", res=16, lut=(32, 32))
+    va, wa, la, ca = oracle_render(a, 0, 4, 9)
+    vb, wb, lb, cb = oracle_render(b, 0, 4, 9)
+    assert ca == cb and np.array_equal(va, vb) and np.array_equal(la, lb) and va.sum() > 0
+    # a dirac profile is another material: the film changes
+    f.write_text(xml.replace('<surface_profile type="fractal"><spectrum name="roughness" constant=".2"/></surface_profile>', '<surface_profile type="dirac"/>'))
+    vd = oracle_render(Scene.from_xml(str(f), res=16, lut=(32, 32)), 0, 4, 9)[0]
+    assert not np.array_equal(vd, va)
+    from wave_tracer_amd.api import WtgpuError
+    f.write_text(xml.replace('value="1.5 1/um"', 'value="1.5 um"'))
+    with pytest.raises(WtgpuError, match="sigma"):
+        Scene.from_xml(str(f), res=16)

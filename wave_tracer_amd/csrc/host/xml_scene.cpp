@@ -808,20 +808,39 @@ struct loader_t {
             // surface profiles (src/interaction/surface_profile/{dirac,fractal,gaussian}.cpp): the roughness-parametrised forms with a
             // constant roughness (T / sigma_h resp. sigma textures are not supported)
             bool fractal = false, gaussian = false;
-            float roughness = 0.f, gamma = 3.f;
+            float roughness = 0.f, gamma = 3.f, gauss_sigma = 0.f;
             if (const xnode_t* sp = n.child("surface_profile")) {
                 const std::string pt = sp->get("type");
                 if (pt == "fractal" || pt == "gaussian") {
                     (pt == "fractal" ? fractal : gaussian) = true;
-                    const xnode_t* ro = sp->named("roughness");
-                    if (!ro || !ro->attr("constant")) throw std::runtime_error(pt + " profile: a constant `roughness` spectrum is expected");
-                    roughness = (float)eval_number(ro->get("constant"));
+                    const xnode_t *ro = sp->named("roughness"), *sg = pt == "gaussian" ? sp->named("sigma") : nullptr;
+                    if (sg) {   // explicit rms roughness [1/length] (gaussian.cpp:44-61: either `roughness` or `sigma`)
+                        if (ro) throw std::runtime_error("(gaussian surface_profile loader) Either 'roughness' or 'sigma' must be provided");
+                        const std::string v = trim(sg->get("value"));
+                        static const std::pair<const char*, double> units[] = {{"1/mm", 1.0}, {"1/um", 1e3}, {"1/m", 1e-3}, {"1/cm", 1e-1}, {"1/nm", 1e6}};
+                        bool ok = false;
+                        for (auto& u : units) {
+                            const std::string suf(u.first);
+                            if (v.size() > suf.size() && v.compare(v.size() - suf.size(), suf.size(), suf) == 0) {
+                                gauss_sigma = (float)(eval_number(v.substr(0, v.size() - suf.size())) * u.second);
+                                ok = true;
+                                break;
+                            }
+                        }
+                        if (!ok || !(gauss_sigma > 0.f)) throw std::runtime_error("gaussian profile: sigma \"" + v + "\": a positive value in 1/mm, 1/um, 1/m, 1/cm or 1/nm expected");
+                    } else {
+                        if (!ro || !ro->attr("constant")) throw std::runtime_error(pt + " profile: a constant `roughness` spectrum is expected");
+                        roughness = (float)eval_number(ro->get("constant"));
+                    }
                     if (const xnode_t* g = sp->named("gamma")) gamma = (float)eval_number(g->get("value"));
                 } else if (pt != "dirac")
                     throw std::runtime_error("surface_profile type \"" + pt + "\" is not supported (dirac | fractal | gaussian)");
             }
             out = mat_spm(s, fractal, roughness, gamma, two_sided, 1.f);
-            if (gaussian) out.profile = PROFILE_GAUSSIAN;
+            if (gaussian) {
+                out.profile = PROFILE_GAUSSIAN;
+                out.gauss_sigma = gauss_sigma;
+            }
             interface_extras(n, out);
             return true;
         }
