@@ -104,6 +104,10 @@ typedef struct wtgpu_material {
     uint32_t mask_tex;      /* mask: opacity texture (0: the constant mask_alpha) */
     uint32_t normal_tex;    /* normalmap wrapper (bsdf/normalmap.hpp:48-62), flattened onto the material it wraps */
     uint32_t normal_flip;
+    /* scale wrapper whose factor is a spectrum (bsdf/scale.hpp:78-97 with a spectrum in place of a constant): spectrum index + 1, 0 = none; */
+    /* multiplies `scale` */
+    uint32_t scale_spec;
+    uint32_t scale_tex;     /* ... or a texture (scale->f(tquery).x): texture index + 1, 0 = none */
 } wtgpu_material;
 
 /* ---- textures (include/wt/texture/texture.hpp:29-90) ------------------------------------------------------------------------------ */

@@ -441,6 +441,9 @@ def test_texture_nodes_in_scene_files(built, tmp_path):
     write_pfm(str(tmp_path / "c.pfm"), tx)
     img, _ = _render_dev(Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(tmp_path / "c.pfm")}))
     assert np.array_equal(img, ref)
+    # the checker as the textured factor of a scale wrapper over a white diffuse wall: the same film (to rounding)
+    img5, c5 = _render_dev(Scene.from_xml(TEX, defines={"variant": 5}))
+    assert c5 == cr and np.abs(img5 - ref).max() <= 1e-6 * ref.max()
     ref, cr = _render_dev(Scene("tex_mask", res=32))
     img, ci = _render_dev(Scene.from_xml(TEX, defines={"variant": 3}))
     assert np.array_equal(img, ref) and ci == cr
@@ -571,3 +574,42 @@ def test_surface_profiles_in_scene_files(built, tmp_path):
     f.write_text(xml.replace('value="1.5 1/um"', 'value="1.5 um"'))
     with pytest.raises(WtgpuError, match="sigma"):
         Scene.from_xml(str(f), res=16)
+
+
+def test_spectral_scale_bsdf(built, tmp_path):
+    """<bsdf type="scale"><spectrum name="scale" rgb=…/>…: the factor is a spectrum (bsdf/scale.hpp:78-97), evaluated per wavenumber on the
+    device (material_t::scale_spec).  Closed box of diffuse walls seen by an RGB sensor: scaling a white wall (reflectance 1 -> the
+    clamp leaves it alone) by rgb(.8, .4, .2) must give the film of walls whose REFLECTANCE is rgb(.8, .4, .2) — bit for bit the same
+    samples, equal to rounding (the product is taken at different points); a constant spectrum written as rgb(.5, .5, .5)
+    is the constant scale .5 up to the uplift's tabulated white (1e-3)."""
+    from wave_tracer_amd import Scene
+
+    def scene(wall):
+        return f'''<scene version="0.1.0">
+  <integrator type="plt_bdpt"><integer name="max_depth" value="5"/><boolean name="FSD" value="false"/></integrator>
+  <sensor type="perspective"><quantity name="fov" value="60°"/>
+    <transform name="to_world"><lookat origin="0m, 0m, .9m" target="0m, 0m, 0m" up="0, 1, 0"/></transform>
+    <film type="array"><integer name="width" value="12"/><integer name="height" value="12"/>
+      <response type="RGB"><string name="white_point" value="E"/></response></film></sensor>
+  <shape type="cube"><quantity name="length" value="2m"/><bsdf type="twosided">{wall}</bsdf></shape>
+  <shape type="rectangle"><point name="p" x="-.25m" y=".95m" z="-.25m"/><point name="x" x="0m" y="0m" z=".5m"/><point name="y" x=".5m" y="0m" z="0m"/>
+    <bsdf type="diffuse"><spectrum name="reflectance" constant="0"/></bsdf>
+    <emitter type="area"><spectrum name="radiance" blackbody="6000K"><float name="scale" value="1e-6"/></spectrum></emitter></shape>
+</scene>'''
+
+    def film(wall):
+        f = tmp_path / "s.xml"
+        f.write_text(scene(wall))
+        sc = Scene.from_xml(str(f), lut=(32, 32))
+        v, w, l, c = oracle_render(sc, 0, 8, 5)
+        return v + l, c
+    white = '<bsdf type="diffuse"><spectrum name="reflectance" constant="1"/></bsdf>'
+    a, ca = film(f'<bsdf type="scale"><spectrum name="scale" rgb=".8, .4, .2"/>{white}</bsdf>')
+    b, cb = film('<bsdf type="diffuse"><spectrum name="reflectance" rgb=".8, .4, .2"/></bsdf>')
+    assert ca == cb and a.sum() > 0
+    assert np.abs(a - b).max() <= 1e-5 * b.max()
+    # red dominates the film of the reddish walls
+    assert a[..., 0].sum() > 1.5 * a[..., 2].sum()
+    g, _ = film(f'<bsdf type="scale"><spectrum name="scale" rgb=".5, .5, .5"/>{white}</bsdf>')
+    h, _ = film(f'<bsdf type="scale"><spectrum name="scale" constant=".5"/>{white}</bsdf>')
+    assert np.abs(g - h).max() <= 2e-3 * h.max()

@@ -616,11 +616,51 @@ struct loader_t {
             if (scale != 1.0) throw std::runtime_error("<spectrum ITU=…>: scale is not supported");
             return b.spectrum_itu(n.get("ITU"), (float)line_mm);
         }
+        // piecewise_linear (<bin wavelength= value=/> knots, linear in WAVENUMBER between them, 0 outside: piecewise_linear.cpp:45-80) and
+        // gaussian (value x exp(-(k - k0)^2 / 2 s^2) with s = k(mean) - k(mean + stddev), cut at 10 s: gaussian.cpp:60-77), baked on the
+        // library's 0.5-nm table over 340..840 nm
+        if (n.get("type") == "piecewise_linear" || n.get("type") == "gaussian") {
+            if (mono) return -2;   // continuous spectrum x line sensor
+            const int N = 1001;
+            const double l0 = 340.0, dl = 0.5;
+            std::vector<float> v(N, 0.f);
+            if (n.get("type") == "gaussian") {
+                const double mean = parse_wavelength(n.get("wavelength"), "gaussian spectrum wavelength").si(), sd = parse_wavelength(n.get("stddev"), "gaussian spectrum stddev").si();
+                const double val = n.attr("value") ? eval_number(n.get("value")) : 1.0;
+                if (val < 0 || sd < 0) throw std::runtime_error("(gaussian spectrum loader) a non-negative value and standard deviation must be provided");
+                const double k0 = 2 * M_PI / mean, sk = k0 - 2 * M_PI / (mean + sd);
+                for (int i = 0; i < N; ++i) {
+                    const double k = 2 * M_PI / ((l0 + dl * i) * 1e-9), d = k - k0;
+                    v[i] = sk > 0 && std::fabs(d) <= 10 * sk ? (float)(val * scale * std::exp(-.5 * d * d / (sk * sk))) : 0.f;
+                }
+            } else {
+                std::vector<std::pair<double, double>> knots;   // (k, value)
+                for (auto& c : n.kids)
+                    if (c.name == "bin") {
+                        const double wl = parse_wavelength(c.get("wavelength"), "piecewise_linear bin").si(), val = eval_number(c.get("value"));
+                        if (!(wl > 0) || val < 0) throw std::runtime_error("(piecewise_linear spectrum loader) wavelength must be positive and value must be non-negative");
+                        knots.push_back({2 * M_PI / wl, val * scale});
+                    }
+                if (knots.size() < 2) throw std::runtime_error("(piecewise_linear spectrum loader) at least 2 spectrum values must be provided");
+                std::sort(knots.begin(), knots.end());
+                for (int i = 0; i < N; ++i) {
+                    const double k = 2 * M_PI / ((l0 + dl * i) * 1e-9);
+                    if (k < knots.front().first || k > knots.back().first) continue;
+                    size_t j = 0;
+                    while (j + 2 < knots.size() && knots[j + 1].first < k) ++j;
+                    const double f = (k - knots[j].first) / (knots[j + 1].first - knots[j].first);
+                    v[i] = (float)(knots[j].second * (1 - f) + knots[j + 1].second * f);
+                }
+            }
+            return b.spectrum_from_wavelength_table(v.data(), nullptr, N, (float)l0, (float)dl);
+        }
         if (n.attr("blackbody")) {
             if (mono) return -2;   // continuous spectrum x line sensor: see the header of this file
             return b.spectrum_blackbody((float)parse_dim(n.get("blackbody"), DIM_TEMPERATURE, "blackbody"), (float)scale);
         }
-        throw std::runtime_error("<spectrum>: unsupported kind");
+        std::string desc = "<" + n.name;
+        for (auto& at : n.attrs) desc += " " + at.first + "=\"" + at.second + "\"";
+        throw std::runtime_error(desc + ">: unsupported kind of spectrum");
     }
     // ---- textures (src/texture/texture_loader.cpp:30-62): constant, checkerboard (colour1 / colour2: a texture or a constant spectrum,
     // defaults 0 and 1), scale (constant `scale` spectrum x nested texture), transform (<matrix value="a,b,c,d"/>, <translate value="x,y"/>
@@ -714,33 +754,50 @@ struct loader_t {
         if (const xnode_t* r = n.named("reflection_scale")) out.refl_scale = const_of(*r, "reflection_scale");
         if (const xnode_t* t = n.named("transmission_scale")) out.trans_scale = const_of(*t, "transmission_scale");
     }
+    // <ref name=… id=…/> in place of a spectrum / texture: the shared top-level element of that id (loader.cpp:168-181)
+    const xnode_t* deref(const xnode_t* n) const {
+        if (!n || n->name != "ref") return n;
+        const std::string id = n->get("id");
+        for (auto& it : items)
+            if ((it.name == "texture" || it.name == "spectrum") && it.get("id") == id) return &it;
+        throw std::runtime_error("<ref id=\"" + id + "\">: no shared texture or spectrum of that id");
+    }
+    // what a wrapper wraps: a nested <bsdf>, or <ref id=…/> = a copy of a named BSDF's record.  FALSE: spectrally empty.
+    bool nested(const xnode_t& n, bool two_sided, material_t& out, const char* what) {
+        if (const xnode_t* in = n.child("bsdf")) return material(*in, two_sided, out);
+        if (const xnode_t* r = n.child("ref")) {
+            const auto it = materials.find(r->get("id"));
+            if (it == materials.end()) return false;
+            out = b.material(it->second);
+            if (two_sided) out.two_sided = 1;
+            return true;
+        }
+        throw std::runtime_error(std::string(what) + " without a nested <bsdf> or <ref id=…/>");
+    }
     // bsdf node -> material (two_sided accumulated from the wrappers)
     bool material(const xnode_t& n, bool two_sided, material_t& out) {
         const std::string type = n.get("type");
-        if (type == "twosided") {
-            if (const xnode_t* r = n.child("ref")) {   // <bsdf type="twosided"><ref id=…/></bsdf>: a two-sided copy of a named BSDF
-                const auto it = materials.find(r->get("id"));
-                if (it == materials.end()) return false;
-                out = b.material(it->second);
-                out.two_sided = 1;
-                return true;
-            }
-            const xnode_t* in = n.child("bsdf");
-            if (!in) throw std::runtime_error("twosided bsdf without a nested <bsdf>");
-            return material(*in, true, out);
-        }
+        if (type == "twosided") return nested(n, true, out, "twosided bsdf");
         if (type.empty() && n.attr("scale")) {   // scale wrapper (bsdf/scale.hpp) with a constant
-            const xnode_t* in = n.child("bsdf");
-            if (!in) throw std::runtime_error("scale bsdf without a nested <bsdf>");
-            if (!material(*in, two_sided, out)) return false;
+            if (!nested(n, two_sided, out, "scale bsdf")) return false;
             out.scale *= (float)eval_number(n.get("scale"));
             return true;
         }
         if (type == "scale") {   // <bsdf type="scale"><spectrum name="scale" constant=…/><bsdf …/></bsdf> (src/bsdf/scale.cpp:50-57)
-            const xnode_t *sc = n.named("scale"), *in = n.child("bsdf");
-            if (!sc || !in) throw std::runtime_error("scale bsdf: a `scale` spectrum and a nested <bsdf> expected");
-            if (!material(*in, two_sided, out)) return false;
-            out.scale *= const_of(*sc, "scale bsdf");
+            const xnode_t* sc = deref(n.named("scale"));
+            if (!sc) throw std::runtime_error("scale bsdf: a `scale` spectrum or texture expected");
+            if (!nested(n, two_sided, out, "scale bsdf")) return false;
+            if (sc->name == "texture") {   // a texture (luminance): material_t::scale_tex
+                if (out.scale_tex) throw std::runtime_error("scale bsdf: nested textured scales are not supported");
+                out.scale_tex = 1 + (uint32_t)texture(*sc);
+            } else if (sc->attr("constant"))
+                out.scale *= const_of(*sc, "scale bsdf");
+            else {   // a spectrum (rgb uplift, tables …): evaluated per wavenumber on the device (material_t::scale_spec)
+                if (out.scale_spec) throw std::runtime_error("scale bsdf: nested spectral scales are not supported");
+                const int sp = spectrum(*sc);
+                if (sp == -2) return false;
+                out.scale_spec = 1 + (uint32_t)sp;
+            }
             return true;
         }
         if (type == "dielectric") {
@@ -759,7 +816,7 @@ struct loader_t {
             return material(*in, two_sided, out);
         }
         if (type == "diffuse") {
-            const xnode_t* r = n.named("reflectance");
+            const xnode_t* r = deref(n.named("reflectance"));
             if (!r) throw std::runtime_error("diffuse bsdf: reflectance expected");
             if (r->name == "texture") {
                 // reflectance = spectrum x luminance texture: a `scale` texture's spectrum carries the wavelength dependence
@@ -783,22 +840,22 @@ struct loader_t {
             return true;
         }
         if (type == "mask") {   // src/bsdf/mask.cpp:94-124: a `mask` texture (or constant spectrum) and a nested bsdf
-            const xnode_t *mk = n.named("mask"), *in = n.child("bsdf");
+            const xnode_t* mk = deref(n.named("mask"));
             if (!mk) throw std::runtime_error("(mask bsdf loader) a real 'mask' spectrum must be provided");
-            if (!in) throw std::runtime_error("(mask bsdf loader) 'mask' bsdf must contain a nested bsdf");
             material_t inner{};
-            if (!material(*in, false, inner)) return false;
+            if (!nested(n, false, inner, "(mask bsdf loader) 'mask' bsdf")) return false;
             const int nested = b.add_material(inner);
             out = mat_mask(nested, mk->name == "spectrum" ? const_of(*mk, "mask") : 1.f, two_sided);
             if (mk->name == "texture") out.mask_tex = 1 + (uint32_t)texture(*mk);
             return true;
         }
         if (type == "normalmap") {   // bsdf/normalmap.hpp: the nested bsdf with a perturbed shading frame
-            const xnode_t *nm = n.named("normalmap"), *in = n.child("bsdf");
-            if (!nm || nm->name != "texture" || !in) throw std::runtime_error("normalmap bsdf: a `normalmap` texture and a nested bsdf expected");
-            if (!material(*in, two_sided, out)) return false;
+            const xnode_t* nm = n.child("texture");   // the texture child needs no name (src/bsdf/normalmap.cpp:43-45)
+            if (!nm) throw std::runtime_error("normalmap bsdf: a texture and a nested bsdf expected");
+            if (!nested(n, two_sided, out, "normalmap bsdf")) return false;
             out.normal_tex = 1 + (uint32_t)texture(*nm);
-            if (const xnode_t* f = n.named("flip")) out.normal_flip = eval_number(f->get("value")) != 0.0 ? 1u : 0u;
+            for (const char* name : {"flip_tangent", "flip"})
+                if (const xnode_t* f = n.named(name)) out.normal_flip = eval_number(f->get("value")) != 0.0 ? 1u : 0u;
             return true;
         }
         if (type == "surface_spm") {
@@ -1016,11 +1073,23 @@ struct loader_t {
                     if (s == -2) continue;
                     const xnode_t* t = n.named("to_world");
                     const xnode_t* la = t ? t->child("lookat") : nullptr;
-                    if (!la) throw std::runtime_error("directional emitter: <lookat> expected");
-                    const dvec3 og = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
-                    // the emitter's local -z is mapped from origin towards target: the direction TO the emitter is origin - target
-                    // (src/emitter/directional.cpp:118-120)
-                    b.add_emitter_directional({og.x - tg.x, og.y - tg.y, og.z - tg.z}, s, (float)scale, 6.794e-5f, 1.f);
+                    // dir = to_world (0, 0, -1) (src/emitter/directional.cpp:115-120) is the direction TO the emitter: with a lookat (local
+                    // +z from origin towards target) that is origin - target
+                    dvec3 to_emitter{0, 0, -1};
+                    if (la) {
+                        const dvec3 og = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
+                        to_emitter = {og.x - tg.x, og.y - tg.y, og.z - tg.z};
+                    } else if (t)
+                        to_emitter = to_world(n, {0, 1, 0}).vector({0, 0, -1});
+                    float sa = 6.794e-5f, pse = 1.f;   // the sun's solid angle (directional.cpp default)
+                    if (const xnode_t* r = n.named("solid_angle")) {
+                        std::string v = trim(r->get("value"));
+                        if (v.size() > 2 && v.compare(v.size() - 2, 2, "sr") == 0) v = v.substr(0, v.size() - 2);
+                        sa = (float)eval_number(v);
+                        if (!(sa > 0.f)) throw std::runtime_error("(directional emitter loader) 'solid_angle' cannot be vanishing or negative");
+                    }
+                    if (const xnode_t* r = n.named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
+                    b.add_emitter_directional(to_emitter, s, (float)scale, sa, pse);
                     emitter_keys.push_back({0, element_id, (int)n_emitters});
                     ++n_emitters;
                 } else

@@ -199,16 +199,27 @@ struct material_wrap_t {
     bool masked;      // a mask wrapper was passed
     bool mask_two;    // ... under a two_sided wrapper: the mask sees the flipped directions
 };
+// the non-constant factor of a scale wrapper (bsdf/scale.hpp:78-97: scale->f(tquery).x): a spectrum and / or a texture
+WT_HD float material_scale_factor(const scene_t& sc, const material_t& m, float k, vec2 uv) {
+    float f = 1.f;
+    if (m.scale_spec) f *= spectrum_f(sc, (int)m.scale_spec - 1, k);
+    if (m.scale_tex) f *= texture_f(sc, (int)m.scale_tex - 1, uv);
+    return f;
+}
 WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, material_t& m, material_wrap_t& wr) {
     m = sc.materials[mat];
     wr.alpha = 1.f;
     wr.masked = wr.mask_two = false;
-    if (m.type < MAT_COMPOSITE) return true;   // a leaf BSDF: the common case (only the fields the caller goes on to use are loaded)
+    if (m.type < MAT_COMPOSITE) {   // a leaf BSDF: the common case (only the fields the caller goes on to use are loaded)
+        if (m.scale_spec | m.scale_tex) m.scale *= material_scale_factor(sc, m, k, uv);
+        return true;
+    }
     uint32_t two = 0;
     float scale = 1.f;
     for (int depth = 0; depth < 4 && m.type >= MAT_COMPOSITE; ++depth) {
         two |= m.two_sided;
         scale *= m.scale;
+        if (m.scale_spec | m.scale_tex) scale *= material_scale_factor(sc, m, k, uv);
         int child = -1;
         if (m.type == MAT_MASK) {
             wr.alpha *= clamp01(m.mask_tex ? texture_f(sc, (int)m.mask_tex - 1, uv) : m.mask_alpha);   // mask.cpp:27, 50: clamp01(mask->f(tquery).x)
@@ -228,6 +239,7 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, materi
     if (m.type >= MAT_COMPOSITE) return false;   // nesting deeper than the flattener produces
     m.two_sided |= two;
     m.scale *= scale;
+    if (m.scale_spec | m.scale_tex) m.scale *= material_scale_factor(sc, m, k, uv);
     return true;
 }
 
