@@ -592,10 +592,13 @@ struct loader_t {
         }
         // named database spectra (spectrum_from_db.cpp): the tables baked into the library (Al, Au, Ag, Cu, SF5, SF11, BK7; the CFL emission
         // spectrum), else a file <data dir>/ior/<name>.yml resp. <data dir>/emission/<name>.yml (data dir: $WTGPU_DATA_DIR, or "data" next to
-        // the scene file)
+        // the scene file, or ../../data as in the reference's checkout)
         auto data_file = [&](const char* sub, const std::string& name) {
-            const char* env = getenv("WTGPU_DATA_DIR");
-            return (env ? std::string(env) : base_dir + "/data") + "/" + sub + "/" + name + ".yml";
+            const std::string rel = std::string("/") + sub + "/" + name + ".yml";
+            if (const char* env = getenv("WTGPU_DATA_DIR")) return std::string(env) + rel;
+            // "data" next to the scene file, else the reference checkout's layout (scenes/<name>/x.xml, data/ beside scenes/)
+            const std::string local = base_dir + "/data" + rel, checkout = base_dir + "/../../data" + rel;
+            return !std::ifstream(local).good() && std::ifstream(checkout).good() ? checkout : local;
         };
         // tabulated spectra cannot fold a scale: the emitters pass theirs separately (emitter_t::scale), elsewhere it must be 1
         if ((n.attr("material") || n.attr("emitter")) && scale != 1.0) throw std::runtime_error("<spectrum>: a scale on a database spectrum is supported for emitters only");
