@@ -159,6 +159,8 @@ float kat_kdist_sample(const void* scene_host, int emitter, float u, float* pdf_
     *pdf_out = w.wpd;
     return w.k;
 }
+// the per-lookup RGB uplift of spectral bitmap textures (wt/scene.h: rgb_uplift)
+float kat_rgb_uplift(float r, float g, float b, float k) { return rgb_uplift(r, g, b, k); }
 float kat_spectrum(const void* scene_host, int id, float k, float* im) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
     const cplx v = spectrum_value(sc, id, k);

@@ -63,6 +63,15 @@ def test_rgb_uplift_spectra(lib):
     assert abs(v650 - (.375 * 1.0 + (.39 - .375) * .9586)) < 0.02                          # yellow only
     assert abs(v450 - (.375 * .9999 + (.39 - .375) * .1088 + (.425 - .39) * .0273)) < 0.02
     assert refl(0, 300) == 0 and refl(0, 800) == 0
+    # the device's per-lookup uplift (RGB bitmaps read spectrally, wt/scene.h: rgb_uplift) is the same function as the baked table:
+    # equal in the interior of every bin (the table smooths the bin edges over ~1.5 nm)
+    lib.kat_rgb_uplift.restype = F
+    lib.kat_rgb_uplift.argtypes = [F, F, F, F]
+    for b in range(10):
+        lam = 380 + 34 * (b + .5)
+        got = lib.kat_rgb_uplift(F(.39), F(.425), F(.375), F(2 * math.pi / (lam * 1e-6)))
+        assert abs(got - refl(0, lam)) <= 1e-5, (lam, got, refl(0, lam))
+    assert lib.kat_rgb_uplift(F(.3), F(.5), F(.7), F(2 * math.pi / 370e-6)) == 0 and lib.kat_rgb_uplift(F(.3), F(.5), F(.7), F(2 * math.pi / 730e-6)) == 0
 
 
 def test_directional_emitter_target_disk(built):

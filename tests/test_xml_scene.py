@@ -613,3 +613,35 @@ def test_spectral_scale_bsdf(built, tmp_path):
     g, _ = film(f'<bsdf type="scale"><spectrum name="scale" rgb=".5, .5, .5"/>{white}</bsdf>')
     h, _ = film(f'<bsdf type="scale"><spectrum name="scale" constant=".5"/>{white}</bsdf>')
     assert np.abs(g - h).max() <= 2e-3 * h.max()
+
+
+def test_rgb_bitmap_reflectance_is_uplifted_per_lookup(built, tmp_path):
+    """bitmap.hpp:125-140: an RGB bitmap read as a spectral texture is uplifted at the query's wavenumber (RGB_to_spectral::uplift).  A
+    1 x 1 RGB bitmap of colour c as the reflectance of the walls of a closed box gives the film of walls with <spectrum rgb="c"/> — the
+    same samples; the values agree to 1 % (the spectrum is the same uplift baked on a 1-nm table, whose bin edges the table smooths)."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.imageio import write_pfm
+    write_pfm(str(tmp_path / "c.pfm"), np.array([[[.8, .4, .2]]], np.float32))
+
+    def film(refl):
+        f = tmp_path / "s.xml"
+        f.write_text(f'''<scene version="0.1.0">
+  <integrator type="plt_bdpt"><integer name="max_depth" value="5"/><boolean name="FSD" value="false"/></integrator>
+  <sensor type="perspective"><quantity name="fov" value="60°"/>
+    <transform name="to_world"><lookat origin="0m, 0m, .9m" target="0m, 0m, 0m" up="0, 1, 0"/></transform>
+    <film type="array"><integer name="width" value="12"/><integer name="height" value="12"/>
+      <response type="RGB"><string name="white_point" value="E"/></response></film></sensor>
+  <shape type="cube"><quantity name="length" value="2m"/><bsdf type="twosided"><bsdf type="diffuse">{refl}</bsdf></bsdf></shape>
+  <shape type="rectangle"><point name="p" x="-.25m" y=".95m" z="-.25m"/><point name="x" x="0m" y="0m" z=".5m"/><point name="y" x=".5m" y="0m" z="0m"/>
+    <bsdf type="diffuse"><spectrum name="reflectance" constant="0"/></bsdf>
+    <emitter type="area"><spectrum name="radiance" blackbody="6000K"><float name="scale" value="1e-6"/></spectrum></emitter></shape>
+</scene>''')
+        sc = Scene.from_xml(str(f), lut=(32, 32))
+        v, w, l, c = oracle_render(sc, 0, 8, 5)
+        return v + l, c
+    a, ca = film(f'<texture name="reflectance" type="bitmap"><path value="{tmp_path / "c.pfm"}"/><string name="filter_type" value="nearest"/></texture>')
+    b, cb = film('<spectrum name="reflectance" rgb=".8, .4, .2"/>')
+    # (a handful of walks take another Russian-roulette decision where the two reflectances differ at a bin edge)
+    assert all(abs(ca[k] - cb[k]) <= 0.01 * max(1, cb[k]) for k in cb) and a.sum() > 0
+    assert np.abs(a - b).sum() <= 2e-2 * b.sum()
+    assert a[..., 0].sum() > 1.5 * a[..., 2].sum()

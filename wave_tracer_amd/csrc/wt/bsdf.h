@@ -203,7 +203,7 @@ struct material_wrap_t {
 WT_HD float material_scale_factor(const scene_t& sc, const material_t& m, float k, vec2 uv) {
     float f = 1.f;
     if (m.scale_spec) f *= spectrum_f(sc, (int)m.scale_spec - 1, k);
-    if (m.scale_tex) f *= texture_f(sc, (int)m.scale_tex - 1, uv);
+    if (m.scale_tex) f *= texture_spectral(sc, (int)m.scale_tex - 1, uv, k);
     return f;
 }
 WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, material_t& m, material_wrap_t& wr) {
@@ -222,7 +222,7 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, materi
         if (m.scale_spec | m.scale_tex) scale *= material_scale_factor(sc, m, k, uv);
         int child = -1;
         if (m.type == MAT_MASK) {
-            wr.alpha *= clamp01(m.mask_tex ? texture_f(sc, (int)m.mask_tex - 1, uv) : m.mask_alpha);   // mask.cpp:27, 50: clamp01(mask->f(tquery).x)
+            wr.alpha *= clamp01(m.mask_tex ? texture_spectral(sc, (int)m.mask_tex - 1, uv, k) : m.mask_alpha);   // mask.cpp:27, 50: clamp01(mask->f(tquery).x)
             wr.masked = true;
             wr.mask_two = two != 0;
             child = m.nested;
@@ -265,7 +265,7 @@ WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k
     }
     mueller_t M = mueller_zero();
     if (m.type == MAT_DIFFUSE) {
-        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_f(sc, (int)m.refl_tex - 1, uv) : 1.f));
+        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_spectral(sc, (int)m.refl_tex - 1, uv, k) : 1.f));
         M = mueller_depolarizer((wi.z > 0.f && wo.z > 0.f) ? wo.z * kInvPi * refl : 0.f);
     } else if (m.type == MAT_SURFACE_SPM) {
         const bool is_scatter = !profile_is_delta_only(m);
@@ -359,7 +359,7 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
 
     if (m.type == MAT_DIFFUSE) {
         if (wi.z <= 0.f) return r;
-        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_f(sc, (int)m.refl_tex - 1, uv) : 1.f));
+        const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_spectral(sc, (int)m.refl_tex - 1, uv, k) : 1.f));
         r.wo = cosine_hemisphere(sampler_r2(sampler));
         r.dpd = cosine_hemisphere_pdf(r.wo.z);
         r.M = mueller_depolarizer(refl);

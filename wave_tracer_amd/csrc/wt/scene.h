@@ -321,8 +321,9 @@ WT_HD rgba_t tex_bitmap(const scene_t& sc, const texture_t& t, vec2 uv) {
 }
 // texture_t::get_RGBA.  Checkerboards nest (checkerboard.hpp:72-79: the parity of the integer parts of u and v picks the nested
 // texture; its uv is the same query), at most 4 levels here.
-WT_HD rgba_t texture_rgba(const scene_t& sc, int id, vec2 uv) {
+WT_HD rgba_t texture_rgba(const scene_t& sc, int id, vec2 uv, bool* is_rgb = nullptr) {
     float scale = 1.f;
+    if (is_rgb) *is_rgb = false;
     for (int depth = 0; depth < 4; ++depth) {
         const texture_t t = sc.textures[id];
         uv = vec2{t.m[0] * uv.x + t.m[1] * uv.y + t.t[0], t.m[2] * uv.x + t.m[3] * uv.y + t.t[1]};
@@ -333,11 +334,65 @@ WT_HD rgba_t texture_rgba(const scene_t& sc, int id, vec2 uv) {
             continue;
         }
         const rgba_t c = t.type == TEX_BITMAP ? tex_bitmap(sc, t, uv) : rgba_t{t.rgba[0], t.rgba[1], t.rgba[2], t.rgba[3]};
+        if (is_rgb) *is_rgb = t.type == TEX_BITMAP && t.channels >= 3;
         return {c.r * scale, c.g * scale, c.b * scale, c.a};
     }
     return {0.f, 0.f, 0.f, 1.f};
 }
 // texture_t::f(query).x for luminance textures
 WT_HD float texture_f(const scene_t& sc, int id, vec2 uv) { return texture_rgba(sc, id, uv).r; }
+
+// colourspace::RGB_to_spectral::uplift (include/wt/spectrum/colourspace/RGB/RGB_to_spectral.hpp:27-84, the Smits-style uplift with ten
+// 34-nm bins over 380..720 nm, 0 outside): the spectral value at wavenumber k [1/mm] of an RGB triple
+WT_HD __attribute__((noinline)) float rgb_uplift(float r, float g, float b, float k) {
+    static constexpr float white_I[10] = {1.0000f, 1.0000f, 0.9999f, 0.9993f, 0.9992f, 0.9998f, 1.0000f, 1.0000f, 1.0000f, 1.0000f};
+    static constexpr float cyan_I[10] = {0.9710f, 0.9426f, 1.0007f, 1.0007f, 1.0007f, 1.0007f, 0.1564f, 0.0000f, 0.0000f, 0.0000f};
+    static constexpr float magenta_I[10] = {1.0000f, 1.0000f, 0.968f, 0.22295f, 0.0000f, 0.0458f, 0.8369f, 1.0000f, 1.0000f, 0.9959f};
+    static constexpr float yellow_I[10] = {0.0001f, 0.0000f, 0.1088f, 0.6651f, 1.0000f, 1.0000f, 0.9996f, 0.9586f, 0.9685f, 0.9840f};
+    static constexpr float red_I[10] = {0.1012f, 0.0515f, 0.0000f, 0.0000f, 0.0000f, 0.0000f, 0.8325f, 1.0149f, 1.0149f, 1.014f};
+    static constexpr float green_I[10] = {0.0000f, 0.0000f, 0.0273f, 0.7937f, 1.0000f, 0.9418f, 0.1719f, 0.0000f, 0.0000f, 0.0025f};
+    static constexpr float blue_I[10] = {1.0000f, 1.0000f, 0.8916f, 0.3323f, 0.0000f, 0.0000f, 0.0003f, 0.0369f, 0.0483f, 0.0496f};
+    const float lambda_nm = 6.2831853f / k * 1e6f;
+    if (!(lambda_nm >= 380.f && lambda_nm <= 720.f)) return 0.f;
+    const int bin = (int)((lambda_nm - 380.f) / (720.f - 380.f) * 10.f);
+    if (bin > 9) return 0.f;   // lambda = 720 nm exactly: the reference's eleventh, empty bin
+    float I = 0.f;
+    if (r <= g && r <= b) {
+        I += white_I[bin] * r;
+        if (g <= b) {
+            I += cyan_I[bin] * (g - r);
+            I += blue_I[bin] * (b - g);
+        } else {
+            I += cyan_I[bin] * (b - r);
+            I += green_I[bin] * (g - b);
+        }
+    } else if (g <= r && g <= b) {
+        I += white_I[bin] * g;
+        if (r <= b) {
+            I += magenta_I[bin] * (r - g);
+            I += blue_I[bin] * (b - r);
+        } else {
+            I += magenta_I[bin] * (b - g);
+            I += red_I[bin] * (r - b);
+        }
+    } else {
+        I += white_I[bin] * b;
+        if (r <= g) {
+            I += yellow_I[bin] * (r - b);
+            I += green_I[bin] * (g - r);
+        } else {
+            I += yellow_I[bin] * (g - b);
+            I += red_I[bin] * (r - g);
+        }
+    }
+    return I;
+}
+// texture_t::f(query).x at wavenumber k: luminance textures are wavelength independent, RGB bitmaps are uplifted per lookup
+// (bitmap.hpp:125-140)
+WT_HD float texture_spectral(const scene_t& sc, int id, vec2 uv, float k) {
+    bool rgb = false;
+    const rgba_t c = texture_rgba(sc, id, uv, &rgb);
+    return rgb ? rgb_uplift(c.r, c.g, c.b, k) : c.r;
+}
 
 }   // namespace wt
