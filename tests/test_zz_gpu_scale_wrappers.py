@@ -53,3 +53,18 @@ def test_spectral_scale_factor_gpu_parity(built, tmp_path):
     f.write_text(BOX)
     g = _parity(Scene.from_xml(str(f), lut=(32, 32)), 8, 5)
     assert g[..., 0].sum() > 1.5 * g[..., 2].sum()     # reddish walls
+
+
+@pytest.mark.gpu
+def test_rgb_bitmap_uplift_gpu_parity(built, tmp_path):
+    """An RGB bitmap as the walls' reflectance: uplifted per lookup on the device (wt/scene.h: rgb_uplift, an out-of-line device function)."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.imageio import write_pfm
+    write_pfm(str(tmp_path / "c.pfm"), np.array([[[.8, .4, .2], [.2, .4, .8]], [[.3, .7, .3], [.6, .6, .6]]], np.float32))
+    walls = (f'<bsdf type="twosided"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"><path value="{tmp_path / "c.pfm"}"/>'
+             '<string name="filter_type" value="bilinear"/></texture></bsdf></bsdf>')
+    start = BOX.index('<bsdf type="twosided">')
+    end = BOX.index('</bsdf></bsdf></bsdf>') + len('</bsdf></bsdf></bsdf>')
+    f = tmp_path / "box.xml"
+    f.write_text(BOX[:start] + walls + BOX[end:])
+    _parity(Scene.from_xml(str(f), lut=(32, 32)), 8, 5)
