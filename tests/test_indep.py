@@ -73,3 +73,25 @@ def test_independent_composition_matches_the_checker(built, name, res, spp, kw):
     fsd_scene = oc["fsd_interactions"] > 0
     assert same.mean() >= (0.97 if fsd_scene else 1.0), same.mean()
     assert np.abs(tot_a - tot_b).sum() <= (2e-2 if fsd_scene else 1e-5) * tot_b.sum()
+
+
+XML_CASES = [("textured.xml", {"variant": 1}, 4), ("textured.xml", {"variant": 3}, 4), ("textured.xml", {"variant": 5}, 4), ("objects.xml", {}, 2),
+             ("single_slit.xml", {}, 4)]
+
+
+@pytest.mark.parametrize("file,defines,spp", XML_CASES)
+def test_independent_composition_on_scene_files(built, file, defines, spp):
+    """The same on scenes read by the XML reader (tests/data/xml/): textures, the mask wrapper, a textured scale factor, the procedural
+    shapes with dielectric / conductor materials, a slit in front of a virtual-plane sensor."""
+    from wave_tracer_amd import Scene
+    sc = Scene.from_xml(os.path.join(ROOT, "tests", "data", "xml", file), defines=defines, lut=(32, 32))
+    if sc.info.integrator != 0:
+        pytest.skip("oracle/indep restates plt_bdpt only")
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 41, threads=1)
+    iv, iw, il, ic = indep_render(sc, 0, spp, 41)
+    for k in ("segments", "vertices", "connections", "fsd_interactions", "null_interactions", "light_splats", "shadow_rays"):
+        assert ic[k] == oc[k], (k, ic[k], oc[k])
+    tot_a, tot_b = iv.sum(axis=2) + il.sum(axis=2), ov.sum(axis=2) + ol.sum(axis=2)
+    assert tot_b.sum() > 0
+    fsd_scene = oc["fsd_interactions"] > 0
+    assert np.abs(tot_a - tot_b).sum() <= (2e-2 if fsd_scene else 1e-5) * tot_b.sum()
