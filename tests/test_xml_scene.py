@@ -454,8 +454,10 @@ def test_texture_nodes_in_scene_files(built, tmp_path):
     img, _ = _render_dev(Scene.from_xml(TEX, defines={"variant": 4, "bitmap": str(tmp_path / "n.pfm")}))
     assert np.abs(img - ref).max() <= 1e-6 * ref.max()
     from wave_tracer_amd.api import WtgpuError
-    with pytest.raises(WtgpuError, match="PFM files only"):
+    with pytest.raises(WtgpuError, match="cannot open .*missing.png"):
         Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(tmp_path / "missing.png")})
+    with pytest.raises(WtgpuError, match="PNG .* and PFM files only"):
+        Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(tmp_path / "picture.jpg")})
 
 
 def _radio_city_xml():
@@ -645,3 +647,104 @@ def test_rgb_bitmap_reflectance_is_uplifted_per_lookup(built, tmp_path):
     assert all(abs(ca[k] - cb[k]) <= 0.01 * max(1, cb[k]) for k in cb) and a.sum() > 0
     assert np.abs(a - b).sum() <= 2e-2 * b.sum()
     assert a[..., 0].sum() > 1.5 * a[..., 2].sum()
+
+
+def _write_png(path, img, depth=8, palette=None, trns=None):
+    """Minimal PNG writer for the reader's test: img [H, W] (grey or palette indices) or [H, W, C] (C = 2 grey + alpha, 3 RGB, 4 RGBA) of
+    integers; row y is written with scanline filter y % 5, so that every filter type of the specification is exercised."""
+    import struct
+    import zlib
+    a = np.asarray(img)
+    if a.ndim == 2:
+        a = a[..., None]
+    H, W, C = a.shape
+    ctype = 3 if palette is not None else {1: 0, 2: 4, 3: 2, 4: 6}[C]
+    raw = (a.astype(">u2") if depth == 16 else a.astype(np.uint8)).reshape(H, -1).view(np.uint8).reshape(H, -1).astype(np.int32)
+    bpp = C * depth // 8
+
+    def paeth(x, y, z):
+        p = x + y - z
+        pa, pb, pc = abs(p - x), abs(p - y), abs(p - z)
+        return x if pa <= pb and pa <= pc else y if pb <= pc else z
+    rows = bytearray()
+    for y in range(H):
+        ft = y % 5
+        cur, up = raw[y], raw[y - 1] if y else np.zeros_like(raw[0])
+        out = []
+        for i in range(len(cur)):
+            l = cur[i - bpp] if i >= bpp else 0
+            ul = up[i - bpp] if i >= bpp else 0
+            pred = [0, l, up[i], (l + up[i]) // 2, paeth(l, up[i], ul)][ft]
+            out.append((cur[i] - pred) & 0xFF)
+        rows += bytes([ft]) + bytes(out)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        data += chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1)))
+        if trns is not None:
+            data += chunk(b"tRNS", bytes(trns))
+    comp = zlib.compress(bytes(rows))
+    data += chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(data)
+
+
+def test_png_bitmaps(built, tmp_path):
+    """PNG textures (src/bitmap/load2d.cpp:200-300, texture2d_loader.cpp:183-227): 8-bit files are sRGB-encoded, 16-bit files linear, the
+    texture node's colour_encoding / gamma override that; grey, grey + alpha, RGB, RGBA, palette; all five scanline filters; IDAT split
+    over several chunks.  Checked against the same texels written as a float PFM after linearising them here: the rendered films are equal."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    from wave_tracer_amd.imageio import write_pfm
+    rng = np.random.default_rng(5)
+
+    def srgb(v):
+        return np.where(v <= .04045, v / 12.92, ((v + .055) / 1.055) ** 2.4)
+
+    def film(bitmap, extra=""):
+        sc = Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(bitmap)}) if not extra else None
+        if extra:
+            txt = open(TEX).read().replace('<string name="filter_type" value="nearest"/>', '<string name="filter_type" value="nearest"/>' + extra, 1)
+            f = tmp_path / "t.xml"
+            f.write_text(txt.replace('parts/grey.pfm', str(bitmap)))
+            sc = Scene.from_xml(str(f), defines={"variant": 2, "bitmap": str(bitmap)})
+        return _render_dev(sc)[0]
+    # grey 8 bit (sRGB by default), 6 x 7: rows with every filter type
+    g8 = rng.integers(0, 256, (7, 6))
+    _write_png(str(tmp_path / "g8.png"), g8)
+    write_pfm(str(tmp_path / "g8.pfm"), srgb(g8 / 255.0).astype(np.float32))
+    a, b = film(tmp_path / "g8.png"), film(tmp_path / "g8.pfm")
+    assert a.sum() > 0 and np.abs(a - b).max() <= 1e-6 * b.max()
+    # ... read as linear, and with gamma 2
+    write_pfm(str(tmp_path / "g8l.pfm"), (g8 / 255.0).astype(np.float32))
+    assert np.abs(film(tmp_path / "g8.png", '<string name="colour_encoding" value="linear"/>') - film(tmp_path / "g8l.pfm")).max() <= 1e-6 * b.max()
+    write_pfm(str(tmp_path / "g8g.pfm"), ((g8 / 255.0) ** 2.0).astype(np.float32))
+    assert np.abs(film(tmp_path / "g8.png", '<float name="gamma" value="2"/>') - film(tmp_path / "g8g.pfm")).max() <= 1e-6 * b.max()
+    # RGB 8 bit and RGB 16 bit (linear by default)
+    c8 = rng.integers(0, 256, (5, 4, 3))
+    _write_png(str(tmp_path / "c8.png"), c8)
+    write_pfm(str(tmp_path / "c8.pfm"), srgb(c8 / 255.0).astype(np.float32))
+    assert np.abs(film(tmp_path / "c8.png") - film(tmp_path / "c8.pfm")).max() <= 1e-6 * b.max()
+    c16 = rng.integers(0, 65536, (5, 4, 3))
+    _write_png(str(tmp_path / "c16.png"), c16, depth=16)
+    write_pfm(str(tmp_path / "c16.pfm"), (c16 / 65535.0).astype(np.float32))
+    assert np.abs(film(tmp_path / "c16.png") - film(tmp_path / "c16.pfm")).max() <= 1e-6 * b.max()
+    # palette: expanded to RGB
+    pal = rng.integers(0, 256, (4, 3))
+    idx = rng.integers(0, 4, (6, 5))
+    _write_png(str(tmp_path / "p.png"), idx, palette=pal)
+    write_pfm(str(tmp_path / "p.pfm"), srgb(pal[idx] / 255.0).astype(np.float32))
+    assert np.abs(film(tmp_path / "p.png") - film(tmp_path / "p.pfm")).max() <= 1e-6 * b.max()
+    # RGBA loads (alpha is not linearised; the reflectance ignores it): same film as the RGB file
+    _write_png(str(tmp_path / "c8a.png"), np.concatenate([c8, rng.integers(0, 256, (5, 4, 1))], axis=2))
+    assert np.abs(film(tmp_path / "c8a.png") - film(tmp_path / "c8.pfm")).max() <= 1e-6 * b.max()
+    # errors
+    (tmp_path / "bad.png").write_bytes(b"not a png")
+    with pytest.raises(WtgpuError, match="not a PNG file"):
+        film(tmp_path / "bad.png")
+    data = bytearray((tmp_path / "g8.png").read_bytes())
+    data[28] = 1        # the interlace flag of IHDR
+    (tmp_path / "il.png").write_bytes(bytes(data))
+    with pytest.raises(WtgpuError, match="interlaced"):
+        film(tmp_path / "il.png")

@@ -196,7 +196,7 @@ mesh_t load_ply(const std::string& path, bool face_normals, double scale) {
 // Portable float map: "PF" (3 channels) | "Pf" (1), width height, scale (< 0: little endian), rows bottom-up
 std::vector<float> load_pfm(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels) {
     std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("(bitmap loader) cannot open " + path + " (PFM files only: no image decoder is available)");
+    if (!f) throw std::runtime_error("(bitmap loader) cannot open " + path);
     std::string magic;
     double scale = 0;
     f >> magic >> width >> height >> scale;

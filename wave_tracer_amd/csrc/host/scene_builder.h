@@ -64,6 +64,9 @@ mesh_t load_ply(const std::string& path, bool face_normals, double scale);
 mesh_t load_obj(const std::string& path, bool face_normals, double scale);
 // Portable float map (PF: RGB, Pf: grey; little or big endian), rows returned from the image's TOP (the file stores them bottom-up)
 std::vector<float> load_pfm(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels);
+// PNG, bit depth 8 or 16 (host/png_loader.cpp; src/bitmap/load2d.cpp:200-300): normalised, linearised floats, rows from the top.
+// encoding: 0 = the file's default (8 bit sRGB, 16 bit linear), 1 linear, 2 sRGB, 3 gamma
+std::vector<float> load_png(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels, int encoding, double gamma);
 
 class scene_builder_t {
 public:

@@ -667,7 +667,7 @@ struct loader_t {
     }
     // ---- textures (src/texture/texture_loader.cpp:30-62): constant, checkerboard (colour1 / colour2: a texture or a constant spectrum,
     // defaults 0 and 1), scale (constant `scale` spectrum x nested texture), transform (<matrix value="a,b,c,d"/>, <translate value="x,y"/>
-    // on the uv of a nested texture), bitmap (<path>: a PFM file — image decoding of other formats is not available here —, filter_type
+    // on the uv of a nested texture), bitmap (<path>: a PNG (host/png_loader.cpp) or PFM file, colour_encoding, gamma, filter_type
     // nearest | bilinear, wrap_mode[_u|_v] black | white | clamp | repeat | mirror).  Luminance (wavelength-independent) values; RGB bitmaps
     // only for normal maps.  Returns the texture id.
     static float const_of(const xnode_t& sp, const char* what) {
@@ -744,7 +744,27 @@ struct loader_t {
                 return b.add_texture_constant(.5f, .5f, .5f);
             }
             uint32_t W = 0, H = 0, C = 0;
-            const std::vector<float> px = load_pfm(file, W, H, C);
+            std::string ext = file.size() >= 4 ? file.substr(file.size() - 4) : std::string();
+            for (char& c : ext) c = (char)std::tolower((unsigned char)c);
+            std::vector<float> px;
+            if (ext == ".png") {   // colour_encoding = linear | sRGB | gamma, gamma = g (src/texture/bitmap.cpp:81-123)
+                int enc = 0;
+                double gamma = 2.2;
+                if (const xnode_t* ce = n.named("colour_encoding")) {
+                    const std::string v = ce->get("value");
+                    enc = v == "linear" ? 1 : v == "sRGB" ? 2 : v == "gamma" ? 3 : -1;
+                    if (enc < 0) throw std::runtime_error("bitmap colour_encoding \"" + v + "\": linear | sRGB | gamma expected");
+                }
+                if (const xnode_t* g = n.named("gamma")) {
+                    if (enc != 0 && enc != 3) throw std::runtime_error("(bitmap texture loader) 'gamma' can only be set for 'gamma' colour encoding");
+                    gamma = eval_number(g->get("value"));
+                    enc = 3;
+                }
+                px = load_png(file, W, H, C, enc, gamma);
+            } else if (ext == ".pfm")
+                px = load_pfm(file, W, H, C);
+            else
+                throw std::runtime_error("(bitmap loader) " + file + ": PNG (8 / 16 bit) and PFM files only");
             return b.add_texture_bitmap(W, H, C, px.data(), bilinear, uw, vw);
         }
         throw std::runtime_error("(texture loader) texture type \"" + type + "\" is not supported");
