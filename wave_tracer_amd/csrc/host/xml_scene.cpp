@@ -1,21 +1,29 @@
-// wave_tracer_amd — a minimal reader of the reference's XML scene format ("next" row): enough of the format to
-// load scenes/diffraction_simple/double_slits.xml, double_slits_and_reflectors.xml and their bits/geometry.xml AS SHIPPED and bake
-// them through scene_builder_t.  Not a general loader.
+// wave_tracer_amd — reader of the reference's XML scene format ("next" row), baking through scene_builder_t.
+// Loads AS SHIPPED: scenes/diffraction_simple/{double_slits,double_slits_and_reflectors}.xml (+ bits/geometry.xml), scenes/cornell-box/
+// {box,sphere_polarization}.xml (Git-LFS pointer files in place of meshes / bitmaps: the bundled stand-ins, host/scenes.cpp:
+// asset_standin_mesh); with -Dwtgpu_missing_assets=skip (absent meshes left out) also room, bike, kitchen, etoile, munich, sponza_day
+// and veach_mis.  Not a general loader: what is unsupported fails with a message that names it.
 //
 // Reference behaviour restated (nothing is copied; the reference parses with pugixml, which is not available here):
-//   * <default name value> defines with command-line overrides ("-Dname=value"), textual "$name" substitution in attribute values
-//     (src/scene/loader/xml/loader.cpp, src/main.cpp:805-928);
-//   * attribute values are arithmetic / boolean expressions, optionally followed by a unit ("($S-.0001) mm", ".001°", "5750K"),
-//     comma-separated for vectors, "a .. b" for ranges, "(re,imi)" for complex constants (include/wt/util/unique_function… the
-//     reference evaluates them with its own expression parser + mp-units' stoq);
+//   * <default name value> defines with command-line overrides ("-Dname=value"), textual "$name" substitution in attribute values,
+//     "\$" for a literal dollar (src/scene/loader/xml/loader.cpp, src/main.cpp:805-928);
+//   * attribute values are arithmetic / boolean expressions (+ - * / comparisons && || !, true / false / pi, sin cos tan asin acos atan
+//     atan2 sqrt abs exp log pow min max round floor ceil), optionally followed by a unit ("($S-.0001) mm", ".001°", "5750K", "10GHz"
+//     where a wavelength is expected), comma-separated for vectors, "a .. b" for ranges, "(re,imi)" for complex constants;
 //   * <include path> is relative to the including file and is spliced in place;
-//   * elements with <boolean name="enabled" value=…/> evaluating to false are skipped (sensors, shapes);
-//   * node vocabulary handled: integrator (plt_bdpt | plt_path + direction), sensor (virtual_plane | perspective) with film
-//     (array; response monochromatic/discrete line or RGB), emitter (spot | directional), bsdf (twosided, surface_spm with
-//     fractal/dirac profile, diffuse, composite bins), spectrum (constant, complex constant, discrete line, rgb, blackbody,
-//     composite bins, dielectric, constant scale wrapper, named IOR / emission tables), shape (rectangle, cube, sphere, cylinder,
-//     prism, lens, ply / obj: host/ply_loader.cpp, host/obj_loader.cpp) with <ref id> or a nested <bsdf>, general to_world transforms, area emitters on shapes.
-//     Textures: constant, checkerboard, scale, transform, bitmap (PFM files) on diffuse reflectances, mask and normalmap bsdfs.
+//   * elements with <boolean name="enabled" value=…/> evaluating to false are skipped (integrators, sensors, emitters, shapes);
+//   * <ref id=…/> stands for a named BSDF (inside shapes and wrappers) or a shared top-level texture / spectrum;
+//   * node vocabulary: integrator (plt_bdpt | plt_path + direction); sensor (virtual_plane | perspective with fov_axis; polarimetric
+//     attribute) with film (array, rfilter_scale; response monochromatic / discrete line or RGB with white point);
+//     emitter (spot, point, directional with lookat or a general transform, area on a shape) in the reference loader's order;
+//     bsdf (twosided, scale with a constant / spectrum / texture, mask, normalmap, composite bins, diffuse, dielectric, surface_spm with
+//     dirac / fractal / gaussian profile, extIOR, reflection_scale, transmission_scale);
+//     spectrum (constant, complex constant, discrete line, rgb, blackbody, piecewise_linear, gaussian, composite bins, named IOR /
+//     emission database entries, ITU-R P.2040 materials);
+//     texture (constant, checkerboard, scale, transform, bitmap from PNG / PFM with filter, wrap modes and colour encoding);
+//     shape (rectangle, cube, sphere, cylinder, prism, lens, ply / obj: host/ply_loader.cpp, host/obj_loader.cpp) with general to_world
+//     transforms (matrix / rotate / scale / translate / lookat).
+//   Not handled: function textures, textured roughness / emitter radiance, sensor masks, max_depth beyond the kernels' 16 vertices.
 // Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
