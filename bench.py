@@ -214,6 +214,7 @@ def main():
                                    f"{'MIS RR Fraunhofer-FSD' if int(sc.info.integrator) == 0 else 'UTD-FSD'}, {S} spp per step; interaction regions exact "
                                    f"(unbounded: regions beyond the 64-triangle fast path are walked in full, DESIGN.md §5)",
                        "samples_per_step": npix * S, "tris": int(sc.info.n_tris),
+                       "emitter_selection": ", ".join(f"{e['type']} {e['select_pmf']:.4g}" for e in sc.emitter_summary()),
                        "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "launches_with_work": with_work,
