@@ -120,7 +120,7 @@ def load_library():
 
 def _check(rc):
     if rc != 0:
-        raise WtgpuError(f"wtgpu error {rc}: {load_library().wtgpu_last_error().decode()}")
+        raise WtgpuError(f"wtgpu error {rc}: {load_library().wtgpu_last_error().decode(errors='replace')}")
 
 
 class Scene:
