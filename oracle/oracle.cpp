@@ -43,6 +43,11 @@ constexpr uint32_t kOracleConeTris = 1u << 18;
 // reference's executed behaviour (the distance is never recorded, the filter never fires) — to measure what that costs
 int g_region_filter = 1;
 int g_traverse_axis = 0;   // oracle_traverse_cones: run the device form of the traversal policy (wt::traverse_axis) instead of the reference's
+// renders (run_walk / run_path_sample): 1 = trace with wt::traverse_axis exactly as the device's per-lane kernel calls it (early exit of
+// too-short attempts, the two remembered rejecting triangles), 0 = the reference's form.  The results must be identical.
+// 2: without the remembered triangles, 3: without the early exit either, 4: like 1 with a work budget of 12 units per cone query and
+// the over-budget queries resumed from their hand-over record (what the device's tiers do).
+int g_walk_axis = 0;
 
 void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
     unsigned long long* pa = reinterpret_cast<unsigned long long*>(&a);
@@ -57,7 +62,13 @@ void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_
     for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
         const cone_t env = walk_trace_envelope(sc, w);
         const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
-        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris);
+        trav_result_t tr = g_walk_axis ? traverse_axis(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris, nullptr, g_walk_axis == 4 ? 12u : 0xFFFFFFFFu, g_walk_axis != 3, false,
+                                                       g_walk_axis == 1 || g_walk_axis == 4 ? w.prev_offset_tuid : kInvalid)
+                                       : traverse(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris);
+        if (g_walk_axis == 4 && tr.aborted == 1) {   // the hand-over of an over-budget query: resumed (second per-lane tier) from the record alone
+            const trav_result_t h = tr;
+            tr = traverse_axis(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris, nullptr, 0xFFFFFFFFu, true, false, w.prev_offset_tuid, &h);
+        }
         ctr.segments++;
         ctr.ray_queries += tr.n_ray_queries;
         ctr.cone_queries += tr.n_cone_queries;
@@ -80,7 +91,8 @@ void run_path_sample(const scene_t& sc, const film_t& film, uint64_t seed, uint6
     path_generate(sc, seed, sample_id, x, y, pw);
     for (uint32_t it = 0; it < kMaxWalkIters && pw.w.active; ++it) {
         const cone_t env = walk_trace_envelope(sc, pw.w);
-        const trav_result_t tr = traverse(sc, env, wavenum_to_wavelen_m(pw.w.beam.k), WT_INF, rt, stack, tris);
+        const trav_result_t tr = g_walk_axis ? traverse_axis(sc, env, wavenum_to_wavelen_m(pw.w.beam.k), WT_INF, rt, stack, tris, nullptr, 0xFFFFFFFFu, g_walk_axis != 3, false, g_walk_axis == 1 ? pw.w.prev_offset_tuid : kInvalid)
+                                             : traverse(sc, env, wavenum_to_wavelen_m(pw.w.beam.k), WT_INF, rt, stack, tris);
         ctr.segments++;
         ctr.ray_queries += tr.n_ray_queries;
         ctr.cone_queries += tr.n_cone_queries;
@@ -239,6 +251,104 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
     return n_calls;
 }
 
+
+// Work profile of wt::traverse_axis (the device form of the traversal policy) on a tile subset, per CONE QUERY: how the attempts of a
+// segment end (too short / accepted / empty), what they cost, and whether the triangle that made an attempt too short — or the
+// triangle the beam started from — would also have decided the next one (the "rejecting-triangle cache" of traverse_axis).
+// out: n x 8 uint32 {call index, segment, outcome (0 too short, 1 accepted, 2 empty), cone_nodes, cone_tri_tests,
+//                    flags (1: the origin triangle alone decides "too short", 2: the previous rejecting triangle does, 4: emitter walk),
+//                    ray_nodes | ray_tris << 16 (first query of a call only), walk iteration}
+// Diagnostic tool, not part of any parity claim.
+uint64_t oracle_profile_axis(const void* scene_host, uint64_t seed, uint32_t tile_stride, uint32_t* out, uint64_t cap) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const uint32_t W = sc.sensor.width, H = sc.sensor.height, B = 24;
+    const uint32_t bx = (W + B - 1) / B, by = (H + B - 1) / B;
+    sample_scratch_t scr;
+    scr.tris.resize(kOracleConeTris);
+    scr.dists.resize(kOracleConeTris);
+    scr.svert.resize(kMaxVerts * kVertexWords);
+    scr.evert.resize(kMaxVerts * kVertexWords);
+    std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);
+    std::vector<fsd_edge_t> edges((2 * kMaxVerts + 8) * (size_t)kFsdMaxEdges);
+    uint32_t pool_counter = 0;
+    const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
+    bdpt_counters_t ctr;
+    std::memset(&ctr, 0, sizeof(ctr));
+    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    uint64_t n_rows = 0, n_calls = 0;
+    auto too_short_by = [&](const cone_t& env, uint32_t tuid, const range_t& range, float min_prog) {
+        if (tuid == kInvalid) return false;
+        const tri_geo_t tri = sc.tri_geo[tuid];
+        cone_tri_hit_t h;
+        return intersect_cone_tri(env, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max) && h.dist - range.min < min_prog;
+    };
+    for (uint32_t blk = 0; blk < bx * by; ++blk) {
+        if (tile_stride > 1 && blk % tile_stride != 0) continue;
+        const uint32_t x0 = (blk % bx) * B, y0 = (blk / bx) * B;
+        for (uint32_t y = y0; y < std::min(H, y0 + B); ++y)
+            for (uint32_t x = x0; x < std::min(W, x0 + B); ++x) {
+                const uint64_t pix = (uint64_t)y * W + x;
+                const uint64_t sample_id = (pix << 32);
+                pool_counter = 0;
+                sample_ctx_t ctx;
+                walk_t sw, ew;
+                const vertex_store_t svs{scr.svert.data(), 1, 0}, evs{scr.evert.data(), 1, 0};
+                bdpt_generate(sc, seed, sample_id, x, y, ctx, sw, ew, svs, evs);
+                for (int which = 0; which < 2; ++which) {
+                    walk_t& w = which ? ew : sw;
+                    const vertex_store_t& vs = which ? evs : svs;
+                    const uint_list_t tris{scr.tris.data(), 1, kMaxConeTris, scr.dists.data()};
+                    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+                        const cone_t env = walk_trace_envelope(sc, w);
+                        const float lambda_m = wavenum_to_wavelen_m(w.beam.k);
+                        // the policy loop of traverse_axis, instrumented
+                        if (!(sc.sensor.ray_trace_only || sc.opts.force_ray_tracing) && !cone_is_ray(env)) {
+                            bvh_counters_t bc;
+                            std::memset(&bc, 0, sizeof(bc));
+                            ray_hit_t ah;
+                            const bool axis_hit = ads_intersect_ray(sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah, &bc);
+                            uint32_t first = 1, prev_short = kInvalid;
+                            float dist = 0.f;
+                            for (uint32_t seg = 0;; ++seg) {
+                                const float bd = max_ballistic_distance(lambda_m, seg, 0.f);
+                                if (axis_hit && ah.dist <= fminf_(WT_INF, dist + bd * kBallisticScale)) break;
+                                dist += bd;
+                                if (bd == WT_INF) break;
+                                const float min_df_prog = cone_axes(env, dist).x / 2.f;
+                                const float cone_max = axis_hit ? cone_axis_bound(env, ah.dist) : WT_INF;
+                                const range_t sr{dist, cone_max};
+                                bvh_counters_t cc;
+                                std::memset(&cc, 0, sizeof(cc));
+                                cone_hit_t ch;
+                                bvh_traverse_cone(sc, env, sr, kMajorAxisToZScale, stack, tris, ch, &cc, 0xFFFFFFFFu, min_df_prog);
+                                const bool df_empty = ch.ntris == 0 && ch.overflow == 0;
+                                const bool accepted = !ch.too_short && (df_empty || ch.dist - dist >= min_df_prog);
+                                uint32_t fl = which ? 4u : 0u;
+                                if (too_short_by(env, w.prev_offset_tuid, sr, min_df_prog)) fl |= 1u;
+                                if (too_short_by(env, prev_short, sr, min_df_prog)) fl |= 2u;
+                                if (n_rows < cap) {
+                                    uint32_t* o = out + 8 * n_rows;
+                                    o[0] = (uint32_t)n_calls; o[1] = seg; o[2] = accepted ? (df_empty ? 2u : 1u) : 0u; o[3] = cc.cone_nodes; o[4] = cc.cone_tri_tests; o[5] = fl;
+                                    o[6] = first ? (bc.nodes | (bc.tri_tests << 16)) : 0u; o[7] = it;
+                                }
+                                ++n_rows;
+                                first = 0;
+                                if (ch.too_short) prev_short = ch.short_tuid;
+                                if (accepted) break;
+                            }
+                        }
+                        ++n_calls;
+                        const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+                        const trav_result_t tr = traverse(sc, env, lambda_m, WT_INF, rt, stack, uint_list_t{scr.tris.data(), 1, kOracleConeTris, scr.dists.data()});
+                        w.active = bdpt_walk_step(sc, w, tr, uint_list_t{scr.tris.data(), 1, kOracleConeTris, scr.dists.data()}, vs, pool, seed, sample_id,
+                                                  which ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK, &ctr) ? 1u : 0u;
+                    }
+                }
+            }
+    }
+    return n_rows;
+}
+
 #ifdef WT_PROFILE_CONE_TRI
 void oracle_fsd_hist(unsigned long long* out) { std::memcpy(out, wt::g_fsd_hist, sizeof(wt::g_fsd_hist)); }
 void oracle_cone_tri_exits(unsigned long long* out) { std::memcpy(out, g_cone_tri_exits, sizeof(g_cone_tri_exits)); }
@@ -297,6 +407,7 @@ int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n
 
 void oracle_set_region_filter(int on) { g_region_filter = on; }
 void oracle_set_traverse_axis(int on) { g_traverse_axis = on; }
+void oracle_set_walk_axis(int on) { g_walk_axis = on; }
 
 // Region summaries of cone queries of any size: what the reference's unbounded intersection record yields (`list`: every triangle
 // the sequential traversal met, traversal_common.hpp:124-148) next to a brute-force scan of ALL scene triangles against the final

@@ -12,7 +12,7 @@ _lib = None
 def load_oracle():
     global _lib
     if _lib is None:
-        p = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+        p = os.environ.get("WT_ORACLE_LIB") or os.path.join(ROOT, "oracle", "_build", "liboracle.so")   # (override: A/B builds of the checker)
         if not os.path.exists(p):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
         lib = C.CDLL(p)

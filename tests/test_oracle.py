@@ -271,3 +271,29 @@ def test_traverse_axis_equals_traverse(built):
     fits = ref[2] < cap
     assert np.array_equal(ref[2][fits], dev[2][fits]) and np.array_equal(ref[3][fits], dev[3][fits])
     assert ((ref[1] & 3) == 0).sum() > 200 and (ref[2] >= 64).sum() > 30 and fits.mean() > 0.99
+
+
+@pytest.mark.parametrize("name,kw,spp,mode", [("cornell_box", dict(res=48, mesh_detail=1), 2, 1), ("furnace", dict(res=24, fsd=1), 4, 1),
+                                              ("double_slits", dict(res=96, lut=(64, 64)), 2, 1), ("etoile", dict(res=48, mesh_detail=0), 4, 1),
+                                              ("cornell_box_path", dict(res=24, mesh_detail=0), 2, 1),
+                                              ("cornell_box", dict(res=48, mesh_detail=1), 2, 4), ("double_slits", dict(res=96, lut=(64, 64)), 2, 4)])
+def test_device_traversal_policy_renders_identically(built, name, kw, spp, mode):
+    """The per-lane kernel's call of wt::traverse_axis — one axis query, early exit of too-short attempts, and the two remembered
+    triangles (the one the beam left, the one that rejected the previous attempt) tested before a cone query is started — against the
+    reference's form of integrator::traverse, over whole renders (one thread: the film sums are order dependent): every film value bit
+    for bit, every counter but the number of ray queries (one per traced segment instead of one per ballistic segment)."""
+    lib = load_oracle()
+    sc = _scene(name, **kw)
+    ref = oracle_render(sc, 0, spp, 7, threads=1)
+    lib.oracle_set_walk_axis(1)
+    try:
+        dev = oracle_render(sc, 0, spp, 7, threads=1)
+    finally:
+        lib.oracle_set_walk_axis(0)
+    for a, b in zip(ref[:3], dev[:3]):
+        assert np.array_equal(a, b)
+    assert ref[0].sum() + ref[2].sum() > 0
+    for k in ref[3]:
+        if k != "ray_queries":
+            assert ref[3][k] == dev[3][k], k
+    assert dev[3]["ray_queries"] == dev[3]["segments"]

@@ -47,6 +47,26 @@ struct vertex_t {
     beam_t beam;          // beam arriving at this vertex
 };
 constexpr size_t kVertexWords = sizeof(vertex_t) / 4;
+// A vertex without its beam (the first 43 of its 89 words) plus the beam's wavenumber: all that the densities of the MIS weights
+// (vertex_t::pdf, vertex.hpp:444-487) read of a vertex.  Same member names as vertex_t, so the helpers below take either.
+struct vertex_nb_t {
+    uint32_t type;
+    uint32_t transport;
+    uint32_t delta;
+    uint32_t fraunhofer_fsd;
+    float pdf_fwd, pdf_bwd;
+    float rr_weight;
+    int32_t ref;
+    int32_t emitter_of_shape;
+    uint32_t fsd_slot;
+    uint32_t geo_kind;
+    uint32_t has_beam;
+    surface_t surf;
+    struct {
+        float k;
+    } beam;
+};
+static_assert(offsetof(vertex_nb_t, beam) == offsetof(vertex_t, beam) && offsetof(vertex_nb_t, surf) == offsetof(vertex_t, surf), "vertex_nb_t is a prefix of vertex_t");
 
 // strided vertex store: vertex v of walk `idx` = words at base[(v*kVertexWords + w)*stride + idx]
 struct vertex_store_t {
@@ -54,6 +74,20 @@ struct vertex_store_t {
     size_t stride;
     size_t idx;
     WT_HD void load(uint32_t v, vertex_t& out) const { soa_load(base + (size_t)v * kVertexWords * stride, stride, idx, out); }
+    // the beam-less part of a vertex (+ its wavenumber)
+    WT_HD void load(uint32_t v, vertex_nb_t& out) const {
+        const uint32_t* b = base + (size_t)v * kVertexWords * stride;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&out);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = 0; i < offsetof(vertex_t, beam) / 4; ++i) w[i] = b[i * stride + idx];
+        out.beam.k = load_word<float>(v, (offsetof(vertex_t, beam) + offsetof(beam_t, k)) / 4);
+    }
+    WT_HD vec3 load_wp(uint32_t v) const {
+        constexpr size_t o = (offsetof(vertex_t, surf) + offsetof(surface_t, wp)) / 4;
+        return vec3{load_word<float>(v, o), load_word<float>(v, o + 1), load_word<float>(v, o + 2)};
+    }
     WT_HD void store(uint32_t v, const vertex_t& in) const { soa_store(base + (size_t)v * kVertexWords * stride, stride, idx, in); }
     template <class F>
     WT_HD void store_word(uint32_t v, size_t word, F value) const {
@@ -124,24 +158,32 @@ WT_HD uint32_t fsd_pool_alloc(const fsd_pool_t& p) {
 }
 
 // ---- vertex helpers (vertex.hpp) --------------------------------------------------------------------
-WT_HD vec3 vertex_wp(const vertex_t& v) { return v.surf.wp; }
-WT_HD bool vertex_is_on_surface(const scene_t& sc, const vertex_t& v) {
+template <class V>
+WT_HD vec3 vertex_wp(const V& v) { return v.surf.wp; }
+template <class V>
+WT_HD bool vertex_is_on_surface(const scene_t& sc, const V& v) {
     return v.type == VT_SURFACE || (v.type == VT_EMITTER && emitter_is_area(sc.emitters[v.ref])) ||
            (v.type == VT_SENSOR && v.geo_kind == GEO_SURFACE);
 }
-WT_HD bool vertex_has_real_surface(const scene_t& sc, const vertex_t& v) {
+template <class V>
+WT_HD bool vertex_has_real_surface(const scene_t& sc, const V& v) {
     return v.type == VT_SURFACE || (v.type == VT_EMITTER && emitter_is_area(sc.emitters[v.ref]));
 }
 // ng()/ns(): sensors report (0,0,1) (vertex.hpp:271-287)
-WT_HD vec3 vertex_ng(const scene_t& sc, const vertex_t& v) { return vertex_has_real_surface(sc, v) ? v.surf.geo.n : vec3{0, 0, 1}; }
-WT_HD vec3 vertex_ns(const scene_t& sc, const vertex_t& v) { return vertex_has_real_surface(sc, v) ? v.surf.shading.n : vec3{0, 0, 1}; }
+template <class V>
+WT_HD vec3 vertex_ng(const scene_t& sc, const V& v) { return vertex_has_real_surface(sc, v) ? v.surf.geo.n : vec3{0, 0, 1}; }
+template <class V>
+WT_HD vec3 vertex_ns(const scene_t& sc, const V& v) { return vertex_has_real_surface(sc, v) ? v.surf.shading.n : vec3{0, 0, 1}; }
 WT_HD bool vertex_is_interaction(const vertex_t& v) { return v.type == VT_FSD || v.type == VT_SURFACE || v.type == VT_MEDIUM; }
 WT_HD bool vertex_on_emitter(const vertex_t& v) { return v.type == VT_EMITTER || (v.type == VT_SURFACE && v.emitter_of_shape >= 0); }
-WT_HD int vertex_get_emitter(const vertex_t& v) { return v.type == VT_EMITTER ? v.ref : v.emitter_of_shape; }
-WT_HD bool vertex_is_delta_emitter(const scene_t& sc, const vertex_t& v) {
+template <class V>
+WT_HD int vertex_get_emitter(const V& v) { return v.type == VT_EMITTER ? v.ref : v.emitter_of_shape; }
+template <class V>
+WT_HD bool vertex_is_delta_emitter(const scene_t& sc, const V& v) {
     return v.type == VT_EMITTER && (emitter_is_delta_direction(sc.emitters[v.ref]) || emitter_is_delta_position(sc.emitters[v.ref]));
 }
-WT_HD bool vertex_is_delta_sensor(const scene_t& sc, const vertex_t& v) {
+template <class V>
+WT_HD bool vertex_is_delta_sensor(const scene_t& sc, const V& v) {
     return v.type == VT_SENSOR && (sensor_is_delta_direction(sc.sensor) || sensor_is_delta_position(sc.sensor));
 }
 WT_HD bool vertex_is_connectible(const scene_t& sc, const vertex_t& v) {
@@ -158,7 +200,8 @@ WT_HD vec3 geo_offseted_ray_origin(const scene_t& sc, const vertex_t& v, vec3 ro
 }
 
 // convert_directional_density_to_area (vertex.hpp:224-243)
-WT_HD float convert_directional_density_to_area(const scene_t& sc, float dpdf_tagged, vec3 p, const vertex_t& next) {
+template <class V>
+WT_HD float convert_directional_density_to_area(const scene_t& sc, float dpdf_tagged, vec3 p, const V& next) {
     const float dens = pd_density_or_zero(dpdf_tagged);
     if (dens == 0.f) return 0.f;
     const vec3 d = vertex_wp(next) - p;
@@ -168,7 +211,8 @@ WT_HD float convert_directional_density_to_area(const scene_t& sc, float dpdf_ta
     if (vertex_is_on_surface(sc, next)) ppdf *= fabsf(dot(vertex_ng(sc, next), normalize(d)));
     return ppdf;
 }
-WT_HD float vertex_pdf_next_from_sensor(const scene_t& sc, const vertex_t& v, const vertex_t& next) {
+template <class V, class N>
+WT_HD float vertex_pdf_next_from_sensor(const scene_t& sc, const V& v, const N& next) {
     const vec3 dl = vertex_wp(next) - vertex_wp(v);
     const float recp_dist2 = 1.f / length2(dl);
     const vec3 d = dl * sqrtf(recp_dist2);
@@ -178,7 +222,8 @@ WT_HD float vertex_pdf_next_from_sensor(const scene_t& sc, const vertex_t& v, co
     return ppdf;
 }
 WT_HD float vertex_pdf_sensor(const scene_t& sc) { return pd_density_or_zero(sensor_pdf_position(sc)); }
-WT_HD float vertex_pdf_next_from_emitter(const scene_t& sc, const vertex_t& v, const vertex_t& next) {
+template <class V, class N>
+WT_HD float vertex_pdf_next_from_emitter(const scene_t& sc, const V& v, const N& next) {
     const vec3 dl = vertex_wp(next) - vertex_wp(v);
     const float recp_dist2 = 1.f / length2(dl);
     const vec3 d = dl * sqrtf(recp_dist2);
@@ -189,16 +234,18 @@ WT_HD float vertex_pdf_next_from_emitter(const scene_t& sc, const vertex_t& v, c
     if (vertex_is_on_surface(sc, next)) ppdf *= fabsf(dot(vertex_ng(sc, next), d));
     return ppdf;
 }
-WT_HD float vertex_pdf_emitter(const scene_t& sc, const vertex_t& v) {
+template <class V>
+WT_HD float vertex_pdf_emitter(const scene_t& sc, const V& v) {
     const int ei = vertex_get_emitter(v);
     return sc.emitters[ei].select_pmf * pd_density_or_zero(emitter_pdf_position(sc, ei));
 }
-// vertex_t::pdf (vertex.hpp:444-487)
-WT_HD float vertex_pdf(const scene_t& sc, const fsd_pool_t& pool, const vertex_t& v, const vertex_t* prev, const vertex_t& next, uint32_t mode) {
+// vertex_t::pdf (vertex.hpp:444-487); of `prev` only the position matters
+template <class V, class N>
+WT_HD float vertex_pdf(const scene_t& sc, const fsd_pool_t& pool, const V& v, vec3 prev_wp, const N& next, uint32_t mode) {
     if (v.type == VT_EMITTER) return vertex_pdf_next_from_emitter(sc, v, next);
     if (v.type == VT_SENSOR) return vertex_pdf_next_from_sensor(sc, v, next);
     const vec3 p = vertex_wp(v);
-    const vec3 wiworld = normalize(vertex_wp(*prev) - p);
+    const vec3 wiworld = normalize(prev_wp - p);
     const vec3 woworld = normalize(vertex_wp(next) - p);
     float pdf = 0.f;
     if (v.type == VT_SURFACE) {
@@ -954,101 +1001,116 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
     }
 }
 
-// bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720)
+// bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720).  The reference copies every vertex's densities into arrays
+// (bdpt_populate_subpaths_pdfs), overwrites the few entries the connection changes, and then forms the running products; here the
+// changed entries are computed first and the products read each vertex's three words (pdf_fwd, pdf_bwd, delta) straight from the
+// vertex store, newest vertex first — the same numbers in the same order without per-thread arrays (which live in scratch memory on
+// the device) and without a cap on the path length.  Vertices enter the densities without their beams (vertex_nb_t), the
+// predecessors with their position only.
 WT_HD float bdpt_mis_weight(const scene_t& sc, const fsd_pool_t& pool, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t,
                             const connect_ret_t& cr) {
     if (s + t <= 2) return 1.f;
-    float spdf[kMaxVerts], srev[kMaxVerts], epdf[kMaxVerts], erev[kMaxVerts];
-    uint32_t sdel[kMaxVerts], edel[kMaxVerts];
-    // bdpt_populate_subpaths_pdfs
-    for (int i = 0; i < t; ++i) {
-        spdf[i] = svs.load_word<float>(i, WT_VWORD(pdf_bwd));
-        srev[i] = svs.load_word<float>(i, WT_VWORD(pdf_fwd));
-        sdel[i] = svs.load_word<uint32_t>(i, WT_VWORD(delta));
-    }
-    for (int i = 0; i < s; ++i) {
-        epdf[i] = evs.load_word<float>(i, WT_VWORD(pdf_fwd));
-        erev[i] = evs.load_word<float>(i, WT_VWORD(pdf_bwd));
-        edel[i] = evs.load_word<uint32_t>(i, WT_VWORD(delta));
-    }
     const vertex_t& tv = cr.temporary_vert;
-    vertex_t sv0, ev0;
-    bool have_sv0 = false, have_ev0 = false;
+    // entries of the sensor (s*) / emitter (e*) subpath arrays that the connection overrides: `last` = index n-1, `prev` = n-2, `first` = 0
+    float srev_last = 0.f, srev_prev = 0.f, spdf_first = 0.f, erev_last = 0.f, erev_prev = 0.f, epdf_first = 0.f;
+    bool has_srev_last = false, has_srev_prev = false, has_spdf_first = false, has_erev_last = false, has_erev_prev = false, has_epdf_first = false;
     if (s == 0) {
-        vertex_t last, prev;
+        vertex_nb_t last, prev;
         svs.load(t - 1, last);
         svs.load(t - 2, prev);
-        srev[t - 1] = vertex_pdf_emitter(sc, last);
-        srev[t - 2] = vertex_pdf_next_from_emitter(sc, last, prev);
+        srev_last = vertex_pdf_emitter(sc, last);
+        srev_prev = vertex_pdf_next_from_emitter(sc, last, prev);
+        has_srev_last = has_srev_prev = true;
     } else if (t == 0) {
-        vertex_t last, prev;
+        vertex_nb_t prev;
+        evs.load(s - 2, prev);
+        erev_last = vertex_pdf_sensor(sc);
         if (sensor_is_virtual(sc.sensor))
-            last = tv;
-        else
+            erev_prev = vertex_pdf_next_from_sensor(sc, tv, prev);
+        else {
+            vertex_nb_t last;
             evs.load(s - 1, last);
-        evs.load(s - 2, prev);
-        erev[s - 1] = vertex_pdf_sensor(sc);
-        erev[s - 2] = vertex_pdf_next_from_sensor(sc, last, prev);
+            erev_prev = vertex_pdf_next_from_sensor(sc, last, prev);
+        }
+        has_erev_last = has_erev_prev = true;
     } else if (s == 1) {
-        vertex_t last, prev;
+        vertex_nb_t last;
         svs.load(t - 1, last);
-        svs.load(t - 2, prev);
-        srev[t - 1] = vertex_pdf_next_from_emitter(sc, tv, last);
-        erev[0] = vertex_pdf(sc, pool, last, &prev, tv, TRANSPORT_BACKWARD);
-        epdf[0] = vertex_pdf_emitter(sc, tv);
+        srev_last = vertex_pdf_next_from_emitter(sc, tv, last);
+        erev_last = vertex_pdf(sc, pool, last, svs.load_wp(t - 2), tv, TRANSPORT_BACKWARD);   // (index 0 = s - 1)
+        epdf_first = vertex_pdf_emitter(sc, tv);
+        has_srev_last = has_erev_last = has_epdf_first = true;
     } else if (t == 1) {
-        vertex_t last, prev;
+        vertex_nb_t last;
         evs.load(s - 1, last);
-        evs.load(s - 2, prev);
-        erev[s - 1] = vertex_pdf_next_from_sensor(sc, tv, last);
-        srev[0] = vertex_pdf(sc, pool, last, &prev, tv, TRANSPORT_FORWARD);
-        spdf[0] = vertex_pdf_sensor(sc);
+        erev_last = vertex_pdf_next_from_sensor(sc, tv, last);
+        srev_last = vertex_pdf(sc, pool, last, evs.load_wp(s - 2), tv, TRANSPORT_FORWARD);   // (index 0 = t - 1)
+        spdf_first = vertex_pdf_sensor(sc);
+        has_erev_last = has_srev_last = has_spdf_first = true;
     } else {
-        vertex_t ev, sv, ev_prev, sv_prev;
+        vertex_nb_t ev, sv;
         evs.load(s - 1, ev);
         svs.load(t - 1, sv);
+        const vec3 ev_prev_wp = evs.load_wp(s - 2), sv_prev_wp = svs.load_wp(t - 2);
+        // (of the predecessors as `next`: position, surface normal and what vertex_is_on_surface reads)
+        vertex_nb_t ev_prev, sv_prev;
         evs.load(s - 2, ev_prev);
         svs.load(t - 2, sv_prev);
-        erev[s - 1] = vertex_pdf(sc, pool, sv, &sv_prev, ev, TRANSPORT_BACKWARD);
-        erev[s - 2] = vertex_pdf(sc, pool, ev, &sv, ev_prev, TRANSPORT_BACKWARD);
-        srev[t - 1] = vertex_pdf(sc, pool, ev, &ev_prev, sv, TRANSPORT_FORWARD);
-        srev[t - 2] = vertex_pdf(sc, pool, sv, &ev, sv_prev, TRANSPORT_FORWARD);
+        erev_last = vertex_pdf(sc, pool, sv, sv_prev_wp, ev, TRANSPORT_BACKWARD);
+        erev_prev = vertex_pdf(sc, pool, ev, vertex_wp(sv), ev_prev, TRANSPORT_BACKWARD);
+        srev_last = vertex_pdf(sc, pool, ev, ev_prev_wp, sv, TRANSPORT_FORWARD);
+        srev_prev = vertex_pdf(sc, pool, sv, vertex_wp(ev), sv_prev, TRANSPORT_FORWARD);
+        has_erev_last = has_erev_prev = has_srev_last = has_srev_prev = true;
     }
-    if (t > 0) sdel[t - 1] = 0;
-    if (s > 0) edel[s - 1] = 0;
     bool delta_emitter, delta_sensor;
     if (s == 1)
         delta_emitter = vertex_is_delta_emitter(sc, tv);
     else if (s > 1) {
-        evs.load(0, ev0);
-        have_ev0 = true;
+        struct {
+            uint32_t type;
+            int32_t ref;
+        } ev0{evs.load_word<uint32_t>(0, WT_VWORD(type)), evs.load_word<int32_t>(0, WT_VWORD(ref))};
         delta_emitter = vertex_is_delta_emitter(sc, ev0);
     } else
         delta_emitter = true;
     if (t == 1)
         delta_sensor = vertex_is_delta_sensor(sc, tv);
     else if (t > 1) {
-        svs.load(0, sv0);
-        have_sv0 = true;
+        struct {
+            uint32_t type;
+        } sv0{svs.load_word<uint32_t>(0, WT_VWORD(type))};
         delta_sensor = vertex_is_delta_sensor(sc, sv0);
     } else
         delta_sensor = true;
-    (void)have_sv0;
-    (void)have_ev0;
 
     float sum_Ri = 0.f, ri = 1.f;
-    for (int i = t - 1; i >= 0; --i) {
-        const float fwd = (finitef(spdf[i]) && spdf[i] > FLT_EPSILON) ? spdf[i] : 1.f;
-        const float rev = (finitef(srev[i]) && srev[i] > FLT_EPSILON) ? srev[i] : 1.f;
-        ri *= rev / fwd;
-        if (!sdel[i] && !(i > 0 ? (sdel[i - 1] != 0) : delta_sensor)) sum_Ri += ri;
+    {
+        // sensor subpath, i = t-1 .. 0: fwd = pdf_bwd, rev = pdf_fwd; the connection vertex counts as non-delta
+        bool del_i = false;   // sdel[t-1] = 0
+        for (int i = t - 1; i >= 0; --i) {
+            const float f = (i == 0 && has_spdf_first) ? spdf_first : svs.load_word<float>(i, WT_VWORD(pdf_bwd));
+            const float rv = (i == t - 1 && has_srev_last) ? srev_last : ((i == t - 2 && has_srev_prev) ? srev_prev : svs.load_word<float>(i, WT_VWORD(pdf_fwd)));
+            const bool del_prev = i > 0 ? svs.load_word<uint32_t>(i - 1, WT_VWORD(delta)) != 0 : delta_sensor;
+            const float fwd = (finitef(f) && f > FLT_EPSILON) ? f : 1.f;
+            const float rev = (finitef(rv) && rv > FLT_EPSILON) ? rv : 1.f;
+            ri *= rev / fwd;
+            if (!del_i && !del_prev) sum_Ri += ri;
+            del_i = del_prev;
+        }
     }
     ri = 1.f;
-    for (int i = s - 1; i >= 0; --i) {
-        const float fwd = (finitef(epdf[i]) && epdf[i] > FLT_EPSILON) ? epdf[i] : 1.f;
-        const float rev = (finitef(erev[i]) && erev[i] > FLT_EPSILON) ? erev[i] : 1.f;
-        ri *= rev / fwd;
-        if (!edel[i] && !(i > 0 ? (edel[i - 1] != 0) : delta_emitter)) sum_Ri += ri;
+    {
+        bool del_i = false;   // edel[s-1] = 0
+        for (int i = s - 1; i >= 0; --i) {
+            const float f = (i == 0 && has_epdf_first) ? epdf_first : evs.load_word<float>(i, WT_VWORD(pdf_fwd));
+            const float rv = (i == s - 1 && has_erev_last) ? erev_last : ((i == s - 2 && has_erev_prev) ? erev_prev : evs.load_word<float>(i, WT_VWORD(pdf_bwd)));
+            const bool del_prev = i > 0 ? evs.load_word<uint32_t>(i - 1, WT_VWORD(delta)) != 0 : delta_emitter;
+            const float fwd = (finitef(f) && f > FLT_EPSILON) ? f : 1.f;
+            const float rev = (finitef(rv) && rv > FLT_EPSILON) ? rv : 1.f;
+            ri *= rev / fwd;
+            if (!del_i && !del_prev) sum_Ri += ri;
+            del_i = del_prev;
+        }
     }
     return 1.f / (1.f + sum_Ri);
 }

@@ -117,6 +117,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
     rec.overflow = 0;
     rec.aborted = 0;
     rec.too_short = 0;
+    rec.short_tuid = kInvalid;
     if (sc.n_nodes == 0) return false;
     const vec3 ro = cone.o, rd = cone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
@@ -172,6 +173,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
             const unsigned long long mask = __ballot(hit);
             if (!mask) continue;
             if (any_hit) {
+                rec.short_tuid = (uint32_t)__shfl((int)t2, __ffsll((long long)mask) - 1, 64);
                 any = true;
                 break;
             }
@@ -182,6 +184,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 rec.front_face = (uint32_t)__shfl((int)ff, src, 64);
                 rec.dist = dm;
                 if (rec.dist - searchrange.min < min_progress) {   // decided: too near to be accepted (see bvh_traverse_cone)
+                    rec.short_tuid = (uint32_t)__shfl((int)t2, src, 64);
                     rec.too_short = 1;
                     any = true;
                     break;
@@ -334,10 +337,13 @@ __device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const ra
     coop_cone_query<false>(sc, cone, searchrange, z_scale, sh, tris, rec, prof, min_progress);
 }
 // Wave-cooperative any-hit probe (see bvh_cone_any_hit).
-__device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh, unsigned long long* prof = nullptr) {
+__device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh, unsigned long long* prof = nullptr,
+                                     uint32_t* hit_tuid = nullptr) {
     cone_hit_t rec;
     const uint_list_t none{nullptr, 0, 0};
-    return coop_cone_query<true>(sc, cone, range, 0.f, sh, none, rec, prof);
+    const bool hit = coop_cone_query<true>(sc, cone, range, 0.f, sh, none, rec, prof);
+    if (hit_tuid) *hit_tuid = rec.short_tuid;
+    return hit;
 }
 
 // ---- interaction-region gather for beams whose footprint holds more triangles than the bounded list (kMaxConeTris) -----------
@@ -766,7 +772,8 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
 __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
                                               coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr, bool resume = false,
                                               uint32_t seg0 = 0, float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0, const ray_hit_t* axis = nullptr,
-                                              bool primary_always = false, bool probe_resumed = true) {
+                                              bool primary_always = false, bool probe_resumed = true, uint32_t short_tuid = kInvalid,
+                                              uint32_t origin_tuid = kInvalid, bool use_cache = true) {
 #ifdef WTGPU_COOP_PROF
 #define WT_COOP_PROF(i, t0_)
 #else
@@ -832,14 +839,32 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         const long long tp0 = prof ? clock64() : 0;
         // (probe_resumed = false: not for the query a per-lane attempt handed over — that attempt spent its budget near-first without
         // meeting a too-near hit, so the full query, which also stops at the first too-near hit, rarely finds one)
-        const bool near_hit = (probe_resumed || !(resume && seg == seg0)) && coop_cone_any(sc, envelope, range_t{dist, fminf_(distance, dist + min_df_prog)}, sh, prof);
+        // ... and before the probe the two remembered triangles (see wt::traverse_axis): the one that satisfied the previous probe — or made
+        // the per-lane attempt before the hand-over too short — and the one the beam started from.  Same test, same slab as the probe's.
+        const range_t thin{dist, fminf_(distance, dist + min_df_prog)};
+        bool near_hit = false;
+        for (int c = 0; c < 2 && !near_hit; ++c) {
+            const uint32_t cand = c == 0 ? short_tuid : origin_tuid;
+            if (!use_cache || cand == kInvalid || (c == 1 && cand == short_tuid)) continue;
+            const tri_geo_t tri = sc.tri_geo[cand];
+            cone_tri_hit_t ht;
+            near_hit = intersect_cone_tri<true>(envelope, tri.a, tri.b, tri.c, tri.n, thin, ht) && !(ht.dist > thin.max);
+        }
+        if (!near_hit) {
+            uint32_t hit_tuid = kInvalid;
+            near_hit = (probe_resumed || !(resume && seg == seg0)) && coop_cone_any(sc, envelope, thin, sh, prof, &hit_tuid);
+            if (near_hit) short_tuid = hit_tuid;
+        }
         WT_COOP_PROF(1, tp0)
         if (near_hit) continue;   // too short (see bvh_cone_any_hit)
         const long long tc0 = prof ? clock64() : 0;
         const float cone_max = axis_hit ? fminf_(distance, cone_axis_bound(envelope, ah.dist)) : distance;
         coop_cone(sc, envelope, range_t{dist, cone_max}, kMajorAxisToZScale, sh, tris, ch, prof, min_df_prog);
         WT_COOP_PROF(2, tc0)
-        if (ch.too_short) continue;   // (boundary case of the probe's inclusive slab)
+        if (ch.too_short) {   // (boundary case of the probe's inclusive slab)
+            short_tuid = ch.short_tuid;
+            continue;
+        }
         const bool df_empty = ch.ntris == 0 && ch.overflow == 0;
         if (df_empty || ch.dist - dist >= min_df_prog) {
             r.ballistic = 0;

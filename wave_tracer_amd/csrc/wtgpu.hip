@@ -166,7 +166,7 @@ struct wtgpu_scene {
     size_t query_scratch_bytes = 0;
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
-        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0;
+        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, lane_cache = 1, heavy_cache = 1;
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
     } knobs;
@@ -208,6 +208,7 @@ struct launch_args_t {
     uint32_t heavy_probe;   // k_trace_heavy: any-hit probe of the near slab before the handed-over cone query too
     uint32_t coop_aperture_min;   // regions with at least this many classified edges get their aperture built by k_edges' wavefront
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
+    uint32_t lane_cache, heavy_cache;   // diagnostic switches of the remembered rejecting triangles (wt::traverse_axis / coop_traverse); default on
     uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
 };
 
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
             uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;   // 64 triangle ids + their 64 cone-hit distances
             const uint_list_t tris{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
             const cone_t env = walk_trace_envelope(a.sc, wk);
-            const trav_result_t tr = traverse_axis(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true, !a.collect_list);
+            const trav_result_t tr = traverse_axis(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
             if (tr.aborted == 1) {
                 heavy = true;
                 // resume state for k_trace_heavy (traverse_axis(): dist / ntris = segment / query counts so far + the axis hit)
@@ -341,6 +342,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
                 a.st.trav[WT_TRAV_WORD(by) * W2 + w] = __float_as_uint(tr.by);
                 a.st.trav[WT_TRAV_WORD(pdist) * W2 + w] = __float_as_uint(tr.pdist);
                 a.st.trav[WT_TRAV_WORD(front_face) * W2 + w] = tr.front_face;
+                a.st.trav[WT_TRAV_WORD(overflow) * W2 + w] = tr.overflow;   // the triangle that made the last attempt too short (kInvalid: none)
             } else {
                 soa_store(a.st.trav, W2, w, tr);
                 ctr.segments += 1;
@@ -350,6 +352,152 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
             }
         }
         wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w);
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
+// k_trace with LANE REFILL (the default; the kernel above is kept as the A/B reference, WTGPU_TRACE_REFILL=0).
+// The cost of a walk's traversal varies by two orders of magnitude — one to seven cone queries of 2..cone_budget work units each —
+// and in the kernel above a wavefront is as slow as its slowest lane: its lanes run the policy and their queries back to back and
+// wait at the end for the longest.  Here a lane is a slot that walks pass through.  The wavefront alternates between
+//   * the traversal loop: every lane that holds a node descends (cq_node_step), every lane that holds a leaf tests its triangles
+//     (cq_leaf_step) — the steps of wt/bvh.h, which the CPU checker drives one query at a time —
+//   * and the service section, entered once enough lanes wait: a lane whose query ended gets the policy's next query (aw_query_done /
+//     aw_next) or stores its record, and lanes without a walk fetch new ones from the queue (one atomic per wavefront), trace the beam
+//     axis and start their first query.
+// A slow query therefore occupies one lane, not 64, which is also what lets the work budget per query be larger (fewer walks
+// handed to the wave-cooperative kernel).  Per walk the sequence of visits and the results are those of wt::traverse_axis.
+#ifndef WTGPU_REFILL_MIN
+#define WTGPU_REFILL_MIN 16
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_COUNT0 + in];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
+        ctl[CTL_HEAD_INTERACT] = 0;
+        ctl[CTL_INTB_COUNT] = 0;
+        ctl[CTL_INTB_HEAD] = 0;
+        ctl[CTL_GATHER_COUNT] = 0;
+        ctl[CTL_GATHER_HEAD] = 0;
+        ctl[CTL_INTC_COUNT] = 0;
+        ctl[CTL_INTC_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = 0;
+        ctl[CTL_FTASK_HEAD] = 0;
+        ctl[CTL_FSPLIT_HEAD] = 0;
+        ctl[CTL_EPOOL_COUNT] = 0;
+        if (n > 0) ctl[CTL_ROUNDS] = round + 1;
+    }
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // lane state: 0 = no walk, 1 = cone query running, 2 = cone query ended (to be served)
+    int st = 0;
+    uint32_t w = 0;
+    cone_t env;
+    axis_walk_t aw;
+    cone_query_t q;
+    uint_list_t tris{nullptr, 1u, 0u, nullptr};
+    memset(&env, 0, sizeof(env));
+    memset(&aw, 0, sizeof(aw));
+    memset(&q, 0, sizeof(q));
+    bool exhausted = false;   // wave-uniform: the queue holds no more walks
+    for (;;) {
+        // ---- service section
+        bool fin = false;
+        trav_result_t r;
+        if (st == 2) {
+            cq_end(env, tris, q);
+            fin = aw_query_done(a.sc, env, aw, q.rec, r);
+            if (!fin) fin = !aw_next(a.sc, env, rt, stack, aw, q, r);
+            st = fin ? 0 : 1;
+        }
+        // (records of finished walks are stored below, together with those of freshly fetched walks that need no cone query)
+        uint32_t w_fin = w;
+        const int n_idle = __popcll(__ballot(st == 0 && !fin)), n_run = __popcll(__ballot(st == 1));
+        bool fetched = false;
+        const bool any_fin = __ballot(fin) != 0;   // (their records are stored first; they fetch in the next turn)
+        if (!exhausted && !any_fin && (n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
+            const unsigned long long im = __ballot(st == 0);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(ctl + CTL_HEAD_TRACE, (uint32_t)__popcll(im));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
+            const uint32_t qi = base + (uint32_t)__popcll(im & below);
+            if (st == 0 && qi < n) {
+                w = queue_walk(a, a.st.queue[in], qi, first_round);
+                w_fin = w;
+                const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
+                // plt_bdpt: the bounded list (64 triangles + their cone-hit distances) of the interaction region; see k_trace
+                uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
+                tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
+                env = walk_trace_envelope(a.sc, wk);
+                ray_hit_t ah;
+                const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
+                aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
+                aw.use_cache = a.lane_cache;
+                fin = !aw_next(a.sc, env, rt, stack, aw, q, r);
+                st = fin ? 0 : 1;
+            }
+            fetched = true;
+        }
+        // store the records of the walks that ended in this section (convergent: the queue append is a wave operation)
+        {
+            const bool heavy = fin && r.aborted == 1;
+            if (fin) {
+                if (heavy) {
+                    // resume state for k_trace_heavy (aw_query_done: dist / ntris = distance / segment of the query, the axis hit, the last
+                    // rejecting triangle in `overflow`)
+                    a.st.trav[WT_TRAV_WORD(dist) * W2 + w_fin] = __float_as_uint(r.dist);
+                    a.st.trav[WT_TRAV_WORD(ntris) * W2 + w_fin] = r.ntris;
+                    a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w_fin] = r.n_ray_queries;
+                    a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w_fin] = r.n_cone_queries;
+                    a.st.trav[WT_TRAV_WORD(tuid) * W2 + w_fin] = r.tuid;
+                    a.st.trav[WT_TRAV_WORD(bx) * W2 + w_fin] = __float_as_uint(r.bx);
+                    a.st.trav[WT_TRAV_WORD(by) * W2 + w_fin] = __float_as_uint(r.by);
+                    a.st.trav[WT_TRAV_WORD(pdist) * W2 + w_fin] = __float_as_uint(r.pdist);
+                    a.st.trav[WT_TRAV_WORD(front_face) * W2 + w_fin] = r.front_face;
+                    a.st.trav[WT_TRAV_WORD(overflow) * W2 + w_fin] = r.overflow;
+                } else {
+                    soa_store(a.st.trav, W2, w_fin, r);
+                    ctr.segments += 1;
+                    ctr.ray_queries += r.n_ray_queries;
+                    ctr.cone_queries += r.n_cone_queries;
+                    if (a.collect_list) ctr.cone_tri_overflow += r.overflow;
+                }
+            }
+            wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w_fin);
+        }
+        // walks that ended left their lanes free: fetch (more) before traversing
+        if (fetched || any_fin) continue;
+        const int running = __popcll(__ballot(st == 1));
+        if (running == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_REFILL_MIN) wait to be served
+        const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
+        for (;;) {
+            // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
+            for (;;) {
+                const bool at_node = st == 1 && q.leaf == 0 && q.s > 0;
+                const unsigned long long nm = __ballot(at_node);
+                if (!nm) break;
+                if (at_node) cq_node_step(a.sc, env, stack, q);
+                if (2 * __popcll(__ballot(st == 1 && q.leaf != 0)) >= running) break;
+            }
+            if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
+            if (st == 1 && !cq_running(q)) st = 2;
+            const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
+            if (waiting >= leave_at || !__ballot(st == 1)) break;
+        }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
@@ -387,8 +535,9 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
         axis.by = __uint_as_float(a.st.trav[WT_TRAV_WORD(by) * W2 + w]);
         axis.dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(pdist) * W2 + w]);
         axis.front_face = a.st.trav[WT_TRAV_WORD(front_face) * W2 + w];
+        const uint32_t short0 = a.st.trav[WT_TRAV_WORD(overflow) * W2 + w];
         const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
-                                                &axis, !a.collect_list, a.heavy_probe != 0);
+                                                &axis, !a.collect_list, a.heavy_probe != 0, a.heavy_cache ? short0 : kInvalid, a.heavy_cache ? wk.prev_offset_tuid : kInvalid, a.heavy_cache != 0);
         if (a.profile == 2 && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
@@ -1355,6 +1504,9 @@ static void read_knobs(wtgpu_scene* s) {
     wtgpu_scene::knobs_t& k = s->knobs;
     k.cone_budget = u("WTGPU_CONE_BUDGET", kConeBudget);
     k.count_stats = u("WTGPU_COUNT_STATS", 1);
+    k.lane_cache = u("WTGPU_LANE_CACHE", 1);
+    k.heavy_cache = u("WTGPU_HEAVY_CACHE", 1);
+    k.trace_refill = u("WTGPU_TRACE_REFILL", 1);   // 0: the per-lane trace kernel without lane refill (A/B reference)
     k.profile = u("WTGPU_PROFILE", 0);
     k.no_lists = getenv("WTGPU_NO_LISTS") ? 1u : 0u;
     k.heavy_waves_per_cu = std::max(1u, u("WTGPU_HEAVY_WAVES", 8));   // swept 6 / 8 / 10 / 12 / 16 / 24 / 32: 169.6 / 168.0 / 171.6 / 174.3 / 176 / 181 / 183 ms per pass
@@ -1557,6 +1709,8 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     a.profile = K.profile;
     a.coop_aperture_min = K.coop_aperture_min;
     a.heavy_probe = K.heavy_probe;
+    a.lane_cache = K.lane_cache;
+    a.heavy_cache = K.heavy_cache;
     a.flux_task_tris = K.flux_task_tris;
     // Bounded triangle lists (64) are the fast path of an interaction region; a region that overflows its list is handled exactly by
     // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_flux_*).
@@ -1612,7 +1766,12 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             const uint32_t shrink = round < 6 ? 1u : (round < 24 ? 4u : 32u);
             const uint32_t g0 = std::max<uint32_t>(1u, g_full / shrink);
             const uint32_t gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < 24 ? 1u : 32u));
-            if (dbg_stage >= 2 + 3 * (int)round) hipLaunchKernelGGL(k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+            if (dbg_stage >= 2 + 3 * (int)round) {
+                if (K.trace_refill)
+                    hipLaunchKernelGGL(k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                else
+                    hipLaunchKernelGGL(k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+            }
             rec();
             if (dbg_stage >= 3 + 3 * (int)round) hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
