@@ -68,37 +68,37 @@ struct vertex_nb_t {
 };
 static_assert(offsetof(vertex_nb_t, beam) == offsetof(vertex_t, beam) && offsetof(vertex_nb_t, surf) == offsetof(vertex_t, surf), "vertex_nb_t is a prefix of vertex_t");
 
-// strided vertex store: vertex v of walk `idx` = words at base[(v*kVertexWords + w)*stride + idx]
+// vertex store: vertex v of walk `idx` = words at base[idx*stride + v*kVertexWords + w] (stride = words of one walk's vertex array)
 struct vertex_store_t {
     uint32_t* base;
     size_t stride;
     size_t idx;
-    WT_HD void load(uint32_t v, vertex_t& out) const { soa_load(base + (size_t)v * kVertexWords * stride, stride, idx, out); }
+    WT_HD void load(uint32_t v, vertex_t& out) const { soa_load(base + (size_t)v * kVertexWords, stride, idx, out); }
     // the beam-less part of a vertex (+ its wavenumber)
     WT_HD void load(uint32_t v, vertex_nb_t& out) const {
-        const uint32_t* b = base + (size_t)v * kVertexWords * stride;
+        const uint32_t* b = base + (size_t)v * kVertexWords + idx * stride;
         uint32_t* w = reinterpret_cast<uint32_t*>(&out);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (size_t i = 0; i < offsetof(vertex_t, beam) / 4; ++i) w[i] = b[i * stride + idx];
+        for (size_t i = 0; i < offsetof(vertex_t, beam) / 4; ++i) w[i] = b[i];
         out.beam.k = load_word<float>(v, (offsetof(vertex_t, beam) + offsetof(beam_t, k)) / 4);
     }
     WT_HD vec3 load_wp(uint32_t v) const {
         constexpr size_t o = (offsetof(vertex_t, surf) + offsetof(surface_t, wp)) / 4;
         return vec3{load_word<float>(v, o), load_word<float>(v, o + 1), load_word<float>(v, o + 2)};
     }
-    WT_HD void store(uint32_t v, const vertex_t& in) const { soa_store(base + (size_t)v * kVertexWords * stride, stride, idx, in); }
+    WT_HD void store(uint32_t v, const vertex_t& in) const { soa_store(base + (size_t)v * kVertexWords, stride, idx, in); }
     template <class F>
     WT_HD void store_word(uint32_t v, size_t word, F value) const {
         static_assert(sizeof(F) == 4, "");
         uint32_t w;
         __builtin_memcpy(&w, &value, 4);
-        base[((size_t)v * kVertexWords + word) * stride + idx] = w;
+        base[idx * stride + (size_t)v * kVertexWords + word] = w;
     }
     template <class F>
     WT_HD F load_word(uint32_t v, size_t word) const {
-        const uint32_t w = base[((size_t)v * kVertexWords + word) * stride + idx];
+        const uint32_t w = base[idx * stride + (size_t)v * kVertexWords + word];
         F f;
         __builtin_memcpy(&f, &w, 4);
         return f;
@@ -425,7 +425,7 @@ struct walk_trace_in_t {
 template <class F>
 WT_HD F soa_word(const uint32_t* base, size_t stride, size_t idx, size_t word) {
     static_assert(sizeof(F) == 4, "");
-    const uint32_t w = base[word * stride + idx];
+    const uint32_t w = base[idx * stride + word];
     F f;
     __builtin_memcpy(&f, &w, 4);
     return f;

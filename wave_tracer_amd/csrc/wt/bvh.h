@@ -109,71 +109,103 @@ WT_HD bool ray_gather_tris(const scene_t& sc, vec3 ro, vec3 rd, uint32_t t0, uin
 // Closest-hit (shadow=false) or any-hit (shadow=true) ray traversal (bvh8w.cpp:469-554).
 // Box culling uses [range.min, min(range.max, closest)] instead of the reference's [0, closest]; the set of
 // accepted triangles is identical because the triangle test itself enforces `range`.
+//
+// Written as resumable steps over an explicit state (ray_query_t) like the cone query further down: rq_begin, then rq_node_step while
+// the query holds no leaf and rq_leaf_step when it does, until rq_running() is false.  bvh_traverse_ray is the sequential driver;
+// the device's trace kernel runs the axis queries of its lanes through the same steps, interleaved with their cone queries.
+struct ray_query_t {
+    range_t range;
+    ray_hit_t rec;
+    int s;                  // stack entries
+    uint32_t lt0, lcnt;     // triangles to test next (lcnt = 0: none)
+};
+WT_HD bool rq_running(const ray_query_t& q) { return q.s > 0 || q.lcnt != 0; }
+WT_HD void rq_begin(const scene_t& sc, const range_t& range, const stack_ref_t& stack, ray_query_t& q) {
+    q.range = range;
+    q.rec.dist = WT_INF;
+    q.rec.tuid = kInvalid;
+    q.rec.bx = q.rec.by = 0.f;
+    q.rec.front_face = 0;
+    q.lt0 = q.lcnt = 0;
+    q.s = 0;
+    if (sc.n_nodes == 0) return;
+    q.s = 1;
+    stack[0] = stack_entry_t{0.f, 1};
+}
+// pops one entry: a leaf (or a node with few triangles) is kept for rq_leaf_step, a node's children are tested and pushed far-first
+// (requires q.s > 0, q.lcnt == 0)
+WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& stack, ray_query_t& q, bvh_counters_t* ctr = nullptr) {
+    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
+    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    int s = q.s;
+    const stack_entry_t top = stack[s - 1];
+    --s;
+    q.s = s;
+    if (top.ptr < 0) {
+        const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
+        if (ctr) ctr->leaves++;
+        q.lt0 = leaf.tris_ptr;
+        q.lcnt = leaf.count;
+        return;
+    }
+    // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+    // one per child field); the unrolled child loop then runs from registers
+    const bvh8_node_t n = sc.nodes[top.ptr - 1];
+    if ((int)n.tris_count <= kRayLeafShortcut) {
+        q.lt0 = n.tris_start;
+        q.lcnt = n.tris_count;
+        return;
+    }
+    if (ctr) ctr->nodes++;
+    const float tfar = fminf_(q.rec.dist, q.range.max);
+    const int begin = s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int32_t cp = n.child[i];
+        if (cp == 0) continue;
+        const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
+        const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
+        const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
+        const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
+        const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
+        const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
+        const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, q.range.min));
+        const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
+        if (rmin <= rmax && s < (int)stack.cap) stack[s++] = stack_entry_t{rmin, cp};
+    }
+    stack_sort_desc(stack, begin, s);
+    q.s = s;
+}
+// tests the held triangles (requires q.lcnt != 0); TRUE: an any-hit (shadow) query is decided
+template <bool shadow>
+WT_HD bool rq_leaf_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& stack, ray_query_t& q, bvh_counters_t* ctr = nullptr) {
+    const uint32_t lt0 = q.lt0, lcnt = q.lcnt;
+    q.lcnt = 0;
+    const bool intr = ray_gather_tris<shadow>(sc, ro, rd, lt0, lcnt, q.range, q.rec, ctr);
+    if (intr) {
+        if (shadow) {
+            q.s = 0;
+            return true;
+        }
+        int s = q.s;
+        while (s > 0 && stack[s - 1].t >= q.rec.dist) --s;
+        q.s = s;
+    }
+    return false;
+}
 template <bool shadow>
 WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack, ray_hit_t& rec,
                             bvh_counters_t* ctr = nullptr) {
-    rec.dist = WT_INF;
-    rec.tuid = kInvalid;
-    rec.bx = rec.by = 0.f;
-    rec.front_face = 0;
-    if (sc.n_nodes == 0) return false;
-    const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
-    const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
-
     // "while-while" form (Aila & Laine): every lane of a wavefront first descends through nodes until it holds a leaf (lanes that
     // found theirs wait at the inner loop's exit), then all of them test their leaf's triangles together — instead of paying the node
     // path AND the leaf path in every iteration because some lane needs each.  Per lane the order of visits is unchanged.
-    int s = 1;
-    stack[0] = stack_entry_t{0.f, 1};
-    while (s > 0) {
-        bool have_leaf = false;
-        uint32_t lt0 = 0, lcnt = 0;
-        while (s > 0) {
-            const stack_entry_t top = stack[s - 1];
-            --s;
-            if (top.ptr < 0) {
-                const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
-                if (ctr) ctr->leaves++;
-                lt0 = leaf.tris_ptr;
-                lcnt = leaf.count;
-                have_leaf = true;
-                break;
-            }
-            // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
-            // one per child field); the unrolled child loop then runs from registers
-            const bvh8_node_t n = sc.nodes[top.ptr - 1];
-            if ((int)n.tris_count <= kRayLeafShortcut) {
-                lt0 = n.tris_start;
-                lcnt = n.tris_count;
-                have_leaf = true;
-                break;
-            }
-            if (ctr) ctr->nodes++;
-            const float tfar = fminf_(rec.dist, range.max);
-            const int begin = s;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int32_t cp = n.child[i];
-                if (cp == 0) continue;
-                const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
-                const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
-                const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
-                const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
-                const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
-                const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
-                const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, range.min));
-                const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
-                if (rmin <= rmax && s < (int)stack.cap) stack[s++] = stack_entry_t{rmin, cp};
-            }
-            stack_sort_desc(stack, begin, s);
-        }
-        if (!have_leaf) break;
-        const bool intr = ray_gather_tris<shadow>(sc, ro, rd, lt0, lcnt, range, rec, ctr);
-        if (intr) {
-            if (shadow) return true;
-            while (s > 0 && stack[s - 1].t >= rec.dist) --s;
-        }
+    ray_query_t q;
+    rq_begin(sc, range, stack, q);
+    while (rq_running(q)) {
+        while (q.s > 0 && q.lcnt == 0) rq_node_step(sc, ro, rd, stack, q, ctr);
+        if (q.lcnt != 0 && rq_leaf_step<shadow>(sc, ro, rd, stack, q, ctr)) break;
     }
+    rec = q.rec;
     return rec.dist < WT_INF;
 }
 
@@ -356,59 +388,70 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
     stack_sort_desc(stack, begin, s);
     q.s = s;
 }
-// tests the triangles of the held leaf (requires q.leaf != 0)
-WT_HD void cq_leaf_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q,
-                        bvh_counters_t* ctr = nullptr) {
-    const vec3 rd = cone.d;
+// What follows from a hit of the running query at distance `dist` on triangle `tuid`: closest distance, list entry, early exit, slab
+// shrink and stack pruning (the body of the reference's leaf loop, bvh8w.cpp:134-185).
+WT_HD void cq_apply_hit(const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q, uint32_t tuid, float dist, bool front_face) {
+    cone_hit_t& rec = q.rec;
+    const bool moved = dist < rec.dist;
+    if (moved) {
+        rec.dist = dist;
+        rec.front_face = front_face;
+    }
+    if (rec.ntris < tris.cap) {
+        if (tris.d) tris.d[(size_t)rec.ntris * tris.stride] = dist;
+        tris[rec.ntris++] = tuid;
+    } else
+        rec.overflow++;
+    // integrator::traverse discards a diffusive hit closer than `min_progress` to the start of the search
+    // (traversal.hpp:146,157); the closest distance only ever decreases, so the outcome is decided right here
+    if (rec.dist - q.sr.min < q.min_progress) {
+        rec.too_short = 1;
+        rec.short_tuid = moved ? tuid : rec.short_tuid;
+        cq_stop(q);
+        return;
+    }
+    if (moved) rec.short_tuid = tuid;   // (the triangle of the closest hit so far: names the rejecting triangle if the query ends too short)
+    q.range = cone_search_range(cone, q.sr, rec.dist, q.z_scale);
+    // Bounded-list regime (device only; the CPU checker's list never saturates): once the triangle list is full
+    // nothing further can be recorded, so only triangles that can still lower the closest distance matter.
+    if (rec.overflow > 0) q.range.max = fminf_(q.range.max, rec.dist);
+    int s = q.s;
+    while (s > 0 && stack[s - 1].t >= q.range.max) --s;
+    q.s = s;
+}
+// One exact cone-triangle test of the running query.
+WT_HD void cq_exact_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q, uint32_t tuid,
+                         bvh_counters_t* ctr = nullptr) {
+    const tri_geo_t tri = sc.tri_geo[tuid];
+    if (ctr) ctr->cone_tri_tests++;
+    cone_tri_hit_t h;
+    if (!intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, q.range, h)) return;
+    if (h.dist > q.range.max) return;   // numerics (bvh8w.cpp:162)
+    cq_apply_hit(cone, stack, tris, q, tuid, h.dist, dot(tri.n, -cone.d) > 0.f);
+}
+// Takes the held leaf (requires q.leaf != 0): charges its triangles to the budget and returns them as (first, count); count 0 when the
+// budget is exceeded (the query is stopped).
+WT_HD bvh8_leaf_t cq_take_leaf(cone_query_t& q, bvh_counters_t* ctr = nullptr) {
     const bvh8_leaf_t leaf = bvh_leaf_of(q.leaf);
     q.leaf = 0;
     if (ctr) ctr->cone_leaves++;
-    bool found = false;
-    uint32_t nearest_here = kInvalid;
     q.tests += leaf.count;
     if (q.tests > q.budget) {
         q.rec.aborted = 1;
         cq_stop(q);
-        return;
+        return bvh8_leaf_t{0u, 0u};
     }
-    cone_hit_t& rec = q.rec;
+    return leaf;
+}
+// tests the triangles of the held leaf one after the other (the sequential form; requires q.leaf != 0)
+WT_HD void cq_leaf_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q,
+                        bvh_counters_t* ctr = nullptr) {
+    const bvh8_leaf_t leaf = cq_take_leaf(q, ctr);
+    const int s_before = q.s;
+    (void)s_before;
     for (uint32_t t = 0; t < leaf.count; ++t) {
-        const uint32_t tuid = leaf.tris_ptr + t;
-        const tri_geo_t tri = sc.tri_geo[tuid];
-        if (ctr) ctr->cone_tri_tests++;
-        const bool front_face = dot(tri.n, -rd) > 0.f;
-        cone_tri_hit_t h;
-        if (intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, q.range, h)) {
-            if (h.dist > q.range.max) continue;   // numerics (bvh8w.cpp:162)
-            if (h.dist < rec.dist) {
-                rec.dist = h.dist;
-                rec.front_face = front_face;
-                nearest_here = tuid;
-            }
-            found = true;
-            if (rec.ntris < tris.cap) {
-                if (tris.d) tris.d[(size_t)rec.ntris * tris.stride] = h.dist;
-                tris[rec.ntris++] = tuid;
-            } else
-                rec.overflow++;
-        }
-    }
-    if (found) {
-        // integrator::traverse discards a diffusive hit closer than `min_progress` to the start of the search
-        // (traversal.hpp:146,157); the closest distance only ever decreases, so the outcome is decided right here
-        if (rec.dist - q.sr.min < q.min_progress) {
-            rec.too_short = 1;
-            rec.short_tuid = nearest_here;   // (the closest hit moved in this leaf, or the exit would have been taken earlier)
-            cq_stop(q);
-            return;
-        }
-        q.range = cone_search_range(cone, q.sr, rec.dist, q.z_scale);
-        // Bounded-list regime (device only; the CPU checker's list never saturates): once the triangle list is full
-        // nothing further can be recorded, so only triangles that can still lower the closest distance matter.
-        if (rec.overflow > 0) q.range.max = fminf_(q.range.max, rec.dist);
-        int s = q.s;
-        while (s > 0 && stack[s - 1].t >= q.range.max) --s;
-        q.s = s;
+        cq_exact_step(sc, cone, stack, tris, q, leaf.tris_ptr + t, ctr);
+        if (q.rec.too_short) return;
     }
 }
 // after the last step: the triangles beyond the final slab leave the list (cone_work_to_intersection_record)
@@ -702,6 +745,8 @@ struct axis_walk_t {
     uint32_t cone_budget, probe_first, primary_always;
     uint32_t use_cache;   // (diagnostic switch: 0 = the remembered triangles are not consulted)
     float min_df_prog;
+    range_t sr;                 // search range of the current segment's diffusive attempt
+    uint32_t cand_idx, cand;    // remembered triangles of the current segment tried so far (0: at the start of a segment) / the one to test
 };
 WT_HD void trav_result_init(trav_result_t& r, vec3 origin) {
     r.aborted = 0;
@@ -727,45 +772,62 @@ WT_HD void aw_ballistic_hit(const axis_walk_t& a, trav_result_t& r) {
     r.front_face = a.ah.front_face;
     r.ntris = 1;
 }
-// TRUE: the cone query `q` (begun on `stack`) has to run next; FALSE: the traversal is over, `r` is final.
-WT_HD bool aw_next(const scene_t& sc, const cone_t& envelope, bool force_ray_tracing, const stack_ref_t& stack, axis_walk_t& a, cone_query_t& q, trav_result_t& r) {
-    trav_result_init(r, envelope.o);
-    if (force_ray_tracing || cone_is_ray(envelope)) {
-        if (a.axis_hit) aw_ballistic_hit(a, r);
-        r.n_ray_queries = a.n_ray_queries;
-        r.n_cone_queries = a.n_cone_queries;
-        return false;
+// What the policy needs next.  AW_FINAL: nothing — the traversal is over, `r` is final.  AW_QUERY: the cone query `q` (begun on `stack`)
+// has to run; feed its outcome to aw_query_done.  AW_TEST: one exact cone-triangle test of a remembered triangle — a.cand against a.sr
+// with a.min_df_prog (cone_attempt_too_short_by) — whose answer goes to aw_test_done.  (The test is handed OUT instead of being done
+// here so that a kernel can run the exact tests of many lanes — these and the survivors of the leaf filters — together.)
+enum aw_need_e : int { AW_FINAL = 0, AW_QUERY = 1, AW_TEST = 2 };
+WT_HD int aw_next(const scene_t& sc, const cone_t& envelope, bool force_ray_tracing, const stack_ref_t& stack, axis_walk_t& a, cone_query_t& q, trav_result_t& r) {
+    if (a.cand_idx == 0) {   // (not in the middle of a segment's remembered-triangle tests)
+        trav_result_init(r, envelope.o);
+        if (force_ray_tracing || cone_is_ray(envelope)) {
+            if (a.axis_hit) aw_ballistic_hit(a, r);
+            r.n_ray_queries = a.n_ray_queries;
+            r.n_cone_queries = a.n_cone_queries;
+            return AW_FINAL;
+        }
     }
     for (;; ++a.seg) {
-        const float ballistic_dist = max_ballistic_distance(a.lambda_m, a.seg, 0.f);
-        if (!a.first_seg_settled) {
-            if (a.axis_hit && a.ah.dist <= fminf_(a.distance, a.dist + ballistic_dist * kBallisticScale)) {
-                aw_ballistic_hit(a, r);
-                break;
+        if (a.cand_idx == 0) {
+            const float ballistic_dist = max_ballistic_distance(a.lambda_m, a.seg, 0.f);
+            if (!a.first_seg_settled) {
+                if (a.axis_hit && a.ah.dist <= fminf_(a.distance, a.dist + ballistic_dist * kBallisticScale)) {
+                    aw_ballistic_hit(a, r);
+                    break;
+                }
+                a.dist += ballistic_dist;
+                if (ballistic_dist == WT_INF || a.dist >= a.distance) break;
             }
-            a.dist += ballistic_dist;
-            if (ballistic_dist == WT_INF || a.dist >= a.distance) break;
+            a.first_seg_settled = 0;
+            a.min_df_prog = cone_axes(envelope, a.dist).x / 2.f;
+            a.n_cone_queries++;
+            const float cone_max = a.axis_hit ? fminf_(a.distance, cone_axis_bound(envelope, a.ah.dist)) : a.distance;
+            a.sr = range_t{a.dist, cone_max};
         }
-        a.first_seg_settled = 0;
-        a.min_df_prog = cone_axes(envelope, a.dist).x / 2.f;
-        a.n_cone_queries++;
-        const float cone_max = a.axis_hit ? fminf_(a.distance, cone_axis_bound(envelope, a.ah.dist)) : a.distance;
-        const range_t sr{a.dist, cone_max};
         if (a.probe_first && a.use_cache) {   // (device form only: decides "too short" exactly like the query's own early exit)
-            bool decided = false;
-            for (int c = 0; c < 2 && !decided; ++c) {
-                const uint32_t cand = c == 0 ? a.short_tuid : a.origin_tuid;
-                if (cand == kInvalid || (c == 1 && cand == a.short_tuid)) continue;
-                decided = cone_attempt_too_short_by(sc, envelope, cand, sr, a.min_df_prog);
+            while (a.cand_idx < 2) {
+                const uint32_t cand = a.cand_idx == 0 ? a.short_tuid : a.origin_tuid;
+                const bool skip = cand == kInvalid || (a.cand_idx == 1 && cand == a.short_tuid);
+                ++a.cand_idx;
+                if (skip) continue;
+                a.cand = cand;
+                return AW_TEST;
             }
-            if (decided) continue;
         }
-        cq_begin(sc, envelope, sr, kMajorAxisToZScale, stack, a.cone_budget, a.probe_first ? a.min_df_prog : -WT_INF, q);
-        return true;
+        a.cand_idx = 0;
+        cq_begin(sc, envelope, a.sr, kMajorAxisToZScale, stack, a.cone_budget, a.probe_first ? a.min_df_prog : -WT_INF, q);
+        return AW_QUERY;
     }
     r.n_ray_queries = a.n_ray_queries;
     r.n_cone_queries = a.n_cone_queries;
-    return false;
+    return AW_FINAL;
+}
+// the answer to AW_TEST; call aw_next again afterwards
+WT_HD void aw_test_done(axis_walk_t& a, bool too_short) {
+    if (too_short) {   // the attempt is settled without a query: on to the next segment
+        a.cand_idx = 0;
+        ++a.seg;
+    }
 }
 // The outcome of the query aw_next asked for (after cq_end).  TRUE: the traversal is over, `r` is final; FALSE: call aw_next again.
 WT_HD bool aw_query_done(const scene_t& sc, const cone_t& envelope, axis_walk_t& a, const cone_hit_t& ch, trav_result_t& r) {
@@ -825,6 +887,9 @@ WT_HD void aw_begin(axis_walk_t& a, float lambda_m, float distance, bool axis_hi
     a.primary_always = primary_always ? 1u : 0u;
     a.use_cache = 1;
     a.min_df_prog = 0.f;
+    a.sr = range_t{0.f, 0.f};
+    a.cand_idx = 0;
+    a.cand = kInvalid;
 }
 // ... of a handed-over traversal (aw_query_done's `aborted` record)
 WT_HD void aw_resume(axis_walk_t& a, float lambda_m, float distance, const trav_result_t& h, uint32_t cone_budget, bool probe_first, bool primary_always,
@@ -857,7 +922,13 @@ WT_HD trav_result_t traverse_axis(const scene_t& sc, const cone_t& envelope, flo
     }
     trav_result_t r;
     cone_query_t q;
-    while (aw_next(sc, envelope, force_ray_tracing, stack, a, q, r)) {
+    for (;;) {
+        const int need = aw_next(sc, envelope, force_ray_tracing, stack, a, q, r);
+        if (need == AW_FINAL) break;
+        if (need == AW_TEST) {
+            aw_test_done(a, cone_attempt_too_short_by(sc, envelope, a.cand, a.sr, a.min_df_prog));
+            continue;
+        }
         while (cq_running(q)) {
             while (q.s > 0 && q.leaf == 0) cq_node_step(sc, envelope, stack, q, ctr);
             if (q.leaf != 0) cq_leaf_step(sc, envelope, stack, tris, q, ctr);

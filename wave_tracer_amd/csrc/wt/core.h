@@ -302,22 +302,25 @@ WT_HD float sincf_(float x) {
     return result;
 }
 
-// generic "struct as array of 32-bit words" SoA accessors: word i of element idx lives at
-// base[i*stride + idx], so a wavefront loading the same field of 64 consecutive elements issues
-// one coalesced 256-B request per word (DESIGN.md "SoA state").
+// generic "struct as array of 32-bit words" accessors of the per-walk state arrays, RECORD-MAJOR: word i of element idx lives at
+// base[idx*stride + i], stride = words per record.  (Rounds 1-2 kept the state word-interleaved — base[i*n + idx] — which coalesces
+// only while the walks of a wavefront are consecutive: true in the first round, but after the first queue compaction a wavefront's 64
+// walks are scattered over the batch and every word of every lane touched its own 64-byte line to use 4 bytes of it.  With one
+// contiguous record per walk a lane reads whole lines of its own record whatever the order of the walks: measured HBM-side traffic
+// of a pass DESIGN.md §4.)  The CPU checker keeps one record per array (idx = 0).
 template <class T>
 WT_HD void soa_store(uint32_t* base, size_t stride, size_t idx, const T& v) {
     static_assert(sizeof(T) % 4 == 0, "POD of 32-bit words expected");
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) base[i * stride + idx] = w[i];
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) base[idx * stride + i] = w[i];
 }
 template <class T>
 WT_HD void soa_load(const uint32_t* base, size_t stride, size_t idx, T& v) {
     static_assert(sizeof(T) % 4 == 0, "POD of 32-bit words expected");
     uint32_t* w = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = base[i * stride + idx];
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = base[idx * stride + i];
 }
 
 }   // namespace wt

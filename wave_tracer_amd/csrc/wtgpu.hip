@@ -13,8 +13,9 @@
 // (generate, kMaxWalkIters rounds, connect) is enqueued blindly, rounds after the queue ran empty cost a few us each.
 // Batches are round-robined over several state slices, each with its own HIP stream, so that the long tails of one batch
 // (a handful of slow walks) overlap with the bulk of the others; wtgpu_render is asynchronous w.r.t. the host.
-// All per-walk / per-sample state lives in HBM as word-interleaved SoA (wt::soa_load/soa_store) so that the 64
-// lanes of a wavefront touch 64 consecutive dwords per field.
+// All per-walk / per-sample state lives in HBM as one contiguous record per walk (wt::soa_load/soa_store, record-major since round 3:
+// after the first queue compaction the walks of a wavefront are scattered over the batch, and a lane that reads whole lines of its own
+// record wastes nothing, whereas the word-interleaved layout of rounds 1-2 fetched a 64-byte line per word and lane).
 //
 // There is no CPU fallback in this file: every entry point that computes requires a HIP device.
 #include <hip/hip_runtime.h>
@@ -88,7 +89,7 @@ int fail(int code, const std::string& msg) {
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_WORDS = 24 };   // (CTL_GATHER_*: queue of k_edges)
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 24 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 // ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
@@ -100,6 +101,8 @@ constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // c
 struct device_state_t {
     uint64_t cap = 0;   // samples per batch
     uint32_t max_verts = 0;
+    uint32_t walk_words = 0;   // words of one walk record (walk_t, or path_walk_t for plt_path scenes)
+    size_t vert_words = 0;     // words of one walk's vertex array (max_verts x kVertexWords)
     uint32_t* walks = nullptr;    // [kWalkWords][2cap]
     uint32_t* verts = nullptr;    // [max_verts*kVertexWords][2cap]
     uint32_t* ctx = nullptr;      // [kCtxWords][cap]
@@ -110,6 +113,7 @@ struct device_state_t {
     uint32_t* intb_queue = nullptr;    // walks whose interaction takes the expensive (no primary triangle) path
     uint32_t* gather_queue = nullptr;  // ... of those, the ones whose triangle list overflowed (coop_gather first)
     uint32_t* intc_queue = nullptr;    // ... and the ones that built a Fraunhofer aperture with edges (sampled in pass C)
+    uint32_t* intd_queue = nullptr;    // ... of those, the ones whose rejection sampling outlasts kEasyTries tries (k_interact_c_hard)
     uint2* ftasks = nullptr;           // (walk, subtree) tasks of the intercepted-power sums of overflowed regions (k_flux_split / k_flux_tasks)
     uint32_t ftask_cap = 0;
     double* facc = nullptr;            // [2cap] their accumulators
@@ -166,8 +170,8 @@ struct wtgpu_scene {
     size_t query_scratch_bytes = 0;
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
-        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, lane_cache = 1, heavy_cache = 1;
-        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
+        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, lane_cache = 1, heavy_cache = 1, split_queues = 1;
+        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
     } knobs;
 };
@@ -208,6 +212,7 @@ struct launch_args_t {
     uint32_t heavy_probe;   // k_trace_heavy: any-hit probe of the near slab before the handed-over cone query too
     uint32_t coop_aperture_min;   // regions with at least this many classified edges get their aperture built by k_edges' wavefront
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
+    uint32_t split_queues;   // round queues keep sensor and emitter walks apart (queue_append); 0: one mixed queue (A/B)
     uint32_t lane_cache, heavy_cache;   // diagnostic switches of the remembered rejecting triangles (wt::traverse_axis / coop_traverse); default on
     uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
 };
@@ -237,9 +242,11 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         uint32_t* ctl = a.st.ctl;
         ctl[CTL_COUNT0] = 2 * a.nb;
         ctl[CTL_COUNT1] = 0;
+        ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
         ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
+        ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -249,11 +256,11 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
     const size_t W2 = 2 * (size_t)a.st.cap;
     sample_ctx_t ctx;
     walk_t sw, ew;
-    const vertex_store_t svs{a.st.verts, W2, i}, evs{a.st.verts, W2, (size_t)a.st.cap + i};
+    const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
     bdpt_generate(a.sc, a.seed, sample_id, pix % a.sc.sensor.width, pix / a.sc.sensor.width, ctx, sw, ew, svs, evs);
-    soa_store(a.st.ctx, (size_t)a.st.cap, i, ctx);
-    soa_store(a.st.walks, W2, i, sw);
-    soa_store(a.st.walks, W2, (size_t)a.st.cap + i, ew);
+    soa_store(a.st.ctx, kCtxWords, i, ctx);
+    soa_store(a.st.walks, a.st.walk_words, i, sw);
+    soa_store(a.st.walks, a.st.walk_words, (size_t)a.st.cap + i, ew);
 }
 
 // walk id -> (sample index, stream)
@@ -266,10 +273,15 @@ __device__ inline void walk_ident(const launch_args_t& a, uint32_t w, uint32_t& 
         stream = STREAM_EMITTER_WALK;
     }
 }
+// The round queues hold the two kinds of walks apart: sensor walks are appended from the front of the array (count CTL_COUNT*), emitter
+// walks from its end backwards (count CTL_BACK*).  A traversal costs an emitter walk of the headline workload 5-10x what it costs a
+// sensor walk (wide beams from the spots against pixel-sized beams from the camera): wavefronts that hold one kind waste fewer lanes.
 // queue item -> walk id; the first round's queue is the identity over [0,nb) (sensor walks) and [cap,cap+nb) (emitter walks)
-__device__ inline uint32_t queue_walk(const launch_args_t& a, const uint32_t* queue, uint32_t qi, int first_round) {
-    if (!first_round) return queue[qi];
-    return qi < a.nb ? qi : (uint32_t)a.st.cap + (qi - a.nb);
+__device__ inline uint32_t queue_count(const uint32_t* ctl, int in) { return ctl[CTL_COUNT0 + in] + ctl[CTL_BACK0 + in]; }
+__device__ inline uint32_t queue_walk(const launch_args_t& a, const uint32_t* ctl, int in, uint32_t qi, int first_round) {
+    if (first_round) return qi < a.nb ? qi : (uint32_t)a.st.cap + (qi - a.nb);
+    const uint32_t front = ctl[CTL_COUNT0 + in];
+    return qi < front ? a.st.queue[in][qi] : a.st.queue[in][2 * (size_t)a.st.cap - 1 - (qi - front)];
 }
 // one wavefront grabs the next 64 queue items
 __device__ inline uint32_t wave_grab(uint32_t* head) {
@@ -289,12 +301,27 @@ __device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, 
     if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
 }
 
+// ... of walk `w` (for lanes with `pred`) to round queue `out`: sensor walks (and plt_path's) at the front, emitter walks at the back
+__device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int out, bool pred, uint32_t w) {
+    const bool back = pred && w >= a.st.cap && a.split_queues;
+    wave_append(a.st.queue[out], ctl + CTL_COUNT0 + out, pred && !back, w);
+    const unsigned long long m = __ballot(back);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(ctl + CTL_BACK0 + out, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (back) a.st.queue[out][2 * (size_t)a.st.cap - 1 - (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = w;
+}
+
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_COUNT0 + in];
+    const uint32_t n = queue_count(ctl, in);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
+        ctl[CTL_BACK0 + (1 - in)] = 0;
         ctl[CTL_HEAD_INTERACT] = 0;
         ctl[CTL_INTB_COUNT] = 0;
         ctl[CTL_INTB_HEAD] = 0;
@@ -306,6 +333,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
         ctl[CTL_FTASK_HEAD] = 0;
         ctl[CTL_FSPLIT_HEAD] = 0;
         ctl[CTL_EPOOL_COUNT] = 0;
+        ctl[CTL_INTD_COUNT] = 0;
+        ctl[CTL_INTD_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -321,8 +350,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
         bool heavy = false;
         uint32_t w = 0;
         if (qi < n) {
-            w = queue_walk(a, a.st.queue[in], qi, first_round);
-            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
+            w = queue_walk(a, ctl, in, qi, first_round);
+            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
             // plt_bdpt: closest-hit-only cone queries (list capacity 0: once something is hit only nearer triangles matter, wt/bvh.h) —
             // what an interaction needs of its region is the triangle under the beam axis (resolve_primary) and, for the few walks
             // without one, sums over the WHOLE region gathered later (k_edges, k_interact_c).  plt_path keeps the bounded list.
@@ -333,18 +362,18 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
             if (tr.aborted == 1) {
                 heavy = true;
                 // resume state for k_trace_heavy (traverse_axis(): dist / ntris = segment / query counts so far + the axis hit)
-                a.st.trav[WT_TRAV_WORD(dist) * W2 + w] = __float_as_uint(tr.dist);
-                a.st.trav[WT_TRAV_WORD(ntris) * W2 + w] = tr.ntris;
-                a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = tr.n_ray_queries;
-                a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = tr.n_cone_queries;
-                a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = tr.tuid;
-                a.st.trav[WT_TRAV_WORD(bx) * W2 + w] = __float_as_uint(tr.bx);
-                a.st.trav[WT_TRAV_WORD(by) * W2 + w] = __float_as_uint(tr.by);
-                a.st.trav[WT_TRAV_WORD(pdist) * W2 + w] = __float_as_uint(tr.pdist);
-                a.st.trav[WT_TRAV_WORD(front_face) * W2 + w] = tr.front_face;
-                a.st.trav[WT_TRAV_WORD(overflow) * W2 + w] = tr.overflow;   // the triangle that made the last attempt too short (kInvalid: none)
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)] = __float_as_uint(tr.dist);
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)] = tr.ntris;
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)] = tr.n_ray_queries;
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)] = tr.n_cone_queries;
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)] = tr.tuid;
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)] = __float_as_uint(tr.bx);
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = __float_as_uint(tr.by);
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(pdist)] = __float_as_uint(tr.pdist);
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)] = tr.front_face;
+                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(overflow)] = tr.overflow;   // the triangle that made the last attempt too short (kInvalid: none)
             } else {
-                soa_store(a.st.trav, W2, w, tr);
+                soa_store(a.st.trav, kTravWords, w, tr);
                 ctr.segments += 1;
                 ctr.ray_queries += tr.n_ray_queries;
                 ctr.cone_queries += tr.n_cone_queries;
@@ -370,12 +399,21 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
 #ifndef WTGPU_REFILL_MIN
 #define WTGPU_REFILL_MIN 16
 #endif
+// the policy up to its next cone query (TRUE) or its end (FALSE: `r` is final); the tests of the remembered triangles run right here
+__device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, bool rt, const stack_ref_t& stack, axis_walk_t& aw, cone_query_t& q, trav_result_t& r) {
+    for (;;) {
+        const int need = aw_next(sc, env, rt, stack, aw, q, r);
+        if (need != AW_TEST) return need == AW_QUERY;
+        aw_test_done(aw, cone_attempt_too_short_by(sc, env, aw.cand, aw.sr, aw.min_df_prog));
+    }
+}
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_COUNT0 + in];
+    const uint32_t n = queue_count(ctl, in);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
+        ctl[CTL_BACK0 + (1 - in)] = 0;
         ctl[CTL_HEAD_INTERACT] = 0;
         ctl[CTL_INTB_COUNT] = 0;
         ctl[CTL_INTB_HEAD] = 0;
@@ -387,6 +425,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         ctl[CTL_FTASK_HEAD] = 0;
         ctl[CTL_FSPLIT_HEAD] = 0;
         ctl[CTL_EPOOL_COUNT] = 0;
+        ctl[CTL_INTD_COUNT] = 0;
+        ctl[CTL_INTD_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -416,7 +456,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         if (st == 2) {
             cq_end(env, tris, q);
             fin = aw_query_done(a.sc, env, aw, q.rec, r);
-            if (!fin) fin = !aw_next(a.sc, env, rt, stack, aw, q, r);
+            if (!fin) fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
             st = fin ? 0 : 1;
         }
         // (records of finished walks are stored below, together with those of freshly fetched walks that need no cone query)
@@ -432,9 +472,9 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
             const uint32_t qi = base + (uint32_t)__popcll(im & below);
             if (st == 0 && qi < n) {
-                w = queue_walk(a, a.st.queue[in], qi, first_round);
+                w = queue_walk(a, ctl, in, qi, first_round);
                 w_fin = w;
-                const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
+                const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
                 // plt_bdpt: the bounded list (64 triangles + their cone-hit distances) of the interaction region; see k_trace
                 uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
                 tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
@@ -443,7 +483,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
                 aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
                 aw.use_cache = a.lane_cache;
-                fin = !aw_next(a.sc, env, rt, stack, aw, q, r);
+                fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
                 st = fin ? 0 : 1;
             }
             fetched = true;
@@ -455,18 +495,18 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 if (heavy) {
                     // resume state for k_trace_heavy (aw_query_done: dist / ntris = distance / segment of the query, the axis hit, the last
                     // rejecting triangle in `overflow`)
-                    a.st.trav[WT_TRAV_WORD(dist) * W2 + w_fin] = __float_as_uint(r.dist);
-                    a.st.trav[WT_TRAV_WORD(ntris) * W2 + w_fin] = r.ntris;
-                    a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w_fin] = r.n_ray_queries;
-                    a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w_fin] = r.n_cone_queries;
-                    a.st.trav[WT_TRAV_WORD(tuid) * W2 + w_fin] = r.tuid;
-                    a.st.trav[WT_TRAV_WORD(bx) * W2 + w_fin] = __float_as_uint(r.bx);
-                    a.st.trav[WT_TRAV_WORD(by) * W2 + w_fin] = __float_as_uint(r.by);
-                    a.st.trav[WT_TRAV_WORD(pdist) * W2 + w_fin] = __float_as_uint(r.pdist);
-                    a.st.trav[WT_TRAV_WORD(front_face) * W2 + w_fin] = r.front_face;
-                    a.st.trav[WT_TRAV_WORD(overflow) * W2 + w_fin] = r.overflow;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(dist)] = __float_as_uint(r.dist);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(ntris)] = r.ntris;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(n_ray_queries)] = r.n_ray_queries;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(n_cone_queries)] = r.n_cone_queries;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(tuid)] = r.tuid;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(bx)] = __float_as_uint(r.bx);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(by)] = __float_as_uint(r.by);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(pdist)] = __float_as_uint(r.pdist);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(front_face)] = r.front_face;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(overflow)] = r.overflow;
                 } else {
-                    soa_store(a.st.trav, W2, w_fin, r);
+                    soa_store(a.st.trav, kTravWords, w_fin, r);
                     ctr.segments += 1;
                     ctr.ray_queries += r.n_ray_queries;
                     ctr.cone_queries += r.n_cone_queries;
@@ -521,21 +561,21 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
         __syncthreads();
         if (item >= n) break;
         const uint32_t w = hq[item];
-        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);   // uniform address: broadcast
+        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
         const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};   // see k_trace
         const cone_t env = walk_trace_envelope(a.sc, wk);
         unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const long long tt0 = a.profile == 2 ? clock64() : 0;
-        const float dist0 = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
-        const uint32_t seg0 = a.st.trav[WT_TRAV_WORD(ntris) * W2 + w];
-        const uint32_t nray0 = a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w], ncone0 = a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w];
+        const float dist0 = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const uint32_t seg0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)];
+        const uint32_t nray0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)], ncone0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)];
         ray_hit_t axis;   // the closest hit of the beam axis, found by k_trace (traverse_axis, wt/bvh.h)
-        axis.tuid = a.st.trav[WT_TRAV_WORD(tuid) * W2 + w];
-        axis.bx = __uint_as_float(a.st.trav[WT_TRAV_WORD(bx) * W2 + w]);
-        axis.by = __uint_as_float(a.st.trav[WT_TRAV_WORD(by) * W2 + w]);
-        axis.dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(pdist) * W2 + w]);
-        axis.front_face = a.st.trav[WT_TRAV_WORD(front_face) * W2 + w];
-        const uint32_t short0 = a.st.trav[WT_TRAV_WORD(overflow) * W2 + w];
+        axis.tuid = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)];
+        axis.bx = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)]);
+        axis.by = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)]);
+        axis.dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(pdist)]);
+        axis.front_face = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)];
+        const uint32_t short0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(overflow)];
         const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
                                                 &axis, !a.collect_list, a.heavy_probe != 0, a.heavy_cache ? short0 : kInvalid, a.heavy_cache ? wk.prev_offset_tuid : kInvalid, a.heavy_cache != 0);
         if (a.profile == 2 && threadIdx.x == 0) {
@@ -547,7 +587,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
             atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
         }
         if (threadIdx.x == 0) {
-            soa_store(a.st.trav, W2, w, tr2);
+            soa_store(a.st.trav, kTravWords, w, tr2);
             ctr.segments += 1;
             ctr.ray_queries += tr2.n_ray_queries;
             ctr.cone_queries += tr2.n_cone_queries;
@@ -566,7 +606,7 @@ template <int PASS>
 __device__ inline void interact_body(const launch_args_t& a, int in, int first_round) {
     constexpr bool PASS_B = PASS == 1;
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : ctl[CTL_COUNT0 + in];
+    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : queue_count(ctl, in);
     if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
@@ -595,7 +635,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
         defer.gather_edges = nullptr;
         bool need_gather = false;
         if (qi < n) {
-            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, a.st.queue[in], qi, first_round);
+            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
             uint32_t i, stream;
             walk_ident(a, w, i, stream);
             const uint64_t j = a.j0 + i;
@@ -603,11 +643,11 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
             const uint64_t s = a.sample_begin + j / a.npix;
             const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
             walk_t wk;
-            soa_load(a.st.walks, W2, w, wk);
+            soa_load(a.st.walks, a.st.walk_words, w, wk);
             trav_result_t tr;
-            soa_load(a.st.trav, W2, w, tr);
+            soa_load(a.st.trav, kTravWords, w, tr);
             const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
-            const vertex_store_t vs{a.st.verts, W2, w};
+            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
             const bool queued_for_c = PASS_B && tr.tuid == kApertureMarker;   // k_edges built the aperture and queued the walk for pass C
             if (PASS_B && tr.tuid == kNullApertureMarker) {   // k_edges built the aperture: no segments (the step restarts the beam)
                 defer.have_aperture = 1;
@@ -622,7 +662,7 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
             }
             const long long pb0 = PASS_B && a.profile == 3 ? clock64() : 0;
             if (!queued_for_c) cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
-            if (PASS_B && defer.to_sampling_pass) a.st.trav[WT_TRAV_WORD(by) * W2 + w] = defer.slot;
+            if (PASS_B && defer.to_sampling_pass) a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = defer.slot;
             if (PASS_B && a.profile == 3) {   // pass-B cost by the number of gathered scene edges
                 const int bin = defer.has_gather ? 32 - __clz((int)defer.gather_n_edges) : 0;   // 0: no gather / none
                 atomicAdd(a.st.counters + kNumCounters + 56 + bin, 1ull);
@@ -633,13 +673,13 @@ __device__ inline void interact_body(const launch_args_t& a, int in, int first_r
             if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list)) need_gather = true;
             if (!defer.no_primary && !defer.to_sampling_pass && !queued_for_c) {
                 wk.active = cont ? 1u : 0u;
-                soa_store(a.st.walks, W2, w, wk);
+                soa_store(a.st.walks, a.st.walk_words, w, wk);
             }
         }
         if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
         if (!PASS_B) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
         if (PASS_B) wave_append(a.st.intc_queue, ctl + CTL_INTC_COUNT, defer.to_sampling_pass != 0, w);
-        wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
+        queue_append(a, ctl, 1 - in, cont, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
@@ -665,9 +705,9 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
         if (item >= n) break;
         const uint32_t w = a.st.gather_queue[item];
         walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
-        const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
-        const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
+        soa_load(a.st.walks, a.st.walk_words, w, wk);   // uniform address: broadcast
+        const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
         const range_t izr{beam_dist, beam_dist + region_depth};
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
         const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
@@ -717,11 +757,11 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
             }
         }
         if (threadIdx.x == 0) {
-            a.st.trav[WT_TRAV_WORD(tuid) * W2 + w] = marker;
-            a.st.trav[WT_TRAV_WORD(by) * W2 + w] = slot;
-            a.st.trav[WT_TRAV_WORD(bx) * W2 + w] = off;
-            a.st.trav[WT_TRAV_WORD(n_ray_queries) * W2 + w] = n_edges;
-            a.st.trav[WT_TRAV_WORD(n_cone_queries) * W2 + w] = dropped;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)] = marker;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = slot;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)] = off;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)] = n_edges;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)] = dropped;
             if (a.profile) {
                 atomicAdd(a.st.counters + kNumCounters + 5, 1ull);
                 atomicAdd(a.st.counters + kNumCounters + 6, (unsigned long long)n_edges);
@@ -751,11 +791,11 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
         __syncthreads();
         if (item >= n) break;
         const uint32_t w = a.st.intc_queue[item];
-        if (is_region_marker(a.st.trav[WT_TRAV_WORD(tuid) * W2 + w])) {   // block-uniform
-            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, W2, w);
+        if (is_region_marker(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)])) {   // block-uniform
+            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
             const cone_t tcone = walk_trace_envelope(a.sc, wk);
-            const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
-            const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
+            const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+            const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
             if (threadIdx.x == 0) a.st.facc[w] = 0.0;
             coop_split(a.sc, tcone, range_t{beam_dist, beam_dist + region_depth}, sh, a.flux_task_tris, [&](int32_t ptr) {
                 const uint32_t idx = atomicAdd(ctl + CTL_FTASK_COUNT, 1u);
@@ -782,10 +822,10 @@ __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t 
         const uint2 task = a.st.ftasks[item];
         const uint32_t w = task.x;
         walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
-        const float beam_dist = __uint_as_float(a.st.trav[WT_TRAV_WORD(dist) * W2 + w]);
-        const float region_depth = __uint_as_float(a.st.trav[WT_TRAV_WORD(region_depth) * W2 + w]);
-        const bool want_front = a.st.trav[WT_TRAV_WORD(front_face) * W2 + w] != 0;
+        soa_load(a.st.walks, a.st.walk_words, w, wk);   // uniform address: broadcast
+        const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
+        const bool want_front = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)] != 0;
         const range_t izr{beam_dist, beam_dist + region_depth};
         const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
@@ -810,85 +850,149 @@ __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t 
 // plt_bdpt_detail.hpp:391-416 — coop_gather walks the WHOLE region, however many triangles it holds: the reference's unbounded list)
 // and the rejection sampling (64 tries per step; tries own their random draws, the lowest accepted try wins like in the sequential
 // loop); lane 0 then re-enters bdpt_walk_step with the outcome (vertex append, beam transform, Russian roulette).
-__global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_args_t a, int in) {
+//
+// The number of tries is wildly non-uniform: most apertures accept within the first 64, but the acceptance probability is
+// |sum of amplitudes|^2 / (n x sum of |amplitudes|^2) and the loop runs up to n x 1024 tries (fsd.h: fsd_max_tries, the reference's
+// cap) — in the headline workload apertures of 8..15 segments average 1,650 tries and account for 2/3 of this pass's arithmetic
+// (WTGPU_PROFILE=3), with single walks keeping one wavefront busy for a millisecond while the round waits.  BLOCK = 64 (k_interact_c)
+// therefore gives up after kEasyTries tries and queues the walk for BLOCK = 256 (k_interact_c_hard): four wavefronts per walk, 256
+// tries per step, continuing at try kEasyTries.
+constexpr uint32_t kEasyTries = 512;
+constexpr uint32_t kStageSegs = 256;
+#ifndef WTGPU_HARD_BLOCK
+#define WTGPU_HARD_BLOCK 256
+#endif
+template <int BLOCK>
+__device__ inline void interact_c_body(const launch_args_t& a, int in) {
+    constexpr bool HARD = BLOCK > 64;
     __shared__ uint32_t s_item;
+    __shared__ uint32_t s_tmin;
+    __shared__ float s_res[3];
     __shared__ stack_entry_t lds[8];   // the resumed step does no BVH queries; lane 0's stack is a formality
+    __shared__ fsd_edge_t s_seg[kStageSegs];   // the walk's aperture segments (7 KB; larger apertures are read from the pool)
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_INTC_COUNT];
-    const int lane = threadIdx.x;
+    const uint32_t n = ctl[HARD ? CTL_INTD_COUNT : CTL_INTC_COUNT];
+    const uint32_t* queue_in = HARD ? a.st.intd_queue : a.st.intc_queue;
+    const int tid = threadIdx.x, lane = threadIdx.x & 63;
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
         const long long pl0 = a.profile == 3 ? clock64() : 0;
-        if (lane == 0) s_item = atomicAdd(ctl + CTL_INTC_HEAD, 1u);
+        if (tid == 0) s_item = atomicAdd(ctl + (HARD ? CTL_INTD_HEAD : CTL_INTC_HEAD), 1u);
         __syncthreads();
         const uint32_t item = s_item;
         __syncthreads();
         if (item >= n) break;
-        const uint32_t w = a.st.intc_queue[item];
+        const uint32_t w = queue_in[item];
         uint32_t i, stream;
         walk_ident(a, w, i, stream);
         const uint64_t j = a.j0 + i;
         const uint32_t pix = (uint32_t)(j % a.npix);
         const uint64_t sample_id = ((uint64_t)pix << 32) | ((a.sample_begin + j / a.npix) & 0xFFFFFFFFull);
-        walk_t wk;
-        soa_load(a.st.walks, W2, w, wk);   // uniform address: broadcast
-        trav_result_t tr;
-        soa_load(a.st.trav, W2, w, tr);
-        const uint32_t slot = a.st.trav[WT_TRAV_WORD(by) * W2 + w];   // left by pass B
+        const uint32_t rng_draws = a.st.walks[(size_t)w * a.st.walk_words + WT_WALK_WORD(rng_draws)];
+        const uint32_t slot = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)];   // left by pass B
         fsd_aperture_t ap = pool.hdr[slot];
         const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
         const long long pc0 = a.profile == 3 ? clock64() : 0;
-        // ---- intercepted power of the whole region (same z-slab, cone and facing as the reference's list-based sum)
-        const range_t izr{tr.dist, tr.dist + tr.region_depth};
-        const vec3 sd3 = beam_footprint(wk.beam, tr.dist) / kBeamEnvelope;
-        const cone_t tcone = walk_trace_envelope(a.sc, wk);
-        double flux;
-        if (is_region_marker(tr.tuid)) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
-            flux = a.st.facc[w];
-        } else {   // lane = triangle of the (complete) list, wave reduction (bdpt_walk_step computes the same sum triangle by triangle)
-            const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
-            flux = (uint32_t)lane < tr.ntris ? (double)region_triangle_flux(a.sc, cone_frame(wk.beam.env), wk.beam.env, izr, vec2{sd3.x, sd3.y}, tl[lane], tr.front_face != 0) : 0.0;
+        if (!HARD) {
+            // ---- intercepted power of the whole region (same z-slab, cone and facing as the reference's list-based sum)
+            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
+            cone_t benv = wk.env;   // the beam's own envelope (not offset for tracing)
+            const float tr_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+            const float tr_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
+            const uint32_t tr_tuid = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)], tr_ntris = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)];
+            const bool tr_front = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)] != 0;
+            const range_t izr{tr_dist, tr_dist + tr_depth};
+            const vec2 axes = cone_axes(benv, tr_dist);
+            const vec2 sigma{axes.x / kBeamEnvelope, axes.y / kBeamEnvelope};
+            double flux;
+            if (is_region_marker(tr_tuid)) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
+                flux = a.st.facc[w];
+            } else {   // lane = triangle of the (complete) list, wave reduction (bdpt_walk_step computes the same sum triangle by triangle)
+                const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
+                flux = (uint32_t)lane < tr_ntris ? (double)region_triangle_flux(a.sc, cone_frame(benv), benv, izr, sigma, tl[lane], tr_front) : 0.0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) flux += __shfl_xor(flux, off, 64);
+                for (int off = 32; off > 0; off >>= 1) flux += __shfl_xor(flux, off, 64);
+            }
+            const float I = (float)(1.0 - flux);
+            ap.recp_I = I > 0.f ? 1.f / I : 0.f;
+            if (lane == 0) pool.hdr[slot] = ap;
         }
-        const float I = (float)(1.0 - flux);
-        ap.recp_I = I > 0.f ? 1.f / I : 0.f;
-        if (lane == 0) pool.hdr[slot] = ap;
-        // ---- rejection sampling, 64 tries per step
+        // ---- rejection sampling.  A try reads every segment of the aperture twice (segment selection by a linear scan of the pdfs,
+        // then the density / scattering-function sums): the segments are staged in LDS once per walk.
         const sampler_t ss = make_sampler(a.seed, sample_id, stream, 0);
-        const uint32_t base = fsd_tries_base(make_sampler(a.seed, sample_id, stream, wk.rng_draws));
+        const uint32_t base = fsd_tries_base(make_sampler(a.seed, sample_id, stream, rng_draws));
         const uint32_t max_tries = fsd_max_tries(ap);
+        const uint32_t t_begin = HARD ? kEasyTries : 0u, t_end = HARD ? max_tries : (max_tries < kEasyTries ? max_tries : kEasyTries);
         bool acc = false;
         uint32_t t_acc = 0;
         float rx = 0.f, ry = 0.f, rf = 0.f;
-        for (uint32_t t0 = 0; t0 < max_tries && !acc; t0 += 64) {
-            const uint32_t t = t0 + (uint32_t)lane;
-            fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
-            if (t < max_tries) r = fsd_try(a.sc, ap, ed, sampler_at(ss, base + t * kFsdDrawsPerTry));
-            const unsigned long long am = __ballot(r.accept != 0);
-            if (am) {
-                const int wl = __ffsll((long long)am) - 1;
-                rx = __shfl(r.x.x, wl, 64);
-                ry = __shfl(r.x.y, wl, 64);
-                rf = __shfl(r.f, wl, 64);
-                t_acc = t0 + (uint32_t)wl;
-                acc = true;
+        auto run_tries = [&](const fsd_edges_ref_t& edr) {
+            for (uint32_t t0 = t_begin; t0 < t_end && !acc; t0 += BLOCK) {
+                const uint32_t t = t0 + (uint32_t)tid;
+                fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
+                if (t < t_end) r = fsd_try(a.sc, ap, edr, sampler_at(ss, base + t * kFsdDrawsPerTry));
+                if (!HARD) {
+                    const unsigned long long am = __ballot(r.accept != 0);
+                    if (am) {
+                        const int wl = __ffsll((long long)am) - 1;
+                        rx = __shfl(r.x.x, wl, 64);
+                        ry = __shfl(r.x.y, wl, 64);
+                        rf = __shfl(r.f, wl, 64);
+                        t_acc = t0 + (uint32_t)wl;
+                        acc = true;
+                    }
+                } else {   // the lowest accepted try of the block
+                    if (tid == 0) s_tmin = 0xFFFFFFFFu;
+                    __syncthreads();
+                    if (r.accept) atomicMin(&s_tmin, t);
+                    __syncthreads();
+                    const uint32_t tm = s_tmin;
+                    if (tm != 0xFFFFFFFFu) {
+                        if (t == tm) {
+                            s_res[0] = r.x.x;
+                            s_res[1] = r.x.y;
+                            s_res[2] = r.f;
+                        }
+                        __syncthreads();
+                        rx = s_res[0];
+                        ry = s_res[1];
+                        rf = s_res[2];
+                        t_acc = tm;
+                        acc = true;
+                    }
+                    __syncthreads();
+                }
             }
-        }
-        if (a.profile == 3 && lane == 0) {   // WTGPU_PROFILE=3: pass-C cost by aperture size (bin = floor(log2(segments)))
+        };
+        if (ap.n_edges <= kStageSegs) {
+            __syncthreads();   // (the previous walk's tries are done with the buffer)
+            for (uint32_t k = (uint32_t)tid; k < ap.n_edges; k += BLOCK) s_seg[k] = ed.p[k];
+            __syncthreads();
+            run_tries(fsd_edges_ref_t{s_seg, 1});
+        } else
+            run_tries(ed);
+        if (a.profile == 3 && tid == 0) {   // WTGPU_PROFILE=3: pass-C cost by aperture size (bin = floor(log2(segments)))
             const int bin = 31 - __clz((int)max(ap.n_edges, 1u));
             atomicAdd(a.st.counters + kNumCounters + 8 + bin, 1ull);
-            atomicAdd(a.st.counters + kNumCounters + 24 + bin, (unsigned long long)(acc ? t_acc + 1u : max_tries));
+            atomicAdd(a.st.counters + kNumCounters + 24 + bin, (unsigned long long)(acc ? t_acc + 1u - t_begin : t_end - t_begin));
             atomicAdd(a.st.counters + kNumCounters + 40 + bin, (unsigned long long)(clock64() - pc0));
             atomicAdd(a.st.counters + kNumCounters + 112 + bin, (unsigned long long)(pc0 - pl0));
         }
         const long long pm0 = a.profile == 3 ? clock64() : 0;
-        // ---- commit: lane 0 resumes the step with the outcome
+        if (!HARD && !acc && t_end < max_tries) {   // none of the first kEasyTries tries accepted: four wavefronts take over
+            if (lane == 0) a.st.intd_queue[atomicAdd(ctl + CTL_INTD_COUNT, 1u)] = w;
+            continue;
+        }
+        // ---- commit: thread 0 resumes the step with the outcome
         bool cont = false;
-        if (lane == 0) {
+        if (tid == 0) {
+            walk_t wk;
+            soa_load(a.st.walks, a.st.walk_words, w, wk);
+            trav_result_t tr;
+            soa_load(a.st.trav, kTravWords, w, tr);
             fsd_defer_t defer;
             defer.defer_sampling = defer.to_sampling_pass = 0;
             defer.have_aperture = 1;
@@ -906,17 +1010,19 @@ __global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_a
             defer.fs = fsd_finalize(ap, acc, vec2{rx, ry}, rf);
             defer.end_draws = fsd_draws_after(base, acc ? t_acc : max_tries - 1u);
             const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
-            const vertex_store_t vs{a.st.verts, W2, w};
+            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
             stack_ref_t stack{lds, 1, 8, 8, nullptr};
             cont = bdpt_walk_step<2>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
             wk.active = cont ? 1u : 0u;
-            soa_store(a.st.walks, W2, w, wk);
+            soa_store(a.st.walks, a.st.walk_words, w, wk);
             if (a.profile == 3) atomicAdd(a.st.counters + kNumCounters + 96 + (31 - __clz((int)max(ap.n_edges, 1u))), (unsigned long long)(clock64() - pm0));
         }
-        wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
+        if (tid < 64) queue_append(a, ctl, 1 - in, cont, w);
     }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
+    if (a.count_stats && tid < 64) flush_counters(a.st.counters, ctr);
 }
+__global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_args_t a, int in) { interact_c_body<64>(a, in); }
+__global__ void __launch_bounds__(WTGPU_HARD_BLOCK) k_interact_c_hard(launch_args_t a, int in) { interact_c_body<WTGPU_HARD_BLOCK>(a, in); }
 
 // ---- plt_path: one walk per sample; k_trace / k_trace_heavy are shared with plt_bdpt (they only read the walk_t
 // prefix of the walk record), the interaction step is path_walk_step (wt/path.h): UTD evaluation of the previous aperture (shadow
@@ -927,9 +1033,11 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
         uint32_t* ctl = a.st.ctl;
         ctl[CTL_COUNT0] = a.nb;
         ctl[CTL_COUNT1] = 0;
+        ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
         ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
+        ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
     }
     if (i >= a.nb) return;
     const uint64_t j = a.j0 + i;
@@ -938,13 +1046,13 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
     const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
     path_walk_t pw;
     path_generate(a.sc, a.seed, sample_id, pix % a.sc.sensor.width, pix / a.sc.sensor.width, pw);
-    soa_store(a.st.walks, 2 * (size_t)a.st.cap, i, pw);
+    soa_store(a.st.walks, a.st.walk_words, i, pw);
 }
 
 __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_COUNT0 + in];
+    const uint32_t n = queue_count(ctl, in);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
@@ -963,35 +1071,35 @@ __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, in
         bool cont = false;
         uint32_t w = 0;
         if (qi < n) {
-            w = queue_walk(a, a.st.queue[in], qi, first_round);
+            w = queue_walk(a, ctl, in, qi, first_round);
             const uint64_t j = a.j0 + w;
             const uint32_t pix = (uint32_t)(j % a.npix);
             const uint64_t s = a.sample_begin + j / a.npix;
             const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
             path_walk_t pw;
-            soa_load(a.st.walks, W2, w, pw);
+            soa_load(a.st.walks, a.st.walk_words, w, pw);
             trav_result_t tr;
-            soa_load(a.st.trav, W2, w, tr);
+            soa_load(a.st.trav, kTravWords, w, tr);
             uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
             const uint_list_t tris{slot, 1u, kMaxConeTris, reinterpret_cast<float*>(slot + kMaxConeTris)};
             const utd_edges_ref_t utd{a.st.utd + (size_t)w * kUtdMaxEdges, 1};
             cont = path_walk_step(a.sc, pw, tr, tris, utd, a.film, a.seed, sample_id, stream, stack, &ctr);
             if (!cont) path_finish(a.sc, a.film, pw);
             pw.w.active = cont ? 1u : 0u;
-            soa_store(a.st.walks, W2, w, pw);
+            soa_store(a.st.walks, a.st.walk_words, w, pw);
         }
-        wave_append(a.st.queue[1 - in], ctl + CTL_COUNT0 + (1 - in), cont, w);
+        queue_append(a, ctl, 1 - in, cont, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 // walks still active after the last round (iteration cap): backward transport splats what they gathered
 __global__ void __launch_bounds__(kBlock) k_path_flush(launch_args_t a, int in) {
-    const uint32_t n = a.st.ctl[CTL_COUNT0 + in];
+    const uint32_t n = queue_count(a.st.ctl, in);
     const size_t W2 = 2 * (size_t)a.st.cap;
     for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < n; qi += gridDim.x * blockDim.x) {
-        const uint32_t w = a.st.queue[in][qi];
+        const uint32_t w = queue_walk(a, a.st.ctl, in, qi, 0);
         path_walk_t pw;
-        soa_load(a.st.walks, W2, w, pw);
+        soa_load(a.st.walks, a.st.walk_words, w, pw);
         path_finish(a.sc, a.film, pw);
     }
 }
@@ -1033,8 +1141,8 @@ __global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
     for (uint32_t k = threadIdx.x; k < kNumKeys; k += blockDim.x) s_cnt[k] = 0;
     int nT = -1, nS = -1;
     if (i < a.nb) {
-        nT = (int)a.st.walks[WT_WALK_NVERTS_WORD * W2 + i];
-        nS = (int)a.st.walks[WT_WALK_NVERTS_WORD * W2 + a.st.cap + i];
+        nT = (int)a.st.walks[(size_t)(i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
+        nS = (int)a.st.walks[(size_t)(a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
 #pragma unroll
         for (int c = 0; c < 4; ++c) a.st.lacc[(size_t)c * a.st.cap + i] = 0.0;
     }
@@ -1103,8 +1211,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(laun
             const uint64_t smp = a.sample_begin + j / a.npix;
             const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
             sample_ctx_t ctx;
-            soa_load(a.st.ctx, (size_t)a.st.cap, i, ctx);
-            const vertex_store_t svs{a.st.verts, W2, i}, evs{a.st.verts, W2, (size_t)a.st.cap + i};
+            soa_load(a.st.ctx, kCtxWords, i, ctx);
+            const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
             const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
             if (t > 1) {
 #pragma unroll
@@ -1119,7 +1227,7 @@ __global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.nb) return;
     sample_ctx_t ctx;
-    soa_load(a.st.ctx, (size_t)a.st.cap, i, ctx);
+    soa_load(a.st.ctx, kCtxWords, i, ctx);
     stokes_t L;
 #pragma unroll
     for (int c = 0; c < 4; ++c) L.s[c] = (float)a.st.lacc[(size_t)c * a.st.cap + i];
@@ -1504,6 +1612,7 @@ static void read_knobs(wtgpu_scene* s) {
     wtgpu_scene::knobs_t& k = s->knobs;
     k.cone_budget = u("WTGPU_CONE_BUDGET", kConeBudget);
     k.count_stats = u("WTGPU_COUNT_STATS", 1);
+    k.split_queues = u("WTGPU_SPLIT_QUEUES", 1);
     k.lane_cache = u("WTGPU_LANE_CACHE", 1);
     k.heavy_cache = u("WTGPU_HEAVY_CACHE", 1);
     k.trace_refill = u("WTGPU_TRACE_REFILL", 1);   // 0: the per-lane trace kernel without lane refill (A/B reference)
@@ -1513,6 +1622,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.round_blocks_per_cu = std::max(1u, u("WTGPU_ROUND_BLOCKS", 8));
     k.grid_div_b = std::max(1u, u("WTGPU_GRID_B", 4));
     k.grid_div_c = std::max(1u, u("WTGPU_GRID_C", 2));
+    k.grid_div_hard = std::max(1u, u("WTGPU_GRID_HARD", 4));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
     k.flux_task_tris = std::max(64u, u("WTGPU_FLUX_TASK_TRIS", kFluxTaskTris));
@@ -1589,6 +1699,8 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         device_state_t& st = s->slices[k];
         st.cap = (total_cap + n_slices - 1) / n_slices;
         st.max_verts = (uint32_t)h.opts.max_depth + 2;
+        st.walk_words = (uint32_t)(h.opts.integrator != INTEGRATOR_BDPT ? kPathWalkWords : kWalkWords);
+        st.vert_words = (size_t)st.max_verts * kVertexWords;
         st.counters = counters;
         const size_t W2 = 2 * (size_t)st.cap;
         const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;   // plt_path: no vertex store / strategy buckets / Fraunhofer pool
@@ -1604,6 +1716,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         if ((rc = dmalloc(s, &st.intb_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.gather_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.intc_queue, W2))) return rc;
+        if ((rc = dmalloc(s, &st.intd_queue, W2))) return rc;
         st.ftask_cap = path_mode ? 1u : (1u << 22);
         if ((rc = dmalloc(s, &st.ftasks, (size_t)st.ftask_cap))) return rc;
         if ((rc = dmalloc(s, &st.facc, path_mode ? 1 : W2))) return rc;
@@ -1642,7 +1755,7 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     if (!r.busy) return WTGPU_OK;
     HIP_CHECK(hipEventSynchronize(r.ev.back()));
     const uint32_t rounds = r.h_ctl[CTL_ROUNDS];
-    s->cap_hits += r.h_ctl[CTL_COUNT0 + (kMaxWalkIters & 1u)];   // walks still active after the last round
+    s->cap_hits += r.h_ctl[CTL_COUNT0 + (kMaxWalkIters & 1u)] + r.h_ctl[CTL_BACK0 + (kMaxWalkIters & 1u)];   // walks still active after the last round
     s->acc[4] += rounds;
     s->acc[5] += rounds;
     s->acc[6] += 1;
@@ -1709,6 +1822,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     a.profile = K.profile;
     a.coop_aperture_min = K.coop_aperture_min;
     a.heavy_probe = K.heavy_probe;
+    a.split_queues = K.split_queues;
     a.lane_cache = K.lane_cache;
     a.heavy_cache = K.heavy_cache;
     a.flux_task_tris = K.flux_task_tris;
@@ -1792,6 +1906,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             hipLaunchKernelGGL(k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
             rec();
             hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
+            hipLaunchKernelGGL(k_interact_c_hard, dim3(std::max<uint32_t>(1u, gh / K.grid_div_hard)), dim3(WTGPU_HARD_BLOCK), 0, st_, a, in);
             rec();
         }
         if (path_mode) {
