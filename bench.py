@@ -100,6 +100,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    comm = None
+    if distributed and args.backend == "nccl":
+        # the film reduce of the timed region goes through the C-ABI (wtgpu_comm_* / wtgpu_film_reduce: RCCL inside the library, what a
+        # C++ host would call); torch.distributed only carries the communicator id and the barriers
+        from wave_tracer_amd.render import make_film_comm
+        comm = make_film_comm(local_rank)
     sc = Scene(args.scene, res=args.res, mesh_detail=1, force_ray_tracing=1 if args.ray_tracing else 0)
     npix = sc.width * sc.height
     sc.upload(local_rank, args.batch or npix)
@@ -133,14 +139,14 @@ def main():
         sc.render_async_into(value, weight, light, base + (Wm + s) * s_rank, base + (Wm + s + 1) * s_rank, 1, stream)
     sc.join(stream)
     if distributed:
-        for t in (value, weight, light):
-            if args.backend == "gloo":
+        if comm is not None:
+            comm.film_reduce(value, weight, light, root=0, stream=stream)
+        else:
+            for t in (value, weight, light):
                 torch.cuda.synchronize(dev)
                 h = t.cpu()
                 dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
                 t.copy_(h)
-            else:
-                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
     sync()
     dt = time.time() - t0
     if distributed:

@@ -4,6 +4,8 @@
 // the primitives into an estimate is invisible to every GPU-vs-checker test.  This file is that composition written a second time,
 // directly from the reference, sharing no header with wt/ (only oracle/indep/prims.h, a C view of the primitives):
 //   * per-sample recursion over std::vector<vertex> like the reference (plt_bdpt_detail.hpp:421-526), not an explicit walk state;
+//   * random_walk itself: the triangle under the beam axis (find_closest_triangle, :362-419), the surface / free-space-diffraction / null
+//     decision and the three interaction samplers (:192-346), composed of single-purpose primitives;
 //   * vertex bookkeeping in double precision: area-measure densities (vertex.hpp:224-243, 444-564), append_vertex / continue_walk
 //     (plt_bdpt_detail.hpp:95-121, 167-182);
 //   * vertex_t::interact (vertex.hpp:330-413), connect_subpaths (plt_bdpt_detail.hpp:747-923), connect_and_integrate (:722-745),
@@ -11,6 +13,7 @@
 //   * bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720) and the (s,t) loop of plt_bdpt_t::integrate (plt_bdpt.cpp:54-147).
 // It consumes the same counter-based random streams in the reference's order, so it must agree with liboracle.so sample for sample
 // (tests/test_indep.py: images to 1e-4, event counters exactly) — any disagreement is a bug in one of the two compositions.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -208,6 +211,36 @@ bool continue_walk(ctx_t& c, walk& w, bool allow_rr) {
     }
     return false;
 }
+// find_closest_triangle, first half (plt_bdpt_detail.hpp:362-389): of the triangles of the interaction record the one the beam AXIS hits
+// closest, inside the region's z-range (grown by the triangle's numeric tolerance: prim_axis_hits_tri)
+struct primary_t {
+    bool found = false;
+    uint32_t tuid = 0;
+    float dist = INFINITY, bary[2] = {0, 0};
+};
+primary_t find_primary(const ctx_t& c, const prim_trav& tr, const float dir[3]) {
+    primary_t p;
+    for (uint32_t i = 0; i < tr.ntris; ++i) {
+        const uint32_t tuid = prim_trav_tri(i);
+        float dist, bary[2];
+        if (prim_axis_hits_tri(c.sc, tuid, tr.origin, dir, tr.dist, tr.dist + tr.region_depth, &dist, bary) && dist < p.dist) {
+            p.found = true;
+            p.tuid = tuid;
+            p.dist = dist;
+            p.bary[0] = bary[0];
+            p.bary[1] = bary[1];
+        }
+    }
+    return p;
+}
+// integrator::shading_normals_correction_scale (integrator/common.hpp:22-33)
+double shading_normals_correction(bool backward, double wig, double wog, double wis, double wos) {
+    return backward ? 1.0 : std::fmin(std::fabs(wis * wog / (wos * wig)), 1e2);
+}
+
+// random_walk (plt_bdpt_detail.hpp:421-526) with the three interaction samplers (:192-346) — which interaction happens, the order of the
+// checks, what reaches the vertex bookkeeping — over primitives that each do one thing (a ray-triangle test, a BSDF sample, one
+// triangle's Gaussian integral, an aperture construction: prims.h).
 void random_walk(ctx_t& c, walk& w, int guard = 0) {
     if (guard >= 96) return;   // the checker's iteration cap (oracle.cpp: kMaxWalkIters); never reached in the shipped scenes
     const vertex& last = w.verts.back();
@@ -225,45 +258,123 @@ void random_walk(ctx_t& c, walk& w, int guard = 0) {
     prim_trace(c.sc, &w.beam, off_tuid, png, &tr);
     c.ctr[0]++;
     if (tr.empty) return;
-    prim_step st;
-    prim_step_sample(c.sc, &w.beam, &tr, c.seed, c.sid, w.stream, &w.draws, &st);
-    bool do_rr = true;
-    if (st.kind == 0) {
-        // (the reference counts a surface interaction before its wo-side check, plt_bdpt_detail.hpp:243; the checker's counter
-        // semantics are compared on vertices / connections, which are unaffected)
-        return;
+
+    float bo[3], bd[3], k, inten;
+    int transport;
+    prim_beam_info(&w.beam, bo, bd, &k, &transport, &inten);
+    const bool ballistic = tr.ballistic || prim_beam_is_ray(&w.beam);
+    const V3 origin = from(tr.origin), dir = from(bd);
+    float iwp[3];   // interaction point: where the beam axis enters the region
+    to(origin + dir * (double)tr.dist, iwp);
+    {   // (single precision like the reference's point arithmetic: the vertex position is compared for equality in append_vertex)
+        for (int a = 0; a < 3; ++a) iwp[a] = tr.origin[a] + tr.dist * bd[a];
     }
-    if (st.kind == 3 || st.kind == 4) {
-        do_rr = false;
-        if (st.kind == 3) c.ctr[5]++;
-        prim_step_apply(&w.beam, &st);
-    } else {
+
+    // ---- which triangle lies under the interaction point, if any
+    primary_t prim;
+    if (ballistic) {
+        prim.found = true;
+        prim.tuid = tr.tuid;
+        prim.dist = tr.dist;
+        prim.bary[0] = tr.bx;
+        prim.bary[1] = tr.by;
+    } else
+        prim = find_primary(c, tr, bd);
+
+    bool do_rr = true;
+    if (prim.found) {
+        // ---- sample_surface_interaction (plt_bdpt_detail.hpp:192-270)
+        float swp[3];
+        for (int a = 0; a < 3; ++a) swp[a] = tr.origin[a] + bd[a] * prim.dist;
+        prim_surface srf;
+        int material, emitter_of_shape;
+        prim_surface_at(c.sc, &w.beam, prim.tuid, prim.bary, swp, tr.dist, &srf, &material, &emitter_of_shape);
+        float wp[3], g[3], sn[3];
+        uint32_t tuid, shape;
+        prim_surface_info(&srf, wp, g, sn, &tuid, &shape);
+        const float wiw[3] = {-bd[0], -bd[1], -bd[2]};
+        float wi[3];
+        prim_surface_to_local(&srf, wiw, wi);
+        const double wig = dot(from(wiw), from(g)), wis = wi[2];
+        if (wig * wis <= 0) return;
+        prim_bsdf_sample bs;
+        prim_material_sample(c.sc, material, &srf, wi, k, transport, c.seed, c.sid, w.stream, &w.draws, &bs);
+        if (!bs.valid || bs.dpd == 0.f) return;
+        float wow_f[3];
+        prim_surface_to_world(&srf, bs.wo, wow_f);
+        const V3 wow = unit(from(wow_f));
+        const double wog = dot(wow, from(g)), wos = bs.wo[2];
+        c.ctr[3]++;   // (the reference records the surface interaction before the outgoing-side check, :243)
+        if (wog * wos <= 0) return;
+        const float pdf_revr = prim_material_pdf(c.sc, material, &srf, bs.wo, wi, k, 1 - transport);   // the reversed interaction: flipped transport mode
         vertex v;
+        v.type = V_SURFACE;
         v.backward = w.backward;
-        v.wp = from(st.wp);
-        if (st.kind == 1) {
-            v.type = V_SURFACE;
-            v.delta = st.is_delta != 0;
-            v.material = st.material;
-            v.emitter_of_shape = st.emitter_of_shape;
-            v.has_surface = true;
-            v.surface = st.surface;
-            float wp[3], g[3], s[3];
-            uint32_t tuid, shape;
-            prim_surface_info(&st.surface, wp, g, s, &tuid, &shape);
-            v.wp = from(wp);
-        } else {
-            v.type = V_FSD;
-            v.fraunhofer = true;
-            v.fsd_slot = st.fsd_slot;
-            const float n[3] = {0, 0, 1};
-            prim_dummy_surface(n, st.wp, &v.surface);
-        }
-        if (!append_vertex(c, w, v, st.dpd, st.pdf_revr)) return;
+        v.delta = is_discrete(bs.dpd);
+        v.material = material;
+        v.emitter_of_shape = emitter_of_shape;
+        v.has_surface = true;
+        v.surface = srf;
+        v.wp = from(wp);
+        if (!append_vertex(c, w, v, bs.dpd, pdf_revr)) return;
         c.ctr[1]++;
-        c.ctr[st.kind == 1 ? 3 : 4]++;
-        prim_step_apply(&w.beam, &st);
-        w.throughput *= st.throughput_mult;
+        double ws = 1;
+        if (!(g[0] == sn[0] && g[1] == sn[1] && g[2] == sn[2])) ws *= shading_normals_correction(w.backward, wig, wog, wis, wos);
+        // transform_surface_interaction (plt_bdpt_detail.hpp:123-136)
+        float wo_w[3];
+        {   // the normalised outgoing direction in single precision, as the beam transform receives it
+            const float l = std::sqrt(wow_f[0] * wow_f[0] + wow_f[1] * wow_f[1] + wow_f[2] * wow_f[2]);
+            for (int a = 0; a < 3; ++a) wo_w[a] = wow_f[a] / l;
+        }
+        prim_beam_transform_surface(&w.beam, &srf, wo_w, bs.M, (float)ws);
+        w.throughput *= (double)((float)ws * bs.M[0]);
+        if (w.backward && bs.eta != 1.f) w.throughput /= (double)(bs.eta * bs.eta);
+    } else {
+        // ---- the classified edges of the region's triangles (traversal_common.hpp:124-148): ordered, without duplicates
+        std::vector<uint32_t> eids;
+        if (c.FSD && !ballistic)
+            for (uint32_t i = 0; i < tr.ntris; ++i) {
+                uint32_t e[3];
+                prim_tri_edges(c.sc, prim_trav_tri(i), e);
+                for (int q = 0; q < 3; ++q)
+                    if (e[q] != 0xFFFFFFFFu) eids.push_back(e[q]);
+            }
+        std::sort(eids.begin(), eids.end());
+        eids.erase(std::unique(eids.begin(), eids.end()), eids.end());
+        if (!eids.empty()) {
+            // ---- free-space diffraction (plt_bdpt_detail.hpp:287-346); aperture power = 1 - the power the region's triangles that face
+            // like the closest hit intercept (find_closest_triangle, second half, :391-416)
+            double flux = 0;
+            for (uint32_t i = 0; i < tr.ntris; ++i) flux += (double)prim_region_tri_flux(c.sc, &w.beam, tr.dist, tr.region_depth, prim_trav_tri(i), tr.front_face);
+            const int slot = prim_fsd_build(c.sc, &w.beam, tr.dist, eids.data(), (uint32_t)eids.size(), (float)(1.0 - flux));
+            if (slot == -1) return;
+            if (slot == -2) {   // empty aperture: the beam restarts behind it, no Russian roulette
+                prim_beam_transform_restart(&w.beam, iwp, tr.dist);
+                do_rr = false;
+            } else {
+                prim_fsd_sampled fs;
+                prim_fsd_sample(c.sc, slot, c.seed, c.sid, w.stream, &w.draws, &fs);
+                if (fs.dpd == 0.f || fs.weight == 0.f) return;
+                c.ctr[4]++;
+                vertex v;
+                v.type = V_FSD;
+                v.backward = w.backward;
+                v.fraunhofer = true;
+                v.fsd_slot = slot;
+                v.wp = from(iwp);
+                const float n[3] = {0, 0, 1};
+                prim_dummy_surface(n, iwp, &v.surface);
+                if (!append_vertex(c, w, v, fs.dpd, fs.dpd)) return;   // (the reverse density of an fsd interaction is a TODO of the reference: = forward)
+                c.ctr[1]++;
+                prim_beam_transform_region(&w.beam, iwp, tr.dist, fs.wo_world, fs.weight);
+                w.throughput *= (double)fs.weight;
+            }
+        } else {
+            // ---- null interaction (plt_bdpt_detail.hpp:273-284): no vertex, the trace restarts
+            do_rr = false;
+            prim_beam_transform_restart(&w.beam, iwp, tr.dist);
+            c.ctr[5]++;
+        }
     }
     if (continue_walk(c, w, do_rr)) random_walk(c, w, guard + 1);
 }
@@ -429,7 +540,7 @@ vertex temp_vertex(vtype_e type, bool backward, int emitter, bool has_surface, c
 connect_ret connect(ctx_t& c, std::vector<vertex>& sv, std::vector<vertex>& ev, int s, int t) {
     connect_ret r;
     c.ctr[2]++;
-    const uint32_t stream = c.st_connect + (uint32_t)t * 32u + (uint32_t)s;
+    const uint32_t stream = s < 32 && t < 32 ? c.st_connect + (uint32_t)t * 32u + (uint32_t)s : c.st_connect + 1024u + (uint32_t)t * 4096u + (uint32_t)s;
     uint32_t draws = 0;
     if (s == 0) {
         const vertex& last = sv[t - 1];
@@ -599,6 +710,7 @@ double mis_weight(const ctx_t& c, const std::vector<vertex>& sv, const std::vect
 // plt_bdpt_t::integrate, one sample (plt_bdpt.cpp:54-147)
 void sample(ctx_t& c, uint32_t px, uint32_t py, double* value, double* weight, double* light) {
     prim_pool_reset();
+    prim_pool_reserve(2u * 96u + 8u);   // one aperture per walk step at most
     prim_gen g;
     prim_generate(c.sc, c.seed, c.sid, px, py, &g);
     std::vector<vertex> sv, ev;

@@ -1,7 +1,8 @@
 // oracle/indep/prims.cpp — the primitive layer behind oracle/indep/prims.h: thin wrappers over the restated physics in
-// wave_tracer_amd/csrc/wt/*.h (one primitive each) plus the SAMPLING half of an interaction (sample_surface_interaction /
-// sample_fraunhofer_fsd_interaction / sample_null_interaction / find_closest_triangle, plt_bdpt_detail.hpp:192-419), restated here a second
-// time.  Nothing in this file composes a path.                                                        *** TEST INFRASTRUCTURE ***
+// wave_tracer_amd/csrc/wt/*.h, one primitive each (a ray-triangle test, a BSDF sample, a Gaussian triangle integral, an aperture
+// construction, ...).  Nothing in this file decides what happens to a beam or composes a path: which triangle lies under the beam axis,
+// whether an interaction is a surface / free-space-diffraction / null interaction and everything after that is oracle/indep/indep.cpp.
+//                                                                                                      *** TEST INFRASTRUCTURE ***
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -63,6 +64,12 @@ void prim_streams(uint32_t out[4]) {
     out[3] = STREAM_CONNECT;
 }
 void prim_pool_reset(void) { tls.n_ap = 0; }
+void prim_pool_reserve(uint32_t n_apertures) {   // one aperture per free-space-diffraction vertex of a sample: 2 x (max_depth + 2) at most
+    if (tls.hdr.size() < n_apertures) {
+        tls.hdr.resize(n_apertures);
+        tls.edges.resize((size_t)n_apertures * kFsdMaxEdges);
+    }
+}
 
 void prim_generate(const void* sc_, uint64_t seed, uint64_t sid, uint32_t px, uint32_t py, prim_gen* out) {
     const scene_t& sc = S(sc_);
@@ -117,127 +124,83 @@ void prim_trace(const void* sc_, const prim_beam* beam, uint32_t prev_offset_tui
     o3(out->origin, tr.origin);
 }
 
-// The sampling half of one interaction (no vertex bookkeeping, no beam transform): plt_bdpt_detail.hpp:192-419.
-void prim_step_sample(const void* sc_, const prim_beam* beam_, const prim_trav* tr, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_step* out) {
+// ---- the pieces of one interaction (composed in indep.cpp) ----------------------------------------------------------------------------
+uint32_t prim_trav_tri(uint32_t i) { return tls.tris[i]; }
+int prim_beam_is_ray(const prim_beam* b) { return beam_is_ray(get<beam_t>(b)) ? 1 : 0; }
+int prim_axis_hits_tri(const void* sc_, uint32_t tuid, const float o[3], const float d[3], float zmin, float zmax, float* dist, float bary[2]) {
+    const scene_t& sc = S(sc_);
+    const tri_geo_t g = sc.tri_geo[tuid];
+    const vec3 origin = v3(o);
+    ray_tri_hit_t h;
+    if (!intersect_ray_tri(origin, v3(d), g.a, g.b, g.c, grow(range_t{zmin, zmax}, cone_intersection_tolerance(origin, g.a, g.b, g.c)), h)) return 0;
+    *dist = h.dist;
+    bary[0] = h.bx;
+    bary[1] = h.by;
+    return 1;
+}
+void prim_tri_edges(const void* sc_, uint32_t tuid, uint32_t e[3]) {
+    const tri_meta_t m = S(sc_).tri_meta[tuid];
+    e[0] = m.edge[0];
+    e[1] = m.edge[1];
+    e[2] = m.edge[2];
+}
+void prim_surface_at(const void* sc_, const prim_beam* beam_, uint32_t tuid, const float bary[2], const float wp[3], float beam_dist, prim_surface* out, int* material,
+                     int* emitter_of_shape) {
     const scene_t& sc = S(sc_);
     const beam_t beam = get<beam_t>(beam_);
+    surface_t srf = make_surface(sc, tuid, sc.tri_geo[tuid].n, vec2{bary[0], bary[1]}, v3(wp));
+    srf.footprint = beam_surface_footprint_static(beam, srf, beam_dist);
+    put(out, srf);
+    const shape_t shp = sc.shapes[srf.shape];
+    *material = shp.material;
+    *emitter_of_shape = shp.emitter;
+}
+void prim_surface_to_world(const prim_surface* s, const float v[3], float out[3]) { o3(out, to_world(get<surface_t>(s).shading, v3(v))); }
+void prim_material_sample(const void* sc_, int mat, const prim_surface* at, const float wi[3], float k, int transport, uint64_t seed, uint64_t sid, uint32_t stream,
+                          uint32_t* draws, prim_bsdf_sample* out) {
     sampler_t smp = make_sampler(seed, sid, stream, *draws);
-    std::memset(out, 0, sizeof(*out));
-    out->fsd_slot = -1;
-    out->emitter_of_shape = -1;
-    const float beam_dist = tr->dist;
-    const range_t izr{beam_dist, beam_dist + tr->region_depth};
-    const bool ballistic = tr->ballistic || beam_is_ray(beam);
-    const vec3 origin = v3(tr->origin), dir = beam.env.d;
-    const vec3 interaction_wp = origin + izr.min * dir;
-    o3(out->wp, interaction_wp);
-    out->apply_dist = beam_dist;
-    const frame_t bf = cone_frame(beam.env);
+    const bsdf_sample_t bs = material_sample(S(sc_), mat, v3(wi), k, (uint32_t)transport, smp, get<surface_t>(at).uv);
+    *draws = smp.draws;
+    out->valid = bs.valid ? 1 : 0;
+    o3(out->wo, bs.wo);
+    out->dpd = bs.dpd;
+    std::memcpy(out->M, bs.M.m, sizeof(out->M));
+    out->eta = bs.eta;
+}
+float prim_region_tri_flux(const void* sc_, const prim_beam* beam_, float beam_dist, float region_depth, uint32_t tuid, int want_front) {
+    const beam_t beam = get<beam_t>(beam_);
     const vec3 sd = beam_footprint(beam, beam_dist) / kBeamEnvelope;
-    const vec2 sigma{sd.x, sd.y};
-    // --- find_closest_triangle
-    uint32_t primary = kInvalid;
-    ray_tri_hit_t ph{WT_INF, 0.f, 0.f};
-    if (ballistic) {
-        primary = tr->tuid;
-        ph = {tr->dist, tr->bx, tr->by};
-    } else {
-        for (uint32_t i = 0; i < tr->ntris; ++i) {
-            const tri_geo_t g = sc.tri_geo[tls.tris[i]];
-            ray_tri_hit_t h;
-            if (intersect_ray_tri(origin, dir, g.a, g.b, g.c, grow(izr, cone_intersection_tolerance(origin, g.a, g.b, g.c)), h) && h.dist < ph.dist) {
-                primary = tls.tris[i];
-                ph = h;
-            }
-        }
-    }
-    if (primary != kInvalid) {
-        // --- sample_surface_interaction
-        const tri_geo_t g = sc.tri_geo[primary];
-        surface_t srf = make_surface(sc, primary, g.n, vec2{ph.bx, ph.by}, origin + dir * ph.dist);
-        srf.footprint = beam_surface_footprint_static(beam, srf, beam_dist);
-        const shape_t shp = sc.shapes[srf.shape];
-        const vec3 wiw = -dir, ng = srf.geo.n, ns = srf.shading.n;
-        const vec3 wi = to_local(srf.shading, wiw);
-        const float wig = dot(wiw, ng), wis = wi.z;
-        if (wig * wis <= 0.f) return;
-        const bsdf_sample_t bs = material_sample(sc, shp.material, wi, beam.k, beam.transport, smp, srf.uv);
-        *draws = smp.draws;
-        if (!bs.valid || bs.dpd == 0.f) return;
-        const vec3 wow = normalize(to_world(srf.shading, bs.wo));
-        const float wog = dot(wow, ng), wos = bs.wo.z;
-        if (wog * wos <= 0.f) return;
-        out->kind = 1;
-        put(&out->surface, srf);
-        out->material = shp.material;
-        out->emitter_of_shape = shp.emitter;
-        out->is_delta = pd_is_discrete(bs.dpd);
-        out->dpd = bs.dpd;
-        out->pdf_revr = material_pdf(sc, shp.material, bs.wo, wi, beam.k, flip_transport(beam.transport), srf.uv);
-        float w = 1.f;
-        if (!veq(ns, ng)) w *= shading_normals_correction_scale(beam.transport, wig, wog, wis, wos);
-        out->apply_w = w;
-        std::memcpy(out->apply_M, bs.M.m, sizeof(out->apply_M));
-        o3(out->apply_wo, wow);
-        out->throughput_mult = w * mueller_mean_intensity(bs.M);
-        if (beam.transport == TRANSPORT_BACKWARD && bs.eta != 1.f) out->throughput_mult /= sqr(bs.eta);
-        return;
-    }
-    // --- edges of the region (traversal_common.hpp:124-148)
-    std::vector<uint32_t> eids;
-    if (sc.opts.FSD && !ballistic)
-        for (uint32_t i = 0; i < tr->ntris; ++i)
-            for (int e = 0; e < 3; ++e) {
-                const uint32_t id = sc.tri_meta[tls.tris[i]].edge[e];
-                if (id != kInvalid) eids.push_back(id);
-            }
-    std::sort(eids.begin(), eids.end());
-    eids.erase(std::unique(eids.begin(), eids.end()), eids.end());
-    if (eids.empty()) {   // --- sample_null_interaction
-        out->kind = 3;
-        out->throughput_mult = 1.f;
-        return;
-    }
-    // --- sample_fraunhofer_fsd_interaction
-    if (tls.n_ap >= tls.hdr.size()) return;
-    const uint32_t slot = tls.n_ap++;
+    return region_triangle_flux(S(sc_), cone_frame(beam.env), beam.env, range_t{beam_dist, beam_dist + region_depth}, vec2{sd.x, sd.y}, tuid, want_front != 0);
+}
+int prim_fsd_build(const void* sc_, const prim_beam* beam_, float beam_dist, const uint32_t* edge_ids, uint32_t n, float aperture_power) {
+    const scene_t& sc = S(sc_);
+    const beam_t beam = get<beam_t>(beam_);
+    if (tls.n_ap >= tls.hdr.size()) return -1;
+    const uint32_t slot = tls.n_ap;
+    const vec3 sd = beam_footprint(beam, beam_dist) / kBeamEnvelope;
     fsd_aperture_t ap;
     ap.edge_offset = slot * kFsdMaxEdges;
     ap.edge_cap = kFsdMaxEdges;
     const fsd_edges_ref_t ed{tls.edges.data() + ap.edge_offset, 1};
-    fsd_build_aperture(sc, bf, beam.k, 1.f, beam.env, eids.data(), (uint32_t)eids.size(), sigma, ap, ed);
-    if (ap.n_edges == 0) {   // empty aperture: restart (do_RR = false), the slot stays unused
-        --tls.n_ap;
-        out->kind = 4;
-        out->throughput_mult = 1.f;
-        return;
-    }
-    double flux = 0;
-    for (uint32_t i = 0; i < tr->ntris; ++i) flux += region_triangle_flux(sc, bf, beam.env, izr, sigma, tls.tris[i], tr->front_face != 0);
-    const float I = (float)(1.0 - flux);
-    ap.recp_I = I > 0.f ? 1.f / I : 0.f;
+    fsd_build_aperture(sc, cone_frame(beam.env), beam.k, aperture_power, beam.env, edge_ids, n, vec2{sd.x, sd.y}, ap, ed);
+    if (ap.n_edges == 0) return -2;   // (the slot stays free)
     tls.hdr[slot] = ap;
-    const fsd_sample_t fs = fsd_sample(sc, ap, ed, smp);
-    *draws = smp.draws;
-    if (fs.dpd == 0.f || fs.weight == 0.f) return;
-    out->kind = 2;
-    out->fsd_slot = (int)slot;
-    out->dpd = out->pdf_revr = fs.dpd;
-    out->apply_w = fs.weight;
-    o3(out->apply_wo, to_world(ap.frame, fs.wo));
-    out->throughput_mult = fs.weight;
+    ++tls.n_ap;
+    return (int)slot;
 }
-void prim_step_apply(prim_beam* beam_, const prim_step* st) {
-    beam_t b = get<beam_t>(beam_);
-    if (st->kind == 1) {
-        mueller_t M;
-        std::memcpy(M.m, st->apply_M, sizeof(M.m));
-        beam_transform_surface_interaction(b, get<surface_t>(&st->surface), v3(st->apply_wo), M, st->apply_w);
-    } else if (st->kind == 2)
-        beam_transform_region_interaction(b, v3(st->wp), st->apply_dist, v3(st->apply_wo), st->apply_w);
-    else if (st->kind == 3 || st->kind == 4)
-        beam_transform_restart(b, v3(st->wp), st->apply_dist);
-    put(beam_, b);
+void prim_fsd_sample(const void* sc_, int slot, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_fsd_sampled* out) {
+    sampler_t smp = make_sampler(seed, sid, stream, *draws);
+    const fsd_aperture_t& ap = tls.hdr[(uint32_t)slot];
+    const fsd_sample_t fs = fsd_sample(S(sc_), ap, fsd_edges_ref_t{tls.edges.data() + ap.edge_offset, 1}, smp);
+    *draws = smp.draws;
+    o3(out->wo_world, to_world(ap.frame, fs.wo));
+    out->dpd = fs.dpd;
+    out->weight = fs.weight;
+}
+void prim_beam_transform_restart(prim_beam* b_, const float wp[3], float dist) {
+    beam_t b = get<beam_t>(b_);
+    beam_transform_restart(b, v3(wp), dist);
+    put(b_, b);
 }
 float prim_uniform(uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws) {
     sampler_t smp = make_sampler(seed, sid, stream, *draws);

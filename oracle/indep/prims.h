@@ -20,14 +20,8 @@ typedef struct {
     prim_beam ebeam; float e_dpd, e_ppd, e_select_pdf; int emitter; int e_has_surface; prim_surface e_surface;   /* emitter sample */
 } prim_gen;
 typedef struct { int empty, ballistic; float dist, region_depth; int front_face; uint32_t tuid; float bx, by; uint32_t ntris; float origin[3]; } prim_trav;
-typedef struct {
-    int kind;   /* 0: the walk ends here, 1 surface, 2 free-space diffraction, 3 null, 4 restart behind an EMPTY aperture (not a 'null interaction' in the statistics) */
-    prim_surface surface; int material, emitter_of_shape, is_delta;
-    float dpd, pdf_revr;      /* sampled / reverse solid-angle densities, tagged (negative = discrete mass) */
-    float throughput_mult;    /* factor on the walk's throughput (Russian roulette input) */
-    int fsd_slot; float wp[3];
-    float apply_M[16], apply_w, apply_wo[3], apply_dist;   /* for prim_step_apply (the beam transform happens AFTER the vertex is appended) */
-} prim_step;
+typedef struct { int valid; float wo[3]; float dpd; float M[16]; float eta; } prim_bsdf_sample;   /* bsdf_t::sample: local wo, tagged density, weighted Mueller matrix */
+typedef struct { float wo_world[3]; float dpd, weight; } prim_fsd_sampled;
 typedef struct { prim_beam beam; float dpd; int emitter; int has_surface; prim_surface surface; } prim_edirect;
 typedef struct { prim_beam beam; float dpd; prim_element element; int has_surface; prim_surface surface; } prim_sdirect;
 typedef struct { int valid; prim_beam beam; prim_element element; prim_surface surface; } prim_si;
@@ -35,10 +29,28 @@ typedef struct { int valid; prim_beam beam; prim_element element; prim_surface s
 void prim_info(const void* sc, int out[14]);   /* max_depth MIS RR FSD sensor_direct emitter_direct width height channels stokes integrator sensor_flags only_s+1 only_t+1 */
 void prim_streams(uint32_t out[4]);            /* scene, sensor walk, emitter walk, connect base (+ t*32 + s) */
 void prim_pool_reset(void);
+void prim_pool_reserve(uint32_t n_apertures);
 void prim_generate(const void* sc, uint64_t seed, uint64_t sid, uint32_t px, uint32_t py, prim_gen* out);
 void prim_trace(const void* sc, const prim_beam* beam, uint32_t prev_offset_tuid, const float prev_ng[3], prim_trav* out);
-void prim_step_sample(const void* sc, const prim_beam* beam, const prim_trav* tr, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_step* out);
-void prim_step_apply(prim_beam* beam, const prim_step* st);
+/* --- the pieces of one interaction; what kind of interaction happens, which triangle lies under the beam axis, the order of the checks and
+ * what is handed to the vertex bookkeeping is decided in indep.cpp (plt_bdpt_detail.hpp:192-526) --- */
+uint32_t prim_trav_tri(uint32_t i);   /* i-th triangle of the interaction record of this thread's last prim_trace */
+int prim_beam_is_ray(const prim_beam* b);
+/* intersect_ray_tri against triangle `tuid` within [zmin, zmax] grown by the triangle's cone_intersection_tolerance (find_closest_triangle's test) */
+int prim_axis_hits_tri(const void* sc, uint32_t tuid, const float o[3], const float d[3], float zmin, float zmax, float* dist, float bary[2]);
+void prim_tri_edges(const void* sc, uint32_t tuid, uint32_t e[3]);   /* classified edges of a triangle (0xFFFFFFFF: none) */
+/* intersection_surface_t of triangle `tuid` at `bary` / `wp` with the beam's static footprint at beam_dist; the shape's bsdf and emitter (-1) */
+void prim_surface_at(const void* sc, const prim_beam* beam, uint32_t tuid, const float bary[2], const float wp[3], float beam_dist, prim_surface* out, int* material,
+                     int* emitter_of_shape);
+void prim_surface_to_world(const prim_surface* s, const float v[3], float out[3]);
+void prim_material_sample(const void* sc, int mat, const prim_surface* at, const float wi[3], float k, int transport, uint64_t seed, uint64_t sid, uint32_t stream,
+                          uint32_t* draws, prim_bsdf_sample* out);
+/* the beam power one triangle of the region intercepts (wavefront_t::integrate_triangle over the clipped, projected triangle); 0 when it faces the other way */
+float prim_region_tri_flux(const void* sc, const prim_beam* beam, float beam_dist, float region_depth, uint32_t tuid, int want_front);
+/* free_space_diffraction_t over the given classified edges: >= 0 the aperture's slot, -1 no slot left, -2 the aperture is empty */
+int prim_fsd_build(const void* sc, const prim_beam* beam, float beam_dist, const uint32_t* edge_ids, uint32_t n, float aperture_power);
+void prim_fsd_sample(const void* sc, int slot, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_fsd_sampled* out);
+void prim_beam_transform_restart(prim_beam* b, const float wp[3], float dist);
 float prim_uniform(uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws);
 void prim_beam_info(const prim_beam* b, float o[3], float d[3], float* k, int* transport, float* intensity);
 void prim_beam_scale(prim_beam* b, float f);

@@ -129,10 +129,10 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
         scr.tris.resize(kOracleConeTris);
     scr.dists.resize(kOracleConeTris);
         scr.dists.resize(kOracleConeTris);
-        scr.svert.resize(kMaxVerts * kVertexWords);
-        scr.evert.resize(kMaxVerts * kVertexWords);
-        std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);
-        std::vector<fsd_edge_t> edges((2 * kMaxVerts + 8) * (size_t)kFsdMaxEdges);
+        scr.svert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+        scr.evert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+        std::vector<fsd_aperture_t> hdr(2 * (size_t)kMaxWalkIters + 8);   // one per walk step at most (a step that restarts behind an empty aperture keeps its slot)
+        std::vector<fsd_edge_t> edges(hdr.size() * (size_t)kFsdMaxEdges);
         uint32_t pool_counter = 0;
         const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
         bdpt_counters_t& ctr = ctrs[tid];
@@ -200,10 +200,10 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
     sample_scratch_t scr;
     scr.tris.resize(kOracleConeTris);
     scr.dists.resize(kOracleConeTris);
-    scr.svert.resize(kMaxVerts * kVertexWords);
-    scr.evert.resize(kMaxVerts * kVertexWords);
-    std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);
-    std::vector<fsd_edge_t> edges((2 * kMaxVerts + 8) * (size_t)kFsdMaxEdges);
+    scr.svert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+    scr.evert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+    std::vector<fsd_aperture_t> hdr(2 * (size_t)kMaxWalkIters + 8);   // one per walk step at most (a step that restarts behind an empty aperture keeps its slot)
+    std::vector<fsd_edge_t> edges(hdr.size() * (size_t)kFsdMaxEdges);
     uint32_t pool_counter = 0;
     const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
     bdpt_counters_t ctr;
@@ -266,10 +266,10 @@ uint64_t oracle_profile_axis(const void* scene_host, uint64_t seed, uint32_t til
     sample_scratch_t scr;
     scr.tris.resize(kOracleConeTris);
     scr.dists.resize(kOracleConeTris);
-    scr.svert.resize(kMaxVerts * kVertexWords);
-    scr.evert.resize(kMaxVerts * kVertexWords);
-    std::vector<fsd_aperture_t> hdr(2 * kMaxVerts + 8);
-    std::vector<fsd_edge_t> edges((2 * kMaxVerts + 8) * (size_t)kFsdMaxEdges);
+    scr.svert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+    scr.evert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+    std::vector<fsd_aperture_t> hdr(2 * (size_t)kMaxWalkIters + 8);   // one per walk step at most (a step that restarts behind an empty aperture keeps its slot)
+    std::vector<fsd_edge_t> edges(hdr.size() * (size_t)kFsdMaxEdges);
     uint32_t pool_counter = 0;
     const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
     bdpt_counters_t ctr;

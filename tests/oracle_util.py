@@ -61,3 +61,30 @@ def oracle_render_tiles(scene, sample_begin, sample_end, seed, tile_stride, tile
     blk = (ys // B) * bx + xs // B
     mask = (blk % tile_stride) == tile_offset if tile_stride > 1 else np.ones((H, W), bool)
     return value, weight, light, dict(zip(ORACLE_COUNTERS, [int(x) for x in ctr])), int(n.value), mask
+
+
+def paired_bias_stats(G, C, rng=None, n_boot=2000):
+    """G, C: [chunks, H, W] film sums of the same samples.  Returns a dict of the statistics the test asserts."""
+    rng = rng or np.random.default_rng(1)
+    d = G - C
+    div = np.abs(d) > 0.5 * np.maximum(G, C)            # cells that hold a sample on a different discrete path
+    n_div, n_pos = int(div.sum()), int((d[div] > 0).sum())
+    tot = C.sum()
+    bias_all = d.sum() / tot
+    bias_trim = d[~div].sum() / C[~div].sum()
+    # bootstrap over cells (the paired differences are i.i.d. across (chunk, pixel) cells to a good approximation)
+    flat_d, flat_c = d.ravel(), C.ravel()
+    idx = rng.integers(0, flat_d.size, size=(n_boot, flat_d.size // 8))   # (1/8 subsamples, rescaled: keeps memory bounded)
+    boot = flat_d[idx].sum(axis=1) / flat_c[idx].sum(axis=1)
+    se_all = float(boot.std() / np.sqrt(8.0))
+    keep = ~div.ravel()
+    kd, kc = flat_d[keep], flat_c[keep]
+    idx = rng.integers(0, kd.size, size=(n_boot, kd.size // 8))
+    boot_t = kd[idx].sum(axis=1) / kc[idx].sum(axis=1)
+    se_trim = float(boot_t.std() / np.sqrt(8.0))
+    # two-sided binomial p-value of the sign split of the divergent cells
+    from math import comb
+    k = min(n_pos, n_div - n_pos)
+    p_sign = min(1.0, 2.0 * sum(comb(n_div, i) for i in range(k + 1)) / 2.0 ** n_div) if n_div else 1.0
+    return dict(bias_all=float(bias_all), se_all=se_all, bias_trim=float(bias_trim), se_trim=se_trim, n_div=n_div, n_pos=n_pos, frac_div=float(div.mean()),
+                p_sign=float(p_sign), rel_l1_trim=float(np.abs(d[~div]).sum() / C[~div].sum()), div_share_of_flux=float(np.maximum(G, C)[div].sum() / tot))

@@ -41,6 +41,10 @@ def _rel_l1(a, b):
     ("tex_bilinear_ramp", 32, 8, {}),
     ("tex_mask", 32, 8, {}),
     ("tex_normal_tilt", 32, 8, {}),
+    # subpaths of up to 34 / 42 vertices (max_depth beyond the 16 of rounds 1-2; Russian roulette off so that the walks really get there):
+    # vertex stores sized from the scene, streaming MIS weights, the open-ended last row / column of the strategy buckets
+    ("furnace", 16, 4, {"max_depth": 32, "rr": 0}),
+    ("white_furnace", 12, 4, {"max_depth": 40, "rr": 0}),
 ])
 def test_image_parity_small(built, name, res, spp, kw):
     """Same Philox streams on both sides => the images agree sample for sample up to fp contraction / libm ulps.
@@ -391,7 +395,7 @@ def test_rccl_film_reduce_world_size_1(built):
     import torch.distributed as dist
     from wave_tracer_amd import Scene, render
     from wave_tracer_amd.api import Comm
-    from wave_tracer_amd.render import alloc_films, render_distributed
+    from wave_tracer_amd.render import alloc_films, make_film_comm, render_distributed
     sc = Scene("furnace", res=24, lut=(32, 32))
     sc.upload(0)
     ref = render(sc, 4, seed=3)
@@ -409,9 +413,42 @@ def test_rccl_film_reduce_world_size_1(built):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         out = render_distributed(sc, 4, seed=3)
+        c2 = make_film_comm(0)   # the path bench.py --gpus N takes: id over torch.distributed, reduce inside the C-ABI
+        out2 = render_distributed(sc, 4, seed=3, comm=c2)
+        c2.close()
     finally:
         dist.destroy_process_group()
     assert np.allclose(out[0], ref[0], rtol=1e-9, atol=1e-30) and np.allclose(out[2], ref[2], rtol=1e-9, atol=1e-30)
+    assert np.allclose(out2[0], ref[0], rtol=1e-9, atol=1e-30) and np.allclose(out2[2], ref[2], rtol=1e-9, atol=1e-30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["furnace", "etoile"])
+def test_two_ranks_one_gpu_sharded_render(built, tmp_path, name):
+    """render_distributed with the PRODUCT shard renderer (HIP) on two ranks that share the box's GPU (gloo: the films are summed over the
+    host): the reduced film equals the single-process render of the whole sample range — sample-index sharding, disjoint Philox streams
+    per shard, additive films — for plt_bdpt and for the forward plt_path scene."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from wave_tracer_amd import Scene, render
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "dist_hip.npz")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(here, "_dist_worker_hip.py"), out, "6", "17", name]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    sc = Scene(name, res=24, lut=(32, 32), mesh_detail=0)
+    v, w, l = render(sc, 6, seed=17)
+    assert v.sum() + l.sum() > 0
+    # (f64 atomics: the order of the film sums differs between one process and two)
+    assert np.allclose(d["value"], v, rtol=1e-9, atol=1e-30) and np.allclose(d["weight"], w, rtol=1e-9) and np.allclose(d["light"], l, rtol=1e-9, atol=1e-30)
 
 
 def test_bench_launches_its_own_ranks(built):
@@ -435,20 +472,24 @@ def test_bench_launches_its_own_ranks(built):
 
 
 def test_converged_bias_dense_crop(built):
-    """BASELINE.json's second metric: converged-image error against the CPU reference.  Dense-mesh crop of the headline film (same
-    pixel pitch as the 1440^2 render).
+    """BASELINE.json's second metric: converged-image error against the CPU reference (north_star: < 1e-3).  Dense-mesh crop of the
+    headline film (same pixel pitch as the 1440^2 render).
     (1) PAIRED estimate of the bias (common random numbers: both sides consume identical Philox streams, so the difference of the
         film sums is carried by the few samples that differ — a low-variance estimate of E[gpu] - E[cpu]), 256 spp in 16 chunks.
-        Two populations (measured): ~0.1 % of the (pixel, chunk) cells DIVERGE discretely — single samples whose MIS
-        weight lands on the other side of one of the estimator's discontinuities (a Fraunhofer pdf is clamped to zero at 100 sr^-1,
-        free_space_diffraction.hpp:133, and a pdf <= FLT_EPSILON counts as 1, plt_bdpt_detail.hpp:688-719) because 1 - flux of an
-        almost completely blocked beam differs in its last bits; rendered strategy by strategy with unit weights those samples agree —
-        and the rest, which must agree: |sum_gpu - sum_cpu| < 3e-3 sum_cpu over the non-divergent cells (measured +4e-4 .. +1.6e-3 with
-        ~1e-3 standard error), < 0.3 % divergent cells.
+        Asserted on ALL cells, nothing trimmed: |sum_gpu - sum_cpu| < 1e-3 sum_cpu and within 3 bootstrap standard errors (+ 1e-4) of
+        zero; the (pixel, chunk) cells that hold a sample on a different discrete path ("divergent": the two sums differ by more than half)
+        are < 0.1 % of the cells and, when there are at least 6 of them, sign-balanced (two-sided binomial p > 0.01).
+        History: round 2 measured +2.35e-2 over all cells with 11 divergent cells, all GPU-larger.  The cause was fused multiply-add
+        contraction: hipcc and g++ contracted different expressions of the shared headers, and the estimator's discontinuities (a
+        Fraunhofer pdf is clamped to zero at 100 sr^-1, free_space_diffraction.hpp:133; a pdf <= FLT_EPSILON counts as 1 in the MIS sums,
+        plt_bdpt_detail.hpp:688-719) turned last-bit differences of 1 - flux into one-sided firefly-weighted flips.  Both sides are now
+        built with -ffp-contract=off (explicit fmaf stays): measured -3e-6 +- 8e-6 at 256 spp, -9e-6 +- 2e-5 at 1024 spp with ONE
+        divergent cell in 65,536 (tools/paired_bias.py, gpurun_out/r3n).
     (2) INDEPENDENT seeds at 1024 spp: GPU(seed A) against the CPU checker(seed C), judged against the Monte-Carlo floor measured
         by two GPU renders with different seeds (A, B): block means and the crop mean agree within the floor.
     Prints all numbers."""
     from wave_tracer_amd import Scene, render, develop
+    from oracle_util import paired_bias_stats
     kw = dict(mesh_detail=1, lut=(128, 128), crop_of=1440)
     res = 32
     sc = Scene("cornell_box", res=res, **kw)
@@ -460,13 +501,29 @@ def test_converged_bias_dense_crop(built):
         ov, ow, ol, _ = oracle_render(sc, b, e, 31)
         G.append(v.sum(axis=2) + l.sum(axis=2))
         C.append(ov.sum(axis=2) + ol.sum(axis=2))
-    G, C = np.array(G), np.array(C)
-    d = G - C
-    div = np.abs(d) > 0.5 * np.maximum(G, C)
-    bias_all, bias_trim = d.sum() / C.sum(), d[~div].sum() / C[~div].sum()
-    print(f"paired bias, 256 spp: all cells {bias_all:+.2e}; {div.sum()} of {d.size} cells diverge discretely ({(d[div] > 0).sum()} GPU-larger); "
-          f"non-divergent cells {bias_trim:+.2e}, rel L1 {np.abs(d[~div]).sum() / C[~div].sum():.2e}")
-    assert div.mean() < 3e-3 and abs(bias_trim) < 3e-3, (div.mean(), bias_trim)
+    st = paired_bias_stats(np.array(G), np.array(C))
+    print(f"paired bias, 256 spp: all cells {st['bias_all']:+.2e} +- {st['se_all']:.1e}; {st['n_div']} of {len(G) * res * res} cells diverge discretely "
+          f"({st['n_pos']} GPU-larger, sign p = {st['p_sign']:.3f}); non-divergent cells {st['bias_trim']:+.2e} +- {st['se_trim']:.1e}, rel L1 {st['rel_l1_trim']:.2e}")
+    assert abs(st["bias_all"]) < 1e-3 and abs(st["bias_all"]) < 3 * st["se_all"] + 1e-4, st
+    assert abs(st["bias_trim"]) < 1e-3, st
+    assert st["frac_div"] < 1e-3 and (st["n_div"] < 6 or st["p_sign"] > 0.01), st
+    # ... and against the checker running the interaction records AS EXECUTED by the reference (the final-slab filter never fires there:
+    # src/ads/bvh8w.cpp:175 records no distance) instead of as written: the one known semantic deviation of this path.
+    # CPU-only measurement at 1024 spp (tools/filter_effect.py): as executed - as written = -2.8e-4 +- 1.6e-4 of the crop's flux (+2.7 %
+    # Fraunhofer interactions), 1e-8 on the double slits.  Here: the GPU stays within the 1e-3 tolerance of that variant too.
+    from oracle_util import load_oracle
+    lib = load_oracle()
+    C0 = []
+    lib.oracle_set_region_filter(0)
+    try:
+        for chunk in range(16):
+            ov, ow, ol, _ = oracle_render(sc, chunk * 16, (chunk + 1) * 16, 31)
+            C0.append(ov.sum(axis=2) + ol.sum(axis=2))
+    finally:
+        lib.oracle_set_region_filter(1)
+    st0 = paired_bias_stats(np.array(G), np.array(C0))
+    print(f"against the as-executed records: all cells {st0['bias_all']:+.2e} +- {st0['se_all']:.1e}, {st0['n_div']} divergent cells")
+    assert abs(st0["bias_all"]) < 1e-3 + 3 * st0["se_all"], st0
 
     # (2) independent seeds
     def blocks(img):

@@ -48,6 +48,10 @@ CASES = [
     ("cornell_box", 16, 2, {"mesh_detail": 0, "lut": (64, 64), "crop_of": 1440}),
     ("lens_b", 16, 4, {}),                               # dielectric (delta) vertices
     ("bidir_room", 20, 2, {"mesh_detail": 0, "lut": (64, 64), "polarimetric": 1}),   # Stokes film: polarised beam integration
+    # subpaths far beyond the 18 vertices rounds 1-2 were compiled for (the reference's max_depth is a plain integer, plt_bdpt.cpp:111,169;
+    # kitchen / sponza / veach_mis / munich ask for 24..128): 82 vertices per sample, strategies up to (s,t) = (41,41)
+    ("white_furnace", 8, 4, {"max_depth": 40, "rr": 0}),
+    ("furnace", 12, 4, {"max_depth": 32, "rr": 0, "fsd": 1, "lut": (64, 64)}),
 ]
 
 

@@ -161,7 +161,9 @@ mesh_t load_ply(const std::string& path, bool face_normals, double scale) {
                         rd.scalar(p.type);
                         continue;
                     }
-                    const size_t n = (size_t)rd.scalar(p.count_type);
+                    const double cnt = rd.scalar(p.count_type);
+                    if (!(cnt >= 0.0 && cnt <= 1e6)) throw std::runtime_error("(PLY loader) " + path + ": list count out of range");
+                    const size_t n = (size_t)cnt;
                     const bool indices = p.name == "vertex_indices" || p.name == "vertex_index";
                     if (indices && n != 3) throw std::runtime_error("(ply loader) triangulation not supported");
                     uint32_t id[3] = {0, 0, 0};
@@ -179,7 +181,9 @@ mesh_t load_ply(const std::string& path, bool face_normals, double scale) {
                         rd.scalar(p.type);
                         continue;
                     }
-                    const size_t n = (size_t)rd.scalar(p.count_type);
+                    const double cnt = rd.scalar(p.count_type);
+                    if (!(cnt >= 0.0 && cnt <= 1e6)) throw std::runtime_error("(PLY loader) " + path + ": list count out of range");
+                    const size_t n = (size_t)cnt;
                     for (size_t k = 0; k < n; ++k) rd.scalar(p.type);
                 }
         }
@@ -201,6 +205,7 @@ std::vector<float> load_pfm(const std::string& path, uint32_t& width, uint32_t& 
     double scale = 0;
     f >> magic >> width >> height >> scale;
     if ((magic != "PF" && magic != "Pf") || !width || !height || scale == 0) throw std::runtime_error("(bitmap loader) " + path + ": not a PFM file");
+    if (width > 65536u || height > 65536u) throw std::runtime_error("(bitmap loader) " + path + ": image dimensions out of range (1..65536)");
     f.get();   // the single whitespace after the header
     channels = magic == "PF" ? 3u : 1u;
     const size_t n = (size_t)width * height * channels;

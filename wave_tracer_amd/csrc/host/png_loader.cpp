@@ -73,6 +73,8 @@ std::vector<float> load_png(const std::string& path, uint32_t& width, uint32_t& 
     }
     if (!(depth == 8 || depth == 16) || (ctype == 3 && depth != 8))
         throw std::runtime_error("(bitmap loader) " + path + ": bit depth " + std::to_string(depth) + " is not supported (8 or 16)");
+    if (width == 0 || height == 0 || width > 65536u || height > 65536u)   // (keeps the size arithmetic below far from wrapping)
+        throw std::runtime_error("(bitmap loader) " + path + ": image dimensions out of range (1..65536)");
     const size_t bps = depth / 8, bpp = samples * bps, row = (size_t)width * bpp;
     std::vector<unsigned char> raw((row + 1) * (size_t)height);
     uLongf got = (uLongf)raw.size();

@@ -133,7 +133,15 @@ struct xml_parser_t {
         return s.substr(b, i - b);
     }
     // parses one element at s[i] == '<'
+    int depth = 0;   // nesting of the element being parsed (a stack overflow could not be caught like the exceptions the C-ABI translates)
+    struct depth_guard_t {
+        int& d;
+        explicit depth_guard_t(int& d_) : d(d_) { ++d; }
+        ~depth_guard_t() { --d; }
+    };
     xnode_t element() {
+        const depth_guard_t guard(depth);
+        if (depth > 256) fail("elements nested deeper than 256 levels");
         xnode_t n;
         ++i;
         n.name = ident();
@@ -216,12 +224,15 @@ struct expr_t {
         }
         return false;
     }
+    int paren_depth = 0;
     double primary() {
         ws();
         if (i >= s.size()) fail("operand expected");
         if (s[i] == '(') {
             ++i;
+            if (++paren_depth > 256) fail("parentheses nested deeper than 256 levels");
             const double v = lor();
+            --paren_depth;
             if (!eat(")")) fail("')' expected");
             return v;
         }
@@ -569,14 +580,24 @@ struct loader_t {
         }
         return nullptr;
     }
-    // real-valued spectrum node -> builder spectrum id (-2: no overlap with the sensor)
-    int spectrum(const xnode_t& n) {
+    // a spectrum node without its `scale` child (the emitters hand their scale to the builder separately, emitter_t::scale); the <bin>s of
+    // piecewise_linear / composite spectra and nested spectra stay
+    static xnode_t without_scale(const xnode_t& n) {
+        xnode_t c = n;
+        c.kids.erase(std::remove_if(c.kids.begin(), c.kids.end(), [](const xnode_t& k) { return k.get("name") == "scale"; }), c.kids.end());
+        return c;
+    }
+    // real-valued spectrum node -> builder spectrum id.  `emitter` = the spectrum of an emitter: -2 when it has no overlap with the sensor's
+    // sensitivity (a continuous spectrum under a monochromatic sensor carries no power at the line: the emitter is dropped, see the header of
+    // this file).  Everything else (IORs, reflectances, scale factors) is baked as a continuous spectrum and evaluated at the sample's
+    // wavenumber on the device, whatever the sensor; -2 only for a composite spectrum without a bin for the sensor.
+    int spectrum(const xnode_t& n, bool emitter = false) {
         if (n.get("type") == "composite") {
             const xnode_t* bin = pick_bin(n);
             if (!bin) return -2;
             const xnode_t* s = bin->child("spectrum");
             if (!s) throw std::runtime_error("composite spectrum: <bin> without <spectrum>");
-            return spectrum(*s);
+            return spectrum(*s, emitter);
         }
         double scale = 1.0;
         if (const xnode_t* sc = n.named("scale")) scale = eval_number(sc->get("value"));
@@ -584,7 +605,7 @@ struct loader_t {
             const quantity_t q = parse_wavelength(n.get("wavelength"), "discrete spectrum wavelength");
             const double wl = q.si();
             const double val = n.attr("value") ? eval_number(n.get("value")) : 1.0;
-            if (mono ? std::fabs(wl - line_m) > 1e-9 * line_m : !(band_lo <= wl && wl <= band_hi)) return -2;
+            if (emitter && (mono ? std::fabs(wl - line_m) > 1e-9 * line_m : !(band_lo <= wl && wl <= band_hi))) return -2;
             return b.spectrum_discrete((float)q.in_mm(), (float)(val * scale));
         }
         if (n.attr("constant")) {
@@ -595,7 +616,7 @@ struct loader_t {
         if (n.attr("rgb")) {
             const auto c = split_list(n.get("rgb"));
             if (c.size() != 3) throw std::runtime_error("rgb spectrum: three components expected");
-            if (mono) return -2;   // RGB uplift is defined over 380..720 nm
+            if (mono && emitter) return -2;   // RGB uplift is defined over 380..720 nm
             return b.spectrum_rgb((float)eval_number(c[0]), (float)eval_number(c[1]), (float)eval_number(c[2]));
         }
         // named database spectra (spectrum_from_db.cpp): the tables baked into the library (Al, Au, Ag, Cu, SF5, SF11, BK7; the CFL emission
@@ -618,7 +639,7 @@ struct loader_t {
         }
         if (n.attr("emitter")) {
             const std::string e = n.get("emitter");
-            if (mono) return -2;
+            if (mono && emitter) return -2;
             if (e == "2534_CFL_Tensor_Twister") return b.spectrum_named("CFL2534");
             return b.spectrum_emission_from_file(data_file("emission", e));
         }
@@ -631,7 +652,7 @@ struct loader_t {
         // gaussian (value x exp(-(k - k0)^2 / 2 s^2) with s = k(mean) - k(mean + stddev), cut at 10 s: gaussian.cpp:60-77), baked on the
         // library's 0.5-nm table over 340..840 nm
         if (n.get("type") == "piecewise_linear" || n.get("type") == "gaussian") {
-            if (mono) return -2;   // continuous spectrum x line sensor
+            if (mono && emitter) return -2;   // continuous spectrum x line sensor
             const int N = 1001;
             const double l0 = 340.0, dl = 0.5;
             std::vector<float> v(N, 0.f);
@@ -666,12 +687,18 @@ struct loader_t {
             return b.spectrum_from_wavelength_table(v.data(), nullptr, N, (float)l0, (float)dl);
         }
         if (n.attr("blackbody")) {
-            if (mono) return -2;   // continuous spectrum x line sensor: see the header of this file
+            if (mono && emitter) return -2;   // continuous spectrum x line sensor: see the header of this file
             return b.spectrum_blackbody((float)parse_dim(n.get("blackbody"), DIM_TEMPERATURE, "blackbody"), (float)scale);
         }
         std::string desc = "<" + n.name;
         for (auto& at : n.attrs) desc += " " + at.first + "=\"" + at.second + "\"";
         throw std::runtime_error(desc + ">: unsupported kind of spectrum");
+    }
+    // an index of refraction: must resolve (the device reads a missing spectrum as 1, i.e. an index-matched interface)
+    int ior_spectrum(const xnode_t& n, const char* what) {
+        const int s = spectrum(n);
+        if (s < 0) throw std::runtime_error(std::string(what) + ": the spectrum has no value at the sensor's wavelengths (a composite without a matching bin?)");
+        return s;
     }
     // ---- textures (src/texture/texture_loader.cpp:30-62): constant, checkerboard (colour1 / colour2: a texture or a constant spectrum,
     // defaults 0 and 1), scale (constant `scale` spectrum x nested texture), transform (<matrix value="a,b,c,d"/>, <translate value="x,y"/>
@@ -781,7 +808,7 @@ struct loader_t {
     // extIOR, reflection_scale, transmission_scale of the two interface BSDFs (src/bsdf/dielectric.cpp:94-97, surface_spm.cpp:225-229);
     // the scales are constants here
     void interface_extras(const xnode_t& n, material_t& out) {
-        if (const xnode_t* e = n.named("extIOR")) out.ext_ior_spec = spectrum(*e);
+        if (const xnode_t* e = n.named("extIOR")) out.ext_ior_spec = ior_spectrum(*e, "extIOR");
         if (const xnode_t* r = n.named("reflection_scale")) out.refl_scale = const_of(*r, "reflection_scale");
         if (const xnode_t* t = n.named("transmission_scale")) out.trans_scale = const_of(*t, "transmission_scale");
     }
@@ -834,7 +861,7 @@ struct loader_t {
         if (type == "dielectric") {
             const xnode_t* ior = n.named("IOR");
             if (!ior) throw std::runtime_error("dielectric bsdf: IOR expected");
-            out = mat_dielectric(spectrum(*ior));
+            out = mat_dielectric(ior_spectrum(*ior, "dielectric IOR"));
             out.two_sided = two_sided;
             interface_extras(n, out);
             return true;
@@ -892,7 +919,7 @@ struct loader_t {
         if (type == "surface_spm") {
             const xnode_t* ior = n.named("IOR");
             if (!ior) throw std::runtime_error("surface_spm bsdf: IOR expected");
-            const int s = spectrum(*ior);
+            const int s = ior_spectrum(*ior, "surface_spm IOR");
             // surface profiles (src/interaction/surface_profile/{dirac,fractal,gaussian}.cpp): the roughness-parametrised forms with a
             // constant roughness (T / sigma_h resp. sigma textures are not supported)
             bool fractal = false, gaussian = false;
@@ -984,7 +1011,9 @@ struct loader_t {
         if (!film || film->get("type") != "array") throw std::runtime_error("sensor: <film type=\"array\"> expected");
         const xnode_t *fw = film->named("width"), *fh = film->named("height");
         if (!fw || !fh) throw std::runtime_error("film: width and height expected");
-        const uint32_t W = (uint32_t)eval_number(fw->get("value")), H = std::max(1u, (uint32_t)eval_number(fh->get("value")));
+        const double Wd = eval_number(fw->get("value")), Hd = eval_number(fh->get("value"));
+        if (!(Wd >= 1.0 && Wd <= 65536.0) || !(Hd >= 0.0 && Hd <= 65536.0)) throw std::runtime_error("film: width / height out of range (1..65536)");
+        const uint32_t W = (uint32_t)Wd, H = std::max(1u, (uint32_t)Hd);
         const xnode_t* resp = film->child("response");
         if (!resp) throw std::runtime_error("film: <response> expected");
         if (resp->get("type") == "monochromatic") {
@@ -1063,9 +1092,8 @@ struct loader_t {
                     if (!sp) throw std::runtime_error("spot emitter: radiant_intensity expected");
                     double scale = 1.0;
                     if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
-                    xnode_t unscaled = *sp;   // the builder takes the scale separately (emitter_t::scale)
-                    unscaled.kids.clear();
-                    const int s = spectrum(unscaled);
+                    const xnode_t unscaled = without_scale(*sp);   // the builder takes the scale separately (emitter_t::scale)
+                                        const int s = spectrum(unscaled, true);
                     if (s == -2) continue;
                     const xnode_t *bw = n.named("beam_width"), *co = n.named("cutoff_angle");
                     if (!co) throw std::runtime_error("spot emitter: cutoff_angle expected");
@@ -1081,9 +1109,8 @@ struct loader_t {
                     if (!sp) throw std::runtime_error("point emitter: radiant_intensity expected");
                     double scale = 1.0;
                     if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
-                    xnode_t unscaled = *sp;
-                    unscaled.kids.clear();
-                    const int s = spectrum(unscaled);
+                    const xnode_t unscaled = without_scale(*sp);
+                                        const int s = spectrum(unscaled, true);
                     if (s == -2) continue;
                     const xnode_t* pos = n.named("position");
                     if (!pos) throw std::runtime_error("point emitter: position expected");
@@ -1098,9 +1125,8 @@ struct loader_t {
                     if (!sp) throw std::runtime_error("directional emitter: irradiance expected");
                     double scale = 1.0;
                     if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
-                    xnode_t unscaled = *sp;   // the builder takes the scale separately (emitter_t::scale)
-                    unscaled.kids.clear();
-                    const int s = spectrum(unscaled);
+                    const xnode_t unscaled = without_scale(*sp);   // the builder takes the scale separately (emitter_t::scale)
+                                        const int s = spectrum(unscaled, true);
                     if (s == -2) continue;
                     const xnode_t* t = n.named("to_world");
                     const xnode_t* la = t ? t->child("lookat") : nullptr;
@@ -1213,9 +1239,8 @@ struct loader_t {
                     if (!sp) throw std::runtime_error("area emitter: radiance expected");
                     double scale = 1.0;
                     if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
-                    xnode_t unscaled = *sp;
-                    unscaled.kids.clear();
-                    const int spec = spectrum(unscaled);
+                    const xnode_t unscaled = without_scale(*sp);
+                                        const int spec = spectrum(unscaled, true);
                     if (spec != -2) {
                         float pse = 1.f;
                         if (const xnode_t* r = em->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));

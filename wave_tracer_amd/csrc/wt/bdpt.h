@@ -20,7 +20,10 @@
 
 namespace wt {
 
-constexpr uint32_t kMaxVerts = 18;       // max_depth(16) + 2
+// Subpath lengths are not bounded at compile time (the reference's max_depth is a plain integer, src/integrator/plt_bdpt.cpp:111,169):
+// vertex stores are sized from the scene's max_depth, the MIS weights stream over the vertices (bdpt_mis_weight).  kMaxVerts only sets the
+// resolution of the device's strategy buckets: strategies with s or t >= kMaxVerts share the last bucket of their row / column.
+constexpr uint32_t kMaxVerts = 18;
 constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
 #ifdef WT_ORACLE_UNBOUNDED
 constexpr uint32_t kMaxEdgeIds = 16384;  // CPU checker: effectively unbounded
@@ -862,6 +865,11 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
 }
 
 // ---- connections -------------------------------------------------------------------------------------------
+// random stream of the (s,t) connection: one per strategy (short subpaths keep the ids of rounds 1-2; longer ones follow behind them)
+WT_HD uint32_t connect_stream(int s, int t) {
+    if (s < 32 && t < 32) return STREAM_CONNECT + (uint32_t)t * 32u + (uint32_t)s;
+    return STREAM_CONNECT + 1024u + (uint32_t)t * 4096u + (uint32_t)s;
+}
 struct connect_ret_t {
     stokes_t L;
     vertex_t temporary_vert;
@@ -905,7 +913,7 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
     ret.L = stokes_zero();
     ret.has_temp = 0;
     ret.has_element = 0;
-    sampler_t smp = make_sampler(seed, sample_id, STREAM_CONNECT + (uint32_t)t * 32u + (uint32_t)s);
+    sampler_t smp = make_sampler(seed, sample_id, connect_stream(s, t));
     if (ctr) ctr->connections++;
 
     if (s == 0) {

@@ -96,7 +96,9 @@ constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose i
 // C — or without (pass B commits the restart)
 constexpr uint32_t kApertureMarker = 0xFFFFFFFDu, kNullApertureMarker = 0xFFFFFFFCu;
 __host__ __device__ inline bool is_region_marker(uint32_t t) { return t == kGatherMarker || t == kApertureMarker; }
-constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;   // connection strategies (s,t), s,t <= max_depth+2
+// connection strategies (s,t) are bucketed by (min(t, kKeyDim-1), min(s, kKeyDim-1)): one bucket per strategy up to 17 vertices per subpath; a
+// bucket of the last row / column holds every longer strategy of its sample (an item of such a bucket loops over them, k_connect_strat)
+constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;
 
 struct device_state_t {
     uint64_t cap = 0;   // samples per batch
@@ -1124,6 +1126,15 @@ __device__ inline bool strategy_valid(const integrator_opts_t& o, int s, int t, 
     if (o.debug_only_t && (int)o.debug_only_t - 1 != t) return false;
     return true;
 }
+// bucket (sk, tk): does it hold a valid strategy of a sample with nS / nT vertices?  (the last row / column stands for every s / t >= kKeyDim-1)
+__device__ inline bool strategy_class_valid(const integrator_opts_t& o, int sk, int tk, int nS, int nT) {
+    const int K = (int)kKeyDim - 1;
+    const int t1 = tk < K ? tk : nT, s1 = sk < K ? sk : nS;
+    for (int t = tk; t <= t1; ++t)
+        for (int s = sk; s <= s1; ++s)
+            if (strategy_valid(o, s, t, nS, nT)) return true;
+    return false;
+}
 __device__ inline int wave_max_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
@@ -1147,9 +1158,11 @@ __global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
         for (int c = 0; c < 4; ++c) a.st.lacc[(size_t)c * a.st.cap + i] = 0.0;
     }
     __syncthreads();
-    for (int t = 0; t <= nT; ++t)
-        for (int s = 0; s <= nS; ++s)
-            if (strategy_valid(a.sc.opts, s, t, nS, nT)) atomicAdd(&s_cnt[(uint32_t)t * kKeyDim + (uint32_t)s], 1u);
+    const int K = (int)kKeyDim - 1;
+    const int kT = nT < K ? nT : K, kS = nS < K ? nS : K;
+    for (int tk = 0; tk <= kT; ++tk)
+        for (int sk = 0; sk <= kS; ++sk)
+            if (strategy_class_valid(a.sc.opts, sk, tk, nS, nT)) atomicAdd(&s_cnt[(uint32_t)tk * kKeyDim + (uint32_t)sk], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < kNumKeys; k += blockDim.x) {
         const uint32_t c = s_cnt[k];
@@ -1157,10 +1170,10 @@ __global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
         s_cnt[k] = 0;
     }
     __syncthreads();
-    for (int t = 0; t <= nT; ++t)
-        for (int s = 0; s <= nS; ++s)
-            if (strategy_valid(a.sc.opts, s, t, nS, nT)) {
-                const uint32_t key = (uint32_t)t * kKeyDim + (uint32_t)s;
+    for (int tk = 0; tk <= kT; ++tk)
+        for (int sk = 0; sk <= kS; ++sk)
+            if (strategy_class_valid(a.sc.opts, sk, tk, nS, nT)) {
+                const uint32_t key = (uint32_t)tk * kKeyDim + (uint32_t)sk;
                 a.st.strat_items[(size_t)key * a.st.cap + s_base[key] + atomicAdd(&s_cnt[key], 1u)] = i;
             }
 }
@@ -1204,7 +1217,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(laun
                     hi = mid;
             }
             const uint32_t key = lo;
-            const int t = (int)(key / kKeyDim), s = (int)(key % kKeyDim);
+            const int tk = (int)(key / kKeyDim), sk = (int)(key % kKeyDim);
             const uint32_t i = a.st.strat_items[(size_t)key * a.st.cap + (idx - s_prefix[key])];
             const uint64_t j = a.j0 + i;
             const uint32_t pix = (uint32_t)(j % a.npix);
@@ -1213,12 +1226,25 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(laun
             sample_ctx_t ctx;
             soa_load(a.st.ctx, kCtxWords, i, ctx);
             const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
-            const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
-            if (t > 1) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
+            // (one strategy per item; the buckets of the last row / column stand for all longer strategies of the sample)
+            const int K = (int)kKeyDim - 1;
+            int t1 = tk, s1 = sk, nT = 0, nS = 0;
+            if (tk == K || sk == K) {
+                nT = (int)a.st.walks[(size_t)i * a.st.walk_words + WT_WALK_NVERTS_WORD];
+                nS = (int)a.st.walks[((size_t)a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
+                if (tk == K) t1 = nT;
+                if (sk == K) s1 = nS;
             }
+            for (int t = tk; t <= t1; ++t)
+                for (int s = sk; s <= s1; ++s) {
+                    if ((tk == K || sk == K) && !strategy_valid(a.sc.opts, s, t, nS, nT)) continue;
+                    const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
+                    if (t > 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
+                    }
+                }
         }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
@@ -1408,7 +1434,6 @@ int wtgpu_scene_create_named_hooks(const char* name, const wtgpu_scene_params* p
         s->stats = s->builder->stats();
         s->lut_power[0] = s->builder->fsd_lut_power(0);
         s->lut_power[1] = s->builder->fsd_lut_power(1);
-        if ((uint32_t)s->host.opts.max_depth + 2 > kMaxVerts) return fail(WTGPU_ERR_INVALID, "max_depth exceeds the compiled vertex capacity (16)");
         *out = s.release();
         return WTGPU_OK;
     } catch (const std::exception& e) {
@@ -1452,7 +1477,6 @@ int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, ui
         }
         wth::build_scene_from_xml(path, defs, p, *s->builder);
         finish_built_scene(s.get());
-        if ((uint32_t)s->host.opts.max_depth + 2 > kMaxVerts) return fail(WTGPU_ERR_INVALID, "max_depth exceeds the compiled vertex capacity (16)");
         *out = s.release();
         return WTGPU_OK;
     } catch (const std::exception& e) {
@@ -1551,7 +1575,6 @@ int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* desc, wtgpu_scene** out
     if (!desc || !out) return fail(WTGPU_ERR_INVALID, "null argument");
     auto s = std::make_unique<wtgpu_scene>();
     std::memcpy(&s->host, desc, sizeof(scene_t));   // identical layouts: scene_abi_check.h
-    if ((uint32_t)s->host.opts.max_depth + 2 > kMaxVerts) return fail(WTGPU_ERR_INVALID, "max_depth exceeds the compiled vertex capacity (16)");
     if (s->host.n_tris > 0 && (!s->host.tri_geo || !s->host.tri_meta || !s->host.tri_shade || !s->host.nodes)) return fail(WTGPU_ERR_INVALID, "scene description lacks geometry arrays");
     s->stats = "{}";
     *out = s.release();
@@ -1685,7 +1708,17 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
 
     // per-batch path state: `n_slices` slices (one internal stream each) that together hold `max_batch` samples in flight
     const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
-    const uint64_t total_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 20);
+    uint64_t total_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 20);
+    {   // the vertex stores grow with max_depth (2 x (max_depth + 2) vertices of 356 B per sample): keep the state of all slices within a budget
+        // (WTGPU_STATE_GB, default 96 of the 288 GB) by shrinking the batches of deep scenes — more, smaller batches, same results
+        const bool pm = h.opts.integrator != INTEGRATOR_BDPT;
+        const uint64_t mv = (uint64_t)h.opts.max_depth + 2;
+        const uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
+        uint64_t budget_gb = 96;
+        if (const char* e = getenv("WTGPU_STATE_GB")) budget_gb = (uint64_t)std::max(1, atoi(e));
+        const uint64_t fit = std::max<uint64_t>(4096, (budget_gb << 30) / per_sample);
+        if (total_cap > fit) total_cap = fit;
+    }
     uint32_t n_slices = 4;
     if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
     n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, total_cap / 64));

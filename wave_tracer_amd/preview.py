@@ -117,7 +117,11 @@ def render_with_preview(scene, spp, preview, seed=1, chunk_spp=8, preview_id="se
             torch.cuda.synchronize(dev)
             v, w, l = (t.cpu().numpy() for t in films)
             per_elem = max(1, done // (scene.width * scene.height))
-            preview.update(preview_id, develop(scene, v, w, l, per_elem).reshape(scene.height, scene.width, -1), force=done == total)
+            img = develop(scene, v, w, l, per_elem)
+            stokes = int(scene.info.stokes)
+            # polarimetric films are [H][W][channels][4 Stokes components]: the viewer shows the intensity plane, like the reference's preview
+            img = img.reshape(scene.height, scene.width, -1, stokes)[..., 0] if stokes > 1 else img.reshape(scene.height, scene.width, -1)
+            preview.update(preview_id, img, force=done == total)
         return 0
 
     scene.render_progressive(*films, 0, spp, seed, chunk_spp=chunk_spp, progress=on_progress, stream=stream)

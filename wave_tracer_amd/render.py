@@ -62,9 +62,22 @@ def _render_shard_hip(scene, begin, end, seed):
     return value, weight, light
 
 
-def render_distributed(scene, spp, seed=1, reduce_dst=0, shard_renderer=None):
+def make_film_comm(device):
+    """The C-ABI's RCCL communicator (wtgpu_comm_*: what a C++ host of the library uses) for the ranks of an initialised
+    torch.distributed job: rank 0 creates the 128-byte id, torch.distributed carries it to the others (any transport would do)."""
+    import torch.distributed as dist
+    from .api import Comm
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return Comm(world, rank, device, box[0])
+
+
+def render_distributed(scene, spp, seed=1, reduce_dst=0, shard_renderer=None, comm=None):
     """One process per GPU (torch.distributed already initialised; backend nccl = RCCL on GPUs).  Each rank renders its
-    sample shard of every pixel into its own film; the films are summed onto `reduce_dst` with one reduce per buffer.
+    sample shard of every pixel into its own film; the films are summed onto `reduce_dst`: with `comm` (make_film_comm) by the
+    C-ABI's wtgpu_film_reduce (one group of three ncclReduce), otherwise by torch.distributed (GPU films go through the host when the
+    backend is gloo: ranks that share a GPU, CPU tests).
     `shard_renderer(scene, begin, end, seed) -> (value, weight, light)` torch tensors is a seam for the CPU (gloo) tests of
     the sharding / reduction logic; the product path is the default (HIP)."""
     import torch
@@ -72,8 +85,15 @@ def render_distributed(scene, spp, seed=1, reduce_dst=0, shard_renderer=None):
     rank, world = dist.get_rank(), dist.get_world_size()
     b, e = shard_samples(spp, rank, world)
     value, weight, light = (shard_renderer or _render_shard_hip)(scene, b, e, seed)
-    for t in (value, weight, light):
-        dist.reduce(t, dst=reduce_dst, op=dist.ReduceOp.SUM)
+    if comm is not None:
+        comm.film_reduce(value, weight, light, root=reduce_dst, stream=torch.cuda.current_stream(value.device).cuda_stream)
+    else:
+        via_host = value.is_cuda and dist.get_backend() == "gloo"
+        if via_host:
+            torch.cuda.synchronize(value.device)
+            value, weight, light = value.cpu(), weight.cpu(), light.cpu()
+        for t in (value, weight, light):
+            dist.reduce(t, dst=reduce_dst, op=dist.ReduceOp.SUM)
     if value.is_cuda:
         torch.cuda.synchronize(value.device)
     if rank == reduce_dst:
