@@ -26,14 +26,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def cpu_baseline(scene_name, res, seconds_target=15.0):
+def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetric=0):
     """CPU checker (oracle/, kind 'port') timed on the host cores on a bounded sample of the SAME workload: every n-th
     24x24 block of the same full-size film (same pixel pitch => same beam footprints and per-sample work), for about
     `seconds_target` seconds.  Only rank 0 at N=1 runs this."""
     from wave_tracer_amd.api import Scene
     from oracle_util import oracle_render_tiles
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    sc = Scene(scene_name, res=res, mesh_detail=1)
+    sc = Scene(scene_name, res=res, mesh_detail=mesh_detail, polarimetric=polarimetric)
     n_tiles = ((sc.width + 23) // 24) * ((sc.height + 23) // 24)
     # work unit of the checker = one 24x24 block (the reference's block size): keep >= 4 blocks per core in flight
     stride = max(1, n_tiles // (4 * cores))
@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--res", type=int, default=1440)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
+    ap.add_argument("--mesh-detail", type=int, default=-1, help="stand-in geometry level (default: 1 for the cornell box = SURVEY 8(d) C1/C3's 283 K triangles; 2 for "
+                    "etoile / bidir_room = C4's ~560 seeded buildings, C5's ~50 objects and 34 materials)")
+    ap.add_argument("--polarimetric", type=int, default=-1, help="Stokes film (default: on for bidir_room = BASELINE.json configs[4])")
     ap.add_argument("--ray-tracing", action="store_true", help="diagnostic: --ray-tracing of the reference CLI (wt_context.hpp:43), no cones / diffraction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -106,7 +109,9 @@ def main():
         # C++ host would call); torch.distributed only carries the communicator id and the barriers
         from wave_tracer_amd.render import make_film_comm
         comm = make_film_comm(local_rank)
-    sc = Scene(args.scene, res=args.res, mesh_detail=1, force_ray_tracing=1 if args.ray_tracing else 0)
+    md = args.mesh_detail if args.mesh_detail >= 0 else (2 if args.scene in ("etoile", "bidir_room") else 1)
+    pol = args.polarimetric if args.polarimetric >= 0 else (1 if args.scene == "bidir_room" else 0)
+    sc = Scene(args.scene, res=args.res, mesh_detail=md, polarimetric=pol, force_ray_tracing=1 if args.ray_tracing else 0)
     npix = sc.width * sc.height
     sc.upload(local_rank, args.batch or npix)
     value, weight, light = alloc_films(sc, dev)
@@ -167,7 +172,7 @@ def main():
         n_conn = counters["connections"] / ns
         n_q = (counters["ray_queries"] + counters["cone_queries"] + counters["shadow_rays"]) / ns
         n_light = counters["light_splats"] / ns
-        C = sc.channels
+        C = sc.channels   # film planes per pixel (spectral channels x Stokes components)
         S_path = 200.0    # mean of backward (224 B) and forward (176 B) walk records
         S_vtx, S_hit = 320.0, 32.0
         b_film = 2 * (9 * C * 16) + n_light * 2 * (9 * C * 8)
@@ -236,7 +241,7 @@ def main():
                                     "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.cpu_seconds, md, pol)
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -339,6 +339,41 @@ static void build_room(const scene_params_t& p, scene_builder_t& b) {
     // back plane the pattern falls on (z = 0 .. the XML's target): a white card
     box(sx - 1.2, sx + 1.2, sy - 1.2, sy + 1.2, -.05, 0, m_diffuse);
 
+    if (p.mesh_detail >= 2) {
+        // "box room + ~50 procedural objects (seeded) with room.xml's material table (21 diffuse / 9 surface_spm / 4
+        // dielectric)".  27 further objects (24 above make ~50) scattered over the free floor, the table top and the shelf, shapes and materials
+        // drawn from a fixed-seed generator; the materials complete the table: 21 diffuse, 9 rough / smooth conductors, 4 glasses.
+        uint32_t rs = 0x5EEDu;
+        auto rnd = [&]() {   // xorshift32, U[0,1)
+            rs ^= rs << 13;
+            rs ^= rs >> 17;
+            rs ^= rs << 5;
+            return double(rs >> 8) * (1.0 / 16777216.0);
+        };
+        std::vector<int> mats = {m_room, m_diffuse, m_wood, m_plastic, m_dark, m_black};   // 6 of the 21 diffuse
+        for (int i = 0; i < 15; ++i) mats.push_back(b.add_material(mat_diffuse(b.spectrum_rgb((float)(.08 + .8 * rnd()), (float)(.08 + .8 * rnd()), (float)(.08 + .8 * rnd())), 1.f, true)));
+        static const char* metals[3] = {"Al", "Au", "Cu"};
+        mats.push_back(m_screen);
+        for (int i = 0; i < 8; ++i) mats.push_back(b.add_material(mat_spm(b.spectrum_named(metals[i % 3]), i % 4 != 3, (float)(.02 + .3 * rnd()), 3.f, true, 1.f)));
+        static const char* glasses[4] = {"BK7", "SF5", "SF11", "BK7"};
+        for (int i = 0; i < 4; ++i) mats.push_back(b.add_material(mat_dielectric(b.spectrum_named(glasses[i]))));
+        for (int i = 0; i < 27; ++i) {
+            // free floor: x in [1.5, 12], z in [-6, 6] (camera at x = 12 looks towards -x: everything in view), a few on the table top (y = 1.7)
+            const bool on_table = i % 9 == 8;
+            const double x = on_table ? -4.6 + 4.2 * rnd() : 1.5 + 9.5 * rnd(), z = on_table ? -1.6 + 3.4 * rnd() : -6.0 + 12.0 * rnd(), y0 = on_table ? 1.7 : 0.0;
+            const double sz = (on_table ? .18 : .35) + (on_table ? .3 : .9) * rnd();
+            const int mat = mats[(size_t)(rnd() * mats.size()) % mats.size()];
+            const int kind = i % 4;
+            if (kind == 0)
+                box(x - sz / 2, x + sz / 2, y0, y0 + sz * (.6 + rnd()), z - sz / 2, z + sz / 2, mat);
+            else if (kind == 1)
+                b.add_shape(mesh_cylinder({x * cm, y0 * cm, z * cm}, {x * cm, (y0 + sz * (.8 + rnd())) * cm, z * cm}, sz / 2 * cm, 32), xform_t::identity(), mat);
+            else if (kind == 2)
+                b.add_shape(mesh_blob(sz / 2 * cm, 3, .08 + .1 * rnd(), 5 + (int)(4 * rnd()), 100u + (uint32_t)i), xform_t::translate(x * cm, (y0 + sz / 2) * cm, z * cm), mat);
+            else
+                b.add_shape(mesh_prism(sz * cm, sz * (.7 + .6 * rnd()) * cm, deg(40 + 30 * rnd())), xform_t::translate(x * cm, y0 * cm, z * cm) * xform_t::rotate(0, 1, 0, deg(360 * rnd())), mat);
+        }
+    }
     const int cfl = b.spectrum_named("CFL2534");
     const xform_t spot = xform_t::lookat({sx * cm, sy * cm, 3.4 * cm}, {sx * cm, sy * cm, 0}, {0, 1, 0});
     b.add_emitter_spot(spot, cfl, 3e2f, (float)deg(.4), (float)deg(.2), -1.f, .25f);
@@ -600,6 +635,32 @@ static void build_etoile(const scene_params_t& p, scene_builder_t& b, bool open_
     box(0, 0, 49, 49.6, 44, 20, 0, m_metal);
     box(-16, -11.2, 0, 4, 3, .4, 0, m_wood);
     box(16, 11.2, 0, 4, 3, .4, 0, m_wood);
+    if (p.mesh_detail >= 2) {
+        // "ground plane 840 m x 630 m + N ~ 560 extruded-box buildings (seeded layout, seed 0x5EED) with the 5 ITU composite
+        // materials".  The twelve blocks between the avenues are cut into 12 x 4 lots each (576 buildings + the arch): footprints inset by a
+        // random street margin, heights 12..45 m, every building its own wall material and a metal roof slab on every third.
+        uint32_t rs = 0x5EEDu;
+        auto rnd = [&]() {
+            rs ^= rs << 13;
+            rs ^= rs >> 17;
+            rs ^= rs << 5;
+            return double(rs >> 8) * (1.0 / 16777216.0);
+        };
+        const int walls[5] = {m_concrete, m_marble, m_metal, m_brick, m_wood};
+        for (int i = 0; i < 12; ++i) {
+            const double ang = 22.5 + 30.0 * i;
+            for (int gx = 0; gx < 12; ++gx)
+                for (int gy = 0; gy < 4; ++gy) {
+                    const double lot = 15.0, margin = .5 + 1.5 * rnd();
+                    const double cx = 150.0 + lot * (gx + .5), cy = -30.0 + lot * (gy + .5);
+                    const double hgt = 12.0 + 33.0 * rnd();
+                    const int wall = walls[(int)(rnd() * 5) % 5];
+                    box(cx, cy, -1, hgt, lot - 2 * margin, lot - 2 * margin, ang, wall);
+                    if ((gx + gy) % 3 == 0) box(cx, cy, hgt, hgt + .4, lot - 2 * margin - 1, lot - 2 * margin - 1, ang, m_metal);
+                }
+        }
+        return;
+    }
     // twelve blocks between the avenues (avenue centres at 7.5 deg + 30 deg i; the transmitter stands in the one at 67.5 deg)
     const int n_bays = p.mesh_detail > 0 ? 6 : 0;
     for (int i = 0; i < 12; ++i) {

@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -88,17 +89,20 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 // control block of one state slice (device memory)
-enum : uint32_t { CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 24 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
+enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 28 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 // ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
 // C — or without (pass B commits the restart)
 constexpr uint32_t kApertureMarker = 0xFFFFFFFDu, kNullApertureMarker = 0xFFFFFFFCu;
 __host__ __device__ inline bool is_region_marker(uint32_t t) { return t == kGatherMarker || t == kApertureMarker; }
-// connection strategies (s,t) are bucketed by (min(t, kKeyDim-1), min(s, kKeyDim-1)): one bucket per strategy up to 17 vertices per subpath; a
+// connection strategies (s,t) are bucketed by (min(t, kKeyDim-1), min(s, kKeyDim-1)): one bucket per strategy up to 18 vertices per subpath; a
 // bucket of the last row / column holds every longer strategy of its sample (an item of such a bucket loops over them, k_connect_strat)
-constexpr uint32_t kKeyDim = kMaxVerts + 1, kNumKeys = kKeyDim * kKeyDim;
+// (kMaxVerts + 2: up to max_depth = 16 — 18 vertices per subpath — every strategy has its own bucket and k_connect_strat_open is not launched;
+// launching it for nothing cost 35 % of a pass with four streams: a 256-register, 22-KB-LDS grid that waits for free CUs holds up the other
+// streams' dispatches)
+constexpr uint32_t kKeyDim = kMaxVerts + 2, kNumKeys = kKeyDim * kKeyDim;
 
 struct device_state_t {
     uint64_t cap = 0;   // samples per batch
@@ -173,6 +177,7 @@ struct wtgpu_scene {
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, lane_cache = 1, heavy_cache = 1, split_queues = 1;
+        uint32_t shrink_r1 = 6, shrink_f1 = 4, shrink_r2 = 12, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
     } knobs;
@@ -605,7 +610,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
 // null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
 // No BVH query happens in these passes (the trace kernels resolved the primary triangle): they carry no traversal stack.
 template <int PASS>
-__device__ inline void interact_body(const launch_args_t& a, int in, int first_round) {
+__device__ inline __attribute__((always_inline)) void interact_body(const launch_args_t& a, int in, int first_round) {
     constexpr bool PASS_B = PASS == 1;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : queue_count(ctl, in);
@@ -865,7 +870,7 @@ constexpr uint32_t kStageSegs = 256;
 #define WTGPU_HARD_BLOCK 256
 #endif
 template <int BLOCK>
-__device__ inline void interact_c_body(const launch_args_t& a, int in) {
+__device__ inline __attribute__((always_inline)) void interact_c_body(const launch_args_t& a, int in) {
     constexpr bool HARD = BLOCK > 64;
     __shared__ uint32_t s_item;
     __shared__ uint32_t s_tmin;
@@ -1188,12 +1193,28 @@ __global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
         }
         a.st.strat_prefix[kNumKeys] = acc;
         a.st.ctl[CTL_STRAT_HEAD] = 0;
+        a.st.ctl[CTL_STRAT_HEAD_OPEN] = 0;
     }
 }
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(launch_args_t a) {
+// OPEN = false: the buckets with one strategy each (all of them while no subpath exceeds 17 vertices).  OPEN = true (k_connect_strat_open): the
+// buckets of the last row / column, whose items loop over every longer strategy of their sample — a kernel of its own so that the loop and
+// the subpath lengths it needs do not weigh on the common case's registers.
+template <bool OPEN>
+__device__ inline __attribute__((always_inline)) void connect_strat_body(const launch_args_t& a) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     __shared__ uint32_t s_prefix[kNumKeys + 1];
-    for (uint32_t k = threadIdx.x; k <= kNumKeys; k += blockDim.x) s_prefix[k] = a.st.strat_prefix[k];
+    constexpr int K = (int)kKeyDim - 1;
+    // flattened item space: OPEN = false all buckets (items of the open ones are skipped), OPEN = true the open buckets only
+    if (!OPEN) {
+        for (uint32_t k = threadIdx.x; k <= kNumKeys; k += blockDim.x) s_prefix[k] = a.st.strat_prefix[k];
+    } else if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < kNumKeys; ++k) {
+            s_prefix[k] = acc;
+            if ((int)(k / kKeyDim) == K || (int)(k % kKeyDim) == K) acc += a.st.strat_prefix[k + 1] - a.st.strat_prefix[k];
+        }
+        s_prefix[kNumKeys] = acc;
+    }
     __syncthreads();
     const uint32_t total = s_prefix[kNumKeys];
     bdpt_counters_t ctr;
@@ -1201,10 +1222,9 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(laun
     stack_entry_t spill[kSpillStack];
     stack_ref_t stack;
     lds_stack(lds, spill, stack);
-    const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap, a.st.ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
-        const uint32_t idx = wave_grab(a.st.ctl + CTL_STRAT_HEAD) + (threadIdx.x & 63);
+        const uint32_t idx = wave_grab(a.st.ctl + (OPEN ? CTL_STRAT_HEAD_OPEN : CTL_STRAT_HEAD)) + (threadIdx.x & 63);
         if (idx - (threadIdx.x & 63) >= total) break;
         if (idx < total) {
             // bucket of this item: last key with prefix <= idx
@@ -1218,6 +1238,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(laun
             }
             const uint32_t key = lo;
             const int tk = (int)(key / kKeyDim), sk = (int)(key % kKeyDim);
+            if (!OPEN && (tk == K || sk == K)) continue;   // (k_connect_strat_open's)
             const uint32_t i = a.st.strat_items[(size_t)key * a.st.cap + (idx - s_prefix[key])];
             const uint64_t j = a.j0 + i;
             const uint32_t pix = (uint32_t)(j % a.npix);
@@ -1226,29 +1247,30 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(laun
             sample_ctx_t ctx;
             soa_load(a.st.ctx, kCtxWords, i, ctx);
             const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
-            // (one strategy per item; the buckets of the last row / column stand for all longer strategies of the sample)
-            const int K = (int)kKeyDim - 1;
-            int t1 = tk, s1 = sk, nT = 0, nS = 0;
-            if (tk == K || sk == K) {
-                nT = (int)a.st.walks[(size_t)i * a.st.walk_words + WT_WALK_NVERTS_WORD];
-                nS = (int)a.st.walks[((size_t)a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
-                if (tk == K) t1 = nT;
-                if (sk == K) s1 = nS;
-            }
-            for (int t = tk; t <= t1; ++t)
-                for (int s = sk; s <= s1; ++s) {
-                    if ((tk == K || sk == K) && !strategy_valid(a.sc.opts, s, t, nS, nT)) continue;
-                    const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
-                    if (t > 1) {
+            auto one = [&](int s, int t) __attribute__((always_inline)) {
+                const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
+                if (t > 1) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
                 }
+            };
+            if constexpr (!OPEN) {
+                one(sk, tk);
+            } else {
+                const int nT = (int)a.st.walks[(size_t)i * a.st.walk_words + WT_WALK_NVERTS_WORD];
+                const int nS = (int)a.st.walks[((size_t)a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
+                const int t1 = tk == K ? nT : tk, s1 = sk == K ? nS : sk;
+                for (int t = tk; t <= t1; ++t)
+                    for (int s = sk; s <= s1; ++s)
+                        if (strategy_valid(a.sc.opts, s, t, nS, nT)) one(s, t);
+            }
         }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(launch_args_t a) { connect_strat_body<false>(a); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat_open(launch_args_t a) { connect_strat_body<true>(a); }
 __global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.nb) return;
@@ -1636,6 +1658,13 @@ static void read_knobs(wtgpu_scene* s) {
     k.cone_budget = u("WTGPU_CONE_BUDGET", kConeBudget);
     k.count_stats = u("WTGPU_COUNT_STATS", 1);
     k.split_queues = u("WTGPU_SPLIT_QUEUES", 1);
+    k.shrink_r1 = u("WTGPU_SHRINK_R1", k.shrink_r1);
+    k.shrink_f1 = std::max(1u, u("WTGPU_SHRINK_F1", k.shrink_f1));
+    k.shrink_r2 = u("WTGPU_SHRINK_R2", k.shrink_r2);
+    k.shrink_f2 = std::max(1u, u("WTGPU_SHRINK_F2", k.shrink_f2));
+    k.shrink_h1 = std::max(1u, u("WTGPU_SHRINK_H1", k.shrink_h1));
+    k.decay_q = u("WTGPU_DECAY_Q", k.decay_q);   // per cent; 0: the step schedule above
+    k.decay_c = std::max(1u, u("WTGPU_DECAY_C", k.decay_c));
     k.lane_cache = u("WTGPU_LANE_CACHE", 1);
     k.heavy_cache = u("WTGPU_HEAVY_CACHE", 1);
     k.trace_refill = u("WTGPU_TRACE_REFILL", 1);   // 0: the per-lane trace kernel without lane refill (A/B reference)
@@ -1910,9 +1939,18 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
             // the queue roughly halves every round and is normally empty after ~25: later rounds get smaller persistent grids
             // (an empty launch costs its grid size; a grid that turns out too small only takes longer, the wavefronts loop)
-            const uint32_t shrink = round < 6 ? 1u : (round < 24 ? 4u : 32u);
-            const uint32_t g0 = std::max<uint32_t>(1u, g_full / shrink);
-            const uint32_t gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < 24 ? 1u : 32u));
+            uint32_t g0, gh;
+            if (K.decay_q > 0) {
+                // geometric schedule: the queue of round r holds ~ N q^r walks (q ~ 0.55 in the headline workload); grids follow with a safety
+                // factor — an undersized persistent grid only takes longer, an oversized one on a short queue holds up the other streams
+                const double f = std::min(1.0, (double)K.decay_c * std::pow(K.decay_q * .01, (double)round));
+                g0 = std::max<uint32_t>(2u, (uint32_t)(g_full * f));
+                gh = std::max<uint32_t>(2u, (uint32_t)(std::min<uint32_t>(grid_heavy, walks_per_sample * nb) * f));
+            } else {
+                const uint32_t shrink = round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_f1 : K.shrink_f2);
+                g0 = std::max<uint32_t>(1u, g_full / shrink);
+                gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
+            }
             if (dbg_stage >= 2 + 3 * (int)round) {
                 if (K.trace_refill)
                     hipLaunchKernelGGL(k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
@@ -1948,6 +1986,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             hipLaunchKernelGGL(k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
             hipLaunchKernelGGL(k_connect_scan, dim3(1), dim3(64), 0, st_, a);
             hipLaunchKernelGGL(k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
+            if ((uint32_t)h.opts.max_depth + 2 >= kKeyDim - 1) hipLaunchKernelGGL(k_connect_strat_open, dim3(std::max<uint32_t>(1u, g_full / 8u)), dim3(kBlock), 0, st_, a);
             hipLaunchKernelGGL(k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         }
         HIP_CHECK(hipGetLastError());
