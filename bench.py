@@ -49,6 +49,53 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
                       f"({n} samples, {dt:.1f}s), {cores} threads; scalar fp32 restatement (oracle/), baseline only"}
 
 
+def measure_traffic(kernel, scene_args, timeout_s=240):
+    """HBM-side bytes per launch of `kernel` measured NOW, on this box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, with
+    --kernel-trace only) over one step of the same workload in a child process, summed over the kernel's dispatches and scaled to bytes with the
+    calibration of profiles/r03_calib.json (a streaming copy of known size with this code's access width, tools/profile_round.sh: the counters read
+    KiB; FETCH_SIZE under-reports by 2 on gfx950, MI355X_MICROARCH.md).  Returns (bytes_per_launch, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not found"
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_calib.json")) as f:
+            cal = json.load(f)
+        kf, kw = float(cal["fetch_factor"]), float(cal["write_factor"])
+    except (OSError, KeyError, ValueError):
+        kf, kw = 2.0, 1.0     # the values every calibration so far gave (profiles/r01..r03)
+    tot = {}
+    n_disp = 0
+    for counter, k in (("FETCH_SIZE", kf), ("WRITE_SIZE", kw)):
+        d = tempfile.mkdtemp(prefix="wtgpu_pmc_")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-traffic"] + scene_args
+            r = subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR=d), capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            s, ids = 0.0, set()
+            for fn in files:
+                with open(fn) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter and (kernel + "_") not in row["Kernel_Name"]:
+                            s += float(row["Counter_Value"])
+                            ids.add((fn, row["Dispatch_Id"]))
+            tot[counter] = s * 1024.0 * k
+            n_disp = max(n_disp, len(ids))
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, f"rocprofv3 --pmc {counter}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if not n_disp:
+        return None, "kernel not found in the counter collection"
+    return (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / n_disp, {"fetch_bytes": tot["FETCH_SIZE"], "write_bytes": tot["WRITE_SIZE"], "dispatches": n_disp, "fetch_factor": kf, "write_factor": kw}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +110,7 @@ def main():
     ap.add_argument("--polarimetric", type=int, default=-1, help="Stokes film (default: on for bidir_room = BASELINE.json configs[4])")
     ap.add_argument("--ray-tracing", action="store_true", help="diagnostic: --ray-tracing of the reference CLI (wt_context.hpp:43), no cones / diffraction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live PMC measurement of roofline.traffic (two rocprofv3 passes over one step, ~20 s)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="film reduce: nccl = RCCL over xGMI (one GPU per rank); gloo: host reduce, ranks may share a GPU (launcher tests on 1-GPU boxes)")
@@ -192,7 +240,7 @@ def main():
                  "k_edges+k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_flux_split+k_flux_tasks": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_c": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
         # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once): `launches`
-        # is the count rocprofv3 --kernel-trace --stats averages over (profiles/r02_kernel_stats_*.csv), `launches_with_work` the rounds
+        # is the count rocprofv3 --kernel-trace --stats averages over (profiles/r03_kernel_stats_*.csv), `launches_with_work` the rounds
         # that had walks queued.  achieved = algorithmic bytes / the kernel's HIP-event time: the same for either count.
         rounds = 96 * tsum["batches"]
         launches = {"k_connect": tsum["batches"], "k_generate": tsum["batches"]}.get(dom, rounds)
@@ -203,17 +251,25 @@ def main():
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # whole path: all algorithmic bytes of a step over the wall time of a step
         whole = bytes_per_sample * npix * s_rank / (dt / K) / 1e9
-        # HBM traffic of that kernel from the PMC passes of the same command (tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
-        # separate rocprofv3 --pmc runs, summary committed under profiles/), per launch like `achieved`
-        traffic = None
-        try:
-            # (one PMC summary per profiled workload: the headline cornell box and the etoile plt_path stand-in)
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json" if args.scene != "etoile" else "r02_pmc_traffic_etoile.json")) as f:
-                pt = json.load(f)
-            if dom in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
-                traffic = pt["kernels"][dom]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM traffic of that kernel, per launch like `achieved`: measured live (measure_traffic: two rocprofv3 --pmc passes over one step of this
+        # workload, on this box, in child processes after the timed region); if rocprofv3 is unavailable, the summary committed under profiles/
+        traffic, traffic_src = None, None
+        if world == 1 and not args.no_traffic:
+            kname = {"k_trace": "k_trace_refill" if os.environ.get("WTGPU_TRACE_REFILL", "1") != "0" else "k_trace", "k_connect": "k_connect_strat", "k_edges+k_interact_b": "k_interact_b",
+                     "k_flux_split+k_flux_tasks": "k_flux_tasks"}.get(dom, dom)
+            scene_args = ["--scene", args.scene, "--res", str(args.res), "--mesh-detail", str(md), "--polarimetric", str(pol)] + (["--ray-tracing"] if args.ray_tracing else [])
+            traffic, detail = measure_traffic(kname, scene_args)
+            traffic_src = {"measured": "live, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one step", "kernel": kname, **detail} if traffic is not None else {"measured": None, "reason": detail}
+        if traffic is None:
+            try:
+                with open(os.path.join(ROOT, "profiles", {"etoile": "r03_pmc_traffic_etoile.json", "bidir_room": "r03_pmc_traffic_bidir_room.json"}.get(args.scene, "r03_pmc_traffic.json"))) as f:
+                    pt = json.load(f)
+                kk = {"k_trace": "k_trace_refill"}.get(dom, dom)
+                if kk in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
+                    traffic = pt["kernels"][kk]["hbm_bytes_per_launch"]
+                    traffic_src = dict(traffic_src or {}, fallback="profiles/" + os.path.basename(f.name))
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             "metric": ("Msamples/sec (whole node), cornell-box 1440^2 wave-mode" if (args.scene, args.res) == ("cornell_box", 1440)
                        else f"Msamples/sec (whole node), {args.scene} res={args.res}"),
@@ -227,14 +283,14 @@ def main():
                        "samples_per_step": npix * S, "tris": int(sc.info.n_tris),
                        "emitter_selection": ", ".join(f"{e['type']} {e['select_pmf']:.4g}" for e in sc.emitter_summary()),
                        "parallelism": f"sample-sharded x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "launches_with_work": with_work,
                          "avg_launch_ms_with_work": kernels[dom] / max(1, with_work),
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "alg_bytes_per_sample_all_kernels": bytes_per_sample,
                          "whole_path": {"alg_bytes_per_step": bytes_per_sample * npix * s_rank, "achieved": whole, "frac": whole / 8000.0},
                          # HIP-event brackets on the 4 concurrent slice streams: each includes the time the kernel shares the GPU with the
-                         # other streams' kernels, so the sum exceeds ms_per_step (exclusive times: profiles/r02_kernel_stats_streams1.csv)
+                         # other streams' kernels, so the sum exceeds ms_per_step (exclusive times: profiles/r03_kernel_stats_streams1.csv)
                          "kernel_ms_per_step_stream_summed": {k: v / K for k, v in kernels.items()}},
             "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,
                                     "cone_tri_overflow": counters["cone_tri_overflow"] / ns, "fsd_interactions": counters["fsd_interactions"] / ns,

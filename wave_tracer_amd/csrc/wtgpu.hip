@@ -74,7 +74,7 @@ constexpr int kBlock = 128;
 #define WTGPU_LDS_STACK 20
 #endif
 constexpr int kLdsStack = WTGPU_LDS_STACK;   // LDS-resident stack entries per lane
-constexpr uint32_t kConeBudget = 32;     // work units (1 per cone-triangle test, 2 per node) one lane may spend on a cone query before it is handed to a wavefront (swept 4..160 after the axis bound: 12 / 20 / 28 / 32 / 48 / 64 / 96 -> 211 / 192 / 181 / 183 / 189 / 196 / 207 ms per pass)
+constexpr uint32_t kConeBudget = 64;     // work units (1 per cone-triangle test, 2 per node) one lane may spend on a cone query before it is handed to a wavefront (with lane refill, round 3: 32 / 48 / 64 / 96 / 128 -> 14.6 / 14.8 / 15.2 / 14.4 / 12.8 Msamples/s; round 2's kernel without refill: optimum 28-32)
 constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 thread_local std::string g_err;
