@@ -753,6 +753,341 @@ void sample(ctx_t& c, uint32_t px, uint32_t py, double* value, double* weight, d
     prim_film_splat(c.sc, value, weight, light, &g.element, f, g.k, 0);
 }
 
+
+// ====================================================================================================================================
+// plt_path — the unidirectional integrator (forward from the emitters / backward from the sensor), restated a second time from
+// include/wt/integrator/plt_path/plt_path_detail.hpp: path_walk_data_t (:33-143), the interaction samplers (:152-242), find_closest_triangle
+// (:256-280), MIS and do_fsd (:303-346), nee_backward / emission (:349-472), nee_forward / sensing (:474-549), random_walk (:551-770) and
+// integrate_backward / integrate_forward (:772-828).  Recursion and optionals like the reference, not the explicit walk state of wt/path.h.
+struct path_ctx_t {
+    const void* sc;
+    int max_depth, RR, FSD;
+    bool backward, virtual_sensor, force_rt;
+    uint64_t seed, sid;
+    uint32_t stream;
+    double *value, *weight, *light;
+    unsigned long long ctr[8] = {0};   // segments, -, connections, surface, fsd apertures, null, light splats, -
+};
+struct path_walk {
+    prim_beam beam;
+    prim_geo prev_geo;             // prev_vert_geo
+    bool has_prev_beam = false;
+    prim_beam prev_beam;           // prev_vert_beam
+    bool sampled_fsd = false;
+    float from_previous_dpd;       // tagged; starts as discrete(0)
+    bool has_fsd = false;          // fsd_bsdf != nullptr (the aperture itself lives behind prims.h)
+    double throughput = 1;
+    uint32_t draws = 0;
+    float k, recp_spectral_pd;
+};
+prim_geo geo_point(const float p[3]) { return prim_geo{0, {p[0], p[1], p[2]}, {0, 0, 1}, 0xFFFFFFFFu}; }
+prim_geo geo_surface(const prim_surface& s) {
+    prim_geo g;
+    g.kind = 1;
+    float ns[3];
+    uint32_t shape;
+    prim_surface_info(&s, g.wp, g.ng, ns, &g.id, &shape);
+    return g;
+}
+struct cpair {
+    double ts_re = 0, ts_im = 0, th_re = 0, th_im = 0;
+};
+// do_fsd (plt_path_detail.hpp:311-346): coherent sum of the wedges' diffracted fields (+ the direct path when the destination lies in the cone)
+cpair do_fsd(path_ctx_t& c, const prim_beam& cone_from_src, const prim_geo& src_geo, const float dst[3], uint32_t n_wedges, float k) {
+    float src[3], d3[3], kk, inten;
+    int tr;
+    prim_beam_info(&cone_from_src, src, d3, &kk, &tr, &inten);
+    const prim_geo dst_geo = geo_point(dst);
+    cpair r;
+    for (uint32_t i = 0; i < n_wedges; ++i) {
+        prim_utd_term f;
+        prim_utd_f_edge(c.sc, i, src, dst, &f);
+        if (!f.valid) continue;
+        prim_geo eintr{2, {f.p[0], f.p[1], f.p[2]}, {0, 0, 1}, f.edge};
+        if (prim_shadow_geo(c.sc, &eintr, &src_geo) || prim_shadow_geo(c.sc, &eintr, &dst_geo)) continue;
+        // phase = exp(-i k d)  (single precision like the reference's c_t; the products below in double)
+        const float arg = -prim_k_times_length(k, f.ro + f.ri);
+        const double pr = std::cos(arg), pi = std::sin(arg);
+        r.ts_re += pr * f.Ds[0] - pi * f.Ds[1];
+        r.ts_im += pr * f.Ds[1] + pi * f.Ds[0];
+        r.th_re += pr * f.Dh[0] - pi * f.Dh[1];
+        r.th_im += pr * f.Dh[1] + pi * f.Dh[0];
+    }
+    if (prim_cone_contains(&cone_from_src, dst) && !prim_shadow_geo(c.sc, &src_geo, &dst_geo)) {
+        const V3 dv = from(dst) - from(src);
+        const float arg = -prim_k_times_length(k, (float)std::sqrt(len2(dv)));
+        r.ts_re += std::cos(arg);
+        r.ts_im += std::sin(arg);
+        r.th_re += std::cos(arg);
+        r.th_im += std::sin(arg);
+    }
+    return r;
+}
+double power_mis(double pd1, double pd2) { return pd2 == 0 ? 1.0 : pd1 * pd1 / (pd1 * pd1 + pd2 * pd2); }
+
+void path_random_walk(path_ctx_t& c, path_walk& w, double L[4], int depth, int guard, uint32_t& n_wedges) {
+    if (guard >= 96) return;   // the checker's iteration cap
+    prim_trav tr;
+    prim_trace(c.sc, &w.beam, w.prev_geo.kind == 1 ? w.prev_geo.id : 0xFFFFFFFFu, w.prev_geo.ng, &tr);
+    c.ctr[0]++;
+    if (tr.empty) return;
+    float bo[3], bd[3], kk, inten;
+    int transport;
+    prim_beam_info(&w.beam, bo, bd, &kk, &transport, &inten);
+    const float k = kk;
+    const bool ballistic = tr.ballistic || prim_beam_is_ray(&w.beam);
+    float iwp[3];
+    for (int a = 0; a < 3; ++a) iwp[a] = tr.origin[a] + tr.dist * bd[a];
+
+    // ---- evaluate fsd from the previous interaction (:616-636)
+    if (w.has_fsd) {
+        const cpair fsd = do_fsd(c, w.prev_beam, w.prev_geo, iwp, n_wedges, k);
+        w.has_fsd = false;
+        const float f = (float)(((fsd.ts_re * fsd.ts_re + fsd.ts_im * fsd.ts_im) + (fsd.th_re * fsd.th_re + fsd.th_im * fsd.th_im)) / 2.0);
+        if (w.sampled_fsd)
+            prim_beam_scale(&w.beam, f);
+        else {
+            float po[3], pd[3], pk, pint;
+            int ptr;
+            prim_beam_info(&w.prev_beam, po, pd, &pk, &ptr, &pint);
+            const V3 dv = from(tr.origin) - from(po);
+            prim_beam_transform_region(&w.prev_beam, tr.origin, (float)std::sqrt(len2(dv)), bd, f);
+            prim_beam_add(&w.beam, &w.prev_beam);
+        }
+    }
+
+    // ---- the triangle under the interaction point (:639-681)
+    primary_t prim;
+    if (ballistic) {
+        prim.found = true;
+        prim.tuid = tr.tuid;
+        prim.dist = tr.dist;
+        prim.bary[0] = tr.bx;
+        prim.bary[1] = tr.by;
+    } else {
+        ctx_t dummy;
+        dummy.sc = c.sc;
+        prim = find_primary(dummy, tr, bd);
+    }
+    const float region_end = prim.found ? prim.dist : tr.dist;
+    prim_surface srf;
+    int material = -1, emitter_of_shape = -1;
+    if (prim.found) {
+        float swp[3];
+        for (int a = 0; a < 3; ++a) swp[a] = tr.origin[a] + prim.dist * bd[a];
+        prim_surface_at(c.sc, &w.beam, prim.tuid, prim.bary, swp, tr.dist, &srf, &material, &emitter_of_shape);
+    }
+
+    // ---- classified edges: of the region's triangles, or (ballistic hit of a beam) of a cone query around the hit (:593, 645-650, 684-689)
+    std::vector<uint32_t> eids;
+    uint32_t n_list = 0;
+    bool have_list = false;
+    if (c.FSD && !ballistic) {
+        n_list = tr.ntris;
+        have_list = true;
+    } else if (ballistic && !prim_beam_is_ray(&w.beam) && !c.force_rt) {
+        n_list = prim_ballistic_region(c.sc, &w.beam, tr.dist);
+        have_list = true;
+        c.ctr[7]++;
+    }
+    if (have_list) {
+        for (uint32_t i = 0; i < n_list; ++i) {
+            uint32_t e[3];
+            prim_tri_edges(c.sc, prim_trav_tri(i), e);
+            for (int q = 0; q < 3; ++q)
+                if (e[q] != 0xFFFFFFFFu) eids.push_back(e[q]);
+        }
+        std::sort(eids.begin(), eids.end());
+        eids.erase(std::unique(eids.begin(), eids.end()), eids.end());
+    }
+    // ---- construct the fsd BSDF (:692-709)
+    if (!eids.empty()) {
+        n_wedges = prim_utd_build(c.sc, &w.beam, iwp, tr.dist, eids.data(), (uint32_t)eids.size());
+        w.has_fsd = n_wedges > 0;
+        c.ctr[4]++;
+    }
+
+    // ---- next-event estimation
+    if (c.backward && depth < c.max_depth && prim.found && !prim_material_is_delta_only(c.sc, material, k)) {
+        // nee_backward (:349-425)
+        float swp[3], g[3], sn[3];
+        uint32_t tuid, shape;
+        prim_surface_info(&srf, swp, g, sn, &tuid, &shape);
+        prim_edirect ds;
+        prim_sample_emitter_direct(c.sc, swp, k, c.seed, c.sid, c.stream, &w.draws, &ds);
+        if (intensity(ds.beam) != 0) {
+            float eo[3], ed[3], ek, eint;
+            int etr;
+            prim_beam_info(&ds.beam, eo, ed, &ek, &etr, &eint);
+            const float wiw[3] = {-bd[0], -bd[1], -bd[2]}, wow[3] = {-ed[0], -ed[1], -ed[2]};
+            float wi[3], wo[3];
+            prim_surface_to_local(&srf, wiw, wi);
+            prim_surface_to_local(&srf, wow, wo);
+            const double wig = dot(from(wiw), from(g)), wog = dot(from(wow), from(g));
+            if (!(wi[2] * wig <= 0 || wo[2] * wog <= 0)) {
+                float M[16];
+                prim_material_f(c.sc, material, &srf, wi, wo, k, 1 /* backward */, M);
+                if (M[0] != 0.f) {
+                    const prim_geo egeo = ds.has_surface ? geo_surface(ds.surface) : geo_point(eo);
+                    const prim_geo sgeo = geo_surface(srf);
+                    if (!prim_shadow_geo(c.sc, &sgeo, &egeo)) {
+                        prim_beam nee = w.beam;
+                        prim_beam_transform_surface(&nee, &srf, wow, M, 1.f);
+                        const stokes sL = integrate_beams(nee, ds.beam);
+                        double mis = 1;
+                        if (!is_discrete(ds.dpd)) {
+                            const double pd_brdf = density_or_zero(prim_material_pdf(c.sc, material, &srf, wi, wo, k, 1));
+                            const double pd_direct = (double)(ds.dpd * prim_emitter_select_pmf(c.sc, ds.emitter));
+                            mis = power_mis(pd_direct, pd_brdf);
+                        }
+                        c.ctr[2]++;
+                        for (int i = 0; i < 4; ++i) L[i] += (double)((float)sL.s[i] * (float)mis);
+                    }
+                }
+            }
+        }
+    }
+    if (!c.backward && depth < c.max_depth && w.has_fsd && c.virtual_sensor) {
+        // nee_forward (:474-518): only on FSD, only towards virtual coverage sensors
+        prim_sdirect sd;
+        prim_sensor_sample_direct(c.sc, iwp, k, c.seed, c.sid, c.stream, &w.draws, &sd);
+        if ((is_discrete(sd.dpd) || sd.dpd != 0.f) && intensity(sd.beam) > 0) {
+            float so[3], sdir[3], sk, sint;
+            int str;
+            prim_beam_info(&sd.beam, so, sdir, &sk, &str, &sint);
+            const cpair fsd = do_fsd(c, w.beam, w.prev_geo, so, n_wedges, k);
+            const float f = (float)(((fsd.ts_re * fsd.ts_re + fsd.ts_im * fsd.ts_im) + (fsd.th_re * fsd.th_re + fsd.th_im * fsd.th_im)) / 2.0);
+            if (f != 0.f) {
+                prim_beam fb = w.beam;
+                const float wo[3] = {-sdir[0], -sdir[1], -sdir[2]};
+                prim_beam_transform_region(&fb, iwp, tr.dist, wo, f);
+                const stokes sL = integrate_beams(sd.beam, fb);
+                float Lf[4];
+                for (int i = 0; i < 4; ++i) Lf[i] = (float)sL.s[i] * w.recp_spectral_pd;
+                prim_film_splat(c.sc, c.value, c.weight, c.light, &sd.element, Lf, k, 1);
+                c.ctr[2]++;
+                c.ctr[6]++;
+            }
+        }
+    }
+
+    // ---- organic connections: emission (backward, :427-472), sensing (forward, :520-549)
+    if (c.backward && prim.found && emitter_of_shape >= 0) {
+        float Le[4];
+        prim_emitter_Li(c.sc, emitter_of_shape, &w.beam, &srf, Le);
+        double mis = 1;
+        if (!is_discrete(w.from_previous_dpd)) {
+            float swp[3], g[3], sn[3];
+            uint32_t tuid, shape;
+            prim_surface_info(&srf, swp, g, sn, &tuid, &shape);
+            const double emitter_pm = prim_emitter_select_pmf(c.sc, emitter_of_shape);
+            const double emitter_ppd = density_or_zero(prim_emitter_pdf_position(c.sc, emitter_of_shape));
+            const double dn = -dot(from(bd), from(g));
+            const double recp_dn = dn != 0 ? 1.0 / std::fabs(dn) : 0.0;
+            const double l2 = len2(from(bo) - from(swp));
+            mis = power_mis((double)w.from_previous_dpd, emitter_ppd * l2 * recp_dn * emitter_pm);
+        }
+        c.ctr[2]++;
+        for (int i = 0; i < 4; ++i) L[i] += (double)(Le[i] * (float)mis);
+    }
+    if (!c.backward && c.virtual_sensor) {
+        const double adv = dot(from(bd), from(tr.origin) - from(bo));
+        prim_si si;
+        prim_vplane_Si(c.sc, &w.beam, region_end - (float)std::fmax(0.0, adv), &si);
+        if (si.valid) {
+            const stokes sL = integrate_beams(si.beam, w.beam);
+            float Lf[4];
+            for (int i = 0; i < 4; ++i) Lf[i] = (float)sL.s[i] * w.recp_spectral_pd;
+            prim_film_splat(c.sc, c.value, c.weight, c.light, &si.element, Lf, k, 1);
+            c.ctr[6]++;
+        }
+    }
+
+    // ---- interactions (:152-242, 728-750)
+    bool sampled_null = false;
+    if (prim.found) {
+        float swp[3], g[3], sn[3];
+        uint32_t tuid, shape;
+        prim_surface_info(&srf, swp, g, sn, &tuid, &shape);
+        const float wiw[3] = {-bd[0], -bd[1], -bd[2]};
+        float wi[3];
+        prim_surface_to_local(&srf, wiw, wi);
+        const double wig = dot(from(wiw), from(g)), wis = wi[2];
+        if (wig * wis <= 0) return;
+        prim_bsdf_sample bs;
+        prim_material_sample(c.sc, material, &srf, wi, k, transport, c.seed, c.sid, c.stream, &w.draws, &bs);
+        if (!bs.valid || bs.dpd == 0.f) return;
+        float wow_f[3];
+        prim_surface_to_world(&srf, bs.wo, wow_f);
+        const float l = std::sqrt(wow_f[0] * wow_f[0] + wow_f[1] * wow_f[1] + wow_f[2] * wow_f[2]);
+        float wo_w[3];
+        for (int a = 0; a < 3; ++a) wo_w[a] = wow_f[a] / l;
+        const double wog = dot(from(wo_w), from(g)), wos = bs.wo[2];
+        c.ctr[3]++;
+        if (wog * wos <= 0) return;
+        // transform_surface_interaction (:63-83)
+        w.from_previous_dpd = bs.dpd;
+        w.prev_geo = geo_surface(srf);
+        w.prev_beam = w.beam;
+        w.has_prev_beam = true;
+        w.sampled_fsd = false;
+        prim_beam_transform_surface(&w.beam, &srf, wo_w, bs.M, 1.f);
+        w.throughput *= (double)bs.M[0];
+        if (bs.eta != 1.f) w.throughput /= (double)(bs.eta * bs.eta);
+    } else if (w.has_fsd) {
+        // sample_fsd_interaction (:217-235) / transform_fsd_interaction (:104-119)
+        float wo[3], weight;
+        prim_utd_sample(c.sc, w.prev_geo.wp, c.seed, c.sid, c.stream, &w.draws, wo, &weight);
+        w.from_previous_dpd = -0.f;   // discrete(0)
+        w.prev_geo = geo_point(iwp);
+        w.prev_beam = w.beam;
+        w.has_prev_beam = true;
+        w.sampled_fsd = true;
+        prim_beam_transform_region(&w.beam, iwp, tr.dist, wo, weight);
+        w.throughput *= (double)weight;
+    } else {
+        sampled_null = true;
+        prim_beam_transform_restart(&w.beam, iwp, tr.dist);
+        c.ctr[5]++;
+    }
+
+    // ---- continue_walk (:125-143)
+    if (depth >= c.max_depth) return;
+    if (intensity(w.beam) == 0) return;
+    if (!sampled_null && c.RR) {
+        const double r = w.throughput < 1 ? std::fmax(w.throughput, .5) : 1.0;
+        if ((double)prim_uniform(c.seed, c.sid, c.stream, &w.draws) <= r) {
+            prim_beam_scale(&w.beam, (float)(1 / r));
+            w.throughput *= 1 / r;
+        } else
+            return;
+    }
+    path_random_walk(c, w, L, sampled_null ? depth : depth + 1, guard + 1, n_wedges);
+}
+
+void path_sample(path_ctx_t& c, uint32_t px, uint32_t py) {
+    if (c.max_depth == 0) return;
+    prim_path_gen g;
+    prim_path_generate(c.sc, c.seed, c.sid, px, py, &g);
+    path_walk w;
+    w.beam = g.beam;
+    float o[3], d[3], k, inten;
+    int tr;
+    prim_beam_info(&g.beam, o, d, &k, &tr, &inten);
+    w.prev_geo = geo_point(o);
+    w.from_previous_dpd = -0.f;
+    w.k = g.k;
+    w.recp_spectral_pd = g.recp_spectral_pd;
+    double L[4] = {0, 0, 0, 0};
+    uint32_t n_wedges = 0;
+    path_random_walk(c, w, L, 1, 0, n_wedges);
+    if (c.backward) {
+        float Lf[4];
+        for (int i = 0; i < 4; ++i) Lf[i] = (float)L[i] * g.recp_spectral_pd;
+        prim_film_splat(c.sc, c.value, c.weight, c.light, &g.element, Lf, g.k, 0);
+    }
+}
+
 }   // namespace
 
 extern "C" {
@@ -787,6 +1122,42 @@ int indep_render(const void* scene_host, uint64_t sample_begin, uint64_t sample_
                 const uint64_t pix = (uint64_t)y * W + x;
                 c.sid = (pix << 32) | (s & 0xFFFFFFFFull);
                 sample(c, x, y, value, weight, light);
+            }
+    if (counters) std::memcpy(counters, c.ctr, sizeof(c.ctr));
+    return 0;
+}
+}
+
+extern "C" {
+// plt_path scenes (either transport direction); counters: segments, -, connections, surface interactions, apertures built, null interactions,
+// light splats, ballistic edge queries
+int indep_render_path(const void* scene_host, uint64_t sample_begin, uint64_t sample_end, uint64_t seed, double* value, double* weight, double* light,
+                      unsigned long long* counters) {
+    int info[14];
+    prim_info(scene_host, info);
+    if (info[10] == 0) return 1;   // plt_path only
+    uint32_t st[4];
+    prim_streams(st);
+    path_ctx_t c;
+    c.sc = scene_host;
+    c.max_depth = info[0];
+    c.RR = info[2];
+    c.FSD = info[3];
+    c.backward = info[10] == 2;
+    c.virtual_sensor = (info[11] & 1) != 0;
+    c.force_rt = (info[11] & 8) != 0;
+    c.seed = seed;
+    c.stream = c.backward ? st[1] : st[2];
+    c.value = value;
+    c.weight = weight;
+    c.light = light;
+    const uint32_t W = (uint32_t)info[6], H = (uint32_t)info[7];
+    for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x)
+            for (uint64_t s = sample_begin; s < sample_end; ++s) {
+                const uint64_t pix = (uint64_t)y * W + x;
+                c.sid = (pix << 32) | (s & 0xFFFFFFFFull);
+                path_sample(c, x, y);
             }
     if (counters) std::memcpy(counters, c.ctr, sizeof(c.ctr));
     return 0;

@@ -51,6 +51,25 @@ float prim_region_tri_flux(const void* sc, const prim_beam* beam, float beam_dis
 int prim_fsd_build(const void* sc, const prim_beam* beam, float beam_dist, const uint32_t* edge_ids, uint32_t n, float aperture_power);
 void prim_fsd_sample(const void* sc, int slot, uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, prim_fsd_sampled* out);
 void prim_beam_transform_restart(prim_beam* b, const float wp[3], float dist);
+
+/* --- plt_path (oracle/indep/indep.cpp: indep_render_path) --- */
+typedef struct { float k, recp_spectral_pd; prim_beam beam; prim_element element; } prim_path_gen;
+/* integrate_forward / integrate_backward up to the first random_walk (plt_path_detail.hpp:772-828): spectral + emitter (forward) or sensor (backward) sample */
+void prim_path_generate(const void* sc, uint64_t seed, uint64_t sid, uint32_t px, uint32_t py, prim_path_gen* out);
+/* vertex_geo_variant_t as shadow() / offseted_ray_origin() see it: 0 a point, 1 a surface (triangle id: the self-intersection offset), 2 a classified edge */
+typedef struct { int kind; float wp[3]; float ng[3]; uint32_t id; } prim_geo;
+int prim_shadow_geo(const void* sc, const prim_geo* a, const prim_geo* b);   /* integrator::shadow (traversal.hpp:319-333): 1 = occluded */
+/* UTD aperture of the current interaction (free_space_diffraction_t, UTD form: free_space_diffraction.cpp:23-79); returns its wedge count */
+uint32_t prim_utd_build(const void* sc, const prim_beam* beam, const float interaction_wp[3], float dist, const uint32_t* edge_ids, uint32_t n);
+typedef struct { int valid; uint32_t edge; float p[3]; float ro, ri; float Ds[2], Dh[2]; } prim_utd_term;
+void prim_utd_f_edge(const void* sc, uint32_t i, const float src[3], const float dst[3], prim_utd_term* out);   /* one wedge's term of free_space_diffraction_t::f */
+void prim_utd_sample(const void* sc, const float prev_wp[3], uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws, float wo[3], float* weight);
+int prim_cone_contains(const prim_beam* b, const float p[3]);   /* elliptic_cone_t::contains of the beam's envelope */
+/* the cone query of a ballistic hit's surroundings (plt_path_detail.hpp:645-650): triangles in this thread's record (prim_trav_tri), their count */
+uint32_t prim_ballistic_region(const void* sc, const prim_beam* beam, float dist);
+void prim_beam_add(prim_beam* b, const prim_beam* o);   /* beam_t::operator+= */
+float prim_k_times_length(float k, float d);              /* the dimensionless product k d in the library's units */
+float prim_beam_axis_x(const prim_beam* b, float dist, float footprint[3]);   /* envelope.axes(dist).x; the beam's footprint at dist */
 float prim_uniform(uint64_t seed, uint64_t sid, uint32_t stream, uint32_t* draws);
 void prim_beam_info(const prim_beam* b, float o[3], float d[3], float* k, int* transport, float* intensity);
 void prim_beam_scale(prim_beam* b, float f);

@@ -99,3 +99,45 @@ def test_independent_composition_on_scene_files(built, file, defines, spp):
     assert tot_b.sum() > 0
     fsd_scene = oc["fsd_interactions"] > 0
     assert np.abs(tot_a - tot_b).sum() <= (2e-2 if fsd_scene else 1e-5) * tot_b.sum()
+
+
+def indep_render_path(sc, b, e, seed):
+    lib = indep()
+    lib.indep_render_path.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    H, W, Cn = sc.height, sc.width, sc.channels
+    v, w, l = np.zeros((H, W, Cn)), np.zeros((H, W)), np.zeros((H, W, Cn))
+    ctr = np.zeros(8, np.uint64)
+    assert lib.indep_render_path(sc.host_desc(), b, e, seed, v.ctypes.data, w.ctypes.data, l.ctypes.data, ctr.ctypes.data) == 0
+    return v, w, l, dict(zip(["segments", "-", "connections", "surface_interactions", "fsd_interactions", "null_interactions", "light_splats", "edge_queries"],
+                             [int(x) for x in ctr]))
+
+
+PATH_CASES = [
+    # forward plt_path from a point transmitter over the etoile stand-in: UTD apertures, do_fsd (Fermat points, two shadow rays per wedge,
+    # coherent sum), nee_forward, sensing on the virtual coverage sensor
+    ("etoile", 32, 4, {"mesh_detail": 0}),
+    ("etoile", 48, 4, {"mesh_detail": 1}),
+    # backward plt_path: nee_backward with the power heuristic, emission, Russian roulette
+    ("white_furnace_path", 12, 8, {}),
+    ("furnace_path", 12, 8, {}),
+    ("cornell_box_path", 16, 4, {"mesh_detail": 0}),
+    ("sunlit_path", 12, 8, {}),          # directional emitter under backward transport
+]
+
+
+@pytest.mark.parametrize("name,res,spp,kw", PATH_CASES)
+def test_independent_plt_path_matches_the_checker(built, name, res, spp, kw):
+    """plt_path restated a second time (oracle/indep/indep.cpp: path_random_walk, from plt_path_detail.hpp:33-828 — recursion, optionals and
+    std::vector like the reference, double-precision bookkeeping, single-purpose primitives) against wt/path.h's explicit walk state through
+    liboracle.so: every event counter identical, every pixel to 1e-4 of the image scale."""
+    from wave_tracer_amd import Scene, develop
+    sc = Scene(name, res=res, **kw)
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 9, threads=1)
+    iv, iw, il, ic = indep_render_path(sc, 0, spp, 9)
+    for k in ("segments", "connections", "surface_interactions", "fsd_interactions", "null_interactions", "light_splats"):
+        assert ic[k] == oc[k], (k, ic[k], oc[k])
+    a = develop(sc, ov, ow, ol, spp).astype(np.float64)
+    b = develop(sc, iv, iw, il, spp).astype(np.float64)
+    assert a.sum() > 0 and np.allclose(iw, ow, rtol=1e-6, atol=1e-12)
+    assert np.abs(a - b).max() <= 1e-4 * a.max(), np.abs(a - b).max() / a.max()
+    assert np.abs(a - b).sum() <= 1e-5 * a.sum()
