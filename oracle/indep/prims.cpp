@@ -227,6 +227,8 @@ static path_geo_t geo_of(const prim_geo* g) {
 int prim_shadow_geo(const void* sc, const prim_geo* a, const prim_geo* b) { return path_shadow(S(sc), geo_of(a), geo_of(b), stack(), nullptr) ? 1 : 0; }
 uint32_t prim_utd_build(const void* sc_, const prim_beam* beam_, const float interaction_wp[3], float dist, const uint32_t* edge_ids, uint32_t n) {
     const beam_t beam = get<beam_t>(beam_);
+    tls.utd_ap.edge_offset = 0;
+    tls.utd_ap.edge_cap = kUtdMaxEdges;
     utd_build_aperture(S(sc_), v3(interaction_wp), cone_frame(beam.env), beam_footprint(beam, dist), -beam.env.d, beam.k, edge_ids, n, tls.utd_ap,
                        utd_edges_ref_t{tls.utd_edges.data(), 1});
     return tls.utd_ap.n_edges;

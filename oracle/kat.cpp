@@ -217,6 +217,8 @@ uint32_t kat_utd_aperture(const void* scene_host, const uint32_t* edge_ids, uint
     utd_aperture_t ap;
     const frame_t fr{{frame9[0], frame9[1], frame9[2]}, {frame9[3], frame9[4], frame9[5]}, {frame9[6], frame9[7], frame9[8]}};
     const vec3 s{src[0], src[1], src[2]}, p{wp[0], wp[1], wp[2]};
+    ap.edge_offset = 0;
+    ap.edge_cap = kUtdMaxEdges;
     utd_build_aperture(sc, p, fr, vec3{size3[0], size3[1], size3[2]}, normalize(s - p), k, edge_ids, n_ids, ap, utd_edges_ref_t{recs, 1});
     for (uint32_t i = 0; i < n; ++i) {
         sampler_t smp = make_sampler(seed, i, 7);

@@ -84,7 +84,6 @@ void run_path_sample(const scene_t& sc, const film_t& film, uint64_t seed, uint6
                      std::vector<utd_edge_rec_t>& utd, bdpt_counters_t& ctr) {
     const stack_ref_t stack = make_flat_stack(scr.stack, 128);
     const uint_list_t tris{scr.tris.data(), 1, kOracleConeTris, g_region_filter ? scr.dists.data() : nullptr};
-    const utd_edges_ref_t utd_edges{utd.data(), 1};
     const uint32_t stream = sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
     const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
     path_walk_t pw;
@@ -97,7 +96,7 @@ void run_path_sample(const scene_t& sc, const film_t& film, uint64_t seed, uint6
         ctr.ray_queries += tr.n_ray_queries;
         ctr.cone_queries += tr.n_cone_queries;
         ctr.cone_tri_overflow += tr.overflow;
-        pw.w.active = path_walk_step(sc, pw, tr, tris, utd_edges, film, seed, sample_id, stream, stack, &ctr) ? 1u : 0u;
+        pw.w.active = path_walk_step(sc, pw, tr, tris, utd.data(), utd_pool_t{utd.data(), nullptr, kUtdMaxEdges}, film, seed, sample_id, stream, stack, &ctr) ? 1u : 0u;
     }
     path_finish(sc, film, pw);
 }

@@ -162,6 +162,35 @@ WT_HD uint32_t path_gather_edge_ids(const scene_t& sc, const TriList& tris, uint
     return n;
 }
 
+// Wedge records of the UTD apertures: the CPU checker hands every walk one fixed slot (counter == nullptr: kUtdMaxEdges records at recs);
+// the device bump-allocates each aperture's records from the round's pool after counting them (utd_count_wedges), so an aperture holds as
+// many wedges as its region has — the reference's std::vector.
+struct utd_pool_t {
+    utd_edge_rec_t* recs;
+    uint32_t* counter;
+    uint32_t cap;
+};
+// Device only: the two coherent UTD sums of a step (do_fsd, plt_path_detail.hpp:311-346: a Fermat point, the UTD coefficients and two shadow rays
+// per wedge) run in wave-per-walk kernels of their own (wtgpu.hip: k_path_fsd before this step, k_path_nee after it), one lane per wedge.
+//   * in:  have_prev_f / prev_f — the sum of the PREVIOUS aperture towards this step's interaction point, already evaluated;
+//   * out: nee_pending / nee — next-event estimation towards the virtual sensor through the NEW aperture: everything k_path_nee needs.
+struct path_nee_rec_t {
+    beam_t beam;         // the walk's beam at the interaction (before it is transformed)
+    beam_t sd_beam;      // the sensor's direct-connection beam
+    sensor_element_t element;
+    vec3 interaction_wp;
+    float dist;
+    vec3 src_wp, src_ng;             // prev_vert_geo
+    uint32_t src_kind, src_tuid;
+    float recp_spectral_pd;
+};
+struct path_defer_t {
+    uint32_t have_prev_f;
+    float prev_f;
+    uint32_t defer_nee, nee_pending;
+    path_nee_rec_t nee;
+};
+
 // integrate_forward / integrate_backward up to the first random_walk call (plt_path_detail.hpp:772-828)
 WT_HD void path_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, uint32_t px, uint32_t py, path_walk_t& pw) {
     sampler_t smp = make_sampler(seed, sample_id, STREAM_SCENE);
@@ -173,6 +202,7 @@ WT_HD void path_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, u
     pw.ap.overflow = 0;
     pw.ap.k = 0.f;
     pw.ap.interaction_wp = vec3{0, 0, 0};
+    pw.ap.edge_offset = pw.ap.edge_cap = 0;
     pw.L[0] = pw.L[1] = pw.L[2] = pw.L[3] = 0.f;
     pw.element = sensor_element_t{0, 0, {0.f, 0.f}};
     w.throughput = 1.f;
@@ -215,9 +245,10 @@ WT_HD void path_finish(const scene_t& sc, const film_t& film, path_walk_t& pw) {
 
 // One step of plt_path::random_walk after traverse() (plt_path_detail.hpp:574-770).  Returns TRUE if the walk continues.
 // `tris`: the traversal's triangle list; also receives the list of the ballistic edge query (plt_path_detail.hpp:645-650).
-// `utd_edges`: the walk's wedge-record slot (kUtdMaxEdges entries).
-WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_t& tr, const uint_list_t& tris, const utd_edges_ref_t& utd_edges,
-                          const film_t& film, uint64_t seed, uint64_t sample_id, uint32_t stream, const stack_ref_t& stack, bdpt_counters_t* ctr) {
+// `prev_recs`: the record array the PREVIOUS step's aperture lives in (pw.ap.edge_offset into it); `pool`: where this step's aperture goes.
+WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_t& tr, const uint_list_t& tris, const utd_edge_rec_t* prev_recs, const utd_pool_t& pool,
+                          const film_t& film, uint64_t seed, uint64_t sample_id, uint32_t stream, const stack_ref_t& stack, bdpt_counters_t* ctr,
+                          path_defer_t* defer = nullptr) {
     walk_t& w = pw.w;
     if (!w.active || tr.empty) return false;   // (inactive: max_depth 0)  no intersection (TODO in the reference: infinite emitters)
     const bool backward = sc.opts.integrator == INTEGRATOR_PATH_BACKWARD;
@@ -236,9 +267,14 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
     // ---- evaluate fsd from the previous interaction (plt_path_detail.hpp:616-636)
     if (pw.has_fsd) {
         const cone_t prev_cone = pw.prev_beam.env;
-        const cpair_t fsd = path_do_fsd(sc, prev_cone, path_geo_prev(w), interaction_wp, pw.ap, utd_edges, k, stack, ctr);
+        float f;
+        if (defer && defer->have_prev_f)
+            f = defer->prev_f;
+        else {
+            const cpair_t fsd = path_do_fsd(sc, prev_cone, path_geo_prev(w), interaction_wp, pw.ap, utd_edges_ref_t{const_cast<utd_edge_rec_t*>(prev_recs) + pw.ap.edge_offset, 1}, k, stack, ctr);
+            f = (cnorm(fsd.ts) + cnorm(fsd.th)) / 2.f;
+        }
         pw.has_fsd = 0;
-        const float f = (cnorm(fsd.ts) + cnorm(fsd.th)) / 2.f;
         if (pw.sampled_fsd)
             beam_scale(beam, f);
         else {
@@ -317,8 +353,26 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
     }
 
     // ---- construct the fsd BSDF (plt_path_detail.hpp:692-709)
+    utd_edges_ref_t utd_edges{pool.recs, 1};   // this step's aperture
     if (n_edge_ids > 0) {
         const vec3 footprint = beam_footprint(beam, dist_to_interaction);
+        pw.ap.edge_offset = 0;
+        pw.ap.edge_cap = kUtdMaxEdges;
+        if (pool.counter) {   // device: exactly as many records as the aperture has wedges, from the round's pool
+            uint32_t need = utd_count_wedges(sc, interaction_wp, beam_frame, footprint, -beam.env.d, edge_ids, n_edge_ids);
+            uint32_t off = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (need) off = atomicAdd(pool.counter, need);
+#endif
+            if ((size_t)off + need > pool.cap) {   // pool exhausted: reported (fsd_pool_overflow), the aperture stays empty
+                if (ctr) ctr->fsd_pool_overflow++;
+                off = 0;
+                need = 0;
+            }
+            pw.ap.edge_offset = off;
+            pw.ap.edge_cap = need;
+        }
+        utd_edges = utd_edges_ref_t{pool.recs + pw.ap.edge_offset, 1};
         utd_build_aperture(sc, interaction_wp, beam_frame, footprint, -beam.env.d, k, edge_ids, n_edge_ids, pw.ap, utd_edges);
         pw.has_fsd = pw.ap.n_edges > 0 ? 1u : 0u;
         if (ctr) {
@@ -363,7 +417,21 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
     if (!backward && depth < sc.opts.max_depth && pw.has_fsd && sensor_is_virtual(sc.sensor)) {
         // nee_forward (plt_path_detail.hpp:474-518): only on FSD, only towards virtual coverage sensors
         const sensor_direct_sample_t sd = sensor_sample_direct(sc, interaction_wp, k, smp);
-        if ((pd_is_discrete(sd.dpd) || sd.dpd != 0.f) && beam_intensity(sd.beam) > 0.f) {
+        if ((pd_is_discrete(sd.dpd) || sd.dpd != 0.f) && beam_intensity(sd.beam) > 0.f && defer && defer->defer_nee) {
+            // device: evaluated by a wavefront of k_path_nee (one lane per wedge), which also splats
+            defer->nee_pending = 1;
+            defer->nee.beam = beam;
+            defer->nee.sd_beam = sd.beam;
+            defer->nee.element = sd.element;
+            defer->nee.interaction_wp = interaction_wp;
+            defer->nee.dist = dist_to_interaction;
+            const path_geo_t pg = path_geo_prev(w);
+            defer->nee.src_wp = pg.wp;
+            defer->nee.src_ng = pg.ng;
+            defer->nee.src_kind = pg.kind;
+            defer->nee.src_tuid = pg.tuid;
+            defer->nee.recp_spectral_pd = pw.recp_spectral_pd;
+        } else if ((pd_is_discrete(sd.dpd) || sd.dpd != 0.f) && beam_intensity(sd.beam) > 0.f) {
             const cpair_t fsd = path_do_fsd(sc, beam.env, path_geo_prev(w), sd.beam.env.o, pw.ap, utd_edges, k, stack, ctr);
             const float f = (cnorm(fsd.ts) + cnorm(fsd.th)) / 2.f;
             if (f != 0.f) {

@@ -13,19 +13,16 @@
 // tests/test_kat.py), then rounded to float like the reference's c_t{cerfc(...)}.
 //
 // The aperture of one interaction region is stored compactly (edge id + front-face bit + the two clamping parameters,
-// 12 B per wedge) and the wedge is rebuilt from the scene's edge table when evaluated; the number of wedges per aperture is
-// bounded (kUtdMaxEdges) on the device, unbounded in the reference (std::vector).
+// 12 B per wedge) and the wedge is rebuilt from the scene's edge table when evaluated.  The number of wedges per aperture is not bounded
+// (the reference's is a std::vector): an aperture owns `edge_cap` records at `edge_offset` of a pool, sized by a counting pass before it
+// is built (utd_count_wedges); kUtdMaxEdges is only the size of the fixed scratch arrays of the CPU checker and the KATs.
 #pragma once
 #include "scene.h"
 #include "rng.h"
 
 namespace wt {
 
-#ifdef WT_ORACLE_UNBOUNDED
 constexpr uint32_t kUtdMaxEdges = 4096;
-#else
-constexpr uint32_t kUtdMaxEdges = 32;
-#endif
 constexpr float kUtdMinSinBeta = 1e-3f;    // utd.hpp:20
 constexpr float kUtdIsSigmaScale = 45.f;   // free_space_diffraction.cpp:20
 
@@ -194,6 +191,7 @@ struct utd_aperture_t {
     uint32_t overflow;
     float k;
     vec3 interaction_wp;
+    uint32_t edge_offset, edge_cap;   // this aperture's wedge records: [edge_offset, edge_offset + edge_cap) of the caller's record array
 };
 
 WT_HD utd_wedge_t utd_wedge(const scene_t& sc, const utd_edge_rec_t& r) {
@@ -212,14 +210,11 @@ WT_HD utd_wedge_t utd_wedge(const scene_t& sc, const utd_edge_rec_t& r) {
     return w;
 }
 
-// free_space_diffraction_t ctor (free_space_diffraction.cpp:23-79)
-template <class EdgeIds>
-WT_HD void utd_build_aperture(const scene_t& sc, vec3 interaction_wp, const frame_t& region_frame, vec3 region_size, vec3 wi, float k, const EdgeIds& edge_ids,
-                              uint32_t n_edge_ids, utd_aperture_t& ap, const utd_edges_ref_t& out) {
-    ap.n_edges = 0;
-    ap.overflow = 0;
-    ap.k = k;
-    ap.interaction_wp = interaction_wp;
+// free_space_diffraction_t ctor (free_space_diffraction.cpp:23-79).  `emit(record)` receives the wedges in edge order; returns their number.
+template <class EdgeIds, class Emit>
+WT_HD uint32_t utd_aperture_wedges(const scene_t& sc, vec3 interaction_wp, const frame_t& region_frame, vec3 region_size, vec3 wi, const EdgeIds& edge_ids,
+                                   uint32_t n_edge_ids, Emit&& emit) {
+    uint32_t n = 0;
     for (uint32_t i = 0; i < n_edge_ids; ++i) {
         const uint32_t id = edge_ids[i];
         const edge_t ed = sc.edges[id];
@@ -235,12 +230,31 @@ WT_HD void utd_build_aperture(const scene_t& sc, vec3 interaction_wp, const fram
         }
         const vec3 v1 = mix3(ed.a, ed.b, t1), v2 = mix3(ed.a, ed.b, t2);
         if (veq(v1, v2)) continue;
-        if (ap.n_edges == kUtdMaxEdges) {
-            ap.overflow++;
-            continue;
-        }
-        out[ap.n_edges++] = utd_edge_rec_t{id | (f1_is_front ? 0x80000000u : 0u), t1, t2};
+        emit(utd_edge_rec_t{id | (f1_is_front ? 0x80000000u : 0u), t1, t2});
+        ++n;
     }
+    return n;
+}
+// the number of wedges utd_build_aperture will store: sizes the aperture's storage (device: a bump allocation from the round's pool)
+template <class EdgeIds>
+WT_HD uint32_t utd_count_wedges(const scene_t& sc, vec3 interaction_wp, const frame_t& region_frame, vec3 region_size, vec3 wi, const EdgeIds& edge_ids,
+                                uint32_t n_edge_ids) {
+    return utd_aperture_wedges(sc, interaction_wp, region_frame, region_size, wi, edge_ids, n_edge_ids, [](const utd_edge_rec_t&) {});
+}
+// `out`: the aperture's records (ap.edge_cap of them; wedges beyond are counted in ap.overflow — cannot happen after utd_count_wedges)
+template <class EdgeIds>
+WT_HD void utd_build_aperture(const scene_t& sc, vec3 interaction_wp, const frame_t& region_frame, vec3 region_size, vec3 wi, float k, const EdgeIds& edge_ids,
+                              uint32_t n_edge_ids, utd_aperture_t& ap, const utd_edges_ref_t& out) {
+    ap.n_edges = 0;
+    ap.overflow = 0;
+    ap.k = k;
+    ap.interaction_wp = interaction_wp;
+    utd_aperture_wedges(sc, interaction_wp, region_frame, region_size, wi, edge_ids, n_edge_ids, [&](const utd_edge_rec_t& r) {
+        if (ap.n_edges < ap.edge_cap)
+            out[ap.n_edges++] = r;
+        else
+            ap.overflow++;
+    });
 }
 
 // free_space_diffraction_t::pdf (free_space_diffraction.cpp:155-195): angle density [1/rad]

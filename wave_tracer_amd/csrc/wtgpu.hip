@@ -89,8 +89,8 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 // control block of one state slice (device memory)
-enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 28 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
+enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 40 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 // ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
@@ -134,7 +134,14 @@ struct device_state_t {
     uint32_t* strat_count = nullptr;    // [kNumKeys]
     uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
     double* lacc = nullptr;             // [4][cap] per-sample sum of the t>1 strategies' fluxes
-    utd_edge_rec_t* utd = nullptr;      // plt_path: [cap][kUtdMaxEdges] wedge records of each walk's UTD aperture
+    // plt_path: wedge records of the walks' UTD apertures, two pools used alternately (round parity: an aperture built in round r is evaluated in
+    // round r + 1), each reset when its round begins; queues of the wave-per-walk UTD kernels and what they exchange with k_path_interact
+    utd_edge_rec_t* utd[2] = {nullptr, nullptr};
+    uint32_t utd_cap = 0;
+    uint32_t* fsdq[2] = {nullptr, nullptr};   // walks that carry an aperture into the next round (k_path_fsd evaluates it there)
+    uint32_t* neeq = nullptr;                  // walks with a deferred next-event estimation of this round (k_path_nee)
+    float* fsd_f = nullptr;                    // [cap] k_path_fsd's result per walk
+    path_nee_rec_t* nee_recs = nullptr;        // [cap]
     unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
@@ -342,6 +349,12 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
         ctl[CTL_EPOOL_COUNT] = 0;
         ctl[CTL_INTD_COUNT] = 0;
         ctl[CTL_INTD_HEAD] = 0;
+        // plt_path: this round's wedge pool and the queue it fills for the next round's k_path_fsd; this round's k_path_fsd / k_path_nee heads
+        ctl[CTL_UTD_COUNT0 + (round & 1u)] = 0;
+        ctl[CTL_FSDQ_COUNT0 + ((round + 1u) & 1u)] = 0;
+        ctl[CTL_FSDQ_HEAD] = 0;
+        ctl[CTL_NEEQ_COUNT] = 0;
+        ctl[CTL_NEEQ_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -434,6 +447,12 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         ctl[CTL_EPOOL_COUNT] = 0;
         ctl[CTL_INTD_COUNT] = 0;
         ctl[CTL_INTD_HEAD] = 0;
+        // plt_path: this round's wedge pool and the queue it fills for the next round's k_path_fsd; this round's k_path_fsd / k_path_nee heads
+        ctl[CTL_UTD_COUNT0 + (round & 1u)] = 0;
+        ctl[CTL_FSDQ_COUNT0 + ((round + 1u) & 1u)] = 0;
+        ctl[CTL_FSDQ_HEAD] = 0;
+        ctl[CTL_NEEQ_COUNT] = 0;
+        ctl[CTL_NEEQ_HEAD] = 0;
         if (n > 0) ctl[CTL_ROUNDS] = round + 1;
     }
     bdpt_counters_t ctr;
@@ -1041,6 +1060,7 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
         ctl[CTL_COUNT0] = a.nb;
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
+        ctl[CTL_UTD_COUNT0] = ctl[CTL_UTD_COUNT1] = ctl[CTL_FSDQ_COUNT0] = ctl[CTL_FSDQ_COUNT1] = ctl[CTL_FSDQ_HEAD] = ctl[CTL_NEEQ_COUNT] = ctl[CTL_NEEQ_HEAD] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
         ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
@@ -1056,7 +1076,82 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
     soa_store(a.st.walks, a.st.walk_words, i, pw);
 }
 
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round) {
+// do_fsd (plt_path_detail.hpp:311-346) by ONE WAVEFRONT: lane = wedge (strided over apertures of any size) — the Fermat point on the wedge, the
+// UTD coefficients and the two shadow rays (per-lane any-hit traversals on the lane's LDS stack) — coherent sums in f64 by wave reduction; the
+// direct path is evaluated redundantly by all lanes (uniform control flow).  Returns (|ts|^2 + |th|^2) / 2.
+__device__ inline float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const path_geo_t& src_geo, vec3 dst, const utd_aperture_t& ap, const utd_edge_rec_t* recs,
+                                    float k, const stack_ref_t& stack, bdpt_counters_t* ctr) {
+    const int lane = threadIdx.x & 63;
+    const vec3 src = cone_from_src.o;
+    const path_geo_t dst_geo = path_geo_point(dst);
+    double tsr = 0, tsi = 0, thr = 0, thi = 0;
+    for (uint32_t i = (uint32_t)lane; i < ap.n_edges; i += 64u) {
+        utd_diffracting_edge_t f;
+        if (!utd_f_edge(sc, ap, recs[i], src, dst, f)) continue;
+        const path_geo_t eintr = path_geo_edge(f.edge, f.p);
+        if (path_shadow(sc, eintr, src_geo, stack, ctr) || path_shadow(sc, eintr, dst_geo, stack, ctr)) continue;
+        const cplx phase = cpolar(1.f, -k_times_len(k, f.ro + f.ri));
+        const cplx a = phase * f.utd.Ds, b = phase * f.utd.Dh;
+        tsr += a.re;
+        tsi += a.im;
+        thr += b.re;
+        thi += b.im;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tsr += __shfl_xor(tsr, off, 64);
+        tsi += __shfl_xor(tsi, off, 64);
+        thr += __shfl_xor(thr, off, 64);
+        thi += __shfl_xor(thi, off, 64);
+    }
+    cplx ts{(float)tsr, (float)tsi}, th{(float)thr, (float)thi};
+    if (cone_contains(cone_from_src, dst)) {
+        bdpt_counters_t* c0 = lane == 0 ? ctr : nullptr;
+        if (!path_shadow(sc, src_geo, dst_geo, stack, c0)) {
+            const cplx phase = cpolar(1.f, -k_times_len(k, length(dst - src)));
+            ts = ts + phase;
+            th = th + phase;
+        }
+    }
+    return (cnorm(ts) + cnorm(th)) / 2.f;
+}
+
+// plt_path, before the interaction step: the coherent UTD sum of the aperture the walk built in the previous round towards this round's
+// interaction point (plt_path_detail.hpp:616-636) — one wavefront per walk, queue filled by the previous round's k_path_interact.
+__global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, uint32_t round) {
+    __shared__ stack_entry_t lds[kLdsStack * 64];
+    __shared__ uint32_t s_item;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t qin = round & 1u;
+    const uint32_t n = ctl[CTL_FSDQ_COUNT0 + qin];
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    const utd_edge_rec_t* prev_pool = a.st.utd[(round + 1u) & 1u];
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSDQ_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.fsdq[qin][item];
+        const uint32_t empty = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)];
+        if (empty) continue;   // (the step ends before do_fsd: plt_path_detail.hpp:577-581)
+        path_walk_t pw;
+        soa_load(a.st.walks, a.st.walk_words, w, pw);   // uniform address: broadcast
+        const vec3 origin{__uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.x)]), __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.y)]),
+                          __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
+        const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const vec3 interaction_wp = origin + dist * pw.w.beam.env.d;
+        const float f = coop_do_fsd(a.sc, pw.prev_beam.env, path_geo_prev(pw.w), interaction_wp, pw.ap, prev_pool + pw.ap.edge_offset, pw.w.beam.k, stack, &ctr);
+        if (threadIdx.x == 0) a.st.fsd_f[w] = f;
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
+__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = queue_count(ctl, in);
@@ -1070,12 +1165,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, in
     stack_entry_t spill[kSpillStack];
     stack_ref_t stack;
     lds_stack(lds, spill, stack);
-    const size_t W2 = 2 * (size_t)a.st.cap;
     const uint32_t stream = a.sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
+    const utd_pool_t pool{a.st.utd[round & 1u], ctl + CTL_UTD_COUNT0 + (round & 1u), a.st.utd_cap};
+    const utd_edge_rec_t* prev_pool = a.st.utd[(round + 1u) & 1u];
     for (;;) {
         const uint32_t qi = wave_grab(ctl + CTL_HEAD_INTERACT) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
-        bool cont = false;
+        bool cont = false, carries_fsd = false, nee = false;
         uint32_t w = 0;
         if (qi < n) {
             w = queue_walk(a, ctl, in, qi, first_round);
@@ -1089,16 +1185,64 @@ __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, in
             soa_load(a.st.trav, kTravWords, w, tr);
             uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
             const uint_list_t tris{slot, 1u, kMaxConeTris, reinterpret_cast<float*>(slot + kMaxConeTris)};
-            const utd_edges_ref_t utd{a.st.utd + (size_t)w * kUtdMaxEdges, 1};
-            cont = path_walk_step(a.sc, pw, tr, tris, utd, a.film, a.seed, sample_id, stream, stack, &ctr);
+            path_defer_t defer;
+            defer.have_prev_f = pw.has_fsd;   // evaluated by k_path_fsd (this round), one lane per wedge
+            defer.prev_f = pw.has_fsd ? a.st.fsd_f[w] : 0.f;
+            defer.defer_nee = 1;
+            defer.nee_pending = 0;
+            cont = path_walk_step(a.sc, pw, tr, tris, prev_pool, pool, a.film, a.seed, sample_id, stream, stack, &ctr, &defer);
             if (!cont) path_finish(a.sc, a.film, pw);
             pw.w.active = cont ? 1u : 0u;
             soa_store(a.st.walks, a.st.walk_words, w, pw);
+            carries_fsd = cont && pw.has_fsd;
+            nee = defer.nee_pending != 0;
+            if (nee) a.st.nee_recs[w] = defer.nee;
         }
         queue_append(a, ctl, 1 - in, cont, w);
+        wave_append(a.st.fsdq[(round + 1u) & 1u], ctl + CTL_FSDQ_COUNT0 + ((round + 1u) & 1u), carries_fsd, w);
+        wave_append(a.st.neeq, ctl + CTL_NEEQ_COUNT, nee, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
+
+// plt_path, after the interaction step: next-event estimation towards the virtual sensor through the aperture the step just built (nee_forward,
+// plt_path_detail.hpp:474-518) — one wavefront per walk: coherent UTD sum (coop_do_fsd), beam transform, integrate_beams, light-image splat.
+__global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, uint32_t round) {
+    __shared__ stack_entry_t lds[kLdsStack * 64];
+    __shared__ uint32_t s_item;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_NEEQ_COUNT];
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    const utd_edge_rec_t* cur_pool = a.st.utd[round & 1u];
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_NEEQ_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.neeq[item];
+        const path_nee_rec_t r = a.st.nee_recs[w];   // uniform address
+        utd_aperture_t ap;
+        soa_load(a.st.walks + offsetof(path_walk_t, ap) / 4, a.st.walk_words, w, ap);   // the aperture k_path_interact just stored
+        const path_geo_t src_geo{r.src_wp, r.src_kind, r.src_ng, r.src_tuid};
+        const float k = r.beam.k;
+        const float f = coop_do_fsd(a.sc, r.beam.env, src_geo, r.sd_beam.env.o, ap, cur_pool + ap.edge_offset, k, stack, &ctr);
+        if (threadIdx.x == 0 && f != 0.f) {
+            beam_t fsd_beam = r.beam;
+            beam_transform_region_interaction(fsd_beam, r.interaction_wp, r.dist, -r.sd_beam.env.d, f);
+            const stokes_t sL = integrate_beams(r.sd_beam, fsd_beam);
+            film_splat_direct(a.sc, a.film, r.element, sL * r.recp_spectral_pd, k);
+            ctr.connections++;
+            ctr.light_splats++;
+        }
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
 // walks still active after the last round (iteration cap): backward transport splats what they gathered
 __global__ void __launch_bounds__(kBlock) k_path_flush(launch_args_t a, int in) {
     const uint32_t n = queue_count(a.st.ctl, in);
@@ -1767,7 +1911,14 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         const size_t W2 = 2 * (size_t)st.cap;
         const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;   // plt_path: no vertex store / strategy buckets / Fraunhofer pool
         if ((rc = dmalloc(s, &st.walks, (path_mode ? kPathWalkWords : kWalkWords) * W2))) return rc;
-        if ((rc = dmalloc(s, &st.utd, path_mode ? (size_t)st.cap * kUtdMaxEdges : 1))) return rc;
+        st.utd_cap = path_mode ? (uint32_t)std::min<uint64_t>(48ull * st.cap + 65536, 1ull << 28) : 1u;   // measured mean on the 576-building etoile: 11 wedges per aperture
+        for (int q = 0; q < 2; ++q) {
+            if ((rc = dmalloc(s, &st.utd[q], (size_t)st.utd_cap))) return rc;
+            if ((rc = dmalloc(s, &st.fsdq[q], path_mode ? (size_t)st.cap : 1))) return rc;
+        }
+        if ((rc = dmalloc(s, &st.neeq, path_mode ? (size_t)st.cap : 1))) return rc;
+        if ((rc = dmalloc(s, &st.fsd_f, path_mode ? (size_t)st.cap : 1))) return rc;
+        if ((rc = dmalloc(s, &st.nee_recs, path_mode ? (size_t)st.cap : 1))) return rc;
         if ((rc = dmalloc(s, &st.verts, path_mode ? 1 : (size_t)st.max_verts * kVertexWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
         if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
@@ -1961,7 +2112,9 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             if (dbg_stage >= 3 + 3 * (int)round) hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
             if (path_mode) {
-                if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+                if (round > 0) hipLaunchKernelGGL(k_path_fsd, dim3(gh), dim3(64), 0, st_, a, round);
+                if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                hipLaunchKernelGGL(k_path_nee, dim3(gh), dim3(64), 0, st_, a, round);
                 rec();
                 rec();
                 rec();
