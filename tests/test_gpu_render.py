@@ -580,6 +580,8 @@ def test_full_size_etoile_720(built):
           "overflows", {k: c[k] for k in ("cone_tri_overflow", "edge_overflow", "fsd_edge_overflow")})
     assert cpu.sum() > 0 and abs(gl.sum() - ol.sum()) < 1e-3 * ol.sum()
     assert _rel_l1(g, cpu) < 2e-2
+    # classified-edge sets and wedge lists are complete (k_path_edges + the per-round wedge pools): nothing truncated, like the reference's vectors
+    assert c["edge_overflow"] == 0 and c["fsd_edge_overflow"] == 0 and c["fsd_pool_overflow"] == 0
     for key in ("segments", "fsd_interactions", "light_splats"):
         assert abs(c[key] - oc[key]) <= 5e-3 * oc[key], (key, c[key], oc[key])
 

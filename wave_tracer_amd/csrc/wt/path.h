@@ -140,7 +140,7 @@ WT_HD cpair_t path_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const 
 
 // ordered, de-duplicated edge set of a triangle list (ads/traversal_common.hpp:124-148)
 template <class TriList>
-WT_HD uint32_t path_gather_edge_ids(const scene_t& sc, const TriList& tris, uint32_t ntris, uint32_t* edge_ids, bdpt_counters_t* ctr) {
+WT_HD uint32_t path_gather_edge_ids(const scene_t& sc, const TriList& tris, uint32_t ntris, uint32_t* edge_ids, bdpt_counters_t* ctr, uint32_t cap = kMaxEdgeIds) {
     uint32_t n = 0;
     for (uint32_t i = 0; i < ntris; ++i) {
         const tri_meta_t m = sc.tri_meta[tris[i]];
@@ -150,7 +150,7 @@ WT_HD uint32_t path_gather_edge_ids(const scene_t& sc, const TriList& tris, uint
             uint32_t pos = 0;
             while (pos < n && edge_ids[pos] < id) ++pos;
             if (pos < n && edge_ids[pos] == id) continue;
-            if (n == kMaxEdgeIds) {
+            if (n == cap) {
                 if (ctr) ctr->edge_overflow++;
                 continue;
             }
@@ -184,12 +184,19 @@ struct path_nee_rec_t {
     uint32_t src_kind, src_tuid;
     float recp_spectral_pd;
 };
+//   * split_gather (in) / need_gather (out): the classified-edge set of a region the bounded per-lane means cannot hold (a truncated
+//     triangle list, more than kMaxEdgeIds / 3 listed triangles, or a ballistic hit's cone query beyond a small work budget) is left to a
+//     wavefront (k_path_edges: closest cone hit, then a walk of the whole final slab with the edge bitmap — any number of edges); the step returns
+//     with nothing committed and is re-run with has_gather / gather_edges / gather_n.
 struct path_defer_t {
     uint32_t have_prev_f;
     float prev_f;
     uint32_t defer_nee, nee_pending;
+    uint32_t split_gather, need_gather, has_gather, gather_n;
+    const uint32_t* gather_edges;
     path_nee_rec_t nee;
 };
+constexpr uint32_t kPathEdgeQueryBudget = 96;   // work units of the per-lane attempt at a ballistic hit's edge query (device)
 
 // integrate_forward / integrate_backward up to the first random_walk call (plt_path_detail.hpp:772-828)
 WT_HD void path_generate(const scene_t& sc, uint64_t seed, uint64_t sample_id, uint32_t px, uint32_t py, path_walk_t& pw) {
@@ -322,34 +329,54 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
     }
 
     // ---- edges of the interaction region (plt_path_detail.hpp:593, 684-689)
-    uint32_t edge_ids[kMaxEdgeIds];
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr uint32_t kEdgeCap = kMaxEdgeIds;   // per lane; larger sets come from k_path_edges
+    uint32_t edge_ids_local[kEdgeCap];
+#else
+    constexpr uint32_t kEdgeCap = 1u << 16;      // the CPU checker: never the limit
+    static thread_local uint32_t edge_ids_local[kEdgeCap];
+#endif
+    const uint32_t* edge_ids = edge_ids_local;
     uint32_t n_edge_ids = 0;
-    // (a region that overflowed the bounded device list gets its edge set from a walk of the whole region — bvh_gather_edges, wt/bvh.h:
-    // the edges of every triangle meeting the cone inside the final slab, the reference's unbounded list; the CPU checker's lists
-    // never overflow)
-    if (sc.opts.FSD && !is_ballistic) {
+    // (a region that overflowed the bounded device list gets its edge set from a walk of the whole region: the edges of every triangle
+    // meeting the cone inside the final slab, the reference's unbounded list — by a wavefront on the device (see path_defer_t), by
+    // bvh_gather_edges otherwise; the CPU checker's lists never overflow)
+    const bool split = defer && defer->split_gather;
+    if (defer && defer->has_gather && ((sc.opts.FSD && !is_ballistic) || (is_ballistic && !beam_is_ray(beam) && !force_rt))) {
+        edge_ids = defer->gather_edges;
+        n_edge_ids = defer->gather_n;
+        if (is_ballistic && ctr) ctr->cone_queries++;
+    } else if (sc.opts.FSD && !is_ballistic) {
+        if (split && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3)) {
+            defer->need_gather = 1;
+            return false;   // nothing has been committed
+        }
         if (tr.overflow > 0) {
             cone_t tcone = envelope;
             tcone.o = origin_wp;
             uint32_t dropped = 0;
-            n_edge_ids = bvh_gather_edges(sc, tcone, range_t{dist_to_interaction, dist_to_interaction + tr.region_depth}, stack, edge_ids, kMaxEdgeIds, dropped);
+            n_edge_ids = bvh_gather_edges(sc, tcone, range_t{dist_to_interaction, dist_to_interaction + tr.region_depth}, stack, edge_ids_local, kEdgeCap, dropped);
             if (ctr) ctr->edge_overflow += dropped;
         } else
-            n_edge_ids = path_gather_edge_ids(sc, tris, tr.ntris, edge_ids, ctr);
+            n_edge_ids = path_gather_edge_ids(sc, tris, tr.ntris, edge_ids_local, ctr, kEdgeCap);
     } else if (is_ballistic && !beam_is_ray(beam) && !force_rt) {
         // ballistic: find the edges around the intersection with a cone query over a slab of the region's depth
         const float zdist = cone_axes(envelope, dist_to_interaction).x * kMajorAxisToZScale;
         const range_t sr{dist_to_interaction - zdist / 2.f, dist_to_interaction + zdist / 2.f};
         cone_hit_t ch;
         // (budget: a full per-lane stack aborts the query instead of silently dropping children, bvh.h)
-        bvh_traverse_cone(sc, envelope, sr, 1.f, stack, tris, ch, nullptr, 1u << 30);
+        bvh_traverse_cone(sc, envelope, sr, 1.f, stack, tris, ch, nullptr, split ? kPathEdgeQueryBudget : 1u << 30);
+        if (split && (ch.aborted || ch.overflow > 0 || ch.ntris > kMaxEdgeIds / 3)) {
+            defer->need_gather = 1;
+            return false;   // nothing has been committed
+        }
         if (ctr) ctr->cone_queries++;
         if (ch.aborted || ch.overflow > 0) {
             uint32_t dropped = 0;
-            n_edge_ids = bvh_gather_edges(sc, envelope, ch.aborted ? sr : cone_search_range(envelope, sr, ch.dist, 1.f), stack, edge_ids, kMaxEdgeIds, dropped);
+            n_edge_ids = bvh_gather_edges(sc, envelope, ch.aborted ? sr : cone_search_range(envelope, sr, ch.dist, 1.f), stack, edge_ids_local, kEdgeCap, dropped);
             if (ctr) ctr->edge_overflow += dropped;
         } else
-            n_edge_ids = path_gather_edge_ids(sc, tris, ch.ntris, edge_ids, ctr);
+            n_edge_ids = path_gather_edge_ids(sc, tris, ch.ntris, edge_ids_local, ctr, kEdgeCap);
     }
 
     // ---- construct the fsd BSDF (plt_path_detail.hpp:692-709)

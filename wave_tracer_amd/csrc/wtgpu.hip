@@ -142,6 +142,7 @@ struct device_state_t {
     uint32_t* neeq = nullptr;                  // walks with a deferred next-event estimation of this round (k_path_nee)
     float* fsd_f = nullptr;                    // [cap] k_path_fsd's result per walk
     path_nee_rec_t* nee_recs = nullptr;        // [cap]
+    uint2* gather_info = nullptr;              // [cap] k_path_edges' result per walk: (offset into the round's edge pool, number of ids)
     unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
@@ -1151,11 +1152,84 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, uint32_t ro
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round, uint32_t round) {
+// plt_path, the classified-edge set of regions the per-lane means cannot hold (path_defer_t::need_gather): one wavefront per walk.  Non-ballistic
+// hit: the triangles of the interaction region [dist, dist + depth] of the traced cone.  Ballistic hit: the reference's cone query around the hit
+// (plt_path_detail.hpp:645-650: closest cone hit inside dist -+ z / 2, then every triangle inside the final slab) — closest hit by the
+// wave-cooperative query, then a walk of that slab.  Edge ids through the LDS bitmap: any number, sorted, into the round's edge pool.
+__global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a) {
+    __shared__ coop_shared_t csh;
+    __shared__ coop_gather_shared_t sh;
+    __shared__ coop_edges_t eg;
+    __shared__ uint32_t s_item;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_GATHER_COUNT];
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.gather_queue[item];
+        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
+        const uint32_t tr_ballistic = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ballistic)];
+        const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const float depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
+        const vec3 origin{__uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.x)]), __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.y)]),
+                          __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
+        const bool ballistic = tr_ballistic || cone_is_ray(wk.env);
+        cone_t cone = wk.env;
+        range_t slab{dist, dist + depth};
+        bool any = true;
+        if (!ballistic)
+            cone.o = origin;   // the traced (self-intersection-offset) cone, like the record's triangles
+        else {
+            const float zdist = cone_axes(cone, dist).x * kMajorAxisToZScale;
+            const range_t sr{dist - zdist / 2.f, dist + zdist / 2.f};
+            cone_hit_t ch;
+            const uint_list_t none{nullptr, 1u, 0u};
+            coop_cone(a.sc, cone, sr, 1.f, csh, none, ch);
+            any = ch.ntris + ch.overflow > 0;
+            slab = cone_search_range(cone, sr, ch.dist, 1.f);
+            __syncthreads();
+        }
+        uint32_t n_edges = 0, off = 0, dropped = 0;
+        if (any) {
+            const gather_out_t g = coop_gather(a.sc, cone, slab, cone, cone_frame(cone), slab, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
+            __syncthreads();
+            if (a.sc.n_edges <= kCoopEdgeBits) {
+                n_edges = coop_edge_count(a.sc, eg);
+                if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
+                __syncthreads();
+                off = s_item;
+                __syncthreads();
+                if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported
+                    dropped = n_edges;
+                    n_edges = 0;
+                } else
+                    coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
+            } else {   // scenes with more classified edges than the bitmap holds: the sorted 96-entry list, into the walk's list slot
+                n_edges = g.n_edges;
+                dropped = g.edge_overflow;
+                off = 0xFFFFFFFFu;
+                uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
+                for (uint32_t j = threadIdx.x; j < n_edges; j += 64) dst[j] = eg.edge_ids[j];
+            }
+        }
+        if (threadIdx.x == 0) {
+            a.st.gather_info[w] = make_uint2(off, n_edges);
+            if (dropped && a.count_stats) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, edge_overflow) / sizeof(unsigned long long), (unsigned long long)dropped);
+        }
+        __syncthreads();
+    }
+}
+
+// PASS 0: the round's queue; walks whose classified-edge set needs a wavefront are only queued for k_path_edges.  PASS 1: those walks, with it.
+template <int PASS>
+__device__ inline __attribute__((always_inline)) void path_interact_body(const launch_args_t& a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = queue_count(ctl, in);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t n = PASS ? ctl[CTL_GATHER_COUNT] : queue_count(ctl, in);
+    if (!PASS && blockIdx.x == 0 && threadIdx.x == 0) {
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
         ctl[CTL_HEAD_TRACE] = 0;
@@ -1169,12 +1243,12 @@ __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, in
     const utd_pool_t pool{a.st.utd[round & 1u], ctl + CTL_UTD_COUNT0 + (round & 1u), a.st.utd_cap};
     const utd_edge_rec_t* prev_pool = a.st.utd[(round + 1u) & 1u];
     for (;;) {
-        const uint32_t qi = wave_grab(ctl + CTL_HEAD_INTERACT) + (threadIdx.x & 63);
+        const uint32_t qi = wave_grab(ctl + (PASS ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
-        bool cont = false, carries_fsd = false, nee = false;
+        bool cont = false, carries_fsd = false, nee = false, gather = false;
         uint32_t w = 0;
         if (qi < n) {
-            w = queue_walk(a, ctl, in, qi, first_round);
+            w = PASS ? a.st.gather_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
             const uint64_t j = a.j0 + w;
             const uint32_t pix = (uint32_t)(j % a.npix);
             const uint64_t s = a.sample_begin + j / a.npix;
@@ -1190,20 +1264,36 @@ __global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, in
             defer.prev_f = pw.has_fsd ? a.st.fsd_f[w] : 0.f;
             defer.defer_nee = 1;
             defer.nee_pending = 0;
+            defer.split_gather = PASS ? 0u : 1u;
+            defer.need_gather = 0;
+            defer.has_gather = PASS ? 1u : 0u;
+            defer.gather_n = 0;
+            defer.gather_edges = nullptr;
+            if (PASS) {
+                const uint2 gi = a.st.gather_info[w];
+                defer.gather_n = gi.y;
+                defer.gather_edges = gi.x != 0xFFFFFFFFu ? a.st.epool + gi.x : slot;
+            }
             cont = path_walk_step(a.sc, pw, tr, tris, prev_pool, pool, a.film, a.seed, sample_id, stream, stack, &ctr, &defer);
-            if (!cont) path_finish(a.sc, a.film, pw);
-            pw.w.active = cont ? 1u : 0u;
-            soa_store(a.st.walks, a.st.walk_words, w, pw);
-            carries_fsd = cont && pw.has_fsd;
-            nee = defer.nee_pending != 0;
-            if (nee) a.st.nee_recs[w] = defer.nee;
+            gather = defer.need_gather != 0;
+            if (!gather) {
+                if (!cont) path_finish(a.sc, a.film, pw);
+                pw.w.active = cont ? 1u : 0u;
+                soa_store(a.st.walks, a.st.walk_words, w, pw);
+                carries_fsd = cont && pw.has_fsd;
+                nee = defer.nee_pending != 0;
+                if (nee) a.st.nee_recs[w] = defer.nee;
+            }
         }
-        queue_append(a, ctl, 1 - in, cont, w);
+        if (!PASS) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, gather, w);
+        queue_append(a, ctl, 1 - in, cont && !gather, w);
         wave_append(a.st.fsdq[(round + 1u) & 1u], ctl + CTL_FSDQ_COUNT0 + ((round + 1u) & 1u), carries_fsd, w);
         wave_append(a.st.neeq, ctl + CTL_NEEQ_COUNT, nee, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
+__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round, uint32_t round) { path_interact_body<0>(a, in, first_round, round); }
+__global__ void __launch_bounds__(kBlock, 2) k_path_interact_b(launch_args_t a, int in, uint32_t round) { path_interact_body<1>(a, in, 0, round); }
 
 // plt_path, after the interaction step: next-event estimation towards the virtual sensor through the aperture the step just built (nee_forward,
 // plt_path_detail.hpp:474-518) — one wavefront per walk: coherent UTD sum (coop_do_fsd), beam transform, integrate_beams, light-image splat.
@@ -1919,6 +2009,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         if ((rc = dmalloc(s, &st.neeq, path_mode ? (size_t)st.cap : 1))) return rc;
         if ((rc = dmalloc(s, &st.fsd_f, path_mode ? (size_t)st.cap : 1))) return rc;
         if ((rc = dmalloc(s, &st.nee_recs, path_mode ? (size_t)st.cap : 1))) return rc;
+        if ((rc = dmalloc(s, &st.gather_info, path_mode ? (size_t)st.cap : 1))) return rc;
         if ((rc = dmalloc(s, &st.verts, path_mode ? 1 : (size_t)st.max_verts * kVertexWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
         if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
@@ -1933,7 +2024,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         st.ftask_cap = path_mode ? 1u : (1u << 22);
         if ((rc = dmalloc(s, &st.ftasks, (size_t)st.ftask_cap))) return rc;
         if ((rc = dmalloc(s, &st.facc, path_mode ? 1 : W2))) return rc;
-        st.epool_cap = path_mode ? 1u : (1u << 23);
+        st.epool_cap = 1u << 23;
         if ((rc = dmalloc(s, &st.epool, (size_t)st.epool_cap))) return rc;
         if ((rc = dmalloc(s, &st.ctl, (size_t)CTL_WORDS))) return rc;
         HIP_CHECK(hipMemset(st.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
@@ -2114,6 +2205,8 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             if (path_mode) {
                 if (round > 0) hipLaunchKernelGGL(k_path_fsd, dim3(gh), dim3(64), 0, st_, a, round);
                 if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                hipLaunchKernelGGL(k_path_edges, dim3(gh), dim3(64), 0, st_, a);
+                hipLaunchKernelGGL(k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, in, round);
                 hipLaunchKernelGGL(k_path_nee, dim3(gh), dim3(64), 0, st_, a, round);
                 rec();
                 rec();
