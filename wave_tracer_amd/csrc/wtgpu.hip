@@ -134,6 +134,11 @@ struct device_state_t {
     uint32_t* strat_count = nullptr;    // [kNumKeys]
     uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
     double* lacc = nullptr;             // [4][cap] per-sample sum of the t>1 strategies' fluxes
+    unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
+};
+// plt_path only — a device-resident block the path kernels get a pointer to (launch_args_t stays below 1024 bytes: by-value kernel
+// arguments beyond that cost 40 % of a plt_bdpt pass with four streams, measured: 976 -> 1048 bytes, 15.4 -> 11.1 Msamples/s).
+struct path_state_t {
     // plt_path: wedge records of the walks' UTD apertures, two pools used alternately (round parity: an aperture built in round r is evaluated in
     // round r + 1), each reset when its round begins; queues of the wave-per-walk UTD kernels and what they exchange with k_path_interact
     utd_edge_rec_t* utd[2] = {nullptr, nullptr};
@@ -143,7 +148,6 @@ struct device_state_t {
     float* fsd_f = nullptr;                    // [cap] k_path_fsd's result per walk
     path_nee_rec_t* nee_recs = nullptr;        // [cap]
     uint2* gather_info = nullptr;              // [cap] k_path_edges' result per walk: (offset into the round's edge pool, number of ids)
-    unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
 };
 constexpr size_t kWalkWords = sizeof(walk_t) / 4;
 constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
@@ -168,6 +172,7 @@ struct wtgpu_scene {
     int device = -1;
     bool uploaded = false;
     std::vector<device_state_t> slices;              // per-batch path state, one slice per internal stream
+    std::vector<const path_state_t*> d_path_slices;  // ... and its plt_path part (device copies)
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> ev_done;
     hipEvent_t ev_begin = nullptr;
@@ -232,9 +237,10 @@ struct launch_args_t {
     uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
 };
 
-__device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s) {
+// (block size as a constant: blockDim would pull 256 bytes of hidden kernel arguments into the kernel-argument segment)
+__device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s, uint32_t block = kBlock) {
     s.p = lds + threadIdx.x;
-    s.stride = blockDim.x;
+    s.stride = block;
     s.n_fast = kLdsStack;
     s.q = spill;
     s.cap = kLdsStack + kSpillStack;
@@ -252,7 +258,7 @@ __device__ inline void flush_counters(unsigned long long* g, const bdpt_counters
 }
 
 __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) {
         uint32_t* ctl = a.st.ctl;
         ctl[CTL_COUNT0] = 2 * a.nb;
@@ -1055,7 +1061,7 @@ __global__ void __launch_bounds__(WTGPU_HARD_BLOCK) k_interact_c_hard(launch_arg
 // prefix of the walk record), the interaction step is path_walk_step (wt/path.h): UTD evaluation of the previous aperture (shadow
 // rays through the LDS stack), primary triangle, edge query, aperture construction, NEE / sensing splats (f64 atomics), sampling.
 __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i == 0) {
         uint32_t* ctl = a.st.ctl;
         ctl[CTL_COUNT0] = a.nb;
@@ -1119,7 +1125,8 @@ __device__ inline float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_s
 
 // plt_path, before the interaction step: the coherent UTD sum of the aperture the walk built in the previous round towards this round's
 // interaction point (plt_path_detail.hpp:616-636) — one wavefront per walk, queue filled by the previous round's k_path_interact.
-__global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, uint32_t round) {
+__global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_state_t* __restrict__ ps, uint32_t round) {
+    const path_state_t& P = *ps;
     __shared__ stack_entry_t lds[kLdsStack * 64];
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
@@ -1127,17 +1134,17 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, uint32_t ro
     const uint32_t n = ctl[CTL_FSDQ_COUNT0 + qin];
     stack_entry_t spill[kSpillStack];
     stack_ref_t stack;
-    lds_stack(lds, spill, stack);
+    lds_stack(lds, spill, stack, 64u);
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
-    const utd_edge_rec_t* prev_pool = a.st.utd[(round + 1u) & 1u];
+    const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSDQ_HEAD, 1u);
         __syncthreads();
         const uint32_t item = s_item;
         __syncthreads();
         if (item >= n) break;
-        const uint32_t w = a.st.fsdq[qin][item];
+        const uint32_t w = P.fsdq[qin][item];
         const uint32_t empty = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)];
         if (empty) continue;   // (the step ends before do_fsd: plt_path_detail.hpp:577-581)
         path_walk_t pw;
@@ -1147,7 +1154,7 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, uint32_t ro
         const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
         const vec3 interaction_wp = origin + dist * pw.w.beam.env.d;
         const float f = coop_do_fsd(a.sc, pw.prev_beam.env, path_geo_prev(pw.w), interaction_wp, pw.ap, prev_pool + pw.ap.edge_offset, pw.w.beam.k, stack, &ctr);
-        if (threadIdx.x == 0) a.st.fsd_f[w] = f;
+        if (threadIdx.x == 0) P.fsd_f[w] = f;
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
@@ -1156,7 +1163,8 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, uint32_t ro
 // hit: the triangles of the interaction region [dist, dist + depth] of the traced cone.  Ballistic hit: the reference's cone query around the hit
 // (plt_path_detail.hpp:645-650: closest cone hit inside dist -+ z / 2, then every triangle inside the final slab) — closest hit by the
 // wave-cooperative query, then a walk of that slab.  Edge ids through the LDS bitmap: any number, sorted, into the round's edge pool.
-__global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a) {
+__global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const path_state_t* __restrict__ ps) {
+    const path_state_t& P = *ps;
     __shared__ coop_shared_t csh;
     __shared__ coop_gather_shared_t sh;
     __shared__ coop_edges_t eg;
@@ -1216,7 +1224,7 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a) {
             }
         }
         if (threadIdx.x == 0) {
-            a.st.gather_info[w] = make_uint2(off, n_edges);
+            P.gather_info[w] = make_uint2(off, n_edges);
             if (dropped && a.count_stats) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, edge_overflow) / sizeof(unsigned long long), (unsigned long long)dropped);
         }
         __syncthreads();
@@ -1225,7 +1233,7 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a) {
 
 // PASS 0: the round's queue; walks whose classified-edge set needs a wavefront are only queued for k_path_edges.  PASS 1: those walks, with it.
 template <int PASS>
-__device__ inline __attribute__((always_inline)) void path_interact_body(const launch_args_t& a, int in, int first_round, uint32_t round) {
+__device__ inline __attribute__((always_inline)) void path_interact_body(const launch_args_t& a, const path_state_t& P, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = PASS ? ctl[CTL_GATHER_COUNT] : queue_count(ctl, in);
@@ -1240,8 +1248,8 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
     stack_ref_t stack;
     lds_stack(lds, spill, stack);
     const uint32_t stream = a.sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
-    const utd_pool_t pool{a.st.utd[round & 1u], ctl + CTL_UTD_COUNT0 + (round & 1u), a.st.utd_cap};
-    const utd_edge_rec_t* prev_pool = a.st.utd[(round + 1u) & 1u];
+    const utd_pool_t pool{P.utd[round & 1u], ctl + CTL_UTD_COUNT0 + (round & 1u), P.utd_cap};
+    const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
     for (;;) {
         const uint32_t qi = wave_grab(ctl + (PASS ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
         if (qi - (threadIdx.x & 63) >= n) break;
@@ -1261,7 +1269,7 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
             const uint_list_t tris{slot, 1u, kMaxConeTris, reinterpret_cast<float*>(slot + kMaxConeTris)};
             path_defer_t defer;
             defer.have_prev_f = pw.has_fsd;   // evaluated by k_path_fsd (this round), one lane per wedge
-            defer.prev_f = pw.has_fsd ? a.st.fsd_f[w] : 0.f;
+            defer.prev_f = pw.has_fsd ? P.fsd_f[w] : 0.f;
             defer.defer_nee = 1;
             defer.nee_pending = 0;
             defer.split_gather = PASS ? 0u : 1u;
@@ -1270,7 +1278,7 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
             defer.gather_n = 0;
             defer.gather_edges = nullptr;
             if (PASS) {
-                const uint2 gi = a.st.gather_info[w];
+                const uint2 gi = P.gather_info[w];
                 defer.gather_n = gi.y;
                 defer.gather_edges = gi.x != 0xFFFFFFFFu ? a.st.epool + gi.x : slot;
             }
@@ -1282,40 +1290,41 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
                 soa_store(a.st.walks, a.st.walk_words, w, pw);
                 carries_fsd = cont && pw.has_fsd;
                 nee = defer.nee_pending != 0;
-                if (nee) a.st.nee_recs[w] = defer.nee;
+                if (nee) P.nee_recs[w] = defer.nee;
             }
         }
         if (!PASS) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, gather, w);
         queue_append(a, ctl, 1 - in, cont && !gather, w);
-        wave_append(a.st.fsdq[(round + 1u) & 1u], ctl + CTL_FSDQ_COUNT0 + ((round + 1u) & 1u), carries_fsd, w);
-        wave_append(a.st.neeq, ctl + CTL_NEEQ_COUNT, nee, w);
+        wave_append(P.fsdq[(round + 1u) & 1u], ctl + CTL_FSDQ_COUNT0 + ((round + 1u) & 1u), carries_fsd, w);
+        wave_append(P.neeq, ctl + CTL_NEEQ_COUNT, nee, w);
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, int in, int first_round, uint32_t round) { path_interact_body<0>(a, in, first_round, round); }
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact_b(launch_args_t a, int in, uint32_t round) { path_interact_body<1>(a, in, 0, round); }
+__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, const path_state_t* __restrict__ ps, int in, int first_round, uint32_t round) { path_interact_body<0>(a, *ps, in, first_round, round); }
+__global__ void __launch_bounds__(kBlock, 2) k_path_interact_b(launch_args_t a, const path_state_t* __restrict__ ps, int in, uint32_t round) { path_interact_body<1>(a, *ps, in, 0, round); }
 
 // plt_path, after the interaction step: next-event estimation towards the virtual sensor through the aperture the step just built (nee_forward,
 // plt_path_detail.hpp:474-518) — one wavefront per walk: coherent UTD sum (coop_do_fsd), beam transform, integrate_beams, light-image splat.
-__global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, uint32_t round) {
+__global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, const path_state_t* __restrict__ ps, uint32_t round) {
+    const path_state_t& P = *ps;
     __shared__ stack_entry_t lds[kLdsStack * 64];
     __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_NEEQ_COUNT];
     stack_entry_t spill[kSpillStack];
     stack_ref_t stack;
-    lds_stack(lds, spill, stack);
+    lds_stack(lds, spill, stack, 64u);
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
-    const utd_edge_rec_t* cur_pool = a.st.utd[round & 1u];
+    const utd_edge_rec_t* cur_pool = P.utd[round & 1u];
     for (;;) {
         if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_NEEQ_HEAD, 1u);
         __syncthreads();
         const uint32_t item = s_item;
         __syncthreads();
         if (item >= n) break;
-        const uint32_t w = a.st.neeq[item];
-        const path_nee_rec_t r = a.st.nee_recs[w];   // uniform address
+        const uint32_t w = P.neeq[item];
+        const path_nee_rec_t r = P.nee_recs[w];   // uniform address
         utd_aperture_t ap;
         soa_load(a.st.walks + offsetof(path_walk_t, ap) / 4, a.st.walk_words, w, ap);   // the aperture k_path_interact just stored
         const path_geo_t src_geo{r.src_wp, r.src_kind, r.src_ng, r.src_tuid};
@@ -1334,10 +1343,11 @@ __global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, uint32_t ro
 }
 
 // walks still active after the last round (iteration cap): backward transport splats what they gathered
+constexpr uint32_t kFlushGrid = 64;
 __global__ void __launch_bounds__(kBlock) k_path_flush(launch_args_t a, int in) {
     const uint32_t n = queue_count(a.st.ctl, in);
     const size_t W2 = 2 * (size_t)a.st.cap;
-    for (uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x; qi < n; qi += gridDim.x * blockDim.x) {
+    for (uint32_t qi = blockIdx.x * kBlock + threadIdx.x; qi < n; qi += kFlushGrid * kBlock) {
         const uint32_t w = queue_walk(a, a.st.ctl, in, qi, 0);
         path_walk_t pw;
         soa_load(a.st.walks, a.st.walk_words, w, pw);
@@ -1386,9 +1396,9 @@ __device__ inline int wave_max_i(int v) {
 constexpr int kEnumBlock = 1024;
 __global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
     __shared__ uint32_t s_cnt[kNumKeys], s_base[kNumKeys];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * kEnumBlock + threadIdx.x;
     const size_t W2 = 2 * (size_t)a.st.cap;
-    for (uint32_t k = threadIdx.x; k < kNumKeys; k += blockDim.x) s_cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < kNumKeys; k += kEnumBlock) s_cnt[k] = 0;
     int nT = -1, nS = -1;
     if (i < a.nb) {
         nT = (int)a.st.walks[(size_t)(i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
@@ -1403,7 +1413,7 @@ __global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
         for (int sk = 0; sk <= kS; ++sk)
             if (strategy_class_valid(a.sc.opts, sk, tk, nS, nT)) atomicAdd(&s_cnt[(uint32_t)tk * kKeyDim + (uint32_t)sk], 1u);
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kNumKeys; k += blockDim.x) {
+    for (uint32_t k = threadIdx.x; k < kNumKeys; k += kEnumBlock) {
         const uint32_t c = s_cnt[k];
         s_base[k] = c ? atomicAdd(a.st.strat_count + k, c) : 0u;
         s_cnt[k] = 0;
@@ -1440,7 +1450,7 @@ __device__ inline __attribute__((always_inline)) void connect_strat_body(const l
     constexpr int K = (int)kKeyDim - 1;
     // flattened item space: OPEN = false all buckets (items of the open ones are skipped), OPEN = true the open buckets only
     if (!OPEN) {
-        for (uint32_t k = threadIdx.x; k <= kNumKeys; k += blockDim.x) s_prefix[k] = a.st.strat_prefix[k];
+        for (uint32_t k = threadIdx.x; k <= kNumKeys; k += kBlock) s_prefix[k] = a.st.strat_prefix[k];
     } else if (threadIdx.x == 0) {
         uint32_t acc = 0;
         for (uint32_t k = 0; k < kNumKeys; ++k) {
@@ -1506,7 +1516,7 @@ __device__ inline __attribute__((always_inline)) void connect_strat_body(const l
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(launch_args_t a) { connect_strat_body<false>(a); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat_open(launch_args_t a) { connect_strat_body<true>(a); }
 __global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.nb) return;
     sample_ctx_t ctx;
     soa_load(a.st.ctx, kCtxWords, i, ctx);
@@ -1525,7 +1535,7 @@ __global__ void __launch_bounds__(256) k_calib_copy(const uint32_t* in, uint32_t
 // ---- per-query kernels (traversal parity tests) --------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_trace_rays(scene_t sc, const float* rays, uint32_t n, float* dist, uint32_t* tuid, float* bary, uint32_t* front) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     stack_entry_t spill[kSpillStack];
     stack_ref_t stack;
@@ -1560,7 +1570,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays_g8(scene_t sc, const floa
 __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
                                                            uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     // (the CPU checker's 128-entry stack: this kernel answers every query by itself — in the pipeline a lane whose 64-entry stack
     // fills up hands the query to a wavefront, k_trace_heavy)
@@ -2001,15 +2011,22 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         const size_t W2 = 2 * (size_t)st.cap;
         const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;   // plt_path: no vertex store / strategy buckets / Fraunhofer pool
         if ((rc = dmalloc(s, &st.walks, (path_mode ? kPathWalkWords : kWalkWords) * W2))) return rc;
-        st.utd_cap = path_mode ? (uint32_t)std::min<uint64_t>(48ull * st.cap + 65536, 1ull << 28) : 1u;   // measured mean on the 576-building etoile: 11 wedges per aperture
-        for (int q = 0; q < 2; ++q) {
-            if ((rc = dmalloc(s, &st.utd[q], (size_t)st.utd_cap))) return rc;
-            if ((rc = dmalloc(s, &st.fsdq[q], path_mode ? (size_t)st.cap : 1))) return rc;
+        {
+            path_state_t P;
+            P.utd_cap = path_mode ? (uint32_t)std::min<uint64_t>(48ull * st.cap + 65536, 1ull << 28) : 1u;   // measured mean on the 576-building etoile: 11 wedges per aperture
+            for (int q = 0; q < 2; ++q) {
+                if ((rc = dmalloc(s, &P.utd[q], (size_t)P.utd_cap))) return rc;
+                if ((rc = dmalloc(s, &P.fsdq[q], path_mode ? (size_t)st.cap : 1))) return rc;
+            }
+            if ((rc = dmalloc(s, &P.neeq, path_mode ? (size_t)st.cap : 1))) return rc;
+            if ((rc = dmalloc(s, &P.fsd_f, path_mode ? (size_t)st.cap : 1))) return rc;
+            if ((rc = dmalloc(s, &P.nee_recs, path_mode ? (size_t)st.cap : 1))) return rc;
+            if ((rc = dmalloc(s, &P.gather_info, path_mode ? (size_t)st.cap : 1))) return rc;
+            path_state_t* dP = nullptr;
+            if ((rc = dmalloc(s, &dP, 1))) return rc;
+            HIP_CHECK(hipMemcpy(dP, &P, sizeof(P), hipMemcpyHostToDevice));
+            s->d_path_slices.push_back(dP);
         }
-        if ((rc = dmalloc(s, &st.neeq, path_mode ? (size_t)st.cap : 1))) return rc;
-        if ((rc = dmalloc(s, &st.fsd_f, path_mode ? (size_t)st.cap : 1))) return rc;
-        if ((rc = dmalloc(s, &st.nee_recs, path_mode ? (size_t)st.cap : 1))) return rc;
-        if ((rc = dmalloc(s, &st.gather_info, path_mode ? (size_t)st.cap : 1))) return rc;
         if ((rc = dmalloc(s, &st.verts, path_mode ? 1 : (size_t)st.max_verts * kVertexWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
         if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
@@ -2114,7 +2131,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     const uint64_t total = npix * (se - sb);
     if (total == 0) return WTGPU_OK;
     launch_args_t a;
-    static_assert(sizeof(launch_args_t) <= 4096, "kernel argument too large");
+    static_assert(sizeof(launch_args_t) <= 984, "by-value kernel arguments beyond 1 KB serialise the streams (see path_state_t)");
     a.sc = s->dev;
     a.film = film_t{d_value, d_weight, d_light, h.sensor.width, h.sensor.height, h.sensor.channels};
     a.seed = seed;
@@ -2159,6 +2176,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         if (rc) return rc;
         const uint32_t nb = (uint32_t)std::min<uint64_t>(cap, total - j0);
         a.st = s->slices[k];
+        const path_state_t* ps = s->d_path_slices[k];
         a.j0 = j0;
         a.nb = nb;
         size_t ev = 0;
@@ -2203,11 +2221,11 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             if (dbg_stage >= 3 + 3 * (int)round) hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
             if (path_mode) {
-                if (round > 0) hipLaunchKernelGGL(k_path_fsd, dim3(gh), dim3(64), 0, st_, a, round);
-                if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
-                hipLaunchKernelGGL(k_path_edges, dim3(gh), dim3(64), 0, st_, a);
-                hipLaunchKernelGGL(k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, in, round);
-                hipLaunchKernelGGL(k_path_nee, dim3(gh), dim3(64), 0, st_, a, round);
+                if (round > 0) hipLaunchKernelGGL(k_path_fsd, dim3(gh), dim3(64), 0, st_, a, ps, round);
+                if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, ps, in, first, round);
+                hipLaunchKernelGGL(k_path_edges, dim3(gh), dim3(64), 0, st_, a, ps);
+                hipLaunchKernelGGL(k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, ps, in, round);
+                hipLaunchKernelGGL(k_path_nee, dim3(gh), dim3(64), 0, st_, a, ps, round);
                 rec();
                 rec();
                 rec();
@@ -2227,7 +2245,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             rec();
         }
         if (path_mode) {
-            hipLaunchKernelGGL(k_path_flush, dim3(64), dim3(kBlock), 0, st_, a, (int)(kMaxWalkIters & 1u));
+            hipLaunchKernelGGL(k_path_flush, dim3(kFlushGrid), dim3(kBlock), 0, st_, a, (int)(kMaxWalkIters & 1u));
         } else {
             hipLaunchKernelGGL(k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
             hipLaunchKernelGGL(k_connect_scan, dim3(1), dim3(64), 0, st_, a);
@@ -2420,6 +2438,7 @@ static void release_device(wtgpu_scene* s) {
         if (st_) (void)hipStreamDestroy(st_);
     s->streams.clear();
     s->slices.clear();
+    s->d_path_slices.clear();
     s->uploaded = false;
 }
 
