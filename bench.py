@@ -17,9 +17,10 @@ import os
 import sys
 import time
 
-# The renderer pipelines batches over 4 HIP streams (plus the caller's); the ROCm runtime reads this when libamdhip64 is loaded (import torch), its
+# The renderer pipelines batches over 3 HIP streams (plus the caller's); the ROCm runtime reads this when libamdhip64 is loaded (import torch), its
 # default of 4 hardware queues makes streams share queues and serialise (see wave_tracer_amd/api.py).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))   # the runtime's kernel-argument ring per stream (default 1 MiB: a full ring blocks the enqueueing thread)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

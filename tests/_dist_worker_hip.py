@@ -11,6 +11,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))   # the runtime's kernel-argument ring per stream (default 1 MiB: a full ring blocks the enqueueing thread)
 
 
 def main():

@@ -438,7 +438,7 @@ def test_two_ranks_one_gpu_sharded_render(built, tmp_path, name):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GPU_MAX_HW_QUEUES="8")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GPU_MAX_HW_QUEUES="8", HSA_KERNARG_POOL_SIZE=str(16 << 20))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(here, "_dist_worker_hip.py"), out, "6", "17", name]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

@@ -7,6 +7,7 @@ import os
 import sys
 import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))   # the runtime's kernel-argument ring per stream (default 1 MiB: a full ring blocks the enqueueing thread)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -9,6 +9,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # hardware queues and streams sharing a queue serialise (measured: 4.8 vs 3.5 Msamples/s).  The variable is read when
 # libamdhip64 is loaded, i.e. it only takes effect if this package is imported BEFORE torch (bench.py sets it itself).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# ... and stages by-value kernel arguments in a 1 MiB ring per stream: a batch enqueues ~1000 launches of ~1 KB, a full ring blocks the
+# enqueueing thread until the GPU catches up, and the internal streams serialise behind it (measured: enqueue 209 ms -> 16 ms per pass).
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))
 
 
 def lib_path():
@@ -75,6 +78,7 @@ def load_library():
     # The renderer pipelines batches over several HIP streams; the ROCm runtime maps streams onto 4 hardware queues by default
     # and streams sharing a queue serialise.  Must be set before the HIP runtime initialises (its first API call).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(16 << 20))
     try:
         import torch  # noqa: F401
     except ImportError:

@@ -19,6 +19,7 @@
 //
 // There is no CPU fallback in this file: every entry point that computes requires a HIP device.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <rccl/rccl.h>
 
 #include <atomic>
@@ -161,6 +162,7 @@ constexpr size_t kProfSlots = 128;   // WTGPU_PROFILE scratch counters behind th
 struct chunk_rec_t {
     std::vector<hipEvent_t> ev;   // [0] start, [1] after generate, then 3 per round (trace, heavy, interact), last: after connect
     uint32_t* h_ctl = nullptr;    // pinned snapshot of the slice's control block after the batch
+    hipEvent_t ev_stagger = nullptr;   // recorded after the batch's round `stagger_round`: the next batch (on the next stream) starts there
     bool busy = false;
 };
 
@@ -176,6 +178,7 @@ struct wtgpu_scene {
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> ev_done;
     hipEvent_t ev_begin = nullptr;
+    hipEvent_t ev_stagger_last = nullptr;   // the previous batch's stagger event (owned by its record)
     std::vector<chunk_rec_t> recs;                   // in-flight batch records (events + control block snapshot)
     size_t rec_next = 0;
     bool timing = true;
@@ -189,7 +192,7 @@ struct wtgpu_scene {
     size_t query_scratch_bytes = 0;
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
-        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, lane_cache = 1, heavy_cache = 1, split_queues = 1;
+        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 6, shrink_f1 = 4, shrink_r2 = 12, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
@@ -482,16 +485,28 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
     memset(&aw, 0, sizeof(aw));
     memset(&q, 0, sizeof(q));
     bool exhausted = false;   // wave-uniform: the queue holds no more walks
+#ifdef WTGPU_REFILL_PROF
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pl[6] = {0, 0, 0, 0, 0, 0};
+    long long pt;
+#define RP_BEGIN() pt = clock64()
+#define RP_END(i, mask) do { const long long d_ = clock64() - pt; pc[i] += (unsigned long long)d_; pl[i] += (unsigned long long)d_ * (unsigned long long)__popcll(mask); } while (0)
+#else
+#define RP_BEGIN()
+#define RP_END(i, mask)
+#endif
     for (;;) {
         // ---- service section
         bool fin = false;
         trav_result_t r;
+        RP_BEGIN();
+        const unsigned long long m_srv = __ballot(st == 2);
         if (st == 2) {
             cq_end(env, tris, q);
             fin = aw_query_done(a.sc, env, aw, q.rec, r);
             if (!fin) fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
             st = fin ? 0 : 1;
         }
+        RP_END(0, m_srv);
         // (records of finished walks are stored below, together with those of freshly fetched walks that need no cone query)
         uint32_t w_fin = w;
         const int n_idle = __popcll(__ballot(st == 0 && !fin)), n_run = __popcll(__ballot(st == 1));
@@ -504,6 +519,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             base = (uint32_t)__shfl((int)base, 0, 64);
             if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
             const uint32_t qi = base + (uint32_t)__popcll(im & below);
+            RP_BEGIN();
+            const unsigned long long m_f = __ballot(st == 0 && qi < n);
             if (st == 0 && qi < n) {
                 w = queue_walk(a, ctl, in, qi, first_round);
                 w_fin = w;
@@ -513,15 +530,19 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
                 env = walk_trace_envelope(a.sc, wk);
                 ray_hit_t ah;
+                // (the axis query in a kernel of its own — 92 registers, all lanes busy — was measured and is no faster: 60 vs 56 ms per pass)
                 const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
                 aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
                 aw.use_cache = a.lane_cache;
                 fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
                 st = fin ? 0 : 1;
             }
+            RP_END(1, m_f);
             fetched = true;
         }
         // store the records of the walks that ended in this section (convergent: the queue append is a wave operation)
+        RP_BEGIN();
+        const unsigned long long m_st = __ballot(fin);
         {
             const bool heavy = fin && r.aborted == 1;
             if (fin) {
@@ -548,6 +569,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             }
             wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w_fin);
         }
+        RP_END(2, m_st);
         // walks that ended left their lanes free: fetch (more) before traversing
         if (fetched || any_fin) continue;
         const int running = __popcll(__ballot(st == 1));
@@ -563,16 +585,30 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 const bool at_node = st == 1 && q.leaf == 0 && q.s > 0;
                 const unsigned long long nm = __ballot(at_node);
                 if (!nm) break;
+                RP_BEGIN();
                 if (at_node) cq_node_step(a.sc, env, stack, q);
+                RP_END(3, nm);
                 if (2 * __popcll(__ballot(st == 1 && q.leaf != 0)) >= running) break;
             }
+            RP_BEGIN();
+            const unsigned long long m_leaf = __ballot(st == 1 && q.leaf != 0);
             if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
+            RP_END(4, m_leaf);
             if (st == 1 && !cq_running(q)) st = 2;
             const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
             if (waiting >= leave_at || !__ballot(st == 1)) break;
         }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
+#ifdef WTGPU_REFILL_PROF
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) {
+            atomicAdd(a.st.counters + kNumCounters + i, pc[i]);
+            atomicAdd(a.st.counters + kNumCounters + 8 + i, pl[i]);
+        }
+    // (the ray timer runs in the first fetching lane: add what other lanes hold)
+    if (lane != 0 && pc[5]) { atomicAdd(a.st.counters + kNumCounters + 5, pc[5]); atomicAdd(a.st.counters + kNumCounters + 8 + 5, pl[5]); }
+#endif
 }
 
 // Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
@@ -1676,6 +1712,11 @@ extern "C" {
 
 const char* wtgpu_last_error(void) { return g_err.c_str(); }
 
+// The HIP runtime stages by-value kernel arguments in a 1 MiB ring per stream; a batch enqueues ~1000 launches of ~1 KB, and a full ring blocks
+// the enqueueing thread until the GPU has caught up — which serialises the internal streams.  Ask for 16 MiB before the runtime reads its
+// settings (it does so at its first use; a process that initialised HIP earlier sets HSA_KERNARG_POOL_SIZE itself).
+__attribute__((constructor)) static void wtgpu_runtime_settings() { setenv("HSA_KERNARG_POOL_SIZE", "16777216", 0); }
+
 int wtgpu_scene_create_named_hooks(const char* name, const wtgpu_scene_params* params, const wtgpu_test_hooks* hooks, wtgpu_scene** out) {
     if (!name || !params || !out) return fail(WTGPU_ERR_INVALID, "null argument");
     try {
@@ -1911,6 +1952,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.decay_c = std::max(1u, u("WTGPU_DECAY_C", k.decay_c));
     k.lane_cache = u("WTGPU_LANE_CACHE", 1);
     k.heavy_cache = u("WTGPU_HEAVY_CACHE", 1);
+    k.stagger_round = std::min<uint32_t>(u("WTGPU_STAGGER_ROUND", 0), kMaxWalkIters - 1);   // 0: all streams start at once
     k.trace_refill = u("WTGPU_TRACE_REFILL", 1);   // 0: the per-lane trace kernel without lane refill (A/B reference)
     k.profile = u("WTGPU_PROFILE", 0);
     k.no_lists = getenv("WTGPU_NO_LISTS") ? 1u : 0u;
@@ -1992,7 +2034,10 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         const uint64_t fit = std::max<uint64_t>(4096, (budget_gb << 30) / per_sample);
         if (total_cap > fit) total_cap = fit;
     }
-    uint32_t n_slices = 4;
+    // Three internal streams: the tails of one batch overlap the bulk of the others.  A single batch already fills the GPU in its first rounds, so
+    // more streams only add contention — measured with an unthrottled enqueue (16 MiB kernel-argument ring), ms per pass at 1 / 2 / 3 / 4 / 6 / 8
+    // streams: 158 / 142 / 130 / 142 / 157 / 206 (headline); etoile 66 vs 78, bidir_room 69 vs 82 at 3 vs 4.
+    uint32_t n_slices = 3;
     if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
     n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, total_cap / 64));
     unsigned long long* counters = nullptr;
@@ -2066,6 +2111,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         r.ev.resize(s->timing ? 3 + 6 * (size_t)kMaxWalkIters : 1);
         for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipHostMalloc((void**)&r.h_ctl, CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&r.ev_stagger, hipEventDisableTiming));
     }
     s->uploaded = true;
     return WTGPU_OK;
@@ -2160,6 +2206,20 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     // the internal streams start after everything already enqueued on the caller's stream ...
     HIP_CHECK(hipEventRecord(s->ev_begin, caller));
     const size_t n_slices = s->slices.size();
+    // WTGPU_HOST_PROF=1: host time spent inside each kind of launch call (diagnostic)
+    static const bool hp_on = getenv("WTGPU_HOST_PROF") != nullptr;
+    double hp_t[32] = {0};
+    unsigned long hp_n[32] = {0};
+#define HP_LAUNCH(slot, ...)                                                                                              \
+    do {                                                                                                                  \
+        if (hp_on) {                                                                                                      \
+            const auto t0_ = std::chrono::steady_clock::now();                                                            \
+            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
+            hp_t[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();      \
+            hp_n[slot]++;                                                                                                 \
+        } else                                                                                                            \
+            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
+    } while (0)
     std::vector<char> used(n_slices, 0);
     const uint64_t cap = s->slices[0].cap;
     size_t chunk = 0;
@@ -2175,6 +2235,10 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         int rc = drain_rec(s, r);   // recycles the oldest record (blocks only when > recs.size() batches are in flight)
         if (rc) return rc;
         const uint32_t nb = (uint32_t)std::min<uint64_t>(cap, total - j0);
+        // WTGPU_STAGGER_ROUND=r (diagnostic, default off): a batch starts when the previous one (on the previous stream) has finished its round r.
+        // Measured on the headline workload with 4 streams: r = 0 / 3 / 6 / 10 / 16 -> 151 / 150 / 161 / 200 / 263 ms per pass: the first
+        // rounds ARE most of a batch, holding the next batch back only idles the GPU.
+        if (K.stagger_round > 0 && s->ev_stagger_last && n_slices > 1) HIP_CHECK(hipStreamWaitEvent(st_, s->ev_stagger_last, 0));
         a.st = s->slices[k];
         const path_state_t* ps = s->d_path_slices[k];
         a.j0 = j0;
@@ -2183,20 +2247,26 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         const bool tm = s->timing;
         bool ev_fail = false;
         auto rec = [&]() {
+            const auto hp0_ = std::chrono::steady_clock::now();
             if (tm && hipEventRecord(r.ev[ev++], st_) != hipSuccess) ev_fail = true;
+            if (hp_on) { hp_t[31] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp0_).count(); hp_n[31]++; }
         };
         rec();
         const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;
         const uint32_t walks_per_sample = path_mode ? 1u : 2u;
         const int dbg_stage = K.dbg_stage;
         if (path_mode)
-            hipLaunchKernelGGL(k_path_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+            HP_LAUNCH(0, k_path_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         else
-            hipLaunchKernelGGL(k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+            HP_LAUNCH(1, k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         rec();
         const uint32_t g_full = std::min<uint32_t>(grid_round, (walks_per_sample * nb + kBlock - 1) / kBlock);
         for (uint32_t round = 0; round < kMaxWalkIters; ++round) {
             const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
+            if (round == K.stagger_round && K.stagger_round > 0) {
+                HIP_CHECK(hipEventRecord(r.ev_stagger, st_));
+                s->ev_stagger_last = r.ev_stagger;
+            }
             // the queue roughly halves every round and is normally empty after ~25: later rounds get smaller persistent grids
             // (an empty launch costs its grid size; a grid that turns out too small only takes longer, the wavefronts loop)
             uint32_t g0, gh;
@@ -2213,45 +2283,45 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
             }
             if (dbg_stage >= 2 + 3 * (int)round) {
                 if (K.trace_refill)
-                    hipLaunchKernelGGL(k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                    HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
                 else
-                    hipLaunchKernelGGL(k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                    HP_LAUNCH(4, k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
             }
             rec();
-            if (dbg_stage >= 3 + 3 * (int)round) hipLaunchKernelGGL(k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
+            if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec();
             if (path_mode) {
-                if (round > 0) hipLaunchKernelGGL(k_path_fsd, dim3(gh), dim3(64), 0, st_, a, ps, round);
-                if (dbg_stage >= 4 + 3 * (int)round) hipLaunchKernelGGL(k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, ps, in, first, round);
-                hipLaunchKernelGGL(k_path_edges, dim3(gh), dim3(64), 0, st_, a, ps);
-                hipLaunchKernelGGL(k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, ps, in, round);
-                hipLaunchKernelGGL(k_path_nee, dim3(gh), dim3(64), 0, st_, a, ps, round);
+                if (round > 0) HP_LAUNCH(6, k_path_fsd, dim3(gh), dim3(64), 0, st_, a, ps, round);
+                if (dbg_stage >= 4 + 3 * (int)round) HP_LAUNCH(7, k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, ps, in, first, round);
+                HP_LAUNCH(8, k_path_edges, dim3(gh), dim3(64), 0, st_, a, ps);
+                HP_LAUNCH(9, k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, ps, in, round);
+                HP_LAUNCH(10, k_path_nee, dim3(gh), dim3(64), 0, st_, a, ps, round);
                 rec();
                 rec();
                 rec();
                 rec();
                 continue;
             }
-            hipLaunchKernelGGL(k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec();
-            hipLaunchKernelGGL(k_edges, dim3(gh), dim3(64), 0, st_, a);
-            hipLaunchKernelGGL(k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
+            HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
+            HP_LAUNCH(13, k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
             rec();
-            hipLaunchKernelGGL(k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
-            hipLaunchKernelGGL(k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
+            HP_LAUNCH(14, k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
+            HP_LAUNCH(15, k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
             rec();
-            hipLaunchKernelGGL(k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
-            hipLaunchKernelGGL(k_interact_c_hard, dim3(std::max<uint32_t>(1u, gh / K.grid_div_hard)), dim3(WTGPU_HARD_BLOCK), 0, st_, a, in);
+            HP_LAUNCH(16, k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
+            HP_LAUNCH(17, k_interact_c_hard, dim3(std::max<uint32_t>(1u, gh / K.grid_div_hard)), dim3(WTGPU_HARD_BLOCK), 0, st_, a, in);
             rec();
         }
         if (path_mode) {
-            hipLaunchKernelGGL(k_path_flush, dim3(kFlushGrid), dim3(kBlock), 0, st_, a, (int)(kMaxWalkIters & 1u));
+            HP_LAUNCH(18, k_path_flush, dim3(kFlushGrid), dim3(kBlock), 0, st_, a, (int)(kMaxWalkIters & 1u));
         } else {
-            hipLaunchKernelGGL(k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
-            hipLaunchKernelGGL(k_connect_scan, dim3(1), dim3(64), 0, st_, a);
-            hipLaunchKernelGGL(k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
-            if ((uint32_t)h.opts.max_depth + 2 >= kKeyDim - 1) hipLaunchKernelGGL(k_connect_strat_open, dim3(std::max<uint32_t>(1u, g_full / 8u)), dim3(kBlock), 0, st_, a);
-            hipLaunchKernelGGL(k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+            HP_LAUNCH(19, k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
+            HP_LAUNCH(20, k_connect_scan, dim3(1), dim3(64), 0, st_, a);
+            HP_LAUNCH(21, k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
+            if ((uint32_t)h.opts.max_depth + 2 >= kKeyDim - 1) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, g_full / 8u)), dim3(kBlock), 0, st_, a);
+            HP_LAUNCH(23, k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
@@ -2259,6 +2329,13 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         if (ev_fail) return fail(WTGPU_ERR_HIP, "hipEventRecord failed");
         r.busy = true;
     }
+    if (hp_on) {
+        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","k_trace","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
+        for (int i = 0; i < 24; ++i)
+            if (hp_n[i]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", hp_names[i], hp_n[i], hp_t[i], hp_t[i] / hp_n[i]);
+        if (hp_n[31]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", "hipEventRecord", hp_n[31], hp_t[31], hp_t[31] / hp_n[31]);
+    }
+#undef HP_LAUNCH
     // (wtgpu_join makes the caller's stream continue after all of them)
     s->samples_rendered += total;
     return WTGPU_OK;
@@ -2329,6 +2406,14 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
         for (int b = 0; b < 16; ++b)
             if (p[56 + b]) fprintf(stderr, "[wtgpu profile]   B %2d %8llu %10.1f %10.1f\n", b, p[56 + b], double(p[72 + b]) / p[56 + b] * 1e-3, double(p[72 + b]) * 1e-6);
     }
+#ifdef WTGPU_REFILL_PROF
+    {
+        unsigned long long p[16];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        const char* nm[6] = {"serve", "fetch", "store", "nodes", "leaf", "(ray in fetch)"};
+        for (int i = 0; i < 6; ++i) fprintf(stderr, "[refill prof] %-16s %10.1f Mticks  lanes %.1f\n", nm[i], p[i] * 1e-6, p[i] ? double(p[8 + i]) / p[i] : 0.);
+    }
+#endif
     if (s->knobs.profile == 2) {
         unsigned long long p[8];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
@@ -2427,11 +2512,13 @@ static void release_device(wtgpu_scene* s) {
         for (auto& e : r.ev)
             if (e) (void)hipEventDestroy(e);
         if (r.h_ctl) (void)hipHostFree(r.h_ctl);
+        if (r.ev_stagger) (void)hipEventDestroy(r.ev_stagger);
     }
     s->recs.clear();
     for (auto& e : s->ev_done)
         if (e) (void)hipEventDestroy(e);
     s->ev_done.clear();
+    s->ev_stagger_last = nullptr;
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     s->ev_begin = nullptr;
     for (auto& st_ : s->streams)
