@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- $BENCH > $
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 if [ -n "$DB" ]; then python $R/tools/rocpd_stats.py $DB $OUT/${TAG}_kernel_stats.csv $OUT/${TAG}_dispatches.csv > /dev/null; fi
 find /tmp/prof_kt -name "*stats*.csv" -exec cp {} $OUT/ \; 2>/dev/null
-# the same with ONE internal stream: exclusive kernel durations (with 4 streams a kernel's duration includes the time it shares the GPU)
+# the same with ONE internal stream: exclusive kernel durations (with several streams a kernel's duration includes the time it shares the GPU)
 rm -rf /tmp/prof_kt1
 WTGPU_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt1 -o kt -- $BENCH > $OUT/${TAG}_bench_streams1_under_rocprof.log 2>&1
 DB1=$(find /tmp/prof_kt1 -name "*.db" | head -1)
