@@ -23,7 +23,7 @@
 //     texture (constant, checkerboard, scale, transform, bitmap from PNG / PFM with filter, wrap modes and colour encoding);
 //     shape (rectangle, cube, sphere, cylinder, prism, lens, ply / obj: host/ply_loader.cpp, host/obj_loader.cpp) with general to_world
 //     transforms (matrix / rotate / scale / translate / lookat).
-//   Not handled: function textures, textured roughness / emitter radiance, sensor masks, max_depth beyond the kernels' 16 vertices.
+//   Not handled: function textures, textured roughness / emitter radiance, sensor masks.
 // Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
