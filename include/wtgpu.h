@@ -93,8 +93,10 @@ int wtgpu_scene_get_info(const wtgpu_scene* scene, wtgpu_scene_info* info);
 /* The flattened description of a handle (for CPU-side checkers and tools). */
 const wtgpu_scene_desc* wtgpu_scene_host_desc(const wtgpu_scene* scene);
 
-/* Copies the flattened scene to `device` and allocates the per-sample path state for `max_batch_samples` samples
- * per launch (0: default).  Fails with WTGPU_ERR_NO_DEVICE when no HIP device is present: there is no CPU fallback. */
+/* Copies the flattened scene to `device` and allocates the per-sample path state: three slices (one internal stream each), each for a
+ * batch of up to `max_batch_samples` samples (0: one sample per sensor element, at most 4 M), shrunk to fit WTGPU_STATE_GB (default 144).
+ * A render call is cut into batches of that size; larger batches are faster.  Fails with WTGPU_ERR_NO_DEVICE when
+ * no HIP device is present: there is no CPU fallback. */
 int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_samples);
 
 /* Renders sample indices [sample_begin, sample_end) of every sensor element (the `spp` loop of

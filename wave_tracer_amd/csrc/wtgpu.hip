@@ -181,6 +181,7 @@ struct wtgpu_scene {
     hipEvent_t ev_stagger_last = nullptr;   // the previous batch's stagger event (owned by its record)
     std::vector<chunk_rec_t> recs;                   // in-flight batch records (events + control block snapshot)
     size_t rec_next = 0;
+    size_t slice_next = 0;   // batches go round-robin over the slices ACROSS render calls (a call with one batch does not always land on stream 0)
     bool timing = true;
     std::string stats;
     double lut_power[2] = {0, 0};
@@ -2021,25 +2022,28 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
 #undef UP
     s->dev = d;
 
-    // per-batch path state: `n_slices` slices (one internal stream each) that together hold `max_batch` samples in flight
-    const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
-    uint64_t total_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 20);
-    {   // the vertex stores grow with max_depth (2 x (max_depth + 2) vertices of 356 B per sample): keep the state of all slices within a budget
-        // (WTGPU_STATE_GB, default 96 of the 288 GB) by shrinking the batches of deep scenes — more, smaller batches, same results
-        const bool pm = h.opts.integrator != INTEGRATOR_BDPT;
-        const uint64_t mv = (uint64_t)h.opts.max_depth + 2;
-        const uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
-        uint64_t budget_gb = 96;
-        if (const char* e = getenv("WTGPU_STATE_GB")) budget_gb = (uint64_t)std::max(1, atoi(e));
-        const uint64_t fit = std::max<uint64_t>(4096, (budget_gb << 30) / per_sample);
-        if (total_cap > fit) total_cap = fit;
-    }
+    // per-batch path state: `n_slices` slices (one internal stream each), EACH holding a batch of up to `max_batch` samples.
     // Three internal streams: the tails of one batch overlap the bulk of the others.  A single batch already fills the GPU in its first rounds, so
     // more streams only add contention — measured with an unthrottled enqueue (16 MiB kernel-argument ring), ms per pass at 1 / 2 / 3 / 4 / 6 / 8
     // streams: 158 / 142 / 130 / 142 / 157 / 206 (headline); etoile 66 vs 78, bidir_room 69 vs 82 at 3 vs 4.
+    // Batches as LARGE as the memory allows: every batch runs its ~30 rounds down to a thin tail, so the cost of the tails is per batch, not
+    // per sample — measured on the headline workload (2.07 M samples per pass, three streams), samples per batch 0.23 / 0.35 / 0.69 / 1.38 /
+    // 2.07 M -> 218 / 175 / 130 / 115 / 101 ms per pass.  288 GB of HBM are there to be used: three slices of a whole 1440^2 pass are 93 GB.
+    const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
     uint32_t n_slices = 3;
     if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
-    n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, total_cap / 64));
+    uint64_t batch_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 22);
+    n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, batch_cap / 64));
+    {   // the vertex stores grow with max_depth (2 x (max_depth + 2) vertices of 356 B per sample): keep the state of all slices within a budget
+        // (WTGPU_STATE_GB, default 144 of the 288 GB) by shrinking the batches of deep scenes — more, smaller batches, same results
+        const bool pm = h.opts.integrator != INTEGRATOR_BDPT;
+        const uint64_t mv = (uint64_t)h.opts.max_depth + 2;
+        const uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
+        uint64_t budget_gb = 144;
+        if (const char* e = getenv("WTGPU_STATE_GB")) budget_gb = (uint64_t)std::max(1, atoi(e));
+        const uint64_t fit = std::max<uint64_t>(4096, (budget_gb << 30) / per_sample / n_slices);
+        if (batch_cap > fit) batch_cap = fit;
+    }
     unsigned long long* counters = nullptr;
     if ((rc = dmalloc(s, &counters, kNumCounters + kProfSlots))) return rc;
     HIP_CHECK(hipMemset(counters, 0, (kNumCounters + kProfSlots) * sizeof(unsigned long long)));
@@ -2048,7 +2052,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     s->ev_done.resize(n_slices);
     for (uint32_t k = 0; k < n_slices; ++k) {
         device_state_t& st = s->slices[k];
-        st.cap = (total_cap + n_slices - 1) / n_slices;
+        st.cap = batch_cap;
         st.max_verts = (uint32_t)h.opts.max_depth + 2;
         st.walk_words = (uint32_t)(h.opts.integrator != INTEGRATOR_BDPT ? kPathWalkWords : kWalkWords);
         st.vert_words = (size_t)st.max_verts * kVertexWords;
@@ -2222,9 +2226,8 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     } while (0)
     std::vector<char> used(n_slices, 0);
     const uint64_t cap = s->slices[0].cap;
-    size_t chunk = 0;
-    for (uint64_t j0 = 0; j0 < total; j0 += cap, ++chunk) {
-        const size_t k = chunk % n_slices;
+    for (uint64_t j0 = 0; j0 < total; j0 += cap) {
+        const size_t k = s->slice_next++ % n_slices;
         hipStream_t st_ = s->streams[k];
         if (!used[k]) {
             HIP_CHECK(hipStreamWaitEvent(st_, s->ev_begin, 0));
