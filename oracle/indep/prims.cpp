@@ -36,7 +36,7 @@ const scene_t& S(const void* sc) { return *static_cast<const scene_t*>(sc); }
 
 // per-thread scratch: traversal stack + unbounded triangle list of the last prim_trace, Fraunhofer apertures of the current sample
 struct tls_t {
-    stack_entry_t stack[128];
+    stack_entry_t stack[4096];
     std::vector<uint32_t> tris = std::vector<uint32_t>(1u << 18);
     std::vector<float> dists = std::vector<float>(1u << 18);
     std::vector<fsd_aperture_t> hdr = std::vector<fsd_aperture_t>(64);
@@ -46,7 +46,7 @@ struct tls_t {
     std::vector<utd_edge_rec_t> utd_edges = std::vector<utd_edge_rec_t>(kUtdMaxEdges);
 };
 thread_local tls_t tls;
-stack_ref_t stack() { return make_flat_stack(tls.stack, 128); }
+stack_ref_t stack() { return make_flat_stack(tls.stack, 4096); }
 }   // namespace
 
 extern "C" {

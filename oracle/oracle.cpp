@@ -30,11 +30,13 @@ using namespace wt;
 
 namespace {
 
+// traversal stack of the checker: never the limit (an unbudgeted query on a full stack stops the process, wt/bvh.h: cq_node_step)
+constexpr uint32_t kOracleStack = 4096;
 constexpr uint32_t kMaxWalkIters = 96;   // must match wave_tracer_amd/csrc/wtgpu.hip (cap on trace/interact rounds per subpath)
 
 struct sample_scratch_t {
     std::vector<uint32_t> svert, evert;   // vertex stores (stride 1)
-    stack_entry_t stack[128];
+    stack_entry_t stack[kOracleStack];
     std::vector<uint32_t> tris;   // unbounded in the reference (std::vector): 2^18 entries here
     std::vector<float> dists;     // ... and their cone-hit distances (uint_list_t::d, wt/bvh.h)
 };
@@ -57,7 +59,7 @@ void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
 
 void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_pool_t& pool, uint64_t seed, uint64_t sample_id, uint32_t stream,
               sample_scratch_t& scr, bdpt_counters_t& ctr) {
-    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
     const uint_list_t tris{scr.tris.data(), 1, kOracleConeTris, g_region_filter ? scr.dists.data() : nullptr};
     for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
         const cone_t env = walk_trace_envelope(sc, w);
@@ -82,7 +84,7 @@ void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_
 // plt_path: src/integrator/plt_path.cpp:39-50 + plt_path_detail.hpp:772-828 — one walk per sample
 void run_path_sample(const scene_t& sc, const film_t& film, uint64_t seed, uint64_t sample_id, uint32_t x, uint32_t y, sample_scratch_t& scr,
                      std::vector<utd_edge_rec_t>& utd, bdpt_counters_t& ctr) {
-    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
     const uint_list_t tris{scr.tris.data(), 1, kOracleConeTris, g_region_filter ? scr.dists.data() : nullptr};
     const uint32_t stream = sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
     const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
@@ -135,7 +137,7 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
         uint32_t pool_counter = 0;
         const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
         bdpt_counters_t& ctr = ctrs[tid];
-        const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+        const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
         std::vector<utd_edge_rec_t> utd(kUtdMaxEdges);
         for (;;) {
             const uint32_t blk = next.fetch_add(1);
@@ -207,7 +209,7 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
     const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
     bdpt_counters_t ctr;
     std::memset(&ctr, 0, sizeof(ctr));
-    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
     uint64_t n_calls = 0;
     for (uint32_t blk = 0; blk < bx * by; ++blk) {
         if (tile_stride > 1 && blk % tile_stride != 0) continue;
@@ -273,7 +275,7 @@ uint64_t oracle_profile_axis(const void* scene_host, uint64_t seed, uint32_t til
     const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
     bdpt_counters_t ctr;
     std::memset(&ctr, 0, sizeof(ctr));
-    const stack_ref_t stack = make_flat_stack(scr.stack, 128);
+    const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
     uint64_t n_rows = 0, n_calls = 0;
     auto too_short_by = [&](const cone_t& env, uint32_t tuid, const range_t& range, float min_prog) {
         if (tuid == kInvalid) return false;
@@ -359,8 +361,8 @@ int oracle_counters_count() { return (int)(sizeof(bdpt_counters_t) / sizeof(unsi
 // rays: n x {ox,oy,oz,dx,dy,dz,tmin,tmax}; out: n x {dist, tuid(as float bits), bx, by, front}
 int oracle_trace_rays(const void* scene_host, const float* rays, uint32_t n, float* out_dist, uint32_t* out_tuid, float* out_bary, uint32_t* out_front) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
-    stack_entry_t st[128];
-    const stack_ref_t stack = make_flat_stack(st, 128);
+    stack_entry_t st[kOracleStack];
+    const stack_ref_t stack = make_flat_stack(st, kOracleStack);
     for (uint32_t i = 0; i < n; ++i) {
         const float* r = rays + 8 * i;
         ray_hit_t h;
@@ -378,8 +380,8 @@ int oracle_trace_rays(const void* scene_host, const float* rays, uint32_t n, flo
 int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n, uint32_t cap, float* out_dist, uint32_t* out_flags, uint32_t* out_ntris,
                           uint32_t* out_tris) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
-    stack_entry_t st[128];
-    const stack_ref_t stack = make_flat_stack(st, 128);
+    stack_entry_t st[kOracleStack];
+    const stack_ref_t stack = make_flat_stack(st, kOracleStack);
     const uint32_t lcap = cap > kMaxConeTris ? cap : kMaxConeTris;   // the device's bounded list unless a larger one is asked for
     std::vector<uint32_t> tl(lcap);
     std::vector<float> dl(lcap);
@@ -415,8 +417,8 @@ int oracle_query_regions(const void* scene_host, const float* cones, uint32_t n,
                          uint32_t* out_primary, uint32_t* out_ntris /* n x {list, slab} */, uint32_t* out_nedges /* n x {list, slab} */,
                          uint32_t* out_edges_list, uint32_t* out_edges_slab, float* out_flux /* n x {list, slab} */) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
-    stack_entry_t st[128];
-    const stack_ref_t stack = make_flat_stack(st, 128);
+    stack_entry_t st[kOracleStack];
+    const stack_ref_t stack = make_flat_stack(st, kOracleStack);
     std::vector<uint32_t> tl(1u << 21);
     std::vector<float> dl(1u << 21);
     for (uint32_t i = 0; i < n; ++i) {

@@ -268,7 +268,11 @@ def test_traverse_axis_equals_traverse(built):
     finally:
         lib.oracle_set_traverse_axis(0)
     assert np.array_equal(ref[1], dev[1]) and np.array_equal(ref[0], dev[0], equal_nan=True)
-    fits = ref[2] < cap
+    # (a region beyond the list's capacity: the list is full, or — when the far triangles filled it before the slab shrank and the final-slab
+    # filter then removed them all — empty although the record is a diffusive hit; either form only says "overflowed")
+    def overflowed(r):
+        return (r[2] >= cap) | ((r[2] == 0) & ((r[1] & 3) == 0))
+    fits = ~overflowed(ref) & ~overflowed(dev)
     assert np.array_equal(ref[2][fits], dev[2][fits]) and np.array_equal(ref[3][fits], dev[3][fits])
     assert ((ref[1] & 3) == 0).sum() > 200 and (ref[2] >= 64).sum() > 30 and fits.mean() > 0.99
 

@@ -25,4 +25,4 @@ for i in range(2, 8):
     t2 = time.perf_counter()
     te.append((t1 - t0) * 1e3)
     tt.append((t2 - t0) * 1e3)
-print("%s %d: enqueue %.1f ms, pass %.1f ms (median of 6)  TIMING=%s STREAMS=%s" % (name, res, sorted(te)[3], sorted(tt)[3], os.environ.get("WTGPU_TIMING", "1"), os.environ.get("WTGPU_STREAMS", "4")))
+print("%s %d: enqueue %.1f ms, pass %.1f ms (median of 6)  TIMING=%s STREAMS=%s" % (name, res, sorted(te)[3], sorted(tt)[3], os.environ.get("WTGPU_TIMING", "1"), os.environ.get("WTGPU_STREAMS", "default")))

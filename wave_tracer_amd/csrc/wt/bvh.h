@@ -12,6 +12,8 @@
 // lane owns its own bank column, ds_read_b64 / ds_write_b64 are conflict-free), while the CPU checker
 // passes a plain local array with stride 1.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "cone.h"
 #include "scene.h"
 
@@ -379,6 +381,12 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
         } else if (q.budget != 0xFFFFFFFFu) {
             full = true;   // device: the 64-entry per-lane stack is full -> the wave-cooperative query (512 entries) takes over
         }
+#if !defined(__HIP_DEVICE_COMPILE__)
+        else {   // CPU checker (unbudgeted): a dropped child would be a silently wrong answer
+            fprintf(stderr, "wt::cq_node_step: traversal stack of %u entries is full\n", stack.cap);
+            abort();
+        }
+#endif
     }
     if (full) {
         q.rec.aborted = 1;
