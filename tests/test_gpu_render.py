@@ -353,6 +353,39 @@ def test_c_host_smoke_program(built):
     assert "smoke.c: furnace 24x24, 4 spp" in out and "4 progress calls" in out, out
 
 
+def test_enqueue_is_not_throttled_by_the_runtime(built):
+    """wtgpu_render_async returns when a pass is ENQUEUED.  The HIP runtime stages by-value kernel arguments in a ring per stream (1 MiB by
+    default); a batch is ~870 launches of a ~1 KB launch block, and a full ring blocks the enqueueing thread until the GPU has caught up —
+    which serialises the internal streams (976 -> 1048 bytes of arguments, or one more kernel per round, cost 40 % of a
+    pass).  With HSA_KERNARG_POOL_SIZE raised by the package (before HIP initialises) the enqueue of a 720^2 pass takes a few ms; throttled
+    it takes about as long as the pass itself.  Guards the launch block's size, the number of launches per batch and the runtime setting."""
+    import os
+    import time
+    import torch
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.render import alloc_films
+    assert int(os.environ.get("HSA_KERNARG_POOL_SIZE", "0")) >= (4 << 20)
+    sc = Scene("cornell_box", res=720)
+    sc.upload(0, sc.width * sc.height)
+    dev = torch.device("cuda", 0)
+    films = alloc_films(sc, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for i in range(2):
+        sc.render_into(*films, i, i + 1, 5, st)
+    torch.cuda.synchronize(dev)
+    ratios = []
+    for i in range(2, 6):
+        t0 = time.perf_counter()
+        sc.render_async_into(*films, i, i + 1, 5, st)
+        t1 = time.perf_counter()
+        sc.join(st)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        ratios.append((t1 - t0) / (t2 - t0))
+    print("enqueue / pass:", ["%.3f" % r for r in ratios])
+    assert sorted(ratios)[1] < 0.35, ratios
+
+
 def test_progressive_render_progress_and_cancel(built):
     """wtgpu_render_progressive / wtgpu_cancel (scene_renderer.hpp:42-62): the callback sees every chunk; stopping after chunk k leaves
     exactly k chunks in the films (= the joined render of those samples); a cancel from another thread does the same."""
