@@ -295,7 +295,8 @@ def main():
                          "kernel_ms_per_step_stream_summed": {k: v / K for k, v in kernels.items()}},
             "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,
                                     "cone_tri_overflow": counters["cone_tri_overflow"] / ns, "fsd_interactions": counters["fsd_interactions"] / ns,
-                                    "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns},
+                                    "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns,
+                                    "traversal_stack_dropped": counters["traversal_stack_dropped"] / ns},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.cpu_seconds, md, pol)

@@ -69,6 +69,7 @@ typedef struct wtgpu_counters {
     uint64_t cone_tri_overflow, edge_overflow, fsd_edge_overflow, fsd_pool_overflow, fsd_interactions, null_interactions;
     uint64_t surface_interactions, light_splats;
     uint64_t walk_iteration_cap_hits;
+    uint64_t traversal_stack_dropped;   /* children a full wave-cooperative traversal stack (512 entries) could not hold: must be 0 */
 } wtgpu_counters;
 
 /* Host-side scene baking (no GPU needed): builds one of the bundled scenes

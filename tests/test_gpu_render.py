@@ -294,7 +294,7 @@ def test_double_slits_full_size_1440(built):
         assert (v >= 0).all() and (w >= 0).all() and (l >= 0).all()
     for k in range(3):
         assert torch.allclose(films[0][k] + films[1][k], films[2][k], rtol=1e-7, atol=1e-30)
-    assert c["samples"] == 2 * sc.width * sc.height and c["walk_iteration_cap_hits"] == 0
+    assert c["samples"] == 2 * sc.width * sc.height and c["walk_iteration_cap_hits"] == 0 and c["traversal_stack_dropped"] == 0
     assert c["edge_overflow"] == 0 and c["fsd_edge_overflow"] == 0 and c["fsd_pool_overflow"] == 0
     # (2) full-film parity
     ov, ow, ol, oc = oracle_render(sc, 0, 2, 9)
@@ -604,7 +604,7 @@ def test_full_size_etoile_720(built):
         assert torch.isfinite(v).all() and torch.isfinite(l).all() and (l >= 0).all() and (v >= 0).all()
     for k in range(3):
         assert torch.allclose(films[0][k] + films[1][k], films[2][k], rtol=1e-7, atol=1e-30)
-    assert c["samples"] == 2 * 720 * 540 and c["walk_iteration_cap_hits"] == 0
+    assert c["samples"] == 2 * 720 * 540 and c["walk_iteration_cap_hits"] == 0 and c["traversal_stack_dropped"] == 0
     ov, ow, ol, oc = oracle_render(sc, 0, 2, 5)
     g = develop(sc, *(t.cpu().numpy() for t in films[2]), 2).astype(np.float64)
     cpu = develop(sc, ov, ow, ol, 2).astype(np.float64)
@@ -652,7 +652,7 @@ def test_full_size_bidir_room_1920_polarimetric(built):
         assert torch.allclose(films[0][k] + films[1][k], films[2][k], rtol=1e-7, atol=1e-30)
     # (the walk-iteration cap — 96 trace/interact rounds per subpath, the CPU checker's too; the reference recurses without one — is reached by
     # a few walks in 10^6 here: beams that restart behind empty apertures over and over)
-    assert c["samples"] == 2 * npix and c["walk_iteration_cap_hits"] <= 2e-5 * c["samples"] and c["fsd_pool_overflow"] == 0
+    assert c["samples"] == 2 * npix and c["walk_iteration_cap_hits"] <= 2e-5 * c["samples"] and c["fsd_pool_overflow"] == 0 and c["traversal_stack_dropped"] == 0
     ov, ow, ol, oc5, n5, mask = oracle_render_tiles(sc, 0, 1, 5, 97)
     inner = mask.copy()
     inner[1:, :] &= mask[:-1, :]

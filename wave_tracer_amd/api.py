@@ -42,7 +42,7 @@ class SceneInfo(C.Structure):
 
 COUNTER_FIELDS = ["samples", "segments", "ray_queries", "cone_queries", "vertices", "connections", "shadow_rays", "cone_tri_overflow",
                   "edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow", "fsd_interactions", "null_interactions",
-                  "surface_interactions", "light_splats", "walk_iteration_cap_hits"]
+                  "surface_interactions", "light_splats", "walk_iteration_cap_hits", "traversal_stack_dropped"]
 
 
 class Counters(C.Structure):

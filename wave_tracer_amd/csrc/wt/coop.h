@@ -23,6 +23,9 @@
 namespace wt {
 
 constexpr int kCoopStack = 512;
+// children a full cooperative stack could not hold (never seen; a dropped child would be a silently wrong region): counted, reported by
+// wtgpu_get_counters as traversal_stack_dropped and asserted zero by the full-size GPU tests
+__device__ unsigned int g_coop_stack_dropped = 0;
 #ifndef WTGPU_COOP_LEAF_TRIS
 #define WTGPU_COOP_LEAF_TRIS 256
 #endif
@@ -274,6 +277,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 const int above = grp < 7 ? __popcll(hm >> ((grp + 1) * 8)) : 0;   // hits of the groups serving deeper entries
                 const int pos = s + above + rank;
                 if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+                else if (h) atomicAdd(&g_coop_stack_dropped, 1u);   // reported: wtgpu_counters::traversal_stack_dropped
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }
@@ -501,6 +505,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             if (hm) {
                 const int pos = s + __popcll(hm & ((1ull << lane) - 1ull));   // order is irrelevant here
                 if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+                else if (h) atomicAdd(&g_coop_stack_dropped, 1u);   // reported: wtgpu_counters::traversal_stack_dropped
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }
@@ -706,6 +711,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
                 const int above = grp < 7 ? __popcll(hm >> ((grp + 1) * 8)) : 0;
                 const int pos = s + above + rank;
                 if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
+                else if (h) atomicAdd(&g_coop_stack_dropped, 1u);   // reported: wtgpu_counters::traversal_stack_dropped
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }

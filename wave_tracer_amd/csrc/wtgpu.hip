@@ -2377,6 +2377,11 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     out->surface_interactions = c.surface_interactions;
     out->light_splats = c.light_splats;
     out->walk_iteration_cap_hits = s->cap_hits;
+    {
+        unsigned int dropped = 0;
+        HIP_CHECK(hipMemcpyFromSymbol(&dropped, HIP_SYMBOL(g_coop_stack_dropped), sizeof(dropped)));
+        out->traversal_stack_dropped = dropped;
+    }
 #ifdef WTGPU_STEP_PROF
     {
         unsigned long long p[8];
@@ -2433,6 +2438,10 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
     }
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemset(s->slices[0].counters, 0, (kNumCounters + kProfSlots) * sizeof(unsigned long long)));
+    {
+        const unsigned int zero = 0;   // (one counter per device, shared by the scenes of a process)
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stack_dropped), &zero, sizeof(zero)));
+    }
     s->samples_rendered = 0;
     s->cap_hits = 0;
     for (double& v : s->acc) v = 0;
