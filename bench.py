@@ -79,15 +79,21 @@ def measure_traffic(kernel, scene_args, timeout_s=240):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
-            s, ids = 0.0, set()
+            # (`kernel` may be a tuple: a HIP-event bracket that spans several kernels — their bytes are summed, per launch of the bracket =
+            # per dispatch of its most frequent kernel)
+            names = kernel if isinstance(kernel, (tuple, list)) else (kernel,)
+            s, ids = 0.0, {n: set() for n in names}
             for fn in files:
                 with open(fn) as fh:
                     for row in csv.DictReader(fh):
-                        if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter and (kernel + "_") not in row["Kernel_Name"]:
-                            s += float(row["Counter_Value"])
-                            ids.add((fn, row["Dispatch_Id"]))
+                        if row["Counter_Name"] != counter:
+                            continue
+                        for n in names:
+                            if n in row["Kernel_Name"] and (n + "_") not in row["Kernel_Name"]:
+                                s += float(row["Counter_Value"])
+                                ids[n].add((fn, row["Dispatch_Id"]))
             tot[counter] = s * 1024.0 * k
-            n_disp = max(n_disp, len(ids))
+            n_disp = max(n_disp, max(len(v) for v in ids.values()))
         except (subprocess.TimeoutExpired, OSError) as e:
             return None, f"rocprofv3 --pmc {counter}: {e}"
         finally:
@@ -230,14 +236,15 @@ def main():
                    "k_edges+k_interact_b": tsum["interact_b_ms"], "k_flux_split+k_flux_tasks": tsum["flux_ms"], "k_interact_c": tsum["interact_c_ms"],
                    "k_connect": tsum["connect_ms"], "k_generate": tsum["generate_ms"]}
         path_mode = int(sc.info.integrator) != 0
-        if path_mode:      # plt_path scenes: the interaction bracket is k_path_interact (the later passes do not exist)
-            kernels = {("k_path_interact" if k == "k_interact" else k): v for k, v in kernels.items()}
+        PATH_BRACKET = "k_path_fsd+interact+edges+interact_b+nee"
+        if path_mode:      # plt_path scenes: ONE bracket spans the five kernels between k_trace_heavy and the next round (the later brackets are empty)
+            kernels = {(PATH_BRACKET if k == "k_interact" else k): v for k, v in kernels.items()}
         dom = max(kernels, key=kernels.get)
         # bytes attributed to the dominant kernel per step (one step = npix samples); the two trace kernels split the segments
         # (every segment is traced by exactly one of them), the two interaction passes split the vertices the same way: each is
         # credited with the WHOLE term (an upper bound of its algorithmic bytes, hence of `achieved`)
         share = {"k_trace": n_seg * S_path + n_q * S_hit, "k_trace_heavy": n_seg * S_path + n_q * S_hit, "k_interact": n_seg * S_path + n_vtx * S_vtx,
-                 "k_path_interact": n_seg * 2 * S_path,
+                 PATH_BRACKET: n_seg * 2 * S_path,
                  "k_edges+k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_flux_split+k_flux_tasks": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_c": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
         # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once): `launches`
@@ -257,7 +264,8 @@ def main():
         traffic, traffic_src = None, None
         if world == 1 and not args.no_traffic:
             kname = {"k_trace": "k_trace_refill" if os.environ.get("WTGPU_TRACE_REFILL", "1") != "0" else "k_trace", "k_connect": "k_connect_strat", "k_edges+k_interact_b": "k_interact_b",
-                     "k_flux_split+k_flux_tasks": "k_flux_tasks"}.get(dom, dom)
+                     "k_flux_split+k_flux_tasks": "k_flux_tasks",
+                     PATH_BRACKET: ("k_path_fsd", "k_path_interact", "k_path_edges", "k_path_interact_b", "k_path_nee")}.get(dom, dom)
             scene_args = ["--scene", args.scene, "--res", str(args.res), "--mesh-detail", str(md), "--polarimetric", str(pol)] + (["--ray-tracing"] if args.ray_tracing else [])
             traffic, detail = measure_traffic(kname, scene_args)
             traffic_src = {"measured": "live, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one step", "kernel": kname, **detail} if traffic is not None else {"measured": None, "reason": detail}
@@ -290,7 +298,7 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "alg_bytes_per_sample_all_kernels": bytes_per_sample,
                          "whole_path": {"alg_bytes_per_step": bytes_per_sample * npix * s_rank, "achieved": whole, "frac": whole / 8000.0},
-                         # HIP-event brackets on the 4 concurrent slice streams: each includes the time the kernel shares the GPU with the
+                         # HIP-event brackets on the concurrent slice streams: each includes the time the kernel shares the GPU with the
                          # other streams' kernels, so the sum exceeds ms_per_step (exclusive times: profiles/r03_kernel_stats_streams1.csv)
                          "kernel_ms_per_step_stream_summed": {k: v / K for k, v in kernels.items()}},
             "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,
