@@ -416,6 +416,10 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
+#ifndef WTGPU_LEAF_NUM
+#define WTGPU_LEAF_NUM 1   // leaf step when at least NUM / DEN of the running lanes hold a leaf (swept 1/3, 1/2, 2/3, 3/4: 99.0 / 97.6 / 96.6 / 97.9 ms per pass, noise 1 ms)
+#define WTGPU_LEAF_DEN 2
+#endif
 // k_trace with LANE REFILL (the default; the kernel above is kept as the A/B reference, WTGPU_TRACE_REFILL=0).
 // The cost of a walk's traversal varies by two orders of magnitude — one to seven cone queries of 2..cone_budget work units each —
 // and in the kernel above a wavefront is as slow as its slowest lane: its lanes run the policy and their queries back to back and
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 RP_BEGIN();
                 if (at_node) cq_node_step(a.sc, env, stack, q);
                 RP_END(3, nm);
-                if (2 * __popcll(__ballot(st == 1 && q.leaf != 0)) >= running) break;
+                if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && q.leaf != 0)) >= WTGPU_LEAF_NUM * running) break;
             }
             RP_BEGIN();
             const unsigned long long m_leaf = __ballot(st == 1 && q.leaf != 0);
