@@ -53,8 +53,8 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
 def measure_traffic(kernel, scene_args, timeout_s=240):
     """HBM-side bytes per launch of `kernel` measured NOW, on this box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, with
     --kernel-trace only) over one step of the same workload in a child process, summed over the kernel's dispatches and scaled to bytes with the
-    calibration of profiles/r03_calib.json (a streaming copy of known size with this code's access width, tools/profile_round.sh: the counters read
-    KiB; FETCH_SIZE under-reports by 2 on gfx950, MI355X_MICROARCH.md).  Returns (bytes_per_launch, detail) or (None, reason)."""
+    newest calibration committed under profiles/ (a streaming copy of known size with this code's access width, tools/profile_round.sh: the counters
+    read KiB; FETCH_SIZE under-reports by 2 on gfx950, MI355X_MICROARCH.md).  Returns (bytes_per_launch, detail) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -62,12 +62,17 @@ def measure_traffic(kernel, scene_args, timeout_s=240):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None, "rocprofv3 not found"
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_calib.json")) as f:
-            cal = json.load(f)
-        kf, kw = float(cal["fetch_factor"]), float(cal["write_factor"])
-    except (OSError, KeyError, ValueError):
-        kf, kw = 2.0, 1.0     # the values every calibration so far gave (profiles/r01..r03)
+    # counter -> bytes factors: the newest committed calibration (profiles/rNN_pmc_traffic.json["calibration"], written by
+    # tools/make_traffic_json.py from the k_calib_copy passes of tools/profile_round.sh); without one, the guide's value for FETCH_SIZE (x2) and 1
+    kf, kw, cal_src = 2.0, 1.0, "MI355X_MICROARCH.md (FETCH_SIZE x 2), uncalibrated"
+    for tag in ("r04", "r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
+                cal = json.load(f)["calibration"]
+            kf, kw, cal_src = float(cal["fetch_factor"]), float(cal["write_factor"]), f"profiles/{tag}_pmc_traffic.json (k_calib_copy: a streaming copy of known size)"
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     tot = {}
     n_disp = 0
     for counter, k in (("FETCH_SIZE", kf), ("WRITE_SIZE", kw)):
@@ -100,7 +105,8 @@ def measure_traffic(kernel, scene_args, timeout_s=240):
             shutil.rmtree(d, ignore_errors=True)
     if not n_disp:
         return None, "kernel not found in the counter collection"
-    return (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / n_disp, {"fetch_bytes": tot["FETCH_SIZE"], "write_bytes": tot["WRITE_SIZE"], "dispatches": n_disp, "fetch_factor": kf, "write_factor": kw}
+    return (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / n_disp, {"fetch_bytes": tot["FETCH_SIZE"], "write_bytes": tot["WRITE_SIZE"], "dispatches": n_disp, "fetch_factor": kf, "write_factor": kw,
+                                                                      "factors_from": cal_src}
 
 
 def main():
@@ -263,7 +269,7 @@ def main():
         # workload, on this box, in child processes after the timed region); if rocprofv3 is unavailable, the summary committed under profiles/
         traffic, traffic_src = None, None
         if world == 1 and not args.no_traffic:
-            kname = {"k_trace": "k_trace_refill" if os.environ.get("WTGPU_TRACE_REFILL", "1") != "0" else "k_trace", "k_connect": "k_connect_strat", "k_edges+k_interact_b": "k_interact_b",
+            kname = {"k_trace": "k_trace_refill", "k_connect": "k_connect_strat", "k_edges+k_interact_b": "k_interact_b",
                      "k_flux_split+k_flux_tasks": "k_flux_tasks",
                      PATH_BRACKET: ("k_path_fsd", "k_path_interact", "k_path_edges", "k_path_interact_b", "k_path_nee")}.get(dom, dom)
             scene_args = ["--scene", args.scene, "--res", str(args.res), "--mesh-detail", str(md), "--polarimetric", str(pol)] + (["--ray-tracing"] if args.ray_tracing else [])
@@ -271,7 +277,7 @@ def main():
             traffic_src = {"measured": "live, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one step", "kernel": kname, **detail} if traffic is not None else {"measured": None, "reason": detail}
         if traffic is None:
             try:
-                with open(os.path.join(ROOT, "profiles", {"etoile": "r03_pmc_traffic_etoile.json", "bidir_room": "r03_pmc_traffic_bidir_room.json"}.get(args.scene, "r03_pmc_traffic.json"))) as f:
+                with open(os.path.join(ROOT, "profiles", {"etoile": "r03_pmc_traffic_etoile.json", "bidir_room": "r03_pmc_traffic_bidir_room.json"}.get(args.scene, "r04_pmc_traffic.json"))) as f:
                     pt = json.load(f)
                 kk = {"k_trace": "k_trace_refill"}.get(dom, dom)
                 if kk in pt["kernels"] and pt["workload"]["res"] == args.res and pt["workload"]["scene"] == args.scene:
@@ -302,7 +308,9 @@ def main():
                          # other streams' kernels, so the sum exceeds ms_per_step (exclusive times: profiles/r03_kernel_stats_streams1.csv)
                          "kernel_ms_per_step_stream_summed": {k: v / K for k, v in kernels.items()}},
             "counters_per_sample": {"segments": n_seg, "vertices": n_vtx, "connections": n_conn, "bvh_queries": n_q, "light_splats": n_light,
-                                    "cone_tri_overflow": counters["cone_tri_overflow"] / ns, "fsd_interactions": counters["fsd_interactions"] / ns,
+                                    # (not an overflow of anything: triangles of interaction regions beyond the 64-entry fast-path list, which the
+                                    # whole-region walks of k_edges / k_flux_* cover — DESIGN.md §5; the C-ABI counter is still called cone_tri_overflow)
+                                    "region_tris_beyond_fast_path_list": counters["cone_tri_overflow"] / ns, "fsd_interactions": counters["fsd_interactions"] / ns,
                                     "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns,
                                     "traversal_stack_dropped": counters["traversal_stack_dropped"] / ns},
         }

@@ -345,11 +345,16 @@ static void kat_make_aperture(const float* edges, uint32_t n_edges, float k, fsd
     fsd_build_finish(k, st, ap, ed);
 }
 // n proposals (sampleN) and n rejection-sampled directions (fsd_run_tries): out = n x {prop.x, prop.y, acc.x, acc.y, accepted}
-void kat_fsd_aperture_sample(const void* scene_host, const float* edges, uint32_t n_edges, float k, uint64_t seed, uint32_t n, float* out, float* ap_out) {
+// ignore_dead: run the reference's full loop even when the aperture is classified dead (wt/fsd.h: kFsdDeadRatio); tries_out (optional): tries
+// per direction; dead_out (optional): the classification
+void kat_fsd_aperture_sample2(const void* scene_host, const float* edges, uint32_t n_edges, float k, uint64_t seed, uint32_t n, float* out, float* ap_out,
+                              int ignore_dead, uint32_t* tries_out, uint32_t* dead_out) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);
     static fsd_edge_t store[kFsdMaxEdges];
     fsd_aperture_t ap;
     kat_make_aperture(edges, n_edges, k, ap, store);
+    if (dead_out) *dead_out = ap.dead;
+    if (ignore_dead) ap.dead = 0;
     const fsd_edges_ref_t ed{store, 1};
     ap_out[0] = ap.P0;
     ap_out[1] = ap.P0_pdf;
@@ -363,7 +368,11 @@ void kat_fsd_aperture_sample(const void* scene_host, const float* edges, uint32_
         const uint32_t t = fsd_run_tries(sc, ap, ed, s2, fsd_tries_base(s2), 0, fsd_max_tries(ap), r);
         float* o = out + 5 * i;
         o[0] = xi.x; o[1] = xi.y; o[2] = r.x.x; o[3] = r.x.y; o[4] = t != 0xFFFFFFFFu ? 1.f : 0.f;
+        if (tries_out) tries_out[i] = t != 0xFFFFFFFFu ? t + 1u : fsd_max_tries(ap);
     }
+}
+void kat_fsd_aperture_sample(const void* scene_host, const float* edges, uint32_t n_edges, float k, uint64_t seed, uint32_t n, float* out, float* ap_out) {
+    kat_fsd_aperture_sample2(scene_host, edges, n_edges, k, seed, n, out, ap_out, 0, nullptr, nullptr);
 }
 // out = n x {ASF (fsd.hpp:143-146), sampling_density (fsd.hpp:122-127)} at the given xi
 void kat_fsd_aperture_eval(const float* edges, uint32_t n_edges, float k, const float* xi, uint32_t n, float* out) {

@@ -355,6 +355,9 @@ void oracle_fsd_hist(unsigned long long* out) { std::memcpy(out, wt::g_fsd_hist,
 void oracle_cone_tri_exits(unsigned long long* out) { std::memcpy(out, g_cone_tri_exits, sizeof(g_cone_tri_exits)); }
 #endif
 
+// 0: dead apertures run the reference's full rejection loop (wt/fsd.h: kFsdDeadRatio); default 1e-10
+void oracle_set_fsd_dead_ratio(float r) { wt::g_fsd_dead_ratio = r; }
+
 int oracle_counters_count() { return (int)(sizeof(bdpt_counters_t) / sizeof(unsigned long long)); }
 
 // ---- per-query entry points for the traversal parity tests ---------------------------------------------------

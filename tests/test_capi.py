@@ -93,6 +93,23 @@ def test_unknown_scene_and_no_device_fail_loudly(built):
             sc.upload(0)
 
 
+def test_upload_refuses_runtime_settings_that_serialise_the_streams(built):
+    """The stream pipeline needs >= 4 hardware queues and a kernel-argument ring of >= 4 MiB: an EXPLICIT smaller setting makes
+    wtgpu_scene_upload fail with a message that says what to export, instead of running 30-50 % slower without a word.  (Checked before the
+    device is looked for, so it runs without a GPU; in a child process because the library reads the environment when it is loaded.)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from wave_tracer_amd import Scene, WtgpuError\n"
+            "sc = Scene('furnace', res=8)\n"
+            "try:\n    sc.upload(0)\n    print('UPLOADED')\nexcept WtgpuError as e:\n    print('ERR', e)\n") % ROOT
+    for env, expect in (({"GPU_MAX_HW_QUEUES": "2"}, "GPU_MAX_HW_QUEUES=2"), ({"HSA_KERNARG_POOL_SIZE": str(1 << 20)}, "HSA_KERNARG_POOL_SIZE=1048576")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert "ERR" in r.stdout and expect in r.stdout, (r.stdout, r.stderr)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, WTGPU_ALLOW_SLOW_RUNTIME="1", **env), capture_output=True, text=True, timeout=300)
+        assert expect not in r.stdout, r.stdout      # overridden: on to the device (UPLOADED on a GPU box, "no HIP device" here)
+
+
 def test_develop_matches_film_storage_semantics(built):
     import numpy as np
     from wave_tracer_amd import Scene, develop

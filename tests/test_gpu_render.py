@@ -236,7 +236,9 @@ def test_full_size_properties_1440(built):
     # 82,000): those regions are walked in full on the device, so all but a fraction of a per cent of the pixels agree
     # with the CPU checker's unbounded lists to fp32 rounding
     assert frac_same > 0.99, frac_same
-    assert c["fsd_pool_overflow"] == 0
+    # nothing was capped or dropped on the HEADLINE workload: per-lane edge sets, aperture segments, the aperture pool, the cooperative stack
+    for key in ("fsd_pool_overflow", "edge_overflow", "fsd_edge_overflow", "traversal_stack_dropped"):
+        assert c[key] == 0, (key, c[key])
     small = Scene("cornell_box", res=96, mesh_detail=1)
     _, _, _, oc = oracle_render(small, 0, 2, 5)
     n_small = 96 * 96 * 2

@@ -256,3 +256,57 @@ def test_fsd_rejection_sampler_density(lut_scene, n_edges, length):
     # is picked with probabilities |a_b|^2 : |iab_2|^2 (fsd_sampler.cpp:44-48) while their powers are PA1 |a_b|^2 : PA2 |iab_2|^2.
     # Rejection (> 1 edge) removes what M g >= f allows; a single edge is not rejection-sampled at all (:80-82).
     assert tv < 0.2
+
+
+def test_dead_apertures_fail_without_the_loop(lut_scene):
+    """A doubled scene edge (the rim of a thin plate: two coincident silhouette edges of opposite direction) enters an aperture as two
+    segment chains whose amplitudes cancel to rounding.  The reference's rejection loop then spins through all n x 1024 tries and reports
+    failure (13 % of the 8-15-segment apertures of the headline workload, 85 % of all tries); wt/fsd.h classifies such an aperture as DEAD
+    when it is built (coherent / incoherent power at the eight probe directions < 1e-10) and fails the sample at once.  Checked here:
+    the classification; that the FULL loop (classification ignored) fails as well but for the odd try that rounding noise lets through
+    after thousands of tries (the one place where the outcomes differ: tools/fsd_dead_effect.py measures it in the image); and that
+    ordinary and partly cancelling apertures are left alone."""
+    lib = load_oracle()
+    lib.kat_fsd_aperture_sample2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p]
+
+    def run(ed, n, ignore_dead):
+        out = np.zeros((n, 5), np.float32)
+        apo = np.zeros(3 + len(ed), np.float32)
+        tries = np.zeros(n, np.uint32)
+        dead = C.c_uint32(7)
+        lib.kat_fsd_aperture_sample2(C.c_void_p(lut_scene.host_desc()), np.ascontiguousarray(ed, np.float32).ctypes.data, len(ed), 12000.0, 11, n,
+                                     out.ctypes.data, apo.ctypes.data, ignore_dead, tries.ctypes.data, C.byref(dead))
+        return out, tries, dead.value, apo
+
+    # a straight edge of 6 segments under a Gaussian beam (amplitudes like fsd_edge_segments': a - b, (a + b) / 2) ...
+    p0, d = np.array([0.08, 0.036]), np.array([-0.0303, -0.0154])
+    amp = lambda q: 1.0e4 * math.exp(-0.25 * (q @ q) / 0.05 ** 2)
+    fwd = []
+    for i in range(6):
+        a, b = p0 + i * d, p0 + (i + 1) * d
+        fwd.append([d[0], d[1], .5 * (a[0] + b[0]), .5 * (a[1] + b[1]), amp(a) - amp(b), .5 * (amp(a) + amp(b))])
+    fwd = np.array(fwd)
+    # ... and the same edge once more, traversed backwards, with the last-digit differences two separately projected copies have
+    rng = np.random.default_rng(3)
+    back = fwd[::-1].copy()
+    back[:, 0:2] *= -1
+    back[:, 4] *= -1
+    back[:, 2:4] *= 1 + 2e-7 * rng.standard_normal((6, 2))
+    doubled = np.concatenate([fwd, back])
+    out, tries, dead, apo = run(doubled, 48, 1)
+    assert dead == 1
+    print("doubled edge: psi0^2 =", apo[2], " full loop: accepted", int((out[:, 4] > 0).sum()), "of 48, tries", tries.min(), "..", tries.max())
+    noise = out[:, 4] > 0
+    assert noise.mean() < 0.2 and (tries[~noise] == 12 * 1024).all()          # the reference's loop: n x 1024 tries, then failure ...
+    assert (tries[noise] > 64).all()                                          # ... or a try let through by rounding noise, late
+    out, tries, dead, _ = run(doubled, 48, 0)
+    assert (out[:, 4] > 0).sum() == 0 and (tries == 0).all()                  # the same outcome without a try
+    # the forward chain alone, and the doubled edge beside a live one, are ordinary apertures
+    out, tries, dead, _ = run(fwd, 2000, 0)
+    assert dead == 0 and (out[:, 4] > 0).mean() > 0.999
+    live = np.array([[0.02, -0.03, -0.05, 0.02, amp(np.array([-0.06, 0.035])) - amp(np.array([-0.04, 0.005])), 3.0e3]])
+    out, tries, dead, _ = run(np.concatenate([doubled, live]), 500, 0)
+    assert dead == 0 and (out[:, 4] > 0).mean() > 0.99
+    for n_edges in (2, 8, 24):
+        assert run(_aperture(n_edges, 40 + n_edges, None)[:, :6], 10, 0)[2] == 0

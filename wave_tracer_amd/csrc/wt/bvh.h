@@ -19,25 +19,78 @@
 
 namespace wt {
 
-struct stack_entry_t {
+struct alignas(8) stack_entry_t {   // (moved as one 64-bit word: stack_ref_t)
     float t;
     int32_t ptr;
 };
 // Two-segment stack: entries [0,n_fast) live at p[i*stride] (LDS, lane-interleaved, on the device), entries
 // [n_fast,cap) in a private spill array q (scratch).  The CPU checker uses n_fast = cap, q = nullptr.
+//
+// An entry travels as ONE 64-bit scalar and, in device code, the two segment pointers carry their address spaces in their TYPES
+// (LDS = 3, scratch = 5).  Both matter: with generic pointers — or with struct-typed loads, which bind a generic reference — the compiler
+// folds "load from p or from q" into a FLAT access through a selected pointer (and sinks half of an entry's store behind the merge as a
+// flat store): every push and pop then went through the texture path and waited on vmcnt together with the node fetches (round 3's
+// kernel: 10 flat loads, 21 flat stores, no ds_read at all).  Typed like this the fast segment is ds_read_b64 / ds_write_b64.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WT_AS_LDS __attribute__((address_space(3)))
+#define WT_AS_PRIVATE __attribute__((address_space(5)))
+#else
+#define WT_AS_LDS
+#define WT_AS_PRIVATE
+#endif
+typedef WT_AS_LDS unsigned long long* stack_fast_ptr_t;
+typedef WT_AS_PRIVATE unsigned long long* stack_spill_ptr_t;
+WT_HD unsigned long long stack_pack(stack_entry_t e) {
+    uint32_t tb;
+    __builtin_memcpy(&tb, &e.t, 4);
+    return ((unsigned long long)(uint32_t)e.ptr << 32) | tb;
+}
+WT_HD stack_entry_t stack_unpack(unsigned long long v) {
+    const uint32_t tb = (uint32_t)v;
+    stack_entry_t e;
+    __builtin_memcpy(&e.t, &tb, 4);
+    e.ptr = (int32_t)(uint32_t)(v >> 32);
+    return e;
+}
 struct stack_ref_t {
-    stack_entry_t* p;
+    stack_fast_ptr_t p;
     uint32_t stride;
     uint32_t cap;
     uint32_t n_fast;
-    stack_entry_t* q;
-    WT_HD stack_entry_t& operator[](int i) const { return (uint32_t)i < n_fast ? p[(size_t)i * stride] : q[(uint32_t)i - n_fast]; }
+    stack_spill_ptr_t q;
+    WT_HD stack_entry_t get(int i) const {
+        unsigned long long v;
+        if ((uint32_t)i < n_fast)
+            v = p[(size_t)i * stride];
+        else
+            v = q[(uint32_t)i - n_fast];
+        return stack_unpack(v);
+    }
+    WT_HD void set(int i, stack_entry_t e) const {
+        const unsigned long long v = stack_pack(e);
+        if ((uint32_t)i < n_fast)
+            p[(size_t)i * stride] = v;
+        else
+            q[(uint32_t)i - n_fast] = v;
+    }
+    WT_HD float get_t(int i) const { return get(i).t; }
 };
+// (stack storage is declared as stack_entry_t arrays: 8-byte entries, 8-byte aligned)
+static_assert(sizeof(stack_entry_t) == 8 && alignof(stack_entry_t) == 8, "stack entries are moved as 64-bit words");
+WT_HD stack_ref_t make_stack_ref(stack_entry_t* fast, uint32_t stride, uint32_t cap, uint32_t n_fast, stack_entry_t* spill) {
+    stack_ref_t s;
+    s.p = (stack_fast_ptr_t)fast;
+    s.stride = stride;
+    s.cap = cap;
+    s.n_fast = n_fast;
+    s.q = (stack_spill_ptr_t)spill;
+    return s;
+}
 WT_HD bvh8_leaf_t bvh_leaf_of(int32_t child) {   // child < 0 (wt/scene.h: bvh8_leaf_t)
     const uint32_t v = (uint32_t)(-child);
     return bvh8_leaf_t{v >> 3, v & 7u};
 }
-WT_HD stack_ref_t make_flat_stack(stack_entry_t* p, uint32_t cap) { return stack_ref_t{p, 1, cap, cap, nullptr}; }
+WT_HD stack_ref_t make_flat_stack(stack_entry_t* p, uint32_t cap) { return make_stack_ref(p, 1, cap, cap, nullptr); }
 
 struct uint_list_t {   // bounded output list with the same (pointer,stride) addressing
     uint32_t* p;
@@ -55,14 +108,28 @@ struct uint_list_t {   // bounded output list with the same (pointer,stride) add
 
 constexpr int kRayLeafShortcut = 16;   // src/ads/bvh8w.cpp:29
 
-// insertion sort, far-first (descending tmin) (bvh8w.cpp:45-57)
-WT_HD void stack_sort_desc(const stack_ref_t& s, int begin, int end) {
-    for (int i = begin + 1; i < end; ++i) {
-        const stack_entry_t p = s[i];
-        int j;
-        for (j = i - 1; j >= begin && p.t > s[j].t; --j) s[j + 1] = s[j];
-        s[j + 1] = p;
+// The children of a node that passed their box test go on the stack far-first (descending tmin; equal tmin: in child order) — the result
+// of the reference's insertion sort of the freshly pushed entries (bvh8w.cpp:45-57).  Here every entry is written ONCE, at its final
+// position: rank = number of accepted children that sort before it, from 28 register compares, no loop over memory and no data-dependent
+// trip count (on the device the insertion sort was a per-lane loop of stack loads and stores whose length differed in every lane).
+// t[i] / c[i]: tmin and child reference of child i, ok bit i: accepted.  Returns the new stack size.
+WT_HD int stack_push_sorted(const stack_ref_t& s, int begin, const float t[8], const int32_t c[8], uint32_t ok) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j == i) continue;
+            const bool before = j < i ? t[j] >= t[i] : t[j] > t[i];   // (j sorts before i: farther, or as far and earlier in child order)
+            rank += (((ok >> j) & 1u) && before) ? 1 : 0;
+        }
+        if ((ok >> i) & 1u) {
+            s.set(begin + rank, stack_entry_t{t[i], c[i]});
+            ++n;
+        }
     }
+    return begin + n;
 }
 
 constexpr uint32_t kNodeBudgetCost = 2;   // budget units charged per node visit of a cone query (1 unit = 1 triangle test)
@@ -132,7 +199,7 @@ WT_HD void rq_begin(const scene_t& sc, const range_t& range, const stack_ref_t& 
     q.s = 0;
     if (sc.n_nodes == 0) return;
     q.s = 1;
-    stack[0] = stack_entry_t{0.f, 1};
+    stack.set(0, stack_entry_t{0.f, 1});
 }
 // pops one entry: a leaf (or a node with few triangles) is kept for rq_leaf_step, a node's children are tested and pushed far-first
 // (requires q.s > 0, q.lcnt == 0)
@@ -140,7 +207,7 @@ WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& 
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
     const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
     int s = q.s;
-    const stack_entry_t top = stack[s - 1];
+    const stack_entry_t top = stack.get(s - 1);
     --s;
     q.s = s;
     if (top.ptr < 0) {
@@ -160,11 +227,14 @@ WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& 
     }
     if (ctr) ctr->nodes++;
     const float tfar = fminf_(q.rec.dist, q.range.max);
-    const int begin = s;
+    // all eight slab tests without a branch, then one write per accepted child at its sorted position (stack_push_sorted)
+    float tm[8];
+    int32_t cps[8];
+    uint32_t ok = 0;
+    int room = (int)stack.cap - s;   // (a full stack drops the children that do not fit, in child order)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int32_t cp = n.child[i];
-        if (cp == 0) continue;
         const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
         const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
         const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
@@ -173,10 +243,13 @@ WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& 
         const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
         const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, q.range.min));
         const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
-        if (rmin <= rmax && s < (int)stack.cap) stack[s++] = stack_entry_t{rmin, cp};
+        const bool acc = cp != 0 && rmin <= rmax && room > 0;
+        room -= acc ? 1 : 0;
+        ok |= acc ? 1u << i : 0u;
+        tm[i] = rmin;
+        cps[i] = cp;
     }
-    stack_sort_desc(stack, begin, s);
-    q.s = s;
+    q.s = stack_push_sorted(stack, s, tm, cps, ok);
 }
 // tests the held triangles (requires q.lcnt != 0); TRUE: an any-hit (shadow) query is decided
 template <bool shadow>
@@ -190,7 +263,7 @@ WT_HD bool rq_leaf_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& 
             return true;
         }
         int s = q.s;
-        while (s > 0 && stack[s - 1].t >= q.rec.dist) --s;
+        while (s > 0 && stack.get_t(s - 1) >= q.rec.dist) --s;
         q.s = s;
     }
     return false;
@@ -244,7 +317,7 @@ WT_HD bool cone_box_outside(float b0x, float b0y, float b0z, float b1x, float b1
     const float slack = 1e-5f * (fabsf(zc) + he) + 1e-12f;
     if (zc - he > range.max + slack || zc + he < range.min - slack) return true;
     const float rho2 = fmaxf_(0.f, cx * cx + cy * cy + cz * cz - zc * zc);
-    const float rbox = sqrtf(hx * hx + hy * hy + hz * hz);
+    const float rbox = cull_sqrtf(hx * hx + hy * hy + hz * hz);   // (the test below carries a 5e-4 margin)
     const float zhi = fminf_(range.max, zc + he);
     const float rcone = fmaxf_(0.f, fmaf(zhi, ta, ix));
     const float lim = (rcone + rbox) * 1.0005f + slack;
@@ -311,7 +384,7 @@ WT_HD void cq_begin(const scene_t& sc, const cone_t& cone, const range_t& search
     q.range = cone_search_range(cone, searchrange, q.rec.dist, z_scale);
     if (sc.n_nodes == 0) return;
     q.s = 1;
-    stack[0] = stack_entry_t{0.f, 1};
+    stack.set(0, stack_entry_t{0.f, 1});
 }
 // ends the query at once (budget exceeded / stack full / too short): nothing is left to visit
 WT_HD void cq_stop(cone_query_t& q) {
@@ -326,7 +399,7 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
     const float ta = cone.tan_alpha, ix = cone.x0;
     const range_t range = q.range;
     int s = q.s;
-    const stack_entry_t top = stack[s - 1];
+    const stack_entry_t top = stack.get(s - 1);
     --s;
     if (top.ptr < 0) {
         q.leaf = top.ptr;
@@ -343,12 +416,15 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
         cq_stop(q);
         return;
     }
-    const int begin = s;
+    // all eight box tests without a branch, then one write per accepted child at its sorted position (stack_push_sorted)
+    float tm[8];
+    int32_t cps[8];
+    uint32_t ok = 0;
+    int room = (int)stack.cap - s;
     bool full = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int32_t cp = n.child[i];
-        if (cp == 0) continue;
         // cone_cluster_intersect (bvh8w.cpp:187-230): grow the box by the cone radius at its far z
         float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
         float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
@@ -372,28 +448,28 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
         tmin = fmaxf_(tmin, dminy);
         tmax = fminf_(tmax, dmaxz);
         tmin = fmaxf_(tmin, dminz);
-        const bool hit = tmin <= tmax && tmax >= range.min && tmin <= range.max;
-        if (!hit) continue;
-        if (tmin >= range.max) continue;
-        if (cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) continue;
-        if (s < (int)stack.cap) {
-            stack[s++] = stack_entry_t{tmin, cp};
-        } else if (q.budget != 0xFFFFFFFFu) {
-            full = true;   // device: the 64-entry per-lane stack is full -> the wave-cooperative query (512 entries) takes over
-        }
-#if !defined(__HIP_DEVICE_COMPILE__)
-        else {   // CPU checker (unbudgeted): a dropped child would be a silently wrong answer
-            fprintf(stderr, "wt::cq_node_step: traversal stack of %u entries is full\n", stack.cap);
-            abort();
-        }
-#endif
+        const bool hit = cp != 0 && tmin <= tmax && tmax >= range.min && tmin <= range.max && !(tmin >= range.max) &&
+                         !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range);
+        const bool acc = hit && room > 0;
+        full = full || (hit && !acc);   // the stack cannot hold this child
+        room -= acc ? 1 : 0;
+        ok |= acc ? 1u << i : 0u;
+        tm[i] = tmin;
+        cps[i] = cp;
     }
     if (full) {
-        q.rec.aborted = 1;
-        cq_stop(q);
-        return;
+        if (q.budget != 0xFFFFFFFFu) {   // device: the 64-entry per-lane stack is full -> the wave-cooperative query (512 entries) takes over
+            q.rec.aborted = 1;
+            cq_stop(q);
+            return;
+        }
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // CPU checker (unbudgeted): a dropped child would be a silently wrong answer
+        fprintf(stderr, "wt::cq_node_step: traversal stack of %u entries is full\n", stack.cap);
+        abort();
+#endif
     }
-    stack_sort_desc(stack, begin, s);
+    s = stack_push_sorted(stack, s, tm, cps, ok);
     q.s = s;
 }
 // What follows from a hit of the running query at distance `dist` on triangle `tuid`: closest distance, list entry, early exit, slab
@@ -424,7 +500,7 @@ WT_HD void cq_apply_hit(const cone_t& cone, const stack_ref_t& stack, const uint
     // nothing further can be recorded, so only triangles that can still lower the closest distance matter.
     if (rec.overflow > 0) q.range.max = fminf_(q.range.max, rec.dist);
     int s = q.s;
-    while (s > 0 && stack[s - 1].t >= q.range.max) --s;
+    while (s > 0 && stack.get_t(s - 1) >= q.range.max) --s;
     q.s = s;
 }
 // One exact cone-triangle test of the running query.
@@ -510,9 +586,9 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
     const float ta = cone.tan_alpha, ix = cone.x0;
     uint32_t tests = 0;
     int s = 1;
-    stack[0] = stack_entry_t{0.f, 1};
+    stack.set(0, stack_entry_t{0.f, 1});
     while (s > 0) {
-        const stack_entry_t top = stack[s - 1];
+        const stack_entry_t top = stack.get(s - 1);
         --s;
         if (top.ptr < 0) {
             const bvh8_leaf_t leaf = bvh_leaf_of(top.ptr);
@@ -538,11 +614,14 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             aborted = true;
             return false;
         }
-        const int begin = s;
+        float tm[8];
+        int32_t cps[8];
+        uint32_t ok = 0;
+        int room = (int)stack.cap - s;
+        bool full = false;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int32_t cp = n.child[i];
-            if (cp == 0) continue;
             float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
             float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
             const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
@@ -560,16 +639,19 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             tmin = fmaxf_(tmin, dminy);
             tmax = fminf_(tmax, dmaxz);
             tmin = fmaxf_(tmin, dminz);
-            if (tmin <= tmax && tmax >= range.min && tmin <= range.max && !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range)) {
-                if (s < (int)stack.cap) {
-                    stack[s++] = stack_entry_t{tmin, cp};
-                } else if (budget != 0xFFFFFFFFu) {
-                    aborted = true;
-                    return false;
-                }
-            }
+            const bool hit = cp != 0 && tmin <= tmax && tmax >= range.min && tmin <= range.max && !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range);
+            const bool acc = hit && room > 0;
+            full = full || (hit && !acc);
+            room -= acc ? 1 : 0;
+            ok |= acc ? 1u << i : 0u;
+            tm[i] = tmin;
+            cps[i] = cp;
         }
-        stack_sort_desc(stack, begin, s);
+        if (full && budget != 0xFFFFFFFFu) {
+            aborted = true;
+            return false;
+        }
+        s = stack_push_sorted(stack, s, tm, cps, ok);
     }
     return false;
 }
@@ -982,9 +1064,9 @@ WT_HD uint32_t bvh_gather_edges(const scene_t& sc, const cone_t& tcone, const ra
     const vec3 ro = tcone.o, rd = tcone.d;
     const float ta = tcone.tan_alpha, ix = tcone.x0;
     int s = 1;
-    stack[0] = stack_entry_t{0.f, 1};
+    stack.set(0, stack_entry_t{0.f, 1});
     while (s > 0) {
-        const int32_t ptr = stack[s - 1].ptr;
+        const int32_t ptr = stack.get(s - 1).ptr;
         --s;
         uint32_t t0, cnt;
         if (ptr < 0) {
@@ -1000,7 +1082,7 @@ WT_HD uint32_t bvh_gather_edges(const scene_t& sc, const cone_t& tcone, const ra
                 const bool room = s < (int)stack.cap;   // (always: the pruned tree is a few levels of a handful of nodes)
                 overflow += room ? 0u : 1u;
                 if (room) {
-                    stack[s] = stack_entry_t{0.f, n.child[i]};
+                    stack.set(s, stack_entry_t{0.f, n.child[i]});
                     ++s;
                 }
             }

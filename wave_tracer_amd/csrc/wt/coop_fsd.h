@@ -86,7 +86,7 @@ __device__ inline bool coop_build_aperture(const scene_t& sc, const frame_t& fra
     // ---- fsd_build_finish: power in the 0-th order lobe (8-point average on a circle of radius 3*P0_sigma)
     const float psi0r = 3.f * kFsdP0Sigma;
     const vec2 dirs[8] = {{-kInvSqrt2, -kInvSqrt2}, {-1, 0}, {-kInvSqrt2, kInvSqrt2}, {0, 1}, {kInvSqrt2, kInvSqrt2}, {1, 0}, {kInvSqrt2, -kInvSqrt2}, {0, -1}};
-    double are[8], aim[8];
+    double are[8], aim[8], inc = 0.0;
 #pragma unroll
     for (int d = 0; d < 8; ++d) are[d] = aim[d] = 0.0;
     for (uint32_t i = lane; i < ap.n_edges; i += 64) {
@@ -96,8 +96,10 @@ __device__ inline bool coop_build_aperture(const scene_t& sc, const frame_t& fra
             const cplx p = fsd_Psi(e, psi0r * dirs[d]);
             are[d] += (double)p.re;
             aim[d] += (double)p.im;
+            inc += (double)cnorm(p);
         }
     }
+    inc = wave_sum(inc);
     float acc = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
@@ -105,6 +107,7 @@ __device__ inline bool coop_build_aperture(const scene_t& sc, const frame_t& fra
         acc += cnorm(cplx{re, im});
     }
     ap.psi02 = acc / 8.f;
+    ap.dead = (ap.n_edges >= 2 && acc < kFsdDeadRatio * (float)inc) ? 1u : 0u;   // (fsd_build_finish)
     ap.P0 = (kTwoPi * sqr(kFsdP0Sigma) * ap.psi02) / sqr(k * 1.f);
     float Pt = (float)P_total;
     Pt += ap.P0;

@@ -23,6 +23,20 @@ constexpr float kFsdP0Sigma = 0.288675134594813f / 4.f;
 constexpr float kFsdUnitM = 1e-3f;       // fsd_unit = 1 mm
 constexpr float kFsdWo2Cutoff = .85f;
 constexpr uint32_t kFsdMaxEdges = 4096;   // segments per aperture: effectively unbounded, like the reference's std::vector (overflow is counted)
+// An aperture is DEAD when the coherent sum of its segments' amplitudes vanishes against their incoherent sum (ratio of the powers at the
+// eight probe directions of the 0-th order estimate below this): a doubled scene edge — the rim of a thin plate modelled by two coincident
+// faces — enters as two segment chains of opposite direction whose amplitudes cancel to rounding (measured ratios 1e-13..1e-14; a real slit
+// would have to be narrower than ~50 nm to come near the threshold).  Its scattering function is rounding noise, the acceptance test
+// u g < f / n of the rejection sampler cannot pass, and the reference's loop spins through all n x 1024 tries before it reports failure:
+// in the headline workload 13 % of the apertures with 8-15 segments, 85 % of all tries of the pass (round 4, oracle fsd histogram).
+// fsd_max_tries is 0 for such an aperture: the same outcome (sample failed, walk ends) without the tries.
+constexpr float kFsdDeadRatio = 1e-10f;
+#if !defined(__HIPCC__)
+inline float g_fsd_dead_ratio = kFsdDeadRatio;   // CPU checker only: 0 switches the classification off (tools/fsd_dead_effect.py measures what it changes)
+#define WT_FSD_DEAD_RATIO ::wt::g_fsd_dead_ratio
+#else
+#define WT_FSD_DEAD_RATIO ::wt::kFsdDeadRatio
+#endif
 
 struct fsd_edge_t {
     vec2 e, v;    // edge vector, mid point (in fsd units = mm)
@@ -37,6 +51,7 @@ struct fsd_aperture_t {
     frame_t frame;
     uint32_t overflow;
     uint32_t edge_offset, edge_cap;   // this aperture's segment records: [edge_offset, edge_offset + edge_cap) of the pool's edge array
+    uint32_t dead;                    // the segments' amplitudes cancel identically: the rejection loop cannot accept (fsd_build_finish)
 };
 // edges of one aperture: contiguous AoS (an aperture is read many times by the one lane that owns it)
 struct fsd_edges_ref_t {
@@ -103,6 +118,7 @@ WT_HD fsd_build_state_t fsd_build_begin(const frame_t& frame, float k, float tot
     ap.frame = frame;
     ap.n_edges = 0;
     ap.overflow = 0;
+    ap.dead = 0;
     ap.recp_I = total_power > 0.f ? 1.f / total_power : 0.f;
     fsd_build_state_t st;
     st.cse = sigma * kBeamEnvelope;
@@ -194,9 +210,18 @@ WT_HD void fsd_build_finish(float k, fsd_build_state_t& st, fsd_aperture_t& ap, 
     // power in the 0-th order lobe (8-point average on a circle of radius 3*P0_sigma)
     const float psi0r = 3.f * kFsdP0Sigma;
     const vec2 dirs[8] = {{-kInvSqrt2, -kInvSqrt2}, {-1, 0}, {-kInvSqrt2, kInvSqrt2}, {0, 1}, {kInvSqrt2, kInvSqrt2}, {1, 0}, {kInvSqrt2, -kInvSqrt2}, {0, -1}};
-    float acc = 0.f;
-    for (int i = 0; i < 8; ++i) acc += fsd_ASF_unclamped(ap, ed, psi0r * dirs[i]);
+    float acc = 0.f, inc = 0.f;
+    for (int i = 0; i < 8; ++i) {   // fsd_ASF_unclamped at the probe direction, and the incoherent sum of the same terms beside it
+        cplx amp{0.f, 0.f};
+        for (uint32_t j = 0; j < ap.n_edges; ++j) {
+            const cplx psi = fsd_Psi(ed.get(j), psi0r * dirs[i]);
+            amp = amp + psi;
+            inc += cnorm(psi);
+        }
+        acc += cnorm(amp);
+    }
     ap.psi02 = acc / 8.f;
+    ap.dead = (ap.n_edges >= 2 && acc < WT_FSD_DEAD_RATIO * inc) ? 1u : 0u;
     ap.P0 = (kTwoPi * sqr(kFsdP0Sigma) * ap.psi02) / sqr(k * 1.f);   // k [1/mm] * fsd_unit [mm]
     P_total += ap.P0;
     if (P_total > 0.f) {
@@ -291,7 +316,7 @@ struct fsd_try_t {
     float f;
     uint32_t accept;
 };
-WT_HD uint32_t fsd_max_tries(const fsd_aperture_t& ap) { return ap.n_edges * 1024u; }
+WT_HD uint32_t fsd_max_tries(const fsd_aperture_t& ap) { return ap.dead ? 0u : ap.n_edges * 1024u; }
 WT_HD uint32_t fsd_tries_base(const sampler_t& s) { return (s.draws + 3u) & ~3u; }
 // one try; `s` positioned at the try's first draw
 // fsd_sampling_density and fsd_ASF of the same point in ONE pass over the segments (same per-segment arithmetic; a try of the

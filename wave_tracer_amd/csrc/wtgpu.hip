@@ -39,7 +39,6 @@
 #include "wt/bdpt.h"
 #include "wt/coop.h"
 #include "wt/coop_fsd.h"
-#include "wt/g8.h"
 #include "wt/path.h"
 
 using namespace wt;
@@ -193,7 +192,7 @@ struct wtgpu_scene {
     size_t query_scratch_bytes = 0;
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
-        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, trace_refill = 1, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
+        uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 6, shrink_f1 = 4, shrink_r2 = 12, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
@@ -243,11 +242,7 @@ struct launch_args_t {
 
 // (block size as a constant: blockDim would pull 256 bytes of hidden kernel arguments into the kernel-argument segment)
 __device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s, uint32_t block = kBlock) {
-    s.p = lds + threadIdx.x;
-    s.stride = block;
-    s.n_fast = kLdsStack;
-    s.q = spill;
-    s.cap = kLdsStack + kSpillStack;
+    s = make_stack_ref(lds + threadIdx.x, block, kLdsStack + kSpillStack, kLdsStack, spill);
 }
 
 __device__ inline void flush_counters(unsigned long long* g, const bdpt_counters_t& c) {
@@ -340,90 +335,14 @@ __device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int o
     if (back) a.st.queue[out][2 * (size_t)a.st.cap - 1 - (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = w;
 }
 
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t a, int in, int first_round, uint32_t round) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = queue_count(ctl, in);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
-        ctl[CTL_BACK0 + (1 - in)] = 0;
-        ctl[CTL_HEAD_INTERACT] = 0;
-        ctl[CTL_INTB_COUNT] = 0;
-        ctl[CTL_INTB_HEAD] = 0;
-        ctl[CTL_GATHER_COUNT] = 0;
-        ctl[CTL_GATHER_HEAD] = 0;
-        ctl[CTL_INTC_COUNT] = 0;
-        ctl[CTL_INTC_HEAD] = 0;
-        ctl[CTL_FTASK_COUNT] = 0;
-        ctl[CTL_FTASK_HEAD] = 0;
-        ctl[CTL_FSPLIT_HEAD] = 0;
-        ctl[CTL_EPOOL_COUNT] = 0;
-        ctl[CTL_INTD_COUNT] = 0;
-        ctl[CTL_INTD_HEAD] = 0;
-        // plt_path: this round's wedge pool and the queue it fills for the next round's k_path_fsd; this round's k_path_fsd / k_path_nee heads
-        ctl[CTL_UTD_COUNT0 + (round & 1u)] = 0;
-        ctl[CTL_FSDQ_COUNT0 + ((round + 1u) & 1u)] = 0;
-        ctl[CTL_FSDQ_HEAD] = 0;
-        ctl[CTL_NEEQ_COUNT] = 0;
-        ctl[CTL_NEEQ_HEAD] = 0;
-        if (n > 0) ctl[CTL_ROUNDS] = round + 1;
-    }
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-    for (;;) {
-        const uint32_t qi = wave_grab(ctl + CTL_HEAD_TRACE) + (threadIdx.x & 63);
-        if (qi - (threadIdx.x & 63) >= n) break;
-        bool heavy = false;
-        uint32_t w = 0;
-        if (qi < n) {
-            w = queue_walk(a, ctl, in, qi, first_round);
-            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
-            // plt_bdpt: closest-hit-only cone queries (list capacity 0: once something is hit only nearer triangles matter, wt/bvh.h) —
-            // what an interaction needs of its region is the triangle under the beam axis (resolve_primary) and, for the few walks
-            // without one, sums over the WHOLE region gathered later (k_edges, k_interact_c).  plt_path keeps the bounded list.
-            uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;   // 64 triangle ids + their 64 cone-hit distances
-            const uint_list_t tris{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
-            const cone_t env = walk_trace_envelope(a.sc, wk);
-            const trav_result_t tr = traverse_axis(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, stack, tris, nullptr, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
-            if (tr.aborted == 1) {
-                heavy = true;
-                // resume state for k_trace_heavy (traverse_axis(): dist / ntris = segment / query counts so far + the axis hit)
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)] = __float_as_uint(tr.dist);
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)] = tr.ntris;
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)] = tr.n_ray_queries;
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)] = tr.n_cone_queries;
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)] = tr.tuid;
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)] = __float_as_uint(tr.bx);
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = __float_as_uint(tr.by);
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(pdist)] = __float_as_uint(tr.pdist);
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)] = tr.front_face;
-                a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(overflow)] = tr.overflow;   // the triangle that made the last attempt too short (kInvalid: none)
-            } else {
-                soa_store(a.st.trav, kTravWords, w, tr);
-                ctr.segments += 1;
-                ctr.ray_queries += tr.n_ray_queries;
-                ctr.cone_queries += tr.n_cone_queries;
-                if (a.collect_list) ctr.cone_tri_overflow += tr.overflow;
-            }
-        }
-        wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w);
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-
 #ifndef WTGPU_LEAF_NUM
 #define WTGPU_LEAF_NUM 1   // leaf step when at least NUM / DEN of the running lanes hold a leaf (swept 1/3, 1/2, 2/3, 3/4: 99.0 / 97.6 / 96.6 / 97.9 ms per pass, noise 1 ms)
 #define WTGPU_LEAF_DEN 2
 #endif
-// k_trace with LANE REFILL (the default; the kernel above is kept as the A/B reference, WTGPU_TRACE_REFILL=0).
+// The per-lane trace kernel, with LANE REFILL.
 // The cost of a walk's traversal varies by two orders of magnitude — one to seven cone queries of 2..cone_budget work units each —
-// and in the kernel above a wavefront is as slow as its slowest lane: its lanes run the policy and their queries back to back and
-// wait at the end for the longest.  Here a lane is a slot that walks pass through.  The wavefront alternates between
+// and a wavefront whose lanes ran the policy and their queries back to back would be as slow as its slowest lane (rounds 1-2: that kernel
+// was kept as an A/B reference until round 4).  Here a lane is a slot that walks pass through.  The wavefront alternates between
 //   * the traversal loop: every lane that holds a node descends (cq_node_step), every lane that holds a leaf tests its triangles
 //     (cq_leaf_step) — the steps of wt/bvh.h, which the CPU checker drives one query at a time —
 //   * and the service section, entered once enough lanes wait: a lane whose query ended gets the policy's next query (aw_query_done /
@@ -431,6 +350,13 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace(launch_args_t 
 //     axis and start their first query.
 // A slow query therefore occupies one lane, not 64, which is also what lets the work budget per query be larger (fewer walks
 // handed to the wave-cooperative kernel).  Per walk the sequence of visits and the results are those of wt::traverse_axis.
+//
+// GUIDED FETCH (round 4).  A wavefront that holds 64 walks in 64 different states advances them almost one at a time (the steps of
+// different kinds serialise: 9 of 64 lanes busy per instruction); that is the price of throughput while the queue is long, but it is also
+// what every round paid at its END: the wavefronts that happened to grab the last 64 walks each took ~1.4 ms to work them off, alone on the
+// GPU, whether the round held 4 million walks or 400 (rounds 4..21 of a 1440^2 pass: 1.5 ms each, 27 of the kernel's 52 ms).  So a
+// wavefront holds at most target = ceil(walks left in the queue / wavefronts of the grid) walks (guided self-scheduling: 64 while the queue is
+// long, 1 near its end), from the queue length it saw at its last fetch; the tail of a round is then as long as its longest single walk.
 #ifndef WTGPU_REFILL_MIN
 #define WTGPU_REFILL_MIN 16
 #endif
@@ -442,7 +368,10 @@ __device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, b
         aw_test_done(aw, cone_attempt_too_short_by(sc, env, aw.cand, aw.sr, aw.min_df_prog));
     }
 }
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) {
+#ifndef WTGPU_GSS_MUL
+#define WTGPU_GSS_MUL 1   // target walks per wavefront = ceil(MUL x walks left / wavefronts); 0: always 64 (round 3's behaviour)
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round, uint32_t n_waves) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = queue_count(ctl, in);
@@ -490,6 +419,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
     memset(&aw, 0, sizeof(aw));
     memset(&q, 0, sizeof(q));
     bool exhausted = false;   // wave-uniform: the queue holds no more walks
+    uint32_t rem_est = n;     // wave-uniform: walks left in the queue when this wavefront last looked (guided fetch)
 #ifdef WTGPU_REFILL_PROF
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pl[6] = {0, 0, 0, 0, 0, 0};
     long long pt;
@@ -517,16 +447,23 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         const int n_idle = __popcll(__ballot(st == 0 && !fin)), n_run = __popcll(__ballot(st == 1));
         bool fetched = false;
         const bool any_fin = __ballot(fin) != 0;   // (their records are stored first; they fetch in the next turn)
-        if (!exhausted && !any_fin && (n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
-            const unsigned long long im = __ballot(st == 0);
+        // guided fetch: the number of walks this wavefront may hold now
+        const int target = WTGPU_GSS_MUL == 0 ? 64 : (int)min(64u, max(1u, (uint32_t)(((unsigned long long)rem_est * WTGPU_GSS_MUL + n_waves - 1u) / n_waves)));
+        const int room = min(n_idle, target - n_run);
+        if (!exhausted && !any_fin && room > 0 && (target < 64 || n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
+            const unsigned long long im0 = __ballot(st == 0);
+            const bool take = st == 0 && __popcll(im0 & below) < room;   // the lowest `room` idle lanes
+            const unsigned long long im = __ballot(take);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(ctl + CTL_HEAD_TRACE, (uint32_t)__popcll(im));
             base = (uint32_t)__shfl((int)base, 0, 64);
-            if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
-            const uint32_t qi = base + (uint32_t)__popcll(im & below);
+            const uint32_t end = base + (uint32_t)__popcll(im);
+            if (end >= n) exhausted = true;
+            rem_est = end >= n ? 0u : n - end;
+            const uint32_t qi = take ? base + (uint32_t)__popcll(im & below) : 0xFFFFFFFFu;
             RP_BEGIN();
-            const unsigned long long m_f = __ballot(st == 0 && qi < n);
-            if (st == 0 && qi < n) {
+            const unsigned long long m_f = __ballot(take && qi < n);
+            if (take && qi < n) {
                 w = queue_walk(a, ctl, in, qi, first_round);
                 w_fin = w;
                 const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
@@ -583,6 +520,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             continue;
         }
         // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_REFILL_MIN) wait to be served
+        // (idle lanes wait for a walk only while this wavefront may fetch: not once it holds its guided share)
+        const bool may_fetch = !exhausted && running < target;
         const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
         for (;;) {
             // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
@@ -600,7 +539,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
             RP_END(4, m_leaf);
             if (st == 1 && !cq_running(q)) st = 2;
-            const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
+            const int waiting = __popcll(__ballot(st == 2)) + (may_fetch ? __popcll(__ballot(st == 0)) : 0);
             if (waiting >= leave_at || !__ballot(st == 1)) break;
         }
     }
@@ -731,8 +670,8 @@ __device__ inline __attribute__((always_inline)) void interact_body(const launch
                 defer.has_gather = 1;
                 defer.gather_n_edges = tr.n_ray_queries;
                 defer.gather_edge_overflow = tr.n_cone_queries;
-                const uint32_t off = __float_as_uint(tr.bx);   // offset into the round's edge pool (0xFFFFFFFF: the list slot)
-                defer.gather_edges = off != 0xFFFFFFFFu ? a.st.epool + off : a.st.tris + (size_t)w * kTriListWords;
+                const uint32_t off = __float_as_uint(tr.bx);   // offset into the round's edge pool
+                defer.gather_edges = a.st.epool + off;
             }
             const long long pb0 = PASS_B && a.profile == 3 ? clock64() : 0;
             if (!queued_for_c) cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
@@ -786,29 +725,26 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
         const cone_t tcone = walk_trace_envelope(a.sc, wk);
         const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
         __syncthreads();
-        // sorted ids -> the round's edge pool (unbounded lists: bitmap mode) or the walk's 128-word list slot (scenes with > 32768 edges)
+        // sorted ids -> the round's edge pool: any number of them in bitmap mode, the sorted 96-entry list for scenes with more than 32768 classified
+        // edges.  (Until round 4 that list went into the walk's triangle-list slot, which a later pass may still read as triangles.)
         const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
-        uint32_t n_edges = g.n_edges, dropped = g.edge_overflow, off = 0xFFFFFFFFu;
-        if (bitmap) {
-            n_edges = coop_edge_count(a.sc, eg);
-            if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
-            __syncthreads();
-            off = s_item;
-            __syncthreads();
-            if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported, cannot happen in the shipped scenes
-                dropped = n_edges;
-                n_edges = 0;
-            } else
-                coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
-        } else {
-            uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
-            for (uint32_t j = threadIdx.x; j < g.n_edges; j += 64) dst[j] = eg.edge_ids[j];
-        }
+        uint32_t n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges, dropped = bitmap ? 0u : g.edge_overflow, off = 0;
+        if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
+        __syncthreads();
+        off = s_item;
+        __syncthreads();
+        if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported, cannot happen in the shipped scenes
+            dropped += n_edges;
+            n_edges = 0;
+        } else if (bitmap)
+            coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
+        else
+            for (uint32_t j = threadIdx.x; j < n_edges; j += 64) a.st.epool[off + j] = eg.edge_ids[j];
         // Regions with many edges: the aperture is built right here, by the whole wavefront (wt/coop_fsd.h), instead of by one lane of
         // pass B; walks whose aperture has segments go straight to the pass-C queue.
         uint32_t marker = kGatherMarker, slot = 0;
         if (n_edges >= a.coop_aperture_min) {
-            const uint32_t* eids = off != 0xFFFFFFFFu ? a.st.epool + off : a.st.tris + (size_t)w * kTriListWords;
+            const uint32_t* eids = a.st.epool + off;
             __syncthreads();   // the ids were written by other lanes
             if (threadIdx.x == 0) s_item = fsd_pool_alloc(pool);
             __syncthreads();
@@ -1085,7 +1021,7 @@ __device__ inline __attribute__((always_inline)) void interact_c_body(const laun
             defer.end_draws = fsd_draws_after(base, acc ? t_acc : max_tries - 1u);
             const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
             const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
-            stack_ref_t stack{lds, 1, 8, 8, nullptr};
+            stack_ref_t stack = make_stack_ref(lds, 1, 8, 8, nullptr);
             cont = bdpt_walk_step<2>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
             wk.active = cont ? 1u : 0u;
             soa_store(a.st.walks, a.st.walk_words, w, wk);
@@ -1245,24 +1181,21 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const pat
         if (any) {
             const gather_out_t g = coop_gather(a.sc, cone, slab, cone, cone_frame(cone), slab, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
             __syncthreads();
-            if (a.sc.n_edges <= kCoopEdgeBits) {
-                n_edges = coop_edge_count(a.sc, eg);
-                if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
-                __syncthreads();
-                off = s_item;
-                __syncthreads();
-                if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported
-                    dropped = n_edges;
-                    n_edges = 0;
-                } else
-                    coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
-            } else {   // scenes with more classified edges than the bitmap holds: the sorted 96-entry list, into the walk's list slot
-                n_edges = g.n_edges;
-                dropped = g.edge_overflow;
-                off = 0xFFFFFFFFu;
-                uint32_t* dst = a.st.tris + (size_t)w * kTriListWords;
-                for (uint32_t j = threadIdx.x; j < n_edges; j += 64) dst[j] = eg.edge_ids[j];
-            }
+            // (every id list goes into the round's edge pool: the walk's triangle-list slot is read again as triangles by PASS 1)
+            const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
+            n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges;
+            dropped = bitmap ? 0u : g.edge_overflow;
+            if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
+            __syncthreads();
+            off = s_item;
+            __syncthreads();
+            if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported
+                dropped += n_edges;
+                n_edges = 0;
+            } else if (bitmap)
+                coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
+            else
+                for (uint32_t j = threadIdx.x; j < n_edges; j += 64) a.st.epool[off + j] = eg.edge_ids[j];
         }
         if (threadIdx.x == 0) {
             P.gather_info[w] = make_uint2(off, n_edges);
@@ -1321,7 +1254,7 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
             if (PASS) {
                 const uint2 gi = P.gather_info[w];
                 defer.gather_n = gi.y;
-                defer.gather_edges = gi.x != 0xFFFFFFFFu ? a.st.epool + gi.x : slot;
+                defer.gather_edges = a.st.epool + gi.x;
             }
             cont = path_walk_step(a.sc, pw, tr, tris, prev_pool, pool, a.film, a.seed, sample_id, stream, stack, &ctr, &defer);
             gather = defer.need_gather != 0;
@@ -1590,24 +1523,6 @@ __global__ void __launch_bounds__(kBlock) k_trace_rays(scene_t sc, const float* 
     bary[2 * i + 1] = h.by;
     front[i] = h.front_face;
 }
-constexpr int kG8Groups = kBlock / 8;
-// 8-lane-group variant (wt/g8.h): one ray per group, 16 groups per block
-__global__ void __launch_bounds__(kBlock) k_trace_rays_g8(scene_t sc, const float* rays, uint32_t n, float* dist, uint32_t* tuid, float* bary, uint32_t* front) {
-    __shared__ stack_entry_t lds[kG8Stack * (kBlock / 8)];
-    const uint32_t i = blockIdx.x * (kBlock / 8) + (threadIdx.x >> 3);
-    if (i >= n) return;
-    const g8_stack_t st{lds + kG8Stack * (threadIdx.x >> 3)};
-    const float* r = rays + 8 * (size_t)i;
-    ray_hit_t h;
-    g8_intersect_ray(sc, vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, range_t{r[6], r[7]}, st, h);
-    if ((threadIdx.x & 7u) == 0) {
-        dist[i] = h.dist;
-        tuid[i] = h.tuid;
-        bary[2 * i] = h.bx;
-        bary[2 * i + 1] = h.by;
-        front[i] = h.front_face;
-    }
-}
 __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
                                                            uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
@@ -1720,7 +1635,43 @@ const char* wtgpu_last_error(void) { return g_err.c_str(); }
 // The HIP runtime stages by-value kernel arguments in a 1 MiB ring per stream; a batch enqueues ~1000 launches of ~1 KB, and a full ring blocks
 // the enqueueing thread until the GPU has caught up — which serialises the internal streams.  Ask for 16 MiB before the runtime reads its
 // settings (it does so at its first use; a process that initialised HIP earlier sets HSA_KERNARG_POOL_SIZE itself).
-__attribute__((constructor)) static void wtgpu_runtime_settings() { setenv("HSA_KERNARG_POOL_SIZE", "16777216", 0); }
+// GPU_MAX_HW_QUEUES likewise (default 4 hardware queues: the three internal streams and the caller's share queues and serialise).  Both are only
+// defaults (a host's own setting wins) and both take effect only if the runtime has not initialised yet; g_env_by_host records what the host had
+// set itself, wtgpu_scene_upload refuses settings that are KNOWN to serialise the streams (runtime_settings_ok).
+static int g_env_by_host = 0;   // bit 0: HSA_KERNARG_POOL_SIZE, bit 1: GPU_MAX_HW_QUEUES were in the environment when the library was loaded
+__attribute__((constructor)) static void wtgpu_runtime_settings() {
+    if (getenv("HSA_KERNARG_POOL_SIZE")) g_env_by_host |= 1;
+    if (getenv("GPU_MAX_HW_QUEUES")) g_env_by_host |= 2;
+    setenv("HSA_KERNARG_POOL_SIZE", "16777216", 0);
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+// The two runtime settings the stream pipeline needs.  An explicit setting that is too small is an ERROR (it would silently cost
+// 30-50 % — WTGPU_ALLOW_SLOW_RUNTIME=1 overrides); settings this library had to default itself are reported once: they are in effect only if HIP
+// was not initialised before libwtgpu.so was loaded, which cannot be queried.
+static int runtime_settings_ok(std::string& why) {
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    const char* k = getenv("HSA_KERNARG_POOL_SIZE");
+    const long nq = q ? atol(q) : 4, ring = k ? atol(k) : (1l << 20);
+    if (getenv("WTGPU_ALLOW_SLOW_RUNTIME")) return 1;
+    if (nq < 4) {
+        why = "GPU_MAX_HW_QUEUES=" + std::string(q ? q : "(unset)") + ": the renderer's three internal streams and the caller's need >= 4 hardware queues (8 recommended); "
+              "export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises, or WTGPU_ALLOW_SLOW_RUNTIME=1 to run serialised";
+        return 0;
+    }
+    if (ring < (4l << 20)) {
+        why = "HSA_KERNARG_POOL_SIZE=" + std::string(k ? k : "(unset)") + ": a batch enqueues ~900 launches of ~1 KB of kernel arguments; with a ring below 4 MiB the enqueueing "
+              "thread blocks and the streams serialise; export HSA_KERNARG_POOL_SIZE=16777216 before the HIP runtime initialises, or WTGPU_ALLOW_SLOW_RUNTIME=1";
+        return 0;
+    }
+    if ((g_env_by_host & 3) != 3 && !getenv("WTGPU_QUIET")) {
+        static bool told = false;
+        if (!told) fprintf(stderr, "[wtgpu] note: %s%s defaulted by libwtgpu.so; effective only if the HIP runtime had not initialised before the library was loaded "
+                           "(a host that uses HIP earlier exports them itself, INTEGRATION.md)\n", (g_env_by_host & 1) ? "" : "HSA_KERNARG_POOL_SIZE=16777216 ",
+                           (g_env_by_host & 2) ? "" : "GPU_MAX_HW_QUEUES=8");
+        told = true;
+    }
+    return 1;
+}
 
 int wtgpu_scene_create_named_hooks(const char* name, const wtgpu_scene_params* params, const wtgpu_test_hooks* hooks, wtgpu_scene** out) {
     if (!name || !params || !out) return fail(WTGPU_ERR_INVALID, "null argument");
@@ -1926,6 +1877,10 @@ static void release_device(wtgpu_scene* s);
 int wtgpu_scene_upload(wtgpu_scene* s, int device, uint64_t max_batch) {
     if (!s) return fail(WTGPU_ERR_INVALID, "null scene");
     if (s->uploaded) return fail(WTGPU_ERR_INVALID, "scene already uploaded");
+    {
+        std::string why;
+        if (!runtime_settings_ok(why)) return fail(WTGPU_ERR_INVALID, why);
+    }
     int ndev = 0;
     const hipError_t dc = hipGetDeviceCount(&ndev);
     if (dc != hipSuccess || ndev == 0)
@@ -1958,7 +1913,6 @@ static void read_knobs(wtgpu_scene* s) {
     k.lane_cache = u("WTGPU_LANE_CACHE", 1);
     k.heavy_cache = u("WTGPU_HEAVY_CACHE", 1);
     k.stagger_round = std::min<uint32_t>(u("WTGPU_STAGGER_ROUND", 0), kMaxWalkIters - 1);   // 0: all streams start at once
-    k.trace_refill = u("WTGPU_TRACE_REFILL", 1);   // 0: the per-lane trace kernel without lane refill (A/B reference)
     k.profile = u("WTGPU_PROFILE", 0);
     k.no_lists = getenv("WTGPU_NO_LISTS") ? 1u : 0u;
     k.heavy_waves_per_cu = std::max(1u, u("WTGPU_HEAVY_WAVES", 8));   // swept 6 / 8 / 10 / 12 / 16 / 24 / 32: 169.6 / 168.0 / 171.6 / 174.3 / 176 / 181 / 183 ms per pass
@@ -1972,14 +1926,6 @@ static void read_knobs(wtgpu_scene* s) {
     k.coop_aperture_min = u("WTGPU_COOP_APERTURE_MIN", 8);   // 0xFFFFFFFF: every aperture by a single lane of pass B
     if (const char* e = getenv("WTGPU_DEBUG_STAGE")) k.dbg_stage = atoi(e);   // bring-up aid: stops launching the round kernels after stage n (invalid results)
     if (const char* e = getenv("WTGPU_TIMING")) s->timing = atoi(e) != 0;
-    // The renderer pipelines batches over several HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware
-    // queues and streams sharing a queue serialise (-30 %).  The variable is read when the HIP runtime initialises: say so once.
-    const char* q = getenv("GPU_MAX_HW_QUEUES");
-    if ((!q || atoi(q) < 8) && !getenv("WTGPU_QUIET")) {
-        static bool warned = false;
-        if (!warned) fprintf(stderr, "[wtgpu] GPU_MAX_HW_QUEUES=%s: export GPU_MAX_HW_QUEUES=8 before the HIP runtime loads, or the 4 internal streams serialise (~30 %% slower)\n", q ? q : "(unset)");
-        warned = true;
-    }
 }
 
 static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
@@ -2042,10 +1988,18 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         // (WTGPU_STATE_GB, default 144 of the 288 GB) by shrinking the batches of deep scenes — more, smaller batches, same results
         const bool pm = h.opts.integrator != INTEGRATOR_BDPT;
         const uint64_t mv = (uint64_t)h.opts.max_depth + 2;
-        const uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
-        uint64_t budget_gb = 144;
-        if (const char* e = getenv("WTGPU_STATE_GB")) budget_gb = (uint64_t)std::max(1, atoi(e));
-        const uint64_t fit = std::max<uint64_t>(4096, (budget_gb << 30) / per_sample / n_slices);
+        uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
+        // plt_path: two wedge pools of 48 records per walk, the deferred-NEE records, the queues of the wave-per-walk kernels
+        if (pm) per_sample += 2ull * 48ull * sizeof(utd_edge_rec_t) + sizeof(path_nee_rec_t) + 3ull * 4ull + 4ull + sizeof(uint2);
+        uint64_t budget = 144ull << 30;
+        if (const char* e = getenv("WTGPU_STATE_GB")) budget = (uint64_t)std::max(1, atoi(e)) << 30;
+        // ... and within what the device has free right now (another scene, torch's caching allocator, a smaller GPU): 85 % of it, the rest is
+        // for the per-slice pools (edge ids, region-sum tasks, Fraunhofer segments: ~0.3 GB per slice) and the caller's films
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)((double)free_b * 0.85));
+        const uint64_t fixed = (uint64_t)n_slices * ((1ull << 23) * 4ull + (1ull << 22) * 8ull + (64ull << 20));   // pools that do not scale with the batch
+        budget = budget > 2 * fixed ? budget - fixed : budget / 2;
+        const uint64_t fit = std::max<uint64_t>(4096, budget / per_sample / n_slices);
         if (batch_cap > fit) batch_cap = fit;
     }
     unsigned long long* counters = nullptr;
@@ -2289,10 +2243,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
                 gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
             }
             if (dbg_stage >= 2 + 3 * (int)round) {
-                if (K.trace_refill)
-                    HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
-                else
-                    HP_LAUNCH(4, k_trace, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round, g0 * (uint32_t)(kBlock / 64));
             }
             rec();
             if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
@@ -2337,7 +2288,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         r.busy = true;
     }
     if (hp_on) {
-        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","k_trace","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
+        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","(unused)","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
         for (int i = 0; i < 24; ++i)
             if (hp_n[i]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", hp_names[i], hp_n[i], hp_t[i], hp_t[i] / hp_n[i]);
         if (hp_n[31]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", "hipEventRecord", hp_n[31], hp_t[31], hp_t[31] / hp_n[31]);
@@ -2455,11 +2406,7 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
 int wtgpu_trace_rays(wtgpu_scene* s, void* stream_, const float* d_rays, uint32_t n, float* d_dist, uint32_t* d_tuid, float* d_bary, uint32_t* d_front) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    static const bool per_lane = getenv("WTGPU_RAYS_G8") == nullptr;   // A/B switch: the pipeline's per-lane traversal (default) / 8-lane groups (wt/g8.h)
-    if (per_lane)
-        hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
-    else
-        hipLaunchKernelGGL(k_trace_rays_g8, dim3((n + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
+    hipLaunchKernelGGL(k_trace_rays, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->dev, d_rays, n, d_dist, d_tuid, d_bary, d_front);
     HIP_CHECK(hipGetLastError());
     return WTGPU_OK;
 }
