@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--res", type=int, default=1440)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
+    ap.add_argument("--batch-target", type=int, default=4200000, help="default step size: as many samples per element as bring one step (= one batch) to about "
+                    "this many samples (every batch runs its rounds down to a thin tail, so the tails cost per BATCH: DESIGN.md §0)")
     ap.add_argument("--mesh-detail", type=int, default=-1, help="stand-in geometry level (default: 1 for the cornell box = SURVEY 8(d) C1/C3's 283 K triangles; 2 for "
                     "etoile / bidir_room = C4's ~560 seeded buildings, C5's ~50 objects and 34 materials)")
     ap.add_argument("--polarimetric", type=int, default=-1, help="Stokes film (default: on for bidir_room = BASELINE.json configs[4])")
@@ -129,6 +131,8 @@ def main():
                     help="film reduce: nccl = RCCL over xGMI (one GPU per rank); gloo: host reduce, ranks may share a GPU (launcher tests on 1-GPU boxes)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--spp-per-step", type=int, default=0, help="samples per element and step (default 1; strong scaling: the number of ranks)")
+    ap.add_argument("--film-sums", action="store_true", help="add the sums of the (reduced) film planes to the JSON line: with --warmup 0 the ranks of a strong-scaling run "
+                    "render exactly the samples a single rank renders with the same --spp-per-step, so the sums must agree (tests/test_gpu_render.py)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -174,17 +178,20 @@ def main():
     pol = args.polarimetric if args.polarimetric >= 0 else (1 if args.scene == "bidir_room" else 0)
     sc = Scene(args.scene, res=args.res, mesh_detail=md, polarimetric=pol, force_ray_tracing=1 if args.ray_tracing else 0)
     npix = sc.width * sc.height
-    sc.upload(local_rank, args.batch or npix)
-    value, weight, light = alloc_films(sc, dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    value, weight, light = None, None, None
     K, Wm = args.steps, args.warmup
     # one step = S samples per element over the whole job.  weak: every rank renders its own S per step (work per GPU fixed); strong:
     # the ranks split the S samples of a step (total work fixed).  Sample indices are disjoint across ranks and steps.
-    S = args.spp_per_step or (world if args.scaling == "strong" else 1)
+    # default: whole passes that fill one batch (round 4: 1440^2 -> 2 spp per step, 720x540 -> 11); strong scaling: a multiple of the ranks
+    S_auto = max(1, min(16, round(args.batch_target / npix)))
+    S = args.spp_per_step or (world * max(1, S_auto // world) if args.scaling == "strong" else S_auto)
     if args.scaling == "strong":
         assert S % world == 0, "--spp-per-step must be a multiple of the number of ranks for strong scaling"
     s_rank = S // world if args.scaling == "strong" else S          # samples per element this rank renders per step
     base = rank * (K + Wm) * s_rank
+    sc.upload(local_rank, args.batch or npix * s_rank)              # one step = one batch (the library shrinks it to what the free HBM holds)
+    value, weight, light = alloc_films(sc, dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -220,6 +227,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    film_sums = [float(t.sum().item()) for t in (value, weight, light)] if args.film_sums else None   # (rank 0 holds the reduced film)
     counters = sc.counters()
     tsum = sc.timings()      # HIP-event kernel times accumulated over the timed region (reset after the warm-up)
     if rank == 0:
@@ -314,6 +322,10 @@ def main():
                                     "iteration_cap_hits": counters["walk_iteration_cap_hits"] / ns,
                                     "traversal_stack_dropped": counters["traversal_stack_dropped"] / ns},
         }
+        if distributed:
+            out["film_reduce"] = {"through": "wtgpu_film_reduce (RCCL inside the C-ABI library)" if comm is not None else "torch.distributed gloo (host)", "ranks": world}
+        if film_sums is not None:
+            out["film_sums"] = {"value": film_sums[0], "weight": film_sums[1], "light": film_sums[2]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scene, args.res, args.cpu_seconds, md, pol)
         print(json.dumps(out))

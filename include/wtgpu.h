@@ -119,13 +119,26 @@ int wtgpu_join(wtgpu_scene* scene, void* stream);
 /* The render seam's control surface (scene_renderer_t: progress callback + terminate interrupt polled between jobs,
  * include/wt/scene/scene_renderer.hpp:42-62, src/scene/render.cpp:306-368).  Renders [sample_begin, sample_end) in chunks of
  * `chunk_spp` samples per element (0: 1), BLOCKING: after every chunk `stream` is synchronised, progress(samples_done, samples_total,
- * user) is called (may be NULL) and the cancel flag is polled; a non-zero return of the callback or a wtgpu_cancel() from any thread
+ * user) is called (may be NULL) and the interrupts are processed (cancel below; pause / resume / capture intermediate further down); a non-zero return of the callback or a wtgpu_cancel() from any thread
  * ends the render after the current chunk with WTGPU_CANCELLED — the films then hold exactly the completed chunks
  * (*spe_done samples per element; may be NULL), which is what the reference's `capture intermediate` develops. */
 typedef int (*wtgpu_progress_cb)(uint64_t samples_done, uint64_t samples_total, void* user);
 int wtgpu_render_progressive(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin,
                              uint64_t sample_end, uint64_t seed, uint32_t chunk_spp, wtgpu_progress_cb progress, void* user, uint64_t* spe_done);
 int wtgpu_cancel(wtgpu_scene* scene);   /* thread-safe; cleared when the next wtgpu_render_progressive starts */
+/* The renderer's other three interrupts (include/wt/scene/interrupts.hpp; scene_renderer_t::process_interrupts, src/scene/render.cpp:329-368),
+ * all thread-safe, all taking effect at the next chunk boundary of a running wtgpu_render_progressive:
+ *   wtgpu_pause / wtgpu_resume      the render thread stops launching (it polls every millisecond) until resumed or cancelled; the films hold
+ *                                   exactly the completed chunks while it waits.
+ *   wtgpu_capture_intermediate      `capture intermediate`: the render thread calls capture(samples_per_element_done, user) ONCE at the next chunk
+ *                                   boundary (also while paused), with `stream` synchronised — the films then hold exactly the completed chunks and
+ *                                   the callback may download / develop them (wtgpu_develop) — and carries on in the state it was in, like the
+ *                                   reference, which pauses, develops and restores the paused state.  One request may be pending at a time (a
+ *                                   second one replaces it); a request made while no render runs is served by the next render's first boundary. */
+int wtgpu_pause(wtgpu_scene* scene);
+int wtgpu_resume(wtgpu_scene* scene);
+typedef void (*wtgpu_capture_cb)(uint64_t samples_per_element_done, void* user);
+int wtgpu_capture_intermediate(wtgpu_scene* scene, wtgpu_capture_cb capture, void* user);
 
 /* Multi-GPU, one process per GPU: samples are sharded by sample index, every rank renders into its own films, and
  * the three linear accumulators are summed onto `root` with one RCCL reduce each over xGMI — film_storage_t's merge of per-worker

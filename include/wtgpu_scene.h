@@ -108,6 +108,7 @@ typedef struct wtgpu_material {
     /* multiplies `scale` */
     uint32_t scale_spec;
     uint32_t scale_tex;     /* ... or a texture (scale->f(tquery).x): texture index + 1, 0 = none */
+    uint32_t rough_tex;     /* fractal / gaussian profile: perceptual roughness from a texture (fractal.hpp:83-92: roughness_tex->f(query).x): index + 1 */
 } wtgpu_material;
 
 /* ---- textures (include/wt/texture/texture.hpp:29-90) ------------------------------------------------------------------------------ */
@@ -115,7 +116,10 @@ typedef struct wtgpu_material {
 /* texture/transform.hpp:35-44; identity when absent) applied before the lookup and `scale` by a constant (texture/scale.hpp:95-97; 1 */
 /* when absent) applied after it.  Bitmaps are float texels (linear, 1..4 channels: luminance, luminance+alpha, RGB, RGBA), rows from the */
 /* image's top; luminance textures are wavelength independent (bitmap.hpp:84-99), RGB ones are only read through get_RGBA (normal maps). */
-enum { WTGPU_TEX_CONSTANT = 0, WTGPU_TEX_CHECKERBOARD = 1, WTGPU_TEX_BITMAP = 2 };   /* texture_type */
+/* TEX_FUNCTION (texture/function.hpp, texture/mix.hpp): a real-valued expression of nested textures and of u, v, k, compiled by the host into */
+/* a postfix program of (opcode, argument) float pairs in texture_data[offset .. offset + width): see texture_function below. */
+enum { WTGPU_TEX_CONSTANT = 0, WTGPU_TEX_CHECKERBOARD = 1, WTGPU_TEX_BITMAP = 2, WTGPU_TEX_FUNCTION = 3 };   /* texture_type */
+enum { WTGPU_TOP_CONST = 0, WTGPU_TOP_U = 1, WTGPU_TOP_V = 2, WTGPU_TOP_K = 3, WTGPU_TOP_TEX = 4, WTGPU_TOP_ADD = 5, WTGPU_TOP_SUB = 6, WTGPU_TOP_MUL = 7, WTGPU_TOP_DIV = 8, WTGPU_TOP_NEG = 9, WTGPU_TOP_POW = 10, WTGPU_TOP_MIN = 11, WTGPU_TOP_MAX = 12, WTGPU_TOP_ABS = 13, WTGPU_TOP_SQRT = 14, WTGPU_TOP_SIN = 15, WTGPU_TOP_COS = 16, WTGPU_TOP_TAN = 17, WTGPU_TOP_EXP = 18, WTGPU_TOP_LOG = 19, WTGPU_TOP_FLOOR = 20, WTGPU_TOP_CEIL = 21, WTGPU_TOP_ROUND = 22, WTGPU_TOP_ASIN = 23, WTGPU_TOP_ACOS = 24, WTGPU_TOP_ATAN = 25, WTGPU_TOP_ATAN2 = 26, WTGPU_TOP_MIX = 27, WTGPU_TOP_LT = 28, WTGPU_TOP_LE = 29, WTGPU_TOP_GT = 30, WTGPU_TOP_GE = 31, WTGPU_TOP_EQ = 32, WTGPU_TOP_NE = 33, WTGPU_TOP_AND = 34, WTGPU_TOP_OR = 35, WTGPU_TOP_NOT = 36 };   /* texture_op */
 enum { WTGPU_WRAP_BLACK = 0, WTGPU_WRAP_WHITE = 1, WTGPU_WRAP_CLAMP = 2, WTGPU_WRAP_REPEAT = 3, WTGPU_WRAP_MIRROR = 4 };   /* texture_wrap */
 typedef struct wtgpu_texture {
     int32_t type;
@@ -124,6 +128,7 @@ typedef struct wtgpu_texture {
     float m[4], t[2];     /* transform: uv' = (m[0] u + m[1] v + t[0], m[2] u + m[3] v + t[1]) */
     float scale;
     uint32_t width, height, channels, offset;   /* TEX_BITMAP: texel (x, y) channel c = texture_data[offset + (y * width + x) * channels + c] */
+                                                /* TEX_FUNCTION: the program = texture_data[offset .. offset + width) */
     uint32_t bilinear;    /* 0: nearest, 1: bilinear */
     uint32_t uwrap, vwrap;
 } wtgpu_texture;

@@ -27,11 +27,17 @@ def main():
         v, w, l, _ = oracle_render(scene, b, e, s, threads=1)
         return torch.from_numpy(v), torch.from_numpy(w), torch.from_numpy(l)
 
-    res = render_distributed(sc, spp, seed=seed, reduce_dst=0, shard_renderer=cpu_shard)
+    partial = []
+    if os.environ.get("WT_DIST_PROGRESSIVE"):   # chunked render with a partial film on rank 0 after every chunk (the preview's multi-GPU path)
+        from wave_tracer_amd.render import render_distributed_progressive
+        res = render_distributed_progressive(sc, spp, seed=seed, reduce_dst=0, chunk_spp=int(os.environ["WT_DIST_PROGRESSIVE"]), shard_renderer=cpu_shard,
+                                             on_partial=lambda v, w, l, n: partial.append((n, float(v.sum() + l.sum()), float(w.sum()))))
+    else:
+        res = render_distributed(sc, spp, seed=seed, reduce_dst=0, shard_renderer=cpu_shard)
     shards = [None] * world
     dist.all_gather_object(shards, shard_samples(spp, rank, world))
     if rank == 0:
-        np.savez(out, value=res[0], weight=res[1], light=res[2], shards=np.array(shards))
+        np.savez(out, value=res[0], weight=res[1], light=res[2], shards=np.array(shards), partial=np.array(partial, dtype=np.float64).reshape(-1, 3))
     else:
         assert res is None
     dist.barrier()

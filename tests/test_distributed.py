@@ -50,6 +50,28 @@ def test_gloo_sharded_render_equals_single_process(built, tmp_path, world, spp, 
     assert np.allclose(d["value"], v, rtol=1e-12) and np.allclose(d["weight"], w, rtol=1e-12) and np.allclose(d["light"], l, rtol=1e-12)
 
 
+def test_gloo_progressive_render_reduces_partial_films(built, tmp_path):
+    """render_distributed_progressive (the preview's multi-GPU path, §8f N4): three ranks render 7 samples in chunks of 2; after every chunk
+    rank 0 holds the SUM of the ranks' partial films — a film of exactly the samples rendered so far (their number is reported, the weights
+    of a furnace film grow in proportion) — and the last one is the finished film."""
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", WT_DIST_PROGRESSIVE="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "_dist_worker.py"), out, "7", "17", "furnace"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    from wave_tracer_amd import Scene
+    sc = Scene("furnace", res=16, lut=(32, 32), mesh_detail=0)
+    v, w, l, _ = oracle_render(sc, 0, 7, 17, threads=1)
+    assert np.allclose(d["value"], v, rtol=1e-12) and np.allclose(d["weight"], w, rtol=1e-12) and np.allclose(d["light"], l, rtol=1e-12)
+    part = d["partial"]
+    # shards of 7 samples over 3 ranks: 2 + 2 + 3 -> chunks of 2: after chunk one 6 samples, after chunk two all 7
+    assert [int(n) for n in part[:, 0]] == [6, 7]
+    assert abs(part[0, 2] / part[1, 2] - 6 / 7) < 2e-2 and abs(part[1, 2] - w.sum()) < 1e-9 * w.sum()
+    assert abs(part[1, 1] - (v.sum() + l.sum())) < 1e-9 * (v.sum() + l.sum())
+
+
 def test_distributed_default_renderer_fails_loudly_without_gpu(built):
     """The product shard renderer is the HIP path; without an uploaded scene / GPU it must raise, not fall back."""
     import torch

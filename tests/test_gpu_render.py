@@ -264,6 +264,27 @@ def test_xml_scene_renders_like_the_checker(built):
     assert abs(c["fsd_interactions"] - oc["fsd_interactions"]) <= 0.02 * oc["fsd_interactions"]
 
 
+@pytest.mark.parametrize("variant,fn", [(2, None), (3, None), (4, "0.5 + 0.3*sin(2*pi*3*u) * cos(2*pi*2*v) * (k > 11424)"), (7, None)])
+def test_function_textures_render_like_the_checker(built, variant, fn):
+    """Function / mix textures and a textured roughness (tests/data/xml/function_textures.xml: the device interprets the compiled expression,
+    wt/scene.h texture_function) through the C-ABI: GPU == CPU checker on the same random numbers."""
+    import os
+    from wave_tracer_amd import Scene, render, develop
+    defines = {"variant": variant}
+    if fn:
+        defines["fn"] = fn
+    sc = Scene.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "xml", "function_textures.xml"), defines=defines, res=64)
+    spp = 8
+    v, w, l = render(sc, spp, seed=9)
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 9)
+    gi, oi = develop(sc, v, w, l, spp).astype(np.float64), develop(sc, ov, ow, ol, spp).astype(np.float64)
+    assert oi.sum() > 0 and np.allclose(w, ow, rtol=1e-5, atol=1e-7)
+    assert _rel_l1(gi, oi) < 1e-2, _rel_l1(gi, oi)
+    c = sc.counters()
+    for key in ("segments", "vertices", "connections"):
+        assert abs(c[key] - oc[key]) <= 5e-3 * oc[key], (key, c[key], oc[key])
+
+
 def test_double_slits_full_size_1440(built):
     """BASELINE.json configs[0] at its real size (scenes/diffraction_simple/double_slits.xml with res = 1440: virtual-plane film
     1440 x 360, 518,400 samples per pass).  The scene is small enough for the CPU checker to render the whole film, so this is a
@@ -504,6 +525,123 @@ def test_bench_launches_its_own_ranks(built):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["samples_per_step"] == 64 * 64 and abs(d["value"] - 2 * 2 * 64 * 64 / (d["ms_per_step"] * 2e-3) / 1e6) < 1e-6 * d["value"]
     assert "roofline" in d and "whole_path" in d["roofline"]
+
+
+def test_pause_resume_and_capture_intermediate(built):
+    """The renderer's remaining interrupts (include/wt/scene/interrupts.hpp; src/scene/render.cpp:306-368) at the C-ABI: a pause requested from
+    the progress callback holds the render at the chunk boundary while another thread asks for an intermediate capture (served WHILE paused, with
+    the films holding exactly the completed chunks: they equal a direct render of those samples), then resumes it; the finished film equals an
+    uninterrupted render."""
+    import threading
+    import time
+    import torch
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.render import alloc_films
+    sc = Scene("furnace", res=48)
+    sc.upload(0)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ref = alloc_films(sc, dev)
+    sc.render_into(*ref, 0, 12, 21, st)
+    part = alloc_films(sc, dev)
+    sc.render_into(*part, 0, 4, 21, st)
+    torch.cuda.synchronize(dev)
+    films = alloc_films(sc, dev)
+    seen = {}
+
+    def capture(done):
+        torch.cuda.synchronize(dev)
+        seen["done"] = done
+        seen["value"] = films[0].clone()
+        seen["t"] = time.monotonic()
+
+    def helper():                       # another thread: waits until the render is paused, captures, then resumes it
+        while "paused_at" not in seen:
+            time.sleep(0.002)
+        sc.capture_intermediate(capture)
+        while "done" not in seen:
+            time.sleep(0.002)
+        time.sleep(0.05)
+        seen["resumed_at"] = time.monotonic()
+        sc.resume()
+
+    def progress(done, total):
+        if done == 4 * 48 * 48 and "paused_at" not in seen:
+            sc.pause()
+            seen["paused_at"] = time.monotonic()
+        seen.setdefault("calls", []).append((done, time.monotonic()))
+        return False
+    th = threading.Thread(target=helper)
+    th.start()
+    cancelled, spe = sc.render_progressive(*films, 0, 12, 21, chunk_spp=4, progress=progress, stream=st)
+    th.join(10)
+    torch.cuda.synchronize(dev)
+    assert not cancelled and spe == 12
+    assert seen["done"] == 4 and torch.allclose(seen["value"], part[0], rtol=1e-12, atol=0)   # captured while paused: exactly the first chunk
+    later = [t for d, t in seen["calls"] if d > 4 * 48 * 48]
+    assert len(later) == 2 and min(later) >= seen["resumed_at"]                             # nothing was launched before the resume
+    for a, b in zip(films, ref):
+        assert torch.allclose(a, b, rtol=1e-12, atol=0)
+    # a capture requested while no render runs is served at the next render's first boundary; a pause with a cancel ends the render
+    sc.capture_intermediate(lambda d: seen.__setitem__("late", d))
+    sc.pause()
+    threading.Timer(0.05, sc.cancel).start()
+    cancelled, spe = sc.render_progressive(*alloc_films(sc, dev), 0, 8, 3, chunk_spp=2, stream=st)
+    sc.resume()
+    assert cancelled and spe == 2 and seen["late"] == 2
+
+
+def test_render_with_preview_on_the_gpu(built):
+    """§8f N4 on hardware: render_with_preview drives wtgpu_render_progressive and pushes the developed partial film to a tev viewer (here the
+    local stand-in of tests/test_preview.py): one CreateImage, updates while the render runs, the last update = the finished, developed film."""
+    from test_preview import _FakeTev, _parse
+    from wave_tracer_amd import Scene, develop
+    from wave_tracer_amd.preview import TevPreview, render_with_preview
+    srv = _FakeTev()
+    pv = TevPreview("127.0.0.1", srv.port, min_interval_s=0.0)
+    sc = Scene("furnace", res=40)
+    v, w, l = render_with_preview(sc, 12, pv, seed=5, chunk_spp=4, preview_id="camera")
+    pv.close()
+    srv.join(5.0)
+    pk = _parse(srv.data)
+    assert [k[0] for k in pk] == ["create", "update", "update", "update"] and all(k[1] == "wave_tracer 'camera'" for k in pk)
+    assert pk[0][3:5] == (sc.width, sc.height)
+    final = develop(sc, v, w, l, 12).reshape(sc.height, sc.width, -1)
+    shown = pk[-1][7].reshape(3, sc.height, sc.width)
+    rgb = np.repeat(final, 3, axis=-1)[..., :3] if final.shape[-1] == 1 else final[..., :3]
+    assert np.allclose(shown, np.moveaxis(rgb, -1, 0), rtol=1e-6, atol=0)
+    ov, ow, ol, _ = oracle_render(sc, 0, 12, 5)
+    assert _rel_l1(final, develop(sc, ov, ow, ol, 12).reshape(final.shape)) < 1e-2
+
+
+def test_two_gpus_strong_scaling_through_rccl(built):
+    """The multi-GPU path on real hardware, wherever the box has two GPUs (skipped on the one-GPU boxes of this round): `bench.py --gpus 2
+    --backend nccl --scaling strong` — two ranks, one GPU each, every rank renders half of the samples of every step, the films are reduced
+    by wtgpu_film_reduce (one ncclGroup of three ncclReduce over RCCL).  With --warmup 0 the two ranks render exactly the samples a single rank
+    renders with the same --spp-per-step: the reduced film must equal the single-rank film (f64 atomics: to rounding)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "3", "--warmup", "0", "--scene", "cornell_box", "--res", "256", "--spp-per-step", "2", "--no-cpu-baseline", "--no-traffic", "--film-sums"]
+
+    def run(extra):
+        out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py")] + extra + common, env=env, stderr=subprocess.DEVNULL).decode()
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out
+        return json.loads(lines[0])
+    two = run(["--gpus", "2", "--backend", "nccl", "--scaling", "strong"])
+    one = run(["--gpus", "1"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["film_reduce"]["ranks"] == 2 and "RCCL" in two["film_reduce"]["through"]
+    assert two["config"]["samples_per_step"] == one["config"]["samples_per_step"] == 2 * 256 * 256
+    for k in ("value", "weight", "light"):
+        a, b = two["film_sums"][k], one["film_sums"][k]
+        assert abs(a - b) <= 1e-9 * abs(b) + 1e-30, (k, a, b)
 
 
 def test_converged_bias_dense_crop(built):

@@ -1,12 +1,12 @@
 #!/bin/bash
-# GPU box: A/B of device-code variants on the default bench workload.  usage: ab_run.sh <outdir> "<label>|<lib or ->|<ENV=V ...>" ...
+# GPU box: A/B of device-code variants on the default bench workload.  usage: ab_run.sh <outdir> "<label>|<lib or ->|<ENV=V ...>|<extra bench.py arguments>" ...
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/$1; shift; mkdir -p $OUT
 cd $R
 for spec in "$@"; do
-  IFS='|' read -r LABEL LIB ENVS <<< "$spec"
+  IFS='|' read -r LABEL LIB ENVS ARGS <<< "$spec"
   ( [ "$LIB" != "-" ] && export WTGPU_LIB=$R/wave_tracer_amd/_v/libwtgpu_$LIB.so
     for kv in $ENVS; do export $kv; done
-    timeout 150 python bench.py --steps ${AB_STEPS:-6} --warmup 2 --no-cpu-baseline > $OUT/$LABEL.json 2> $OUT/$LABEL.err )
+    timeout 150 python bench.py --steps ${AB_STEPS:-6} --warmup 2 --no-cpu-baseline --no-traffic $ARGS > $OUT/$LABEL.json 2> $OUT/$LABEL.err )
   python - <<PY
 import json
 try:

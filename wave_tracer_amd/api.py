@@ -57,8 +57,9 @@ SYMBOLS = ["wtgpu_scene_create_named", "wtgpu_scene_create_from_desc", "wtgpu_sc
            "wtgpu_scene_upload", "wtgpu_render", "wtgpu_trace_rays", "wtgpu_traverse_cones", "wtgpu_get_counters",
            "wtgpu_reset_counters", "wtgpu_last_render_timings", "wtgpu_develop", "wtgpu_scene_destroy", "wtgpu_last_error",
            "wtgpu_scene_stats_json", "wtgpu_calibrate_copy", "wtgpu_render_async", "wtgpu_join", "wtgpu_query_regions", "wtgpu_render_progressive",
-           "wtgpu_cancel", "wtgpu_comm_unique_id", "wtgpu_comm_create", "wtgpu_film_reduce", "wtgpu_comm_destroy", "wtgpu_scene_create_from_xml"]
+           "wtgpu_cancel", "wtgpu_pause", "wtgpu_resume", "wtgpu_capture_intermediate", "wtgpu_comm_unique_id", "wtgpu_comm_create", "wtgpu_film_reduce", "wtgpu_comm_destroy", "wtgpu_scene_create_from_xml"]
 PROGRESS_CB = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p)
+CAPTURE_CB = C.CFUNCTYPE(None, C.c_uint64, C.c_void_p)
 
 _lib = None
 
@@ -93,6 +94,9 @@ def load_library():
     lib.wtgpu_scene_compare_part.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.c_size_t]
     lib.wtgpu_render_progressive.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64, u32, PROGRESS_CB, vp, C.POINTER(u64)]
     lib.wtgpu_cancel.argtypes = [vp]
+    lib.wtgpu_pause.argtypes = [vp]
+    lib.wtgpu_resume.argtypes = [vp]
+    lib.wtgpu_capture_intermediate.argtypes = [vp, CAPTURE_CB, vp]
     lib.wtgpu_comm_unique_id.argtypes = [vp]
     lib.wtgpu_comm_create.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
     lib.wtgpu_film_reduce.argtypes = [vp, vp, vp, vp, vp, u64, u64, i32]
@@ -251,6 +255,20 @@ class Scene:
 
     def cancel(self):
         _check(load_library().wtgpu_cancel(self._h))
+
+    def pause(self):
+        """The running render_progressive stops launching at its next chunk boundary until resume() (scene_renderer_t's pause interrupt)."""
+        _check(load_library().wtgpu_pause(self._h))
+
+    def resume(self):
+        _check(load_library().wtgpu_resume(self._h))
+
+    def capture_intermediate(self, fn):
+        """`capture intermediate`: fn(samples_per_element_done) is called once by the render thread at its next chunk boundary, with the films
+        consistent (exactly the completed chunks).  Thread-safe."""
+        cb = CAPTURE_CB(lambda done, user: fn(int(done)))
+        self._capture_keepalive = cb          # the C side keeps the pointer until it has been called
+        _check(load_library().wtgpu_capture_intermediate(self._h, cb, None))
 
     def join(self, stream=None):
         _check(load_library().wtgpu_join(self._h, C.c_void_p(stream) if stream else None))

@@ -690,6 +690,48 @@ int scene_builder_t::add_texture_bitmap(uint32_t width, uint32_t height, uint32_
     textures_.push_back(t);
     return (int)textures_.size() - 1;
 }
+int scene_builder_t::add_texture_function(const std::vector<float>& program) {
+    if (program.empty() || program.size() % 2) throw std::runtime_error("function texture: empty or malformed program");
+    std::vector<float> flat;
+    int depth = 0, max_depth = 0;
+    for (size_t i = 0; i < program.size(); i += 2) {
+        const int op = (int)program[i];
+        if (op == TOP_TEX) {
+            const int id = (int)program[i + 1];
+            if (id < 0 || id >= (int)textures_.size()) throw std::runtime_error("function texture: unknown nested texture");
+            const texture_t& n = textures_[id];
+            if (n.type == TEX_FUNCTION) {   // inline the nested program (the device evaluates no function inside a function)
+                if (n.m[0] != 1.f || n.m[1] != 0.f || n.m[2] != 0.f || n.m[3] != 1.f || n.t[0] != 0.f || n.t[1] != 0.f)
+                    throw std::runtime_error("function texture: a transformed function texture cannot be nested (transform its operands)");
+                flat.insert(flat.end(), texture_data_.begin() + n.offset, texture_data_.begin() + n.offset + n.width);
+                if (n.scale != 1.f) {
+                    flat.push_back((float)TOP_CONST);
+                    flat.push_back(n.scale);
+                    flat.push_back((float)TOP_MUL);
+                    flat.push_back(0.f);
+                }
+                continue;
+            }
+        }
+        flat.push_back(program[i]);
+        flat.push_back(program[i + 1]);
+    }
+    for (size_t i = 0; i < flat.size(); i += 2) {   // stack discipline (the device's evaluation stack holds 12 values)
+        const int op = (int)flat[i];
+        const bool unary = op == TOP_NEG || (op >= TOP_ABS && op <= TOP_ATAN) || op == TOP_NOT;
+        depth += op <= TOP_TEX ? 1 : (unary ? 0 : (op == TOP_MIX ? -2 : -1));
+        if (op > TOP_NOT || op < 0 || depth < 1) throw std::runtime_error("function texture: malformed program");
+        max_depth = std::max(max_depth, depth);
+    }
+    if (depth != 1) throw std::runtime_error("function texture: the program does not leave exactly one value");
+    if (max_depth > 12) throw std::runtime_error("function texture: expression too deep (more than 12 intermediate values)");
+    texture_t t = texture_base(TEX_FUNCTION);
+    t.offset = (uint32_t)texture_data_.size();
+    t.width = (uint32_t)flat.size();
+    texture_data_.insert(texture_data_.end(), flat.begin(), flat.end());
+    textures_.push_back(t);
+    return (int)textures_.size() - 1;
+}
 void scene_builder_t::texture_set_transform(int tex, const float M[4], const float tr[2]) {
     texture_t& t = textures_.at(tex);
     for (int i = 0; i < 4; ++i) t.m[i] = M[i];

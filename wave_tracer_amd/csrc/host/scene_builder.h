@@ -90,6 +90,10 @@ public:
     int add_texture_checkerboard(int tex1, int tex2);
     // float texels, rows from the image's top, 1..4 channels; wrap: wt::WRAP_*
     int add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, bool bilinear, uint32_t uwrap, uint32_t vwrap);
+    // function / mix textures (texture/function.hpp, texture/mix.hpp): a postfix program of (wt::TOP_*, argument) pairs; TOP_TEX arguments are
+    // texture ids — a nested FUNCTION texture is inlined (its own transform / scale must be the identity: wrap its operands instead)
+    int add_texture_function(const std::vector<float>& program);
+    bool texture_is_function(int tex) const { return textures_.at(tex).type == wt::TEX_FUNCTION; }
     void texture_set_transform(int tex, const float M[4], const float t[2]);   // uv' = M uv + t (texture/transform.hpp)
     void texture_set_scale(int tex, float scale);                               // texture/scale.hpp with a constant scale
     float texture_scale(int tex) const { return textures_.at(tex).scale; }

@@ -356,6 +356,174 @@ double eval_number(const std::string& s) {
     return v;
 }
 
+// The same grammar, COMPILED instead of evaluated: the postfix program of a function texture (wt/scene.h: texture_function) over named variables
+// (src/texture/function.cpp:38-107: the nested textures by name, then u, v, k).  `vars`: name -> (opcode, argument).
+struct expr_compiler_t {
+    const std::string& s;
+    const std::vector<std::pair<std::string, std::pair<int, float>>>& vars;
+    std::vector<float>& out;
+    size_t i = 0;
+    int depth = 0;
+    expr_compiler_t(const std::string& t, const std::vector<std::pair<std::string, std::pair<int, float>>>& v, std::vector<float>& o) : s(t), vars(v), out(o) {}
+    [[noreturn]] void fail(const std::string& w) const { throw std::runtime_error("function \"" + s + "\": " + w); }
+    void emit(int op, float arg = 0.f) {
+        out.push_back((float)op);
+        out.push_back(arg);
+    }
+    void ws() {
+        while (i < s.size() && std::isspace((unsigned char)s[i])) ++i;
+    }
+    bool eat(const char* t) {
+        ws();
+        const size_t n = std::strlen(t);
+        if (s.compare(i, n, t) == 0) {
+            i += n;
+            return true;
+        }
+        return false;
+    }
+    void primary() {
+        ws();
+        if (i >= s.size()) fail("operand expected");
+        if (s[i] == '(') {
+            ++i;
+            if (++depth > 64) fail("parentheses nested too deeply");
+            lor();
+            --depth;
+            if (!eat(")")) fail("')' expected");
+            return;
+        }
+        if (std::isalpha((unsigned char)s[i]) || s[i] == '_') {
+            const size_t b = i;
+            while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_')) ++i;
+            const std::string w = s.substr(b, i - b);
+            static const std::pair<const char*, int> f1[] = {{"sin", TOP_SIN}, {"cos", TOP_COS}, {"tan", TOP_TAN}, {"asin", TOP_ASIN}, {"acos", TOP_ACOS}, {"atan", TOP_ATAN},
+                                                             {"sqrt", TOP_SQRT}, {"abs", TOP_ABS}, {"exp", TOP_EXP}, {"log", TOP_LOG}, {"round", TOP_ROUND}, {"floor", TOP_FLOOR},
+                                                             {"ceil", TOP_CEIL}};
+            static const std::pair<const char*, int> f2[] = {{"min", TOP_MIN}, {"max", TOP_MAX}, {"pow", TOP_POW}, {"atan2", TOP_ATAN2}};
+            ws();
+            const bool call = i < s.size() && s[i] == '(';
+            if (call) {
+                for (auto& f : f1)
+                    if (w == f.first) {
+                        eat("(");
+                        lor();
+                        if (!eat(")")) fail("')' expected");
+                        emit(f.second);
+                        return;
+                    }
+                for (auto& f : f2)
+                    if (w == f.first) {
+                        eat("(");
+                        lor();
+                        if (!eat(",")) fail("',' expected in " + w + "(a, b)");
+                        lor();
+                        if (!eat(")")) fail("')' expected");
+                        emit(f.second);
+                        return;
+                    }
+                if (w == "mix") {   // mix(a, b, t)
+                    eat("(");
+                    lor();
+                    if (!eat(",")) fail("',' expected in mix(a, b, t)");
+                    lor();
+                    if (!eat(",")) fail("',' expected in mix(a, b, t)");
+                    lor();
+                    if (!eat(")")) fail("')' expected");
+                    emit(TOP_MIX);
+                    return;
+                }
+                fail("unknown function " + w);
+            }
+            for (auto& v : vars)
+                if (v.first == w) {
+                    emit(v.second.first, v.second.second);
+                    return;
+                }
+            if (w == "pi") return emit(TOP_CONST, (float)M_PI);
+            if (w == "true") return emit(TOP_CONST, 1.f);
+            if (w == "false") return emit(TOP_CONST, 0.f);
+            fail("unknown variable " + w);
+        }
+        const char* b = s.c_str() + i;
+        char* e = nullptr;
+        const double v = std::strtod(b, &e);
+        if (e == b) fail("number expected");
+        i += (size_t)(e - b);
+        emit(TOP_CONST, (float)v);
+    }
+    void unary() {
+        ws();
+        if (eat("-")) {
+            unary();
+            return emit(TOP_NEG);
+        }
+        if (eat("+")) return unary();
+        if (i < s.size() && s[i] == '!' && !(i + 1 < s.size() && s[i + 1] == '=')) {
+            ++i;
+            unary();
+            return emit(TOP_NOT);
+        }
+        primary();
+    }
+    void mul() {
+        unary();
+        for (;;) {
+            if (eat("*")) {
+                unary();
+                emit(TOP_MUL);
+            } else if (eat("/")) {
+                unary();
+                emit(TOP_DIV);
+            } else
+                return;
+        }
+    }
+    void add() {
+        mul();
+        for (;;) {
+            ws();
+            if (eat("+")) {
+                mul();
+                emit(TOP_ADD);
+            } else if (i < s.size() && s[i] == '-') {
+                ++i;
+                mul();
+                emit(TOP_SUB);
+            } else
+                return;
+        }
+    }
+    void cmp() {
+        add();
+        static const std::pair<const char*, int> ops[] = {{"==", TOP_EQ}, {"!=", TOP_NE}, {"<=", TOP_LE}, {">=", TOP_GE}, {"<", TOP_LT}, {">", TOP_GT}};
+        for (auto& o : ops)
+            if (eat(o.first)) {
+                add();
+                return emit(o.second);
+            }
+    }
+    void land() {
+        cmp();
+        while (eat("&&")) {
+            cmp();
+            emit(TOP_AND);
+        }
+    }
+    void lor() {
+        land();
+        while (eat("||")) {
+            land();
+            emit(TOP_OR);
+        }
+    }
+    void compile() {
+        lor();
+        ws();
+        if (i != s.size()) fail("trailing characters");
+    }
+};
+
 enum dim_e { DIM_NONE, DIM_LENGTH, DIM_ANGLE, DIM_TEMPERATURE };
 struct quantity_t {
     double raw;      // the number as written
@@ -537,9 +705,16 @@ struct loader_t {
     }
     // src/math/transform_loader.cpp:60-143: a <lookat> (exclusive), or matrix / rotate / translate / scale applied in file order (each
     // multiplies from the left)
-    static xform_t to_world(const xnode_t& n, dvec3 default_up) {
+    xform_t to_world(const xnode_t& n, dvec3 default_up) const {
         const xnode_t* t = n.named("to_world");
         if (!t) return xform_t::identity();
+        if (t->name == "ref") {   // <ref name="to_world" id=…/>: a shared top-level <transform id=…> (loader.cpp:168-181; scenes/objects/objects.xml)
+            const std::string id = t->get("id");
+            t = nullptr;
+            for (auto& it : items)
+                if (it.name == "transform" && it.get("id") == id) t = &it;
+            if (!t) throw std::runtime_error("<ref name=\"to_world\" id=\"" + id + "\">: no shared transform of that id");
+        }
         if (const xnode_t* la = t->child("lookat")) {
             const dvec3 o = parse_point(la->get("origin"), DIM_LENGTH, "lookat origin"), tg = parse_point(la->get("target"), DIM_LENGTH, "lookat target");
             const dvec3 up = la->attr("up") ? parse_point(la->get("up"), DIM_NONE, "lookat up") : default_up;
@@ -719,6 +894,7 @@ struct loader_t {
     int texture(const xnode_t& n) {
         std::string type = n.get("type");
         if (type.empty() && n.attr("bitmap")) type = "bitmap";
+        if (type.empty() && n.attr("function")) type = "function";   // <texture name=… function="…"> (src/texture/texture_loader.cpp:46-53 shorthands)
         if (type == "constant") {
             const xnode_t* sp = n.child("spectrum");
             if (!sp) throw std::runtime_error("(constant texture loader) A nested real spectrum must be provided");
@@ -801,6 +977,37 @@ struct loader_t {
             else
                 throw std::runtime_error("(bitmap loader) " + file + ": PNG (8 / 16 bit) and PFM files only");
             return b.add_texture_bitmap(W, H, C, px.data(), bilinear, uw, vw);
+        }
+        if (type == "function") {   // src/texture/function.cpp:38-124: nested NAMED textures are the variables, then u, v, k; the expression inline
+            // (function="...") or as a <function value="..."/> child
+            std::vector<std::pair<std::string, std::pair<int, float>>> vars;
+            for (const xnode_t& c : n.kids)
+                if (c.name == "texture" || (c.name == "ref" && deref(&c)->name == "texture")) {
+                    const std::string name = c.get("name");
+                    if (name.empty()) throw std::runtime_error("(function texture loader) Nested texture must be given a name");
+                    vars.push_back({name, {TOP_TEX, (float)texture(*deref(&c))}});
+                }
+            vars.push_back({"u", {TOP_U, 0.f}});
+            vars.push_back({"v", {TOP_V, 0.f}});
+            vars.push_back({"k", {TOP_K, 0.f}});
+            std::string fn = n.get("function");
+            if (const xnode_t* f = n.child("function")) fn = f->get("value");
+            if (fn.empty()) throw std::runtime_error("(function texture loader) No function 'function' provided");
+            std::vector<float> prog;
+            expr_compiler_t(fn, vars, prog).compile();
+            return b.add_texture_function(prog);
+        }
+        if (type == "mix") {   // src/texture/mix.cpp:34-62: texture1, texture2, mix (each a texture; constants as spectra are accepted too)
+            const xnode_t *t1 = deref(n.named("texture1")), *t2 = deref(n.named("texture2")), *m = deref(n.named("mix"));
+            if (!t1 || !t2 || !m) throw std::runtime_error("(mix texture loader) Nested textures 'texture1', 'texture2' and 'mix' must be provided");
+            std::vector<float> prog;
+            for (const xnode_t* t : {t1, t2, m}) {
+                prog.push_back((float)TOP_TEX);
+                prog.push_back((float)texture_or_constant(*t));
+            }
+            prog.push_back((float)TOP_MIX);
+            prog.push_back(0.f);
+            return b.add_texture_function(prog);
         }
         throw std::runtime_error("(texture loader) texture type \"" + type + "\" is not supported");
     }
@@ -924,6 +1131,7 @@ struct loader_t {
             // constant roughness (T / sigma_h resp. sigma textures are not supported)
             bool fractal = false, gaussian = false;
             float roughness = 0.f, gamma = 3.f, gauss_sigma = 0.f;
+            uint32_t rough_tex = 0;   // a textured roughness (fractal.cpp:94-123: `roughness` is a texture; a constant spectrum is the constant texture)
             if (const xnode_t* sp = n.child("surface_profile")) {
                 const std::string pt = sp->get("type");
                 if (pt == "fractal" || pt == "gaussian") {
@@ -944,14 +1152,22 @@ struct loader_t {
                         }
                         if (!ok || !(gauss_sigma > 0.f)) throw std::runtime_error("gaussian profile: sigma \"" + v + "\": a positive value in 1/mm, 1/um, 1/m, 1/cm or 1/nm expected");
                     } else {
-                        if (!ro || !ro->attr("constant")) throw std::runtime_error(pt + " profile: a constant `roughness` spectrum is expected");
-                        roughness = (float)eval_number(ro->get("constant"));
+                        ro = deref(ro);
+                        if (!ro) throw std::runtime_error(pt + " profile: `roughness` expected");
+                        if (ro->name == "texture") {
+                            rough_tex = 1 + (uint32_t)texture(*ro);
+                            roughness = 1.f;   // (placeholder: evaluated per interaction, wt/bsdf.h: material_resolve)
+                        } else {
+                            if (!ro->attr("constant")) throw std::runtime_error(pt + " profile: a constant `roughness` spectrum or a texture is expected");
+                            roughness = (float)eval_number(ro->get("constant"));
+                        }
                     }
                     if (const xnode_t* g = sp->named("gamma")) gamma = (float)eval_number(g->get("value"));
                 } else if (pt != "dirac")
                     throw std::runtime_error("surface_profile type \"" + pt + "\" is not supported (dirac | fractal | gaussian)");
             }
             out = mat_spm(s, fractal, roughness, gamma, two_sided, 1.f);
+            out.rough_tex = rough_tex;
             if (gaussian) {
                 out.profile = PROFILE_GAUSSIAN;
                 out.gauss_sigma = gauss_sigma;
@@ -1180,12 +1396,18 @@ struct loader_t {
                     material_t m{};
                     if (!material(*inl, false, m)) throw std::runtime_error("shape: its bsdf has no bin for the sensor's sensitivity");
                     mat = b.add_material(m);
-                } else if (const xnode_t* ref = n.child("ref")) {
+                } else {
+                    const xnode_t* ref = nullptr;   // <ref id=…/> or <ref name="bsdf" id=…/> (not the <ref name="to_world" …/> of a shared transform)
+                    for (auto& k : n.kids)
+                        if (k.name == "ref" && (k.get("name").empty() || k.get("name") == "bsdf")) {
+                            ref = &k;
+                            break;
+                        }
+                    if (!ref) throw std::runtime_error("(shape loader) no bsdf found");
                     const auto it = materials.find(ref->get("id"));
                     if (it == materials.end()) throw std::runtime_error("shape refers to unknown or spectrally empty material \"" + ref->get("id") + "\"");
                     mat = it->second;
-                } else
-                    throw std::runtime_error("(shape loader) no bsdf found");
+                }
                 // defaults: src/scene/shape.cpp:196-380
                 const std::string type = n.get("type");
                 xform_t M = to_world(n, {0, 1, 0});

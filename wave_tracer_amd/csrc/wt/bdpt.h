@@ -1091,33 +1091,72 @@ WT_HD float bdpt_mis_weight(const scene_t& sc, const fsd_pool_t& pool, const ver
     } else
         delta_sensor = true;
 
+    // The running products read three words per vertex, newest vertex first.  They are FETCHED FOUR VERTICES AT A TIME before the arithmetic of
+    // the first of them: one load per loop iteration is one dependent memory round trip per vertex on the device (wave-uniform trip counts: the
+    // 64 items of a wavefront share (s, t)), and this kernel is bound by such round trips.  Same operands, same order of operations.
     float sum_Ri = 0.f, ri = 1.f;
     {
         // sensor subpath, i = t-1 .. 0: fwd = pdf_bwd, rev = pdf_fwd; the connection vertex counts as non-delta
         bool del_i = false;   // sdel[t-1] = 0
-        for (int i = t - 1; i >= 0; --i) {
-            const float f = (i == 0 && has_spdf_first) ? spdf_first : svs.load_word<float>(i, WT_VWORD(pdf_bwd));
-            const float rv = (i == t - 1 && has_srev_last) ? srev_last : ((i == t - 2 && has_srev_prev) ? srev_prev : svs.load_word<float>(i, WT_VWORD(pdf_fwd)));
-            const bool del_prev = i > 0 ? svs.load_word<uint32_t>(i - 1, WT_VWORD(delta)) != 0 : delta_sensor;
-            const float fwd = (finitef(f) && f > FLT_EPSILON) ? f : 1.f;
-            const float rev = (finitef(rv) && rv > FLT_EPSILON) ? rv : 1.f;
-            ri *= rev / fwd;
-            if (!del_i && !del_prev) sum_Ri += ri;
-            del_i = del_prev;
+        for (int i0 = t - 1; i0 >= 0; i0 -= 4) {
+            float F[4], R[4];
+            uint32_t D[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 - j;
+                F[j] = R[j] = 0.f;
+                D[j] = 0u;
+                if (i >= 0) {
+                    F[j] = svs.load_word<float>(i, WT_VWORD(pdf_bwd));
+                    R[j] = svs.load_word<float>(i, WT_VWORD(pdf_fwd));
+                    if (i > 0) D[j] = svs.load_word<uint32_t>(i - 1, WT_VWORD(delta));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 - j;
+                if (i < 0) break;
+                const float f = (i == 0 && has_spdf_first) ? spdf_first : F[j];
+                const float rv = (i == t - 1 && has_srev_last) ? srev_last : ((i == t - 2 && has_srev_prev) ? srev_prev : R[j]);
+                const bool del_prev = i > 0 ? D[j] != 0 : delta_sensor;
+                const float fwd = (finitef(f) && f > FLT_EPSILON) ? f : 1.f;
+                const float rev = (finitef(rv) && rv > FLT_EPSILON) ? rv : 1.f;
+                ri *= rev / fwd;
+                if (!del_i && !del_prev) sum_Ri += ri;
+                del_i = del_prev;
+            }
         }
     }
     ri = 1.f;
     {
         bool del_i = false;   // edel[s-1] = 0
-        for (int i = s - 1; i >= 0; --i) {
-            const float f = (i == 0 && has_epdf_first) ? epdf_first : evs.load_word<float>(i, WT_VWORD(pdf_fwd));
-            const float rv = (i == s - 1 && has_erev_last) ? erev_last : ((i == s - 2 && has_erev_prev) ? erev_prev : evs.load_word<float>(i, WT_VWORD(pdf_bwd)));
-            const bool del_prev = i > 0 ? evs.load_word<uint32_t>(i - 1, WT_VWORD(delta)) != 0 : delta_emitter;
-            const float fwd = (finitef(f) && f > FLT_EPSILON) ? f : 1.f;
-            const float rev = (finitef(rv) && rv > FLT_EPSILON) ? rv : 1.f;
-            ri *= rev / fwd;
-            if (!del_i && !del_prev) sum_Ri += ri;
-            del_i = del_prev;
+        for (int i0 = s - 1; i0 >= 0; i0 -= 4) {
+            float F[4], R[4];
+            uint32_t D[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 - j;
+                F[j] = R[j] = 0.f;
+                D[j] = 0u;
+                if (i >= 0) {
+                    F[j] = evs.load_word<float>(i, WT_VWORD(pdf_fwd));
+                    R[j] = evs.load_word<float>(i, WT_VWORD(pdf_bwd));
+                    if (i > 0) D[j] = evs.load_word<uint32_t>(i - 1, WT_VWORD(delta));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 - j;
+                if (i < 0) break;
+                const float f = (i == 0 && has_epdf_first) ? epdf_first : F[j];
+                const float rv = (i == s - 1 && has_erev_last) ? erev_last : ((i == s - 2 && has_erev_prev) ? erev_prev : R[j]);
+                const bool del_prev = i > 0 ? D[j] != 0 : delta_emitter;
+                const float fwd = (finitef(f) && f > FLT_EPSILON) ? f : 1.f;
+                const float rev = (finitef(rv) && rv > FLT_EPSILON) ? rv : 1.f;
+                ri *= rev / fwd;
+                if (!del_i && !del_prev) sum_Ri += ri;
+                del_i = del_prev;
+            }
         }
     }
     return 1.f / (1.f + sum_Ri);

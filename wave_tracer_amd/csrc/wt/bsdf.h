@@ -102,6 +102,9 @@ WT_HD float profile_alpha(const material_t& m, vec3 wi, vec3 wo, float k) {
 }
 WT_HD bool profile_is_delta_only(const material_t& m) {
     if (m.profile == PROFILE_GAUSSIAN && m.gauss_sigma > 0.f) return false;
+    // (a textured roughness decides through its MEAN value, which a bitmap / function texture does not have: fractal.hpp:169-177 -> false;
+    // constant textures are folded into `roughness` by the host)
+    if (m.rough_tex) return m.profile == PROFILE_DIRAC;
     return m.profile == PROFILE_DIRAC || m.roughness == 0.f;
 }
 WT_HD float profile_psd(const material_t& m, vec3 wi, vec3 wo, float k) {
@@ -212,6 +215,7 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, materi
     wr.masked = wr.mask_two = false;
     if (m.type < MAT_COMPOSITE) {   // a leaf BSDF: the common case (only the fields the caller goes on to use are loaded)
         if (m.scale_spec | m.scale_tex) m.scale *= material_scale_factor(sc, m, k, uv);
+        if (m.rough_tex) m.roughness = texture_spectral(sc, (int)m.rough_tex - 1, uv, k);   // fractal.hpp:83-92: roughness_tex->f(query).x
         return true;
     }
     uint32_t two = 0;
@@ -240,6 +244,7 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, materi
     m.two_sided |= two;
     m.scale *= scale;
     if (m.scale_spec | m.scale_tex) m.scale *= material_scale_factor(sc, m, k, uv);
+    if (m.rough_tex) m.roughness = texture_spectral(sc, (int)m.rough_tex - 1, uv, k);
     return true;
 }
 

@@ -148,28 +148,45 @@ struct ray_hit_t {
     uint32_t front_face;
 };
 
+// The triangles of a leaf are FETCHED FOUR AT A TIME before the first of them is tested: a loop that loads triangle t inside iteration t is a
+// chain of dependent memory round trips (the loads cannot be hoisted over the early exits), and on the device — where every wavefront's steps
+// are bounded by such round trips, not by arithmetic — a 4-triangle leaf then costs four latencies instead of one.  The tests run in the
+// reference's order.
+#ifndef WT_LEAF_BATCH
+#define WT_LEAF_BATCH 1
+#endif
+constexpr uint32_t kLeafBatch = WT_LEAF_BATCH;
 template <bool shadow>
 WT_HD bool ray_gather_tris(const scene_t& sc, vec3 ro, vec3 rd, uint32_t t0, uint32_t count, const range_t& range, ray_hit_t& rec,
                            bvh_counters_t* ctr) {
     bool intersects = false;
-    for (uint32_t t = 0; t < count; ++t) {
-        const tri_geo_t tri = sc.tri_geo[t0 + t];
-        if (ctr) ctr->tri_tests++;
-        if (shadow) {
-            if (test_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range)) {
-                rec.dist = range.min;
-                return true;
+    for (uint32_t b = 0; b < count; b += kLeafBatch) {
+        tri_geo_t T[kLeafBatch];
+        const uint32_t m = count - b < kLeafBatch ? count - b : kLeafBatch;
+#pragma unroll
+        for (uint32_t i = 0; i < kLeafBatch; ++i)
+            if (i < m) T[i] = sc.tri_geo[t0 + b + i];
+#pragma unroll
+        for (uint32_t i = 0; i < kLeafBatch; ++i) {
+            if (i >= m) break;
+            const tri_geo_t& tri = T[i];
+            if (ctr) ctr->tri_tests++;
+            if (shadow) {
+                if (test_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range)) {
+                    rec.dist = range.min;
+                    return true;
+                }
+                continue;
             }
-            continue;
-        }
-        ray_tri_hit_t h;
-        if (intersect_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range, h) && h.dist < rec.dist) {
-            rec.dist = h.dist;
-            rec.bx = h.bx;
-            rec.by = h.by;
-            rec.tuid = t0 + t;
-            rec.front_face = dot(tri.n, rd) <= 0.f;
-            intersects = true;
+            ray_tri_hit_t h;
+            if (intersect_ray_tri_wide(ro, rd, tri.a, tri.b, tri.c, range, h) && h.dist < rec.dist) {
+                rec.dist = h.dist;
+                rec.bx = h.bx;
+                rec.by = h.by;
+                rec.tuid = t0 + b + i;
+                rec.front_face = dot(tri.n, rd) <= 0.f;
+                intersects = true;
+            }
         }
     }
     return intersects;
@@ -363,10 +380,8 @@ struct cone_query_t {
     uint32_t tests;
     int s;                // stack entries
     int32_t leaf;         // child reference of the leaf to test next (0: none)
-    uint32_t leaf_t;      // ... and how many of its triangles have been looked at
-    uint32_t pend;        // triangle that passed the conservative filter and awaits its exact test (kInvalid: none)
 };
-WT_HD bool cq_running(const cone_query_t& q) { return q.s > 0 || q.leaf != 0 || q.pend != kInvalid; }
+WT_HD bool cq_running(const cone_query_t& q) { return q.s > 0 || q.leaf != 0; }
 WT_HD void cq_begin(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack, uint32_t budget, float min_progress,
                     cone_query_t& q) {
     q.sr = searchrange;
@@ -382,8 +397,6 @@ WT_HD void cq_begin(const scene_t& sc, const cone_t& cone, const range_t& search
     q.rec.short_tuid = kInvalid;
     q.tests = 0;
     q.leaf = 0;
-    q.leaf_t = 0;
-    q.pend = kInvalid;
     q.s = 0;
     q.range = cone_search_range(cone, searchrange, q.rec.dist, z_scale);
     if (sc.n_nodes == 0) return;
@@ -394,8 +407,6 @@ WT_HD void cq_begin(const scene_t& sc, const cone_t& cone, const range_t& search
 WT_HD void cq_stop(cone_query_t& q) {
     q.s = 0;
     q.leaf = 0;
-    q.leaf_t = 0;
-    q.pend = kInvalid;
 }
 // pops one entry: a leaf is kept for cq_leaf_step, a node's children are tested and pushed far-first (requires q.s > 0, q.leaf == 0)
 WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, cone_query_t& q, bvh_counters_t* ctr = nullptr) {
@@ -510,62 +521,48 @@ WT_HD void cq_apply_hit(const cone_t& cone, const stack_ref_t& stack, const uint
     q.s = s;
 }
 // One exact cone-triangle test of the running query.
-WT_HD void cq_exact_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q, uint32_t tuid,
-                         bvh_counters_t* ctr = nullptr) {
-    const tri_geo_t tri = sc.tri_geo[tuid];
-    (void)ctr;
+WT_HD void cq_exact_step_tri(const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q, uint32_t tuid, const tri_geo_t& tri,
+                             bvh_counters_t* ctr = nullptr) {
+    if (ctr) ctr->cone_tri_tests++;
     cone_tri_hit_t h;
     if (!intersect_cone_tri(cone, tri.a, tri.b, tri.c, tri.n, q.range, h)) return;
     if (h.dist > q.range.max) return;   // numerics (bvh8w.cpp:162)
     cq_apply_hit(cone, stack, tris, q, tuid, h.dist, dot(tri.n, -cone.d) > 0.f);
 }
-// A held leaf is worked off in two kinds of steps.  cq_leaf_filter_step looks at its triangles in order with the two CONSERVATIVE rejections
-// of intersect_cone_tri alone (cone_tri_maybe: z-slab, lateral distance — 97 % of the triangles a leaf hands over end there, at ~1/10 of the
-// exact test's cost) and stops at the first one that passes: q.pend.  cq_exact_pending then runs the exact test of that triangle and applies
-// its hit; the next filter step continues behind it.  Per query that is the reference's loop over the leaf (bvh8w.cpp:134-185), triangle by
-// triangle, in the same order with the same slab.  The split exists for the device: a wavefront whose lanes hold different queries runs the
-// filter step for all lanes that hold a leaf and parks the (few) lanes with a pending triangle until enough of them wait for ONE exact-test
-// step — instead of every leaf step paying the long exact path for the one or two lanes that need it (round 3: 1.4 lanes busy in there).
-// (requires q.leaf != 0 && q.pend == kInvalid)
-WT_HD void cq_leaf_filter_step(const scene_t& sc, const cone_t& cone, cone_query_t& q, bvh_counters_t* ctr = nullptr) {
+WT_HD void cq_exact_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q, uint32_t tuid,
+                         bvh_counters_t* ctr = nullptr) {
+    cq_exact_step_tri(cone, stack, tris, q, tuid, sc.tri_geo[tuid], ctr);
+}
+// Takes the held leaf (requires q.leaf != 0): charges its triangles to the budget and returns them as (first, count); count 0 when the
+// budget is exceeded (the query is stopped).
+WT_HD bvh8_leaf_t cq_take_leaf(cone_query_t& q, bvh_counters_t* ctr = nullptr) {
     const bvh8_leaf_t leaf = bvh_leaf_of(q.leaf);
-    uint32_t t = q.leaf_t;
-    if (t == 0) {   // the leaf is charged to the budget when it is taken up
-        if (ctr) ctr->cone_leaves++;
-        q.tests += leaf.count;
-        if (q.tests > q.budget) {
-            q.rec.aborted = 1;
-            cq_stop(q);
-            return;
-        }
+    q.leaf = 0;
+    if (ctr) ctr->cone_leaves++;
+    q.tests += leaf.count;
+    if (q.tests > q.budget) {
+        q.rec.aborted = 1;
+        cq_stop(q);
+        return bvh8_leaf_t{0u, 0u};
     }
-    for (; t < leaf.count; ++t) {
-        const tri_geo_t tri = sc.tri_geo[leaf.tris_ptr + t];
-        if (ctr) ctr->cone_tri_tests++;
-        if (cone_tri_maybe(cone, tri.a, tri.b, tri.c, q.range)) {
-            q.pend = leaf.tris_ptr + t;
-            ++t;
-            break;
-        }
-    }
-    if (t >= leaf.count) {
-        q.leaf = 0;
-        q.leaf_t = 0;
-    } else
-        q.leaf_t = t;
+    return leaf;
 }
-// (requires q.pend != kInvalid)
-WT_HD void cq_exact_pending(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q) {
-    const uint32_t tuid = q.pend;
-    q.pend = kInvalid;
-    cq_exact_step(sc, cone, stack, tris, q, tuid);   // (a query that ends here — too short — drops the rest of its leaf: cq_stop)
-}
-// tests the triangles of the held leaf one after the other (the sequential form; requires q.leaf != 0)
+// tests the triangles of the held leaf one after the other, fetched kLeafBatch at a time (see ray_gather_tris; requires q.leaf != 0)
 WT_HD void cq_leaf_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q,
                         bvh_counters_t* ctr = nullptr) {
-    while (q.leaf != 0) {
-        cq_leaf_filter_step(sc, cone, q, ctr);
-        if (q.pend != kInvalid) cq_exact_pending(sc, cone, stack, tris, q);
+    const bvh8_leaf_t leaf = cq_take_leaf(q, ctr);
+    for (uint32_t b = 0; b < leaf.count; b += kLeafBatch) {
+        tri_geo_t T[kLeafBatch];
+        const uint32_t m = leaf.count - b < kLeafBatch ? leaf.count - b : kLeafBatch;
+#pragma unroll
+        for (uint32_t i = 0; i < kLeafBatch; ++i)
+            if (i < m) T[i] = sc.tri_geo[leaf.tris_ptr + b + i];
+#pragma unroll
+        for (uint32_t i = 0; i < kLeafBatch; ++i) {
+            if (i >= m) break;
+            cq_exact_step_tri(cone, stack, tris, q, leaf.tris_ptr + b + i, T[i], ctr);
+            if (q.rec.too_short) return;
+        }
     }
 }
 // after the last step: the triangles beyond the final slab leave the list (cone_work_to_intersection_record)
@@ -628,10 +625,18 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
                 aborted = true;
                 return false;
             }
-            for (uint32_t t = 0; t < leaf.count; ++t) {
-                const tri_geo_t tri = sc.tri_geo[leaf.tris_ptr + t];
-                cone_tri_hit_t h;
-                if (intersect_cone_tri<true>(cone, tri.a, tri.b, tri.c, tri.n, range, h) && !(h.dist > range.max)) return true;
+            for (uint32_t b = 0; b < leaf.count; b += kLeafBatch) {   // (fetched kLeafBatch at a time: ray_gather_tris)
+                tri_geo_t T[kLeafBatch];
+                const uint32_t m = leaf.count - b < kLeafBatch ? leaf.count - b : kLeafBatch;
+#pragma unroll
+                for (uint32_t i = 0; i < kLeafBatch; ++i)
+                    if (i < m) T[i] = sc.tri_geo[leaf.tris_ptr + b + i];
+#pragma unroll
+                for (uint32_t i = 0; i < kLeafBatch; ++i) {
+                    if (i >= m) break;
+                    cone_tri_hit_t h;
+                    if (intersect_cone_tri<true>(cone, T[i].a, T[i].b, T[i].c, T[i].n, range, h) && !(h.dist > range.max)) return true;
+                }
             }
             continue;
         }

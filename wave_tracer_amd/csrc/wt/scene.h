@@ -108,6 +108,7 @@ struct material_t {
     // multiplies `scale`
     uint32_t scale_spec;
     uint32_t scale_tex;     // ... or a texture (scale->f(tquery).x): texture index + 1, 0 = none
+    uint32_t rough_tex;     // fractal / gaussian profile: perceptual roughness from a texture (fractal.hpp:83-92: roughness_tex->f(query).x): index + 1
 };
 
 // ---- textures (include/wt/texture/texture.hpp:29-90) ------------------------------------------------------------------------------
@@ -115,7 +116,10 @@ struct material_t {
 // texture/transform.hpp:35-44; identity when absent) applied before the lookup and `scale` by a constant (texture/scale.hpp:95-97; 1
 // when absent) applied after it.  Bitmaps are float texels (linear, 1..4 channels: luminance, luminance+alpha, RGB, RGBA), rows from the
 // image's top; luminance textures are wavelength independent (bitmap.hpp:84-99), RGB ones are only read through get_RGBA (normal maps).
-enum texture_type_e : int32_t { TEX_CONSTANT = 0, TEX_CHECKERBOARD = 1, TEX_BITMAP = 2 };
+// TEX_FUNCTION (texture/function.hpp, texture/mix.hpp): a real-valued expression of nested textures and of u, v, k, compiled by the host into
+// a postfix program of (opcode, argument) float pairs in texture_data[offset .. offset + width): see texture_function below.
+enum texture_type_e : int32_t { TEX_CONSTANT = 0, TEX_CHECKERBOARD = 1, TEX_BITMAP = 2, TEX_FUNCTION = 3 };
+enum texture_op_e : int32_t { TOP_CONST = 0, TOP_U = 1, TOP_V = 2, TOP_K = 3, TOP_TEX = 4, TOP_ADD = 5, TOP_SUB = 6, TOP_MUL = 7, TOP_DIV = 8, TOP_NEG = 9, TOP_POW = 10, TOP_MIN = 11, TOP_MAX = 12, TOP_ABS = 13, TOP_SQRT = 14, TOP_SIN = 15, TOP_COS = 16, TOP_TAN = 17, TOP_EXP = 18, TOP_LOG = 19, TOP_FLOOR = 20, TOP_CEIL = 21, TOP_ROUND = 22, TOP_ASIN = 23, TOP_ACOS = 24, TOP_ATAN = 25, TOP_ATAN2 = 26, TOP_MIX = 27, TOP_LT = 28, TOP_LE = 29, TOP_GT = 30, TOP_GE = 31, TOP_EQ = 32, TOP_NE = 33, TOP_AND = 34, TOP_OR = 35, TOP_NOT = 36 };
 enum texture_wrap_e : uint32_t { WRAP_BLACK = 0, WRAP_WHITE = 1, WRAP_CLAMP = 2, WRAP_REPEAT = 3, WRAP_MIRROR = 4 };
 struct texture_t {
     int32_t type;
@@ -124,6 +128,7 @@ struct texture_t {
     float m[4], t[2];     // transform: uv' = (m[0] u + m[1] v + t[0], m[2] u + m[3] v + t[1])
     float scale;
     uint32_t width, height, channels, offset;   // TEX_BITMAP: texel (x, y) channel c = texture_data[offset + (y * width + x) * channels + c]
+                                                // TEX_FUNCTION: the program = texture_data[offset .. offset + width)
     uint32_t bilinear;    // 0: nearest, 1: bilinear
     uint32_t uwrap, vwrap;
 };
@@ -387,12 +392,80 @@ WT_HD __attribute__((noinline)) float rgb_uplift(float r, float g, float b, floa
     }
     return I;
 }
-// texture_t::f(query).x at wavenumber k: luminance textures are wavelength independent, RGB bitmaps are uplifted per lookup
-// (bitmap.hpp:125-140)
-WT_HD float texture_spectral(const scene_t& sc, int id, vec2 uv, float k) {
+// texture_t::f(query).x at wavenumber k of a constant / checkerboard / bitmap texture: luminance textures are wavelength independent, RGB
+// bitmaps are uplifted per lookup (bitmap.hpp:125-140)
+WT_HD float texture_spectral_leaf(const scene_t& sc, int id, vec2 uv, float k) {
     bool rgb = false;
     const rgba_t c = texture_rgba(sc, id, uv, &rgb);
     return rgb ? rgb_uplift(c.r, c.g, c.b, k) : c.r;
+}
+// function_t::f / mix_t::f (texture/function.hpp:120-125, src/texture/function.cpp:92-107; texture/mix.hpp:96-106): the host compiled the
+// expression — variables: the nested textures by name, u, v and k [1/mm] — into a postfix program; nested function textures are inlined, so a
+// TOP_TEX operand is always a constant / checkerboard / bitmap texture, looked up at the SAME query (its own transform applies on top).
+// Kept out of line: the kernels that never meet one keep their register allocation.
+WT_HD __attribute__((noinline)) float texture_function(const scene_t& sc, uint32_t offset, uint32_t len, vec2 uv, float k) {
+    float st[12];
+    int sp = 0;
+    const float* prog = sc.texture_data + offset;
+    for (uint32_t i = 0; i + 1 < len; i += 2) {
+        const int op = (int)prog[i];
+        const float arg = prog[i + 1];
+        if (op <= TOP_TEX) {   // operands
+            if (sp >= 12) return 0.f;
+            st[sp++] = op == TOP_CONST ? arg : op == TOP_U ? uv.x : op == TOP_V ? uv.y : op == TOP_K ? k : texture_spectral_leaf(sc, (int)arg, uv, k);
+            continue;
+        }
+        const bool unary = op == TOP_NEG || (op >= TOP_ABS && op <= TOP_ATAN) || op == TOP_NOT;
+        const int need = unary ? 1 : (op == TOP_MIX ? 3 : 2);
+        if (sp < need) return 0.f;
+        const float c = st[sp - 1], b = need >= 2 ? st[sp - 2] : 0.f, a = need >= 3 ? st[sp - 3] : 0.f;
+        sp -= need;
+        float r = 0.f;
+        switch (op) {
+        case TOP_ADD: r = b + c; break;
+        case TOP_SUB: r = b - c; break;
+        case TOP_MUL: r = b * c; break;
+        case TOP_DIV: r = b / c; break;
+        case TOP_NEG: r = -c; break;
+        case TOP_POW: r = powf(b, c); break;
+        case TOP_MIN: r = b < c ? b : c; break;
+        case TOP_MAX: r = b > c ? b : c; break;
+        case TOP_ABS: r = fabsf(c); break;
+        case TOP_SQRT: r = sqrtf(c); break;
+        case TOP_SIN: r = sinf(c); break;
+        case TOP_COS: r = cosf(c); break;
+        case TOP_TAN: r = tanf(c); break;
+        case TOP_EXP: r = expf(c); break;
+        case TOP_LOG: r = logf(c); break;
+        case TOP_FLOOR: r = floorf(c); break;
+        case TOP_CEIL: r = ceilf(c); break;
+        case TOP_ROUND: r = roundf(c); break;
+        case TOP_ASIN: r = asinf(c); break;
+        case TOP_ACOS: r = acosf(c); break;
+        case TOP_ATAN: r = atanf(c); break;
+        case TOP_ATAN2: r = atan2f(b, c); break;
+        case TOP_MIX: r = c == 0.f ? a : (c == 1.f ? b : a * (1.f - c) + b * c); break;   // mix(texture1, texture2, m): m::mix
+        case TOP_LT: r = b < c ? 1.f : 0.f; break;
+        case TOP_LE: r = b <= c ? 1.f : 0.f; break;
+        case TOP_GT: r = b > c ? 1.f : 0.f; break;
+        case TOP_GE: r = b >= c ? 1.f : 0.f; break;
+        case TOP_EQ: r = b == c ? 1.f : 0.f; break;
+        case TOP_NE: r = b != c ? 1.f : 0.f; break;
+        case TOP_AND: r = (b != 0.f && c != 0.f) ? 1.f : 0.f; break;
+        case TOP_OR: r = (b != 0.f || c != 0.f) ? 1.f : 0.f; break;
+        case TOP_NOT: r = c == 0.f ? 1.f : 0.f; break;
+        default: return 0.f;
+        }
+        st[sp++] = r;
+    }
+    return sp == 1 ? st[0] : 0.f;
+}
+// texture_t::f(query).x at wavenumber k
+WT_HD float texture_spectral(const scene_t& sc, int id, vec2 uv, float k) {
+    if (sc.textures[id].type != TEX_FUNCTION) return texture_spectral_leaf(sc, id, uv, k);
+    const texture_t t = sc.textures[id];
+    uv = vec2{t.m[0] * uv.x + t.m[1] * uv.y + t.t[0], t.m[2] * uv.x + t.m[3] * uv.y + t.t[1]};
+    return t.scale * texture_function(sc, t.offset, t.width, uv, k);
 }
 
 }   // namespace wt

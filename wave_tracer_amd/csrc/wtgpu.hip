@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -188,6 +190,10 @@ struct wtgpu_scene {
     uint64_t samples_rendered = 0;
     uint64_t cap_hits = 0;
     std::atomic<int> cancel{0};
+    std::atomic<int> paused{0};
+    std::mutex capture_mutex;
+    wtgpu_capture_cb capture_cb = nullptr;   // pending `capture intermediate` (under capture_mutex)
+    void* capture_user = nullptr;
     uint32_t* query_scratch = nullptr;   // wtgpu_traverse_cones
     size_t query_scratch_bytes = 0;
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
@@ -368,7 +374,7 @@ __device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int o
 // stored (the five words k_trace_heavy's hand-over also uses: tuid / bx / by / pdist / front_face of the walk's traversal record) and new
 // walks fetched once a quarter of the lanes wait.  Two kinds of steps instead of seven: the lanes stay together.
 #ifndef WTGPU_AXIS_KERNEL
-#define WTGPU_AXIS_KERNEL 1
+#define WTGPU_AXIS_KERNEL 0
 #endif
 #ifndef WTGPU_LB_AXIS
 #define WTGPU_LB_AXIS 4
@@ -450,9 +456,6 @@ __device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, b
 #endif
 #ifndef WTGPU_GSS_STATIC
 #define WTGPU_GSS_STATIC 1   // 1: "walks left" = the length of the round's queue (one target per round); 0: what the wavefront saw at its last fetch
-#endif
-#ifndef WTGPU_EXACT_MIN
-#define WTGPU_EXACT_MIN 8   // lanes with a pending exact cone-triangle test that make an exact-test step worth its while (see the traversal loop)
 #endif
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round, uint32_t n_waves) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
@@ -616,38 +619,24 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         // (idle lanes wait for a walk only while this wavefront may fetch: not once it holds its guided share)
         const bool may_fetch = !exhausted && running < target;
         const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
-        // A lane with a running query is in one of three positions: it holds a node to expand (cq_node_step), a leaf whose triangles are to be
-        // filtered (cq_leaf_filter_step), or a triangle that passed the filter and awaits its exact test (q.pend; cq_exact_pending).  The exact
-        // test costs ~10 filter steps and is needed by ~3 % of the triangles: lanes that reach one wait until WTGPU_EXACT_MIN of them do (or a
-        // quarter of the running lanes, or nobody else can move), then ONE exact-test step serves them all.  Per lane the order of the steps,
-        // and therefore every result, is that of the sequential loop (wt/bvh.h: cq_leaf_step).
-        const int exact_at = running >= 4 * WTGPU_EXACT_MIN ? WTGPU_EXACT_MIN : (running + 3) / 4;
         for (;;) {
-            // nodes: every lane that holds a node descends, until the lanes with a leaf are the majority
+            // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
             for (;;) {
-                const bool at_node = st == 1 && q.leaf == 0 && q.pend == kInvalid && q.s > 0;
+                const bool at_node = st == 1 && q.leaf == 0 && q.s > 0;
                 const unsigned long long nm = __ballot(at_node);
                 if (!nm) break;
                 RP_BEGIN();
                 if (at_node) cq_node_step(a.sc, env, stack, q);
                 RP_END(3, nm);
-                if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && q.leaf != 0 && q.pend == kInvalid)) >= WTGPU_LEAF_NUM * running) break;
+                if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && q.leaf != 0)) >= WTGPU_LEAF_NUM * running) break;
             }
+            // (Deferring the exact cone-triangle tests of a leaf step — 3 % of its triangles, ~10x a filter test, 1-2 lanes busy — to a step of
+            // their own, taken once 4 / 8 / 16 lanes wait for one, was built and measured in round 4: 5 % SLOWER per pass.  The kernel is bound by
+            // dependent memory round trips, not by instruction issue, and the deferred test re-fetches its triangle: one more round trip per hit.)
             RP_BEGIN();
-            const bool at_leaf = st == 1 && q.leaf != 0 && q.pend == kInvalid;
-            const unsigned long long m_leaf = __ballot(at_leaf);
-            if (at_leaf) cq_leaf_filter_step(a.sc, env, q);
+            const unsigned long long m_leaf = __ballot(st == 1 && q.leaf != 0);
+            if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
             RP_END(4, m_leaf);
-            const bool pending = st == 1 && q.pend != kInvalid;
-            const unsigned long long m_ex = __ballot(pending);
-            if (m_ex) {
-                const bool others = __ballot(st == 1 && q.pend == kInvalid && (q.leaf != 0 || q.s > 0)) != 0;
-                if (__popcll(m_ex) >= exact_at || !others) {
-                    RP_BEGIN();
-                    if (pending) cq_exact_pending(a.sc, env, stack, tris, q);
-                    RP_END(5, m_ex);
-                }
-            }
             if (st == 1 && !cq_running(q)) st = 2;
             const int waiting = __popcll(__ballot(st == 2)) + (may_fetch ? __popcll(__ballot(st == 0)) : 0);
             if (waiting >= leave_at || !__ballot(st == 1)) break;
@@ -2068,7 +2057,10 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     UP(textures, h.n_textures)
     size_t tex_words = 0;
     for (uint32_t i = 0; i < h.n_textures; ++i)
-        if (h.textures[i].type == TEX_BITMAP) tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width * h.textures[i].height * h.textures[i].channels);
+        if (h.textures[i].type == TEX_BITMAP)
+            tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width * h.textures[i].height * h.textures[i].channels);
+        else if (h.textures[i].type == TEX_FUNCTION)
+            tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width);
     UP(texture_data, tex_words)
     UP(emitters, h.n_emitters)
     UP(emitter_cdf, h.n_emitters + 1)
@@ -2094,16 +2086,16 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     const uint64_t npix = (uint64_t)h.sensor.width * h.sensor.height;
     uint32_t n_slices = 3;
     if (const char* e = getenv("WTGPU_STREAMS")) n_slices = (uint32_t)std::max(1, atoi(e));
-    uint64_t batch_cap = max_batch ? max_batch : std::min<uint64_t>(npix, 1u << 22);
+    uint64_t batch_cap = max_batch ? std::min<uint64_t>(max_batch, 1u << 24) : std::min<uint64_t>(npix, 1u << 22);
     n_slices = (uint32_t)std::min<uint64_t>(n_slices, std::max<uint64_t>(1, batch_cap / 64));
     {   // the vertex stores grow with max_depth (2 x (max_depth + 2) vertices of 356 B per sample): keep the state of all slices within a budget
-        // (WTGPU_STATE_GB, default 144 of the 288 GB) by shrinking the batches of deep scenes — more, smaller batches, same results
+        // (WTGPU_STATE_GB, default 224 of the 288 GB, and never more than 85 % of what is free) by shrinking the batches of deep scenes — more, smaller batches, same results
         const bool pm = h.opts.integrator != INTEGRATOR_BDPT;
         const uint64_t mv = (uint64_t)h.opts.max_depth + 2;
         uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
         // plt_path: two wedge pools of 48 records per walk, the deferred-NEE records, the queues of the wave-per-walk kernels
         if (pm) per_sample += 2ull * 48ull * sizeof(utd_edge_rec_t) + sizeof(path_nee_rec_t) + 3ull * 4ull + 4ull + sizeof(uint2);
-        uint64_t budget = 144ull << 30;
+        uint64_t budget = 224ull << 30;   // of the MI355X's 288 GB (three slices of a two-pass 1440^2 batch are 186 GB); WTGPU_STATE_GB overrides
         if (const char* e = getenv("WTGPU_STATE_GB")) budget = (uint64_t)std::max(1, atoi(e)) << 30;
         // ... and within what the device has free right now (another scene, torch's caching allocator, a smaller GPU): 85 % of it, the rest is
         // for the per-slice pools (edge ids, region-sum tasks, Fraunhofer segments: ~0.3 GB per slice) and the caller's films
@@ -2619,6 +2611,23 @@ int wtgpu_cancel(wtgpu_scene* s) {
     s->cancel.store(1, std::memory_order_relaxed);
     return WTGPU_OK;
 }
+int wtgpu_pause(wtgpu_scene* s) {
+    if (!s) return fail(WTGPU_ERR_INVALID, "null scene");
+    s->paused.store(1, std::memory_order_relaxed);
+    return WTGPU_OK;
+}
+int wtgpu_resume(wtgpu_scene* s) {
+    if (!s) return fail(WTGPU_ERR_INVALID, "null scene");
+    s->paused.store(0, std::memory_order_relaxed);
+    return WTGPU_OK;
+}
+int wtgpu_capture_intermediate(wtgpu_scene* s, wtgpu_capture_cb capture, void* user) {
+    if (!s || !capture) return fail(WTGPU_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> l(s->capture_mutex);
+    s->capture_cb = capture;
+    s->capture_user = user;
+    return WTGPU_OK;
+}
 int wtgpu_render_progressive(wtgpu_scene* s, void* stream_, double* d_value, double* d_weight, double* d_light, uint64_t sb, uint64_t se, uint64_t seed,
                              uint32_t chunk_spp, wtgpu_progress_cb progress, void* user, uint64_t* spe_done) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
@@ -2628,6 +2637,18 @@ int wtgpu_render_progressive(wtgpu_scene* s, void* stream_, double* d_value, dou
     const uint64_t step = chunk_spp ? chunk_spp : 1;
     const uint64_t npix = (uint64_t)s->host.sensor.width * s->host.sensor.height;
     device_guard_t guard(s->device);
+    // a pending `capture intermediate` at a chunk boundary: the stream is idle, the films hold the completed chunks
+    auto serve_capture = [&](uint64_t done) {
+        wtgpu_capture_cb cb = nullptr;
+        void* cu = nullptr;
+        {
+            std::lock_guard<std::mutex> l(s->capture_mutex);
+            cb = s->capture_cb;
+            cu = s->capture_user;
+            s->capture_cb = nullptr;
+        }
+        if (cb) cb(done, cu);
+    };
     for (uint64_t b = sb; b < se; b += step) {
         const uint64_t e = std::min(se, b + step);
         const int rc = wtgpu_render(s, stream_, d_value, d_weight, d_light, b, e, seed);
@@ -2635,6 +2656,12 @@ int wtgpu_render_progressive(wtgpu_scene* s, void* stream_, double* d_value, dou
         HIP_CHECK(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
         if (spe_done) *spe_done = e - sb;
         const bool stop = progress && progress((e - sb) * npix, (se - sb) * npix, user) != 0;
+        serve_capture(e - sb);
+        // paused: nothing is launched until wtgpu_resume (or a cancel); captures are still served (the reference's capture needs the paused state)
+        while (s->paused.load(std::memory_order_relaxed) && !s->cancel.load(std::memory_order_relaxed) && !stop && e < se) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            serve_capture(e - sb);
+        }
         if ((stop || s->cancel.load(std::memory_order_relaxed)) && e < se) return fail(WTGPU_CANCELLED, "render cancelled");
     }
     return WTGPU_OK;

@@ -99,3 +99,47 @@ def render_distributed(scene, spp, seed=1, reduce_dst=0, shard_renderer=None, co
     if rank == reduce_dst:
         return value.cpu().numpy(), weight.cpu().numpy(), light.cpu().numpy()
     return None
+
+
+def render_distributed_progressive(scene, spp, seed=1, reduce_dst=0, chunk_spp=8, on_partial=None, shard_renderer=None, comm=None):
+    """render_distributed in chunks, with a PARTIAL film on `reduce_dst` after every chunk — what the reference's preview shows while a render
+    runs (src/scene/render.cpp:306-368: the intermediate result is the merge of every worker's image), across ranks.  Every rank renders its
+    shard [b, e) of the samples in chunks of `chunk_spp`; after each chunk the ranks reduce COPIES of their accumulators (the accumulators
+    themselves stay per-rank: samples keep adding up locally, only the last reduce is the final film) and `on_partial(value, weight, light,
+    samples_per_element_so_far)` is called on `reduce_dst` with the summed numpy films — e.g. to develop and push them to a TevPreview.  The
+    chunk boundaries are the same on every rank (shards differ by at most one sample: ranks that run out render empty chunks), so the reduces
+    match up without any other coordination.  Returns the final films on `reduce_dst` (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    b, e = shard_samples(spp, rank, world)
+    longest = max(shard_samples(spp, r, world)[1] - shard_samples(spp, r, world)[0] for r in range(world))
+    acc = None
+    done_here = 0
+    result = None
+    for c0 in range(0, max(longest, 1), max(1, chunk_spp)):
+        cb, ce = min(e, b + c0), min(e, b + c0 + max(1, chunk_spp))
+        if ce > cb or acc is None:
+            part = (shard_renderer or _render_shard_hip)(scene, cb, ce, seed)     # (an empty range renders nothing and returns zero films)
+            acc = part if acc is None else tuple(a.add_(p_) for a, p_ in zip(acc, part))
+            done_here += ce - cb
+        copies = tuple(t.clone() for t in acc)
+        if comm is not None:
+            comm.film_reduce(*copies, root=reduce_dst, stream=torch.cuda.current_stream(copies[0].device).cuda_stream)
+        else:
+            if copies[0].is_cuda and dist.get_backend() == "gloo":
+                torch.cuda.synchronize(copies[0].device)
+                copies = tuple(t.cpu() for t in copies)
+            for t in copies:
+                dist.reduce(t, dst=reduce_dst, op=dist.ReduceOp.SUM)
+        if copies[0].is_cuda:
+            torch.cuda.synchronize(copies[0].device)
+        counts = torch.tensor([done_here], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            counts = counts.to(copies[0].device)
+        dist.reduce(counts, dst=reduce_dst, op=dist.ReduceOp.SUM)
+        if rank == reduce_dst:
+            result = tuple(t.cpu().numpy() for t in copies)
+            if on_partial is not None:
+                on_partial(*result, int(counts.item()))
+    return result if rank == reduce_dst else None
