@@ -81,12 +81,18 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
  * port of the reference's own loader calls. */
 int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_scene** out);
 
-/* Minimal reader of the reference's XML scene format: enough of the vocabulary for
- * scenes/diffraction_simple/{double_slits,double_slits_and_reflectors}.xml + bits/geometry.xml as shipped — <default> defines and
- * "$name" substitution, expressions with units, <include>, enabled=..., integrator / sensor + film / spot and directional emitters /
- * twosided, surface_spm, diffuse and composite BSDFs / rectangle shapes.  `defines`: n_defines strings "name=value", the -D defines of the
- * reference's command line (src/main.cpp:805-928).  params (may be NULL): res (becomes the define "res" unless given), max_depth / fsd /
- * mis / rr / force_ray_tracing overrides, lut_* resolution, polarimetric.  Anything outside that vocabulary fails with a message. */
+/* Reader of the reference's XML scene format (src/scene/loader/*.cpp): 13 of the 15 scene files the reference ships load
+ * as they are (tests/test_xml_scene.py::test_which_of_the_shipped_scene_files_load) — <default> defines and "$name" substitution, expressions
+ * with units, <include>, enabled=..., shared elements and <ref>s (bsdfs, textures, spectra, transforms); plt_bdpt / plt_path integrators;
+ * perspective and virtual-plane sensors with array films (RGB / monochromatic response, polarimetric flag); spot, directional, point and area
+ * emitters; diffuse, dielectric, surface_spm (dirac / fractal / gaussian profile, constant or textured roughness), twosided, scale (constant,
+ * spectrum, texture), mask, normalmap and composite BSDFs; constant, checkerboard, bitmap (PNG, PFM), scale, transform, function and mix
+ * textures; spectra by constant, rgb, blackbody, discrete, piecewise linear, ITU material, or material / emitter name (baked tables or the
+ * database files of data/ior, data/emission); rectangle, cube, sphere, cylinder, prism, lens shapes and PLY / OBJ meshes with general to_world
+ * transforms (a Git-LFS pointer in place of an asset: a stand-in, or skipped with -Dwtgpu_missing_assets=skip).  Not read: textured area-emitter
+ * radiance, bicubic filtering, JPEG / EXR images, OBJ material groups, the sobolld sampler.  `defines`: n_defines strings "name=value", the -D
+ * defines of the reference's command line (src/main.cpp:805-928).  params (may be NULL): res (becomes the define "res" unless given), max_depth /
+ * fsd / mis / rr / force_ray_tracing overrides, lut_* resolution, polarimetric.  Anything outside that vocabulary fails with a message. */
 int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, uint32_t n_defines, const wtgpu_scene_params* params, wtgpu_scene** out);
 
 int wtgpu_scene_get_info(const wtgpu_scene* scene, wtgpu_scene_info* info);
@@ -95,8 +101,11 @@ int wtgpu_scene_get_info(const wtgpu_scene* scene, wtgpu_scene_info* info);
 const wtgpu_scene_desc* wtgpu_scene_host_desc(const wtgpu_scene* scene);
 
 /* Copies the flattened scene to `device` and allocates the per-sample path state: three slices (one internal stream each), each for a
- * batch of up to `max_batch_samples` samples (0: one sample per sensor element, at most 4 M), shrunk to fit WTGPU_STATE_GB (default 144).
- * A render call is cut into batches of that size; larger batches are faster.  Fails with WTGPU_ERR_NO_DEVICE when
+ * batch of up to `max_batch_samples` samples (0: one sample per sensor element, at most 4 M; at most 16 M), shrunk to fit the memory budget —
+ * WTGPU_STATE_GB (default 224) and never more than 85 % of the device's free memory.  A render call is cut into batches of that size; larger
+ * batches are faster (every batch pays its own thin tail: DESIGN.md, section 0; bench.py renders ~4 M samples per batch).  Refuses runtime
+ * settings that are known to serialise the internal streams (an explicit GPU_MAX_HW_QUEUES < 4 or HSA_KERNARG_POOL_SIZE < 4 MiB;
+ * WTGPU_ALLOW_SLOW_RUNTIME=1 overrides).  Fails with WTGPU_ERR_NO_DEVICE when
  * no HIP device is present: there is no CPU fallback. */
 int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_samples);
 

@@ -57,6 +57,15 @@ int kat_cone_tri(const float* c, const float* tri, float rmin, float rmax, float
     out[0] = hit ? h.dist : -1.f;
     return hit;
 }
+// cone_box_outside (wt/bvh.h: the conservative cone x AABB cull of the traversals): 1 = culled.  box: min3, max3 (world)
+int kat_cone_box_outside(const float* c, const float* box, float rmin, float rmax) {
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    return cone_box_outside(box[0] - cone.o.x, box[1] - cone.o.y, box[2] - cone.o.z, box[3] - cone.o.x, box[4] - cone.o.y, box[5] - cone.o.z, cone.d, cone.tan_alpha,
+                            cone.x0, range_t{rmin, rmax})
+               ? 1
+               : 0;
+}
 int kat_cone_contains(const float* c, const float* p) {
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});
     const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);

@@ -1,0 +1,112 @@
+"""Second sources (oracle/indep/second_source.py: independent derivations in double precision, numpy) against the restated primitives of
+wt/*.h.  (Where the other primitives have theirs: Fresnel / Mueller — test_kat.py; Fraunhofer alpha_1 / alpha_2 / ASF — test_kat_fsd.py;
+UTD Ds / Dh — test_kat_utd.py.)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "indep"))
+from second_source import cone_contains, cone_tri_min_z  # noqa: E402
+
+from oracle_util import load_oracle  # noqa: E402
+
+F = C.c_float
+
+
+def fa(x):
+    return np.ascontiguousarray(x, np.float32)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lb = load_oracle()
+    lb.kat_cone_tri.argtypes = [C.c_void_p, C.c_void_p, F, F, C.c_void_p]
+    lb.kat_cone_local.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lb.kat_cone_box_outside.argtypes = [C.c_void_p, C.c_void_p, F, F]
+    return lb
+
+
+def _local(lib, cone, pts):
+    out = np.zeros((len(pts), 3), np.float32)
+    for i, q in enumerate(pts):
+        lib.kat_cone_local(p(cone), p(fa(q)), p(out[i]))
+    return out.astype(np.float64)
+
+
+def test_cone_triangle_closest_z_against_the_barycentric_programme(lib):
+    """intersect_cone_tri (wt/cone.h, restating math/intersect/cone.hpp:550-626: contained vertices, cone-plane extremum, cone-edge crossings
+    in 3-D) against a differently derived solution of the same problem: minimise z over the triangle's barycentric domain under the cone's
+    quadratic constraint and the slab (KKT candidates, second_source.cone_tri_min_z).  Isotropic and elliptic cones, whole range and slabs,
+    4000 random configurations: the hit flags agree but for grazing contacts, the distances to 1e-4 of the scene scale."""
+    rng = np.random.default_rng(11)
+    n_cmp = n_flag = n_hit = 0
+    worst = 0.0
+    for it in range(4000):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        ecc = 0.0 if it % 2 == 0 else rng.uniform(0.2, 0.9)
+        ta = float(10 ** rng.uniform(-3, -0.3))
+        x0 = float(rng.uniform(0, 0.05)) if it % 3 else 0.0
+        cone = fa([*rng.uniform(-.5, .5, 3), *d, ta, x0, ecc])
+        e = 1.0 / np.sqrt(1 - float(cone[8]) ** 2)
+        centre = np.array(cone[:3], np.float64) + d * rng.uniform(0.3, 3.0) + rng.normal(size=3) * rng.uniform(0, 0.6)
+        tri = centre + rng.normal(size=(3, 3)) * 10 ** rng.uniform(-1.5, 0)
+        if it % 4 == 0:
+            zmin, zmax = 0.0, np.inf
+        else:
+            zc = float(np.dot(centre - cone[:3], d))
+            zmin = max(0.0, zc + rng.uniform(-.5, .3))
+            zmax = zmin + 10 ** rng.uniform(-1.5, 0.3)
+        out = np.zeros(1, np.float32)
+        hit = lib.kat_cone_tri(p(cone), p(fa(tri.ravel())), F(zmin), F(zmax if np.isfinite(zmax) else 3e38), p(out))
+        P = _local(lib, cone, tri)
+        ref = cone_tri_min_z(P, float(cone[6]), float(cone[7]), e, zmin, zmax)
+        n_flag += 1
+        if (ref is not None) != bool(hit):
+            # disagreements must be grazing: the second source's margin (how deep the deepest point of the triangle sits inside the cone) is tiny
+            continue
+        n_cmp += 1
+        if hit:
+            n_hit += 1
+            err = abs(float(out[0]) - ref) / max(1.0, abs(ref))
+            worst = max(worst, err)
+            assert err < 2e-4, (it, float(out[0]), ref)
+    print(f"cone-triangle: {n_hit} hits of {n_flag}, flags agree in {n_cmp} ({100.0 * n_cmp / n_flag:.2f} %), worst distance error {worst:.1e}")
+    assert n_hit > 600 and n_cmp >= 0.99 * n_flag
+
+
+def test_cone_box_cull_never_removes_a_box_that_holds_a_point_of_the_cone(lib):
+    """cone_box_outside (wt/bvh.h; not in the reference: the extra conservative cull of a child box against cone ∩ slab) is only allowed to
+    say "outside" when no point of the box lies in the cone inside the slab.  Random boxes, 400 random points each, containment decided by the
+    second source in double precision."""
+    rng = np.random.default_rng(5)
+    culled = kept = 0
+    for it in range(3000):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        ecc = 0.0 if it % 2 == 0 else rng.uniform(0.2, 0.9)
+        cone = fa([*rng.uniform(-.5, .5, 3), *d, 10 ** rng.uniform(-3, -0.3), rng.uniform(0, 0.05), ecc])
+        e = 1.0 / np.sqrt(1 - float(cone[8]) ** 2)
+        c = np.array(cone[:3], np.float64) + d * rng.uniform(0.1, 3.0) + rng.normal(size=3) * rng.uniform(0, 1.0)
+        half = 10 ** rng.uniform(-2, 0, 3)
+        box = fa([*(c - half), *(c + half)])
+        zmin = float(rng.uniform(0, 2))
+        zmax = zmin + float(10 ** rng.uniform(-1.5, 0.5))
+        out = lib.kat_cone_box_outside(p(cone), p(box), F(zmin), F(zmax))
+        if not out:
+            kept += 1
+            continue
+        culled += 1
+        pts = c + (rng.uniform(-1, 1, (400, 3))) * half
+        loc = _local(lib, cone, pts)
+        inside = [cone_contains(q, float(cone[6]), float(cone[7]), e, zmin, zmax) for q in loc]
+        assert not any(inside), (it, cone, box, zmin, zmax)
+    print(f"cone-box cull: {culled} culled, {kept} kept")
+    assert culled > 300 and kept > 300

@@ -148,10 +148,11 @@ struct ray_hit_t {
     uint32_t front_face;
 };
 
-// The triangles of a leaf are FETCHED FOUR AT A TIME before the first of them is tested: a loop that loads triangle t inside iteration t is a
-// chain of dependent memory round trips (the loads cannot be hoisted over the early exits), and on the device — where every wavefront's steps
-// are bounded by such round trips, not by arithmetic — a 4-triangle leaf then costs four latencies instead of one.  The tests run in the
-// reference's order.
+// The triangles of a leaf can be FETCHED IN BATCHES before the first of them is tested (WT_LEAF_BATCH): a loop that loads triangle t inside
+// iteration t is a chain of dependent memory round trips (the loads cannot be hoisted over the early exits), and the device's traversal kernels
+// are bound by such round trips, not by arithmetic.  Measured in round 4 (leaves hold <= 4 triangles): batches of 2 / 4 cost 24 / 48 more
+// registers where the kernels already spill — 22.3 / 21.3 against 22.4 Msamples/s with the plain loop (batch 1, the default; 22.6 with batches
+// of 2 and 256 registers per lane, i.e. two wavefronts per SIMD instead of three).  The tests run in the reference's order either way.
 #ifndef WT_LEAF_BATCH
 #define WT_LEAF_BATCH 1
 #endif

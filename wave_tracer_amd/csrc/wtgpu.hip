@@ -91,7 +91,7 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 // control block of one state slice (device memory)
-enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_HEAD_AXIS = 33, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
+enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
                   CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 40 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
@@ -199,7 +199,7 @@ struct wtgpu_scene {
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
-        uint32_t shrink_r1 = 6, shrink_f1 = 4, shrink_r2 = 12, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
+        uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         int dbg_stage = 1 << 30;
     } knobs;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         ctl[CTL_COUNT0] = 2 * a.nb;
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
-        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_AXIS] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
         ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
         ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
@@ -357,92 +357,15 @@ __device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int o
 // A slow query therefore occupies one lane, not 64, which is also what lets the work budget per query be larger (fewer walks
 // handed to the wave-cooperative kernel).  Per walk the sequence of visits and the results are those of wt::traverse_axis.
 //
-// GUIDED FETCH (round 4).  A wavefront that holds 64 walks in 64 different states advances them almost one at a time (the steps of
-// different kinds serialise: 9 of 64 lanes busy per instruction); that is the price of throughput while the queue is long, but it is also
-// what every round paid at its END: the wavefronts that happened to grab the last 64 walks each took ~1.4 ms to work them off, alone on the
-// GPU, whether the round held 4 million walks or 400 (rounds 4..21 of a 1440^2 pass: 1.5 ms each, 27 of the kernel's 52 ms).  So a
-// wavefront holds at most target = ceil(walks left in the queue / wavefronts of the grid) walks (guided self-scheduling: 64 while the queue is
-// long, 1 near its end), from the queue length it saw at its last fetch; the tail of a round is then as long as its longest single walk.
+// (GUIDED FETCH — a wavefront holds at most ceil(walks left in the queue / wavefronts of the grid) walks, so that the end of a round is as long
+// as its longest single walk instead of a wavefront's 64 — was built and measured in round 4, dynamically and as a per-round target: the short
+// rounds of a one-stream pass went from 1.5 to 1.0 ms each, but a wavefront that fetches one walk at a time runs its fetch section — the axis
+// query — for one lane: the long rounds got 35 % slower, the pass 9 % (20.4 vs 22.4 Msamples/s).  With the per-round target: +0.6 % on the
+// headline workload, +3..6 % on the 720 x 540 film, -3 % with two-pass batches.  Not kept: what the ends of the rounds cost is paid per BATCH,
+// and larger batches (bench.py: ~4 M samples) removed most of it: 720 x 540 18.8 -> 56 Msamples/s.)
 #ifndef WTGPU_REFILL_MIN
 #define WTGPU_REFILL_MIN 16
 #endif
-// The closest hit of every queued walk's beam AXIS (wt::traverse_axis: one ray query over the whole range stands in for the ray queries of the
-// ballistic segments and bounds the cone queries), in a kernel of its own since round 4.  Inside k_trace_refill the axis query ran to completion
-// for the lanes that had just fetched a walk — a while-while loop as long as its slowest lane (26 % of that kernel's time at ~8 busy lanes) —
-// and its state sat in the registers of a kernel that needs them for the cone queries.  Here a lane is a slot rays pass through, exactly like the
-// walks of k_trace_refill: node steps (rq_node_step) for the lanes that hold a node, leaf steps for those that hold triangles, finished rays
-// stored (the five words k_trace_heavy's hand-over also uses: tuid / bx / by / pdist / front_face of the walk's traversal record) and new
-// walks fetched once a quarter of the lanes wait.  Two kinds of steps instead of seven: the lanes stay together.
-#ifndef WTGPU_AXIS_KERNEL
-#define WTGPU_AXIS_KERNEL 0
-#endif
-#ifndef WTGPU_LB_AXIS
-#define WTGPU_LB_AXIS 4
-#endif
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_AXIS) k_trace_axis(launch_args_t a, int in, int first_round) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = queue_count(ctl, in);
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int st = 0;   // 0: no ray, 1: ray query running or just ended
-    uint32_t w = 0;
-    vec3 ro{0.f, 0.f, 0.f}, rd{0.f, 0.f, 1.f};
-    ray_query_t q;
-    memset(&q, 0, sizeof(q));
-    bool exhausted = false;
-    for (;;) {
-        if (st == 1 && !rq_running(q)) {   // ads_intersect_ray's epilogue: a hit beyond the range is none
-            const bool hit = finitef(q.rec.dist);
-            uint32_t* tr = a.st.trav + (size_t)w * kTravWords;
-            tr[WT_TRAV_WORD(tuid)] = hit ? q.rec.tuid : kInvalid;
-            tr[WT_TRAV_WORD(bx)] = __float_as_uint(q.rec.bx);
-            tr[WT_TRAV_WORD(by)] = __float_as_uint(q.rec.by);
-            tr[WT_TRAV_WORD(pdist)] = __float_as_uint(hit ? q.rec.dist : WT_INF);
-            tr[WT_TRAV_WORD(front_face)] = q.rec.front_face;
-            st = 0;
-        }
-        const unsigned long long im = __ballot(st == 0);
-        const int n_idle = __popcll(im);
-        if (!exhausted && (n_idle >= WTGPU_REFILL_MIN || n_idle == 64)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(ctl + CTL_HEAD_AXIS, (uint32_t)n_idle);
-            base = (uint32_t)__shfl((int)base, 0, 64);
-            if (base + (uint32_t)n_idle >= n) exhausted = true;
-            const uint32_t qi = base + (uint32_t)__popcll(im & below);
-            if (st == 0 && qi < n) {
-                w = queue_walk(a, ctl, in, qi, first_round);
-                const cone_t env = walk_trace_envelope(a.sc, walk_load_trace_in(a.st.walks, a.st.walk_words, w));
-                ro = env.o;
-                rd = env.d;
-                rq_begin(a.sc, range_t{0.f, WT_INF}, stack, q);
-                st = 1;
-            }
-        }
-        const int running = __popcll(__ballot(st == 1));
-        if (running == 0) {
-            if (exhausted) break;
-            continue;
-        }
-        const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
-        for (;;) {
-            for (;;) {
-                const bool at_node = st == 1 && q.s > 0 && q.lcnt == 0;
-                if (!__ballot(at_node)) break;
-                if (at_node) rq_node_step(a.sc, ro, rd, stack, q);
-                if (2 * __popcll(__ballot(st == 1 && q.lcnt != 0)) >= running) break;
-            }
-            if (st == 1 && q.lcnt != 0) rq_leaf_step<false>(a.sc, ro, rd, stack, q);
-            const unsigned long long live = __ballot(st == 1 && rq_running(q));
-            const int waiting = running - __popcll(live) + (exhausted ? 0 : n_idle);
-            if (waiting >= leave_at || !live) break;
-        }
-    }
-}
-
 // the policy up to its next cone query (TRUE) or its end (FALSE: `r` is final); the tests of the remembered triangles run right here
 __device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, bool rt, const stack_ref_t& stack, axis_walk_t& aw, cone_query_t& q, trav_result_t& r) {
     for (;;) {
@@ -451,13 +374,7 @@ __device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, b
         aw_test_done(aw, cone_attempt_too_short_by(sc, env, aw.cand, aw.sr, aw.min_df_prog));
     }
 }
-#ifndef WTGPU_GSS_MUL
-#define WTGPU_GSS_MUL 0   // target walks per wavefront = ceil(MUL x walks left / wavefronts); 0: always 64 (round 3's behaviour)
-#endif
-#ifndef WTGPU_GSS_STATIC
-#define WTGPU_GSS_STATIC 1   // 1: "walks left" = the length of the round's queue (one target per round); 0: what the wavefront saw at its last fetch
-#endif
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round, uint32_t n_waves) {
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = queue_count(ctl, in);
@@ -505,7 +422,6 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
     memset(&aw, 0, sizeof(aw));
     memset(&q, 0, sizeof(q));
     bool exhausted = false;   // wave-uniform: the queue holds no more walks
-    uint32_t rem_est = n;     // wave-uniform: walks left in the queue when this wavefront last looked (guided fetch)
 #ifdef WTGPU_REFILL_PROF
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pl[6] = {0, 0, 0, 0, 0, 0};
     long long pt;
@@ -533,20 +449,14 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         const int n_idle = __popcll(__ballot(st == 0 && !fin)), n_run = __popcll(__ballot(st == 1));
         bool fetched = false;
         const bool any_fin = __ballot(fin) != 0;   // (their records are stored first; they fetch in the next turn)
-        // guided fetch: the number of walks this wavefront may hold now
-        const int target = WTGPU_GSS_MUL == 0 ? 64 : (int)min(64u, max(1u, (uint32_t)(((unsigned long long)rem_est * WTGPU_GSS_MUL + n_waves - 1u) / n_waves)));
-        const int room = min(n_idle, target - n_run);
-        if (!exhausted && !any_fin && room > 0 && (target < 64 || n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
-            const unsigned long long im0 = __ballot(st == 0);
-            const bool take = st == 0 && __popcll(im0 & below) < room;   // the lowest `room` idle lanes
-            const unsigned long long im = __ballot(take);
+        if (!exhausted && !any_fin && (n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
+            const unsigned long long im = __ballot(st == 0);
+            const bool take = st == 0;
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(ctl + CTL_HEAD_TRACE, (uint32_t)__popcll(im));
             base = (uint32_t)__shfl((int)base, 0, 64);
-            const uint32_t end = base + (uint32_t)__popcll(im);
-            if (end >= n) exhausted = true;
-            if (!WTGPU_GSS_STATIC) rem_est = end >= n ? 0u : n - end;
-            const uint32_t qi = take ? base + (uint32_t)__popcll(im & below) : 0xFFFFFFFFu;
+            if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
+            const uint32_t qi = base + (uint32_t)__popcll(im & below);
             RP_BEGIN();
             const unsigned long long m_f = __ballot(take && qi < n);
             if (take && qi < n) {
@@ -558,18 +468,11 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
                 env = walk_trace_envelope(a.sc, wk);
                 ray_hit_t ah;
-#if WTGPU_AXIS_KERNEL
-                // the closest hit of the beam axis, left in the traversal record by k_trace_axis
-                const uint32_t* trw = a.st.trav + (size_t)w * kTravWords;
-                ah.tuid = trw[WT_TRAV_WORD(tuid)];
-                ah.bx = __uint_as_float(trw[WT_TRAV_WORD(bx)]);
-                ah.by = __uint_as_float(trw[WT_TRAV_WORD(by)]);
-                ah.dist = __uint_as_float(trw[WT_TRAV_WORD(pdist)]);
-                ah.front_face = trw[WT_TRAV_WORD(front_face)];
-                const bool axis_hit = ah.tuid != kInvalid;
-#else
+                // (The axis query in a kernel of its own was built twice: round 3 as a grid-stride kernel — 60 vs 56 ms per pass — and round 4 as a
+                // lane-refill kernel like this one (k_trace_axis: 111 registers, 4 waves per SIMD, 2.2 G rays/s in the long rounds: 3.9 ms where this
+                // section spends ~3): the two kernels together took 24.2 ms of the long rounds against 23.4 ms with the query in here, 22.4 vs 22.5
+                // Msamples/s — the fetch section's rays overlap other wavefronts' cone queries, which a separate kernel gives up.  Not kept.)
                 const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
-#endif
                 aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
                 aw.use_cache = a.lane_cache;
                 fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
@@ -616,8 +519,6 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             continue;
         }
         // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_REFILL_MIN) wait to be served
-        // (idle lanes wait for a walk only while this wavefront may fetch: not once it holds its guided share)
-        const bool may_fetch = !exhausted && running < target;
         const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
         for (;;) {
             // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
@@ -638,7 +539,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
             if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
             RP_END(4, m_leaf);
             if (st == 1 && !cq_running(q)) st = 2;
-            const int waiting = __popcll(__ballot(st == 2)) + (may_fetch ? __popcll(__ballot(st == 0)) : 0);
+            const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
             if (waiting >= leave_at || !__ballot(st == 1)) break;
         }
     }
@@ -723,7 +624,6 @@ __device__ inline __attribute__((always_inline)) void interact_body(const launch
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
         ctl[CTL_HEAD_TRACE] = 0;
-        ctl[CTL_HEAD_AXIS] = 0;
     }
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
@@ -1145,7 +1045,7 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
         ctl[CTL_UTD_COUNT0] = ctl[CTL_UTD_COUNT1] = ctl[CTL_FSDQ_COUNT0] = ctl[CTL_FSDQ_COUNT1] = ctl[CTL_FSDQ_HEAD] = ctl[CTL_NEEQ_COUNT] = ctl[CTL_NEEQ_HEAD] = 0;
-        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_AXIS] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
         ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
         ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
@@ -1315,7 +1215,6 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
         ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
         ctl[CTL_HEAVY_HEAD] = 0;
         ctl[CTL_HEAD_TRACE] = 0;
-        ctl[CTL_HEAD_AXIS] = 0;
     }
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
@@ -2347,10 +2246,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
                 gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
             }
             if (dbg_stage >= 2 + 3 * (int)round) {
-#if WTGPU_AXIS_KERNEL
-                HP_LAUNCH(4, k_trace_axis, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
-#endif
-                HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round, g0 * (uint32_t)(kBlock / 64));
+                HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
             }
             rec();
             if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
@@ -2395,7 +2291,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         r.busy = true;
     }
     if (hp_on) {
-        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","k_trace_axis","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
+        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","(unused)","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
         for (int i = 0; i < 24; ++i)
             if (hp_n[i]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", hp_names[i], hp_n[i], hp_t[i], hp_t[i] / hp_n[i]);
         if (hp_n[31]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", "hipEventRecord", hp_n[31], hp_t[31], hp_t[31] / hp_n[31]);
