@@ -276,7 +276,13 @@ def main():
         # HBM traffic of that kernel, per launch like `achieved`: measured live (measure_traffic: two rocprofv3 --pmc passes over one step of this
         # workload, on this box, in child processes after the timed region); if rocprofv3 is unavailable, the summary committed under profiles/
         traffic, traffic_src = None, None
+        integ, max_depth, n_tris_scene, emitters = int(sc.info.integrator), int(sc.info.max_depth), int(sc.info.n_tris), sc.emitter_summary()
         if world == 1 and not args.no_traffic:
+            # the child processes size their batches from the FREE device memory (wtgpu_scene_upload): give this process's state and films back
+            # first, or the child splits the step into smaller batches than the timed region ran and `traffic` is per a different launch
+            del value, weight, light
+            sc.close()
+            torch.cuda.empty_cache()
             kname = {"k_trace": "k_trace_refill", "k_connect": "k_connect_strat", "k_edges+k_interact_b": "k_interact_b",
                      "k_flux_split+k_flux_tasks": "k_flux_tasks",
                      PATH_BRACKET: ("k_path_fsd", "k_path_interact", "k_path_edges", "k_path_interact_b", "k_path_nee")}.get(dom, dom)
@@ -300,11 +306,11 @@ def main():
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} stand-in (the scene file's geometry, LFS meshes replaced by procedural stand-ins) res={args.res} "
-                                   f"{['plt_bdpt', 'plt_path forward', 'plt_path backward'][int(sc.info.integrator)]} max_depth={int(sc.info.max_depth)} "
-                                   f"{'MIS RR Fraunhofer-FSD' if int(sc.info.integrator) == 0 else 'UTD-FSD'}, {S} spp per step; interaction regions exact "
+                                   f"{['plt_bdpt', 'plt_path forward', 'plt_path backward'][integ]} max_depth={max_depth} "
+                                   f"{'MIS RR Fraunhofer-FSD' if integ == 0 else 'UTD-FSD'}, {S} spp per step; interaction regions exact "
                                    f"(unbounded: regions beyond the 64-triangle fast path are walked in full, DESIGN.md §5)",
-                       "samples_per_step": npix * S, "tris": int(sc.info.n_tris),
-                       "emitter_selection": ", ".join(f"{e['type']} {e['select_pmf']:.4g}" for e in sc.emitter_summary()),
+                       "samples_per_step": npix * S, "tris": n_tris_scene,
+                       "emitter_selection": ", ".join(f"{e['type']} {e['select_pmf']:.4g}" for e in emitters),
                        "parallelism": f"sample-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dom, "avg_launch_ms": avg_ms, "launches": launches, "launches_with_work": with_work,

@@ -518,7 +518,7 @@ def test_bench_launches_its_own_ranks(built):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-                                   "--scene", "furnace", "--res", "64", "--no-cpu-baseline"], env=env, stderr=subprocess.DEVNULL).decode()
+                                   "--scene", "furnace", "--res", "64", "--spp-per-step", "1", "--no-cpu-baseline", "--no-traffic"], env=env, stderr=subprocess.DEVNULL).decode()
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out
     d = json.loads(lines[0])

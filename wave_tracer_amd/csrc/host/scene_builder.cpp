@@ -1245,6 +1245,7 @@ void scene_builder_t::build_bvh() {
                     bn[g].right = fresh;
             }
             parent[at] = parent[x] = fresh;
+            if (g < 0) root = fresh;   // inserted beside the root: the searches and the `p == root` guards below must see the new one
             refit_up(fresh);
         };
         for (int pass = 0; pass < reinsert_passes; ++pass) {
