@@ -318,19 +318,30 @@ WT_HD float sincf_(float x) {
 // walks are scattered over the batch and every word of every lane touched its own 64-byte line to use 4 bytes of it.  With one
 // contiguous record per walk a lane reads whole lines of its own record whatever the order of the walks: measured HBM-side traffic
 // of a pass DESIGN.md §4.)  The CPU checker keeps one record per array (idx = 0).
+// (WT_NT_RECORDS, device only, OFF: marks the record accesses non-temporal — the records are a stream of gigabytes per round, each word used
+// once per kernel, next to BVH nodes and triangles that the traversal kernels keep re-reading from L2.  Measured in round 4: 14 % SLOWER per
+// pass (21.6 / 22.0 vs 25.3 / 25.1 Msamples/s): what one kernel of a round writes the next one reads, and much of that still comes from the
+// L2 / the memory-side cache when it is allowed to stay there.)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WT_NT_RECORDS)
+#define WT_REC_LOAD(p) __builtin_nontemporal_load(p)
+#define WT_REC_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define WT_REC_LOAD(p) (*(p))
+#define WT_REC_STORE(v, p) (*(p) = (v))
+#endif
 template <class T>
 WT_HD void soa_store(uint32_t* base, size_t stride, size_t idx, const T& v) {
     static_assert(sizeof(T) % 4 == 0, "POD of 32-bit words expected");
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) base[idx * stride + i] = w[i];
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) WT_REC_STORE(w[i], base + idx * stride + i);
 }
 template <class T>
 WT_HD void soa_load(const uint32_t* base, size_t stride, size_t idx, T& v) {
     static_assert(sizeof(T) % 4 == 0, "POD of 32-bit words expected");
     uint32_t* w = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = base[idx * stride + i];
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = WT_REC_LOAD(base + idx * stride + i);
 }
 
 }   // namespace wt
