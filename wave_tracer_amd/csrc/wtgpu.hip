@@ -360,8 +360,8 @@ __device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int o
 // (GUIDED FETCH — a wavefront holds at most ceil(walks left in the queue / wavefronts of the grid) walks, so that the end of a round is as long
 // as its longest single walk instead of a wavefront's 64 — was built and measured in round 4, dynamically and as a per-round target: the short
 // rounds of a one-stream pass went from 1.5 to 1.0 ms each, but a wavefront that fetches one walk at a time runs its fetch section — the axis
-// query — for one lane: the long rounds got 35 % slower, the pass 9 % (20.4 vs 22.4 Msamples/s).  With the per-round target: +0.6 % on the
-// headline workload, +3..6 % on the 720 x 540 film, -3 % with two-pass batches.  Not kept: what the ends of the rounds cost is paid per BATCH,
+// query — for one lane: the long rounds got 35 % slower, the pass 9 % (20.4 vs 22.4 Msamples/s).  With the per-round target: -4 % on the
+// headline workload (21.5 vs 22.5), +3..6 % on the 720 x 540 film, -3 % with two-pass batches.  Not kept: what the ends of the rounds cost is paid per BATCH,
 // and larger batches (bench.py: ~4 M samples) removed most of it: 720 x 540 18.8 -> 56 Msamples/s.)
 #ifndef WTGPU_REFILL_MIN
 #define WTGPU_REFILL_MIN 16
