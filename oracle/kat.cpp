@@ -66,6 +66,18 @@ int kat_cone_box_outside(const float* c, const float* box, float rmin, float rma
                ? 1
                : 0;
 }
+// cone_sphere_maybe on the triangle's bounding sphere (wt/cone.h: the first filter of the wave-cooperative queries): 1 = kept.  out4: the sphere
+int kat_cone_tri_sphere_maybe(const float* c, const float* tri, float rmin, float rmax, float* out4) {
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    tri_bounding_sphere(vec3{tri[0], tri[1], tri[2]}, vec3{tri[3], tri[4], tri[5]}, vec3{tri[6], tri[7], tri[8]}, out4);
+    return cone_sphere_maybe(cone, vec3{out4[0], out4[1], out4[2]}, out4[3], range_t{rmin, rmax}) ? 1 : 0;
+}
+int kat_cone_tri_maybe(const float* c, const float* tri, float rmin, float rmax) {
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    return cone_tri_maybe(cone, vec3{tri[0], tri[1], tri[2]}, vec3{tri[3], tri[4], tri[5]}, vec3{tri[6], tri[7], tri[8]}, range_t{rmin, rmax}) ? 1 : 0;
+}
 int kat_cone_contains(const float* c, const float* p) {
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});
     const cone_t cone = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);

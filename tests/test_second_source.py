@@ -110,3 +110,53 @@ def test_cone_box_cull_never_removes_a_box_that_holds_a_point_of_the_cone(lib):
         assert not any(inside), (it, cone, box, zmin, zmax)
     print(f"cone-box cull: {culled} culled, {kept} kept")
     assert culled > 300 and kept > 300
+
+
+def test_bounding_sphere_filter_is_conservative(lib):
+    """The first filter of the wave-cooperative queries (wt/cone.h: cone_sphere_maybe on tri_bounding_sphere; not in the reference) may only
+    drop a triangle that cone_tri_maybe — and therefore the exact test — drops too.  12000 random configurations with small and large
+    triangles, thin and wide cones, slabs: (1) the sphere contains the triangle (checked in double), (2) exact hit or filter pass => sphere
+    pass, (3) the filter does filter (most non-hits of the small-triangle cases are dropped)."""
+    lib.kat_cone_tri_sphere_maybe.argtypes = [C.c_void_p, C.c_void_p, F, F, C.c_void_p]
+    lib.kat_cone_tri_maybe.argtypes = [C.c_void_p, C.c_void_p, F, F]
+    rng = np.random.default_rng(23)
+    n_hit = n_maybe = n_sphere = n_small = n_small_drop = 0
+    for it in range(12000):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        ecc = 0.0 if it % 2 == 0 else rng.uniform(0.2, 0.9)
+        ta = float(10 ** rng.uniform(-3, -0.3))
+        x0 = float(rng.uniform(0, 0.05)) if it % 3 else 0.0
+        cone = fa([*rng.uniform(-.5, .5, 3), *d, ta, x0, ecc])
+        z = rng.uniform(0.3, 3.0)
+        small = it % 2 == 1
+        size = 10 ** rng.uniform(-3, -1.5) if small else 10 ** rng.uniform(-1.5, 0)
+        centre = np.array(cone[:3], np.float64) + d * z + rng.normal(size=3) * rng.uniform(0, 2.0) * (ta * z + x0 + size)
+        tri = fa((centre + rng.normal(size=(3, 3)) * size).ravel())
+        if it % 4 == 0:
+            zmin, zmax = 0.0, 3e38
+        else:
+            zc = float(np.dot(centre - cone[:3], d))
+            zmin = max(0.0, zc + rng.uniform(-.5, .3) * (0.1 if small else 1.0))
+            zmax = zmin + 10 ** rng.uniform(-2.5 if small else -1.5, 0.3)
+        sph = np.zeros(4, np.float32)
+        s_ok = lib.kat_cone_tri_sphere_maybe(p(cone), p(tri), F(zmin), F(zmax), p(sph))
+        T = tri.reshape(3, 3).astype(np.float64)
+        assert np.all(np.linalg.norm(T - sph[:3].astype(np.float64), axis=1) <= float(sph[3])), (it, T, sph)
+        # ... and is not wastefully large: the radius never exceeds the longest edge's length / sqrt(3) (equilateral circumradius) by more than rounding
+        edges = [np.linalg.norm(T[i] - T[(i + 1) % 3]) for i in range(3)]
+        assert float(sph[3]) <= max(edges) / np.sqrt(3.0) * (1 + 1e-4) + 1e-12
+        out = np.zeros(1, np.float32)
+        hit = lib.kat_cone_tri(p(cone), p(tri), F(zmin), F(zmax), p(out))
+        maybe = lib.kat_cone_tri_maybe(p(cone), p(tri), F(zmin), F(zmax))
+        n_hit += bool(hit)
+        n_maybe += bool(maybe)
+        n_sphere += bool(s_ok)
+        assert not (hit and not maybe), it
+        assert not (maybe and not s_ok), (it, cone, tri, zmin, zmax)
+        if small and not hit:
+            n_small += 1
+            n_small_drop += not s_ok
+    print(f"bounding spheres: {n_hit} exact hits, {n_maybe} pass cone_tri_maybe, {n_sphere} pass the sphere filter of 12000; "
+          f"small non-hit triangles dropped by the sphere alone: {n_small_drop} of {n_small}")
+    assert n_hit > 1500 and n_small_drop > 0.5 * n_small

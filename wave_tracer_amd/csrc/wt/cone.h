@@ -459,6 +459,56 @@ WT_HD bool cone_tri_laterally_outside(const cone_t& cone, const vec3 vs[3], floa
     const float lim = r_hi * 1.002f + 1e-7f * (fabsf(p0.x) + fabsf(p0.y) + fabsf(p1.x) + fabsf(p1.y) + fabsf(p2.x) + fabsf(p2.y));
     return d2 > lim * lim;
 }
+// Smallest sphere around a triangle (centre xyz, radius w): the circumsphere of an acute triangle, otherwise the sphere on its longest edge;
+// computed in double and rounded OUTWARDS (the radius is the largest float distance from the float centre to a vertex, plus a relative 1e-6).
+WT_HD void tri_bounding_sphere(vec3 a, vec3 b, vec3 c, float out[4]) {
+    const double ax = a.x, ay = a.y, az = a.z;
+    const double abx = b.x - ax, aby = b.y - ay, abz = b.z - az, acx = c.x - ax, acy = c.y - ay, acz = c.z - az;
+    const double d00 = abx * abx + aby * aby + abz * abz, d01 = abx * acx + aby * acy + abz * acz, d11 = acx * acx + acy * acy + acz * acz;
+    // circumcentre a + s ab + t ac; outside the triangle (s < 0, t < 0 or s + t > 1) for obtuse triangles: then the midpoint of the longest edge
+    const double den = 2.0 * (d00 * d11 - d01 * d01);
+    double s = 0.5, t = 0.0;   // degenerate: midpoint of ab, the radius below covers every vertex anyway
+    if (den > 0.0) {
+        s = d11 * (d00 - d01) / den;
+        t = d00 * (d11 - d01) / den;
+        if (s < 0.0) { s = 0.0; t = 0.5; }                       // obtuse at b: the longest edge is ac
+        else if (t < 0.0) { s = 0.5; t = 0.0; }                  // the longest edge is ab
+        else if (s + t > 1.0) { s = 0.5; t = 0.5; }              // the longest edge is bc
+    }
+    const float cx = (float)(ax + s * abx + t * acx), cy = (float)(ay + s * aby + t * acy), cz = (float)(az + s * abz + t * acz);
+    double r2 = 0.0;
+    const vec3 vs[3] = {a, b, c};
+    for (int i = 0; i < 3; ++i) {
+        const double dx = (double)vs[i].x - cx, dy = (double)vs[i].y - cy, dz = (double)vs[i].z - cz;
+        const double q = dx * dx + dy * dy + dz * dz;
+        r2 = q > r2 ? q : r2;
+    }
+    const double r = sqrt(r2);
+    out[0] = cx;
+    out[1] = cy;
+    out[2] = cz;
+    out[3] = (float)(r * (1.0 + 1e-6)) + 1e-30f;
+    if ((double)out[3] < r) out[3] = nextafterf(out[3], WT_INF);
+}
+// Pre-filter on a triangle's BOUNDING SPHERE (centre c, radius r, both rounded outwards by whoever built them): FALSE only if no point of the
+// sphere — hence of the triangle — lies inside the cone within `range`, i.e. only if cone_tri_maybe / intersect_cone_tri would say no too.
+// Every point of the sphere has z in [zc - r, zc + r] and a Euclidean distance from the axis of at least l - r (l: that of the centre); the
+// cone's cross-section at z, an ellipse of semi-axes (R(z), R(z) / e) with e >= 1, lies inside the circle of radius R(z) <= R(zhi), zhi =
+// min(zc + r, range.max).  The margin covers the rounding of l (components of |v| eps each) many times over.  16 B and ~20 operations per
+// triangle against 36 B and ~150 for cone_tri_maybe: the wave-cooperative queries run it first (wt/coop.h).
+WT_HD bool cone_sphere_maybe(const cone_t& cone, vec3 c, float r, const range_t& range) {
+    if (cone_is_ray(cone)) return true;
+    const vec3 v = c - cone.o;
+    const float zc = dot(v, cone.d);
+    if (zc + r < range.min || zc - r > range.max) return false;
+    const float zhi = fminf_(zc + r, range.max);
+    const float r_hi = zhi * cone.tan_alpha + cone.x0;
+    if (!(r_hi >= 0.f) || !finitef(r_hi)) return true;
+    const vec3 w = v - zc * cone.d;
+    const float l2 = dot(w, w);
+    const float lim = r_hi * 1.002f + r + 4e-6f * (fabsf(v.x) + fabsf(v.y) + fabsf(v.z));
+    return !(l2 > lim * lim);
+}
 // The two conservative rejections of intersect_cone_tri on their own: FALSE only if intersect_cone_tri(cone,a,b,c,..,range) would
 // return false as well (used by the wave-cooperative traversal to filter candidates before the exact test).
 WT_HD bool cone_tri_maybe(const cone_t& cone, vec3 a, vec3 b, vec3 c, const range_t& range) {

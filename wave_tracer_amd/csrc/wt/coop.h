@@ -44,6 +44,16 @@ constexpr uint32_t kCoopTriBuf = 64 + 8 * kCoopLeafTris;   // buffered triangle 
 constexpr uint32_t kCoopFlushAt = WTGPU_COOP_FLUSH_AT;   // survivors worth an exact-test pass before the stack is empty
 constexpr uint32_t kCoopSurvCap = 128;   // candidates that passed the cheap filter and await the exact cone-triangle test
 
+#ifndef WT_COOP_SPHERES
+#define WT_COOP_SPHERES 1
+#endif
+#ifndef WT_COOP_SPHERE_PREFETCH
+#define WT_COOP_SPHERE_PREFETCH 1
+#endif
+constexpr uint32_t kCoopSpherePrefetch = WT_COOP_SPHERE_PREFETCH;   // batches of 64 bounding spheres fetched ahead of their tests (coop_cone_query, phase B1a)
+// The triangles' bounding spheres (centre, radius: tri_bounding_sphere, wt/cone.h) are uploaded right behind the scene's triangles, in the
+// same allocation (wtgpu_scene_upload) — reached through tri_geo, so that the kernels' launch block does not grow by another pointer.
+__device__ inline const float4* coop_tri_spheres(const scene_t& sc) { return reinterpret_cast<const float4*>(sc.tri_geo + sc.n_tris); }
 struct coop_shared_t {
     stack_entry_t stack[kCoopStack];
     uint32_t tri_buf[kCoopTriBuf];
@@ -159,6 +169,9 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
         __syncthreads();
         bool any = false;
         for (uint32_t b2 = 0; b2 < nsurv && !any; b2 += 64) {
+#ifdef WTGPU_COOP_PROF
+            if (prof) prof[9] += 1;
+#endif
             const uint32_t k2 = b2 + lane;
             bool hit = false, ff = false;
             float d = WT_INF;
@@ -303,6 +316,51 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
         // them fail it; testing them with the exact routine would make every 64-wide batch pay its ~20x more expensive
         // plane/edge path for the 2-3 lanes that need it.  Survivors are compacted into an LDS list instead.
         bool found_any = false;
+#ifdef WTGPU_COOP_PROF
+        if (prof) { prof[10] += 1; prof[11] += leaf_total; prof[8] += (leaf_total + 63u) / 64u; }
+#endif
+#if WT_COOP_SPHERES
+        // B1a (round 4): the candidates' BOUNDING SPHERES first (cone_sphere_maybe: 16 B and ~20 operations per triangle; the scene's spheres lie
+        // behind its triangles, coop_tri_spheres); what passes is compacted IN PLACE at the front of sh.tri_buf (a survivor's slot lies at or
+        // below a slot that was already read) and only that goes through the filter below (36 B, ~150 operations per triangle, whichever lane
+        // needs them): k_trace_heavy 139 -> 127 ms per three steps, exclusive (run r4q).  An item averages 3.8 entries into this phase with
+        // 1,150 candidates in 19 batches, and 2.3 exact-test batches (WTGPU_COOP_PROF).  The spheres of kCoopSpherePrefetch batches can be
+        // fetched before the first of them is tested (the empty asm pins the loaded values: the compiler would otherwise sink every load into
+        // the block that tests it; the loop holds no calls, so it unrolls without pushing the kernel over the inliner's budget): measured 1 / 4 /
+        // 8 batches ahead -> 127 / - / 130 ms, i.e. the batches' round trips are not what this phase waits for.  Default 1.
+        {
+            const float4* spheres = coop_tri_spheres(sc);
+            uint32_t n2 = 0;
+            for (uint32_t base0 = 0; base0 < leaf_total; base0 += 64u * kCoopSpherePrefetch) {
+                float4 bs[kCoopSpherePrefetch];
+                uint32_t tu[kCoopSpherePrefetch];
+#pragma unroll
+                for (uint32_t j = 0; j < kCoopSpherePrefetch; ++j) {
+                    const uint32_t k = base0 + 64u * j + lane;
+                    tu[j] = 0;
+                    bs[j] = float4{0.f, 0.f, 0.f, 0.f};
+                    if (k < leaf_total) {
+                        tu[j] = sh.tri_buf[k];
+                        bs[j] = spheres[tu[j]];
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kCoopSpherePrefetch; ++j) asm volatile("" : "+v"(bs[j].x), "+v"(bs[j].y), "+v"(bs[j].z), "+v"(bs[j].w));
+                __syncthreads();   // every slot of this chunk has been read before any is overwritten
+#pragma unroll
+                for (uint32_t j = 0; j < kCoopSpherePrefetch; ++j) {
+                    const uint32_t k = base0 + 64u * j + lane;
+                    const bool p1 = k < leaf_total && cone_sphere_maybe(cone, vec3{bs[j].x, bs[j].y, bs[j].z}, bs[j].w, range);
+                    const unsigned long long pm1 = __ballot(p1);
+                    if (p1) sh.tri_buf[n2 + (uint32_t)__popcll(pm1 & ((1ull << lane) - 1ull))] = tu[j];
+                    n2 += (uint32_t)__popcll(pm1);
+                }
+            }
+            leaf_total = n2;
+            __syncthreads();
+            CP(7);
+        }
+#endif
         for (uint32_t base = 0; base < leaf_total && !found_any; base += 64) {
             const uint32_t k = base + lane;
             bool pass = false;

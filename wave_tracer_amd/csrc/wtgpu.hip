@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
         const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};   // see k_trace
         const cone_t env = walk_trace_envelope(a.sc, wk);
-        unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const long long tt0 = a.profile == 2 ? clock64() : 0;
         const float dist0 = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
         const uint32_t seg0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)];
@@ -597,6 +597,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
             atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
             atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
             atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
+            for (int q = 8; q < 12; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);   // (WTGPU_COOP_PROF: batch counts)
             atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
         }
         if (threadIdx.x == 0) {
@@ -1936,7 +1937,21 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     int rc;
 #define UP(field, n) \
     if ((rc = upload(s, h.field, (size_t)(n), &d.field)) != WTGPU_OK) return rc;
-    UP(tri_geo, h.n_tris)
+    {   // the triangles, and behind them — same allocation — their bounding spheres (coop_tri_spheres, wt/coop.h: the first filter of the
+        // wave-cooperative queries)
+        d.tri_geo = nullptr;
+        if (h.n_tris > 0 && h.tri_geo) {
+            const size_t nt = h.n_tris;
+            std::vector<float> sph(4 * nt);
+            for (size_t i = 0; i < nt; ++i) tri_bounding_sphere(h.tri_geo[i].a, h.tri_geo[i].b, h.tri_geo[i].c, &sph[4 * i]);
+            void* p = nullptr;
+            HIP_CHECK(hipMalloc(&p, nt * (sizeof(tri_geo_t) + 16)));
+            s->dev_allocs.push_back(p);
+            HIP_CHECK(hipMemcpy(p, h.tri_geo, nt * sizeof(tri_geo_t), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(static_cast<char*>(p) + nt * sizeof(tri_geo_t), sph.data(), nt * 16, hipMemcpyHostToDevice));
+            d.tri_geo = static_cast<const tri_geo_t*>(p);
+        }
+    }
     UP(tri_meta, h.n_tris)
     UP(tri_shade, h.n_tris)
     UP(edges, h.n_edges)
@@ -2350,11 +2365,11 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
 #endif
 #ifdef WTGPU_COOP_PROF
     if (getenv("WTGPU_PROFILE")) {
-        unsigned long long p[8];
+        unsigned long long p[12];
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
         const double n = p[4] ? double(p[4]) : 1.;
-        fprintf(stderr, "[coop prof] items %llu; per item ticks: A.pop %.0f A.node+test %.0f A.push %.0f A.leafappend %.0f B1.filter %.0f flush %.0f\n", p[4], p[0] / n, p[1] / n,
-                p[2] / n, p[3] / n, p[7] / n, p[6] / n);
+        fprintf(stderr, "[coop prof] items %llu; per item ticks: A.pop %.0f A.node+test %.0f A.push %.0f B1.filter %.0f flush+phaseB %.0f; per item: phase-B entries %.1f, candidates %.0f, filter batches %.1f, exact batches %.1f\n", p[4], p[0] / n, p[1] / n,
+                p[2] / n, p[7] / n, p[6] / n, p[10] / n, p[11] / n, p[8] / n, p[9] / n);
     }
 #endif
     if (s->knobs.profile == 1) {
