@@ -23,9 +23,9 @@
 namespace wt {
 
 constexpr int kCoopStack = 512;
-// children a full cooperative stack could not hold (never seen; a dropped child would be a silently wrong region): counted, reported by
-// wtgpu_get_counters as traversal_stack_dropped and asserted zero by the full-size GPU tests
-__device__ unsigned int g_coop_stack_dropped = 0;
+// Children a full cooperative stack could not hold (never seen; a dropped child would be a silently wrong region) are COUNTED, in the scene's own
+// counter block: every kernel that declares one of the shared structs below points its `dropped` member at the scene's slot first
+// (coop_set_dropped_counter); wtgpu_get_counters reports the slot as traversal_stack_dropped and the full-size GPU tests assert it zero.
 #ifndef WTGPU_COOP_LEAF_TRIS
 #define WTGPU_COOP_LEAF_TRIS 256
 #endif
@@ -55,6 +55,7 @@ constexpr uint32_t kCoopSpherePrefetch = WT_COOP_SPHERE_PREFETCH;   // batches o
 // same allocation (wtgpu_scene_upload) — reached through tri_geo, so that the kernels' launch block does not grow by another pointer.
 __device__ inline const float4* coop_tri_spheres(const scene_t& sc) { return reinterpret_cast<const float4*>(sc.tri_geo + sc.n_tris); }
 struct coop_shared_t {
+    unsigned long long* dropped;   // the scene's counter of children a full stack could not hold
     stack_entry_t stack[kCoopStack];
     uint32_t tri_buf[kCoopTriBuf];
     uint32_t surv[kCoopSurvCap];
@@ -62,6 +63,7 @@ struct coop_shared_t {
 };
 // the region walks' (coop_gather, coop_split) LDS: the same with the smaller candidate buffer their leaf threshold needs
 struct coop_gather_shared_t {
+    unsigned long long* dropped;
     stack_entry_t stack[kCoopStack];
     uint32_t tri_buf[64 + 8 * 64];
     uint32_t surv[kCoopSurvCap];
@@ -74,6 +76,11 @@ struct coop_edges_t {
 };
 constexpr uint32_t kCoopEdgeBits = 32768;
 
+template <class SH>
+__device__ inline void coop_set_dropped_counter(SH& sh, unsigned long long* slot) {
+    if (threadIdx.x == 0) sh.dropped = slot;
+    __syncthreads();
+}
 __device__ inline float wave_min(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
@@ -290,7 +297,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
                 const int above = grp < 7 ? __popcll(hm >> ((grp + 1) * 8)) : 0;   // hits of the groups serving deeper entries
                 const int pos = s + above + rank;
                 if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
-                else if (h) atomicAdd(&g_coop_stack_dropped, 1u);   // reported: wtgpu_counters::traversal_stack_dropped
+                else if (h) atomicAdd(sh.dropped, 1ull);   // reported: wtgpu_counters::traversal_stack_dropped
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }
@@ -563,7 +570,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
             if (hm) {
                 const int pos = s + __popcll(hm & ((1ull << lane) - 1ull));   // order is irrelevant here
                 if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
-                else if (h) atomicAdd(&g_coop_stack_dropped, 1u);   // reported: wtgpu_counters::traversal_stack_dropped
+                else if (h) atomicAdd(sh.dropped, 1ull);   // reported: wtgpu_counters::traversal_stack_dropped
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }
@@ -769,7 +776,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
                 const int above = grp < 7 ? __popcll(hm >> ((grp + 1) * 8)) : 0;
                 const int pos = s + above + rank;
                 if (h && pos < kCoopStack) sh.stack[pos] = stack_entry_t{tmin, cp};
-                else if (h) atomicAdd(&g_coop_stack_dropped, 1u);   // reported: wtgpu_counters::traversal_stack_dropped
+                else if (h) atomicAdd(sh.dropped, 1ull);   // reported: wtgpu_counters::traversal_stack_dropped
                 const int total = s + __popcll(hm);
                 s = total < kCoopStack ? total : kCoopStack;
             }

@@ -157,6 +157,7 @@ constexpr size_t kTravWords = sizeof(trav_result_t) / 4;
 #define WT_TRAV_WORD(field) (offsetof(trav_result_t, field) / 4)
 constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long long);
 constexpr size_t kProfSlots = 128;   // WTGPU_PROFILE scratch counters behind the public ones
+constexpr size_t kDroppedSlot = kNumCounters + kProfSlots;   // ... and behind those: children a full cooperative traversal stack could not hold (wt/coop.h)
 
 }   // namespace
 
@@ -559,6 +560,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
 __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_t a) {
     __shared__ coop_shared_t sh;
     __shared__ uint32_t s_item;
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_HEAVY_COUNT];
     const uint32_t* hq = a.st.heavy_queue;
@@ -707,6 +709,7 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
     __shared__ coop_gather_shared_t sh;
     __shared__ coop_edges_t eg;
     __shared__ uint32_t s_item;
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_GATHER_COUNT];
     const size_t W2 = 2 * (size_t)a.st.cap;
@@ -792,6 +795,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(laun
 __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     __shared__ coop_gather_shared_t sh;
     __shared__ uint32_t s_item;
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_INTC_COUNT];
     const size_t W2 = 2 * (size_t)a.st.cap;
@@ -821,6 +825,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
 __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t a) {
     __shared__ coop_gather_shared_t sh;
     __shared__ uint32_t s_item;
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = min(ctl[CTL_FTASK_COUNT], a.st.ftask_cap);
     const size_t W2 = 2 * (size_t)a.st.cap;
@@ -1147,6 +1152,8 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const pat
     __shared__ coop_gather_shared_t sh;
     __shared__ coop_edges_t eg;
     __shared__ uint32_t s_item;
+    coop_set_dropped_counter(csh, a.st.counters + kDroppedSlot);
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_GATHER_COUNT];
     for (;;) {
@@ -1566,10 +1573,12 @@ __global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const flo
 // traversal policy with closest-hit-only cone queries, then — for a diffusive hit — resolves the triangle under the axis and walks
 // the region [dist, dist + 2 x major axis] for its triangle count, sorted classified-edge set and intercepted power (sigma = axes/3).
 __global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* cones, uint32_t n, uint32_t edge_cap, float* dist, uint32_t* flags,
-                                                      uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux) {
+                                                      uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux, unsigned long long* dropped) {
     __shared__ coop_shared_t sh;
     __shared__ coop_gather_shared_t gsh;
     __shared__ coop_edges_t eg;
+    coop_set_dropped_counter(sh, dropped);
+    coop_set_dropped_counter(gsh, dropped);
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
     const float* c = cones + 10 * (size_t)i;
@@ -2021,8 +2030,8 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         if (batch_cap > fit) batch_cap = fit;
     }
     unsigned long long* counters = nullptr;
-    if ((rc = dmalloc(s, &counters, kNumCounters + kProfSlots))) return rc;
-    HIP_CHECK(hipMemset(counters, 0, (kNumCounters + kProfSlots) * sizeof(unsigned long long)));
+    if ((rc = dmalloc(s, &counters, kNumCounters + kProfSlots + 1))) return rc;
+    HIP_CHECK(hipMemset(counters, 0, (kNumCounters + kProfSlots + 1) * sizeof(unsigned long long)));
     s->slices.resize(n_slices);
     s->streams.resize(n_slices);
     s->ev_done.resize(n_slices);
@@ -2351,8 +2360,8 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
     out->light_splats = c.light_splats;
     out->walk_iteration_cap_hits = s->cap_hits;
     {
-        unsigned int dropped = 0;
-        HIP_CHECK(hipMemcpyFromSymbol(&dropped, HIP_SYMBOL(g_coop_stack_dropped), sizeof(dropped)));
+        unsigned long long dropped = 0;   // (per scene since round 4: the slot behind the profile counters)
+        HIP_CHECK(hipMemcpy(&dropped, s->slices[0].counters + kDroppedSlot, sizeof(dropped), hipMemcpyDeviceToHost));
         out->traversal_stack_dropped = dropped;
     }
 #ifdef WTGPU_STEP_PROF
@@ -2410,11 +2419,7 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
         if (rc) return rc;
     }
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemset(s->slices[0].counters, 0, (kNumCounters + kProfSlots) * sizeof(unsigned long long)));
-    {
-        const unsigned int zero = 0;   // (one counter per device, shared by the scenes of a process)
-        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stack_dropped), &zero, sizeof(zero)));
-    }
+    HIP_CHECK(hipMemset(s->slices[0].counters, 0, (kNumCounters + kProfSlots + 1) * sizeof(unsigned long long)));
     s->samples_rendered = 0;
     s->cap_hits = 0;
     for (double& v : s->acc) v = 0;
@@ -2453,7 +2458,7 @@ int wtgpu_query_regions(wtgpu_scene* s, void* stream_, const float* d_cones, uin
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     if (n == 0) return WTGPU_OK;
     hipLaunchKernelGGL(k_query_regions, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream_), s->dev, d_cones, n, edge_cap, d_dist, d_flags, d_primary,
-                       d_ntris, d_nedges, d_edges, d_flux);
+                       d_ntris, d_nedges, d_edges, d_flux, s->slices[0].counters + kDroppedSlot);
     HIP_CHECK(hipGetLastError());
     return WTGPU_OK;
 }
