@@ -40,6 +40,11 @@ for k in fetch:
 json.dump({"workload": {"scene": scene, "res": res, "steps": 1}, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0",
            "calibration": {"known_bytes_each_way": known, "FETCH_SIZE_KiB": cal_f[0], "WRITE_SIZE_KiB": cal_w[0], "fetch_factor": kf, "write_factor": kw,
                            "note": "factor = true bytes / (counter * 1024) for a one-dword-per-lane coalesced streaming copy"},
-           "note": "per launch = per step / dispatches of that kernel in one step (96 rounds x 6 batches for the round kernels, most of them empty)",
+           "note": "per launch = per step / dispatches of that kernel in one step (96 rounds per batch for the round kernels, most of them empty)",
            "kernels": kernels}, open(out, "w"), indent=1)
+# ... and into the calibration record itself, next to the copy's size (profiles/<tag>_calib.json)
+import os
+cal_out = os.path.join(os.path.dirname(os.path.abspath(out)), f"{tag}_calib.json")
+json.dump(dict(calib, known_bytes_each_way=known, FETCH_SIZE_KiB=cal_f[0], WRITE_SIZE_KiB=cal_w[0], fetch_factor=kf, write_factor=kw,
+               note="k_calib_copy: streaming copy, one dword per lane; factor = true bytes / (counter * 1024)"), open(cal_out, "w"))
 print(json.dumps({"fetch_factor": kf, "write_factor": kw, "total_GB_per_step": sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in kernels.values()) / 1e9}))
