@@ -2,8 +2,9 @@
 
 Independent derivations (numpy f64, no wt/ header, no line of the restated algorithms) of quantities the physics headers compute, for
 tests/test_second_source.py.  Where the other risky primitives have theirs: Fresnel coefficients and the Mueller matrix of a diagonal Jones
-matrix — tests/test_kat.py (complex closed forms, Kronecker construction); Fraunhofer alpha_1 / alpha_2 / ASF — tests/test_kat_fsd.py
-(numpy re-typing of fsd.hpp:65-185 in f64); UTD Ds / Dh — tests/test_kat_utd.py (Sommerfeld's exact half-plane solution).
+matrix — tests/test_kat.py (complex closed forms, Kronecker construction); UTD Ds / Dh — tests/test_kat_utd.py (Sommerfeld's exact half-plane
+solution); the Fraunhofer edge sum (alpha_1 / alpha_2 / Psi / ASF, fsd.hpp:65-146) — fraunhofer_boundary_integral and polygon_fourier_integral
+below (quadrature of the integrals the closed forms are the antiderivatives of).
 
 cone_tri_min_z: the closest distance along the axis at which an elliptic cone  x^2 + (e y)^2 <= (z tan_alpha + x0)^2  meets a triangle
 inside a z-slab (what intersect_cone_tri returns; the reference: include/wt/math/intersect/cone.hpp:550-626 via cone-plane and cone-edge
@@ -128,3 +129,45 @@ def cone_contains(p, tan_alpha, x0, e, zmin, zmax):
     """A point (local frame) inside the cone within the slab."""
     r = p[2] * tan_alpha + x0
     return zmin <= p[2] <= zmax and r >= 0 and p[0] ** 2 + (e * p[1]) ** 2 <= r * r
+
+
+# ---- Fraunhofer aperture: the edge sum of fsd.hpp:65-146 against the integrals it is the closed form of -------------------------------------
+_GL_X, _GL_W = np.polynomial.legendre.leggauss(64)
+_GL_X, _GL_W = (_GL_X + 1) / 2, _GL_W / 2
+
+
+def fraunhofer_boundary_integral(segments, xi):
+    """The far-field amplitude of an aperture given by boundary segments, as the LINE integral Stokes' theorem turns the Fourier integral of
+    the aperture into:  B(xi) = sum_j (xi x e_j) / |xi|^2  *  int_0^1 c_j(t) exp(-i xi . (a_j + t e_j)) dt,  c_j(t) = ca_j + t (cb_j - ca_j)
+    the (linearly interpolated) field amplitude along segment j from a_j to a_j + e_j.  64-point Gauss-Legendre per segment, f64.  The
+    reference evaluates the same integral in closed form per segment — alpha_2 (the sinc term) for the mean amplitude, alpha_1 (its
+    derivative) for the slope, times |e|^2 and the phase of the segment's midpoint (fsd.hpp:65-121) — and squares the sum: ASF = |B|^2 / (2 pi)^2.
+    segments: iterable of (a[2], e[2], ca, cb)."""
+    xi = np.asarray(xi, np.float64)
+    B = 0j
+    for a, e, ca, cb in segments:
+        a, e = np.asarray(a, np.float64), np.asarray(e, np.float64)
+        ph = np.exp(-1j * ((a[0] + _GL_X * e[0]) * xi[0] + (a[1] + _GL_X * e[1]) * xi[1]))
+        B += (xi[0] * e[1] - xi[1] * e[0]) / (xi[0] ** 2 + xi[1] ** 2) * np.sum(_GL_W * (ca + _GL_X * (cb - ca)) * ph)
+    return B
+
+
+def polygon_fourier_integral(P, xi, n=40):
+    """int_P exp(-i xi . x) d^2x over a simple polygon (vertices P[n,2]) by fan triangulation from P[0] and a Duffy-transformed tensor
+    Gauss-Legendre rule per triangle (signed areas: any simple polygon).  The physics behind the edge sum: for a uniformly lit aperture
+    |B(xi)| equals |this| — the Fraunhofer pattern IS the Fourier transform of the aperture."""
+    P = np.asarray(P, np.float64)
+    xi = np.asarray(xi, np.float64)
+    g, w = np.polynomial.legendre.leggauss(n)
+    g, w = (g + 1) / 2, w / 2
+    U, V = np.meshgrid(g, g, indexing="ij")
+    W = np.outer(w, w) * (1 - U)
+    S, T = U, V * (1 - U)
+    tot = 0j
+    for i in range(1, len(P) - 1):
+        a, b, c = P[0], P[i], P[i + 1]
+        J = (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+        X = a[0] + S * (b[0] - a[0]) + T * (c[0] - a[0])
+        Y = a[1] + S * (b[1] - a[1]) + T * (c[1] - a[1])
+        tot += J * np.sum(W * np.exp(-1j * (xi[0] * X + xi[1] * Y)))
+    return tot

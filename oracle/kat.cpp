@@ -406,6 +406,15 @@ void kat_fsd_aperture_eval(const float* edges, uint32_t n_edges, float k, const 
         out[2 * i + 1] = fsd_sampling_density(ap, ed, vec2{xi[2 * i], xi[2 * i + 1]});
     }
 }
+// |sum_j Psi_j(xi)|^2 alone (fsd.hpp:143-146 without the masks chi_e / chi_0 and the 0-th order term): what tests/test_second_source.py compares
+// with the Fourier integral over the aperture polygon
+void kat_fsd_asf_unclamped(const float* edges, uint32_t n_edges, float k, const float* xi, uint32_t n, float* out) {
+    static fsd_edge_t store[kFsdMaxEdges];
+    fsd_aperture_t ap;
+    kat_make_aperture(edges, n_edges, k, ap, store);
+    const fsd_edges_ref_t ed{store, 1};
+    for (uint32_t i = 0; i < n; ++i) out[i] = fsd_ASF_unclamped(ap, ed, vec2{xi[2 * i], xi[2 * i + 1]});
+}
 // raw LUT draw in zeta space (fsd_lut.hpp:50-69)
 void kat_fsd_lut_sample(const void* scene_host, int which, uint64_t seed, uint32_t n, float* out2) {
     const scene_t& sc = *static_cast<const scene_t*>(scene_host);

@@ -1,6 +1,6 @@
 """Second sources (oracle/indep/second_source.py: independent derivations in double precision, numpy) against the restated primitives of
-wt/*.h.  (Where the other primitives have theirs: Fresnel / Mueller — test_kat.py; Fraunhofer alpha_1 / alpha_2 / ASF — test_kat_fsd.py;
-UTD Ds / Dh — test_kat_utd.py.)"""
+wt/*.h.  (Where the other primitives have theirs: Fresnel / Mueller — test_kat.py; UTD Ds / Dh — test_kat_utd.py; the sampler built on the
+Fraunhofer ASF — test_kat_fsd.py.)"""
 import ctypes as C
 import os
 import sys
@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "indep"))
-from second_source import cone_contains, cone_tri_min_z  # noqa: E402
+from second_source import cone_contains, cone_tri_min_z, fraunhofer_boundary_integral, polygon_fourier_integral  # noqa: E402
 
 from oracle_util import load_oracle  # noqa: E402
 
@@ -160,3 +160,54 @@ def test_bounding_sphere_filter_is_conservative(lib):
     print(f"bounding spheres: {n_hit} exact hits, {n_maybe} pass cone_tri_maybe, {n_sphere} pass the sphere filter of 12000; "
           f"small non-hit triangles dropped by the sphere alone: {n_small_drop} of {n_small}")
     assert n_hit > 1500 and n_small_drop > 0.5 * n_small
+
+
+def _asf_unclamped(lib, segments, xis):
+    lib.kat_fsd_asf_unclamped.argtypes = [C.c_void_p, C.c_uint32, F, C.c_void_p, C.c_uint32, C.c_void_p]
+    E = fa([[e[0], e[1], a[0] + e[0] / 2, a[1] + e[1] / 2, ca - cb, (ca + cb) / 2] for a, e, ca, cb in segments])
+    X = fa(xis)
+    out = np.zeros(len(X), np.float32)
+    lib.kat_fsd_asf_unclamped(p(E), len(E), F(1.0), p(X), len(X), p(out))
+    return out.astype(np.float64)
+
+
+def test_fraunhofer_edge_sum_against_the_boundary_integral(lib):
+    """fsd_Psi / fsd_alpha1 / fsd_alpha2 / fsd_ASF_unclamped (wt/fsd.h, restating fsd.hpp:65-146: per segment a closed form in zeta = (xi.e,
+    xi x e)) against a quadrature of the line integral those closed forms solve (second_source.fraunhofer_boundary_integral): 40 random sets of
+    1-7 segments — open, unconnected, each with its own pair of end amplitudes, i.e. exactly what an aperture record holds — at 12 directions
+    each, small and large |xi| (the sinc's series branch and its oscillating tail).  ASF = |B|^2 / (2 pi)^2 to 2e-5."""
+    rng = np.random.default_rng(41)
+    worst = 0.0
+    n = 0
+    for it in range(40):
+        segs = [(rng.normal(size=2), rng.normal(size=2) * 10 ** rng.uniform(-1, 0.3), *rng.uniform(0.1, 1.5, 2)) for _ in range(rng.integers(1, 8))]
+        xis = rng.normal(size=(12, 2)) * 10 ** rng.uniform(-2, 1, (12, 1))
+        got = _asf_unclamped(lib, segs, xis)
+        for x, g in zip(fa(xis).astype(np.float64), got):
+            ref = abs(fraunhofer_boundary_integral(segs, x)) ** 2 / (4 * np.pi ** 2)
+            err = abs(g - ref) / max(ref, 1e-6 * max(1.0, np.max(got)))
+            worst = max(worst, err)
+            n += 1
+            assert err < 2e-4, (it, x, g, ref)
+    print(f"Fraunhofer edge sum vs boundary integral: {n} directions, worst relative error {worst:.1e}")
+
+
+def test_fraunhofer_pattern_of_a_uniform_polygon_is_its_fourier_transform(lib):
+    """The physics the edge sum stands for: a uniformly lit polygonal aperture (every segment with end amplitudes 1, 1) diffracts into
+    |FT of its indicator function|^2 / (2 pi)^2 — here the AREA integral by Gauss quadrature over a fan triangulation, which shares nothing
+    with the edge formulation but Stokes' theorem.  Convex and non-convex polygons, both orientations."""
+    rng = np.random.default_rng(43)
+    polys = [np.array([[-1, -.7], [1.2, -.7], [1.0, .9], [-.8, .6]]), np.array([[0, 0], [2, 0], [2, 1], [1, .3], [0, 1.2]]),
+             np.array([[0, 0], [.4, 0], [.4, 3], [0, 3]])]
+    polys.append(polys[0][::-1])
+    worst = 0.0
+    for P in polys:
+        segs = [(P[i], P[(i + 1) % len(P)] - P[i], 1.0, 1.0) for i in range(len(P))]
+        xis = rng.normal(size=(16, 2)) * 10 ** rng.uniform(-1.5, 0.8, (16, 1))
+        got = _asf_unclamped(lib, segs, xis)
+        for x, g in zip(fa(xis).astype(np.float64), got):
+            ref = abs(polygon_fourier_integral(P, x)) ** 2 / (4 * np.pi ** 2)
+            err = abs(g - ref) / max(ref, 1e-6 * np.max(got))
+            worst = max(worst, err)
+            assert err < 5e-4, (x, g, ref)
+    print(f"uniform polygons: worst relative error of the edge sum against the area Fourier integral {worst:.1e}")
