@@ -261,10 +261,10 @@ def main():
                  PATH_BRACKET: n_seg * 2 * S_path,
                  "k_edges+k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_flux_split+k_flux_tasks": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_c": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
-        # every batch launches each round kernel kMaxWalkIters = 96 times (rounds after its queue ran empty return at once): `launches`
+        # every batch launches each round kernel kMaxWalkIters (wt/bdpt.h: 96) times (rounds after its queue ran empty return at once): `launches`
         # is the count rocprofv3 --kernel-trace --stats averages over (profiles/r03_kernel_stats_*.csv), `launches_with_work` the rounds
         # that had walks queued.  achieved = algorithmic bytes / the kernel's HIP-event time: the same for either count.
-        rounds = 96 * tsum["batches"]
+        rounds = tsum["rounds_per_batch"] * tsum["batches"]
         launches = {"k_connect": tsum["batches"], "k_generate": tsum["batches"]}.get(dom, rounds)
         with_work = tsum["trace_launches"] if launches == rounds else launches
         avg_ms = kernels[dom] / max(1, launches)

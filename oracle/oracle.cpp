@@ -32,7 +32,7 @@ namespace {
 
 // traversal stack of the checker: never the limit (an unbudgeted query on a full stack stops the process, wt/bvh.h: cq_node_step)
 constexpr uint32_t kOracleStack = 4096;
-constexpr uint32_t kMaxWalkIters = 96;   // must match wave_tracer_amd/csrc/wtgpu.hip (cap on trace/interact rounds per subpath)
+// (kMaxWalkIters — the cap on trace / interact rounds per subpath — is wt/bdpt.h's: one definition for the device driver and this one)
 
 struct sample_scratch_t {
     std::vector<uint32_t> svert, evert;   // vertex stores (stride 1)

@@ -40,7 +40,7 @@ for k in fetch:
 json.dump({"workload": {"scene": scene, "res": res, "steps": 1}, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0",
            "calibration": {"known_bytes_each_way": known, "FETCH_SIZE_KiB": cal_f[0], "WRITE_SIZE_KiB": cal_w[0], "fetch_factor": kf, "write_factor": kw,
                            "note": "factor = true bytes / (counter * 1024) for a one-dword-per-lane coalesced streaming copy"},
-           "note": "per launch = per step / dispatches of that kernel in one step (96 rounds per batch for the round kernels, most of them empty)",
+           "note": "per launch = per step / dispatches of that kernel in one step (kMaxWalkIters rounds per batch for the round kernels, most of them empty)",
            "kernels": kernels}, open(out, "w"), indent=1)
 # ... and into the calibration record itself, next to the copy's size (profiles/<tag>_calib.json)
 import os

@@ -24,6 +24,13 @@ namespace wt {
 // vertex stores are sized from the scene's max_depth, the MIS weights stream over the vertices (bdpt_mis_weight).  kMaxVerts only sets the
 // resolution of the device's strategy buckets: strategies with s or t >= kMaxVerts share the last bucket of their row / column.
 constexpr uint32_t kMaxVerts = 18;
+// Trace / interact rounds a subpath may take (device: rounds launched per batch; CPU checker: iterations of its walk loops — one definition for
+// both).  The reference recurses without such a cap (plt_bdpt_detail.hpp:421-526): vertices are bounded by max_depth, but null interactions and
+// restarts behind empty apertures add rounds without adding vertices.  Walks still active after the last round are dropped and COUNTED
+// (wtgpu_counters::walk_iteration_cap_hits): none in the cornell / etoile workloads, 29 of 4.2 M samples of the full-size bidir_room test.
+// 128 rounds were measured in round 4: 16 of 4.2 M still reach the cap (those beams restart behind empty apertures over and over — a longer
+// loop is not what they lack) and the 32 more empty rounds per batch cost 2-4 % of a pass.  Kept at 96.
+constexpr uint32_t kMaxWalkIters = 96;
 constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
 #ifdef WT_ORACLE_UNBOUNDED
 constexpr uint32_t kMaxEdgeIds = 16384;  // CPU checker: effectively unbounded

@@ -70,7 +70,6 @@ namespace {
 #define WTGPU_LB_CONNECT 2   // 355 -> 105 spilled registers (the rest of its frame are the two vertices and beams of a connection)
 #endif
 constexpr uint32_t kFluxTaskTris = 2048;   // default size of a region-sum task (k_flux_split / k_flux_tasks)
-constexpr uint32_t kMaxWalkIters = 96;   // must match oracle/oracle.cpp
 constexpr int kBlock = 128;
 #ifndef WTGPU_LDS_STACK
 #define WTGPU_LDS_STACK 20
@@ -2331,6 +2330,7 @@ int wtgpu_last_render_timings(wtgpu_scene* s, float out[12]) {
     const int rc = drain_all(s);
     if (rc) return rc;
     for (int i = 0; i < 12; ++i) out[i] = (float)s->acc[i];
+    out[11] = (float)kMaxWalkIters;   // rounds launched per batch
     return WTGPU_OK;
 }
 
