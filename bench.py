@@ -52,9 +52,9 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
 
 def measure_traffic(kernel, scene_args, timeout_s=240):
     """HBM-side bytes per launch of `kernel` measured NOW, on this box: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, with
-    --kernel-trace only) over one step of the same workload in a child process, summed over the kernel's dispatches and scaled to bytes with the
+    --kernel-trace only) over one step of the same workload in a child process, summed over the kernel's dispatches of that step and scaled to bytes with the
     newest calibration committed under profiles/ (a streaming copy of known size with this code's access width, tools/profile_round.sh: the counters
-    read KiB; FETCH_SIZE under-reports by 2 on gfx950, MI355X_MICROARCH.md).  Returns (bytes_per_launch, detail) or (None, reason)."""
+    read KiB; FETCH_SIZE under-reports by 2 on gfx950, MI355X_MICROARCH.md).  Returns (bytes_per_step, detail) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -105,8 +105,10 @@ def measure_traffic(kernel, scene_args, timeout_s=240):
             shutil.rmtree(d, ignore_errors=True)
     if not n_disp:
         return None, "kernel not found in the counter collection"
-    return (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / n_disp, {"fetch_bytes": tot["FETCH_SIZE"], "write_bytes": tot["WRITE_SIZE"], "dispatches": n_disp, "fetch_factor": kf, "write_factor": kw,
-                                                                      "factors_from": cal_src}
+    # bytes of ONE step (the caller divides by the launches per step of its own timed region: the child's first batch launches its rounds without
+    # the history the library's expectation of rounds-with-work builds on, i.e. more empty ones — same bytes, other dispatch count)
+    return tot["FETCH_SIZE"] + tot["WRITE_SIZE"], {"fetch_bytes": tot["FETCH_SIZE"], "write_bytes": tot["WRITE_SIZE"], "dispatches": n_disp, "fetch_factor": kf, "write_factor": kw,
+                                                   "factors_from": cal_src}
 
 
 def main():
@@ -261,10 +263,10 @@ def main():
                  PATH_BRACKET: n_seg * 2 * S_path,
                  "k_edges+k_interact_b": n_seg * S_path + n_vtx * S_vtx, "k_flux_split+k_flux_tasks": n_seg * S_path + n_vtx * S_vtx,
                  "k_interact_c": n_seg * S_path + n_vtx * S_vtx, "k_connect": n_conn * 2 * S_vtx + b_film, "k_generate": 2 * S_path + 2 * S_vtx}[dom]
-        # every batch launches each round kernel kMaxWalkIters (wt/bdpt.h: 96) times (rounds after its queue ran empty return at once): `launches`
-        # is the count rocprofv3 --kernel-trace --stats averages over (profiles/r03_kernel_stats_*.csv), `launches_with_work` the rounds
-        # that had walks queued.  achieved = algorithmic bytes / the kernel's HIP-event time: the same for either count.
-        rounds = tsum["rounds_per_batch"] * tsum["batches"]
+        # A batch launches its round kernels for the rounds its walks are expected to need (+ a margin; wtgpu.hip: batch_launcher_t) — until round 4
+        # all kMaxWalkIters = 96 of them: `launches` is the count rocprofv3 --kernel-trace --stats averages over (profiles/rNN_kernel_stats*.csv),
+        # `launches_with_work` the rounds that had walks queued.  achieved = algorithmic bytes / the kernel's HIP-event time: the same for either count.
+        rounds = int(round(tsum["rounds_per_batch"] * tsum["batches"]))
         launches = {"k_connect": tsum["batches"], "k_generate": tsum["batches"]}.get(dom, rounds)
         with_work = tsum["trace_launches"] if launches == rounds else launches
         avg_ms = kernels[dom] / max(1, launches)
@@ -288,6 +290,8 @@ def main():
                      PATH_BRACKET: ("k_path_fsd", "k_path_interact", "k_path_edges", "k_path_interact_b", "k_path_nee")}.get(dom, dom)
             scene_args = ["--scene", args.scene, "--res", str(args.res), "--mesh-detail", str(md), "--polarimetric", str(pol)] + (["--ray-tracing"] if args.ray_tracing else [])
             traffic, detail = measure_traffic(kname, scene_args)
+            if traffic is not None:
+                traffic /= max(1.0, launches / K)   # per launch like `achieved`: the step's bytes over the launches per step of the timed region
             traffic_src = {"measured": "live, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one step", "kernel": kname, **detail} if traffic is not None else {"measured": None, "reason": detail}
         if traffic is None:
             try:

@@ -191,7 +191,7 @@ int wtgpu_reset_counters(wtgpu_scene* scene);
  * out[0]=generate, out[1]=trace (sum over rounds), out[2]=interact first pass (sum), out[3]=connect (4 kernels), out[4]=rounds with work,
  * out[5]=trace launches with work, out[6]=batches, out[7]=cooperative (heavy) trace (sum), out[8]=region edge sets + second
  * interaction pass (k_edges, k_interact_b), out[9]=region power sums (k_flux_split, k_flux_tasks), out[10]=Fraunhofer sampling pass
- * (k_interact_c), out[11] rounds launched per batch (kMaxWalkIters).  Batches run concurrently on
+ * (k_interact_c), out[11] mean number of rounds launched per batch.  Batches run concurrently on
  * several streams, so the sums may exceed the wall time. */
 int wtgpu_last_render_timings(wtgpu_scene* scene, float out[12]);
 

@@ -174,6 +174,46 @@ def test_async_renders_pipeline_and_join(built):
         assert np.allclose(a.cpu().numpy(), b, rtol=1e-9, atol=1e-30)
 
 
+def test_batches_enqueued_in_two_parts_render_the_same(built, monkeypatch):
+    """A batch is enqueued in two parts (wtgpu.hip: batch_launcher_t): the rounds its walks are expected to need, and — once the host has seen
+    the round queue empty, or has launched ALL the remaining rounds — the connections.  Whatever the expectation, the film is the one a blind
+    launch of every round gives: WTGPU_FIRST_ROUNDS=96 (every round up front, as before round 4), =2 (every batch needs several more
+    looks), and the default (adaptive: after the first batches only the rounds that have work, + a margin, are launched).  Many small
+    batches, both integrators."""
+    import torch
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.render import alloc_films
+    for name, kw in (("cornell_box", dict(res=48, mesh_detail=0)), ("etoile", dict(res=48, mesh_detail=0))):
+        out = {}
+        for mode in ("96", "2", "0"):
+            monkeypatch.setenv("WTGPU_FIRST_ROUNDS", mode)
+            sc = Scene(name, **kw)
+            sc.upload(0, 512)                       # 512 samples per batch: ~4 batches per sample per element
+            dev = torch.device("cuda", 0)
+            films = alloc_films(sc, dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            sc.reset_counters()
+            for i in range(6):
+                sc.render_async_into(*films, i, i + 1, 77, st)
+            sc.join(st)
+            torch.cuda.synchronize(dev)
+            c, t = sc.counters(), sc.timings()
+            out[mode] = ([f.cpu().numpy() for f in films], c, t)
+            sc.close()
+        ref, cref, tref = out["96"]
+        assert tref["rounds_per_batch"] == 96
+        for mode in ("2", "0"):
+            films, c, t = out[mode]
+            for a, b in zip(films, ref):
+                assert np.allclose(a, b, rtol=1e-9, atol=1e-30), (name, mode)
+            for k in ("samples", "segments", "vertices", "connections", "fsd_interactions", "light_splats", "walk_iteration_cap_hits"):
+                assert c[k] == cref[k], (name, mode, k, c[k], cref[k])
+        with_work = tref["rounds"] / tref["batches"]
+        assert with_work <= out["2"][2]["rounds_per_batch"] <= with_work + 10      # every batch: 2 rounds, then 8 at a time until the queue is empty
+        print(name, "rounds launched per batch, adaptive:", out["0"][2]["rounds_per_batch"], "with work:", tref["rounds"] / tref["batches"])
+        assert out["0"][2]["rounds_per_batch"] <= with_work + 16   # (the first batches guess 32; afterwards: the recent mean + 2, then 8 at a time)
+
+
 def test_empty_sample_range_is_a_noop(built):
     from wave_tracer_amd import Scene, render
     sc = Scene("furnace", res=16, lut=(32, 32))

@@ -336,7 +336,7 @@ class Scene:
         _check(load_library().wtgpu_last_render_timings(self._h, C.byref(t)))
         return {"generate_ms": t[0], "trace_ms": t[1], "interact_ms": t[2], "connect_ms": t[3], "rounds": int(t[4]),
                 "trace_launches": int(t[5]), "batches": int(t[6]), "trace_heavy_ms": t[7], "interact_b_ms": t[8], "flux_ms": t[9],
-                "interact_c_ms": t[10], "rounds_per_batch": int(t[11])}
+                "interact_c_ms": t[10], "rounds_per_batch": float(t[11])}
 
     def close(self):
         if self._h:

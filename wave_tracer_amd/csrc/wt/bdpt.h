@@ -30,7 +30,10 @@ constexpr uint32_t kMaxVerts = 18;
 // (wtgpu_counters::walk_iteration_cap_hits): none in the cornell / etoile workloads, 29 of 4.2 M samples of the full-size bidir_room test.
 // 128 rounds were measured in round 4: 16 of 4.2 M still reach the cap (those beams restart behind empty apertures over and over — a longer
 // loop is not what they lack) and the 32 more empty rounds per batch cost 2-4 % of a pass.  Kept at 96.
-constexpr uint32_t kMaxWalkIters = 96;
+#ifndef WT_MAX_WALK_ITERS
+#define WT_MAX_WALK_ITERS 96
+#endif
+constexpr uint32_t kMaxWalkIters = WT_MAX_WALK_ITERS;
 constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
 #ifdef WT_ORACLE_UNBOUNDED
 constexpr uint32_t kMaxEdgeIds = 16384;  // CPU checker: effectively unbounded

@@ -161,9 +161,14 @@ constexpr size_t kDroppedSlot = kNumCounters + kProfSlots;   // ... and behind t
 }   // namespace
 
 struct chunk_rec_t {
-    std::vector<hipEvent_t> ev;   // [0] start, [1] after generate, then 3 per round (trace, heavy, interact), last: after connect
+    std::vector<hipEvent_t> ev;   // [0] start, [1] after generate, then 6 per LAUNCHED round, last used: after connect
     uint32_t* h_ctl = nullptr;    // pinned snapshot of the slice's control block after the batch
+    uint32_t* h_mid = nullptr;    // ... and after the rounds launched up front (render_first_part): is the queue empty?
+    hipEvent_t ev_mid = nullptr;
     hipEvent_t ev_stagger = nullptr;   // recorded after the batch's round `stagger_round`: the next batch (on the next stream) starts there
+    uint32_t rounds_launched = 0;
+    size_t ev_used = 0;           // timing events recorded so far (the next one closes the batch)
+    size_t ev_final = 0;          // index of the event recorded after the batch's last kernel
     bool busy = false;
 };
 
@@ -183,6 +188,20 @@ struct wtgpu_scene {
     std::vector<chunk_rec_t> recs;                   // in-flight batch records (events + control block snapshot)
     size_t rec_next = 0;
     size_t slice_next = 0;   // batches go round-robin over the slices ACROSS render calls (a call with one batch does not always land on stream 0)
+    // A batch is enqueued in two parts (render_first_part / render_finish_part): generation + the rounds its walks are EXPECTED to need, and —
+    // once the host has seen that the round queue is empty (or has launched the remaining rounds) — the connections.  Between the two it is
+    // `pending` on its slice; the next batch of that slice, wtgpu_join and everything that reads results finish it first.
+    struct pending_t {
+        bool active = false;
+        unsigned char args[1024];   // the batch's launch block (launch_args_t, defined below)
+        chunk_rec_t* rec = nullptr;
+        uint32_t rounds_first = 0;
+    };
+    std::vector<pending_t> pending;   // per slice
+    uint32_t rounds_hist[8] = {0};    // rounds with work of the last batches seen (the expectation is their maximum + a margin)
+    uint32_t rounds_hist_n = 0;
+    uint64_t round_fallbacks = 0;     // batches whose queue was not empty after the first part (they got all kMaxWalkIters rounds)
+    uint64_t rounds_launched_total = 0;
     bool timing = true;
     std::string stats;
     double lut_power[2] = {0, 0};
@@ -201,6 +220,7 @@ struct wtgpu_scene {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
+        uint32_t first_rounds = 0, rounds_margin = 2;   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
 };
@@ -1913,6 +1933,8 @@ static void read_knobs(wtgpu_scene* s) {
     k.count_stats = u("WTGPU_COUNT_STATS", 1);
     k.split_queues = u("WTGPU_SPLIT_QUEUES", 1);
     k.shrink_r1 = u("WTGPU_SHRINK_R1", k.shrink_r1);
+    k.first_rounds = std::min<uint32_t>(u("WTGPU_FIRST_ROUNDS", k.first_rounds), kMaxWalkIters);
+    k.rounds_margin = u("WTGPU_ROUNDS_MARGIN", k.rounds_margin);
     k.shrink_f1 = std::max(1u, u("WTGPU_SHRINK_F1", k.shrink_f1));
     k.shrink_r2 = u("WTGPU_SHRINK_R2", k.shrink_r2);
     k.shrink_f2 = std::max(1u, u("WTGPU_SHRINK_F2", k.shrink_f2));
@@ -2095,25 +2117,31 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_begin, hipEventDisableTiming));
     // in-flight batch records: events for per-kernel timings + pinned snapshot of the control block
     s->recs.resize(4 * (size_t)n_slices);
+    s->pending.assign(n_slices, wtgpu_scene::pending_t{});
     for (auto& r : s->recs) {
         r.ev.resize(s->timing ? 3 + 6 * (size_t)kMaxWalkIters : 1);
         for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
         HIP_CHECK(hipHostMalloc((void**)&r.h_ctl, CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&r.h_mid, CTL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&r.ev_mid, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&r.ev_stagger, hipEventDisableTiming));
     }
     s->uploaded = true;
     return WTGPU_OK;
 }
 
+static void note_rounds(wtgpu_scene* s, uint32_t n) { s->rounds_hist[s->rounds_hist_n++ % 8u] = n; }
 // Waits for one in-flight batch record and folds its event timings / control-block snapshot into the accumulators.
 static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     if (!r.busy) return WTGPU_OK;
-    HIP_CHECK(hipEventSynchronize(r.ev.back()));
+    HIP_CHECK(hipEventSynchronize(r.ev[r.ev_final]));
     const uint32_t rounds = r.h_ctl[CTL_ROUNDS];
-    s->cap_hits += r.h_ctl[CTL_COUNT0 + (kMaxWalkIters & 1u)] + r.h_ctl[CTL_BACK0 + (kMaxWalkIters & 1u)];   // walks still active after the last round
+    s->cap_hits += r.h_ctl[CTL_COUNT0 + (r.rounds_launched & 1u)] + r.h_ctl[CTL_BACK0 + (r.rounds_launched & 1u)];   // walks still active after the last round
     s->acc[4] += rounds;
     s->acc[5] += rounds;
     s->acc[6] += 1;
+    s->rounds_launched_total += r.rounds_launched;
+    if (r.rounds_launched == kMaxWalkIters) note_rounds(s, rounds);   // (a batch that got every round: what it really needed)
     if (s->timing) {
         // (an event pair that cannot be resolved contributes 0 ms: timings are diagnostics, the render itself has completed)
         auto elapsed = [](hipEvent_t a, hipEvent_t b) {
@@ -2122,7 +2150,7 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
         };
         s->acc[0] += elapsed(r.ev[0], r.ev[1]);
         size_t e = 1;
-        for (uint32_t k = 0; k < kMaxWalkIters; ++k, e += 6) {
+        for (uint32_t k = 0; k < r.rounds_launched; ++k, e += 6) {
             static const int slot[6] = {1, 7, 2, 8, 9, 10};   // trace, heavy trace, pass A, edges + pass B, region flux, pass C
             for (int q = 0; q < 6; ++q) s->acc[slot[q]] += elapsed(r.ev[e + q], r.ev[e + q + 1]);
         }
@@ -2131,7 +2159,206 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     r.busy = false;
     return WTGPU_OK;
 }
+
+// ---- enqueueing a batch -------------------------------------------------------------------------------------------------------------
+// The launches of one batch, in two parts.  FIRST: generation and the rounds its walks are expected to need — the rounds with work of the
+// last batches on average + a margin (`rounds_hist`; a guess of 32 until a batch has been seen) — then a copy of the control block to pinned
+// memory and an event.  FINISH (when the slice is needed again, at wtgpu_join, or before results are read): the host waits for that event;
+// if the round queue is NOT empty — a batch whose walks outlasted the expectation — 8 more rounds are launched and the host looks again, up
+// to kMaxWalkIters; then the connections.  Nothing is ever dropped that a blind launch of every round (as until round 4) would have kept.
+// Why: ~25 of the 96 rounds have work; the other ~70 x 9 launches only find an empty queue, and cost 2.6 % of a pass on the headline
+// workload and 3 % on the 720 x 540 film (run r4r: the same build launching 96 / 48 / 32 rounds).
+struct batch_launcher_t {
+    wtgpu_scene* s;
+    const wtgpu_scene::knobs_t& K;
+    uint32_t grid_round = 0, grid_heavy = 0;
+    bool path_mode = false;
+    bool ev_fail = false;
+    bool hp_on = false;
+    double hp_t[32] = {0};
+    unsigned long hp_n[32] = {0};
+    explicit batch_launcher_t(wtgpu_scene* s_) : s(s_), K(s_->knobs) {
+        int n_cu = 256;   // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
+        grid_round = (uint32_t)n_cu * K.round_blocks_per_cu;
+        grid_heavy = (uint32_t)n_cu * K.heavy_waves_per_cu;
+        path_mode = s->host.opts.integrator != INTEGRATOR_BDPT;
+        static const bool hp = getenv("WTGPU_HOST_PROF") != nullptr;   // WTGPU_HOST_PROF=1: host time spent inside each kind of launch call (diagnostic)
+        hp_on = hp;
+    }
+#define HP_LAUNCH(slot, ...)                                                                                              \
+    do {                                                                                                                  \
+        if (hp_on) {                                                                                                      \
+            const auto t0_ = std::chrono::steady_clock::now();                                                            \
+            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
+            hp_t[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();      \
+            hp_n[slot]++;                                                                                                 \
+        } else                                                                                                            \
+            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
+    } while (0)
+    void rec(chunk_rec_t& r, hipStream_t st_) {
+        const auto hp0_ = std::chrono::steady_clock::now();
+        if (s->timing && hipEventRecord(r.ev[r.ev_used++], st_) != hipSuccess) ev_fail = true;
+        if (hp_on) { hp_t[31] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp0_).count(); hp_n[31]++; }
+    }
+    uint32_t g_full(uint32_t nb) const { return std::min<uint32_t>(grid_round, ((path_mode ? 1u : 2u) * nb + kBlock - 1) / kBlock); }
+    void generate(const launch_args_t& a, chunk_rec_t& r, hipStream_t st_) {
+        r.ev_used = 0;
+        r.rounds_launched = 0;
+        rec(r, st_);
+        if (path_mode)
+            HP_LAUNCH(0, k_path_generate, dim3((a.nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        else
+            HP_LAUNCH(1, k_generate, dim3((a.nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        rec(r, st_);
+    }
+    int rounds(const launch_args_t& a, const path_state_t* ps, chunk_rec_t& r, hipStream_t st_, uint32_t r_begin, uint32_t r_end) {
+        const uint32_t nb = a.nb, walks_per_sample = path_mode ? 1u : 2u, gf = g_full(nb);
+        const uint32_t grid_div_b = K.grid_div_b, grid_div_c = K.grid_div_c, grid_mul_flux = K.grid_mul_flux;   // persistent grids of the expensive-interaction passes relative to the round's
+        const int dbg_stage = K.dbg_stage;
+        for (uint32_t round = r_begin; round < r_end; ++round) {
+            const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
+            if (round == K.stagger_round && K.stagger_round > 0) {
+                HIP_CHECK(hipEventRecord(r.ev_stagger, st_));
+                s->ev_stagger_last = r.ev_stagger;
+            }
+            // the queue roughly halves every round and is normally empty after ~25: later rounds get smaller persistent grids
+            // (an empty launch costs its grid size; a grid that turns out too small only takes longer, the wavefronts loop)
+            uint32_t g0, gh;
+            if (K.decay_q > 0) {
+                // geometric schedule: the queue of round r holds ~ N q^r walks (q ~ 0.55 in the headline workload); grids follow with a safety
+                // factor — an undersized persistent grid only takes longer, an oversized one on a short queue holds up the other streams
+                const double f = std::min(1.0, (double)K.decay_c * std::pow(K.decay_q * .01, (double)round));
+                g0 = std::max<uint32_t>(2u, (uint32_t)(gf * f));
+                gh = std::max<uint32_t>(2u, (uint32_t)(std::min<uint32_t>(grid_heavy, walks_per_sample * nb) * f));
+            } else {
+                const uint32_t shrink = round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_f1 : K.shrink_f2);
+                g0 = std::max<uint32_t>(1u, gf / shrink);
+                gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
+            }
+            if (dbg_stage >= 2 + 3 * (int)round) {
+                HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+            }
+            rec(r, st_);
+            if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
+            rec(r, st_);
+            if (path_mode) {
+                if (round > 0) HP_LAUNCH(6, k_path_fsd, dim3(gh), dim3(64), 0, st_, a, ps, round);
+                if (dbg_stage >= 4 + 3 * (int)round) HP_LAUNCH(7, k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, ps, in, first, round);
+                HP_LAUNCH(8, k_path_edges, dim3(gh), dim3(64), 0, st_, a, ps);
+                HP_LAUNCH(9, k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, ps, in, round);
+                HP_LAUNCH(10, k_path_nee, dim3(gh), dim3(64), 0, st_, a, ps, round);
+                rec(r, st_);
+                rec(r, st_);
+                rec(r, st_);
+                rec(r, st_);
+                continue;
+            }
+            HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            rec(r, st_);
+            HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
+            HP_LAUNCH(13, k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
+            rec(r, st_);
+            HP_LAUNCH(14, k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
+            HP_LAUNCH(15, k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
+            rec(r, st_);
+            HP_LAUNCH(16, k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
+            HP_LAUNCH(17, k_interact_c_hard, dim3(std::max<uint32_t>(1u, gh / K.grid_div_hard)), dim3(WTGPU_HARD_BLOCK), 0, st_, a, in);
+            rec(r, st_);
+        }
+        r.rounds_launched = r_end;
+        return WTGPU_OK;
+    }
+    // after the batch's last round: connections (plt_bdpt) / what is left of the walks (plt_path), the control block's snapshot, the closing event
+    int tail(const launch_args_t& a, chunk_rec_t& r, hipStream_t st_) {
+        const uint32_t nb = a.nb, gf = g_full(nb);
+        if (path_mode) {
+            HP_LAUNCH(18, k_path_flush, dim3(kFlushGrid), dim3(kBlock), 0, st_, a, (int)(r.rounds_launched & 1u));
+        } else {
+            HP_LAUNCH(19, k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
+            HP_LAUNCH(20, k_connect_scan, dim3(1), dim3(64), 0, st_, a);
+            HP_LAUNCH(21, k_connect_strat, dim3(gf), dim3(kBlock), 0, st_, a);
+            if ((uint32_t)s->host.opts.max_depth + 2 >= kKeyDim - 1) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
+            HP_LAUNCH(23, k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        r.ev_final = s->timing ? r.ev_used : 0;
+        HIP_CHECK(hipEventRecord(r.ev[r.ev_final], st_));
+        if (ev_fail) return fail(WTGPU_ERR_HIP, "hipEventRecord failed");
+        r.busy = true;
+        return WTGPU_OK;
+    }
+#undef HP_LAUNCH
+    void report() const {
+        if (!hp_on) return;
+        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","(unused)","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
+        for (int i = 0; i < 24; ++i)
+            if (hp_n[i]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", hp_names[i], hp_n[i], hp_t[i], hp_t[i] / hp_n[i]);
+        if (hp_n[31]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", "hipEventRecord", hp_n[31], hp_t[31], hp_t[31] / hp_n[31]);
+    }
+};
+static_assert(sizeof(launch_args_t) <= sizeof(wtgpu_scene::pending_t::args), "pending_t::args holds a launch block");
+
+// rounds to launch up front: what the recent batches needed ON AVERAGE + a small margin.  (Not their maximum: the number of rounds a batch needs
+// is set by its single longest walk — 36 on average on the headline workload, now and then 60 — and a batch that needs more than expected only
+// costs another look, 8 rounds at a time.)  WTGPU_FIRST_ROUNDS forces a number: tests use 2, 96 = as before round 4.
+static uint32_t expected_rounds(const wtgpu_scene* s) {
+    if (s->knobs.first_rounds) return s->knobs.first_rounds;
+    if (s->rounds_hist_n == 0) return std::min<uint32_t>(kMaxWalkIters, 32u);   // nothing seen yet: a guess
+    const uint32_t n = std::min<uint32_t>(s->rounds_hist_n, 8u);
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < n; ++i) sum += s->rounds_hist[i];
+    return std::min<uint32_t>(kMaxWalkIters, (sum + n - 1) / n + s->knobs.rounds_margin);
+}
+// the second part of the batch pending on slice k (see batch_launcher_t); blocks the calling thread until its first part has run
+static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
+    wtgpu_scene::pending_t& p = s->pending[k];
+    if (!p.active) return WTGPU_OK;
+    p.active = false;
+    chunk_rec_t& r = *p.rec;
+    launch_args_t a;
+    std::memcpy(&a, p.args, sizeof(a));
+    hipStream_t st_ = s->streams[k];
+    // Is the round queue empty?  If not — a batch whose walks outlasted the expectation — another kRoundsStep rounds, and look again.
+    constexpr uint32_t kRoundsStep = 8;
+    uint32_t launched = p.rounds_first;
+    while (launched < kMaxWalkIters) {
+        HIP_CHECK(hipEventSynchronize(r.ev_mid));
+        const uint32_t q = launched & 1u;
+        const uint32_t left = r.h_mid[CTL_COUNT0 + q] + r.h_mid[CTL_BACK0 + q];
+        if (left == 0) {
+            note_rounds(s, r.h_mid[CTL_ROUNDS]);
+            break;
+        }
+        s->round_fallbacks++;
+        const uint32_t next = std::min<uint32_t>(kMaxWalkIters, launched + kRoundsStep);
+        const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, next);
+        if (rc) return rc;
+        launched = next;
+        if (launched < kMaxWalkIters) {
+            HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+            HIP_CHECK(hipEventRecord(r.ev_mid, st_));
+        }   // (else: every round has been launched; what the batch needed is noted when it is drained)
+    }
+    return L.tail(a, r, st_);
+}
+static int finish_all_pending(wtgpu_scene* s) {
+    bool any = false;
+    for (const auto& p : s->pending) any = any || p.active;
+    if (!any) return WTGPU_OK;
+    batch_launcher_t L(s);
+    for (size_t k = 0; k < s->pending.size(); ++k) {
+        const int rc = render_finish_part(s, k, L);
+        if (rc) return rc;
+    }
+    return WTGPU_OK;
+}
 static int drain_all(wtgpu_scene* s) {
+    {
+        const int rc = finish_all_pending(s);
+        if (rc) return rc;
+    }
     for (auto& r : s->recs) {
         const int rc = drain_rec(s, r);
         if (rc) return rc;
@@ -2143,6 +2370,10 @@ int wtgpu_join(wtgpu_scene* s, void* stream_) {
     if (!s || !s->uploaded) return fail(WTGPU_ERR_INVALID, "scene not uploaded");
     hipStream_t caller = static_cast<hipStream_t>(stream_);
     device_guard_t guard(s->device);
+    {   // (blocks until the first parts of the pending batches have run: their second parts are enqueued here)
+        const int rc = finish_all_pending(s);
+        if (rc) return rc;
+    }
     for (size_t k = 0; k < s->slices.size(); ++k) {
         HIP_CHECK(hipEventRecord(s->ev_done[k], s->streams[k]));
         HIP_CHECK(hipStreamWaitEvent(caller, s->ev_done[k], 0));
@@ -2185,34 +2416,21 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_flux_*).
     // WTGPU_NO_LISTS=1 (plt_bdpt, diagnostic): no lists at all, every region is gathered.
     a.collect_list = (h.opts.integrator != INTEGRATOR_BDPT || !K.no_lists) ? 1u : 0u;
-    // persistent grids: enough blocks to fill the 256 CUs; wavefronts pull work until the queue is empty
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s->device);
-    const uint32_t grid_round = (uint32_t)n_cu * K.round_blocks_per_cu, grid_heavy = (uint32_t)n_cu * K.heavy_waves_per_cu;
-    const uint32_t grid_div_b = K.grid_div_b, grid_div_c = K.grid_div_c, grid_mul_flux = K.grid_mul_flux;   // persistent grids of the expensive-interaction passes relative to the round's
+    batch_launcher_t L(s);
 
     // the internal streams start after everything already enqueued on the caller's stream ...
     HIP_CHECK(hipEventRecord(s->ev_begin, caller));
     const size_t n_slices = s->slices.size();
-    // WTGPU_HOST_PROF=1: host time spent inside each kind of launch call (diagnostic)
-    static const bool hp_on = getenv("WTGPU_HOST_PROF") != nullptr;
-    double hp_t[32] = {0};
-    unsigned long hp_n[32] = {0};
-#define HP_LAUNCH(slot, ...)                                                                                              \
-    do {                                                                                                                  \
-        if (hp_on) {                                                                                                      \
-            const auto t0_ = std::chrono::steady_clock::now();                                                            \
-            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
-            hp_t[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();      \
-            hp_n[slot]++;                                                                                                 \
-        } else                                                                                                            \
-            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
-    } while (0)
     std::vector<char> used(n_slices, 0);
     const uint64_t cap = s->slices[0].cap;
     for (uint64_t j0 = 0; j0 < total; j0 += cap) {
         const size_t k = s->slice_next++ % n_slices;
         hipStream_t st_ = s->streams[k];
+        {   // the batch that still holds this slice gets its second part first (the host waits for its first part here: by now the other
+            // slices' batches have been enqueued behind it, so the GPU is not idle meanwhile)
+            const int rc = render_finish_part(s, k, L);
+            if (rc) return rc;
+        }
         if (!used[k]) {
             HIP_CHECK(hipStreamWaitEvent(st_, s->ev_begin, 0));
             used[k] = 1;
@@ -2227,100 +2445,29 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         // rounds ARE most of a batch, holding the next batch back only idles the GPU.
         if (K.stagger_round > 0 && s->ev_stagger_last && n_slices > 1) HIP_CHECK(hipStreamWaitEvent(st_, s->ev_stagger_last, 0));
         a.st = s->slices[k];
-        const path_state_t* ps = s->d_path_slices[k];
         a.j0 = j0;
         a.nb = nb;
-        size_t ev = 0;
-        const bool tm = s->timing;
-        bool ev_fail = false;
-        auto rec = [&]() {
-            const auto hp0_ = std::chrono::steady_clock::now();
-            if (tm && hipEventRecord(r.ev[ev++], st_) != hipSuccess) ev_fail = true;
-            if (hp_on) { hp_t[31] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp0_).count(); hp_n[31]++; }
-        };
-        rec();
-        const bool path_mode = h.opts.integrator != INTEGRATOR_BDPT;
-        const uint32_t walks_per_sample = path_mode ? 1u : 2u;
-        const int dbg_stage = K.dbg_stage;
-        if (path_mode)
-            HP_LAUNCH(0, k_path_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
-        else
-            HP_LAUNCH(1, k_generate, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
-        rec();
-        const uint32_t g_full = std::min<uint32_t>(grid_round, (walks_per_sample * nb + kBlock - 1) / kBlock);
-        for (uint32_t round = 0; round < kMaxWalkIters; ++round) {
-            const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
-            if (round == K.stagger_round && K.stagger_round > 0) {
-                HIP_CHECK(hipEventRecord(r.ev_stagger, st_));
-                s->ev_stagger_last = r.ev_stagger;
-            }
-            // the queue roughly halves every round and is normally empty after ~25: later rounds get smaller persistent grids
-            // (an empty launch costs its grid size; a grid that turns out too small only takes longer, the wavefronts loop)
-            uint32_t g0, gh;
-            if (K.decay_q > 0) {
-                // geometric schedule: the queue of round r holds ~ N q^r walks (q ~ 0.55 in the headline workload); grids follow with a safety
-                // factor — an undersized persistent grid only takes longer, an oversized one on a short queue holds up the other streams
-                const double f = std::min(1.0, (double)K.decay_c * std::pow(K.decay_q * .01, (double)round));
-                g0 = std::max<uint32_t>(2u, (uint32_t)(g_full * f));
-                gh = std::max<uint32_t>(2u, (uint32_t)(std::min<uint32_t>(grid_heavy, walks_per_sample * nb) * f));
-            } else {
-                const uint32_t shrink = round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_f1 : K.shrink_f2);
-                g0 = std::max<uint32_t>(1u, g_full / shrink);
-                gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
-            }
-            if (dbg_stage >= 2 + 3 * (int)round) {
-                HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
-            }
-            rec();
-            if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
-            rec();
-            if (path_mode) {
-                if (round > 0) HP_LAUNCH(6, k_path_fsd, dim3(gh), dim3(64), 0, st_, a, ps, round);
-                if (dbg_stage >= 4 + 3 * (int)round) HP_LAUNCH(7, k_path_interact, dim3(g0), dim3(kBlock), 0, st_, a, ps, in, first, round);
-                HP_LAUNCH(8, k_path_edges, dim3(gh), dim3(64), 0, st_, a, ps);
-                HP_LAUNCH(9, k_path_interact_b, dim3(std::max<uint32_t>(1u, g0 / 2u)), dim3(kBlock), 0, st_, a, ps, in, round);
-                HP_LAUNCH(10, k_path_nee, dim3(gh), dim3(64), 0, st_, a, ps, round);
-                rec();
-                rec();
-                rec();
-                rec();
-                continue;
-            }
-            HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
-            rec();
-            HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
-            HP_LAUNCH(13, k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
-            rec();
-            HP_LAUNCH(14, k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
-            HP_LAUNCH(15, k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
-            rec();
-            HP_LAUNCH(16, k_interact_c, dim3(std::max<uint32_t>(1u, gh / grid_div_c)), dim3(64), 0, st_, a, in);
-            HP_LAUNCH(17, k_interact_c_hard, dim3(std::max<uint32_t>(1u, gh / K.grid_div_hard)), dim3(WTGPU_HARD_BLOCK), 0, st_, a, in);
-            rec();
-        }
-        if (path_mode) {
-            HP_LAUNCH(18, k_path_flush, dim3(kFlushGrid), dim3(kBlock), 0, st_, a, (int)(kMaxWalkIters & 1u));
-        } else {
-            HP_LAUNCH(19, k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
-            HP_LAUNCH(20, k_connect_scan, dim3(1), dim3(64), 0, st_, a);
-            HP_LAUNCH(21, k_connect_strat, dim3(g_full), dim3(kBlock), 0, st_, a);
-            if ((uint32_t)h.opts.max_depth + 2 >= kKeyDim - 1) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, g_full / 8u)), dim3(kBlock), 0, st_, a);
-            HP_LAUNCH(23, k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
-        }
+        const uint32_t r1 = expected_rounds(s);
+        L.generate(a, r, st_);
+        rc = L.rounds(a, s->d_path_slices[k], r, st_, 0, r1);
+        if (rc) return rc;
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-        HIP_CHECK(hipEventRecord(r.ev[tm ? ev : 0], st_));
-        if (ev_fail) return fail(WTGPU_ERR_HIP, "hipEventRecord failed");
-        r.busy = true;
+        if (r1 < kMaxWalkIters) {
+            HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+            HIP_CHECK(hipEventRecord(r.ev_mid, st_));
+        }
+        wtgpu_scene::pending_t& p = s->pending[k];
+        std::memcpy(p.args, &a, sizeof(a));
+        p.rec = &r;
+        p.rounds_first = r1;
+        p.active = true;
+        if (r1 >= kMaxWalkIters) {   // nothing to wait for: the whole batch goes out at once, as before round 4
+            rc = render_finish_part(s, k, L);
+            if (rc) return rc;
+        }
     }
-    if (hp_on) {
-        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","(unused)","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
-        for (int i = 0; i < 24; ++i)
-            if (hp_n[i]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", hp_names[i], hp_n[i], hp_t[i], hp_t[i] / hp_n[i]);
-        if (hp_n[31]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", "hipEventRecord", hp_n[31], hp_t[31], hp_t[31] / hp_n[31]);
-    }
-#undef HP_LAUNCH
-    // (wtgpu_join makes the caller's stream continue after all of them)
+    L.report();
+    // (wtgpu_join enqueues what is pending and makes the caller's stream continue after all of it)
     s->samples_rendered += total;
     return WTGPU_OK;
 }
@@ -2330,7 +2477,7 @@ int wtgpu_last_render_timings(wtgpu_scene* s, float out[12]) {
     const int rc = drain_all(s);
     if (rc) return rc;
     for (int i = 0; i < 12; ++i) out[i] = (float)s->acc[i];
-    out[11] = (float)kMaxWalkIters;   // rounds launched per batch
+    out[11] = s->acc[6] > 0 ? (float)((double)s->rounds_launched_total / s->acc[6]) : (float)kMaxWalkIters;   // rounds launched per batch (mean)
     return WTGPU_OK;
 }
 
@@ -2423,6 +2570,7 @@ int wtgpu_reset_counters(wtgpu_scene* s) {
     s->samples_rendered = 0;
     s->cap_hits = 0;
     for (double& v : s->acc) v = 0;
+    s->rounds_launched_total = 0;
     return WTGPU_OK;
 }
 
@@ -2498,9 +2646,12 @@ static void release_device(wtgpu_scene* s) {
         for (auto& e : r.ev)
             if (e) (void)hipEventDestroy(e);
         if (r.h_ctl) (void)hipHostFree(r.h_ctl);
+        if (r.h_mid) (void)hipHostFree(r.h_mid);
+        if (r.ev_mid) (void)hipEventDestroy(r.ev_mid);
         if (r.ev_stagger) (void)hipEventDestroy(r.ev_stagger);
     }
     s->recs.clear();
+    s->pending.clear();
     for (auto& e : s->ev_done)
         if (e) (void)hipEventDestroy(e);
     s->ev_done.clear();
