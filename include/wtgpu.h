@@ -112,15 +112,21 @@ int wtgpu_scene_upload(wtgpu_scene* scene, int device, uint64_t max_batch_sample
 /* Renders sample indices [sample_begin, sample_end) of every sensor element (the `spp` loop of
  * integrator_t::integrate for all pixels) and accumulates into the caller-owned DEVICE film buffers
  *     d_value  [height][width][channels][stokes] f64,  d_weight [height][width] f64,  d_light [height][width][channels][stokes] f64.
- * `stream` is a hipStream_t (NULL = default stream).  The call only ENQUEUES work (internal streams that start after
- * everything already on `stream`; `stream` continues after them): synchronise `stream` before reading the films.  RNG: Philox-4x32-10 keyed by `seed`, counter = (pixel, sample, stream). */
+ * `stream` is a hipStream_t (NULL = default stream).  The work runs on internal streams that start after everything already on
+ * `stream`, and `stream` continues after them: synchronise `stream` before reading the films.  (The call returns once the LAST part of
+ * the work is enqueued; since round 4 a batch of samples is enqueued in two parts with a look at its round queue in between, so the
+ * calling thread waits for most of the work to have run — see wtgpu_join.)  RNG: Philox-4x32-10 keyed by `seed`, counter = (pixel, sample, stream). */
 int wtgpu_render(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin, uint64_t sample_end,
                  uint64_t seed);
 
 /* The two halves of wtgpu_render.  wtgpu_render_async enqueues the work behind everything already on `stream` but does not make
  * `stream` wait for it, so consecutive calls (more samples into the same accumulators) pipeline on the GPU; wtgpu_join makes
  * `stream` continue after everything enqueued so far.  Nothing may read or overwrite the films between an async render and its
- * join. */
+ * join.  A batch is enqueued in two parts: generation and the rounds its walks are expected to need, and — after the host has seen
+ * its round queue empty (looking again every 8 rounds otherwise) — the connections.  wtgpu_render_async enqueues the first part of
+ * its batches (and the second part of whichever earlier batch still holds the state slice it reuses: it may wait for that one);
+ * wtgpu_join WAITS on the host for the first parts of the batches still pending, enqueues their second parts, and makes `stream`
+ * continue after them. */
 int wtgpu_render_async(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin,
                        uint64_t sample_end, uint64_t seed);
 int wtgpu_join(wtgpu_scene* scene, void* stream);
