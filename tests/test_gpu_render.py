@@ -174,6 +174,26 @@ def test_async_renders_pipeline_and_join(built):
         assert np.allclose(a.cpu().numpy(), b, rtol=1e-9, atol=1e-30)
 
 
+def test_tiled_film_splat_equals_the_per_sample_splat(built, monkeypatch):
+    """k_connect_splat_tiled (one block per 128-element row segment, footprints accumulated in an LDS tile, one global add per tile entry) against
+    the per-sample splat kernel (WTGPU_TILED_SPLAT=0): the same films up to the order of the f64 sums — intensity and Stokes films, widths that
+    are not multiples of the block, several samples per element and batch, batches that start in the middle of the film."""
+    import torch
+    from wave_tracer_amd import Scene, render
+    for name, kw, batch in (("cornell_box", dict(res=150, mesh_detail=0), 0), ("bidir_room", dict(res=136, mesh_detail=0, polarimetric=1), 0),
+                            ("furnace", dict(res=40, lut=(32, 32)), 1000)):
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("WTGPU_TILED_SPLAT", mode)
+            sc = Scene(name, **kw)
+            sc.upload(0, batch if batch else 3 * sc.width * sc.height)
+            out[mode] = render(sc, 5, seed=31)
+            sc.close()
+        assert out["0"][0].sum() > 0 and out["0"][1].sum() > 0
+        for a, b in zip(out["0"], out["1"]):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-30), name
+
+
 def test_batches_enqueued_in_two_parts_render_the_same(built, monkeypatch):
     """A batch is enqueued in two parts (wtgpu.hip: batch_launcher_t): the rounds its walks are expected to need, and — once the host has seen
     the round queue empty, or has launched ALL the remaining rounds — the connections.  Whatever the expectation, the film is the one a blind

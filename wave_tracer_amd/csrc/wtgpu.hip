@@ -220,7 +220,7 @@ struct wtgpu_scene {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
-        uint32_t first_rounds = 0, rounds_margin = 2;   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
+        uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
 };
@@ -1527,6 +1527,84 @@ __global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
     film_splat(a.sc, a.film, ctx.element, L, ctx.k);
 }
 
+// The same splat for batches that cover (most of) the film: one block per 128-element row segment accumulates the footprints of its
+// elements' samples in an LDS tile (3 rows x 130 columns x (planes + 1) f64, plane-major) and adds the tile to the film once.  Per sample the
+// plain kernel issues 9 x (planes + 1) f64 atomics on addresses its neighbours in the wavefront hit too — 117 for the Stokes film of the
+// polarimetric workload, where it took 19.7 ms of a 204-ms batch (run r4t) — the tile turns them into LDS atomics and one global add per tile
+// entry.  Same weights, same products, f64 sums in another order.  Reconstruction-filter radius <= 1 (the host launches the plain kernel
+// otherwise); a sample whose element is not where the block expects it (never, for the sensors built so far) goes to the film directly.
+constexpr uint32_t kSplatCols = kBlock + 2;
+__global__ void __launch_bounds__(kBlock) k_connect_splat_tiled(launch_args_t a) {
+    extern __shared__ double tile[];   // [planes + 1][3][kSplatCols]
+    const sensor_t& sn = a.sc.sensor;
+    const uint32_t W = a.film.width, H = a.film.height;
+    const uint32_t S = film_stokes(sn), P = sn.channels * S, PL = P + 1;
+    const uint32_t bpr = (W + kBlock - 1) / kBlock;
+    const uint32_t row = blockIdx.x / bpr, x0 = (blockIdx.x % bpr) * kBlock;
+    const int r = sn.rf_radius;
+    const uint32_t n_px = 3 * kSplatCols;
+    for (uint32_t q = threadIdx.x; q < n_px * PL; q += kBlock) tile[q] = 0.0;
+    __syncthreads();
+    const uint32_t x = x0 + threadIdx.x;
+    if (x < W && row < H) {
+        const uint64_t p = (uint64_t)row * W + x;
+        // the samples of this batch that belong to element p: work items i with (j0 + i) % npix == p
+        const uint64_t first = (p + a.npix - (a.j0 % a.npix)) % a.npix;
+        for (uint64_t i = first; i < a.nb; i += a.npix) {
+            sample_ctx_t ctx;
+            soa_load(a.st.ctx, kCtxWords, i, ctx);
+            stokes_t L;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) L.s[c] = (float)a.st.lacc[(size_t)c * a.st.cap + i];
+            // (what follows is film_splat, wt/film.h, with the tile in place of the film)
+            const rfilter_weights_t rw = film_rfilter_weights(sn, ctx.element.offset);
+            float val[16];
+            for (uint32_t c = 0; c < sn.channels; ++c) {
+                const float f = spectrum_f(a.sc, sn.response_spec[c], ctx.k);
+                bool ok = true;
+                for (uint32_t q = 0; q < S; ++q) {
+                    val[c * S + q] = L.s[q] * f;
+                    ok = ok && finitef(val[c * S + q]);
+                }
+                ok = ok && val[c * S] >= 0.f;
+                if (!ok)
+                    for (uint32_t q = 0; q < S; ++q) val[c * S + q] = 0.f;
+            }
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = (int)ctx.element.y + dy;
+                if (y < 0 || y >= (int)H) continue;
+                for (int dx = -r; dx <= r; ++dx) {
+                    const int xx = (int)ctx.element.x + dx;
+                    if (xx < 0 || xx >= (int)W) continue;
+                    const float w = fmaxf_(0.f, rw.wx[dx + r] * rw.wy[dy + r]) * rw.recp_total;
+                    const int ty = y - ((int)row - 1), tx = xx - ((int)x0 - 1);
+                    if (ty >= 0 && ty < 3 && tx >= 0 && tx < (int)kSplatCols) {
+                        const uint32_t q = (uint32_t)ty * kSplatCols + (uint32_t)tx;
+                        unsafeAtomicAdd(&tile[q], (double)w);
+                        for (uint32_t c = 0; c < P; ++c) unsafeAtomicAdd(&tile[(size_t)(1 + c) * n_px + q], (double)(w * val[c]));
+                    } else {
+                        const size_t pix = (size_t)y * W + xx;
+                        film_add(&a.film.weight[pix], (double)w);
+                        for (uint32_t c = 0; c < P; ++c) film_add(&a.film.value[pix * P + c], (double)(w * val[c]));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < n_px; q += kBlock) {
+        const int y = (int)row - 1 + (int)(q / kSplatCols), xx = (int)x0 - 1 + (int)(q % kSplatCols);
+        if (y < 0 || y >= (int)H || xx < 0 || xx >= (int)W) continue;
+        const size_t pix = (size_t)y * W + xx;
+        const double wsum = tile[q];
+        if (wsum != 0.0) film_add(&a.film.weight[pix], wsum);
+        for (uint32_t c = 0; c < P; ++c) {
+            const double v = tile[(size_t)(1 + c) * n_px + q];
+            if (v != 0.0) film_add(&a.film.value[pix * P + c], v);
+        }
+    }
+}
+
 // ---- PMC calibration: a streaming copy with the access width of the SoA state (one dword per lane, fully coalesced) and a known
 // byte count, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled to bytes for THIS access pattern (tools/profile_round.sh)
 __global__ void __launch_bounds__(256) k_calib_copy(const uint32_t* in, uint32_t* out, size_t n) {
@@ -1935,6 +2013,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.shrink_r1 = u("WTGPU_SHRINK_R1", k.shrink_r1);
     k.first_rounds = std::min<uint32_t>(u("WTGPU_FIRST_ROUNDS", k.first_rounds), kMaxWalkIters);
     k.rounds_margin = u("WTGPU_ROUNDS_MARGIN", k.rounds_margin);
+    k.tiled_splat = u("WTGPU_TILED_SPLAT", k.tiled_splat);
     k.shrink_f1 = std::max(1u, u("WTGPU_SHRINK_F1", k.shrink_f1));
     k.shrink_r2 = u("WTGPU_SHRINK_R2", k.shrink_r2);
     k.shrink_f2 = std::max(1u, u("WTGPU_SHRINK_F2", k.shrink_f2));
@@ -2279,7 +2358,12 @@ struct batch_launcher_t {
             HP_LAUNCH(20, k_connect_scan, dim3(1), dim3(64), 0, st_, a);
             HP_LAUNCH(21, k_connect_strat, dim3(gf), dim3(kBlock), 0, st_, a);
             if ((uint32_t)s->host.opts.max_depth + 2 >= kKeyDim - 1) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
-            HP_LAUNCH(23, k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
+            // (the tiled splat pays off when the batch holds most of the film's elements: it visits every row segment of the film)
+            const uint32_t fw = a.film.width, fh = a.film.height, planes = film_planes(s->host.sensor);
+            if (K.tiled_splat && s->host.sensor.rf_radius <= 1 && planes <= 16 && (uint64_t)nb * 2u >= (uint64_t)a.npix)
+                HP_LAUNCH(23, k_connect_splat_tiled, dim3(fh * ((fw + kBlock - 1) / kBlock)), dim3(kBlock), 3 * kSplatCols * (planes + 1) * sizeof(double), st_, a);
+            else
+                HP_LAUNCH(23, k_connect_splat, dim3((nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(r.h_ctl, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
