@@ -219,7 +219,7 @@ struct wtgpu_scene {
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
-        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 2, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
+        uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 1, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -2028,7 +2028,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.heavy_waves_per_cu = std::max(1u, u("WTGPU_HEAVY_WAVES", 8));   // swept 6 / 8 / 10 / 12 / 16 / 24 / 32: 169.6 / 168.0 / 171.6 / 174.3 / 176 / 181 / 183 ms per pass
     k.round_blocks_per_cu = std::max(1u, u("WTGPU_ROUND_BLOCKS", 8));
     k.grid_div_b = std::max(1u, u("WTGPU_GRID_B", 4));
-    k.grid_div_c = std::max(1u, u("WTGPU_GRID_C", 2));
+    k.grid_div_c = std::max(1u, u("WTGPU_GRID_C", 1));   // (2 until round 4; 1: bidir_room 33.6 -> 33.9, cornell 25.15 -> 25.35 Msamples/s, pass C's bracket 69 -> 56 / 93 -> 65 ms)
     k.grid_div_hard = std::max(1u, u("WTGPU_GRID_HARD", 4));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
