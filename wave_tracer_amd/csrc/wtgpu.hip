@@ -817,15 +817,27 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_INTC_COUNT];
-    const size_t W2 = 2 * (size_t)a.st.cap;
+    const int lane = threadIdx.x & 63;
+    // 64 queue items per grab: every lane looks at one walk's marker (most pass-C walks have a region that fitted its list and need no
+    // split — bidir_room: 400,000 items a round, a few thousand to split; one item per grab was 11.5 ms of a 125-ms batch there), the
+    // wavefront then cuts the regions of the flagged ones, one after the other
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSPLIT_HEAD, 1u);
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSPLIT_HEAD, 64u);
         __syncthreads();
-        const uint32_t item = s_item;
+        const uint32_t base = s_item;
         __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = a.st.intc_queue[item];
-        if (is_region_marker(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)])) {   // block-uniform
+        if (base >= n) break;
+        uint32_t w_mine = 0;
+        bool need = false;
+        if (base + (uint32_t)lane < n) {
+            w_mine = a.st.intc_queue[base + lane];
+            need = is_region_marker(a.st.trav[(size_t)w_mine * kTravWords + WT_TRAV_WORD(tuid)]);
+        }
+        unsigned long long m = __ballot(need);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t w = (uint32_t)__shfl((int)w_mine, src, 64);   // block-uniform
             const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
             const cone_t tcone = walk_trace_envelope(a.sc, wk);
             const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
@@ -838,6 +850,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
                 else
                     atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_pool_overflow) / sizeof(unsigned long long), 1ull);   // reported; cannot happen below 4M tasks per batch
             });
+            __syncthreads();
         }
     }
 }
