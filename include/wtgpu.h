@@ -83,8 +83,8 @@ int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_
 
 /* Reader of the reference's XML scene format (src/scene/loader/*.cpp): 13 of the 15 scene files the reference ships load
  * as they are (tests/test_xml_scene.py::test_which_of_the_shipped_scene_files_load) — <default> defines and "$name" substitution, expressions
- * with units, <include>, enabled=..., shared elements and <ref>s (bsdfs, textures, spectra, transforms); plt_bdpt / plt_path integrators;
- * perspective and virtual-plane sensors with array films (RGB / monochromatic response, polarimetric flag); spot, directional, point and area
+ * with units, <include>, enabled=..., shared elements and <ref>s (bsdfs, textures, spectra, transforms); plt_bdpt / plt_path integrators; <sampler> of type
+ * independent / uniform / sobolld (all served by the library's counter-based streams); perspective and virtual-plane sensors with array films (RGB / monochromatic response, polarimetric flag); spot, directional, point and area
  * emitters; diffuse, dielectric, surface_spm (dirac / fractal / gaussian profile, constant or textured roughness), twosided, scale (constant,
  * spectrum, texture), mask, normalmap and composite BSDFs; constant, checkerboard, bitmap (PNG, PFM), scale, transform, function and mix
  * textures; spectra by constant, rgb, blackbody, discrete, piecewise linear, ITU material, or material / emitter name (baked tables or the

@@ -1215,6 +1215,22 @@ struct loader_t {
         b.set_integrator(o);
         if (prm.lut_m) b.set_fsd_lut_resolution(prm.lut_n_theta, prm.lut_m);
 
+        // ---- <sampler> (src/scene/loader/loader.cpp:192-199, src/sampler/sampler_loader.cpp:24-33): optional, at most one, of type independent /
+        // uniform / sobolld.  Every type is served by the library's counter-based streams (Philox-4x32-10 keyed by seed, pixel, sample, stream:
+        // DESIGN.md section 5) — sample sequences are not the reference's for any of them, `sobolld`'s low-discrepancy points included.
+        {
+            const xnode_t* smp = nullptr;
+            for (auto& n : items)
+                if (n.name == "sampler" && enabled(n)) {
+                    if (smp) throw std::runtime_error("only one sampler must be provided");
+                    smp = &n;
+                }
+            if (smp) {
+                const std::string t = smp->get("type");
+                if (t != "independent" && t != "uniform" && t != "sobolld") throw std::runtime_error("sampler type \"" + t + "\" is not recognised");
+            }
+        }
+
         // ---- the enabled sensor (exactly one: one wtgpu_scene renders one film)
         const xnode_t* sensor = nullptr;
         for (auto& n : items)
