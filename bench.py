@@ -120,8 +120,9 @@ def main():
     ap.add_argument("--scene", default="cornell_box")
     ap.add_argument("--res", type=int, default=1440)
     ap.add_argument("--batch", type=int, default=0, help="samples per kernel batch (0: one full step)")
-    ap.add_argument("--batch-target", type=int, default=4200000, help="default step size: as many samples per element as bring one step (= one batch) to about "
-                    "this many samples (every batch runs its rounds down to a thin tail, so the tails cost per BATCH: DESIGN.md §0)")
+    ap.add_argument("--batch-target", type=int, default=0, help="default step size: as many samples per element as bring one step (= one batch) to about "
+                    "this many samples (every batch runs its rounds down to a thin tail, so the tails cost per BATCH: DESIGN.md §0).  0: 4.2 M for plt_bdpt "
+                    "scenes (three slices of that are 186 GB), 9 M for plt_path scenes (no vertex stores: 2 KB of state per sample)")
     ap.add_argument("--mesh-detail", type=int, default=-1, help="stand-in geometry level (default: 1 for the cornell box = SURVEY 8(d) C1/C3's 283 K triangles; 2 for "
                     "etoile / bidir_room = C4's ~560 seeded buildings, C5's ~50 objects and 34 materials)")
     ap.add_argument("--polarimetric", type=int, default=-1, help="Stokes film (default: on for bidir_room = BASELINE.json configs[4])")
@@ -184,8 +185,10 @@ def main():
     K, Wm = args.steps, args.warmup
     # one step = S samples per element over the whole job.  weak: every rank renders its own S per step (work per GPU fixed); strong:
     # the ranks split the S samples of a step (total work fixed).  Sample indices are disjoint across ranks and steps.
-    # default: whole passes that fill one batch (round 4: 1440^2 -> 2 spp per step, 720x540 -> 11); strong scaling: a multiple of the ranks
-    S_auto = max(1, min(16, round(args.batch_target / npix)))
+    # default: whole passes that fill one batch (round 4: cornell 1440^2 -> 2 spp per step, etoile 720x540 -> 23); strong scaling: a multiple of the ranks
+    batch_target = args.batch_target or (9000000 if int(sc.info.integrator) != 0 else 4200000)   # (measured, run r4z: etoile 720x540 at 4.3 / 6.2 / 9.3 / 12.4 M
+    # samples per batch 59.1 / 62.8 / 66.9 / 62.9 Msamples/s, 1440x1080 at 4.7 / 7.8 / 12.4 M 60.7 / 64.6 / 62.6; cornell at 6.2 M 24.7 vs 25.7 at 4.15 M)
+    S_auto = max(1, min(32, round(batch_target / npix)))
     S = args.spp_per_step or (world * max(1, S_auto // world) if args.scaling == "strong" else S_auto)
     if args.scaling == "strong":
         assert S % world == 0, "--spp-per-step must be a multiple of the number of ranks for strong scaling"
