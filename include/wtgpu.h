@@ -81,7 +81,7 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
  * port of the reference's own loader calls. */
 int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_scene** out);
 
-/* Reader of the reference's XML scene format (src/scene/loader/*.cpp): 13 of the 15 scene files the reference ships load
+/* Reader of the reference's XML scene format (src/scene/loader/*.cpp): 14 of the 15 scene files the reference ships load
  * as they are (tests/test_xml_scene.py::test_which_of_the_shipped_scene_files_load) — <default> defines and "$name" substitution, expressions
  * with units, <include>, enabled=..., shared elements and <ref>s (bsdfs, textures, spectra, transforms); plt_bdpt / plt_path integrators; <sampler> of type
  * independent / uniform / sobolld (all served by the library's counter-based streams); perspective and virtual-plane sensors with array films (RGB / monochromatic response, polarimetric flag); spot, directional, point and area

@@ -465,10 +465,11 @@ FTEX = os.path.join(HERE, "data", "xml", "function_textures.xml")
 
 @needs_reference
 def test_which_of_the_shipped_scene_files_load(built):
-    """Every scene file the reference ships (scenes/*/*.xml), read in place with the Git-LFS assets skipped (-Dwtgpu_missing_assets=skip): 13 of
+    """Every scene file the reference ships (scenes/*/*.xml), read in place with the Git-LFS assets skipped (-Dwtgpu_missing_assets=skip): 14 of
     the 15 load completely since round 4 (function / mix textures, textured roughness, shared transforms and named <ref>s: box_empty.xml and
-    objects.xml joined).  The other two say why: sponza_night.xml needs a textured area-emitter radiance (src/emitter/area.cpp:153-260: per-triangle
-    barycentric sampling tables — not built), colourchecker.xml's only light sits on a mesh that is a Git-LFS pointer."""
+    objects.xml joined; sponza_night.xml: its emitter's radiance texture is an image absent from the checkout, whose mid-grey stand-in makes
+    it a uniform emitter — a spatially varying radiance texture, src/emitter/area.cpp:153-260, is still not built).  The last one says why:
+    colourchecker.xml's only light sits on a mesh that is a Git-LFS pointer."""
     import glob
     from wave_tracer_amd import Scene
     from wave_tracer_amd.api import WtgpuError
@@ -482,8 +483,42 @@ def test_which_of_the_shipped_scene_files_load(built):
             loaded.append(name)
         except WtgpuError as e:
             failed[name] = str(e)
-    assert len(loaded) == 13 and set(failed) == {"sponza/sponza_night.xml", "colourchecker/colourchecker.xml"}, (loaded, failed)
-    assert "radiance" in failed["sponza/sponza_night.xml"] and "no emitters" in failed["colourchecker/colourchecker.xml"]
+    assert len(loaded) == 14 and set(failed) == {"colourchecker/colourchecker.xml"}, (loaded, failed)
+    assert "no emitters" in failed["colourchecker/colourchecker.xml"]
+
+
+def test_constant_radiance_textures_on_area_emitters(built, tmp_path):
+    """<texture name="radiance"> on an area emitter (area.hpp:103-116: radiance->f({uv, k}).x times the emitter's own `scale`): a texture that is
+    the same everywhere makes the uniform emitter with the colour's uplifted spectrum — the film of the rgb= spectrum twin, bit for bit, also
+    through a `scale` wrapper; a spatially varying one is refused with the reason."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    xml = """<scene version="0.1.0">
+  <integrator type="plt_bdpt"><integer name="max_depth" value="6"/><boolean name="FSD" value="false"/></integrator>
+  <sensor type="perspective"><quantity name="fov" value="60°"/>
+    <transform name="to_world"><lookat origin="0m, 0m, .9m" target="0m, 0m, 0m" up="0, 1, 0"/></transform>
+    <film type="array"><integer name="width" value="24"/><integer name="height" value="24"/>
+      <response type="RGB"><string name="white_point" value="E"/></response></film></sensor>
+  <bsdf type="twosided" id="grey"><bsdf type="diffuse"><spectrum name="reflectance" constant=".5"/></bsdf></bsdf>
+  <shape type="cube"><quantity name="length" value="2m"/><ref id="grey"/></shape>
+  <shape type="rectangle"><point name="p" x="-.25m" y=".95m" z="-.25m"/><point name="x" x="0m" y="0m" z=".5m"/><point name="y" x=".5m" y="0m" z="0m"/>
+    <bsdf type="diffuse"><spectrum name="reflectance" constant="0"/></bsdf>
+    <emitter type="area">$radiance</emitter></shape>
+</scene>"""
+
+    def scene(radiance, tag):
+        f = tmp_path / f"{tag}.xml"
+        f.write_text(xml.replace("$radiance", radiance))
+        return Scene.from_xml(str(f))
+    ref, cref = _render_dev(scene('<spectrum name="radiance" rgb=".5, .5, .5"><float name="scale" value="3"/></spectrum>', "rgb"))
+    assert ref.sum() > 0
+    img, c = _render_dev(scene('<texture name="radiance" type="constant"><spectrum constant=".5"/></texture><float name="scale" value="3"/>', "const"))
+    assert np.array_equal(img, ref) and c == cref
+    img, c = _render_dev(scene('<texture name="radiance" type="scale"><spectrum name="scale" constant=".25"/><texture type="constant"><spectrum constant="2"/></texture>'
+                               '</texture><float name="scale" value="3"/>', "scaled"))
+    assert np.array_equal(img, ref) and c == cref
+    with pytest.raises(WtgpuError, match="spatially varying radiance"):
+        scene('<texture name="radiance" type="checkerboard"/><float name="scale" value="3"/>', "checker")
 
 
 def test_function_and_mix_textures_and_textured_roughness(built):

@@ -97,6 +97,13 @@ public:
     void texture_set_transform(int tex, const float M[4], const float t[2]);   // uv' = M uv + t (texture/transform.hpp)
     void texture_set_scale(int tex, float scale);                               // texture/scale.hpp with a constant scale
     float texture_scale(int tex) const { return textures_.at(tex).scale; }
+    // TRUE (and its colour, scale included) if the texture is the same everywhere: a constant, whatever its transform
+    bool texture_constant_rgb(int tex, float rgb[3]) const {
+        const wt::texture_t& t = textures_.at(tex);
+        if (t.type != wt::TEX_CONSTANT) return false;
+        for (int c = 0; c < 3; ++c) rgb[c] = t.rgba[c] * t.scale;
+        return true;
+    }
     // wraps `tex` in another transform texture: uv' = M_tex (M uv + t) + t_tex
     void texture_compose_transform(int tex, const float M[4], const float t[2]);
     wt::material_t& material(int id) { return materials_[id]; }

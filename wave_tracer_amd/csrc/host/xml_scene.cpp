@@ -23,7 +23,7 @@
 //     texture (constant, checkerboard, scale, transform, bitmap from PNG / PFM with filter, wrap modes and colour encoding);
 //     shape (rectangle, cube, sphere, cylinder, prism, lens, ply / obj: host/ply_loader.cpp, host/obj_loader.cpp) with general to_world
 //     transforms (matrix / rotate / scale / translate / lookat).
-//   Not handled: function textures, textured roughness / emitter radiance, sensor masks.
+//   Not handled: spatially varying emitter radiance textures (constant ones are), sensor masks.
 // Spectral resolution at bake time (as in host/scenes.cpp): composite BSDFs / spectra take the bin that contains the sensor's
 // sensitivity range; an emitter whose spectrum has no line-for-line overlap with the sensor's (a continuous spectrum against a
 // monochromatic sensor: the reference integrates it over a 2e-6 relative band, scene_build_sensor_sampling_data.cpp:55-60, ~1e-9
@@ -1476,9 +1476,23 @@ struct loader_t {
                     const xnode_t* sp = em->named("radiance");
                     if (!sp) throw std::runtime_error("area emitter: radiance expected");
                     double scale = 1.0;
-                    if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
-                    const xnode_t unscaled = without_scale(*sp);
-                                        const int spec = spectrum(unscaled, true);
+                    int spec = -2;
+                    if (sp->name == "texture" || (sp->name == "ref" && deref(sp)->name == "texture")) {
+                        // A radiance TEXTURE (area.hpp:103-116: radiance->f({uv, k}).x times the emitter's own `scale`; src/emitter/area.cpp:153-260: positions
+                        // drawn from per-triangle texel tables).  Served when the texture is the same everywhere — a constant, or the mid-grey that stands
+                        // in for an image missing from the checkout: then the emitter is a uniform one with the colour's uplifted spectrum (positions are
+                        // drawn uniformly over the shape, which is what the reference's tables reduce to).  Spatially varying radiance is not built.
+                        const int t = texture(*deref(sp));
+                        float rgb[3];
+                        if (!b.texture_constant_rgb(t, rgb))
+                            throw std::runtime_error("area emitter: a spatially varying radiance texture (per-triangle sampling tables, src/emitter/area.cpp:153-260) is not supported");
+                        if (const xnode_t* sc = em->named("scale")) scale = eval_number(sc->get("value"));
+                        spec = b.spectrum_rgb(rgb[0], rgb[1], rgb[2]);
+                    } else {
+                        if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
+                        const xnode_t unscaled = without_scale(*sp);
+                        spec = spectrum(unscaled, true);
+                    }
                     if (spec != -2) {
                         float pse = 1.f;
                         if (const xnode_t* r = em->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
