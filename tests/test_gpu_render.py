@@ -869,3 +869,26 @@ def test_full_size_bidir_room_1920_polarimetric(built):
     print("bidir_room 1920x1088 polarimetric: rel L1", rel, "frac_same", frac_same, "fsd", c["fsd_interactions"], "overflows",
           {k: c[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow")})
     assert rel < 2e-2 and frac_same > 0.99, (rel, frac_same)
+
+
+def test_c1_against_the_committed_cpu_record(built):
+    """BASELINE.json configs[0] (C1: cornell-box res 256, spp 64): the GPU render of the very samples of the CPU checker's committed record
+    (profiles/r04_cpu_c1_record.json, tools/cpu_c1_record.py: seed 1, samples [0, 64)) — film sums to 2e-3 (a few samples in 10^3 take another
+    discrete path on the GPU: DESIGN.md section 5), event statistics per sample to 0.5 %, weights to 1e-5."""
+    import json
+    import os
+    from wave_tracer_amd import Scene, render
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_cpu_c1_record.json")))
+    sc = Scene("cornell_box", res=256, mesh_detail=1)
+    sc.upload(0)
+    sc.reset_counters()
+    v, w, l = render(sc, 64, seed=1)
+    c = sc.counters()
+    n = sc.width * sc.height * 64
+    assert rec["samples"] == n == c["samples"]
+    fs = rec["film_sums"]
+    assert abs(w.sum() / fs["weight"] - 1) < 1e-5
+    assert abs(v.sum() / fs["value"] - 1) < 2e-3 and abs(l.sum() / fs["light"] - 1) < 2e-3, (v.sum() / fs["value"], l.sum() / fs["light"])
+    for k in ("segments", "vertices", "connections"):
+        assert abs(c[k] / n / rec["counters_per_sample"][k] - 1) < 5e-3, (k, c[k] / n, rec["counters_per_sample"][k])
+    assert c["walk_iteration_cap_hits"] == 0 and c["traversal_stack_dropped"] == 0
