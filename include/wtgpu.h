@@ -81,7 +81,7 @@ int wtgpu_scene_create_named(const char* name, const wtgpu_scene_params* params,
  * port of the reference's own loader calls. */
 int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_scene** out);
 
-/* Reader of the reference's XML scene format (src/scene/loader/*.cpp): 14 of the 15 scene files the reference ships load
+/* Reader of the reference's XML scene format (src/scene/loader/): 14 of the 15 scene files the reference ships load
  * as they are (tests/test_xml_scene.py::test_which_of_the_shipped_scene_files_load) — <default> defines and "$name" substitution, expressions
  * with units, <include>, enabled=..., shared elements and <ref>s (bsdfs, textures, spectra, transforms); plt_bdpt / plt_path integrators; <sampler> of type
  * independent / uniform / sobolld (all served by the library's counter-based streams); perspective and virtual-plane sensors with array films (RGB / monochromatic response, polarimetric flag); spot, directional, point and area
@@ -90,7 +90,8 @@ int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_
  * textures; spectra by constant, rgb, blackbody, discrete, piecewise linear, ITU material, or material / emitter name (baked tables or the
  * database files of data/ior, data/emission); rectangle, cube, sphere, cylinder, prism, lens shapes and PLY / OBJ meshes with general to_world
  * transforms (a Git-LFS pointer in place of an asset: a stand-in, or skipped with -Dwtgpu_missing_assets=skip).  Not read: textured area-emitter
- * radiance, bicubic filtering, JPEG / EXR images, OBJ material groups, the sobolld sampler.  `defines`: n_defines strings "name=value", the -D
+ * radiance, bicubic filtering, JPEG / EXR images, OBJ material groups; `sobolld`'s low-discrepancy point set itself is not reproduced (a scene that asks for it
+ * renders with the same counter-based streams as every other sampler type).  `defines`: n_defines strings "name=value", the -D
  * defines of the reference's command line (src/main.cpp:805-928).  params (may be NULL): res (becomes the define "res" unless given), max_depth /
  * fsd / mis / rr / force_ray_tracing overrides, lut_* resolution, polarimetric.  Anything outside that vocabulary fails with a message. */
 int wtgpu_scene_create_from_xml(const char* path, const char* const* defines, uint32_t n_defines, const wtgpu_scene_params* params, wtgpu_scene** out);

@@ -1,0 +1,383 @@
+// wave_tracer_amd — the traversal kernels: per-lane with lane refill (k_trace_refill), wave-cooperative (k_trace_heavy); per-query test kernels (see wtgpu_kernels.h for the list of kernel translation units).
+#include "wtgpu_kernels.h"
+
+namespace wtk {
+
+#ifndef WTGPU_LEAF_NUM
+#define WTGPU_LEAF_NUM 1   // leaf step when at least NUM / DEN of the running lanes hold a leaf (swept 1/3, 1/2, 2/3, 3/4: 99.0 / 97.6 / 96.6 / 97.9 ms per pass, noise 1 ms)
+#define WTGPU_LEAF_DEN 2
+#endif
+// The per-lane trace kernel, with LANE REFILL.
+// The cost of a walk's traversal varies by two orders of magnitude — one to seven cone queries of 2..cone_budget work units each —
+// and a wavefront whose lanes ran the policy and their queries back to back would be as slow as its slowest lane (rounds 1-2: that kernel
+// was kept as an A/B reference until round 4).  Here a lane is a slot that walks pass through.  The wavefront alternates between
+//   * the traversal loop: every lane that holds a node descends (cq_node_step), every lane that holds a leaf tests its triangles
+//     (cq_leaf_step) — the steps of wt/bvh.h, which the CPU checker drives one query at a time —
+//   * and the service section, entered once enough lanes wait: a lane whose query ended gets the policy's next query (aw_query_done /
+//     aw_next) or stores its record, and lanes without a walk fetch new ones from the queue (one atomic per wavefront), trace the beam
+//     axis and start their first query.
+// A slow query therefore occupies one lane, not 64, which is also what lets the work budget per query be larger (fewer walks
+// handed to the wave-cooperative kernel).  Per walk the sequence of visits and the results are those of wt::traverse_axis.
+//
+// (GUIDED FETCH — a wavefront holds at most ceil(walks left in the queue / wavefronts of the grid) walks, so that the end of a round is as long
+// as its longest single walk instead of a wavefront's 64 — was built and measured in round 4, dynamically and as a per-round target: the short
+// rounds of a one-stream pass went from 1.5 to 1.0 ms each, but a wavefront that fetches one walk at a time runs its fetch section — the axis
+// query — for one lane: the long rounds got 35 % slower, the pass 9 % (20.4 vs 22.4 Msamples/s).  With the per-round target: -4 % on the
+// headline workload (21.5 vs 22.5), +3..6 % on the 720 x 540 film, -3 % with two-pass batches.  Not kept: what the ends of the rounds cost is paid per BATCH,
+// and larger batches (bench.py: ~4 M samples) removed most of it: 720 x 540 18.8 -> 56 Msamples/s.)
+#ifndef WTGPU_REFILL_MIN
+#define WTGPU_REFILL_MIN 16
+#endif
+// the policy up to its next cone query (TRUE) or its end (FALSE: `r` is final); the tests of the remembered triangles run right here
+__device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, bool rt, const stack_ref_t& stack, axis_walk_t& aw, cone_query_t& q, trav_result_t& r) {
+    for (;;) {
+        const int need = aw_next(sc, env, rt, stack, aw, q, r);
+        if (need != AW_TEST) return need == AW_QUERY;
+        aw_test_done(aw, cone_attempt_too_short_by(sc, env, aw.cand, aw.sr, aw.min_df_prog));
+    }
+}
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = queue_count(ctl, in);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
+        ctl[CTL_BACK0 + (1 - in)] = 0;
+        ctl[CTL_HEAD_INTERACT] = 0;
+        ctl[CTL_INTB_COUNT] = 0;
+        ctl[CTL_INTB_HEAD] = 0;
+        ctl[CTL_GATHER_COUNT] = 0;
+        ctl[CTL_GATHER_HEAD] = 0;
+        ctl[CTL_INTC_COUNT] = 0;
+        ctl[CTL_INTC_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = 0;
+        ctl[CTL_FTASK_HEAD] = 0;
+        ctl[CTL_FSPLIT_HEAD] = 0;
+        ctl[CTL_EPOOL_COUNT] = 0;
+        ctl[CTL_INTD_COUNT] = 0;
+        ctl[CTL_INTD_HEAD] = 0;
+        // plt_path: this round's wedge pool and the queue it fills for the next round's k_path_fsd; this round's k_path_fsd / k_path_nee heads
+        ctl[CTL_UTD_COUNT0 + (round & 1u)] = 0;
+        ctl[CTL_FSDQ_COUNT0 + ((round + 1u) & 1u)] = 0;
+        ctl[CTL_FSDQ_HEAD] = 0;
+        ctl[CTL_NEEQ_COUNT] = 0;
+        ctl[CTL_NEEQ_HEAD] = 0;
+        if (n > 0) ctl[CTL_ROUNDS] = round + 1;
+    }
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // lane state: 0 = no walk, 1 = cone query running, 2 = cone query ended (to be served)
+    int st = 0;
+    uint32_t w = 0;
+    cone_t env;
+    axis_walk_t aw;
+    cone_query_t q;
+    uint_list_t tris{nullptr, 1u, 0u, nullptr};
+    memset(&env, 0, sizeof(env));
+    memset(&aw, 0, sizeof(aw));
+    memset(&q, 0, sizeof(q));
+    bool exhausted = false;   // wave-uniform: the queue holds no more walks
+#ifdef WTGPU_REFILL_PROF
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pl[6] = {0, 0, 0, 0, 0, 0};
+    long long pt;
+#define RP_BEGIN() pt = clock64()
+#define RP_END(i, mask) do { const long long d_ = clock64() - pt; pc[i] += (unsigned long long)d_; pl[i] += (unsigned long long)d_ * (unsigned long long)__popcll(mask); } while (0)
+#else
+#define RP_BEGIN()
+#define RP_END(i, mask)
+#endif
+    for (;;) {
+        // ---- service section
+        bool fin = false;
+        trav_result_t r;
+        RP_BEGIN();
+        const unsigned long long m_srv = __ballot(st == 2);
+        if (st == 2) {
+            cq_end(env, tris, q);
+            fin = aw_query_done(a.sc, env, aw, q.rec, r);
+            if (!fin) fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
+            st = fin ? 0 : 1;
+        }
+        RP_END(0, m_srv);
+        // (records of finished walks are stored below, together with those of freshly fetched walks that need no cone query)
+        uint32_t w_fin = w;
+        const int n_idle = __popcll(__ballot(st == 0 && !fin)), n_run = __popcll(__ballot(st == 1));
+        bool fetched = false;
+        const bool any_fin = __ballot(fin) != 0;   // (their records are stored first; they fetch in the next turn)
+        if (!exhausted && !any_fin && (n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
+            const unsigned long long im = __ballot(st == 0);
+            const bool take = st == 0;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(ctl + CTL_HEAD_TRACE, (uint32_t)__popcll(im));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
+            const uint32_t qi = base + (uint32_t)__popcll(im & below);
+            RP_BEGIN();
+            const unsigned long long m_f = __ballot(take && qi < n);
+            if (take && qi < n) {
+                w = queue_walk(a, ctl, in, qi, first_round);
+                w_fin = w;
+                const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
+                // plt_bdpt: the bounded list (64 triangles + their cone-hit distances) of the interaction region; see k_trace
+                uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
+                tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
+                env = walk_trace_envelope(a.sc, wk);
+                ray_hit_t ah;
+                // (The axis query in a kernel of its own was built twice: round 3 as a grid-stride kernel — 60 vs 56 ms per pass — and round 4 as a
+                // lane-refill kernel like this one (k_trace_axis: 111 registers, 4 waves per SIMD, 2.2 G rays/s in the long rounds: 3.9 ms where this
+                // section spends ~3): the two kernels together took 24.2 ms of the long rounds against 23.4 ms with the query in here, 22.4 vs 22.5
+                // Msamples/s — the fetch section's rays overlap other wavefronts' cone queries, which a separate kernel gives up.  Not kept.)
+                const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
+                aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
+                aw.use_cache = a.lane_cache;
+                fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
+                st = fin ? 0 : 1;
+            }
+            RP_END(1, m_f);
+            fetched = true;
+        }
+        // store the records of the walks that ended in this section (convergent: the queue append is a wave operation)
+        RP_BEGIN();
+        const unsigned long long m_st = __ballot(fin);
+        {
+            const bool heavy = fin && r.aborted == 1;
+            if (fin) {
+                if (heavy) {
+                    // resume state for k_trace_heavy (aw_query_done: dist / ntris = distance / segment of the query, the axis hit, the last
+                    // rejecting triangle in `overflow`)
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(dist)] = __float_as_uint(r.dist);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(ntris)] = r.ntris;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(n_ray_queries)] = r.n_ray_queries;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(n_cone_queries)] = r.n_cone_queries;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(tuid)] = r.tuid;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(bx)] = __float_as_uint(r.bx);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(by)] = __float_as_uint(r.by);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(pdist)] = __float_as_uint(r.pdist);
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(front_face)] = r.front_face;
+                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(overflow)] = r.overflow;
+                } else {
+                    soa_store(a.st.trav, kTravWords, w_fin, r);
+                    ctr.segments += 1;
+                    ctr.ray_queries += r.n_ray_queries;
+                    ctr.cone_queries += r.n_cone_queries;
+                    if (a.collect_list) ctr.cone_tri_overflow += r.overflow;
+                }
+            }
+            wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w_fin);
+        }
+        RP_END(2, m_st);
+        // walks that ended left their lanes free: fetch (more) before traversing
+        if (fetched || any_fin) continue;
+        const int running = __popcll(__ballot(st == 1));
+        if (running == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_REFILL_MIN) wait to be served
+        const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
+        for (;;) {
+            // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
+            for (;;) {
+                const bool at_node = st == 1 && q.leaf == 0 && q.s > 0;
+                const unsigned long long nm = __ballot(at_node);
+                if (!nm) break;
+                RP_BEGIN();
+                if (at_node) cq_node_step(a.sc, env, stack, q);
+                RP_END(3, nm);
+                if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && q.leaf != 0)) >= WTGPU_LEAF_NUM * running) break;
+            }
+            // (Deferring the exact cone-triangle tests of a leaf step — 3 % of its triangles, ~10x a filter test, 1-2 lanes busy — to a step of
+            // their own, taken once 4 / 8 / 16 lanes wait for one, was built and measured in round 4: 5 % SLOWER per pass.  The kernel is bound by
+            // dependent memory round trips, not by instruction issue, and the deferred test re-fetches its triangle: one more round trip per hit.)
+            RP_BEGIN();
+            const unsigned long long m_leaf = __ballot(st == 1 && q.leaf != 0);
+            if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
+            RP_END(4, m_leaf);
+            if (st == 1 && !cq_running(q)) st = 2;
+            const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
+            if (waiting >= leave_at || !__ballot(st == 1)) break;
+        }
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+#ifdef WTGPU_REFILL_PROF
+    if (lane == 0)
+        for (int i = 0; i < 6; ++i) {
+            atomicAdd(a.st.counters + kNumCounters + i, pc[i]);
+            atomicAdd(a.st.counters + kNumCounters + 8 + i, pl[i]);
+        }
+    // (the ray timer runs in the first fetching lane: add what other lanes hold)
+    if (lane != 0 && pc[5]) { atomicAdd(a.st.counters + kNumCounters + 5, pc[5]); atomicAdd(a.st.counters + kNumCounters + 8 + 5, pl[5]); }
+#endif
+}
+
+// Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
+__global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_t a) {
+    __shared__ coop_shared_t sh;
+    __shared__ uint32_t s_item;
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_HEAVY_COUNT];
+    const uint32_t* hq = a.st.heavy_queue;
+    uint32_t* head = ctl + CTL_HEAVY_HEAD;
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = hq[item];
+        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
+        const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};   // see k_trace
+        const cone_t env = walk_trace_envelope(a.sc, wk);
+        unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const long long tt0 = a.profile == 2 ? clock64() : 0;
+        const float dist0 = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const uint32_t seg0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)];
+        const uint32_t nray0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)], ncone0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)];
+        ray_hit_t axis;   // the closest hit of the beam axis, found by k_trace (traverse_axis, wt/bvh.h)
+        axis.tuid = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)];
+        axis.bx = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)]);
+        axis.by = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)]);
+        axis.dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(pdist)]);
+        axis.front_face = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)];
+        const uint32_t short0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(overflow)];
+        const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
+                                                &axis, !a.collect_list, a.heavy_probe != 0, a.heavy_cache ? short0 : kInvalid, a.heavy_cache ? wk.prev_offset_tuid : kInvalid, a.heavy_cache != 0);
+        if (a.profile == 2 && threadIdx.x == 0) {
+            prof[3] = (unsigned long long)(clock64() - tt0);
+            for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
+            atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
+            atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
+            atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
+            for (int q = 8; q < 12; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);   // (WTGPU_COOP_PROF: batch counts)
+            atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
+        }
+        if (threadIdx.x == 0) {
+            soa_store(a.st.trav, kTravWords, w, tr2);
+            ctr.segments += 1;
+            ctr.ray_queries += tr2.n_ray_queries;
+            ctr.cone_queries += tr2.n_cone_queries;
+            if (a.collect_list) ctr.cone_tri_overflow += tr2.overflow;
+        }
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
+// ---- PMC calibration: a streaming copy with the access width of the SoA state (one dword per lane, fully coalesced) and a known
+// byte count, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled to bytes for THIS access pattern (tools/profile_round.sh)
+__global__ void __launch_bounds__(256) k_calib_copy(const uint32_t* in, uint32_t* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i] + 1u;
+}
+
+// ---- per-query kernels (traversal parity tests) --------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_trace_rays(scene_t sc, const float* rays, uint32_t n, float* dist, uint32_t* tuid, float* bary, uint32_t* front) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const float* r = rays + 8 * (size_t)i;
+    ray_hit_t h;
+    ads_intersect_ray(sc, vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, range_t{r[6], r[7]}, stack, h);
+    dist[i] = h.dist;
+    tuid[i] = h.tuid;
+    bary[2 * i] = h.bx;
+    bary[2 * i + 1] = h.by;
+    front[i] = h.front_face;
+}
+__global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
+                                                           uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    // (the CPU checker's 128-entry stack: this kernel answers every query by itself — in the pipeline a lane whose 64-entry stack
+    // fills up hands the query to a wavefront, k_trace_heavy)
+    stack_entry_t spill[128 - kLdsStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    stack.cap = 128;
+    const float* c = cones + 10 * (size_t)i;
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    const uint_list_t tris{scratch_tris + i, n, kMaxConeTris, reinterpret_cast<float*>(scratch_tris + (size_t)n * kMaxConeTris) + i};
+    const trav_result_t tr = traverse(sc, env, c[9], WT_INF, false, stack, tris);
+    dist[i] = tr.dist;
+    flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
+    ntris[i] = tr.ballistic ? (tr.empty ? 0 : 1) : tr.ntris;
+    for (uint32_t j = 0; j < cap; ++j) out_tris[(size_t)i * cap + j] = kInvalid;
+    if (tr.ballistic) {
+        if (!tr.empty) out_tris[(size_t)i * cap] = tr.tuid;
+    } else {
+        // insertion sort of the (short) list into the output
+        uint32_t m = 0;
+        for (uint32_t j = 0; j < tr.ntris; ++j) {
+            const uint32_t v = tris[j];
+            uint32_t pos = m < cap ? m : cap;
+            while (pos > 0 && out_tris[(size_t)i * cap + pos - 1] > v) {
+                if (pos < cap) out_tris[(size_t)i * cap + pos] = out_tris[(size_t)i * cap + pos - 1];
+                --pos;
+            }
+            if (pos < cap) out_tris[(size_t)i * cap + pos] = v;
+            if (m < cap) ++m;
+        }
+    }
+}
+
+// Region summaries of cone queries of ANY size (parity tests of the whole-region machinery): one wavefront per cone runs the
+// traversal policy with closest-hit-only cone queries, then — for a diffusive hit — resolves the triangle under the axis and walks
+// the region [dist, dist + 2 x major axis] for its triangle count, sorted classified-edge set and intercepted power (sigma = axes/3).
+__global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* cones, uint32_t n, uint32_t edge_cap, float* dist, uint32_t* flags,
+                                                      uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux, unsigned long long* dropped) {
+    __shared__ coop_shared_t sh;
+    __shared__ coop_gather_shared_t gsh;
+    __shared__ coop_edges_t eg;
+    coop_set_dropped_counter(sh, dropped);
+    coop_set_dropped_counter(gsh, dropped);
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const float* c = cones + 10 * (size_t)i;
+    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+    const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+    const uint_list_t none{nullptr, 1u, 0u};
+    const trav_result_t tr = coop_traverse(sc, env, c[9], WT_INF, false, sh, none, nullptr, false, 0, 0.f, 0, 0, nullptr, true);
+    uint32_t prim = kInvalid;
+    gather_out_t ge{0.0, 0u, 0u, 0u}, gf{0.0, 0u, 0u, 0u};
+    if (tr.ballistic) {
+        prim = tr.tuid;
+    } else if (!tr.empty) {
+        const range_t izr{tr.dist, tr.dist + tr.region_depth};
+        prim = tr.tuid;   // primary_from_axis (kInvalid: the axis misses the region)
+        const vec2 ax = cone_axes(env, tr.dist);
+        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, gsh, false, true, nullptr, 1, &eg);
+        __syncthreads();
+        if (sc.n_edges <= kCoopEdgeBits) {
+            ge.n_edges = coop_edge_count(sc, eg);
+            coop_edge_write(sc, eg, edges + (size_t)i * edge_cap, edge_cap);
+        } else
+            for (uint32_t j = threadIdx.x; j < ge.n_edges && j < edge_cap; j += 64) edges[(size_t)i * edge_cap + j] = eg.edge_ids[j];
+        __syncthreads();
+        gf = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope}, tr.front_face != 0, gsh, true, false);
+    }
+    if (threadIdx.x == 0) {
+        dist[i] = tr.dist;
+        flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
+        primary[i] = prim;
+        ntris[i] = gf.n_tris;
+        nedges[i] = ge.n_edges + ge.edge_overflow;
+        flux[i] = (float)gf.flux;
+    }
+}
+
+}   // namespace wtk

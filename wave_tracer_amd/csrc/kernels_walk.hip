@@ -1,0 +1,208 @@
+// wave_tracer_amd — generation and the per-lane interaction passes A / B of plt_bdpt, the classified-edge gather (k_edges) (see wtgpu_kernels.h for the list of kernel translation units).
+#include "wtgpu_kernels.h"
+
+namespace wtk {
+
+__global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {
+        uint32_t* ctl = a.st.ctl;
+        ctl[CTL_COUNT0] = 2 * a.nb;
+        ctl[CTL_COUNT1] = 0;
+        ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
+        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
+        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
+        ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
+    }
+    if (i >= a.nb) return;
+    const uint64_t j = a.j0 + i;
+    const uint32_t pix = (uint32_t)(j % a.npix);
+    const uint64_t s = a.sample_begin + j / a.npix;
+    const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    sample_ctx_t ctx;
+    walk_t sw, ew;
+    const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
+    bdpt_generate(a.sc, a.seed, sample_id, pix % a.sc.sensor.width, pix / a.sc.sensor.width, ctx, sw, ew, svs, evs);
+    soa_store(a.st.ctx, kCtxWords, i, ctx);
+    soa_store(a.st.walks, a.st.walk_words, i, sw);
+    soa_store(a.st.walks, a.st.walk_words, (size_t)a.st.cap + i, ew);
+}
+
+// Interaction step of the queued walks.  PASS 0 (A): the queue of the round — surface interactions; walks whose beam axis misses
+// every triangle of the interaction region (8 % of them; what follows costs ~50x a surface interaction) are only appended to the
+// pass-B queue.  k_edges then gathers the classified-edge set of their regions.  PASS 1 (B): Fraunhofer aperture construction,
+// null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
+// No BVH query happens in these passes (the trace kernels resolved the primary triangle): they carry no traversal stack.
+template <int PASS>
+__device__ inline __attribute__((always_inline)) void interact_body(const launch_args_t& a, int in, int first_round) {
+    constexpr bool PASS_B = PASS == 1;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : queue_count(ctl, in);
+    if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
+        ctl[CTL_HEAVY_HEAD] = 0;
+        ctl[CTL_HEAD_TRACE] = 0;
+    }
+    bdpt_counters_t ctr;
+    memset(&ctr, 0, sizeof(ctr));
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
+    for (;;) {
+        const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
+        if (qi - (threadIdx.x & 63) >= n) break;
+        bool cont = false;
+        uint32_t w = 0;
+        fsd_defer_t defer;
+        defer.pending = defer.resolved = 0;
+        defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
+        defer.defer_sampling = PASS_B ? 1u : 0u;
+        defer.to_sampling_pass = 0;
+        defer.have_aperture = 0;
+        defer.split_no_primary = PASS_B ? 0u : 1u;
+        defer.known_no_primary = PASS_B ? 1u : 0u;
+        defer.no_primary = 0;
+        defer.has_gather = defer.gather_n_edges = defer.gather_edge_overflow = 0;
+        defer.gather_flux = 0.f;
+        defer.gather_edges = nullptr;
+        bool need_gather = false;
+        if (qi < n) {
+            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
+            uint32_t i, stream;
+            walk_ident(a, w, i, stream);
+            const uint64_t j = a.j0 + i;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t s = a.sample_begin + j / a.npix;
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+            walk_t wk;
+            soa_load(a.st.walks, a.st.walk_words, w, wk);
+            trav_result_t tr;
+            soa_load(a.st.trav, kTravWords, w, tr);
+            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
+            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
+            const bool queued_for_c = PASS_B && tr.tuid == kApertureMarker;   // k_edges built the aperture and queued the walk for pass C
+            if (PASS_B && tr.tuid == kNullApertureMarker) {   // k_edges built the aperture: no segments (the step restarts the beam)
+                defer.have_aperture = 1;
+                defer.slot = __float_as_uint(tr.by);
+            }
+            if (PASS_B && tr.tuid == kGatherMarker) {   // k_edges left the region's sorted classified-edge ids in the walk's list slot
+                defer.has_gather = 1;
+                defer.gather_n_edges = tr.n_ray_queries;
+                defer.gather_edge_overflow = tr.n_cone_queries;
+                const uint32_t off = __float_as_uint(tr.bx);   // offset into the round's edge pool
+                defer.gather_edges = a.st.epool + off;
+            }
+            const long long pb0 = PASS_B && a.profile == 3 ? clock64() : 0;
+            if (!queued_for_c) cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
+            if (PASS_B && defer.to_sampling_pass) a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = defer.slot;
+            if (PASS_B && a.profile == 3) {   // pass-B cost by the number of gathered scene edges
+                const int bin = defer.has_gather ? 32 - __clz((int)defer.gather_n_edges) : 0;   // 0: no gather / none
+                atomicAdd(a.st.counters + kNumCounters + 56 + bin, 1ull);
+                atomicAdd(a.st.counters + kNumCounters + 72 + bin, (unsigned long long)(clock64() - pb0));
+            }
+            // a region that did not fit the bounded list: its edge set comes from a walk of the whole region (k_edges)
+            // (... or whose list holds more than kMaxEdgeIds / 3 triangles: the per-lane edge set of pass B is bounded)
+            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list)) need_gather = true;
+            if (!defer.no_primary && !defer.to_sampling_pass && !queued_for_c) {
+                wk.active = cont ? 1u : 0u;
+                soa_store(a.st.walks, a.st.walk_words, w, wk);
+            }
+        }
+        if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
+        if (!PASS_B) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
+        if (PASS_B) wave_append(a.st.intc_queue, ctl + CTL_INTC_COUNT, defer.to_sampling_pass != 0, w);
+        queue_append(a, ctl, 1 - in, cont, w);
+    }
+    if (a.count_stats) flush_counters(a.st.counters, ctr);
+}
+
+// The classified-edge set of the interaction regions that overflowed the bounded triangle list: the WHOLE region, whatever its
+// triangle count — the reference's unbounded std::vector (include/wt/ads/traversal_common.hpp:124-148).  One wavefront per walk
+// (coop_gather, edges only): only subtrees that hold classified edges are entered and only edge-bearing triangles are tested, 64 at
+// a time (a wide beam over the whole scene still meets ~10^3 of them: a single lane needs milliseconds for that).
+// Sorted ids -> the walk's list slot, marker + count -> its traversal record.
+__global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
+    __shared__ coop_gather_shared_t sh;
+    __shared__ coop_edges_t eg;
+    __shared__ uint32_t s_item;
+    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_GATHER_COUNT];
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
+        if (item >= n) break;
+        const uint32_t w = a.st.gather_queue[item];
+        walk_t wk;
+        soa_load(a.st.walks, a.st.walk_words, w, wk);   // uniform address: broadcast
+        const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+        const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
+        const range_t izr{beam_dist, beam_dist + region_depth};
+        const cone_t tcone = walk_trace_envelope(a.sc, wk);
+        const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
+        __syncthreads();
+        // sorted ids -> the round's edge pool: any number of them in bitmap mode, the sorted 96-entry list for scenes with more than 32768 classified
+        // edges.  (Until round 4 that list went into the walk's triangle-list slot, which a later pass may still read as triangles.)
+        const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
+        uint32_t n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges, dropped = bitmap ? 0u : g.edge_overflow, off = 0;
+        if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
+        __syncthreads();
+        off = s_item;
+        __syncthreads();
+        if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported, cannot happen in the shipped scenes
+            dropped += n_edges;
+            n_edges = 0;
+        } else if (bitmap)
+            coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
+        else
+            for (uint32_t j = threadIdx.x; j < n_edges; j += 64) a.st.epool[off + j] = eg.edge_ids[j];
+        // Regions with many edges: the aperture is built right here, by the whole wavefront (wt/coop_fsd.h), instead of by one lane of
+        // pass B; walks whose aperture has segments go straight to the pass-C queue.
+        uint32_t marker = kGatherMarker, slot = 0;
+        if (n_edges >= a.coop_aperture_min) {
+            const uint32_t* eids = a.st.epool + off;
+            __syncthreads();   // the ids were written by other lanes
+            if (threadIdx.x == 0) s_item = fsd_pool_alloc(pool);
+            __syncthreads();
+            slot = s_item;
+            __syncthreads();
+            if (slot < pool.cap) {
+                fsd_aperture_t ap;
+                const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
+                const bool ok = coop_build_aperture(a.sc, cone_frame(wk.beam.env), wk.beam.k, wk.beam.env, eids, n_edges, vec2{sd3.x, sd3.y}, pool, slot, ap);
+                marker = ap.n_edges > 0 ? kApertureMarker : kNullApertureMarker;
+                if (threadIdx.x == 0) {
+                    pool.hdr[slot] = ap;
+                    if (marker == kApertureMarker) a.st.intc_queue[atomicAdd(ctl + CTL_INTC_COUNT, 1u)] = w;
+                    if (a.count_stats) {
+                        if (dropped) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, edge_overflow) / sizeof(unsigned long long), (unsigned long long)dropped);
+                        if (ap.overflow) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_edge_overflow) / sizeof(unsigned long long), (unsigned long long)ap.overflow);
+                        if (!ok) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_pool_overflow) / sizeof(unsigned long long), 1ull);
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)] = marker;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = slot;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)] = off;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)] = n_edges;
+            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)] = dropped;
+            if (a.profile) {
+                atomicAdd(a.st.counters + kNumCounters + 5, 1ull);
+                atomicAdd(a.st.counters + kNumCounters + 6, (unsigned long long)n_edges);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT) k_interact(launch_args_t a, int in, int first_round) { interact_body<0>(a, in, first_round); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
+
+}   // namespace wtk

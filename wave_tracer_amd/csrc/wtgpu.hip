@@ -34,49 +34,12 @@
 #include <string>
 #include <vector>
 
-#include "../../include/wtgpu.h"
+#include "wtgpu_kernels.h"
 #include "wtgpu_test_hooks.h"
 #include "scene_abi_check.h"
 #include "host/scene_builder.h"
-#include "wt/bdpt.h"
-#include "wt/coop.h"
-#include "wt/coop_fsd.h"
-#include "wt/path.h"
-
-using namespace wt;
 
 namespace {
-
-// Register budgets (second __launch_bounds__ argument = minimum waves per SIMD => 512 / n unified VGPRs per lane).
-#ifndef WTGPU_LB_TRACE
-#define WTGPU_LB_TRACE 3
-#endif
-#ifndef WTGPU_LB_HEAVY
-#define WTGPU_LB_HEAVY 2   // 215 VGPRs, no spills, no scratch frame: as fast as 3 waves with 93 spilled registers, 27 GB per pass less HBM traffic
-#endif
-#ifndef WTGPU_LB_INTERACT
-#define WTGPU_LB_INTERACT 4
-#endif
-#ifndef WTGPU_LB_INTERACT_B
-#define WTGPU_LB_INTERACT_B 3
-#endif
-#ifndef WTGPU_LB_INTERACT_C
-#define WTGPU_LB_INTERACT_C 3
-#endif
-#ifndef WTGPU_LB_FLUX
-#define WTGPU_LB_FLUX 3
-#endif
-#ifndef WTGPU_LB_CONNECT
-#define WTGPU_LB_CONNECT 2   // 355 -> 105 spilled registers (the rest of its frame are the two vertices and beams of a connection)
-#endif
-constexpr uint32_t kFluxTaskTris = 2048;   // default size of a region-sum task (k_flux_split / k_flux_tasks)
-constexpr int kBlock = 128;
-#ifndef WTGPU_LDS_STACK
-#define WTGPU_LDS_STACK 20
-#endif
-constexpr int kLdsStack = WTGPU_LDS_STACK;   // LDS-resident stack entries per lane
-constexpr uint32_t kConeBudget = 64;     // work units (1 per cone-triangle test, 2 per node) one lane may spend on a cone query before it is handed to a wavefront (with lane refill, round 3: 32 / 48 / 64 / 96 / 128 -> 14.6 / 14.8 / 15.2 / 14.4 / 12.8 Msamples/s; round 2's kernel without refill: optimum 28-32)
-constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
@@ -89,74 +52,6 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(WTGPU_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));    \
     } while (0)
 
-// control block of one state slice (device memory)
-enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 40 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
-constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
-constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
-// ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
-// C — or without (pass B commits the restart)
-constexpr uint32_t kApertureMarker = 0xFFFFFFFDu, kNullApertureMarker = 0xFFFFFFFCu;
-__host__ __device__ inline bool is_region_marker(uint32_t t) { return t == kGatherMarker || t == kApertureMarker; }
-// connection strategies (s,t) are bucketed by (min(t, kKeyDim-1), min(s, kKeyDim-1)): one bucket per strategy up to 18 vertices per subpath; a
-// bucket of the last row / column holds every longer strategy of its sample (an item of such a bucket loops over them, k_connect_strat)
-// (kMaxVerts + 2: up to max_depth = 16 — 18 vertices per subpath — every strategy has its own bucket and k_connect_strat_open is not launched;
-// launching it for nothing cost 35 % of a pass with four streams: a 256-register, 22-KB-LDS grid that waits for free CUs holds up the other
-// streams' dispatches)
-constexpr uint32_t kKeyDim = kMaxVerts + 2, kNumKeys = kKeyDim * kKeyDim;
-
-struct device_state_t {
-    uint64_t cap = 0;   // samples per batch
-    uint32_t max_verts = 0;
-    uint32_t walk_words = 0;   // words of one walk record (walk_t, or path_walk_t for plt_path scenes)
-    size_t vert_words = 0;     // words of one walk's vertex array (max_verts x kVertexWords)
-    uint32_t* walks = nullptr;    // [kWalkWords][2cap]
-    uint32_t* verts = nullptr;    // [max_verts*kVertexWords][2cap]
-    uint32_t* ctx = nullptr;      // [kCtxWords][cap]
-    uint32_t* trav = nullptr;     // [kTravWords][2cap]
-    uint32_t* tris = nullptr;     // [kMaxConeTris][2cap]
-    uint32_t* queue[2] = {nullptr, nullptr};
-    uint32_t* heavy_queue = nullptr;   // walks whose traversal exceeded the per-lane budget
-    uint32_t* intb_queue = nullptr;    // walks whose interaction takes the expensive (no primary triangle) path
-    uint32_t* gather_queue = nullptr;  // ... of those, the ones whose triangle list overflowed (coop_gather first)
-    uint32_t* intc_queue = nullptr;    // ... and the ones that built a Fraunhofer aperture with edges (sampled in pass C)
-    uint32_t* intd_queue = nullptr;    // ... of those, the ones whose rejection sampling outlasts kEasyTries tries (k_interact_c_hard)
-    uint2* ftasks = nullptr;           // (walk, subtree) tasks of the intercepted-power sums of overflowed regions (k_flux_split / k_flux_tasks)
-    uint32_t ftask_cap = 0;
-    double* facc = nullptr;            // [2cap] their accumulators
-    uint32_t* epool = nullptr;         // edge-id lists of the gathered regions of one round (bump allocator, k_edges)
-    uint32_t epool_cap = 0;
-    uint32_t* ctl = nullptr;           // [CTL_WORDS] queue sizes, dequeue heads, FSD pool bump counter, rounds done
-    fsd_aperture_t* fsd_hdr = nullptr;
-    fsd_edge_t* fsd_edges = nullptr;
-    uint32_t fsd_cap = 0;
-    uint32_t fsd_ecap = 0;            // segment records of all apertures of a batch (bump allocator)
-    uint32_t* strat_items = nullptr;    // [kNumKeys][cap] sample indices bucketed by connection strategy (s,t)
-    uint32_t* strat_count = nullptr;    // [kNumKeys]
-    uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
-    double* lacc = nullptr;             // [4][cap] per-sample sum of the t>1 strategies' fluxes
-    unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
-};
-// plt_path only — a device-resident block the path kernels get a pointer to (launch_args_t stays below 1024 bytes: by-value kernel
-// arguments beyond that cost 40 % of a plt_bdpt pass with four streams, measured: 976 -> 1048 bytes, 15.4 -> 11.1 Msamples/s).
-struct path_state_t {
-    // plt_path: wedge records of the walks' UTD apertures, two pools used alternately (round parity: an aperture built in round r is evaluated in
-    // round r + 1), each reset when its round begins; queues of the wave-per-walk UTD kernels and what they exchange with k_path_interact
-    utd_edge_rec_t* utd[2] = {nullptr, nullptr};
-    uint32_t utd_cap = 0;
-    uint32_t* fsdq[2] = {nullptr, nullptr};   // walks that carry an aperture into the next round (k_path_fsd evaluates it there)
-    uint32_t* neeq = nullptr;                  // walks with a deferred next-event estimation of this round (k_path_nee)
-    float* fsd_f = nullptr;                    // [cap] k_path_fsd's result per walk
-    path_nee_rec_t* nee_recs = nullptr;        // [cap]
-    uint2* gather_info = nullptr;              // [cap] k_path_edges' result per walk: (offset into the round's edge pool, number of ids)
-};
-constexpr size_t kWalkWords = sizeof(walk_t) / 4;
-constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
-constexpr size_t kTravWords = sizeof(trav_result_t) / 4;
-#define WT_TRAV_WORD(field) (offsetof(trav_result_t, field) / 4)
-constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long long);
-constexpr size_t kProfSlots = 128;   // WTGPU_PROFILE scratch counters behind the public ones
-constexpr size_t kDroppedSlot = kNumCounters + kProfSlots;   // ... and behind those: children a full cooperative traversal stack could not hold (wt/coop.h)
 
 }   // namespace
 
@@ -243,1486 +138,7 @@ struct device_guard_t {
     }
 };
 
-// ================================================ kernels ============================================================
 namespace {
-
-struct launch_args_t {
-    scene_t sc;
-    device_state_t st;
-    film_t film;
-    uint64_t seed;
-    uint64_t j0;        // first global work item of this batch
-    uint32_t nb;        // samples in this batch
-    uint32_t npix;
-    uint64_t sample_begin;
-    uint32_t count_stats;
-    uint32_t cone_budget;
-    uint32_t flux_task_tris;   // k_flux_split: largest subtree handed to one wavefront of k_flux_tasks
-    uint32_t heavy_probe;   // k_trace_heavy: any-hit probe of the near slab before the handed-over cone query too
-    uint32_t coop_aperture_min;   // regions with at least this many classified edges get their aperture built by k_edges' wavefront
-    uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
-    uint32_t split_queues;   // round queues keep sensor and emitter walks apart (queue_append); 0: one mixed queue (A/B)
-    uint32_t lane_cache, heavy_cache;   // diagnostic switches of the remembered rejecting triangles (wt::traverse_axis / coop_traverse); default on
-    uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
-};
-
-// (block size as a constant: blockDim would pull 256 bytes of hidden kernel arguments into the kernel-argument segment)
-__device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s, uint32_t block = kBlock) {
-    s = make_stack_ref(lds + threadIdx.x, block, kLdsStack + kSpillStack, kLdsStack, spill);
-}
-
-__device__ inline void flush_counters(unsigned long long* g, const bdpt_counters_t& c) {
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(&c);
-#pragma unroll
-    for (size_t i = 0; i < kNumCounters; ++i) {
-        unsigned long long v = p[i];
-        // wave reduction (64 lanes)
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&g[i], v);
-    }
-}
-
-__global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) {
-        uint32_t* ctl = a.st.ctl;
-        ctl[CTL_COUNT0] = 2 * a.nb;
-        ctl[CTL_COUNT1] = 0;
-        ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
-        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
-        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
-        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
-        ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
-    }
-    if (i >= a.nb) return;
-    const uint64_t j = a.j0 + i;
-    const uint32_t pix = (uint32_t)(j % a.npix);
-    const uint64_t s = a.sample_begin + j / a.npix;
-    const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    sample_ctx_t ctx;
-    walk_t sw, ew;
-    const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
-    bdpt_generate(a.sc, a.seed, sample_id, pix % a.sc.sensor.width, pix / a.sc.sensor.width, ctx, sw, ew, svs, evs);
-    soa_store(a.st.ctx, kCtxWords, i, ctx);
-    soa_store(a.st.walks, a.st.walk_words, i, sw);
-    soa_store(a.st.walks, a.st.walk_words, (size_t)a.st.cap + i, ew);
-}
-
-// walk id -> (sample index, stream)
-__device__ inline void walk_ident(const launch_args_t& a, uint32_t w, uint32_t& i, uint32_t& stream) {
-    if (w < a.st.cap) {
-        i = w;
-        stream = STREAM_SENSOR_WALK;
-    } else {
-        i = w - (uint32_t)a.st.cap;
-        stream = STREAM_EMITTER_WALK;
-    }
-}
-// The round queues hold the two kinds of walks apart: sensor walks are appended from the front of the array (count CTL_COUNT*), emitter
-// walks from its end backwards (count CTL_BACK*).  A traversal costs an emitter walk of the headline workload 5-10x what it costs a
-// sensor walk (wide beams from the spots against pixel-sized beams from the camera): wavefronts that hold one kind waste fewer lanes.
-// queue item -> walk id; the first round's queue is the identity over [0,nb) (sensor walks) and [cap,cap+nb) (emitter walks)
-__device__ inline uint32_t queue_count(const uint32_t* ctl, int in) { return ctl[CTL_COUNT0 + in] + ctl[CTL_BACK0 + in]; }
-__device__ inline uint32_t queue_walk(const launch_args_t& a, const uint32_t* ctl, int in, uint32_t qi, int first_round) {
-    if (first_round) return qi < a.nb ? qi : (uint32_t)a.st.cap + (qi - a.nb);
-    const uint32_t front = ctl[CTL_COUNT0 + in];
-    return qi < front ? a.st.queue[in][qi] : a.st.queue[in][2 * (size_t)a.st.cap - 1 - (qi - front)];
-}
-// one wavefront grabs the next 64 queue items
-__device__ inline uint32_t wave_grab(uint32_t* head) {
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(head, 64u);
-    return (uint32_t)__shfl((int)base, 0, 64);
-}
-// wave-aggregated append of `w` (for lanes with `pred`) to a device queue
-__device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, uint32_t w) {
-    const unsigned long long m = __ballot(pred);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
-}
-
-// ... of walk `w` (for lanes with `pred`) to round queue `out`: sensor walks (and plt_path's) at the front, emitter walks at the back
-__device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int out, bool pred, uint32_t w) {
-    const bool back = pred && w >= a.st.cap && a.split_queues;
-    wave_append(a.st.queue[out], ctl + CTL_COUNT0 + out, pred && !back, w);
-    const unsigned long long m = __ballot(back);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(ctl + CTL_BACK0 + out, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (back) a.st.queue[out][2 * (size_t)a.st.cap - 1 - (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = w;
-}
-
-#ifndef WTGPU_LEAF_NUM
-#define WTGPU_LEAF_NUM 1   // leaf step when at least NUM / DEN of the running lanes hold a leaf (swept 1/3, 1/2, 2/3, 3/4: 99.0 / 97.6 / 96.6 / 97.9 ms per pass, noise 1 ms)
-#define WTGPU_LEAF_DEN 2
-#endif
-// The per-lane trace kernel, with LANE REFILL.
-// The cost of a walk's traversal varies by two orders of magnitude — one to seven cone queries of 2..cone_budget work units each —
-// and a wavefront whose lanes ran the policy and their queries back to back would be as slow as its slowest lane (rounds 1-2: that kernel
-// was kept as an A/B reference until round 4).  Here a lane is a slot that walks pass through.  The wavefront alternates between
-//   * the traversal loop: every lane that holds a node descends (cq_node_step), every lane that holds a leaf tests its triangles
-//     (cq_leaf_step) — the steps of wt/bvh.h, which the CPU checker drives one query at a time —
-//   * and the service section, entered once enough lanes wait: a lane whose query ended gets the policy's next query (aw_query_done /
-//     aw_next) or stores its record, and lanes without a walk fetch new ones from the queue (one atomic per wavefront), trace the beam
-//     axis and start their first query.
-// A slow query therefore occupies one lane, not 64, which is also what lets the work budget per query be larger (fewer walks
-// handed to the wave-cooperative kernel).  Per walk the sequence of visits and the results are those of wt::traverse_axis.
-//
-// (GUIDED FETCH — a wavefront holds at most ceil(walks left in the queue / wavefronts of the grid) walks, so that the end of a round is as long
-// as its longest single walk instead of a wavefront's 64 — was built and measured in round 4, dynamically and as a per-round target: the short
-// rounds of a one-stream pass went from 1.5 to 1.0 ms each, but a wavefront that fetches one walk at a time runs its fetch section — the axis
-// query — for one lane: the long rounds got 35 % slower, the pass 9 % (20.4 vs 22.4 Msamples/s).  With the per-round target: -4 % on the
-// headline workload (21.5 vs 22.5), +3..6 % on the 720 x 540 film, -3 % with two-pass batches.  Not kept: what the ends of the rounds cost is paid per BATCH,
-// and larger batches (bench.py: ~4 M samples) removed most of it: 720 x 540 18.8 -> 56 Msamples/s.)
-#ifndef WTGPU_REFILL_MIN
-#define WTGPU_REFILL_MIN 16
-#endif
-// the policy up to its next cone query (TRUE) or its end (FALSE: `r` is final); the tests of the remembered triangles run right here
-__device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, bool rt, const stack_ref_t& stack, axis_walk_t& aw, cone_query_t& q, trav_result_t& r) {
-    for (;;) {
-        const int need = aw_next(sc, env, rt, stack, aw, q, r);
-        if (need != AW_TEST) return need == AW_QUERY;
-        aw_test_done(aw, cone_attempt_too_short_by(sc, env, aw.cand, aw.sr, aw.min_df_prog));
-    }
-}
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = queue_count(ctl, in);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl[CTL_COUNT0 + (1 - in)] = 0;   // output queue of this round's k_interact
-        ctl[CTL_BACK0 + (1 - in)] = 0;
-        ctl[CTL_HEAD_INTERACT] = 0;
-        ctl[CTL_INTB_COUNT] = 0;
-        ctl[CTL_INTB_HEAD] = 0;
-        ctl[CTL_GATHER_COUNT] = 0;
-        ctl[CTL_GATHER_HEAD] = 0;
-        ctl[CTL_INTC_COUNT] = 0;
-        ctl[CTL_INTC_HEAD] = 0;
-        ctl[CTL_FTASK_COUNT] = 0;
-        ctl[CTL_FTASK_HEAD] = 0;
-        ctl[CTL_FSPLIT_HEAD] = 0;
-        ctl[CTL_EPOOL_COUNT] = 0;
-        ctl[CTL_INTD_COUNT] = 0;
-        ctl[CTL_INTD_HEAD] = 0;
-        // plt_path: this round's wedge pool and the queue it fills for the next round's k_path_fsd; this round's k_path_fsd / k_path_nee heads
-        ctl[CTL_UTD_COUNT0 + (round & 1u)] = 0;
-        ctl[CTL_FSDQ_COUNT0 + ((round + 1u) & 1u)] = 0;
-        ctl[CTL_FSDQ_HEAD] = 0;
-        ctl[CTL_NEEQ_COUNT] = 0;
-        ctl[CTL_NEEQ_HEAD] = 0;
-        if (n > 0) ctl[CTL_ROUNDS] = round + 1;
-    }
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    // lane state: 0 = no walk, 1 = cone query running, 2 = cone query ended (to be served)
-    int st = 0;
-    uint32_t w = 0;
-    cone_t env;
-    axis_walk_t aw;
-    cone_query_t q;
-    uint_list_t tris{nullptr, 1u, 0u, nullptr};
-    memset(&env, 0, sizeof(env));
-    memset(&aw, 0, sizeof(aw));
-    memset(&q, 0, sizeof(q));
-    bool exhausted = false;   // wave-uniform: the queue holds no more walks
-#ifdef WTGPU_REFILL_PROF
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pl[6] = {0, 0, 0, 0, 0, 0};
-    long long pt;
-#define RP_BEGIN() pt = clock64()
-#define RP_END(i, mask) do { const long long d_ = clock64() - pt; pc[i] += (unsigned long long)d_; pl[i] += (unsigned long long)d_ * (unsigned long long)__popcll(mask); } while (0)
-#else
-#define RP_BEGIN()
-#define RP_END(i, mask)
-#endif
-    for (;;) {
-        // ---- service section
-        bool fin = false;
-        trav_result_t r;
-        RP_BEGIN();
-        const unsigned long long m_srv = __ballot(st == 2);
-        if (st == 2) {
-            cq_end(env, tris, q);
-            fin = aw_query_done(a.sc, env, aw, q.rec, r);
-            if (!fin) fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
-            st = fin ? 0 : 1;
-        }
-        RP_END(0, m_srv);
-        // (records of finished walks are stored below, together with those of freshly fetched walks that need no cone query)
-        uint32_t w_fin = w;
-        const int n_idle = __popcll(__ballot(st == 0 && !fin)), n_run = __popcll(__ballot(st == 1));
-        bool fetched = false;
-        const bool any_fin = __ballot(fin) != 0;   // (their records are stored first; they fetch in the next turn)
-        if (!exhausted && !any_fin && (n_idle >= WTGPU_REFILL_MIN || n_run == 0)) {
-            const unsigned long long im = __ballot(st == 0);
-            const bool take = st == 0;
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(ctl + CTL_HEAD_TRACE, (uint32_t)__popcll(im));
-            base = (uint32_t)__shfl((int)base, 0, 64);
-            if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
-            const uint32_t qi = base + (uint32_t)__popcll(im & below);
-            RP_BEGIN();
-            const unsigned long long m_f = __ballot(take && qi < n);
-            if (take && qi < n) {
-                w = queue_walk(a, ctl, in, qi, first_round);
-                w_fin = w;
-                const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
-                // plt_bdpt: the bounded list (64 triangles + their cone-hit distances) of the interaction region; see k_trace
-                uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
-                tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
-                env = walk_trace_envelope(a.sc, wk);
-                ray_hit_t ah;
-                // (The axis query in a kernel of its own was built twice: round 3 as a grid-stride kernel — 60 vs 56 ms per pass — and round 4 as a
-                // lane-refill kernel like this one (k_trace_axis: 111 registers, 4 waves per SIMD, 2.2 G rays/s in the long rounds: 3.9 ms where this
-                // section spends ~3): the two kernels together took 24.2 ms of the long rounds against 23.4 ms with the query in here, 22.4 vs 22.5
-                // Msamples/s — the fetch section's rays overlap other wavefronts' cone queries, which a separate kernel gives up.  Not kept.)
-                const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
-                aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
-                aw.use_cache = a.lane_cache;
-                fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
-                st = fin ? 0 : 1;
-            }
-            RP_END(1, m_f);
-            fetched = true;
-        }
-        // store the records of the walks that ended in this section (convergent: the queue append is a wave operation)
-        RP_BEGIN();
-        const unsigned long long m_st = __ballot(fin);
-        {
-            const bool heavy = fin && r.aborted == 1;
-            if (fin) {
-                if (heavy) {
-                    // resume state for k_trace_heavy (aw_query_done: dist / ntris = distance / segment of the query, the axis hit, the last
-                    // rejecting triangle in `overflow`)
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(dist)] = __float_as_uint(r.dist);
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(ntris)] = r.ntris;
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(n_ray_queries)] = r.n_ray_queries;
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(n_cone_queries)] = r.n_cone_queries;
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(tuid)] = r.tuid;
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(bx)] = __float_as_uint(r.bx);
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(by)] = __float_as_uint(r.by);
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(pdist)] = __float_as_uint(r.pdist);
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(front_face)] = r.front_face;
-                    a.st.trav[(size_t)w_fin * kTravWords + WT_TRAV_WORD(overflow)] = r.overflow;
-                } else {
-                    soa_store(a.st.trav, kTravWords, w_fin, r);
-                    ctr.segments += 1;
-                    ctr.ray_queries += r.n_ray_queries;
-                    ctr.cone_queries += r.n_cone_queries;
-                    if (a.collect_list) ctr.cone_tri_overflow += r.overflow;
-                }
-            }
-            wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w_fin);
-        }
-        RP_END(2, m_st);
-        // walks that ended left their lanes free: fetch (more) before traversing
-        if (fetched || any_fin) continue;
-        const int running = __popcll(__ballot(st == 1));
-        if (running == 0) {
-            if (exhausted) break;
-            continue;
-        }
-        // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_REFILL_MIN) wait to be served
-        const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
-        for (;;) {
-            // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
-            for (;;) {
-                const bool at_node = st == 1 && q.leaf == 0 && q.s > 0;
-                const unsigned long long nm = __ballot(at_node);
-                if (!nm) break;
-                RP_BEGIN();
-                if (at_node) cq_node_step(a.sc, env, stack, q);
-                RP_END(3, nm);
-                if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && q.leaf != 0)) >= WTGPU_LEAF_NUM * running) break;
-            }
-            // (Deferring the exact cone-triangle tests of a leaf step — 3 % of its triangles, ~10x a filter test, 1-2 lanes busy — to a step of
-            // their own, taken once 4 / 8 / 16 lanes wait for one, was built and measured in round 4: 5 % SLOWER per pass.  The kernel is bound by
-            // dependent memory round trips, not by instruction issue, and the deferred test re-fetches its triangle: one more round trip per hit.)
-            RP_BEGIN();
-            const unsigned long long m_leaf = __ballot(st == 1 && q.leaf != 0);
-            if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris, q);
-            RP_END(4, m_leaf);
-            if (st == 1 && !cq_running(q)) st = 2;
-            const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
-            if (waiting >= leave_at || !__ballot(st == 1)) break;
-        }
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-#ifdef WTGPU_REFILL_PROF
-    if (lane == 0)
-        for (int i = 0; i < 6; ++i) {
-            atomicAdd(a.st.counters + kNumCounters + i, pc[i]);
-            atomicAdd(a.st.counters + kNumCounters + 8 + i, pl[i]);
-        }
-    // (the ray timer runs in the first fetching lane: add what other lanes hold)
-    if (lane != 0 && pc[5]) { atomicAdd(a.st.counters + kNumCounters + 5, pc[5]); atomicAdd(a.st.counters + kNumCounters + 8 + 5, pl[5]); }
-#endif
-}
-
-// Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
-__global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_t a) {
-    __shared__ coop_shared_t sh;
-    __shared__ uint32_t s_item;
-    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_HEAVY_COUNT];
-    const uint32_t* hq = a.st.heavy_queue;
-    uint32_t* head = ctl + CTL_HEAVY_HEAD;
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = hq[item];
-        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
-        const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};   // see k_trace
-        const cone_t env = walk_trace_envelope(a.sc, wk);
-        unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const long long tt0 = a.profile == 2 ? clock64() : 0;
-        const float dist0 = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-        const uint32_t seg0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)];
-        const uint32_t nray0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)], ncone0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)];
-        ray_hit_t axis;   // the closest hit of the beam axis, found by k_trace (traverse_axis, wt/bvh.h)
-        axis.tuid = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)];
-        axis.bx = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)]);
-        axis.by = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)]);
-        axis.dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(pdist)]);
-        axis.front_face = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)];
-        const uint32_t short0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(overflow)];
-        const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
-                                                &axis, !a.collect_list, a.heavy_probe != 0, a.heavy_cache ? short0 : kInvalid, a.heavy_cache ? wk.prev_offset_tuid : kInvalid, a.heavy_cache != 0);
-        if (a.profile == 2 && threadIdx.x == 0) {
-            prof[3] = (unsigned long long)(clock64() - tt0);
-            for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
-            atomicAdd(a.st.counters + kNumCounters + 5, prof[5]);
-            atomicAdd(a.st.counters + kNumCounters + 6, prof[6]);
-            atomicAdd(a.st.counters + kNumCounters + 7, prof[7]);
-            for (int q = 8; q < 12; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);   // (WTGPU_COOP_PROF: batch counts)
-            atomicAdd(a.st.counters + kNumCounters + 4, 1ull);
-        }
-        if (threadIdx.x == 0) {
-            soa_store(a.st.trav, kTravWords, w, tr2);
-            ctr.segments += 1;
-            ctr.ray_queries += tr2.n_ray_queries;
-            ctr.cone_queries += tr2.n_cone_queries;
-            if (a.collect_list) ctr.cone_tri_overflow += tr2.overflow;
-        }
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-
-// Interaction step of the queued walks.  PASS 0 (A): the queue of the round — surface interactions; walks whose beam axis misses
-// every triangle of the interaction region (8 % of them; what follows costs ~50x a surface interaction) are only appended to the
-// pass-B queue.  k_edges then gathers the classified-edge set of their regions.  PASS 1 (B): Fraunhofer aperture construction,
-// null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
-// No BVH query happens in these passes (the trace kernels resolved the primary triangle): they carry no traversal stack.
-template <int PASS>
-__device__ inline __attribute__((always_inline)) void interact_body(const launch_args_t& a, int in, int first_round) {
-    constexpr bool PASS_B = PASS == 1;
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : queue_count(ctl, in);
-    if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
-        ctl[CTL_HEAVY_HEAD] = 0;
-        ctl[CTL_HEAD_TRACE] = 0;
-    }
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
-    for (;;) {
-        const uint32_t qi = wave_grab(ctl + (PASS_B ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
-        if (qi - (threadIdx.x & 63) >= n) break;
-        bool cont = false;
-        uint32_t w = 0;
-        fsd_defer_t defer;
-        defer.pending = defer.resolved = 0;
-        defer.slot = defer.base = defer.next_try = defer.end_draws = 0;
-        defer.defer_sampling = PASS_B ? 1u : 0u;
-        defer.to_sampling_pass = 0;
-        defer.have_aperture = 0;
-        defer.split_no_primary = PASS_B ? 0u : 1u;
-        defer.known_no_primary = PASS_B ? 1u : 0u;
-        defer.no_primary = 0;
-        defer.has_gather = defer.gather_n_edges = defer.gather_edge_overflow = 0;
-        defer.gather_flux = 0.f;
-        defer.gather_edges = nullptr;
-        bool need_gather = false;
-        if (qi < n) {
-            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
-            uint32_t i, stream;
-            walk_ident(a, w, i, stream);
-            const uint64_t j = a.j0 + i;
-            const uint32_t pix = (uint32_t)(j % a.npix);
-            const uint64_t s = a.sample_begin + j / a.npix;
-            const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-            walk_t wk;
-            soa_load(a.st.walks, a.st.walk_words, w, wk);
-            trav_result_t tr;
-            soa_load(a.st.trav, kTravWords, w, tr);
-            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
-            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
-            const bool queued_for_c = PASS_B && tr.tuid == kApertureMarker;   // k_edges built the aperture and queued the walk for pass C
-            if (PASS_B && tr.tuid == kNullApertureMarker) {   // k_edges built the aperture: no segments (the step restarts the beam)
-                defer.have_aperture = 1;
-                defer.slot = __float_as_uint(tr.by);
-            }
-            if (PASS_B && tr.tuid == kGatherMarker) {   // k_edges left the region's sorted classified-edge ids in the walk's list slot
-                defer.has_gather = 1;
-                defer.gather_n_edges = tr.n_ray_queries;
-                defer.gather_edge_overflow = tr.n_cone_queries;
-                const uint32_t off = __float_as_uint(tr.bx);   // offset into the round's edge pool
-                defer.gather_edges = a.st.epool + off;
-            }
-            const long long pb0 = PASS_B && a.profile == 3 ? clock64() : 0;
-            if (!queued_for_c) cont = bdpt_walk_step<PASS_B ? 2 : 1>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, nullptr, &defer);
-            if (PASS_B && defer.to_sampling_pass) a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = defer.slot;
-            if (PASS_B && a.profile == 3) {   // pass-B cost by the number of gathered scene edges
-                const int bin = defer.has_gather ? 32 - __clz((int)defer.gather_n_edges) : 0;   // 0: no gather / none
-                atomicAdd(a.st.counters + kNumCounters + 56 + bin, 1ull);
-                atomicAdd(a.st.counters + kNumCounters + 72 + bin, (unsigned long long)(clock64() - pb0));
-            }
-            // a region that did not fit the bounded list: its edge set comes from a walk of the whole region (k_edges)
-            // (... or whose list holds more than kMaxEdgeIds / 3 triangles: the per-lane edge set of pass B is bounded)
-            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list)) need_gather = true;
-            if (!defer.no_primary && !defer.to_sampling_pass && !queued_for_c) {
-                wk.active = cont ? 1u : 0u;
-                soa_store(a.st.walks, a.st.walk_words, w, wk);
-            }
-        }
-        if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
-        if (!PASS_B) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
-        if (PASS_B) wave_append(a.st.intc_queue, ctl + CTL_INTC_COUNT, defer.to_sampling_pass != 0, w);
-        queue_append(a, ctl, 1 - in, cont, w);
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-
-// The classified-edge set of the interaction regions that overflowed the bounded triangle list: the WHOLE region, whatever its
-// triangle count — the reference's unbounded std::vector (include/wt/ads/traversal_common.hpp:124-148).  One wavefront per walk
-// (coop_gather, edges only): only subtrees that hold classified edges are entered and only edge-bearing triangles are tested, 64 at
-// a time (a wide beam over the whole scene still meets ~10^3 of them: a single lane needs milliseconds for that).
-// Sorted ids -> the walk's list slot, marker + count -> its traversal record.
-__global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
-    __shared__ coop_gather_shared_t sh;
-    __shared__ coop_edges_t eg;
-    __shared__ uint32_t s_item;
-    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_GATHER_COUNT];
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = a.st.gather_queue[item];
-        walk_t wk;
-        soa_load(a.st.walks, a.st.walk_words, w, wk);   // uniform address: broadcast
-        const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-        const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
-        const range_t izr{beam_dist, beam_dist + region_depth};
-        const cone_t tcone = walk_trace_envelope(a.sc, wk);
-        const gather_out_t g = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
-        __syncthreads();
-        // sorted ids -> the round's edge pool: any number of them in bitmap mode, the sorted 96-entry list for scenes with more than 32768 classified
-        // edges.  (Until round 4 that list went into the walk's triangle-list slot, which a later pass may still read as triangles.)
-        const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
-        uint32_t n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges, dropped = bitmap ? 0u : g.edge_overflow, off = 0;
-        if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
-        __syncthreads();
-        off = s_item;
-        __syncthreads();
-        if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported, cannot happen in the shipped scenes
-            dropped += n_edges;
-            n_edges = 0;
-        } else if (bitmap)
-            coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
-        else
-            for (uint32_t j = threadIdx.x; j < n_edges; j += 64) a.st.epool[off + j] = eg.edge_ids[j];
-        // Regions with many edges: the aperture is built right here, by the whole wavefront (wt/coop_fsd.h), instead of by one lane of
-        // pass B; walks whose aperture has segments go straight to the pass-C queue.
-        uint32_t marker = kGatherMarker, slot = 0;
-        if (n_edges >= a.coop_aperture_min) {
-            const uint32_t* eids = a.st.epool + off;
-            __syncthreads();   // the ids were written by other lanes
-            if (threadIdx.x == 0) s_item = fsd_pool_alloc(pool);
-            __syncthreads();
-            slot = s_item;
-            __syncthreads();
-            if (slot < pool.cap) {
-                fsd_aperture_t ap;
-                const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
-                const bool ok = coop_build_aperture(a.sc, cone_frame(wk.beam.env), wk.beam.k, wk.beam.env, eids, n_edges, vec2{sd3.x, sd3.y}, pool, slot, ap);
-                marker = ap.n_edges > 0 ? kApertureMarker : kNullApertureMarker;
-                if (threadIdx.x == 0) {
-                    pool.hdr[slot] = ap;
-                    if (marker == kApertureMarker) a.st.intc_queue[atomicAdd(ctl + CTL_INTC_COUNT, 1u)] = w;
-                    if (a.count_stats) {
-                        if (dropped) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, edge_overflow) / sizeof(unsigned long long), (unsigned long long)dropped);
-                        if (ap.overflow) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_edge_overflow) / sizeof(unsigned long long), (unsigned long long)ap.overflow);
-                        if (!ok) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_pool_overflow) / sizeof(unsigned long long), 1ull);
-                    }
-                }
-            }
-        }
-        if (threadIdx.x == 0) {
-            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)] = marker;
-            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)] = slot;
-            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(bx)] = off;
-            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_ray_queries)] = n_edges;
-            a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(n_cone_queries)] = dropped;
-            if (a.profile) {
-                atomicAdd(a.st.counters + kNumCounters + 5, 1ull);
-                atomicAdd(a.st.counters + kNumCounters + 6, (unsigned long long)n_edges);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT) k_interact(launch_args_t a, int in, int first_round) { interact_body<0>(a, in, first_round); }
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
-// Intercepted power of interaction regions that overflowed the bounded list (find_closest_triangle's sum over ALL region triangles,
-// plt_bdpt_detail.hpp:391-416) for the pass-C walks.  Such regions hold 10^3..10^5 triangles (a wide emitter beam over a finely
-// tessellated mesh), 5000 on average in the headline workload: one wavefront per region would leave the round waiting for the
-// largest one (measured: 27 ms for a 130,000-triangle region).  k_flux_split cuts the part of the tree that overlaps the region
-// into subtrees of <= kFluxTaskTris (2048; swept 128 / 512 / 2048: 247 / 216 / 208 ms per pass) triangles, k_flux_tasks sums every subtree on whichever wavefront is free (f64 atomics).
-__global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
-    __shared__ coop_gather_shared_t sh;
-    __shared__ uint32_t s_item;
-    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_INTC_COUNT];
-    const int lane = threadIdx.x & 63;
-    // 64 queue items per grab: every lane looks at one walk's marker (most pass-C walks have a region that fitted its list and need no
-    // split — bidir_room: 400,000 items a round, a few thousand to split; one item per grab was 11.5 ms of a 125-ms batch there), the
-    // wavefront then cuts the regions of the flagged ones, one after the other
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSPLIT_HEAD, 64u);
-        __syncthreads();
-        const uint32_t base = s_item;
-        __syncthreads();
-        if (base >= n) break;
-        uint32_t w_mine = 0;
-        bool need = false;
-        if (base + (uint32_t)lane < n) {
-            w_mine = a.st.intc_queue[base + lane];
-            need = is_region_marker(a.st.trav[(size_t)w_mine * kTravWords + WT_TRAV_WORD(tuid)]);
-        }
-        unsigned long long m = __ballot(need);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t w = (uint32_t)__shfl((int)w_mine, src, 64);   // block-uniform
-            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
-            const cone_t tcone = walk_trace_envelope(a.sc, wk);
-            const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-            const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
-            if (threadIdx.x == 0) a.st.facc[w] = 0.0;
-            coop_split(a.sc, tcone, range_t{beam_dist, beam_dist + region_depth}, sh, a.flux_task_tris, [&](int32_t ptr) {
-                const uint32_t idx = atomicAdd(ctl + CTL_FTASK_COUNT, 1u);
-                if (idx < a.st.ftask_cap)
-                    a.st.ftasks[idx] = make_uint2(w, (uint32_t)ptr);
-                else
-                    atomicAdd(a.st.counters + offsetof(bdpt_counters_t, fsd_pool_overflow) / sizeof(unsigned long long), 1ull);   // reported; cannot happen below 4M tasks per batch
-            });
-            __syncthreads();
-        }
-    }
-}
-__global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t a) {
-    __shared__ coop_gather_shared_t sh;
-    __shared__ uint32_t s_item;
-    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = min(ctl[CTL_FTASK_COUNT], a.st.ftask_cap);
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FTASK_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint2 task = a.st.ftasks[item];
-        const uint32_t w = task.x;
-        walk_t wk;
-        soa_load(a.st.walks, a.st.walk_words, w, wk);   // uniform address: broadcast
-        const float beam_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-        const float region_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
-        const bool want_front = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)] != 0;
-        const range_t izr{beam_dist, beam_dist + region_depth};
-        const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;
-        const cone_t tcone = walk_trace_envelope(a.sc, wk);
-        unsigned long long gst[2] = {0, 0};
-        const double flux = coop_gather(a.sc, tcone, izr, wk.beam.env, cone_frame(wk.beam.env), izr, vec2{sd3.x, sd3.y}, want_front, sh, true, false,
-                                        a.profile ? gst : nullptr, (int32_t)task.y).flux;
-        if (threadIdx.x == 0) {
-            if (flux != 0.0) unsafeAtomicAdd(&a.st.facc[w], flux);
-            if (a.profile) {   // WTGPU_PROFILE=1: sizes of the gathered regions
-                atomicAdd(a.st.counters + kNumCounters + 0, 1ull);
-                atomicAdd(a.st.counters + kNumCounters + 1, gst[0]);
-                atomicAdd(a.st.counters + kNumCounters + 2, gst[1]);
-                atomicMax(a.st.counters + kNumCounters + 4, gst[0]);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// Pass C: the walks of pass B whose Fraunhofer aperture has edges, ONE WAVEFRONT PER WALK.  What a single lane would do serially
-// is spread over the 64 lanes: the intercepted-power integral over every triangle of the interaction region (find_closest_triangle,
-// plt_bdpt_detail.hpp:391-416 — coop_gather walks the WHOLE region, however many triangles it holds: the reference's unbounded list)
-// and the rejection sampling (64 tries per step; tries own their random draws, the lowest accepted try wins like in the sequential
-// loop); lane 0 then re-enters bdpt_walk_step with the outcome (vertex append, beam transform, Russian roulette).
-//
-// The number of tries is wildly non-uniform: most apertures accept within the first 64, but the acceptance probability is
-// |sum of amplitudes|^2 / (n x sum of |amplitudes|^2) and the loop runs up to n x 1024 tries (fsd.h: fsd_max_tries, the reference's
-// cap) — in the headline workload apertures of 8..15 segments average 1,650 tries and account for 2/3 of this pass's arithmetic
-// (WTGPU_PROFILE=3), with single walks keeping one wavefront busy for a millisecond while the round waits.  BLOCK = 64 (k_interact_c)
-// therefore gives up after kEasyTries tries and queues the walk for BLOCK = 256 (k_interact_c_hard): four wavefronts per walk, 256
-// tries per step, continuing at try kEasyTries.
-constexpr uint32_t kEasyTries = 512;
-constexpr uint32_t kStageSegs = 256;
-#ifndef WTGPU_HARD_BLOCK
-#define WTGPU_HARD_BLOCK 256
-#endif
-template <int BLOCK>
-__device__ inline __attribute__((always_inline)) void interact_c_body(const launch_args_t& a, int in) {
-    constexpr bool HARD = BLOCK > 64;
-    __shared__ uint32_t s_item;
-    __shared__ uint32_t s_tmin;
-    __shared__ float s_res[3];
-    __shared__ stack_entry_t lds[8];   // the resumed step does no BVH queries; lane 0's stack is a formality
-    __shared__ fsd_edge_t s_seg[kStageSegs];   // the walk's aperture segments (7 KB; larger apertures are read from the pool)
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[HARD ? CTL_INTD_COUNT : CTL_INTC_COUNT];
-    const uint32_t* queue_in = HARD ? a.st.intd_queue : a.st.intc_queue;
-    const int tid = threadIdx.x, lane = threadIdx.x & 63;
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
-    for (;;) {
-        const long long pl0 = a.profile == 3 ? clock64() : 0;
-        if (tid == 0) s_item = atomicAdd(ctl + (HARD ? CTL_INTD_HEAD : CTL_INTC_HEAD), 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = queue_in[item];
-        uint32_t i, stream;
-        walk_ident(a, w, i, stream);
-        const uint64_t j = a.j0 + i;
-        const uint32_t pix = (uint32_t)(j % a.npix);
-        const uint64_t sample_id = ((uint64_t)pix << 32) | ((a.sample_begin + j / a.npix) & 0xFFFFFFFFull);
-        const uint32_t rng_draws = a.st.walks[(size_t)w * a.st.walk_words + WT_WALK_WORD(rng_draws)];
-        const uint32_t slot = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(by)];   // left by pass B
-        fsd_aperture_t ap = pool.hdr[slot];
-        const fsd_edges_ref_t ed = fsd_pool_edges(pool, slot);
-        const long long pc0 = a.profile == 3 ? clock64() : 0;
-        if (!HARD) {
-            // ---- intercepted power of the whole region (same z-slab, cone and facing as the reference's list-based sum)
-            const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
-            cone_t benv = wk.env;   // the beam's own envelope (not offset for tracing)
-            const float tr_dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-            const float tr_depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
-            const uint32_t tr_tuid = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(tuid)], tr_ntris = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ntris)];
-            const bool tr_front = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)] != 0;
-            const range_t izr{tr_dist, tr_dist + tr_depth};
-            const vec2 axes = cone_axes(benv, tr_dist);
-            const vec2 sigma{axes.x / kBeamEnvelope, axes.y / kBeamEnvelope};
-            double flux;
-            if (is_region_marker(tr_tuid)) {   // the region overflowed the bounded list: summed over all of it by k_flux_split / k_flux_tasks
-                flux = a.st.facc[w];
-            } else {   // lane = triangle of the (complete) list, wave reduction (bdpt_walk_step computes the same sum triangle by triangle)
-                const uint32_t* tl = a.st.tris + (size_t)w * kTriListWords;
-                flux = (uint32_t)lane < tr_ntris ? (double)region_triangle_flux(a.sc, cone_frame(benv), benv, izr, sigma, tl[lane], tr_front) : 0.0;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) flux += __shfl_xor(flux, off, 64);
-            }
-            const float I = (float)(1.0 - flux);
-            ap.recp_I = I > 0.f ? 1.f / I : 0.f;
-            if (lane == 0) pool.hdr[slot] = ap;
-        }
-        // ---- rejection sampling.  A try reads every segment of the aperture twice (segment selection by a linear scan of the pdfs,
-        // then the density / scattering-function sums): the segments are staged in LDS once per walk.
-        const sampler_t ss = make_sampler(a.seed, sample_id, stream, 0);
-        const uint32_t base = fsd_tries_base(make_sampler(a.seed, sample_id, stream, rng_draws));
-        const uint32_t max_tries = fsd_max_tries(ap);
-        const uint32_t t_begin = HARD ? kEasyTries : 0u, t_end = HARD ? max_tries : (max_tries < kEasyTries ? max_tries : kEasyTries);
-        bool acc = false;
-        uint32_t t_acc = 0;
-        float rx = 0.f, ry = 0.f, rf = 0.f;
-        auto run_tries = [&](const fsd_edges_ref_t& edr) {
-            for (uint32_t t0 = t_begin; t0 < t_end && !acc; t0 += BLOCK) {
-                const uint32_t t = t0 + (uint32_t)tid;
-                fsd_try_t r{{0.f, 0.f}, 0.f, 0u};
-                if (t < t_end) r = fsd_try(a.sc, ap, edr, sampler_at(ss, base + t * kFsdDrawsPerTry));
-                if (!HARD) {
-                    const unsigned long long am = __ballot(r.accept != 0);
-                    if (am) {
-                        const int wl = __ffsll((long long)am) - 1;
-                        rx = __shfl(r.x.x, wl, 64);
-                        ry = __shfl(r.x.y, wl, 64);
-                        rf = __shfl(r.f, wl, 64);
-                        t_acc = t0 + (uint32_t)wl;
-                        acc = true;
-                    }
-                } else {   // the lowest accepted try of the block
-                    if (tid == 0) s_tmin = 0xFFFFFFFFu;
-                    __syncthreads();
-                    if (r.accept) atomicMin(&s_tmin, t);
-                    __syncthreads();
-                    const uint32_t tm = s_tmin;
-                    if (tm != 0xFFFFFFFFu) {
-                        if (t == tm) {
-                            s_res[0] = r.x.x;
-                            s_res[1] = r.x.y;
-                            s_res[2] = r.f;
-                        }
-                        __syncthreads();
-                        rx = s_res[0];
-                        ry = s_res[1];
-                        rf = s_res[2];
-                        t_acc = tm;
-                        acc = true;
-                    }
-                    __syncthreads();
-                }
-            }
-        };
-        if (ap.n_edges <= kStageSegs) {
-            __syncthreads();   // (the previous walk's tries are done with the buffer)
-            for (uint32_t k = (uint32_t)tid; k < ap.n_edges; k += BLOCK) s_seg[k] = ed.p[k];
-            __syncthreads();
-            run_tries(fsd_edges_ref_t{s_seg, 1});
-        } else
-            run_tries(ed);
-        if (a.profile == 3 && tid == 0) {   // WTGPU_PROFILE=3: pass-C cost by aperture size (bin = floor(log2(segments)))
-            const int bin = 31 - __clz((int)max(ap.n_edges, 1u));
-            atomicAdd(a.st.counters + kNumCounters + 8 + bin, 1ull);
-            atomicAdd(a.st.counters + kNumCounters + 24 + bin, (unsigned long long)(acc ? t_acc + 1u - t_begin : t_end - t_begin));
-            atomicAdd(a.st.counters + kNumCounters + 40 + bin, (unsigned long long)(clock64() - pc0));
-            atomicAdd(a.st.counters + kNumCounters + 112 + bin, (unsigned long long)(pc0 - pl0));
-        }
-        const long long pm0 = a.profile == 3 ? clock64() : 0;
-        if (!HARD && !acc && t_end < max_tries) {   // none of the first kEasyTries tries accepted: four wavefronts take over
-            if (lane == 0) a.st.intd_queue[atomicAdd(ctl + CTL_INTD_COUNT, 1u)] = w;
-            continue;
-        }
-        // ---- commit: thread 0 resumes the step with the outcome
-        bool cont = false;
-        if (tid == 0) {
-            walk_t wk;
-            soa_load(a.st.walks, a.st.walk_words, w, wk);
-            trav_result_t tr;
-            soa_load(a.st.trav, kTravWords, w, tr);
-            fsd_defer_t defer;
-            defer.defer_sampling = defer.to_sampling_pass = 0;
-            defer.have_aperture = 1;
-            defer.split_no_primary = 0;
-            defer.known_no_primary = 1;
-            defer.no_primary = 0;
-            defer.has_gather = defer.gather_n_edges = defer.gather_edge_overflow = 0;
-            defer.gather_flux = 0.f;
-            defer.gather_edges = nullptr;
-            defer.pending = 0;
-            defer.resolved = 1;
-            defer.slot = slot;
-            defer.base = base;
-            defer.next_try = 0;
-            defer.fs = fsd_finalize(ap, acc, vec2{rx, ry}, rf);
-            defer.end_draws = fsd_draws_after(base, acc ? t_acc : max_tries - 1u);
-            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
-            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
-            stack_ref_t stack = make_stack_ref(lds, 1, 8, 8, nullptr);
-            cont = bdpt_walk_step<2>(a.sc, wk, tr, tris, vs, pool, a.seed, sample_id, stream, &ctr, &stack, &defer);
-            wk.active = cont ? 1u : 0u;
-            soa_store(a.st.walks, a.st.walk_words, w, wk);
-            if (a.profile == 3) atomicAdd(a.st.counters + kNumCounters + 96 + (31 - __clz((int)max(ap.n_edges, 1u))), (unsigned long long)(clock64() - pm0));
-        }
-        if (tid < 64) queue_append(a, ctl, 1 - in, cont, w);
-    }
-    if (a.count_stats && tid < 64) flush_counters(a.st.counters, ctr);
-}
-__global__ void __launch_bounds__(64, WTGPU_LB_INTERACT_C) k_interact_c(launch_args_t a, int in) { interact_c_body<64>(a, in); }
-__global__ void __launch_bounds__(WTGPU_HARD_BLOCK) k_interact_c_hard(launch_args_t a, int in) { interact_c_body<WTGPU_HARD_BLOCK>(a, in); }
-
-// ---- plt_path: one walk per sample; k_trace / k_trace_heavy are shared with plt_bdpt (they only read the walk_t
-// prefix of the walk record), the interaction step is path_walk_step (wt/path.h): UTD evaluation of the previous aperture (shadow
-// rays through the LDS stack), primary triangle, edge query, aperture construction, NEE / sensing splats (f64 atomics), sampling.
-__global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) {
-        uint32_t* ctl = a.st.ctl;
-        ctl[CTL_COUNT0] = a.nb;
-        ctl[CTL_COUNT1] = 0;
-        ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
-        ctl[CTL_UTD_COUNT0] = ctl[CTL_UTD_COUNT1] = ctl[CTL_FSDQ_COUNT0] = ctl[CTL_FSDQ_COUNT1] = ctl[CTL_FSDQ_HEAD] = ctl[CTL_NEEQ_COUNT] = ctl[CTL_NEEQ_HEAD] = 0;
-        ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
-        ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
-        ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
-        ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;
-    }
-    if (i >= a.nb) return;
-    const uint64_t j = a.j0 + i;
-    const uint32_t pix = (uint32_t)(j % a.npix);
-    const uint64_t s = a.sample_begin + j / a.npix;
-    const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-    path_walk_t pw;
-    path_generate(a.sc, a.seed, sample_id, pix % a.sc.sensor.width, pix / a.sc.sensor.width, pw);
-    soa_store(a.st.walks, a.st.walk_words, i, pw);
-}
-
-// do_fsd (plt_path_detail.hpp:311-346) by ONE WAVEFRONT: lane = wedge (strided over apertures of any size) — the Fermat point on the wedge, the
-// UTD coefficients and the two shadow rays (per-lane any-hit traversals on the lane's LDS stack) — coherent sums in f64 by wave reduction; the
-// direct path is evaluated redundantly by all lanes (uniform control flow).  Returns (|ts|^2 + |th|^2) / 2.
-__device__ inline float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const path_geo_t& src_geo, vec3 dst, const utd_aperture_t& ap, const utd_edge_rec_t* recs,
-                                    float k, const stack_ref_t& stack, bdpt_counters_t* ctr) {
-    const int lane = threadIdx.x & 63;
-    const vec3 src = cone_from_src.o;
-    const path_geo_t dst_geo = path_geo_point(dst);
-    double tsr = 0, tsi = 0, thr = 0, thi = 0;
-    for (uint32_t i = (uint32_t)lane; i < ap.n_edges; i += 64u) {
-        utd_diffracting_edge_t f;
-        if (!utd_f_edge(sc, ap, recs[i], src, dst, f)) continue;
-        const path_geo_t eintr = path_geo_edge(f.edge, f.p);
-        if (path_shadow(sc, eintr, src_geo, stack, ctr) || path_shadow(sc, eintr, dst_geo, stack, ctr)) continue;
-        const cplx phase = cpolar(1.f, -k_times_len(k, f.ro + f.ri));
-        const cplx a = phase * f.utd.Ds, b = phase * f.utd.Dh;
-        tsr += a.re;
-        tsi += a.im;
-        thr += b.re;
-        thi += b.im;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        tsr += __shfl_xor(tsr, off, 64);
-        tsi += __shfl_xor(tsi, off, 64);
-        thr += __shfl_xor(thr, off, 64);
-        thi += __shfl_xor(thi, off, 64);
-    }
-    cplx ts{(float)tsr, (float)tsi}, th{(float)thr, (float)thi};
-    if (cone_contains(cone_from_src, dst)) {
-        bdpt_counters_t* c0 = lane == 0 ? ctr : nullptr;
-        if (!path_shadow(sc, src_geo, dst_geo, stack, c0)) {
-            const cplx phase = cpolar(1.f, -k_times_len(k, length(dst - src)));
-            ts = ts + phase;
-            th = th + phase;
-        }
-    }
-    return (cnorm(ts) + cnorm(th)) / 2.f;
-}
-
-// plt_path, before the interaction step: the coherent UTD sum of the aperture the walk built in the previous round towards this round's
-// interaction point (plt_path_detail.hpp:616-636) — one wavefront per walk, queue filled by the previous round's k_path_interact.
-__global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_state_t* __restrict__ ps, uint32_t round) {
-    const path_state_t& P = *ps;
-    __shared__ stack_entry_t lds[kLdsStack * 64];
-    __shared__ uint32_t s_item;
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t qin = round & 1u;
-    const uint32_t n = ctl[CTL_FSDQ_COUNT0 + qin];
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack, 64u);
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSDQ_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = P.fsdq[qin][item];
-        const uint32_t empty = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)];
-        if (empty) continue;   // (the step ends before do_fsd: plt_path_detail.hpp:577-581)
-        path_walk_t pw;
-        soa_load(a.st.walks, a.st.walk_words, w, pw);   // uniform address: broadcast
-        const vec3 origin{__uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.x)]), __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.y)]),
-                          __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
-        const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-        const vec3 interaction_wp = origin + dist * pw.w.beam.env.d;
-        const float f = coop_do_fsd(a.sc, pw.prev_beam.env, path_geo_prev(pw.w), interaction_wp, pw.ap, prev_pool + pw.ap.edge_offset, pw.w.beam.k, stack, &ctr);
-        if (threadIdx.x == 0) P.fsd_f[w] = f;
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-
-// plt_path, the classified-edge set of regions the per-lane means cannot hold (path_defer_t::need_gather): one wavefront per walk.  Non-ballistic
-// hit: the triangles of the interaction region [dist, dist + depth] of the traced cone.  Ballistic hit: the reference's cone query around the hit
-// (plt_path_detail.hpp:645-650: closest cone hit inside dist -+ z / 2, then every triangle inside the final slab) — closest hit by the
-// wave-cooperative query, then a walk of that slab.  Edge ids through the LDS bitmap: any number, sorted, into the round's edge pool.
-__global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const path_state_t* __restrict__ ps) {
-    const path_state_t& P = *ps;
-    __shared__ coop_shared_t csh;
-    __shared__ coop_gather_shared_t sh;
-    __shared__ coop_edges_t eg;
-    __shared__ uint32_t s_item;
-    coop_set_dropped_counter(csh, a.st.counters + kDroppedSlot);
-    coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_GATHER_COUNT];
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = a.st.gather_queue[item];
-        const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
-        const uint32_t tr_ballistic = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(ballistic)];
-        const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-        const float depth = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(region_depth)]);
-        const vec3 origin{__uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.x)]), __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.y)]),
-                          __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
-        const bool ballistic = tr_ballistic || cone_is_ray(wk.env);
-        cone_t cone = wk.env;
-        range_t slab{dist, dist + depth};
-        bool any = true;
-        if (!ballistic)
-            cone.o = origin;   // the traced (self-intersection-offset) cone, like the record's triangles
-        else {
-            const float zdist = cone_axes(cone, dist).x * kMajorAxisToZScale;
-            const range_t sr{dist - zdist / 2.f, dist + zdist / 2.f};
-            cone_hit_t ch;
-            const uint_list_t none{nullptr, 1u, 0u};
-            coop_cone(a.sc, cone, sr, 1.f, csh, none, ch);
-            any = ch.ntris + ch.overflow > 0;
-            slab = cone_search_range(cone, sr, ch.dist, 1.f);
-            __syncthreads();
-        }
-        uint32_t n_edges = 0, off = 0, dropped = 0;
-        if (any) {
-            const gather_out_t g = coop_gather(a.sc, cone, slab, cone, cone_frame(cone), slab, vec2{1.f, 1.f}, false, sh, false, true, nullptr, 1, &eg);
-            __syncthreads();
-            // (every id list goes into the round's edge pool: the walk's triangle-list slot is read again as triangles by PASS 1)
-            const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
-            n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges;
-            dropped = bitmap ? 0u : g.edge_overflow;
-            if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
-            __syncthreads();
-            off = s_item;
-            __syncthreads();
-            if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported
-                dropped += n_edges;
-                n_edges = 0;
-            } else if (bitmap)
-                coop_edge_write(a.sc, eg, a.st.epool + off, n_edges);
-            else
-                for (uint32_t j = threadIdx.x; j < n_edges; j += 64) a.st.epool[off + j] = eg.edge_ids[j];
-        }
-        if (threadIdx.x == 0) {
-            P.gather_info[w] = make_uint2(off, n_edges);
-            if (dropped && a.count_stats) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, edge_overflow) / sizeof(unsigned long long), (unsigned long long)dropped);
-        }
-        __syncthreads();
-    }
-}
-
-// PASS 0: the round's queue; walks whose classified-edge set needs a wavefront are only queued for k_path_edges.  PASS 1: those walks, with it.
-template <int PASS>
-__device__ inline __attribute__((always_inline)) void path_interact_body(const launch_args_t& a, const path_state_t& P, int in, int first_round, uint32_t round) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = PASS ? ctl[CTL_GATHER_COUNT] : queue_count(ctl, in);
-    if (!PASS && blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
-        ctl[CTL_HEAVY_HEAD] = 0;
-        ctl[CTL_HEAD_TRACE] = 0;
-    }
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    const uint32_t stream = a.sc.opts.integrator == INTEGRATOR_PATH_FORWARD ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK;
-    const utd_pool_t pool{P.utd[round & 1u], ctl + CTL_UTD_COUNT0 + (round & 1u), P.utd_cap};
-    const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
-    for (;;) {
-        const uint32_t qi = wave_grab(ctl + (PASS ? CTL_INTB_HEAD : CTL_HEAD_INTERACT)) + (threadIdx.x & 63);
-        if (qi - (threadIdx.x & 63) >= n) break;
-        bool cont = false, carries_fsd = false, nee = false, gather = false;
-        uint32_t w = 0;
-        if (qi < n) {
-            w = PASS ? a.st.gather_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
-            const uint64_t j = a.j0 + w;
-            const uint32_t pix = (uint32_t)(j % a.npix);
-            const uint64_t s = a.sample_begin + j / a.npix;
-            const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-            path_walk_t pw;
-            soa_load(a.st.walks, a.st.walk_words, w, pw);
-            trav_result_t tr;
-            soa_load(a.st.trav, kTravWords, w, tr);
-            uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
-            const uint_list_t tris{slot, 1u, kMaxConeTris, reinterpret_cast<float*>(slot + kMaxConeTris)};
-            path_defer_t defer;
-            defer.have_prev_f = pw.has_fsd;   // evaluated by k_path_fsd (this round), one lane per wedge
-            defer.prev_f = pw.has_fsd ? P.fsd_f[w] : 0.f;
-            defer.defer_nee = 1;
-            defer.nee_pending = 0;
-            defer.split_gather = PASS ? 0u : 1u;
-            defer.need_gather = 0;
-            defer.has_gather = PASS ? 1u : 0u;
-            defer.gather_n = 0;
-            defer.gather_edges = nullptr;
-            if (PASS) {
-                const uint2 gi = P.gather_info[w];
-                defer.gather_n = gi.y;
-                defer.gather_edges = a.st.epool + gi.x;
-            }
-            cont = path_walk_step(a.sc, pw, tr, tris, prev_pool, pool, a.film, a.seed, sample_id, stream, stack, &ctr, &defer);
-            gather = defer.need_gather != 0;
-            if (!gather) {
-                if (!cont) path_finish(a.sc, a.film, pw);
-                pw.w.active = cont ? 1u : 0u;
-                soa_store(a.st.walks, a.st.walk_words, w, pw);
-                carries_fsd = cont && pw.has_fsd;
-                nee = defer.nee_pending != 0;
-                if (nee) P.nee_recs[w] = defer.nee;
-            }
-        }
-        if (!PASS) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, gather, w);
-        queue_append(a, ctl, 1 - in, cont && !gather, w);
-        wave_append(P.fsdq[(round + 1u) & 1u], ctl + CTL_FSDQ_COUNT0 + ((round + 1u) & 1u), carries_fsd, w);
-        wave_append(P.neeq, ctl + CTL_NEEQ_COUNT, nee, w);
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, const path_state_t* __restrict__ ps, int in, int first_round, uint32_t round) { path_interact_body<0>(a, *ps, in, first_round, round); }
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact_b(launch_args_t a, const path_state_t* __restrict__ ps, int in, uint32_t round) { path_interact_body<1>(a, *ps, in, 0, round); }
-
-// plt_path, after the interaction step: next-event estimation towards the virtual sensor through the aperture the step just built (nee_forward,
-// plt_path_detail.hpp:474-518) — one wavefront per walk: coherent UTD sum (coop_do_fsd), beam transform, integrate_beams, light-image splat.
-__global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, const path_state_t* __restrict__ ps, uint32_t round) {
-    const path_state_t& P = *ps;
-    __shared__ stack_entry_t lds[kLdsStack * 64];
-    __shared__ uint32_t s_item;
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_NEEQ_COUNT];
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack, 64u);
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    const utd_edge_rec_t* cur_pool = P.utd[round & 1u];
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_NEEQ_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
-        if (item >= n) break;
-        const uint32_t w = P.neeq[item];
-        const path_nee_rec_t r = P.nee_recs[w];   // uniform address
-        utd_aperture_t ap;
-        soa_load(a.st.walks + offsetof(path_walk_t, ap) / 4, a.st.walk_words, w, ap);   // the aperture k_path_interact just stored
-        const path_geo_t src_geo{r.src_wp, r.src_kind, r.src_ng, r.src_tuid};
-        const float k = r.beam.k;
-        const float f = coop_do_fsd(a.sc, r.beam.env, src_geo, r.sd_beam.env.o, ap, cur_pool + ap.edge_offset, k, stack, &ctr);
-        if (threadIdx.x == 0 && f != 0.f) {
-            beam_t fsd_beam = r.beam;
-            beam_transform_region_interaction(fsd_beam, r.interaction_wp, r.dist, -r.sd_beam.env.d, f);
-            const stokes_t sL = integrate_beams(r.sd_beam, fsd_beam);
-            film_splat_direct(a.sc, a.film, r.element, sL * r.recp_spectral_pd, k);
-            ctr.connections++;
-            ctr.light_splats++;
-        }
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-
-// walks still active after the last round (iteration cap): backward transport splats what they gathered
-constexpr uint32_t kFlushGrid = 64;
-__global__ void __launch_bounds__(kBlock) k_path_flush(launch_args_t a, int in) {
-    const uint32_t n = queue_count(a.st.ctl, in);
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    for (uint32_t qi = blockIdx.x * kBlock + threadIdx.x; qi < n; qi += kFlushGrid * kBlock) {
-        const uint32_t w = queue_walk(a, a.st.ctl, in, qi, 0);
-        path_walk_t pw;
-        soa_load(a.st.walks, a.st.walk_words, w, pw);
-        path_finish(a.sc, a.film, pw);
-    }
-}
-
-// ---- connections: strategy-major -------------------------------------------------------------------------------------
-// plt_bdpt.cpp:105-146 loops over all (s,t) pairs of a sample.  One thread per sample would leave a wavefront executing the
-// UNION of its 64 samples' pairs (~80 iterations with ~10 lanes' worth of work: subpath lengths are geometric).  Instead:
-//   k_connect_enum  : every sample appends its index to one bucket per valid (s,t) pair (block-aggregated: LDS counts, one global
-//                     atomic per bucket and block),
-//   k_connect_scan  : prefix sum over the 19x19 bucket sizes,
-//   k_connect_strat : persistent; 64 consecutive items of the flattened bucket space = 64 samples with the SAME (s,t): uniform
-//                     control flow, coalesced vertex loads; the t>1 fluxes are summed per sample (f64 atomics), t<=1 strategies
-//                     splat into the light image directly,
-//   k_connect_splat : one film splat per sample with the summed flux (film.hpp:214-342).
-__device__ inline bool strategy_valid(const integrator_opts_t& o, int s, int t, int nS, int nT) {
-    const int depth = t + s - 2;
-    if (t > nT || s > nS) return false;
-    if ((t == 1 && s == 1) || depth < 0 || depth > o.max_depth) return false;
-    if (!o.emitter_direct && s == 1) return false;
-    if (!o.sensor_direct && t == 1) return false;
-    if (o.debug_only_s && (int)o.debug_only_s - 1 != s) return false;
-    if (o.debug_only_t && (int)o.debug_only_t - 1 != t) return false;
-    return true;
-}
-// bucket (sk, tk): does it hold a valid strategy of a sample with nS / nT vertices?  (the last row / column stands for every s / t >= kKeyDim-1)
-__device__ inline bool strategy_class_valid(const integrator_opts_t& o, int sk, int tk, int nS, int nT) {
-    const int K = (int)kKeyDim - 1;
-    const int t1 = tk < K ? tk : nT, s1 = sk < K ? sk : nS;
-    for (int t = tk; t <= t1; ++t)
-        for (int s = sk; s <= s1; ++s)
-            if (strategy_valid(o, s, t, nS, nT)) return true;
-    return false;
-}
-__device__ inline int wave_max_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-// Block-aggregated bucket append: 1024 samples per block count their valid (s,t) pairs per bucket in LDS, reserve one range per
-// bucket with ONE global atomic each, and fill it.  (Wave-aggregated global atomics on the ~30 hot bucket counters serialised in
-// L2: PMC SQ_WAIT_ANY 99 % of this kernel's wave cycles, 9.5 ms per pass.)
-constexpr int kEnumBlock = 1024;
-__global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
-    __shared__ uint32_t s_cnt[kNumKeys], s_base[kNumKeys];
-    const uint32_t i = blockIdx.x * kEnumBlock + threadIdx.x;
-    const size_t W2 = 2 * (size_t)a.st.cap;
-    for (uint32_t k = threadIdx.x; k < kNumKeys; k += kEnumBlock) s_cnt[k] = 0;
-    int nT = -1, nS = -1;
-    if (i < a.nb) {
-        nT = (int)a.st.walks[(size_t)(i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
-        nS = (int)a.st.walks[(size_t)(a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a.st.lacc[(size_t)c * a.st.cap + i] = 0.0;
-    }
-    __syncthreads();
-    const int K = (int)kKeyDim - 1;
-    const int kT = nT < K ? nT : K, kS = nS < K ? nS : K;
-    for (int tk = 0; tk <= kT; ++tk)
-        for (int sk = 0; sk <= kS; ++sk)
-            if (strategy_class_valid(a.sc.opts, sk, tk, nS, nT)) atomicAdd(&s_cnt[(uint32_t)tk * kKeyDim + (uint32_t)sk], 1u);
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kNumKeys; k += kEnumBlock) {
-        const uint32_t c = s_cnt[k];
-        s_base[k] = c ? atomicAdd(a.st.strat_count + k, c) : 0u;
-        s_cnt[k] = 0;
-    }
-    __syncthreads();
-    for (int tk = 0; tk <= kT; ++tk)
-        for (int sk = 0; sk <= kS; ++sk)
-            if (strategy_class_valid(a.sc.opts, sk, tk, nS, nT)) {
-                const uint32_t key = (uint32_t)tk * kKeyDim + (uint32_t)sk;
-                a.st.strat_items[(size_t)key * a.st.cap + s_base[key] + atomicAdd(&s_cnt[key], 1u)] = i;
-            }
-}
-__global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < kNumKeys; ++k) {
-            const uint32_t c = a.st.strat_count[k];
-            a.st.strat_prefix[k] = acc;
-            acc += c;
-            a.st.strat_count[k] = 0;   // ready for the next batch
-        }
-        a.st.strat_prefix[kNumKeys] = acc;
-        a.st.ctl[CTL_STRAT_HEAD] = 0;
-        a.st.ctl[CTL_STRAT_HEAD_OPEN] = 0;
-    }
-}
-// OPEN = false: the buckets with one strategy each (all of them while no subpath exceeds 17 vertices).  OPEN = true (k_connect_strat_open): the
-// buckets of the last row / column, whose items loop over every longer strategy of their sample — a kernel of its own so that the loop and
-// the subpath lengths it needs do not weigh on the common case's registers.
-template <bool OPEN>
-__device__ inline __attribute__((always_inline)) void connect_strat_body(const launch_args_t& a) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    __shared__ uint32_t s_prefix[kNumKeys + 1];
-    constexpr int K = (int)kKeyDim - 1;
-    // flattened item space: OPEN = false all buckets (items of the open ones are skipped), OPEN = true the open buckets only
-    if (!OPEN) {
-        for (uint32_t k = threadIdx.x; k <= kNumKeys; k += kBlock) s_prefix[k] = a.st.strat_prefix[k];
-    } else if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < kNumKeys; ++k) {
-            s_prefix[k] = acc;
-            if ((int)(k / kKeyDim) == K || (int)(k % kKeyDim) == K) acc += a.st.strat_prefix[k + 1] - a.st.strat_prefix[k];
-        }
-        s_prefix[kNumKeys] = acc;
-    }
-    __syncthreads();
-    const uint32_t total = s_prefix[kNumKeys];
-    bdpt_counters_t ctr;
-    memset(&ctr, 0, sizeof(ctr));
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap, a.st.ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
-    for (;;) {
-        const uint32_t idx = wave_grab(a.st.ctl + (OPEN ? CTL_STRAT_HEAD_OPEN : CTL_STRAT_HEAD)) + (threadIdx.x & 63);
-        if (idx - (threadIdx.x & 63) >= total) break;
-        if (idx < total) {
-            // bucket of this item: last key with prefix <= idx
-            uint32_t lo = 0, hi = kNumKeys;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_prefix[mid] <= idx)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const uint32_t key = lo;
-            const int tk = (int)(key / kKeyDim), sk = (int)(key % kKeyDim);
-            if (!OPEN && (tk == K || sk == K)) continue;   // (k_connect_strat_open's)
-            const uint32_t i = a.st.strat_items[(size_t)key * a.st.cap + (idx - s_prefix[key])];
-            const uint64_t j = a.j0 + i;
-            const uint32_t pix = (uint32_t)(j % a.npix);
-            const uint64_t smp = a.sample_begin + j / a.npix;
-            const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
-            sample_ctx_t ctx;
-            soa_load(a.st.ctx, kCtxWords, i, ctx);
-            const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
-            auto one = [&](int s, int t) __attribute__((always_inline)) {
-                const stokes_t flux = bdpt_strategy(a.sc, pool, a.film, svs, evs, s, t, ctx, a.seed, sample_id, stack, &ctr, nullptr);
-                if (t > 1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
-                }
-            };
-            if constexpr (!OPEN) {
-                one(sk, tk);
-            } else {
-                const int nT = (int)a.st.walks[(size_t)i * a.st.walk_words + WT_WALK_NVERTS_WORD];
-                const int nS = (int)a.st.walks[((size_t)a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
-                const int t1 = tk == K ? nT : tk, s1 = sk == K ? nS : sk;
-                for (int t = tk; t <= t1; ++t)
-                    for (int s = sk; s <= s1; ++s)
-                        if (strategy_valid(a.sc.opts, s, t, nS, nT)) one(s, t);
-            }
-        }
-    }
-    if (a.count_stats) flush_counters(a.st.counters, ctr);
-}
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(launch_args_t a) { connect_strat_body<false>(a); }
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat_open(launch_args_t a) { connect_strat_body<true>(a); }
-__global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.nb) return;
-    sample_ctx_t ctx;
-    soa_load(a.st.ctx, kCtxWords, i, ctx);
-    stokes_t L;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) L.s[c] = (float)a.st.lacc[(size_t)c * a.st.cap + i];
-    film_splat(a.sc, a.film, ctx.element, L, ctx.k);
-}
-
-// The same splat for batches that cover (most of) the film: one block per 128-element row segment accumulates the footprints of its
-// elements' samples in an LDS tile (3 rows x 130 columns x (planes + 1) f64, plane-major) and adds the tile to the film once.  Per sample the
-// plain kernel issues 9 x (planes + 1) f64 atomics on addresses its neighbours in the wavefront hit too — 117 for the Stokes film of the
-// polarimetric workload, where it took 19.7 ms of a 204-ms batch (run r4t) — the tile turns them into LDS atomics and one global add per tile
-// entry.  Same weights, same products, f64 sums in another order.  Reconstruction-filter radius <= 1 (the host launches the plain kernel
-// otherwise); a sample whose element is not where the block expects it (never, for the sensors built so far) goes to the film directly.
-constexpr uint32_t kSplatCols = kBlock + 2;
-__global__ void __launch_bounds__(kBlock) k_connect_splat_tiled(launch_args_t a) {
-    extern __shared__ double tile[];   // [planes + 1][3][kSplatCols]
-    const sensor_t& sn = a.sc.sensor;
-    const uint32_t W = a.film.width, H = a.film.height;
-    const uint32_t S = film_stokes(sn), P = sn.channels * S, PL = P + 1;
-    const uint32_t bpr = (W + kBlock - 1) / kBlock;
-    const uint32_t row = blockIdx.x / bpr, x0 = (blockIdx.x % bpr) * kBlock;
-    const int r = sn.rf_radius;
-    const uint32_t n_px = 3 * kSplatCols;
-    for (uint32_t q = threadIdx.x; q < n_px * PL; q += kBlock) tile[q] = 0.0;
-    __syncthreads();
-    const uint32_t x = x0 + threadIdx.x;
-    if (x < W && row < H) {
-        const uint64_t p = (uint64_t)row * W + x;
-        // the samples of this batch that belong to element p: work items i with (j0 + i) % npix == p
-        const uint64_t first = (p + a.npix - (a.j0 % a.npix)) % a.npix;
-        for (uint64_t i = first; i < a.nb; i += a.npix) {
-            sample_ctx_t ctx;
-            soa_load(a.st.ctx, kCtxWords, i, ctx);
-            stokes_t L;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) L.s[c] = (float)a.st.lacc[(size_t)c * a.st.cap + i];
-            // (what follows is film_splat, wt/film.h, with the tile in place of the film)
-            const rfilter_weights_t rw = film_rfilter_weights(sn, ctx.element.offset);
-            float val[16];
-            for (uint32_t c = 0; c < sn.channels; ++c) {
-                const float f = spectrum_f(a.sc, sn.response_spec[c], ctx.k);
-                bool ok = true;
-                for (uint32_t q = 0; q < S; ++q) {
-                    val[c * S + q] = L.s[q] * f;
-                    ok = ok && finitef(val[c * S + q]);
-                }
-                ok = ok && val[c * S] >= 0.f;
-                if (!ok)
-                    for (uint32_t q = 0; q < S; ++q) val[c * S + q] = 0.f;
-            }
-            for (int dy = -r; dy <= r; ++dy) {
-                const int y = (int)ctx.element.y + dy;
-                if (y < 0 || y >= (int)H) continue;
-                for (int dx = -r; dx <= r; ++dx) {
-                    const int xx = (int)ctx.element.x + dx;
-                    if (xx < 0 || xx >= (int)W) continue;
-                    const float w = fmaxf_(0.f, rw.wx[dx + r] * rw.wy[dy + r]) * rw.recp_total;
-                    const int ty = y - ((int)row - 1), tx = xx - ((int)x0 - 1);
-                    if (ty >= 0 && ty < 3 && tx >= 0 && tx < (int)kSplatCols) {
-                        const uint32_t q = (uint32_t)ty * kSplatCols + (uint32_t)tx;
-                        unsafeAtomicAdd(&tile[q], (double)w);
-                        for (uint32_t c = 0; c < P; ++c) unsafeAtomicAdd(&tile[(size_t)(1 + c) * n_px + q], (double)(w * val[c]));
-                    } else {
-                        const size_t pix = (size_t)y * W + xx;
-                        film_add(&a.film.weight[pix], (double)w);
-                        for (uint32_t c = 0; c < P; ++c) film_add(&a.film.value[pix * P + c], (double)(w * val[c]));
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t q = threadIdx.x; q < n_px; q += kBlock) {
-        const int y = (int)row - 1 + (int)(q / kSplatCols), xx = (int)x0 - 1 + (int)(q % kSplatCols);
-        if (y < 0 || y >= (int)H || xx < 0 || xx >= (int)W) continue;
-        const size_t pix = (size_t)y * W + xx;
-        const double wsum = tile[q];
-        if (wsum != 0.0) film_add(&a.film.weight[pix], wsum);
-        for (uint32_t c = 0; c < P; ++c) {
-            const double v = tile[(size_t)(1 + c) * n_px + q];
-            if (v != 0.0) film_add(&a.film.value[pix * P + c], v);
-        }
-    }
-}
-
-// ---- PMC calibration: a streaming copy with the access width of the SoA state (one dword per lane, fully coalesced) and a known
-// byte count, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled to bytes for THIS access pattern (tools/profile_round.sh)
-__global__ void __launch_bounds__(256) k_calib_copy(const uint32_t* in, uint32_t* out, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i] + 1u;
-}
-
-// ---- per-query kernels (traversal parity tests) --------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_trace_rays(scene_t sc, const float* rays, uint32_t n, float* dist, uint32_t* tuid, float* bary, uint32_t* front) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    stack_entry_t spill[kSpillStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    const float* r = rays + 8 * (size_t)i;
-    ray_hit_t h;
-    ads_intersect_ray(sc, vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, range_t{r[6], r[7]}, stack, h);
-    dist[i] = h.dist;
-    tuid[i] = h.tuid;
-    bary[2 * i] = h.bx;
-    bary[2 * i + 1] = h.by;
-    front[i] = h.front_face;
-}
-__global__ void __launch_bounds__(kBlock) k_traverse_cones(scene_t sc, const float* cones, uint32_t n, uint32_t cap, float* dist, uint32_t* flags,
-                                                           uint32_t* ntris, uint32_t* out_tris, uint32_t* scratch_tris) {
-    __shared__ stack_entry_t lds[kLdsStack * kBlock];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    // (the CPU checker's 128-entry stack: this kernel answers every query by itself — in the pipeline a lane whose 64-entry stack
-    // fills up hands the query to a wavefront, k_trace_heavy)
-    stack_entry_t spill[128 - kLdsStack];
-    stack_ref_t stack;
-    lds_stack(lds, spill, stack);
-    stack.cap = 128;
-    const float* c = cones + 10 * (size_t)i;
-    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
-    const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
-    const uint_list_t tris{scratch_tris + i, n, kMaxConeTris, reinterpret_cast<float*>(scratch_tris + (size_t)n * kMaxConeTris) + i};
-    const trav_result_t tr = traverse(sc, env, c[9], WT_INF, false, stack, tris);
-    dist[i] = tr.dist;
-    flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
-    ntris[i] = tr.ballistic ? (tr.empty ? 0 : 1) : tr.ntris;
-    for (uint32_t j = 0; j < cap; ++j) out_tris[(size_t)i * cap + j] = kInvalid;
-    if (tr.ballistic) {
-        if (!tr.empty) out_tris[(size_t)i * cap] = tr.tuid;
-    } else {
-        // insertion sort of the (short) list into the output
-        uint32_t m = 0;
-        for (uint32_t j = 0; j < tr.ntris; ++j) {
-            const uint32_t v = tris[j];
-            uint32_t pos = m < cap ? m : cap;
-            while (pos > 0 && out_tris[(size_t)i * cap + pos - 1] > v) {
-                if (pos < cap) out_tris[(size_t)i * cap + pos] = out_tris[(size_t)i * cap + pos - 1];
-                --pos;
-            }
-            if (pos < cap) out_tris[(size_t)i * cap + pos] = v;
-            if (m < cap) ++m;
-        }
-    }
-}
-
-// Region summaries of cone queries of ANY size (parity tests of the whole-region machinery): one wavefront per cone runs the
-// traversal policy with closest-hit-only cone queries, then — for a diffusive hit — resolves the triangle under the axis and walks
-// the region [dist, dist + 2 x major axis] for its triangle count, sorted classified-edge set and intercepted power (sigma = axes/3).
-__global__ void __launch_bounds__(64) k_query_regions(scene_t sc, const float* cones, uint32_t n, uint32_t edge_cap, float* dist, uint32_t* flags,
-                                                      uint32_t* primary, uint32_t* ntris, uint32_t* nedges, uint32_t* edges, float* flux, unsigned long long* dropped) {
-    __shared__ coop_shared_t sh;
-    __shared__ coop_gather_shared_t gsh;
-    __shared__ coop_edges_t eg;
-    coop_set_dropped_counter(sh, dropped);
-    coop_set_dropped_counter(gsh, dropped);
-    const uint32_t i = blockIdx.x;
-    if (i >= n) return;
-    const float* c = cones + 10 * (size_t)i;
-    const vec3 d = normalize(vec3{c[3], c[4], c[5]});
-    const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
-    const uint_list_t none{nullptr, 1u, 0u};
-    const trav_result_t tr = coop_traverse(sc, env, c[9], WT_INF, false, sh, none, nullptr, false, 0, 0.f, 0, 0, nullptr, true);
-    uint32_t prim = kInvalid;
-    gather_out_t ge{0.0, 0u, 0u, 0u}, gf{0.0, 0u, 0u, 0u};
-    if (tr.ballistic) {
-        prim = tr.tuid;
-    } else if (!tr.empty) {
-        const range_t izr{tr.dist, tr.dist + tr.region_depth};
-        prim = tr.tuid;   // primary_from_axis (kInvalid: the axis misses the region)
-        const vec2 ax = cone_axes(env, tr.dist);
-        ge = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{1.f, 1.f}, false, gsh, false, true, nullptr, 1, &eg);
-        __syncthreads();
-        if (sc.n_edges <= kCoopEdgeBits) {
-            ge.n_edges = coop_edge_count(sc, eg);
-            coop_edge_write(sc, eg, edges + (size_t)i * edge_cap, edge_cap);
-        } else
-            for (uint32_t j = threadIdx.x; j < ge.n_edges && j < edge_cap; j += 64) edges[(size_t)i * edge_cap + j] = eg.edge_ids[j];
-        __syncthreads();
-        gf = coop_gather(sc, env, izr, env, cone_frame(env), izr, vec2{ax.x / kBeamEnvelope, ax.y / kBeamEnvelope}, tr.front_face != 0, gsh, true, false);
-    }
-    if (threadIdx.x == 0) {
-        dist[i] = tr.dist;
-        flags[i] = (tr.empty ? 1u : 0u) | (tr.ballistic ? 2u : 0u) | (tr.front_face ? 4u : 0u);
-        primary[i] = prim;
-        ntris[i] = gf.n_tris;
-        nedges[i] = ge.n_edges + ge.edge_overflow;
-        flux[i] = (float)gf.flux;
-    }
-}
 
 template <class T>
 int upload(wtgpu_scene* s, const T* src, size_t n, const T** dst) {
