@@ -50,6 +50,13 @@ int g_traverse_axis = 0;   // oracle_traverse_cones: run the device form of the 
 // 2: without the remembered triangles, 3: without the early exit either, 4: like 1 with a work budget of 12 units per cone query and
 // the over-budget queries resumed from their hand-over record (what the device's tiers do).
 int g_walk_axis = 0;
+// 1 / 2: surface interactions through the device's material-sorted pass A (wt/bdpt.h: bdpt_classify + bdpt_surface_step; 1 = the class-agnostic
+// instantiation, 2 = one instantiation per material class, as the class kernels run it) instead of bdpt_walk_step's surface branch.  The
+// results must be identical (tests/test_oracle.py::test_split_surface_step_is_the_walk_step).
+int g_split_step = 0;
+// 1: every (s,t) strategy the way the device's staged connection kernels run it (wt/bdpt.h: bdpt_strategy<true> — flux without the shadow ray, the
+// ray, MIS + splat with the temporary vertex formed again).  The results must be identical (test_staged_connections_are_the_connections).
+int g_staged_connect = 0;
 
 void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
     unsigned long long* pa = reinterpret_cast<unsigned long long*>(&a);
@@ -75,6 +82,28 @@ void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_
         ctr.ray_queries += tr.n_ray_queries;
         ctr.cone_queries += tr.n_cone_queries;
         ctr.cone_tri_overflow += tr.overflow;
+        if (g_split_step) {
+            primary_hit_t ph;
+            const uint32_t cls = bdpt_classify(sc, w.beam.env.d, beam_is_ray(w.beam), tr, tris, nullptr, ph);
+            if (cls == WCLS_END) {
+                w.active = 0;
+                continue;
+            }
+            if (cls != WCLS_NO_PRIMARY) {
+                const walk_rec_t wr{reinterpret_cast<uint32_t*>(&w)};
+                bool cont;
+                if (g_split_step == 2 && cls == WCLS_DIFFUSE)
+                    cont = bdpt_surface_step<MAT_DIFFUSE>(sc, wr, tr.origin, tr.dist, ph, vs, seed, sample_id, stream, &ctr);
+                else if (g_split_step == 2 && cls == WCLS_DIELECTRIC)
+                    cont = bdpt_surface_step<MAT_DIELECTRIC>(sc, wr, tr.origin, tr.dist, ph, vs, seed, sample_id, stream, &ctr);
+                else if (g_split_step == 2 && cls == WCLS_SPM)
+                    cont = bdpt_surface_step<MAT_SURFACE_SPM>(sc, wr, tr.origin, tr.dist, ph, vs, seed, sample_id, stream, &ctr);
+                else
+                    cont = bdpt_surface_step<-1>(sc, wr, tr.origin, tr.dist, ph, vs, seed, sample_id, stream, &ctr);
+                w.active = cont ? 1u : 0u;
+                continue;
+            }
+        }
         w.active = bdpt_walk_step(sc, w, tr, tris, vs, pool, seed, sample_id, stream, &ctr) ? 1u : 0u;
     }
     w.active = 0;
@@ -161,7 +190,10 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
                         bdpt_generate(sc, seed, sample_id, x, y, ctx, sw, ew, svs, evs);
                         run_walk(sc, sw, svs, pool, seed, sample_id, STREAM_SENSOR_WALK, scr, ctr);
                         run_walk(sc, ew, evs, pool, seed, sample_id, STREAM_EMITTER_WALK, scr, ctr);
-                        bdpt_connect_all(sc, pool, film, svs, evs, (int)sw.nverts, (int)ew.nverts, ctx, seed, sample_id, stack, &ctr, nullptr);
+                        if (g_staged_connect)
+                            bdpt_connect_all<true>(sc, pool, film, svs, evs, (int)sw.nverts, (int)ew.nverts, ctx, seed, sample_id, stack, &ctr, nullptr);
+                        else
+                            bdpt_connect_all(sc, pool, film, svs, evs, (int)sw.nverts, (int)ew.nverts, ctx, seed, sample_id, stack, &ctr, nullptr);
                     }
         }
     };
@@ -412,6 +444,8 @@ int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n
 void oracle_set_region_filter(int on) { g_region_filter = on; }
 void oracle_set_traverse_axis(int on) { g_traverse_axis = on; }
 void oracle_set_walk_axis(int on) { g_walk_axis = on; }
+void oracle_set_split_step(int mode) { g_split_step = mode; }
+void oracle_set_staged_connect(int on) { g_staged_connect = on; }
 
 // Region summaries of cone queries of any size: what the reference's unbounded intersection record yields (`list`: every triangle
 // the sequential traversal met, traversal_common.hpp:124-148) next to a brute-force scan of ALL scene triangles against the final

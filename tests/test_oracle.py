@@ -301,3 +301,47 @@ def test_device_traversal_policy_renders_identically(built, name, kw, spp, mode)
         if k != "ray_queries":
             assert ref[3][k] == dev[3][k], k
     assert dev[3]["ray_queries"] == dev[3]["segments"]
+
+
+@pytest.mark.parametrize("name,kw,spp", [("cornell_box", dict(res=48, mesh_detail=1), 2), ("furnace", dict(res=24, fsd=1), 4), ("double_slits", dict(res=96, lut=(64, 64)), 2),
+                                         ("bidir_room", dict(res=48), 2), ("furnace_wall_mask", dict(res=16), 4), ("furnace_wall_composite", dict(res=16), 4), ("tex_normal_tilt", dict(res=24), 4),
+                                         ("furnace_spm", dict(res=24), 4), ("etoile_bdpt", dict(res=32, mesh_detail=0), 4)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_split_surface_step_is_the_walk_step(built, name, kw, spp, mode):
+    """The device's material-sorted pass A (wt/bdpt.h: bdpt_classify + bdpt_surface_step — the walk record read and written field by field,
+    the vertex written as its parts become known, one instantiation per material class) against the surface branch of bdpt_walk_step, over
+    whole renders: every film value bit for bit and every counter.  mode 1: the class-agnostic instantiation for every walk; mode 2: walks
+    on unwrapped diffuse / dielectric / surface_spm materials through their class's instantiation."""
+    lib = load_oracle()
+    sc = _scene(name, **kw)
+    ref = oracle_render(sc, 0, spp, 7, threads=1)
+    lib.oracle_set_split_step(mode)
+    try:
+        dev = oracle_render(sc, 0, spp, 7, threads=1)
+    finally:
+        lib.oracle_set_split_step(0)
+    for a, b in zip(ref[:3], dev[:3]):
+        assert np.array_equal(a, b)
+    assert ref[0].sum() + ref[2].sum() > 0 and ref[3]["surface_interactions"] > 100
+    assert ref[3] == dev[3]
+
+
+@pytest.mark.parametrize("name,kw,spp", [("cornell_box", dict(res=48, mesh_detail=1), 2), ("furnace", dict(res=24, fsd=1), 4), ("double_slits", dict(res=96, lut=(64, 64)), 2),
+                                         ("bidir_room", dict(res=48), 2), ("furnace_wall_mask", dict(res=16), 4), ("etoile_bdpt", dict(res=32, mesh_detail=0), 4),
+                                         ("sunlit", dict(res=24), 4), ("furnace_spm", dict(res=24), 4)])
+def test_staged_connections_are_the_connections(built, name, kw, spp):
+    """The device's staged connections (wt/bdpt.h: bdpt_connect<true> hands the shadow ray out instead of tracing it; the ray is traced by a
+    kernel of its own; MIS weight and splat follow with the temporary vertex of the s = 1 / t = 1 / virtual-sensor strategies formed again
+    from the same random numbers) against connect_subpaths as one piece, over whole renders: every film value bit for bit, every counter."""
+    lib = load_oracle()
+    sc = _scene(name, **kw)
+    ref = oracle_render(sc, 0, spp, 7, threads=1)
+    lib.oracle_set_staged_connect(1)
+    try:
+        dev = oracle_render(sc, 0, spp, 7, threads=1)
+    finally:
+        lib.oracle_set_staged_connect(0)
+    for a, b in zip(ref[:3], dev[:3]):
+        assert np.array_equal(a, b)
+    assert ref[0].sum() + ref[2].sum() > 0 and ref[3]["connections"] > 100
+    assert ref[3] == dev[3]

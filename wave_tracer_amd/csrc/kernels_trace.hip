@@ -56,6 +56,8 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
         ctl[CTL_EPOOL_COUNT] = 0;
         ctl[CTL_INTD_COUNT] = 0;
         ctl[CTL_INTD_HEAD] = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < kNumWalkClasses; ++c) ctl[CTL_CLS_COUNT0 + c] = ctl[CTL_CLS_HEAD0 + c] = 0;   // the class queues of this round's pass A
         // plt_path: this round's wedge pool and the queue it fills for the next round's k_path_fsd; this round's k_path_fsd / k_path_nee heads
         ctl[CTL_UTD_COUNT0 + (round & 1u)] = 0;
         ctl[CTL_FSDQ_COUNT0 + ((round + 1u) & 1u)] = 0;

@@ -117,6 +117,108 @@ __device__ inline __attribute__((always_inline)) void interact_body(const launch
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
+// ---- pass A, material-sorted (the default; k_interact, one kernel for every walk, stays as the A/B reference: WTGPU_SORTED_INTERACT=0) ------------------------------
+// k_classify (lane / walk of the round's queue): the primary triangle (wt/bdpt.h: bdpt_classify — ballistic hit, the trace kernels' axis hit of an
+// overflowed region, or a scan of the region's list) goes back into the walk's traversal record, and the walk goes into the queue of its CLASS — the
+// BSDF type of the hit shape's material (one byte per triangle, built at upload), WCLS_ANY for wrapped materials — or, without a primary triangle,
+// into pass B's queue (and k_edges').  41 registers, no frame: the dependent loads of this part (record -> list -> triangles) run at full occupancy.
+// k_interact_<class> (lane / walk of one class queue): bdpt_surface_step<CLS> — one BSDF's code per kernel (src/bsdf/diffuse.cpp:23-71,
+// dielectric.cpp:26-72, surface_spm.cpp:40-201), the walk record and the new vertex read / written field by field.
+__global__ void __launch_bounds__(kBlock) k_classify(launch_args_t a, int in, int first_round) {
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = queue_count(ctl, in);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl[CTL_HEAVY_COUNT] = 0;   // for the next round's k_trace
+        ctl[CTL_HEAVY_HEAD] = 0;
+        ctl[CTL_HEAD_TRACE] = 0;
+    }
+    const bdpt_ext_t& x = *a.st.ext;
+    const size_t W2 = 2 * (size_t)a.st.cap;
+    for (;;) {
+        const uint32_t qi = wave_grab(ctl + CTL_HEAD_INTERACT) + (threadIdx.x & 63);
+        if (qi - (threadIdx.x & 63) >= n) break;
+        uint32_t cls = WCLS_END, w = 0;
+        bool need_gather = false;
+        if (qi < n) {
+            w = queue_walk(a, ctl, in, qi, first_round);
+            trav_result_t tr;
+            soa_load(a.st.trav, kTravWords, w, tr);
+            const uint32_t* wp = a.st.walks + (size_t)w * a.st.walk_words;
+            const vec3 d{__uint_as_float(wp[WT_WALK_WORD(beam.env.d.x)]), __uint_as_float(wp[WT_WALK_WORD(beam.env.d.y)]), __uint_as_float(wp[WT_WALK_WORD(beam.env.d.z)])};
+            const bool beam_ray = __uint_as_float(wp[WT_WALK_WORD(beam.env.tan_alpha)]) == 0.f && __uint_as_float(wp[WT_WALK_WORD(beam.env.x0)]) == 0.f;
+            const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
+            primary_hit_t ph;
+            cls = bdpt_classify(a.sc, d, beam_ray, tr, tris, x.tri_class, ph);
+            if (cls < kNumWalkClasses) {
+                uint32_t* tv = a.st.trav + (size_t)w * kTravWords;
+                tv[WT_TRAV_WORD(tuid)] = ph.tuid;
+                tv[WT_TRAV_WORD(bx)] = __float_as_uint(ph.bx);
+                tv[WT_TRAV_WORD(by)] = __float_as_uint(ph.by);
+                tv[WT_TRAV_WORD(pdist)] = __float_as_uint(ph.dist);
+            }
+            // a region that did not fit the bounded list (or whose list holds more than kMaxEdgeIds / 3 triangles): its edge set comes from k_edges
+            need_gather = cls == WCLS_NO_PRIMARY && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list);
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < kNumWalkClasses; ++c) wave_append(x.cls_queue + (size_t)c * W2, ctl + CTL_CLS_COUNT0 + c, cls == c, w);
+        wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, cls == WCLS_NO_PRIMARY, w);
+        wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
+    }
+}
+template <int CLS>
+__device__ inline __attribute__((always_inline)) void interact_cls_body(const launch_args_t& a, int in) {
+    constexpr uint32_t cls = CLS < 0 ? (uint32_t)WCLS_ANY : (uint32_t)CLS;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_CLS_COUNT0 + cls];
+    const uint32_t* queue = a.st.ext->cls_queue + (size_t)cls * 2 * (size_t)a.st.cap;
+    bdpt_counters_t ctr;
+    ctr.surface_interactions = ctr.vertices = 0;
+    for (;;) {
+        const uint32_t qi = wave_grab(ctl + CTL_CLS_HEAD0 + cls) + (threadIdx.x & 63);
+        if (qi - (threadIdx.x & 63) >= n) break;
+        bool cont = false;
+        uint32_t w = 0;
+        if (qi < n) {
+            w = queue[qi];
+            uint32_t i, stream;
+            walk_ident(a, w, i, stream);
+            const uint64_t j = a.j0 + i;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t s = a.sample_begin + j / a.npix;
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
+            const uint32_t* tv = a.st.trav + (size_t)w * kTravWords;
+            const vec3 origin{__uint_as_float(tv[WT_TRAV_WORD(origin.x)]), __uint_as_float(tv[WT_TRAV_WORD(origin.y)]), __uint_as_float(tv[WT_TRAV_WORD(origin.z)])};
+            const float beam_dist = __uint_as_float(tv[WT_TRAV_WORD(dist)]);
+            const primary_hit_t ph{tv[WT_TRAV_WORD(tuid)], __uint_as_float(tv[WT_TRAV_WORD(pdist)]), __uint_as_float(tv[WT_TRAV_WORD(bx)]), __uint_as_float(tv[WT_TRAV_WORD(by)])};
+            const walk_rec_t wr{a.st.walks + (size_t)w * a.st.walk_words};
+            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
+            cont = bdpt_surface_step<CLS>(a.sc, wr, origin, beam_dist, ph, vs, a.seed, sample_id, stream, &ctr);
+        }
+        queue_append(a, ctl, 1 - in, cont, w);
+    }
+    if (a.count_stats) {
+        unsigned long long vsi = ctr.surface_interactions, vv = ctr.vertices;
+        for (int off = 32; off > 0; off >>= 1) {
+            vsi += __shfl_down(vsi, off, 64);
+            vv += __shfl_down(vv, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (vsi) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, surface_interactions) / sizeof(unsigned long long), vsi);
+            if (vv) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, vertices) / sizeof(unsigned long long), vv);
+        }
+    }
+}
+#ifndef WTGPU_LB_CLS
+#define WTGPU_LB_CLS 4
+#endif
+#ifndef WTGPU_LB_CLS_SPM
+#define WTGPU_LB_CLS_SPM 3
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS) k_interact_diffuse(launch_args_t a, int in) { interact_cls_body<MAT_DIFFUSE>(a, in); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS) k_interact_dielectric(launch_args_t a, int in) { interact_cls_body<MAT_DIELECTRIC>(a, in); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS_SPM) k_interact_spm(launch_args_t a, int in) { interact_cls_body<MAT_SURFACE_SPM>(a, in); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS_SPM) k_interact_any(launch_args_t a, int in) { interact_cls_body<-1>(a, in); }
+
 // The classified-edge set of the interaction regions that overflowed the bounded triangle list: the WHOLE region, whatever its
 // triangle count — the reference's unbounded std::vector (include/wt/ads/traversal_common.hpp:124-148).  One wavefront per walk
 // (coop_gather, edges only): only subtrees that hold classified edges are entered and only edge-bearing triangles are tested, 64 at

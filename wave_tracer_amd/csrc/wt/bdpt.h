@@ -272,18 +272,19 @@ WT_HD float vertex_pdf(const scene_t& sc, const fsd_pool_t& pool, const V& v, ve
 }
 
 // vertex_t::interact (vertex.hpp:330-413): beam arriving at `v` transformed towards `next`.
-WT_HD bool vertex_interact(const scene_t& sc, const fsd_pool_t& pool, const vertex_t& v, const vertex_t& next, bool ignore_fsd, beam_t& out) {
+// (of `next` only its position matters)
+WT_HD bool vertex_interact(const scene_t& sc, const fsd_pool_t& pool, const vertex_t& v, vec3 next_wp, bool ignore_fsd, beam_t& out) {
     const vec3 wiworld = -v.beam.env.d;
     const float k = v.beam.k;
     float f = 0.f;
     if (v.fraunhofer_fsd && !ignore_fsd) {
         const fsd_aperture_t ap = pool.hdr[v.fsd_slot];
-        const vec3 woworld = normalize(vertex_wp(next) - vertex_wp(v));
+        const vec3 woworld = normalize(next_wp - vertex_wp(v));
         f = fsd_pdf(ap, fsd_pool_edges(pool, v.fsd_slot), to_local(ap.frame, woworld));
     }
     if (v.type == VT_SURFACE) {
         const surface_t& srf = v.surf;
-        const vec3 woworld = normalize(vertex_wp(next) - vertex_wp(v));
+        const vec3 woworld = normalize(next_wp - vertex_wp(v));
         const vec3 wi = to_local(srf.shading, wiworld), wo = to_local(srf.shading, woworld);
         const vec3 ng = srf.geo.n, ns = srf.shading.n;
         const float wig = dot(wiworld, ng), wog = dot(woworld, ng);
@@ -302,7 +303,7 @@ WT_HD bool vertex_interact(const scene_t& sc, const fsd_pool_t& pool, const vert
     if (v.type == VT_FSD) {
         const vec3 p = vertex_wp(v);
         const float beam_dist = dot(p - v.beam.env.o, v.beam.env.d);
-        const vec3 woworld = normalize(vertex_wp(next) - p);
+        const vec3 woworld = normalize(next_wp - p);
         out = v.beam;
         beam_transform_region_interaction(out, p, beam_dist, woworld, f);
         return true;
@@ -310,15 +311,37 @@ WT_HD bool vertex_interact(const scene_t& sc, const fsd_pool_t& pool, const vert
     return false;
 }
 
-// integrator::shadow (traversal.hpp:319-333): TRUE if occluded
-WT_HD bool bdpt_shadow(const scene_t& sc, const vertex_t& a, const vertex_t& b, const stack_ref_t& stack, bvh_counters_t* ctr) {
-    const vec3 start_wp = vertex_wp(a), end_wp = vertex_wp(b);
-    const vec3 rd = normalize(end_wp - start_wp);
-    const vec3 o = geo_offseted_ray_origin(sc, a, start_wp, rd);
-    const vec3 t = geo_offseted_ray_origin(sc, b, end_wp, -rd);
+// integrator::shadow (traversal.hpp:319-333).  What the ray between two path vertices needs of them: position and, for a vertex on a
+// surface, the triangle and geometric normal of its self-intersection offset (intersection.cpp:148-185).
+struct conn_end_t {
+    vec3 wp, ng;
+    uint32_t geo_kind, tuid;
+};
+template <class V>
+WT_HD conn_end_t conn_end_of(const V& v) { return conn_end_t{v.surf.wp, v.surf.geo.n, v.geo_kind, v.surf.tuid}; }
+WT_HD vec3 conn_end_offseted_origin(const scene_t& sc, const conn_end_t& e, vec3 ro, vec3 rd) {   // (geo_offseted_ray_origin / surface_offseted_ray_origin)
+    if (e.geo_kind != GEO_SURFACE || e.tuid == kInvalid) return ro;
+    const tri_geo_t g = sc.tri_geo[e.tuid];
+    const vec3 err = triangle_fp_errors(g.a, g.b, g.c, ro);
+    const float offset_dist = dot(err, vabs(e.ng));
+    const vec3 offset = offset_dist * e.ng;
+    return ro + (dot(rd, offset) >= 0.f ? offset : -offset);
+}
+struct shadow_ray_t {
+    vec3 o, d;
+    float dist;
+};
+WT_HD shadow_ray_t conn_shadow_ray(const scene_t& sc, const conn_end_t& a, const conn_end_t& b) {
+    const vec3 rd = normalize(b.wp - a.wp);
+    const vec3 o = conn_end_offseted_origin(sc, a, a.wp, rd);
+    const vec3 t = conn_end_offseted_origin(sc, b, b.wp, -rd);
     const float dist = length(t - o);
-    const vec3 d = (t - o) / dist;
-    return ads_shadow_ray(sc, o, d, range_t{0.f, dist}, stack, ctr);
+    return shadow_ray_t{o, (t - o) / dist, dist};
+}
+// TRUE if occluded
+WT_HD bool bdpt_shadow(const scene_t& sc, const vertex_t& a, const vertex_t& b, const stack_ref_t& stack, bvh_counters_t* ctr) {
+    const shadow_ray_t r = conn_shadow_ray(sc, conn_end_of(a), conn_end_of(b));
+    return ads_shadow_ray(sc, r.o, r.d, range_t{0.f, r.dist}, stack, ctr);
 }
 
 // ---- walk state -----------------------------------------------------------------------------------------
@@ -874,6 +897,244 @@ WT_HD bool bdpt_walk_step(const scene_t& sc, walk_t& w, const trav_result_t& tr,
     return cont;
 }
 
+// ---- the surface interaction on its own: what the device's material-sorted pass A runs -----------------------------------------------
+// Pass A of a round (the walks whose beam axis meets a triangle of the interaction region: 92 % of them) is cut in two on the device:
+//   bdpt_classify      finds the primary triangle exactly as bdpt_walk_step does (ballistic hit / the trace kernels' axis hit of an overflowed
+//                      region / scan of the region's list) and names the walk's CLASS: the leaf type of the hit shape's material when that is not
+//                      a wrapper, WCLS_ANY otherwise; walks without a primary triangle leave for pass B, walks that hit nothing end;
+//   bdpt_surface_step  sample_surface_interaction (plt_bdpt_detail.hpp:192-270) + append_vertex + transform + continue_walk for ONE class, so
+//                      that a wavefront of the class kernel runs one BSDF's code (src/bsdf/diffuse.cpp:23-71, dielectric.cpp:26-72,
+//                      surface_spm.cpp:40-201) and the kernel carries only that BSDF's registers.
+// bdpt_surface_step reads and writes the walk RECORD (its 32-bit words, in memory) field by field, each where the step needs it, and writes
+// the new vertex as its parts become known — header, surface, a straight copy of the arriving beam — instead of holding walk_t (57 words),
+// vertex_t (86) and the traversal record (17) in registers across the BSDF: same operands, same operations, same order as the surface
+// branch of bdpt_walk_step (the CPU checker can run its walks through this pair: oracle_set_split_step, tests/test_oracle.py).
+enum walk_class_e : uint32_t { WCLS_DIFFUSE = 0, WCLS_DIELECTRIC = 1, WCLS_SPM = 2, WCLS_ANY = 3, kNumWalkClasses = 4, WCLS_NO_PRIMARY = 4, WCLS_END = 5 };
+struct primary_hit_t {
+    uint32_t tuid;
+    float dist, bx, by;
+};
+WT_HD uint32_t walk_class_of_material_type(int32_t type) { return type >= 0 && type < (int32_t)MAT_COMPOSITE ? (uint32_t)type : (uint32_t)WCLS_ANY; }
+WT_HD uint32_t walk_class_of_triangle(const scene_t& sc, uint32_t tuid) {
+    return walk_class_of_material_type(sc.materials[sc.shapes[sc.tri_meta[tuid].shape_idx].material].type);
+}
+// `tri_class`: walk_class_of_triangle for every triangle, one byte each (device: built at upload), or nullptr
+template <class TriList>
+WT_HD uint32_t bdpt_classify(const scene_t& sc, vec3 beam_d, bool beam_ray, const trav_result_t& tr, const TriList& tris, const unsigned char* tri_class, primary_hit_t& ph) {
+    ph.tuid = kInvalid;
+    ph.dist = WT_INF;
+    ph.bx = ph.by = 0.f;
+    if (tr.empty) return WCLS_END;
+    const bool is_ballistic = tr.ballistic || beam_ray;
+    if (is_ballistic) {
+        ph.tuid = tr.tuid;
+        ph.dist = tr.dist;
+        ph.bx = tr.bx;
+        ph.by = tr.by;
+    } else if (tr.aborted == 2) {
+        if (tr.tuid != kInvalid) {
+            ph.tuid = tr.tuid;
+            ph.dist = tr.pdist;
+            ph.bx = tr.bx;
+            ph.by = tr.by;
+        }
+    } else {
+        const range_t izr{tr.dist, tr.dist + tr.region_depth};
+        for (uint32_t i = 0; i < tr.ntris; ++i) {
+            const uint32_t tuid = tris[i];
+            const tri_geo_t g = sc.tri_geo[tuid];
+            const float fptol = cone_intersection_tolerance(tr.origin, g.a, g.b, g.c);
+            ray_tri_hit_t h;
+            if (intersect_ray_tri(tr.origin, beam_d, g.a, g.b, g.c, grow(izr, fptol), h) && h.dist < ph.dist) {
+                ph.tuid = tuid;
+                ph.dist = h.dist;
+                ph.bx = h.bx;
+                ph.by = h.by;
+            }
+        }
+    }
+    if (ph.tuid == kInvalid) return WCLS_NO_PRIMARY;
+    return tri_class ? (uint32_t)tri_class[ph.tuid] : walk_class_of_triangle(sc, ph.tuid);
+}
+
+// the words of a walk record in memory
+struct walk_rec_t {
+    uint32_t* p;
+    template <class F>
+    WT_HD F get(size_t word) const {
+        static_assert(sizeof(F) == 4, "");
+        const uint32_t w = p[word];
+        F f;
+        __builtin_memcpy(&f, &w, 4);
+        return f;
+    }
+    template <class F>
+    WT_HD void set(size_t word, F value) const {
+        static_assert(sizeof(F) == 4, "");
+        uint32_t w;
+        __builtin_memcpy(&w, &value, 4);
+        p[word] = w;
+    }
+    WT_HD vec3 get3(size_t word) const { return vec3{get<float>(word), get<float>(word + 1), get<float>(word + 2)}; }
+    WT_HD void set3(size_t word, vec3 v) const {
+        set(word, v.x);
+        set(word + 1, v.y);
+        set(word + 2, v.z);
+    }
+};
+// CLS: MAT_DIFFUSE / MAT_DIELECTRIC / MAT_SURFACE_SPM — the walk's class, the material is an unwrapped BSDF of that type — or -1 (WCLS_ANY).
+// Returns TRUE if the walk continues.  A walk that ends leaves its record as it is, except for what an appended vertex changed.
+template <int CLS>
+WT_HD bool bdpt_surface_step(const scene_t& sc, const walk_rec_t& wr, vec3 origin_wp, float beam_dist, const primary_hit_t& ph, const vertex_store_t& vs, uint64_t seed,
+                             uint64_t sample_id, uint32_t stream, bdpt_counters_t* ctr) {
+    sampler_t smp = make_sampler(seed, sample_id, stream, wr.get<uint32_t>(WT_WALK_WORD(rng_draws)));
+    cone_t env;
+    {
+        uint32_t* e = reinterpret_cast<uint32_t*>(&env);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = 0; i < sizeof(cone_t) / 4; ++i) e[i] = wr.p[WT_WALK_WORD(beam.env) + i];
+    }
+    const float k = wr.get<float>(WT_WALK_WORD(beam.k));
+    const uint32_t transport = wr.get<uint32_t>(WT_WALK_WORD(beam.transport));
+    // ---- sample_surface_interaction (plt_bdpt_detail.hpp:192-270)
+    const uint32_t primary = ph.tuid;
+    const vec3 gn = sc.tri_geo[primary].n;
+    const vec3 sampled_tri_wp = origin_wp + env.d * ph.dist;
+    surface_t srf = make_surface(sc, primary, gn, vec2{ph.bx, ph.by}, sampled_tri_wp);
+    srf.footprint = cone_surface_footprint_static(env, srf, beam_dist);
+    const shape_t shp = sc.shapes[srf.shape];
+    const vec3 ng = srf.geo.n, ns = srf.shading.n;
+    const vec3 wiworld = -env.d;
+    const vec3 wi = to_local(srf.shading, wiworld);
+    const float wig = dot(wiworld, ng), wis = wi.z;
+    if (!(wig * wis > 0.f)) return false;
+    const bsdf_sample_t bs = material_sample<CLS>(sc, shp.material, wi, k, transport, smp, srf.uv);
+    if (!(bs.valid && bs.dpd != 0.f)) return false;
+    const bool is_delta = pd_is_discrete(bs.dpd);
+    const vec3 wo = bs.wo;
+    const vec3 woworld = normalize(to_world(srf.shading, wo));
+    const float wog = dot(woworld, ng), wos = wo.z;
+    if (ctr) ctr->surface_interactions++;
+    if (!(wog * wos > 0.f)) return false;
+    const float pdf_revr = material_pdf<CLS>(sc, shp.material, wo, wi, k, flip_transport(transport), srf.uv);
+    // ---- append_vertex (plt_bdpt_detail.hpp:95-121; walk_append_vertex above)
+    const vec3 prev_wp = wr.get3(WT_WALK_WORD(prev_wp));
+    if (veq(prev_wp, srf.wp)) return false;
+    uint32_t nverts = wr.get<uint32_t>(WT_WALK_WORD(nverts));
+    {
+        struct {
+            uint32_t type;
+            int32_t ref;
+            uint32_t geo_kind;
+            const surface_t& surf;
+        } vview{VT_SURFACE, shp.material, GEO_SURFACE, srf};
+        const float pv = convert_directional_density_to_area(sc, wr.get<float>(WT_WALK_WORD(pdf_from_prev)), prev_wp, vview);
+        const uint32_t hdr[12] = {VT_SURFACE,
+                                  transport,
+                                  is_delta ? 1u : 0u,
+                                  0u,
+                                  __builtin_bit_cast(uint32_t, transport == TRANSPORT_FORWARD ? pv : -1.f),
+                                  __builtin_bit_cast(uint32_t, transport == TRANSPORT_FORWARD ? -1.f : pv),
+                                  __builtin_bit_cast(uint32_t, 1.f),
+                                  (uint32_t)shp.material,
+                                  (uint32_t)shp.emitter,
+                                  kInvalid,
+                                  (uint32_t)GEO_SURFACE,
+                                  1u};
+        static_assert(WT_VWORD(type) == 0 && WT_VWORD(transport) == 1 && WT_VWORD(delta) == 2 && WT_VWORD(fraunhofer_fsd) == 3 && WT_VWORD(pdf_fwd) == 4 && WT_VWORD(pdf_bwd) == 5 &&
+                          WT_VWORD(rr_weight) == 6 && WT_VWORD(ref) == 7 && WT_VWORD(emitter_of_shape) == 8 && WT_VWORD(fsd_slot) == 9 && WT_VWORD(geo_kind) == 10 &&
+                          WT_VWORD(has_beam) == 11 && WT_VWORD(surf) == 12,
+                      "vertex_t header layout");
+        uint32_t* vp = vs.base + vs.idx * vs.stride + (size_t)nverts * kVertexWords;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 12; ++i) vp[i] = hdr[i];
+        const uint32_t* sw = reinterpret_cast<const uint32_t*>(&srf);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = 0; i < sizeof(surface_t) / 4; ++i) vp[WT_VWORD(surf) + i] = sw[i];
+        // the arriving beam: a copy of the walk's (its envelope is in registers already)
+        const uint32_t* ew = reinterpret_cast<const uint32_t*>(&env);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = 0; i < sizeof(cone_t) / 4; ++i) vp[WT_VWORD(beam) + i] = ew[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = sizeof(cone_t) / 4; i < sizeof(beam_t) / 4; ++i) vp[WT_VWORD(beam) + i] = wr.p[WT_WALK_WORD(beam) + i];
+        // reversed pdf of the previous vertex (sampling prev from v)
+        const float dens = pd_density_or_zero(pdf_revr);
+        float prev_rev = 0.f;
+        if (dens != 0.f) {
+            const vec3 d = prev_wp - srf.wp;
+            const float d2 = length2(d);
+            if (d2 == 0.f)
+                prev_rev = WT_INF;
+            else {
+                prev_rev = dens * (1.f / d2);
+                if (wr.get<uint32_t>(WT_WALK_WORD(prev_on_surface))) prev_rev *= fabsf(dot(wr.get3(WT_WALK_WORD(prev_ng)), normalize(d)));
+            }
+        }
+        vs.store_word(nverts - 1, transport == TRANSPORT_BACKWARD ? WT_VWORD(pdf_fwd) : WT_VWORD(pdf_bwd), prev_rev);
+        ++nverts;
+        wr.set(WT_WALK_WORD(pdf_from_prev), bs.dpd);
+        wr.set(WT_WALK_WORD(nverts), nverts);
+        // walk_cache_prev
+        wr.set3(WT_WALK_WORD(prev_wp), srf.wp);
+        wr.set3(WT_WALK_WORD(prev_ng), ng);
+        wr.set(WT_WALK_WORD(prev_on_surface), 1u);
+        wr.set(WT_WALK_WORD(prev_offset_tuid), srf.tuid);
+    }
+    if (ctr) ctr->vertices++;
+    float ws = 1.f;
+    if (!veq(ns, ng)) ws *= shading_normals_correction_scale(transport, wig, wog, wis, wos);
+    // ---- transform_surface_interaction (plt_bdpt_detail.hpp:123-136; beam.hpp:379-398)
+    {
+        beam_t b;
+        float sid;
+        b.env = cone_through_surface_footprint(srf, srf.wp, woworld, env.tan_alpha, &sid);
+        b.k = k;
+        b.transport = transport;
+        uint32_t* bw = reinterpret_cast<uint32_t*>(&b);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = offsetof(beam_t, frame) / 4; i < sizeof(beam_t) / 4; ++i) bw[i] = wr.p[WT_WALK_WORD(beam) + i];
+        beam_apply_bsdf(b, ws * bs.M, woworld, srf, cone_frame(b.env));
+        b.self_intersection_distance = sid;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (size_t i = 0; i < sizeof(beam_t) / 4; ++i) wr.p[WT_WALK_WORD(beam) + i] = bw[i];
+    }
+    float throughput = wr.get<float>(WT_WALK_WORD(throughput)) * (ws * mueller_mean_intensity(bs.M));
+    if (transport == TRANSPORT_BACKWARD && bs.eta != 1.f) throughput /= sqr(bs.eta);
+    // ---- continue_walk (plt_bdpt_detail.hpp:167-182; walk_continue above)
+    bool cont = true;
+    float rr_weight = wr.get<float>(WT_WALK_WORD(rr_weight));
+    if ((int)nverts > sc.opts.max_depth + 1)
+        cont = false;
+    else if (sc.opts.RR) {
+        vs.store_word(nverts - 1, WT_VWORD(rr_weight), rr_weight);
+        const float r = throughput < 1.f ? fmaxf_(throughput, .5f) : 1.f;
+        if (sampler_r(smp) <= r) {
+            const float scale = 1.f / r;
+            rr_weight *= scale;
+            throughput *= scale;
+        } else
+            cont = false;
+    }
+    wr.set(WT_WALK_WORD(throughput), throughput);
+    wr.set(WT_WALK_WORD(rr_weight), rr_weight);
+    wr.set(WT_WALK_WORD(rng_draws), smp.draws);
+    return cont;
+}
+
 // ---- connections -------------------------------------------------------------------------------------------
 // random stream of the (s,t) connection: one per strategy (short subpaths keep the ids of rounds 1-2; longer ones follow behind them)
 WT_HD uint32_t connect_stream(int s, int t) {
@@ -886,14 +1147,29 @@ struct connect_ret_t {
     uint32_t has_temp;
     sensor_element_t element;
     uint32_t has_element;
+    // DEFER (bdpt_connect<true>): the connection's shadow ray has not been traced — L is the flux of the unoccluded connection, `ray` the ray
+    // integrator::shadow would cast (need_shadow = 0: the strategy casts none, or L is zero already)
+    shadow_ray_t ray;
+    uint32_t need_shadow;
 };
 
-// connect_and_integrate (plt_bdpt_detail.hpp:722-745)
-WT_HD stokes_t connect_and_integrate(const scene_t& sc, const beam_t& db, const vertex_t& dv, const beam_t& eb, const vertex_t& ev,
-                                     const stack_ref_t& stack, bdpt_counters_t* ctr, bvh_counters_t* bctr) {
+// connect_and_integrate (plt_bdpt_detail.hpp:722-745).  DEFER: the ray is handed out instead of being traced (the device traces the rays of
+// all connections of a batch in one kernel of their own, all lanes busy: k_connect_shadow).
+template <bool DEFER>
+WT_HD stokes_t connect_and_integrate(const scene_t& sc, const beam_t& db, const conn_end_t& dv, const beam_t& eb, const conn_end_t& ev, const stack_ref_t& stack,
+                                     bdpt_counters_t* ctr, bvh_counters_t* bctr, connect_ret_t& ret) {
     if (beam_intensity(db) == 0.f || beam_intensity(eb) == 0.f) return stokes_zero();
     if (ctr) ctr->shadow_rays++;
-    if (bdpt_shadow(sc, dv, ev, stack, bctr)) return stokes_zero();
+    const shadow_ray_t ray = conn_shadow_ray(sc, dv, ev);
+    if (DEFER) {
+        const stokes_t L = integrate_beams(db, eb);
+        if (L.s[0] > 0.f) {   // (otherwise the strategy contributes nothing whatever the ray meets: bdpt_strategy)
+            ret.ray = ray;
+            ret.need_shadow = 1;
+        }
+        return L;
+    }
+    if (ads_shadow_ray(sc, ray.o, ray.d, range_t{0.f, ray.dist}, stack, bctr)) return stokes_zero();
     return integrate_beams(db, eb);
 }
 
@@ -916,13 +1192,34 @@ WT_HD void make_temp_vertex(vertex_t& v, uint32_t type, uint32_t transport, int 
         v.surf = make_dummy_surface(vec3{0, 0, 1}, p);
     }
 }
+// vertex_is_connectible from the vertex store: the three words it reads
+WT_HD bool vertex_store_connectible(const scene_t& sc, const vertex_store_t& vs, uint32_t idx) {
+    struct {
+        uint32_t type;
+        int32_t ref;
+        struct {
+            float k;
+        } beam;
+    } v{vs.load_word<uint32_t>(idx, WT_VWORD(type)), vs.load_word<int32_t>(idx, WT_VWORD(ref)), {vs.load_word<float>(idx, WT_VWORD(beam) + offsetof(beam_t, k) / 4)}};
+    switch (v.type) {
+    case VT_FSD: return true;
+    case VT_EMITTER: return !emitter_is_delta_direction(sc.emitters[v.ref]);
+    case VT_SENSOR: return !sensor_is_delta_direction(sc.sensor);
+    case VT_SURFACE: return !material_is_delta_only(sc, v.ref, v.beam.k);
+    default: return false;
+    }
+}
 
 // connect_subpaths (plt_bdpt_detail.hpp:747-923).  nS/nT = number of vertices of the emitter/sensor subpaths.
+// (The vertices of a connection are loaded one at a time, each dropped once the beam it sends towards the other has been formed: two
+// vertex_t and their two beams at once are 258 registers on the device.)
+template <bool DEFER = false>
 WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t,
                         uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, connect_ret_t& ret, bdpt_counters_t* ctr, bvh_counters_t* bctr) {
     ret.L = stokes_zero();
     ret.has_temp = 0;
     ret.has_element = 0;
+    ret.need_shadow = 0;
     sampler_t smp = make_sampler(seed, sample_id, connect_stream(s, t));
     if (ctr) ctr->connections++;
 
@@ -936,8 +1233,9 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
         }
     } else if (t == 0) {
         if (sensor_is_virtual(sc.sensor)) {
-            vertex_t last, current;
+            vertex_t last;
             evs.load(s - 1, last);
+            vertex_nb_t current;
             evs.load(s - 2, current);
             const vec3 wp_end = vertex_wp(last);
             const beam_t& beam = last.beam;
@@ -947,7 +1245,7 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
                 ret.element = dc.element;
                 ret.has_element = 1;
                 float wgt = current.rr_weight;
-                if (vertex_is_on_surface(sc, current) && vertex_is_interaction(current) && !current.delta)
+                if (vertex_is_on_surface(sc, current) && (current.type == VT_FSD || current.type == VT_SURFACE || current.type == VT_MEDIUM) && !current.delta)
                     wgt /= fabsf(dot(dc.beam.env.d, vertex_ns(sc, current)));
                 wgt /= fabsf(dot(dc.beam.env.d, dc.surface.geo.n));
                 beam_scale(dc.beam, wgt);
@@ -970,8 +1268,8 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
                 make_temp_vertex(ret.temporary_vert, VT_EMITTER, TRANSPORT_FORWARD, ed.emitter, ed.has_surface, ed.surface, ed.beam.env.o);
                 ret.has_temp = 1;
                 beam_t db;
-                if (vertex_interact(sc, pool, last, ret.temporary_vert, false, db))
-                    ret.L = connect_and_integrate(sc, db, last, ed.beam, ret.temporary_vert, stack, ctr, bctr);
+                if (vertex_interact(sc, pool, last, vertex_wp(ret.temporary_vert), false, db))
+                    ret.L = connect_and_integrate<DEFER>(sc, db, conn_end_of(last), ed.beam, conn_end_of(ret.temporary_vert), stack, ctr, bctr, ret);
             }
         }
     } else if (t == 1) {
@@ -988,35 +1286,90 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
                 make_temp_vertex(ret.temporary_vert, VT_SENSOR, TRANSPORT_BACKWARD, -1, sd.has_surface, sd.surface, sd.beam.env.o);
                 ret.has_temp = 1;
                 beam_t eb;
-                if (vertex_interact(sc, pool, last, ret.temporary_vert, false, eb)) {
-                    ret.L = connect_and_integrate(sc, sd.beam, ret.temporary_vert, eb, last, stack, ctr, bctr);
+                if (vertex_interact(sc, pool, last, vertex_wp(ret.temporary_vert), false, eb)) {
+                    ret.L = connect_and_integrate<DEFER>(sc, sd.beam, conn_end_of(ret.temporary_vert), eb, conn_end_of(last), stack, ctr, bctr, ret);
                     ret.element = sd.element;
                     ret.has_element = 1;
                 }
             }
         }
     } else {
-        vertex_t ev, sv;
-        evs.load(s - 1, ev);
-        svs.load(t - 1, sv);
-        const vec3 dl = vertex_wp(ev) - vertex_wp(sv);
-        if (vertex_is_connectible(sc, ev) && vertex_is_connectible(sc, sv) && !(dl.x == 0.f && dl.y == 0.f && dl.z == 0.f)) {
+        const vec3 ev_wp = evs.load_wp(s - 1), sv_wp = svs.load_wp(t - 1);
+        const vec3 dl = ev_wp - sv_wp;
+        if (vertex_store_connectible(sc, evs, s - 1) && vertex_store_connectible(sc, svs, t - 1) && !(dl.x == 0.f && dl.y == 0.f && dl.z == 0.f)) {
             beam_t eb, db;
-            const bool heb = vertex_interact(sc, pool, ev, sv, true, eb);
-            const bool hdb = vertex_interact(sc, pool, sv, ev, true, db);
+            conn_end_t ev_end, sv_end;
+            vec3 ev_ns, sv_ns;
+            bool ev_on, sv_on, heb, hdb = false;
+            float ev_rr, sv_rr;
+            {
+                vertex_t ev;
+                evs.load(s - 1, ev);
+                heb = vertex_interact(sc, pool, ev, sv_wp, true, eb);
+                ev_end = conn_end_of(ev);
+                ev_ns = vertex_ns(sc, ev);
+                ev_on = vertex_is_on_surface(sc, ev);
+                ev_rr = ev.rr_weight;
+            }
+            if (heb) {
+                vertex_t sv;
+                svs.load(t - 1, sv);
+                hdb = vertex_interact(sc, pool, sv, ev_wp, true, db);
+                sv_end = conn_end_of(sv);
+                sv_ns = vertex_ns(sc, sv);
+                sv_on = vertex_is_on_surface(sc, sv);
+                sv_rr = sv.rr_weight;
+            }
             if (heb && hdb) {
                 const float recp_d2 = 1.f / length2(dl);
                 const vec3 d = dl * sqrtf(recp_d2);
-                float wev = ev.rr_weight;
-                float wsv = sv.rr_weight * recp_d2;
-                if (vertex_is_on_surface(sc, sv)) wev *= fabsf(dot(vertex_ns(sc, sv), d));
-                if (vertex_is_on_surface(sc, ev)) wsv *= fabsf(dot(vertex_ns(sc, ev), d));
+                float wev = ev_rr;
+                float wsv = sv_rr * recp_d2;
+                if (sv_on) wev *= fabsf(dot(sv_ns, d));
+                if (ev_on) wsv *= fabsf(dot(ev_ns, d));
                 beam_scale(db, wsv);
                 beam_scale(eb, wev);
-                ret.L = connect_and_integrate(sc, db, sv, eb, ev, stack, ctr, bctr);
+                ret.L = connect_and_integrate<DEFER>(sc, db, sv_end, eb, ev_end, stack, ctr, bctr, ret);
             }
         }
     }
+}
+// The temporary vertex (and the sensor element) of a t = 0 (virtual sensor), s = 1 or t = 1 connection once more, from the same random
+// numbers — what the MIS weight and the light-image splat of the strategy need of bdpt_connect's outcome.  (Device: the connection's flux
+// waits for its shadow ray in a 52-byte record; the 43 words of the temporary vertex are cheaper to form again than to carry along.)
+WT_HD void bdpt_connect_temp(const scene_t& sc, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t, uint64_t seed, uint64_t sample_id, vertex_nb_t& tv,
+                             sensor_element_t& element, bool& has_element) {
+    has_element = false;
+    vertex_t tmp;
+    bool has_temp = false;
+    sampler_t smp = make_sampler(seed, sample_id, connect_stream(s, t));
+    if (s == 0) {
+    } else if (t == 0) {
+        if (sensor_is_virtual(sc.sensor)) {
+            vertex_t last;
+            evs.load(s - 1, last);
+            const float dist = length(vertex_wp(last) - last.beam.env.o);
+            const sensor_direct_connection_t dc = vplane_Si(sc, last.beam, range_t{0.f, dist});
+            if (dc.valid) {
+                element = dc.element;
+                has_element = true;
+                make_temp_vertex(tmp, VT_SENSOR, TRANSPORT_BACKWARD, -1, true, dc.surface, dc.beam.env.o);
+                has_temp = true;
+            }
+        }
+    } else if (s == 1) {
+        const emitter_direct_sample_t ed = scene_sample_emitter_direct(sc, svs.load_wp(t - 1), svs.load_word<float>(t - 1, WT_VWORD(beam) + offsetof(beam_t, k) / 4), smp);
+        make_temp_vertex(tmp, VT_EMITTER, TRANSPORT_FORWARD, ed.emitter, ed.has_surface, ed.surface, ed.beam.env.o);
+        has_temp = true;
+    } else if (t == 1) {
+        const sensor_direct_sample_t sd = sensor_sample_direct(sc, evs.load_wp(s - 1), evs.load_word<float>(s - 1, WT_VWORD(beam) + offsetof(beam_t, k) / 4), smp);
+        make_temp_vertex(tmp, VT_SENSOR, TRANSPORT_BACKWARD, -1, sd.has_surface, sd.surface, sd.beam.env.o);
+        has_temp = true;
+        element = sd.element;
+        has_element = true;
+    }
+    if (has_temp) __builtin_memcpy(&tv, &tmp, offsetof(vertex_t, beam));
+    tv.beam.k = 0.f;
 }
 
 // bdpt_compute_mis_weight (plt_bdpt_detail.hpp:604-720).  The reference copies every vertex's densities into arrays
@@ -1025,10 +1378,10 @@ WT_HD void bdpt_connect(const scene_t& sc, const fsd_pool_t& pool, const vertex_
 // vertex store, newest vertex first — the same numbers in the same order without per-thread arrays (which live in scratch memory on
 // the device) and without a cap on the path length.  Vertices enter the densities without their beams (vertex_nb_t), the
 // predecessors with their position only.
-WT_HD float bdpt_mis_weight(const scene_t& sc, const fsd_pool_t& pool, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t,
-                            const connect_ret_t& cr) {
+// `tv`: the connection's temporary vertex (vertex_t or its beam-less part vertex_nb_t: the densities read nothing else of it).
+template <class TV>
+WT_HD float bdpt_mis_weight(const scene_t& sc, const fsd_pool_t& pool, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t, const TV& tv) {
     if (s + t <= 2) return 1.f;
-    const vertex_t& tv = cr.temporary_vert;
     // entries of the sensor (s*) / emitter (e*) subpath arrays that the connection overrides: `last` = index n-1, `prev` = n-2, `first` = 0
     float srev_last = 0.f, srev_prev = 0.f, spdf_first = 0.f, erev_last = 0.f, erev_prev = 0.f, epdf_first = 0.f;
     bool has_srev_last = false, has_srev_prev = false, has_spdf_first = false, has_erev_last = false, has_erev_prev = false, has_epdf_first = false;
@@ -1172,31 +1525,50 @@ WT_HD float bdpt_mis_weight(const scene_t& sc, const fsd_pool_t& pool, const ver
     return 1.f / (1.f + sum_Ri);
 }
 
-// One (s,t) strategy of plt_bdpt.cpp:105-140.  Returns the flux to be accumulated into L (t>1) and performs the
-// light-image splat itself for t<=1.
-WT_HD stokes_t bdpt_strategy(const scene_t& sc, const fsd_pool_t& pool, const film_t& film, const vertex_store_t& svs, const vertex_store_t& evs, int s,
-                             int t, const sample_ctx_t& ctx, uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, bdpt_counters_t* ctr,
-                             bvh_counters_t* bctr) {
-    connect_ret_t cr;
-    bdpt_connect(sc, pool, svs, evs, s, t, seed, sample_id, stack, cr, ctr, bctr);
-    if (!(cr.L.s[0] > 0.f)) return stokes_zero();
+// What follows the connection of strategy (s,t) with flux L > 0 (plt_bdpt.cpp:113-140): MIS weight, the light-image splat of the t <= 1
+// strategies (performed here), the flux to be accumulated into the sample's L for t > 1 (returned).
+template <class TV>
+WT_HD stokes_t bdpt_strategy_finish(const scene_t& sc, const fsd_pool_t& pool, const film_t& film, const vertex_store_t& svs, const vertex_store_t& evs, int s, int t,
+                                    const sample_ctx_t& ctx, const stokes_t& L, const TV& tv, const sensor_element_t& element, bool has_element, bdpt_counters_t* ctr) {
     float mis;
     if (sc.opts.debug_only_s || sc.opts.debug_only_t)
         mis = ctx.recp_spectral_pd;
     else if (sc.opts.MIS)
-        mis = bdpt_mis_weight(sc, pool, svs, evs, s, t, cr) * ctx.recp_spectral_pd;
+        mis = bdpt_mis_weight(sc, pool, svs, evs, s, t, tv) * ctx.recp_spectral_pd;
     else
         mis = 1.f / (float(s + t + 1) * ctx.k_density);
-    const stokes_t flux = cr.L * mis;
+    const stokes_t flux = L * mis;
     if (t > 1) return flux;
-    if (cr.has_element) {
-        film_splat_direct(sc, film, cr.element, flux, ctx.k);
+    if (has_element) {
+        film_splat_direct(sc, film, element, flux, ctx.k);
         if (ctr) ctr->light_splats++;
     }
     return stokes_zero();
 }
+// One (s,t) strategy of plt_bdpt.cpp:105-140.  Returns the flux to be accumulated into L (t>1) and performs the
+// light-image splat itself for t<=1.
+// STAGED (CPU checker only, oracle_set_staged_connect): the connection the way the device's three connection kernels run it — flux without
+// the shadow ray, the ray, then MIS and splat with the temporary vertex formed again (bdpt_connect_temp) — must give the same numbers.
+template <bool STAGED = false>
+WT_HD stokes_t bdpt_strategy(const scene_t& sc, const fsd_pool_t& pool, const film_t& film, const vertex_store_t& svs, const vertex_store_t& evs, int s,
+                             int t, const sample_ctx_t& ctx, uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, bdpt_counters_t* ctr,
+                             bvh_counters_t* bctr) {
+    connect_ret_t cr;
+    bdpt_connect<STAGED>(sc, pool, svs, evs, s, t, seed, sample_id, stack, cr, ctr, bctr);
+    if (!(cr.L.s[0] > 0.f)) return stokes_zero();
+    if (STAGED) {
+        if (cr.need_shadow && ads_shadow_ray(sc, cr.ray.o, cr.ray.d, range_t{0.f, cr.ray.dist}, stack, bctr)) return stokes_zero();
+        vertex_nb_t tv;
+        sensor_element_t element;
+        bool has_element;
+        bdpt_connect_temp(sc, svs, evs, s, t, seed, sample_id, tv, element, has_element);
+        return bdpt_strategy_finish(sc, pool, film, svs, evs, s, t, ctx, cr.L, tv, element, has_element, ctr);
+    }
+    return bdpt_strategy_finish(sc, pool, film, svs, evs, s, t, ctx, cr.L, cr.temporary_vert, cr.element, cr.has_element != 0, ctr);
+}
 
 // The (s,t) loop of plt_bdpt.cpp:105-146 for one sample, given both finished subpaths.
+template <bool STAGED = false>
 WT_HD void bdpt_connect_all(const scene_t& sc, const fsd_pool_t& pool, const film_t& film, const vertex_store_t& svs, const vertex_store_t& evs, int nT,
                             int nS, const sample_ctx_t& ctx, uint64_t seed, uint64_t sample_id, const stack_ref_t& stack, bdpt_counters_t* ctr,
                             bvh_counters_t* bctr) {
@@ -1210,7 +1582,7 @@ WT_HD void bdpt_connect_all(const scene_t& sc, const fsd_pool_t& pool, const fil
             if (depth > sc.opts.max_depth) break;
             if (sc.opts.debug_only_s && (int)sc.opts.debug_only_s - 1 != s) continue;
             if (sc.opts.debug_only_t && (int)sc.opts.debug_only_t - 1 != t) continue;
-            L = L + bdpt_strategy(sc, pool, film, svs, evs, s, t, ctx, seed, sample_id, stack, ctr, bctr);
+            L = L + bdpt_strategy<STAGED>(sc, pool, film, svs, evs, s, t, ctx, seed, sample_id, stack, ctr, bctr);
         }
 #if defined(WTGPU_DEBUG_PRINT) && defined(__HIP_DEVICE_COMPILE__)
     if (ctx.element.x == 0 && ctx.element.y == 0)

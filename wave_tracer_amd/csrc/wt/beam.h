@@ -295,6 +295,15 @@ WT_HD void beam_transform_restart(beam_t& b, vec3 wp, float dist) {
 }
 
 // beam_generic_t::surface_footprint_static (beam_generic.hpp:165-190)
+// (of the beam's envelope alone: all it reads of the beam)
+WT_HD footprint_t cone_surface_footprint_static(const cone_t& env, const surface_t& surface, float beam_z_dist) {
+    const vec2 a = cone_axes(env, beam_z_dist);
+    const vec3 ls{a.x, a.y, kMajorAxisToZScale * a.x};
+    const vec3 x = to_local(surface.geo, env.x);
+    if (x.x != 0.f || x.y != 0.f) return {normalize(vec2{x.x, x.y}), ls.x, ls.y};
+    const float avg = (ls.x + ls.y) / 2.f;
+    return {{1.f, 0.f}, avg, avg};
+}
 WT_HD footprint_t beam_surface_footprint_static(const beam_t& b, const surface_t& surface, float beam_z_dist) {
     const vec3 ls = beam_footprint(b, beam_z_dist);
     const vec3 x = to_local(surface.geo, b.env.x);

@@ -209,11 +209,13 @@ WT_HD float material_scale_factor(const scene_t& sc, const material_t& m, float 
     if (m.scale_tex) f *= texture_spectral(sc, (int)m.scale_tex - 1, uv, k);
     return f;
 }
+// (LEAF: the caller knows that `mat` is an unwrapped BSDF — the wrappers' code is not compiled in)
+template <bool LEAF = false>
 WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, material_t& m, material_wrap_t& wr) {
     m = sc.materials[mat];
     wr.alpha = 1.f;
     wr.masked = wr.mask_two = false;
-    if (m.type < MAT_COMPOSITE) {   // a leaf BSDF: the common case (only the fields the caller goes on to use are loaded)
+    if (LEAF || m.type < MAT_COMPOSITE) {   // a leaf BSDF: the common case (only the fields the caller goes on to use are loaded)
         if (m.scale_spec | m.scale_tex) m.scale *= material_scale_factor(sc, m, k, uv);
         if (m.rough_tex) m.roughness = texture_spectral(sc, (int)m.rough_tex - 1, uv, k);   // fractal.hpp:83-92: roughness_tex->f(query).x
         return true;
@@ -297,12 +299,17 @@ WT_HD mueller_t material_f(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k
     return M;
 }
 
+// CLS (here and in material_sample): the leaf type of the material when the caller knows it at compile time (MAT_DIFFUSE / MAT_DIELECTRIC /
+// MAT_SURFACE_SPM: the class kernels of the device's material-sorted interaction pass, which are handed only walks on unwrapped materials of
+// that type) — the other BSDFs' code is not compiled in; -1: any material (wrappers resolved at run time).  Same arithmetic either way.
+template <int CLS = -1>
 WT_HD float material_pdf_leaf(const scene_t& sc, const material_t& m, vec3 wi, vec3 wo, float k, uint32_t transport);
+template <int CLS = -1>
 WT_HD float material_pdf(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, uint32_t transport, vec2 uv = vec2{0.f, 0.f}) {
     material_t m;
     material_wrap_t wr;
-    if (!material_resolve(sc, mat, k, uv, m, wr)) return 0.f;
-    if (wr.masked) {
+    if (!material_resolve<(CLS >= 0)>(sc, mat, k, uv, m, wr)) return 0.f;
+    if (CLS < 0 && wr.masked) {
         // mask.cpp:79-92: no transmission through a masked BSDF; the nested density times the probability of not taking the null lobe
         if (wr.mask_two) {
             const float z = wi.z;
@@ -310,18 +317,20 @@ WT_HD float material_pdf(const scene_t& sc, int mat, vec3 wi, vec3 wo, float k, 
             wo = two_sided_flip(wo, z);
         }
         if (wi.z <= 0.f || wo.z <= 0.f) return 0.f;
-        return material_pdf_leaf(sc, m, wi, wo, k, transport) * wr.alpha;
+        return material_pdf_leaf<CLS>(sc, m, wi, wo, k, transport) * wr.alpha;
     }
-    return material_pdf_leaf(sc, m, wi, wo, k, transport);
+    return material_pdf_leaf<CLS>(sc, m, wi, wo, k, transport);
 }
+template <int CLS>
 WT_HD float material_pdf_leaf(const scene_t& sc, const material_t& m, vec3 wi, vec3 wo, float k, uint32_t transport) {
+    const int type = CLS >= 0 ? CLS : m.type;
+    if (type == MAT_DIELECTRIC) return 0.f;
     if (m.two_sided) {
         const float z = wi.z;
         wi = two_sided_flip(wi, z);
         wo = two_sided_flip(wo, z);
     }
-    if (m.type == MAT_DIFFUSE) return (wi.z > 0.f && wo.z > 0.f) ? cosine_hemisphere_pdf(wo.z) : 0.f;
-    if (m.type == MAT_DIELECTRIC) return 0.f;
+    if (type == MAT_DIFFUSE) return (wi.z > 0.f && wo.z > 0.f) ? cosine_hemisphere_pdf(wo.z) : 0.f;
     const bool is_reflection = wi.z * wo.z >= 0.f;
     const cplx eta_12 = material_IOR(sc, m, k);
     const bool has_transmission = IOR_has_transmission(eta_12);
@@ -334,6 +343,7 @@ WT_HD float material_pdf_leaf(const scene_t& sc, const material_t& m, vec3 wi, v
     return (1.f - pdf_specular) * profile_pdf(m, wi, abs_wo, k) * (is_reflection ? 1.f - pdf_transmission : pdf_transmission);
 }
 
+template <int CLS = -1>
 WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, float k, uint32_t transport, sampler_t& sampler, vec2 uv = vec2{0.f, 0.f}) {
     bsdf_sample_t r;
     r.valid = false;
@@ -343,11 +353,12 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
     r.M = mueller_zero();
     material_t m;
     material_wrap_t wr;
-    if (!material_resolve(sc, mat, k, uv, m, wr)) return r;   // composite: no bin at this wavenumber
+    if (!material_resolve<(CLS >= 0)>(sc, mat, k, uv, m, wr)) return r;   // composite: no bin at this wavenumber
     // mask.cpp:37-77 (every lobe is admitted by the integrators' queries: has_null = true): the null lobe passes the beam straight
     // through with probability 1 - alpha (always, from behind), the nested BSDF is sampled otherwise
     float not_null = 1.f;
-    if (wr.masked) {
+    const int type = CLS >= 0 ? CLS : m.type;
+    if (CLS < 0 && wr.masked) {
         const float pdf_null = (wr.mask_two ? wi_in.z == 0.f : wi_in.z <= 0.f) ? 1.f : 1.f - wr.alpha;
         const bool is_null = pdf_null == 0.f ? false : (pdf_null == 1.f ? true : sampler_r(sampler) < pdf_null);
         if (is_null) {
@@ -362,14 +373,14 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
     const float flipz = wi_in.z;
     const vec3 wi = m.two_sided ? two_sided_flip(wi_in, flipz) : wi_in;
 
-    if (m.type == MAT_DIFFUSE) {
+    if (type == MAT_DIFFUSE) {
         if (wi.z <= 0.f) return r;
         const float refl = clamp01(spectrum_f(sc, m.refl_spec, k) * m.refl_tex_scale * (m.refl_tex ? texture_spectral(sc, (int)m.refl_tex - 1, uv, k) : 1.f));
         r.wo = cosine_hemisphere(sampler_r2(sampler));
         r.dpd = cosine_hemisphere_pdf(r.wo.z);
         r.M = mueller_depolarizer(refl);
         r.valid = true;
-    } else if (m.type == MAT_DIELECTRIC) {
+    } else if (type == MAT_DIELECTRIC) {
         // dielectric.cpp:26-72 — IOR() returns Re(eta_1/eta_2)
         const float eta_12 = material_IOR(sc, m, k).re;
         const fresnel_t f = fresnel(cplx{eta_12, 0.f}, wi, vec3{0, 0, 1});
@@ -442,7 +453,7 @@ WT_HD bsdf_sample_t material_sample(const scene_t& sc, int mat, vec3 wi_in, floa
     if (r.valid) {
         if (m.two_sided) r.wo = two_sided_flip(r.wo, flipz);
         if (m.scale != 1.f) r.M = r.M * m.scale;
-        if (wr.masked) {   // mask.cpp:72-75
+        if (CLS < 0 && wr.masked) {   // mask.cpp:72-75
             r.dpd *= not_null;   // (a discrete mass is stored negated: scaling keeps the flag)
             r.M = r.M * (wr.alpha / not_null);
         }

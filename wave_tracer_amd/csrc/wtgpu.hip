@@ -76,6 +76,7 @@ struct wtgpu_scene {
     bool uploaded = false;
     std::vector<device_state_t> slices;              // per-batch path state, one slice per internal stream
     std::vector<const path_state_t*> d_path_slices;  // ... and its plt_path part (device copies)
+    const unsigned char* d_tri_class = nullptr;       // walk class of every triangle (bdpt_ext_t::tri_class)
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> ev_done;
     hipEvent_t ev_begin = nullptr;
@@ -115,6 +116,7 @@ struct wtgpu_scene {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 1, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
+        uint32_t sorted_interact = 1, staged_connect = 1, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -461,6 +463,13 @@ static void read_knobs(wtgpu_scene* s) {
     k.grid_div_hard = std::max(1u, u("WTGPU_GRID_HARD", 4));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
+    k.sorted_interact = u("WTGPU_SORTED_INTERACT", 1);
+    k.staged_connect = u("WTGPU_STAGED_CONNECT", 1);
+    if (const char* e = getenv("WTGPU_GRID_CLS")) {
+        unsigned v[4] = {1, 4, 2, 4};
+        sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]);
+        for (int c = 0; c < 4; ++c) k.grid_div_cls[c] = std::max(1u, v[c]);
+    }
     k.flux_task_tris = std::max(64u, u("WTGPU_FLUX_TASK_TRIS", kFluxTaskTris));
     k.coop_aperture_min = u("WTGPU_COOP_APERTURE_MIN", 8);   // 0xFFFFFFFF: every aperture by a single lane of pass B
     if (const char* e = getenv("WTGPU_DEBUG_STAGE")) k.dbg_stage = atoi(e);   // bring-up aid: stops launching the round kernels after stage n (invalid results)
@@ -527,6 +536,12 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     if ((rc = upload(s, h.lut.icdf2, (size_t)h.lut.m * h.lut.m, &d.lut.icdf2)) != WTGPU_OK) return rc;
 #undef UP
     s->dev = d;
+    s->d_tri_class = nullptr;
+    if (h.n_tris > 0 && h.opts.integrator == INTEGRATOR_BDPT) {   // the material-sorted pass A: class of every triangle (wt/bdpt.h: walk_class_of_triangle)
+        std::vector<unsigned char> cls(h.n_tris);
+        for (uint32_t t = 0; t < h.n_tris; ++t) cls[t] = (unsigned char)walk_class_of_triangle(h, t);
+        if ((rc = upload(s, cls.data(), cls.size(), &s->d_tri_class)) != WTGPU_OK) return rc;
+    }
 
     // per-batch path state: `n_slices` slices (one internal stream each), EACH holding a batch of up to `max_batch` samples.
     // Three internal streams: the tails of one batch overlap the bulk of the others.  A single batch already fills the GPU in its first rounds, so
@@ -589,6 +604,15 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
             if ((rc = dmalloc(s, &dP, 1))) return rc;
             HIP_CHECK(hipMemcpy(dP, &P, sizeof(P), hipMemcpyHostToDevice));
             s->d_path_slices.push_back(dP);
+        }
+        if (!path_mode) {
+            bdpt_ext_t X;
+            X.tri_class = s->d_tri_class;
+            if ((rc = dmalloc(s, &X.cls_queue, (size_t)kNumWalkClasses * W2))) return rc;
+            bdpt_ext_t* dX = nullptr;
+            if ((rc = dmalloc(s, &dX, 1))) return rc;
+            HIP_CHECK(hipMemcpy(dX, &X, sizeof(X), hipMemcpyHostToDevice));
+            st.ext = dX;
         }
         if ((rc = dmalloc(s, &st.verts, path_mode ? 1 : (size_t)st.max_verts * kVertexWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
@@ -762,7 +786,14 @@ struct batch_launcher_t {
                 rec(r, st_);
                 continue;
             }
-            HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            if (K.sorted_interact) {
+                HP_LAUNCH(11, k_classify, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+                HP_LAUNCH(24, k_interact_diffuse, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[0])), dim3(kBlock), 0, st_, a, in);
+                HP_LAUNCH(25, k_interact_dielectric, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[1])), dim3(kBlock), 0, st_, a, in);
+                HP_LAUNCH(26, k_interact_spm, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[2])), dim3(kBlock), 0, st_, a, in);
+                HP_LAUNCH(27, k_interact_any, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[3])), dim3(kBlock), 0, st_, a, in);
+            } else
+                HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec(r, st_);
             HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
             HP_LAUNCH(13, k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
@@ -805,8 +836,8 @@ struct batch_launcher_t {
 #undef HP_LAUNCH
     void report() const {
         if (!hp_on) return;
-        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","(unused)","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat"};
-        for (int i = 0; i < 24; ++i)
+        static const char* hp_names[] = {"k_path_generate","k_generate","(unused)","k_trace_refill","(unused)","k_trace_heavy","k_path_fsd","k_path_interact","k_path_edges","k_path_interact_b","k_path_nee","k_interact","k_edges","k_interact_b","k_flux_split","k_flux_tasks","k_interact_c","k_interact_c_hard","k_path_flush","k_connect_enum","k_connect_scan","k_connect_strat","k_connect_strat_open","k_connect_splat","k_interact_diffuse","k_interact_dielectric","k_interact_spm","k_interact_any","k_connect_eval","k_connect_shadow","k_connect_mis"};
+        for (int i = 0; i < 31; ++i)
             if (hp_n[i]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", hp_names[i], hp_n[i], hp_t[i], hp_t[i] / hp_n[i]);
         if (hp_n[31]) fprintf(stderr, "[host prof] %-22s %6lu calls %9.1f us total %7.2f us each\n", "hipEventRecord", hp_n[31], hp_t[31], hp_t[31] / hp_n[31]);
     }
@@ -1176,6 +1207,7 @@ static void release_device(wtgpu_scene* s) {
     s->streams.clear();
     s->slices.clear();
     s->d_path_slices.clear();
+    s->d_tri_class = nullptr;
     s->uploaded = false;
 }
 

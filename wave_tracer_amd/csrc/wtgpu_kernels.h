@@ -59,7 +59,10 @@ constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane 
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
-                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23, CTL_WORDS = 40 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
+                  CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23,
+                  CTL_CLS_COUNT0 = 33, CTL_CLS_HEAD0 = 37,   // the material-sorted pass A: sizes and dequeue heads of the kNumWalkClasses class queues (k_classify / k_interact_cls)
+                  CTL_PEND_COUNT = 41, CTL_PEND_HEAD = 42, CTL_MIS_HEAD = 43,   // the staged connections (k_connect_eval / k_connect_shadow / k_connect_mis)
+                  CTL_WORDS = 48 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 // ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
@@ -104,6 +107,16 @@ struct device_state_t {
     uint32_t* strat_prefix = nullptr;   // [kNumKeys + 1]
     double* lacc = nullptr;             // [4][cap] per-sample sum of the t>1 strategies' fluxes
     unsigned long long* counters = nullptr;   // bdpt_counters_t + 2 (shared by all slices)
+    const struct bdpt_ext_t* ext = nullptr;   // more plt_bdpt state behind one pointer (device memory; the launch block must stay below 1 KB, see path_state_t)
+};
+// plt_bdpt only — like path_state_t a device-resident block that kernels reach through one pointer of the launch block.
+struct bdpt_ext_t {
+    // material-sorted pass A: walk class of every triangle (wt/bdpt.h: walk_class_of_triangle, built at upload) and the round's class queues
+    const unsigned char* tri_class = nullptr;
+    uint32_t* cls_queue = nullptr;   // [kNumWalkClasses][2 cap]
+    // staged connections: the connections that wait for their shadow ray (k_connect_eval -> k_connect_shadow -> k_connect_mis)
+    struct conn_pending_t* pend = nullptr;
+    uint32_t pend_cap = 0;
 };
 // plt_path only — a device-resident block the path kernels get a pointer to (launch_args_t stays below 1024 bytes: by-value kernel
 // arguments beyond that cost 40 % of a plt_bdpt pass with four streams, measured: 976 -> 1048 bytes, 15.4 -> 11.1 Msamples/s).
@@ -226,6 +239,11 @@ __global__ void k_generate(launch_args_t a);
 __global__ void k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round);
 __global__ void k_trace_heavy(launch_args_t a);
 __global__ void k_interact(launch_args_t a, int in, int first_round);
+__global__ void k_classify(launch_args_t a, int in, int first_round);
+__global__ void k_interact_diffuse(launch_args_t a, int in);
+__global__ void k_interact_dielectric(launch_args_t a, int in);
+__global__ void k_interact_spm(launch_args_t a, int in);
+__global__ void k_interact_any(launch_args_t a, int in);
 __global__ void k_edges(launch_args_t a);
 __global__ void k_interact_b(launch_args_t a, int in);
 __global__ void k_flux_split(launch_args_t a);
