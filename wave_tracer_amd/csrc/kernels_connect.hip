@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
         a.st.strat_prefix[kNumKeys] = acc;
         a.st.ctl[CTL_STRAT_HEAD] = 0;
         a.st.ctl[CTL_STRAT_HEAD_OPEN] = 0;
+        a.st.ctl[CTL_PEND_COUNT] = a.st.ctl[CTL_PEND_HEAD] = a.st.ctl[CTL_SURV_COUNT] = a.st.ctl[CTL_MIS_HEAD] = 0;
     }
 }
 // OPEN = false: the buckets with one strategy each (all of them while no subpath exceeds 17 vertices).  OPEN = true (k_connect_strat_open): the
@@ -162,6 +163,181 @@ __device__ inline __attribute__((always_inline)) void connect_strat_body(const l
 }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat(launch_args_t a) { connect_strat_body<false>(a); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat_open(launch_args_t a) { connect_strat_body<true>(a); }
+// ---- staged connections (the default; k_connect_strat, one kernel for the whole strategy, stays as the A/B reference: WTGPU_STAGED_CONNECT=0) ---
+// A connection is three things with very different shapes: forming the two connecting beams (two vertex loads, two BSDF evaluations, ~200
+// registers), one any-hit ray (a BVH stack, ~90 registers, a run time that varies by two orders of magnitude), and the MIS weight (a stream
+// over both subpaths).  One kernel for all three (k_connect_strat) carries the union of their registers — 256 + a 1.5-KB frame, two wavefronts
+// per SIMD — and runs the ray with whatever lanes still have a connection.  Here:
+//   k_connect_eval    lane / (sample, s, t), items bucketed by strategy as before: bdpt_connect<DEFER> — everything of connect_subpaths but the
+//                     ray; connections with flux > 0 go into the pending list (52 B: sample, (s,t), flux, ray);
+//   k_connect_shadow  lane / pending connection, ALL lanes: the any-hit ray (src/ads/bvh8w.cpp:556-603), survivors compacted;
+//   k_connect_mis     lane / survivor: the temporary vertex of the s = 1 / t = 1 / virtual-sensor strategies formed again from the same random
+//                     numbers (bdpt_connect_temp), streaming MIS weight (plt_bdpt_detail.hpp:604-720), flux sum or light-image splat.
+// Same functions, same numbers as the one-piece form (the CPU checker runs both: tests/test_oracle.py::test_staged_connections_are_the_connections).
+constexpr uint32_t kPendShadow = 0x80000000u;   // conn_pending_t::st: the connection waits for its ray (t in bits 16..30, s in bits 0..15)
+__device__ inline void pending_append(const launch_args_t& a, bool keep, uint32_t i, int s, int t, const connect_ret_t& cr) {
+    const bdpt_ext_t& x = *a.st.ext;
+    const unsigned long long m = __ballot(keep);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(a.st.ctl + CTL_PEND_COUNT, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (!keep || slot >= x.pend_cap) return;   // (a full pool: the count keeps growing, the host reports the batch as failed — wtgpu.hip: drain_rec)
+    conn_pending_t r;
+    r.i = i;
+    r.st = (uint32_t)s | ((uint32_t)t << 16) | (cr.need_shadow ? kPendShadow : 0u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.L[c] = cr.L.s[c];
+    r.o[0] = cr.ray.o.x, r.o[1] = cr.ray.o.y, r.o[2] = cr.ray.o.z;
+    r.d[0] = cr.ray.d.x, r.d[1] = cr.ray.d.y, r.d[2] = cr.ray.d.z;
+    r.dist = cr.ray.dist;
+    x.pend[slot] = r;
+}
+template <bool OPEN>
+__device__ inline __attribute__((always_inline)) void connect_eval_body(const launch_args_t& a) {
+    __shared__ uint32_t s_prefix[kNumKeys + 1];
+    constexpr int K = (int)kKeyDim - 1;
+    if (!OPEN) {
+        for (uint32_t k = threadIdx.x; k <= kNumKeys; k += kBlock) s_prefix[k] = a.st.strat_prefix[k];
+    } else if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < kNumKeys; ++k) {
+            s_prefix[k] = acc;
+            if ((int)(k / kKeyDim) == K || (int)(k % kKeyDim) == K) acc += a.st.strat_prefix[k + 1] - a.st.strat_prefix[k];
+        }
+        s_prefix[kNumKeys] = acc;
+    }
+    __syncthreads();
+    const uint32_t total = s_prefix[kNumKeys];
+    bdpt_counters_t ctr;
+    ctr.connections = ctr.shadow_rays = 0;
+    const stack_ref_t no_stack = make_stack_ref(nullptr, 0, 0, 0, nullptr);   // (bdpt_connect<true> traces nothing)
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap, a.st.ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
+    for (;;) {
+        const uint32_t idx = wave_grab(a.st.ctl + (OPEN ? CTL_STRAT_HEAD_OPEN : CTL_STRAT_HEAD)) + (threadIdx.x & 63);
+        if (idx - (threadIdx.x & 63) >= total) break;
+        if (idx < total) {
+            uint32_t lo = 0, hi = kNumKeys;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_prefix[mid] <= idx)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const uint32_t key = lo;
+            const int tk = (int)(key / kKeyDim), sk = (int)(key % kKeyDim);
+            if (!OPEN && (tk == K || sk == K)) continue;   // (k_connect_eval_open's)
+            const uint32_t i = a.st.strat_items[(size_t)key * a.st.cap + (idx - s_prefix[key])];
+            const uint64_t j = a.j0 + i;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t smp = a.sample_begin + j / a.npix;
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
+            const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
+            auto one = [&](int s, int t) __attribute__((always_inline)) {
+                connect_ret_t cr;
+                bdpt_connect<true>(a.sc, pool, svs, evs, s, t, a.seed, sample_id, no_stack, cr, &ctr, nullptr);
+                pending_append(a, cr.L.s[0] > 0.f, i, s, t, cr);
+            };
+            if constexpr (!OPEN) {
+                one(sk, tk);
+            } else {
+                const int nT = (int)a.st.walks[(size_t)i * a.st.walk_words + WT_WALK_NVERTS_WORD];
+                const int nS = (int)a.st.walks[((size_t)a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
+                const int t1 = tk == K ? nT : tk, s1 = sk == K ? nS : sk;
+                for (int t = tk; t <= t1; ++t)
+                    for (int s = sk; s <= s1; ++s)
+                        if (strategy_valid(a.sc.opts, s, t, nS, nT)) one(s, t);
+            }
+        }
+    }
+    if (a.count_stats) {
+        unsigned long long vc = ctr.connections, vr = ctr.shadow_rays;
+        for (int off = 32; off > 0; off >>= 1) {
+            vc += __shfl_down(vc, off, 64);
+            vr += __shfl_down(vr, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (vc) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, connections) / sizeof(unsigned long long), vc);
+            if (vr) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, shadow_rays) / sizeof(unsigned long long), vr);
+        }
+    }
+}
+#ifndef WTGPU_LB_EVAL
+#define WTGPU_LB_EVAL 2
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_EVAL) k_connect_eval(launch_args_t a) { connect_eval_body<false>(a); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_EVAL) k_connect_eval_open(launch_args_t a) { connect_eval_body<true>(a); }
+
+__global__ void __launch_bounds__(kBlock, 4) k_connect_shadow(launch_args_t a) {
+    __shared__ stack_entry_t lds[kLdsStack * kBlock];
+    stack_entry_t spill[kSpillStack];
+    stack_ref_t stack;
+    lds_stack(lds, spill, stack);
+    const bdpt_ext_t& x = *a.st.ext;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = min(ctl[CTL_PEND_COUNT], x.pend_cap);
+    for (;;) {
+        const uint32_t idx = wave_grab(ctl + CTL_PEND_HEAD) + (threadIdx.x & 63);
+        if (idx - (threadIdx.x & 63) >= n) break;
+        bool alive = false;
+        if (idx < n) {
+            const conn_pending_t& r = x.pend[idx];
+            alive = true;
+            if (r.st & kPendShadow) alive = !ads_shadow_ray(a.sc, vec3{r.o[0], r.o[1], r.o[2]}, vec3{r.d[0], r.d[1], r.d[2]}, range_t{0.f, r.dist}, stack, nullptr);
+        }
+        wave_append(x.surv, ctl + CTL_SURV_COUNT, alive, idx);
+    }
+}
+
+#ifndef WTGPU_LB_MIS
+#define WTGPU_LB_MIS 2
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_MIS) k_connect_mis(launch_args_t a) {
+    const bdpt_ext_t& x = *a.st.ext;
+    uint32_t* ctl = a.st.ctl;
+    const uint32_t n = ctl[CTL_SURV_COUNT];
+    const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
+    bdpt_counters_t ctr;
+    ctr.light_splats = 0;
+    for (;;) {
+        const uint32_t k = wave_grab(ctl + CTL_MIS_HEAD) + (threadIdx.x & 63);
+        if (k - (threadIdx.x & 63) >= n) break;
+        if (k >= n) continue;
+        const conn_pending_t& r = x.pend[x.surv[k]];
+        const uint32_t i = r.i, st = r.st;
+        const int s = (int)(st & 0xFFFFu), t = (int)((st >> 16) & 0x7FFFu);
+        stokes_t L;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) L.s[c] = r.L[c];
+        const uint64_t j = a.j0 + i;
+        const uint32_t pix = (uint32_t)(j % a.npix);
+        const uint64_t smp = a.sample_begin + j / a.npix;
+        const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
+        sample_ctx_t ctx;
+        soa_load(a.st.ctx, kCtxWords, i, ctx);
+        const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
+        vertex_nb_t tv;
+        sensor_element_t element;
+        bool has_element = false;
+        if (s <= 1 || t <= 1) bdpt_connect_temp(a.sc, svs, evs, s, t, a.seed, sample_id, tv, element, has_element);
+        const stokes_t flux = bdpt_strategy_finish(a.sc, pool, a.film, svs, evs, s, t, ctx, L, tv, element, has_element, &ctr);
+        if (t > 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
+        }
+    }
+    if (a.count_stats) {
+        unsigned long long v = ctr.light_splats;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.st.counters + offsetof(bdpt_counters_t, light_splats) / sizeof(unsigned long long), v);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_connect_splat(launch_args_t a) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.nb) return;

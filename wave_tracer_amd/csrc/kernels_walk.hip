@@ -209,7 +209,7 @@ __device__ inline __attribute__((always_inline)) void interact_cls_body(const la
     }
 }
 #ifndef WTGPU_LB_CLS
-#define WTGPU_LB_CLS 4
+#define WTGPU_LB_CLS 3
 #endif
 #ifndef WTGPU_LB_CLS_SPM
 #define WTGPU_LB_CLS_SPM 3

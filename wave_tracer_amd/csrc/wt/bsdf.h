@@ -222,6 +222,7 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, materi
     }
     uint32_t two = 0;
     float scale = 1.f;
+    int cur = mat;
     for (int depth = 0; depth < 4 && m.type >= MAT_COMPOSITE; ++depth) {
         two |= m.two_sided;
         scale *= m.scale;
@@ -233,13 +234,16 @@ WT_HD bool material_resolve(const scene_t& sc, int mat, float k, vec2 uv, materi
             wr.mask_two = two != 0;
             child = m.nested;
         } else {
+            // (the bins are read from the scene's record, not from the local copy: a dynamically indexed local array lives in scratch memory on the device)
+            const material_t& gm = sc.materials[cur];
             for (uint32_t i = 0; i < m.n_bins && i < (uint32_t)kMaxCompositeBins; ++i)
-                if (m.bin_kmin[i] <= k && k < m.bin_kmax[i]) {
-                    child = m.bin_child[i];
+                if (gm.bin_kmin[i] <= k && k < gm.bin_kmax[i]) {
+                    child = gm.bin_child[i];
                     break;
                 }
         }
         if (child < 0) return false;
+        cur = child;
         m = sc.materials[child];
     }
     if (m.type >= MAT_COMPOSITE) return false;   // nesting deeper than the flattener produces

@@ -77,6 +77,9 @@ struct wtgpu_scene {
     std::vector<device_state_t> slices;              // per-batch path state, one slice per internal stream
     std::vector<const path_state_t*> d_path_slices;  // ... and its plt_path part (device copies)
     const unsigned char* d_tri_class = nullptr;       // walk class of every triangle (bdpt_ext_t::tri_class)
+    uint32_t pend_cap = 0;                            // pending-connection records per slice (bdpt_ext_t::pend_cap)
+    uint64_t conn_pool_overflow = 0;                  // connections a full pool dropped (the render call that drains such a batch fails)
+    uint64_t pend_high_water = 0;                     // most pending connections a batch produced (stats)
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> ev_done;
     hipEvent_t ev_begin = nullptr;
@@ -116,7 +119,7 @@ struct wtgpu_scene {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 1, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
-        uint32_t sorted_interact = 1, staged_connect = 1, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
+        uint32_t sorted_interact = 1, staged_connect = 1, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -465,6 +468,7 @@ static void read_knobs(wtgpu_scene* s) {
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
     k.sorted_interact = u("WTGPU_SORTED_INTERACT", 1);
     k.staged_connect = u("WTGPU_STAGED_CONNECT", 1);
+    k.conn_pool = std::max(1u, u("WTGPU_CONN_POOL", 16));
     if (const char* e = getenv("WTGPU_GRID_CLS")) {
         unsigned v[4] = {1, 4, 2, 4};
         sscanf(e, "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]);
@@ -562,6 +566,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
         // plt_path: two wedge pools of 48 records per walk, the deferred-NEE records, the queues of the wave-per-walk kernels
         if (pm) per_sample += 2ull * 48ull * sizeof(utd_edge_rec_t) + sizeof(path_nee_rec_t) + 3ull * 4ull + 4ull + sizeof(uint2);
+        else per_sample += (uint64_t)s->knobs.conn_pool * (sizeof(conn_pending_t) + 4ull) + 4ull * 2ull * kNumWalkClasses;   // pending connections, class queues
         uint64_t budget = 224ull << 30;   // of the MI355X's 288 GB (three slices of a two-pass 1440^2 batch are 186 GB); WTGPU_STATE_GB overrides
         if (const char* e = getenv("WTGPU_STATE_GB")) budget = (uint64_t)std::max(1, atoi(e)) << 30;
         // ... and within what the device has free right now (another scene, torch's caching allocator, a smaller GPU): 85 % of it, the rest is
@@ -609,6 +614,13 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
             bdpt_ext_t X;
             X.tri_class = s->d_tri_class;
             if ((rc = dmalloc(s, &X.cls_queue, (size_t)kNumWalkClasses * W2))) return rc;
+            // staged connections: room for `conn_pool` (16; WTGPU_CONN_POOL) pending connections per sample of the batch — the high-water mark of a
+            // render is printed with WTGPU_VERBOSE=1 (release_device), DESIGN.md §4 has the measured ones; a batch that needs more is reported as
+            // failed (drain_rec), never silently short
+            X.pend_cap = (uint32_t)std::min<uint64_t>((uint64_t)s->knobs.conn_pool * st.cap + 4096, 0xFFFFFF00ull);
+            if ((rc = dmalloc(s, &X.pend, (size_t)X.pend_cap))) return rc;
+            if ((rc = dmalloc(s, &X.surv, (size_t)X.pend_cap))) return rc;
+            s->pend_cap = X.pend_cap;
             bdpt_ext_t* dX = nullptr;
             if ((rc = dmalloc(s, &dX, 1))) return rc;
             HIP_CHECK(hipMemcpy(dX, &X, sizeof(X), hipMemcpyHostToDevice));
@@ -668,6 +680,15 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     if (!r.busy) return WTGPU_OK;
     HIP_CHECK(hipEventSynchronize(r.ev[r.ev_final]));
     const uint32_t rounds = r.h_ctl[CTL_ROUNDS];
+    if (s->pend_cap) {   // staged connections: a batch that overran the pending pool lost connections
+        s->pend_high_water = std::max<uint64_t>(s->pend_high_water, r.h_ctl[CTL_PEND_COUNT]);
+        if (r.h_ctl[CTL_PEND_COUNT] > s->pend_cap) {
+            s->conn_pool_overflow += r.h_ctl[CTL_PEND_COUNT] - s->pend_cap;
+            r.busy = false;
+            return fail(WTGPU_ERR_OVERFLOW, "the pending-connection pool of a batch overflowed (" + std::to_string(r.h_ctl[CTL_PEND_COUNT]) + " connections, room for " +
+                                           std::to_string(s->pend_cap) + "): the films of this render are incomplete; set WTGPU_CONN_POOL (records per sample, default 16) higher");
+        }
+    }
     s->cap_hits += r.h_ctl[CTL_COUNT0 + (r.rounds_launched & 1u)] + r.h_ctl[CTL_BACK0 + (r.rounds_launched & 1u)];   // walks still active after the last round
     s->acc[4] += rounds;
     s->acc[5] += rounds;
@@ -816,8 +837,16 @@ struct batch_launcher_t {
         } else {
             HP_LAUNCH(19, k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
             HP_LAUNCH(20, k_connect_scan, dim3(1), dim3(64), 0, st_, a);
-            HP_LAUNCH(21, k_connect_strat, dim3(gf), dim3(kBlock), 0, st_, a);
-            if ((uint32_t)s->host.opts.max_depth + 2 >= kKeyDim - 1) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
+            const bool open = (uint32_t)s->host.opts.max_depth + 2 >= kKeyDim - 1;
+            if (K.staged_connect) {
+                HP_LAUNCH(28, k_connect_eval, dim3(gf), dim3(kBlock), 0, st_, a);
+                if (open) HP_LAUNCH(28, k_connect_eval_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
+                HP_LAUNCH(29, k_connect_shadow, dim3(gf), dim3(kBlock), 0, st_, a);
+                HP_LAUNCH(30, k_connect_mis, dim3(gf), dim3(kBlock), 0, st_, a);
+            } else {
+                HP_LAUNCH(21, k_connect_strat, dim3(gf), dim3(kBlock), 0, st_, a);
+                if (open) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
+            }
             // (the tiled splat pays off when the batch holds most of the film's elements: it visits every row segment of the film)
             const uint32_t fw = a.film.width, fh = a.film.height, planes = film_planes(s->host.sensor);
             if (K.tiled_splat && s->host.sensor.rf_radius <= 1 && planes <= 16 && (uint64_t)nb * 2u >= (uint64_t)a.npix)
@@ -1206,8 +1235,12 @@ static void release_device(wtgpu_scene* s) {
         if (st_) (void)hipStreamDestroy(st_);
     s->streams.clear();
     s->slices.clear();
+    if (getenv("WTGPU_VERBOSE") && s->pend_cap && !s->slices.empty())
+        fprintf(stderr, "[wtgpu] pending connections of a batch, high water: %llu (%.2f per sample of a full batch; pool %u)\n", (unsigned long long)s->pend_high_water,
+                (double)s->pend_high_water / (double)s->slices[0].cap, s->pend_cap);
     s->d_path_slices.clear();
     s->d_tri_class = nullptr;
+    s->pend_cap = 0;
     s->uploaded = false;
 }
 
