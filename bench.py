@@ -36,8 +36,8 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     sc = Scene(scene_name, res=res, mesh_detail=mesh_detail, polarimetric=polarimetric)
     n_tiles = ((sc.width + 23) // 24) * ((sc.height + 23) // 24)
-    # work unit of the checker = one 24x24 block (the reference's block size): keep >= 4 blocks per core in flight
-    stride = max(1, n_tiles // (4 * cores))
+    # work unit of the checker = one 24x24 block x one sample index: >= 8 blocks per core, spp work items per block
+    stride = max(1, n_tiles // (8 * cores))
     t = time.time()
     _, _, _, _, n1, _ = oracle_render_tiles(sc, 0, 1, 123, stride, 0, threads=cores)      # calibration pass
     dt1 = max(1e-3, time.time() - t)
@@ -45,9 +45,15 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
     t = time.time()
     _, _, _, _, n, _ = oracle_render_tiles(sc, 1, 1 + spp, 123, stride, 0, threads=cores)
     dt = time.time() - t
-    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+    import ctypes
+    from oracle_util import load_oracle
+    lib = load_oracle()
+    lib.oracle_last_utilisation.restype = ctypes.c_double
+    util = float(lib.oracle_last_utilisation())
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "thread_utilisation": util,
             "sample": f"{scene_name} res={res}: every {stride}th 24x24 block of the SAME {sc.width}x{sc.height} film, {spp} spp "
-                      f"({n} samples, {dt:.1f}s), {cores} threads; scalar fp32 restatement (oracle/), baseline only"}
+                      f"({n} samples, {dt:.1f}s), {cores} threads, work items of one block x one sample index (mean busy / longest busy thread "
+                      f"{util:.2f}); scalar fp32 restatement (oracle/), baseline only"}
 
 
 def measure_traffic(kernel, scene_args, timeout_s=240):
@@ -65,7 +71,7 @@ def measure_traffic(kernel, scene_args, timeout_s=240):
     # counter -> bytes factors: the newest committed calibration (profiles/rNN_pmc_traffic.json["calibration"], written by
     # tools/make_traffic_json.py from the k_calib_copy passes of tools/profile_round.sh); without one, the guide's value for FETCH_SIZE (x2) and 1
     kf, kw, cal_src = 2.0, 1.0, "MI355X_MICROARCH.md (FETCH_SIZE x 2), uncalibrated"
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
                 cal = json.load(f)["calibration"]
@@ -227,11 +233,18 @@ def main():
                 t.copy_(h)
     sync()
     dt = time.time() - t0
+    dt_rank = dt
     if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # self-diagnosing multi-GPU line: every rank's own wall time of the K steps (before the max), gathered on rank 0
+    per_rank_s = [dt_rank]
+    if distributed:
+        gl = [torch.zeros(1, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu") for _ in range(world)]
+        dist.all_gather(gl, torch.tensor([dt_rank], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu"))
+        per_rank_s = [float(x.item()) for x in gl]
     film_sums = [float(t.sum().item()) for t in (value, weight, light)] if args.film_sums else None   # (rank 0 holds the reduced film)
     counters = sc.counters()
     tsum = sc.timings()      # HIP-event kernel times accumulated over the timed region (reset after the warm-up)
@@ -288,7 +301,12 @@ def main():
             del value, weight, light
             sc.close()
             torch.cuda.empty_cache()
-            kname = {"k_trace": "k_trace_refill", "k_connect": "k_connect_strat", "k_edges+k_interact_b": "k_interact_b",
+            # (the brackets of the material-sorted pass A and of the staged connections span several kernels: their bytes are summed)
+            staged = os.environ.get("WTGPU_STAGED_CONNECT", "1") != "0"
+            sorted_a = os.environ.get("WTGPU_SORTED_INTERACT", "1") != "0"
+            kname = {"k_trace": "k_trace_refill", "k_connect": ("k_connect_eval", "k_connect_shadow", "k_connect_mis") if staged else "k_connect_strat",
+                     "k_interact": ("k_classify", "k_interact_diffuse", "k_interact_dielectric", "k_interact_spm", "k_interact_any") if sorted_a else "k_interact",
+                     "k_edges+k_interact_b": "k_interact_b",
                      "k_flux_split+k_flux_tasks": "k_flux_tasks",
                      PATH_BRACKET: ("k_path_fsd", "k_path_interact", "k_path_edges", "k_path_interact_b", "k_path_nee")}.get(dom, dom)
             scene_args = ["--scene", args.scene, "--res", str(args.res), "--mesh-detail", str(md), "--polarimetric", str(pol)] + (["--ray-tracing"] if args.ray_tracing else [])
@@ -336,7 +354,17 @@ def main():
                                     "traversal_stack_dropped": counters["traversal_stack_dropped"] / ns},
         }
         if distributed:
-            out["film_reduce"] = {"through": "wtgpu_film_reduce (RCCL inside the C-ABI library)" if comm is not None else "torch.distributed gloo (host)", "ranks": world}
+            rccl = None
+            try:
+                v = torch.cuda.nccl.version()
+                rccl = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+            except Exception:
+                pass
+            film_bytes = sum(int(t.numel()) * t.element_size() for t in (value, weight, light)) if value is not None else None
+            out["film_reduce"] = {"through": "wtgpu_film_reduce (RCCL inside the C-ABI library: one group of three ncclReduce)" if comm is not None else "torch.distributed gloo (host)",
+                                  "ranks": world, "rccl_version": rccl, "bytes_per_rank": film_bytes, "backend": args.backend}
+            # per rank: wall seconds of the timed region and the rate of the samples that rank rendered (weak: K * S * npix each)
+            out["per_rank"] = [{"rank": r, "seconds": per_rank_s[r], "msamples_per_s": npix * K * s_rank / per_rank_s[r] / 1e6} for r in range(world)]
         if film_sums is not None:
             out["film_sums"] = {"value": film_sums[0], "weight": film_sums[1], "light": film_sums[2]}
         if world == 1 and not args.no_cpu_baseline:

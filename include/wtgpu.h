@@ -141,11 +141,12 @@ int wtgpu_join(wtgpu_scene* scene, void* stream);
 typedef int (*wtgpu_progress_cb)(uint64_t samples_done, uint64_t samples_total, void* user);
 int wtgpu_render_progressive(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin,
                              uint64_t sample_end, uint64_t seed, uint32_t chunk_spp, wtgpu_progress_cb progress, void* user, uint64_t* spe_done);
-int wtgpu_cancel(wtgpu_scene* scene);   /* thread-safe; cleared when the next wtgpu_render_progressive starts */
+int wtgpu_cancel(wtgpu_scene* scene);   /* thread-safe; cleared when the next wtgpu_render_progressive starts; also lifts a pause (a full reset) */
 /* The renderer's other three interrupts (include/wt/scene/interrupts.hpp; scene_renderer_t::process_interrupts, src/scene/render.cpp:329-368),
  * all thread-safe, all taking effect at the next chunk boundary of a running wtgpu_render_progressive:
  *   wtgpu_pause / wtgpu_resume      the render thread stops launching (it polls every millisecond) until resumed or cancelled; the films hold
- *                                   exactly the completed chunks while it waits.
+ *                                   exactly the completed chunks while it waits.  A pause is STICKY: issued while no render runs it holds the
+ *                                   next wtgpu_render_progressive after its first chunk; wtgpu_resume or wtgpu_cancel lift it.
  *   wtgpu_capture_intermediate      `capture intermediate`: the render thread calls capture(samples_per_element_done, user) ONCE at the next chunk
  *                                   boundary (also while paused), with `stream` synchronised — the films then hold exactly the completed chunks and
  *                                   the callback may download / develop them (wtgpu_develop) — and carries on in the state it was in, like the

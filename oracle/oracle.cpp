@@ -17,6 +17,7 @@
 // tests/test_path_oracle.py (free-space coverage, white furnace).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -57,6 +58,7 @@ int g_split_step = 0;
 // 1: every (s,t) strategy the way the device's staged connection kernels run it (wt/bdpt.h: bdpt_strategy<true> — flux without the shadow ray, the
 // ray, MIS + splat with the temporary vertex formed again).  The results must be identical (test_staged_connections_are_the_connections).
 int g_staged_connect = 0;
+double g_last_utilisation = 1.0;   // of the worker threads of the last render (oracle_last_utilisation)
 
 void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
     unsigned long long* pa = reinterpret_cast<unsigned long long*>(&a);
@@ -153,6 +155,9 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
     std::atomic<uint64_t> n_done{0};
     std::vector<bdpt_counters_t> ctrs(n_threads);
     for (auto& c : ctrs) std::memset(&c, 0, sizeof(c));
+    std::vector<double> busy(n_threads, 0.0);
+    const uint64_t n_spp = sample_end > sample_begin ? sample_end - sample_begin : 0;
+    const uint32_t items_per_block = (n_threads > 1 && n_spp > 1 && n_spp <= 4096) ? (uint32_t)n_spp : 1u;
     // FSD aperture pool: per thread, reset per sample (apertures only live for one sample)
     auto worker = [&](int tid) {
         sample_scratch_t scr;
@@ -168,14 +173,20 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
         bdpt_counters_t& ctr = ctrs[tid];
         const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
         std::vector<utd_edge_rec_t> utd(kUtdMaxEdges);
+        const auto t_begin = std::chrono::steady_clock::now();
         for (;;) {
-            const uint32_t blk = next.fetch_add(1);
+            const uint32_t item = next.fetch_add(1);
+            const uint32_t blk = item / items_per_block;
             if (blk >= bx * by) break;
             if (tile_stride > 1 && blk % tile_stride != tile_offset) continue;
+            // the samples of this work item: all of the block's (one thread: the summation order the golden fixtures were made with), or one
+            // sample index of it (several threads: 24 x 24 x spp samples per item left a 256-thread host waiting for its slowest blocks)
+            const uint64_t s_lo = items_per_block > 1 ? sample_begin + item % items_per_block : sample_begin;
+            const uint64_t s_hi = items_per_block > 1 ? s_lo + 1 : sample_end;
             const uint32_t x0 = (blk % bx) * B, y0 = (blk / bx) * B;
             for (uint32_t y = y0; y < std::min(H, y0 + B); ++y)
                 for (uint32_t x = x0; x < std::min(W, x0 + B); ++x)
-                    for (uint64_t s = sample_begin; s < sample_end; ++s) {
+                    for (uint64_t s = s_lo; s < s_hi; ++s) {
                         n_done.fetch_add(1, std::memory_order_relaxed);
                         const uint64_t pix = (uint64_t)y * W + x;
                         const uint64_t sample_id = (pix << 32) | (s & 0xFFFFFFFFull);
@@ -196,10 +207,19 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
                             bdpt_connect_all(sc, pool, film, svs, evs, (int)sw.nverts, (int)ew.nverts, ctx, seed, sample_id, stack, &ctr, nullptr);
                     }
         }
+        busy[tid] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     };
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
     for (auto& t : th) t.join();
+    {   // utilisation of the workers over the render: mean busy time / longest busy time (1 = nobody waited for a straggler)
+        double sum = 0, mx = 0;
+        for (double b : busy) {
+            sum += b;
+            mx = std::max(mx, b);
+        }
+        g_last_utilisation = mx > 0 ? sum / (mx * n_threads) : 1.0;
+    }
     if (counters_out) {
         bdpt_counters_t total;
         std::memset(&total, 0, sizeof(total));
@@ -445,6 +465,7 @@ void oracle_set_region_filter(int on) { g_region_filter = on; }
 void oracle_set_traverse_axis(int on) { g_traverse_axis = on; }
 void oracle_set_walk_axis(int on) { g_walk_axis = on; }
 void oracle_set_split_step(int mode) { g_split_step = mode; }
+double oracle_last_utilisation() { return g_last_utilisation; }
 void oracle_set_staged_connect(int on) { g_staged_connect = on; }
 
 // Region summaries of cone queries of any size: what the reference's unbounded intersection record yields (`list`: every triangle

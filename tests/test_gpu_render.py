@@ -234,6 +234,39 @@ def test_batches_enqueued_in_two_parts_render_the_same(built, monkeypatch):
         assert out["0"][2]["rounds_per_batch"] <= with_work + 16   # (the first batches guess 32; afterwards: the recent mean + 2, then 8 at a time)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,spp", [("cornell_box", dict(res=48, mesh_detail=0), 4), ("bidir_room", dict(res=48), 2), ("furnace_wall_mask", dict(res=24), 8),
+                                         ("furnace_spm", dict(res=32), 4), ("double_slits", dict(res=96, lut=(64, 64)), 2)])
+def test_material_sorted_pass_and_staged_connections_render_the_same(built, monkeypatch, name, kw, spp):
+    """The interaction pass sorted by material class (k_classify + one kernel per BSDF class, or the one-launch form with work stealing) and the
+    connections in three stages (k_connect_eval -> k_connect_shadow -> k_connect_mis, in chunks that cannot overflow their pending list) against
+    the one-kernel forms: the same walks, vertices and connections (every counter equal), the same films up to the order of the f64 / f32 sums."""
+    import torch
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.render import alloc_films
+    out = {}
+    for mode in ((0, 0), (1, 0), (2, 0), (0, 1), (2, 1)):
+        monkeypatch.setenv("WTGPU_SORTED_INTERACT", str(mode[0]))
+        monkeypatch.setenv("WTGPU_STAGED_CONNECT", str(mode[1]))
+        monkeypatch.setenv("WTGPU_CONN_POOL", "2")   # (two pending records per sample: several chunks have work)
+        sc = Scene(name, **kw)
+        sc.upload(0, 2048)
+        dev = torch.device("cuda", 0)
+        films = alloc_films(sc, dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        sc.reset_counters()
+        sc.render_into(*films, 0, spp, 31, st)
+        torch.cuda.synchronize(dev)
+        out[mode] = ([f.cpu().numpy() for f in films], sc.counters())
+        sc.close()
+    ref, cref = out[(0, 0)]
+    assert cref["surface_interactions"] > 1000 and cref["connections"] > 1000 and cref["shadow_rays"] > 100
+    for mode, (films, c) in out.items():
+        assert c == cref, (mode, c, cref)
+        for a, b in zip(films, ref):
+            assert np.allclose(a, b, rtol=2e-6, atol=1e-12 * max(1.0, float(np.abs(b).max()))), (name, mode, float(np.abs(a - b).max()))
+
+
 def test_empty_sample_range_is_a_noop(built):
     from wave_tracer_amd import Scene, render
     sc = Scene("furnace", res=16, lut=(32, 32))

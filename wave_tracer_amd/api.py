@@ -266,8 +266,22 @@ class Scene:
     def capture_intermediate(self, fn):
         """`capture intermediate`: fn(samples_per_element_done) is called once by the render thread at its next chunk boundary, with the films
         consistent (exactly the completed chunks).  Thread-safe."""
-        cb = CAPTURE_CB(lambda done, user: fn(int(done)))
-        self._capture_keepalive = cb          # the C side keeps the pointer until it has been called
+        # every trampoline stays alive until it has been CALLED: a request that replaces a pending one may arrive after the render thread has
+        # already copied the old pointer
+        keep = self.__dict__.setdefault("_capture_keepalive", [])
+        slot = []
+
+        def tramp(done, user):
+            try:
+                fn(int(done))
+            finally:
+                if slot and slot[0] in keep:
+                    keep.remove(slot[0])
+        cb = CAPTURE_CB(tramp)
+        slot.append(cb)
+        keep.append(cb)
+        if len(keep) > 64:   # (requests that were replaced before they ran are never called: bound the list, oldest first)
+            del keep[0]
         _check(load_library().wtgpu_capture_intermediate(self._h, cb, None))
 
     def join(self, stream=None):

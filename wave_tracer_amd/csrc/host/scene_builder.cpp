@@ -670,6 +670,10 @@ int scene_builder_t::add_texture_constant(float r, float g, float b, float a) {
 }
 int scene_builder_t::add_texture_checkerboard(int tex1, int tex2) {
     if (tex1 < 0 || tex2 < 0 || tex1 >= (int)textures_.size() || tex2 >= (int)textures_.size()) throw std::runtime_error("checkerboard: unknown nested texture");
+    // (a checkerboard's cells are looked up through texture_rgba, wt/scene.h, which knows constants, checkerboards and bitmaps: an expression
+    // there would render as its default colour without a word)
+    if (texture_is_function(tex1) || texture_is_function(tex2))
+        throw std::runtime_error("checkerboard: function / mix textures as cell colours are not supported (only constant, checkerboard and bitmap textures)");
     texture_t t = texture_base(TEX_CHECKERBOARD);
     t.col1 = tex1;
     t.col2 = tex2;

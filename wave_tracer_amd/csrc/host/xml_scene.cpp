@@ -1118,7 +1118,9 @@ struct loader_t {
             const xnode_t* nm = n.child("texture");   // the texture child needs no name (src/bsdf/normalmap.cpp:43-45)
             if (!nm) throw std::runtime_error("normalmap bsdf: a texture and a nested bsdf expected");
             if (!nested(n, two_sided, out, "normalmap bsdf")) return false;
-            out.normal_tex = 1 + (uint32_t)texture(*nm);
+            const int nt = texture(*nm);
+            if (b.texture_is_function(nt)) throw std::runtime_error("normalmap bsdf: a function / mix texture as the normal map is not supported (its RGB lookup knows constant, checkerboard and bitmap textures)");
+            out.normal_tex = 1 + (uint32_t)nt;
             for (const char* name : {"flip_tangent", "flip"})
                 if (const xnode_t* f = n.named(name)) out.normal_flip = eval_number(f->get("value")) != 0.0 ? 1u : 0u;
             return true;
@@ -1487,7 +1489,10 @@ struct loader_t {
                         if (!b.texture_constant_rgb(t, rgb))
                             throw std::runtime_error("area emitter: a spatially varying radiance texture (per-triangle sampling tables, src/emitter/area.cpp:153-260) is not supported");
                         if (const xnode_t* sc = em->named("scale")) scale = eval_number(sc->get("value"));
-                        spec = b.spectrum_rgb(rgb[0], rgb[1], rgb[2]);
+                        // a luminance texture (every constant texture is one) is wavelength independent — area.hpp: scale * radiance->f({uv, k}).x —
+                        // at ANY wavenumber: a flat spectrum, not the RGB uplift, which is zero outside 380-720 nm (an IR / radio sensor would see a
+                        // dark emitter); only a genuinely coloured stand-in (an RGB bitmap's mean colour) is uplifted
+                        spec = (rgb[0] == rgb[1] && rgb[1] == rgb[2]) ? b.spectrum_const(rgb[0]) : b.spectrum_rgb(rgb[0], rgb[1], rgb[2]);
                     } else {
                         if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
                         const xnode_t unscaled = without_scale(*sp);

@@ -74,6 +74,8 @@ __global__ void __launch_bounds__(kEnumBlock) k_connect_enum(launch_args_t a) {
             }
 }
 __global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
+    if (a.st.ext)   // the counters of the staged connections' chunks
+        for (uint32_t q = threadIdx.x; q < a.st.ext->n_chunks * kChunkCtlWords; q += 64) a.st.ext->chunk_ctl[q] = 0;
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
         for (uint32_t k = 0; k < kNumKeys; ++k) {
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
         a.st.strat_prefix[kNumKeys] = acc;
         a.st.ctl[CTL_STRAT_HEAD] = 0;
         a.st.ctl[CTL_STRAT_HEAD_OPEN] = 0;
-        a.st.ctl[CTL_PEND_COUNT] = a.st.ctl[CTL_PEND_HEAD] = a.st.ctl[CTL_SURV_COUNT] = a.st.ctl[CTL_MIS_HEAD] = 0;
+
     }
 }
 // OPEN = false: the buckets with one strategy each (all of them while no subpath exceeds 17 vertices).  OPEN = true (k_connect_strat_open): the
@@ -169,23 +171,25 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat_open
 // over both subpaths).  One kernel for all three (k_connect_strat) carries the union of their registers — 256 + a 1.5-KB frame, two wavefronts
 // per SIMD — and runs the ray with whatever lanes still have a connection.  Here:
 //   k_connect_eval    lane / (sample, s, t), items bucketed by strategy as before: bdpt_connect<DEFER> — everything of connect_subpaths but the
-//                     ray; connections with flux > 0 go into the pending list (52 B: sample, (s,t), flux, ray);
+//                     ray; connections with flux > 0 go into the pending list (52 B: sample, (s,t), flux, ray).  The items of a batch are taken
+//                     in CHUNKS of as many items as the list has records, each chunk through the three kernels in turn: the list cannot
+//                     overflow, whatever the depth of the scene (bdpt_ext_t);
 //   k_connect_shadow  lane / pending connection, ALL lanes: the any-hit ray (src/ads/bvh8w.cpp:556-603), survivors compacted;
 //   k_connect_mis     lane / survivor: the temporary vertex of the s = 1 / t = 1 / virtual-sensor strategies formed again from the same random
 //                     numbers (bdpt_connect_temp), streaming MIS weight (plt_bdpt_detail.hpp:604-720), flux sum or light-image splat.
 // Same functions, same numbers as the one-piece form (the CPU checker runs both: tests/test_oracle.py::test_staged_connections_are_the_connections).
 constexpr uint32_t kPendShadow = 0x80000000u;   // conn_pending_t::st: the connection waits for its ray (t in bits 16..30, s in bits 0..15)
-__device__ inline void pending_append(const launch_args_t& a, bool keep, uint32_t i, int s, int t, const connect_ret_t& cr) {
+__device__ inline void pending_append(const launch_args_t& a, uint32_t* cctl, bool keep, uint32_t i, int s, int t, const connect_ret_t& cr) {
     const bdpt_ext_t& x = *a.st.ext;
     const unsigned long long m = __ballot(keep);
     if (!m) return;
     const int lane = threadIdx.x & 63;
     const int leader = __ffsll((long long)m) - 1;
     uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(a.st.ctl + CTL_PEND_COUNT, (uint32_t)__popcll(m));
+    if (lane == leader) base = atomicAdd(cctl + CHUNK_PEND_COUNT, (uint32_t)__popcll(m));
     base = (uint32_t)__shfl((int)base, leader, 64);
     const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (!keep || slot >= x.pend_cap) return;   // (a full pool: the count keeps growing, the host reports the batch as failed — wtgpu.hip: drain_rec)
+    if (!keep || slot >= x.pend_cap) return;   // (cannot happen: a chunk holds pend_cap items, each yields at most one connection)
     conn_pending_t r;
     r.i = i;
     r.st = (uint32_t)s | ((uint32_t)t << 16) | (cr.need_shadow ? kPendShadow : 0u);
@@ -196,30 +200,29 @@ __device__ inline void pending_append(const launch_args_t& a, bool keep, uint32_
     r.dist = cr.ray.dist;
     x.pend[slot] = r;
 }
-template <bool OPEN>
-__device__ inline __attribute__((always_inline)) void connect_eval_body(const launch_args_t& a) {
+#ifndef WTGPU_LB_EVAL
+#define WTGPU_LB_EVAL 2
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_EVAL) k_connect_eval(launch_args_t a, uint32_t chunk) {
     __shared__ uint32_t s_prefix[kNumKeys + 1];
-    constexpr int K = (int)kKeyDim - 1;
-    if (!OPEN) {
-        for (uint32_t k = threadIdx.x; k <= kNumKeys; k += kBlock) s_prefix[k] = a.st.strat_prefix[k];
-    } else if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < kNumKeys; ++k) {
-            s_prefix[k] = acc;
-            if ((int)(k / kKeyDim) == K || (int)(k % kKeyDim) == K) acc += a.st.strat_prefix[k + 1] - a.st.strat_prefix[k];
-        }
-        s_prefix[kNumKeys] = acc;
-    }
+    for (uint32_t k = threadIdx.x; k <= kNumKeys; k += kBlock) s_prefix[k] = a.st.strat_prefix[k];
     __syncthreads();
+    const bdpt_ext_t& x = *a.st.ext;
+    uint32_t* cctl = x.chunk_ctl + (size_t)chunk * kChunkCtlWords;
     const uint32_t total = s_prefix[kNumKeys];
+    const uint64_t begin = (uint64_t)chunk * x.pend_cap;
+    if (begin >= total) return;   // (the host launches the chunks a batch of this depth can need at most: most are empty)
+    const uint32_t span = (uint32_t)min<uint64_t>(x.pend_cap, total - begin);
     bdpt_counters_t ctr;
     ctr.connections = ctr.shadow_rays = 0;
     const stack_ref_t no_stack = make_stack_ref(nullptr, 0, 0, 0, nullptr);   // (bdpt_connect<true> traces nothing)
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, a.st.ctl + CTL_FSD_COUNTER, a.st.fsd_cap, a.st.ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
-        const uint32_t idx = wave_grab(a.st.ctl + (OPEN ? CTL_STRAT_HEAD_OPEN : CTL_STRAT_HEAD)) + (threadIdx.x & 63);
-        if (idx - (threadIdx.x & 63) >= total) break;
-        if (idx < total) {
+        const uint32_t off = wave_grab(cctl + CHUNK_EVAL_HEAD) + (threadIdx.x & 63);
+        if (off - (threadIdx.x & 63) >= span) break;
+        if (off < span) {
+            const uint32_t idx = (uint32_t)begin + off;
+            // bucket of this item: last key with prefix <= idx
             uint32_t lo = 0, hi = kNumKeys;
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -229,29 +232,16 @@ __device__ inline __attribute__((always_inline)) void connect_eval_body(const la
                     hi = mid;
             }
             const uint32_t key = lo;
-            const int tk = (int)(key / kKeyDim), sk = (int)(key % kKeyDim);
-            if (!OPEN && (tk == K || sk == K)) continue;   // (k_connect_eval_open's)
+            const int t = (int)(key / kKeyDim), s = (int)(key % kKeyDim);
             const uint32_t i = a.st.strat_items[(size_t)key * a.st.cap + (idx - s_prefix[key])];
             const uint64_t j = a.j0 + i;
             const uint32_t pix = (uint32_t)(j % a.npix);
             const uint64_t smp = a.sample_begin + j / a.npix;
             const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
             const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
-            auto one = [&](int s, int t) __attribute__((always_inline)) {
-                connect_ret_t cr;
-                bdpt_connect<true>(a.sc, pool, svs, evs, s, t, a.seed, sample_id, no_stack, cr, &ctr, nullptr);
-                pending_append(a, cr.L.s[0] > 0.f, i, s, t, cr);
-            };
-            if constexpr (!OPEN) {
-                one(sk, tk);
-            } else {
-                const int nT = (int)a.st.walks[(size_t)i * a.st.walk_words + WT_WALK_NVERTS_WORD];
-                const int nS = (int)a.st.walks[((size_t)a.st.cap + i) * a.st.walk_words + WT_WALK_NVERTS_WORD];
-                const int t1 = tk == K ? nT : tk, s1 = sk == K ? nS : sk;
-                for (int t = tk; t <= t1; ++t)
-                    for (int s = sk; s <= s1; ++s)
-                        if (strategy_valid(a.sc.opts, s, t, nS, nT)) one(s, t);
-            }
+            connect_ret_t cr;
+            bdpt_connect<true>(a.sc, pool, svs, evs, s, t, a.seed, sample_id, no_stack, cr, &ctr, nullptr);
+            pending_append(a, cctl, cr.L.s[0] > 0.f, i, s, t, cr);
         }
     }
     if (a.count_stats) {
@@ -266,22 +256,18 @@ __device__ inline __attribute__((always_inline)) void connect_eval_body(const la
         }
     }
 }
-#ifndef WTGPU_LB_EVAL
-#define WTGPU_LB_EVAL 2
-#endif
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_EVAL) k_connect_eval(launch_args_t a) { connect_eval_body<false>(a); }
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_EVAL) k_connect_eval_open(launch_args_t a) { connect_eval_body<true>(a); }
 
-__global__ void __launch_bounds__(kBlock, 4) k_connect_shadow(launch_args_t a) {
+__global__ void __launch_bounds__(kBlock, 4) k_connect_shadow(launch_args_t a, uint32_t chunk) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     stack_entry_t spill[kSpillStack];
     stack_ref_t stack;
     lds_stack(lds, spill, stack);
     const bdpt_ext_t& x = *a.st.ext;
-    uint32_t* ctl = a.st.ctl;
-    const uint32_t n = min(ctl[CTL_PEND_COUNT], x.pend_cap);
+    uint32_t* cctl = x.chunk_ctl + (size_t)chunk * kChunkCtlWords;
+    const uint32_t n = min(cctl[CHUNK_PEND_COUNT], x.pend_cap);
+    if (n == 0) return;
     for (;;) {
-        const uint32_t idx = wave_grab(ctl + CTL_PEND_HEAD) + (threadIdx.x & 63);
+        const uint32_t idx = wave_grab(cctl + CHUNK_PEND_HEAD) + (threadIdx.x & 63);
         if (idx - (threadIdx.x & 63) >= n) break;
         bool alive = false;
         if (idx < n) {
@@ -289,22 +275,24 @@ __global__ void __launch_bounds__(kBlock, 4) k_connect_shadow(launch_args_t a) {
             alive = true;
             if (r.st & kPendShadow) alive = !ads_shadow_ray(a.sc, vec3{r.o[0], r.o[1], r.o[2]}, vec3{r.d[0], r.d[1], r.d[2]}, range_t{0.f, r.dist}, stack, nullptr);
         }
-        wave_append(x.surv, ctl + CTL_SURV_COUNT, alive, idx);
+        wave_append(x.surv, cctl + CHUNK_SURV_COUNT, alive, idx);
     }
 }
 
 #ifndef WTGPU_LB_MIS
 #define WTGPU_LB_MIS 2
 #endif
-__global__ void __launch_bounds__(kBlock, WTGPU_LB_MIS) k_connect_mis(launch_args_t a) {
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_MIS) k_connect_mis(launch_args_t a, uint32_t chunk) {
     const bdpt_ext_t& x = *a.st.ext;
     uint32_t* ctl = a.st.ctl;
-    const uint32_t n = ctl[CTL_SURV_COUNT];
+    uint32_t* cctl = x.chunk_ctl + (size_t)chunk * kChunkCtlWords;
+    const uint32_t n = cctl[CHUNK_SURV_COUNT];
+    if (n == 0) return;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     bdpt_counters_t ctr;
     ctr.light_splats = 0;
     for (;;) {
-        const uint32_t k = wave_grab(ctl + CTL_MIS_HEAD) + (threadIdx.x & 63);
+        const uint32_t k = wave_grab(cctl + CHUNK_MIS_HEAD) + (threadIdx.x & 63);
         if (k - (threadIdx.x & 63) >= n) break;
         if (k >= n) continue;
         const conn_pending_t& r = x.pend[x.surv[k]];

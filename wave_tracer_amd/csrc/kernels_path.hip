@@ -99,6 +99,12 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_
                           __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
         const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
         const vec3 interaction_wp = origin + dist * pw.w.beam.env.d;
+#ifdef WTGPU_FSD_DEBUG
+        if (pw.ap.n_edges > pw.ap.edge_cap || pw.ap.n_edges > 100000u || !pw.has_fsd) {
+            if (threadIdx.x == 0) printf("[k_path_fsd] round %u item %u/%u walk %u: n_edges %u cap %u offset %u has_fsd %u active %u nverts %u\n", round, item, n, w, pw.ap.n_edges, pw.ap.edge_cap, pw.ap.edge_offset, pw.has_fsd, pw.w.active, pw.w.nverts);
+            continue;
+        }
+#endif
         const float f = coop_do_fsd(a.sc, pw.prev_beam.env, path_geo_prev(pw.w), interaction_wp, pw.ap, prev_pool + pw.ap.edge_offset, pw.w.beam.k, stack, &ctr);
         if (threadIdx.x == 0) P.fsd_f[w] = f;
     }
@@ -245,8 +251,11 @@ __device__ inline __attribute__((always_inline)) void path_interact_body(const l
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact(launch_args_t a, const path_state_t* __restrict__ ps, int in, int first_round, uint32_t round) { path_interact_body<0>(a, *ps, in, first_round, round); }
-__global__ void __launch_bounds__(kBlock, 2) k_path_interact_b(launch_args_t a, const path_state_t* __restrict__ ps, int in, uint32_t round) { path_interact_body<1>(a, *ps, in, 0, round); }
+#ifndef WTGPU_LB_PATH
+#define WTGPU_LB_PATH 2
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_PATH) k_path_interact(launch_args_t a, const path_state_t* __restrict__ ps, int in, int first_round, uint32_t round) { path_interact_body<0>(a, *ps, in, first_round, round); }
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_PATH) k_path_interact_b(launch_args_t a, const path_state_t* __restrict__ ps, int in, uint32_t round) { path_interact_body<1>(a, *ps, in, 0, round); }
 
 // plt_path, after the interaction step: next-event estimation towards the virtual sensor through the aperture the step just built (nee_forward,
 // plt_path_detail.hpp:474-518) — one wavefront per walk: coherent UTD sum (coop_do_fsd), beam transform, integrate_beams, light-image splat.

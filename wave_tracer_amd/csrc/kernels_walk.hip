@@ -214,6 +214,27 @@ __device__ inline __attribute__((always_inline)) void interact_cls_body(const la
 #ifndef WTGPU_LB_CLS_SPM
 #define WTGPU_LB_CLS_SPM 3
 #endif
+// ... and all four in ONE launch (the default): a block starts with the class its index names — in proportion to what the classes typically hold — and,
+// once that queue is empty, goes on to the next (every block visits every class, so every queue is drained whatever the mix).  Four launches in a
+// row each pay the ramp-up and the tail of a persistent grid on 256 CUs — per round, 40 rounds a batch — and cannot overlap one another on their
+// stream: measured (run r5a) the four-kernel form lost what the sorting gained.  Here a wavefront still runs ONE class at a time (its own code, no
+// divergence across BSDFs); the kernel carries the registers of the widest class.
+#ifndef WTGPU_LB_SORTED
+#define WTGPU_LB_SORTED 2
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_SORTED) k_interact_sorted(launch_args_t a, int in) {
+    static constexpr unsigned char start_of[8] = {0, 0, 2, 0, 1, 0, 2, 3};
+    const uint32_t first = start_of[blockIdx.x & 7u];
+#pragma unroll 1
+    for (uint32_t k = 0; k < kNumWalkClasses; ++k) {
+        switch ((first + k) & 3u) {
+        case WCLS_DIFFUSE: interact_cls_body<MAT_DIFFUSE>(a, in); break;
+        case WCLS_DIELECTRIC: interact_cls_body<MAT_DIELECTRIC>(a, in); break;
+        case WCLS_SPM: interact_cls_body<MAT_SURFACE_SPM>(a, in); break;
+        default: interact_cls_body<-1>(a, in); break;
+        }
+    }
+}
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS) k_interact_diffuse(launch_args_t a, int in) { interact_cls_body<MAT_DIFFUSE>(a, in); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS) k_interact_dielectric(launch_args_t a, int in) { interact_cls_body<MAT_DIELECTRIC>(a, in); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS_SPM) k_interact_spm(launch_args_t a, int in) { interact_cls_body<MAT_SURFACE_SPM>(a, in); }

@@ -549,9 +549,45 @@ WT_HD bvh8_leaf_t cq_take_leaf(cone_query_t& q, bvh_counters_t* ctr = nullptr) {
     return leaf;
 }
 // tests the triangles of the held leaf one after the other, fetched kLeafBatch at a time (see ray_gather_tris; requires q.leaf != 0)
+// Device: the triangles' BOUNDING SPHERES first (16 B each, stored behind the scene's triangles at upload: wt/coop.h) — all of a leaf's at once, one
+// memory round trip — and the 48-byte triangle only of those whose sphere meets the cone inside the current slab (cone_sphere_maybe: conservative,
+// tests/test_gpu_traversal.py::test_bounding_sphere_filter_is_conservative; a slab that shrinks while the leaf is tested only rejects more).  The
+// plain loop fetches triangle after triangle, each fetch behind the previous test: up to four dependent round trips per leaf visit in a kernel that
+// waits for memory 60 % of its time, for triangles of which three in four fail the slab test at once.  Same hits, same order, same budget charge.
+#ifndef WT_LEAF_SPHERES
+#define WT_LEAF_SPHERES 0   // (A/B: tools/build_variant.sh lsph -DWT_LEAF_SPHERES=1)
+#endif
+#ifndef WT_LEAF_SPHERE_GROUP
+#define WT_LEAF_SPHERE_GROUP 4   // spheres fetched together
+#endif
 WT_HD void cq_leaf_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, const uint_list_t& tris, cone_query_t& q,
                         bvh_counters_t* ctr = nullptr) {
     const bvh8_leaf_t leaf = cq_take_leaf(q, ctr);
+#if defined(__HIP_DEVICE_COMPILE__) && WT_LEAF_SPHERES
+    {
+        const float4* sph = reinterpret_cast<const float4*>(sc.tri_geo + sc.n_tris) + leaf.tris_ptr;
+        constexpr uint32_t G = WT_LEAF_SPHERE_GROUP;
+        for (uint32_t b = 0; b < leaf.count; b += G) {
+            const uint32_t m = leaf.count - b < G ? leaf.count - b : G;
+            float4 bs[G];
+#pragma unroll
+            for (uint32_t i = 0; i < G; ++i)
+                if (i < m) bs[i] = sph[b + i];
+            uint32_t pass = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < G; ++i)
+                if (i < m && cone_sphere_maybe(cone, vec3{bs[i].x, bs[i].y, bs[i].z}, bs[i].w, q.range)) pass |= 1u << i;
+            while (pass) {
+                const uint32_t i = (uint32_t)__builtin_ctz(pass);
+                pass &= pass - 1u;
+                const uint32_t tuid = leaf.tris_ptr + b + i;
+                cq_exact_step_tri(cone, stack, tris, q, tuid, sc.tri_geo[tuid], ctr);
+                if (q.rec.too_short) return;
+            }
+        }
+        return;
+    }
+#endif
     for (uint32_t b = 0; b < leaf.count; b += kLeafBatch) {
         tri_geo_t T[kLeafBatch];
         const uint32_t m = leaf.count - b < kLeafBatch ? leaf.count - b : kLeafBatch;

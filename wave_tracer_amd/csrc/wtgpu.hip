@@ -77,9 +77,7 @@ struct wtgpu_scene {
     std::vector<device_state_t> slices;              // per-batch path state, one slice per internal stream
     std::vector<const path_state_t*> d_path_slices;  // ... and its plt_path part (device copies)
     const unsigned char* d_tri_class = nullptr;       // walk class of every triangle (bdpt_ext_t::tri_class)
-    uint32_t pend_cap = 0;                            // pending-connection records per slice (bdpt_ext_t::pend_cap)
-    uint64_t conn_pool_overflow = 0;                  // connections a full pool dropped (the render call that drains such a batch fails)
-    uint64_t pend_high_water = 0;                     // most pending connections a batch produced (stats)
+    uint32_t pend_cap = 0, n_chunks = 0;              // staged connections: items per chunk, chunks per batch (bdpt_ext_t)
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> ev_done;
     hipEvent_t ev_begin = nullptr;
@@ -119,7 +117,7 @@ struct wtgpu_scene {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 1, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
-        uint32_t sorted_interact = 1, staged_connect = 1, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
+        uint32_t sorted_interact = 0, staged_connect = 0, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -466,8 +464,12 @@ static void read_knobs(wtgpu_scene* s) {
     k.grid_div_hard = std::max(1u, u("WTGPU_GRID_HARD", 4));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
-    k.sorted_interact = u("WTGPU_SORTED_INTERACT", 1);
-    k.staged_connect = u("WTGPU_STAGED_CONNECT", 1);
+    // Pass A and the connections each exist in two forms (DESIGN.md §4 has the measurements: the one-kernel forms are 1-6 % faster on the headline
+    // workload and are the default; the sorted / staged forms move a third of the bytes):
+    //   WTGPU_SORTED_INTERACT  0: k_interact (one kernel, every walk); 1: k_classify + one kernel per material class; 2: k_classify + k_interact_sorted
+    //   WTGPU_STAGED_CONNECT   0: k_connect_strat (one kernel per strategy item); 1: k_connect_eval -> k_connect_shadow -> k_connect_mis, in chunks
+    k.sorted_interact = u("WTGPU_SORTED_INTERACT", 0);
+    k.staged_connect = u("WTGPU_STAGED_CONNECT", 0);
     k.conn_pool = std::max(1u, u("WTGPU_CONN_POOL", 16));
     if (const char* e = getenv("WTGPU_GRID_CLS")) {
         unsigned v[4] = {1, 4, 2, 4};
@@ -566,7 +568,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
         // plt_path: two wedge pools of 48 records per walk, the deferred-NEE records, the queues of the wave-per-walk kernels
         if (pm) per_sample += 2ull * 48ull * sizeof(utd_edge_rec_t) + sizeof(path_nee_rec_t) + 3ull * 4ull + 4ull + sizeof(uint2);
-        else per_sample += (uint64_t)s->knobs.conn_pool * (sizeof(conn_pending_t) + 4ull) + 4ull * 2ull * kNumWalkClasses;   // pending connections, class queues
+        else per_sample += (s->knobs.staged_connect ? (uint64_t)s->knobs.conn_pool * (sizeof(conn_pending_t) + 4ull) : 0ull) + (s->knobs.sorted_interact ? 4ull * 2ull * kNumWalkClasses : 0ull);   // pending connections, class queues
         uint64_t budget = 224ull << 30;   // of the MI355X's 288 GB (three slices of a two-pass 1440^2 batch are 186 GB); WTGPU_STATE_GB overrides
         if (const char* e = getenv("WTGPU_STATE_GB")) budget = (uint64_t)std::max(1, atoi(e)) << 30;
         // ... and within what the device has free right now (another scene, torch's caching allocator, a smaller GPU): 85 % of it, the rest is
@@ -613,14 +615,25 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         if (!path_mode) {
             bdpt_ext_t X;
             X.tri_class = s->d_tri_class;
-            if ((rc = dmalloc(s, &X.cls_queue, (size_t)kNumWalkClasses * W2))) return rc;
-            // staged connections: room for `conn_pool` (16; WTGPU_CONN_POOL) pending connections per sample of the batch — the high-water mark of a
-            // render is printed with WTGPU_VERBOSE=1 (release_device), DESIGN.md §4 has the measured ones; a batch that needs more is reported as
-            // failed (drain_rec), never silently short
+            if (s->knobs.sorted_interact && (rc = dmalloc(s, &X.cls_queue, (size_t)kNumWalkClasses * W2))) return rc;
+            // staged connections: the strategy items of a batch are connected in chunks of pend_cap = `conn_pool` (16; WTGPU_CONN_POOL) x batch size
+            // items — a chunk's pending connections cannot outnumber its items; as many chunks as a batch of this scene's depth can hold items for
+            // (every (s,t) with s + t - 2 <= max_depth for every sample: 186 per sample at max_depth 16 => 12 chunks, all but the first one or two empty)
             X.pend_cap = (uint32_t)std::min<uint64_t>((uint64_t)s->knobs.conn_pool * st.cap + 4096, 0xFFFFFF00ull);
-            if ((rc = dmalloc(s, &X.pend, (size_t)X.pend_cap))) return rc;
-            if ((rc = dmalloc(s, &X.surv, (size_t)X.pend_cap))) return rc;
+            if (s->knobs.staged_connect) {
+                uint64_t pairs = 0;
+                const int md = h.opts.max_depth;
+                for (int t = 0; t <= md + 2; ++t)
+                    for (int q = 0; q <= md + 2; ++q)
+                        if (t + q - 2 >= 0 && t + q - 2 <= md && !(t == 1 && q == 1)) ++pairs;
+                X.n_chunks = (uint32_t)((pairs * st.cap + X.pend_cap - 1) / X.pend_cap);
+                if ((rc = dmalloc(s, &X.pend, (size_t)X.pend_cap))) return rc;
+                if ((rc = dmalloc(s, &X.surv, (size_t)X.pend_cap))) return rc;
+                if ((rc = dmalloc(s, &X.chunk_ctl, (size_t)X.n_chunks * kChunkCtlWords))) return rc;
+            } else
+                X.pend_cap = 0;
             s->pend_cap = X.pend_cap;
+            s->n_chunks = X.n_chunks;
             bdpt_ext_t* dX = nullptr;
             if ((rc = dmalloc(s, &dX, 1))) return rc;
             HIP_CHECK(hipMemcpy(dX, &X, sizeof(X), hipMemcpyHostToDevice));
@@ -680,15 +693,6 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     if (!r.busy) return WTGPU_OK;
     HIP_CHECK(hipEventSynchronize(r.ev[r.ev_final]));
     const uint32_t rounds = r.h_ctl[CTL_ROUNDS];
-    if (s->pend_cap) {   // staged connections: a batch that overran the pending pool lost connections
-        s->pend_high_water = std::max<uint64_t>(s->pend_high_water, r.h_ctl[CTL_PEND_COUNT]);
-        if (r.h_ctl[CTL_PEND_COUNT] > s->pend_cap) {
-            s->conn_pool_overflow += r.h_ctl[CTL_PEND_COUNT] - s->pend_cap;
-            r.busy = false;
-            return fail(WTGPU_ERR_OVERFLOW, "the pending-connection pool of a batch overflowed (" + std::to_string(r.h_ctl[CTL_PEND_COUNT]) + " connections, room for " +
-                                           std::to_string(s->pend_cap) + "): the films of this render are incomplete; set WTGPU_CONN_POOL (records per sample, default 16) higher");
-        }
-    }
     s->cap_hits += r.h_ctl[CTL_COUNT0 + (r.rounds_launched & 1u)] + r.h_ctl[CTL_BACK0 + (r.rounds_launched & 1u)];   // walks still active after the last round
     s->acc[4] += rounds;
     s->acc[5] += rounds;
@@ -727,7 +731,7 @@ struct batch_launcher_t {
     uint32_t grid_round = 0, grid_heavy = 0;
     bool path_mode = false;
     bool ev_fail = false;
-    bool hp_on = false;
+    bool hp_on = false, trace_on = false;
     double hp_t[32] = {0};
     unsigned long hp_n[32] = {0};
     explicit batch_launcher_t(wtgpu_scene* s_) : s(s_), K(s_->knobs) {
@@ -738,10 +742,17 @@ struct batch_launcher_t {
         path_mode = s->host.opts.integrator != INTEGRATOR_BDPT;
         static const bool hp = getenv("WTGPU_HOST_PROF") != nullptr;   // WTGPU_HOST_PROF=1: host time spent inside each kind of launch call (diagnostic)
         hp_on = hp;
+        static const bool tr = getenv("WTGPU_TRACE_LAUNCH") != nullptr;
+        trace_on = tr;
     }
 #define HP_LAUNCH(slot, ...)                                                                                              \
     do {                                                                                                                  \
-        if (hp_on) {                                                                                                      \
+        if (trace_on) {   /* WTGPU_TRACE_LAUNCH=1 (bring-up aid): every launch is named and waited for — the last line names a kernel that hangs */ \
+            fprintf(stderr, "[wtgpu launch] slot %d ...", slot);                                                            \
+            hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
+            const hipError_t e_ = hipDeviceSynchronize();                                                                 \
+            fprintf(stderr, " done (%s)\n", hipGetErrorString(e_));                                                       \
+        } else if (hp_on) {                                                                                                      \
             const auto t0_ = std::chrono::steady_clock::now();                                                            \
             hipLaunchKernelGGL(__VA_ARGS__);                                                                              \
             hp_t[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0_).count();      \
@@ -809,10 +820,14 @@ struct batch_launcher_t {
             }
             if (K.sorted_interact) {
                 HP_LAUNCH(11, k_classify, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+                if (K.sorted_interact >= 2)
+                    HP_LAUNCH(24, k_interact_sorted, dim3(g0), dim3(kBlock), 0, st_, a, in);
+                else {
                 HP_LAUNCH(24, k_interact_diffuse, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[0])), dim3(kBlock), 0, st_, a, in);
                 HP_LAUNCH(25, k_interact_dielectric, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[1])), dim3(kBlock), 0, st_, a, in);
                 HP_LAUNCH(26, k_interact_spm, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[2])), dim3(kBlock), 0, st_, a, in);
                 HP_LAUNCH(27, k_interact_any, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[3])), dim3(kBlock), 0, st_, a, in);
+                }
             } else
                 HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec(r, st_);
@@ -838,11 +853,15 @@ struct batch_launcher_t {
             HP_LAUNCH(19, k_connect_enum, dim3((nb + kEnumBlock - 1) / kEnumBlock), dim3(kEnumBlock), 0, st_, a);
             HP_LAUNCH(20, k_connect_scan, dim3(1), dim3(64), 0, st_, a);
             const bool open = (uint32_t)s->host.opts.max_depth + 2 >= kKeyDim - 1;
-            if (K.staged_connect) {
-                HP_LAUNCH(28, k_connect_eval, dim3(gf), dim3(kBlock), 0, st_, a);
-                if (open) HP_LAUNCH(28, k_connect_eval_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
-                HP_LAUNCH(29, k_connect_shadow, dim3(gf), dim3(kBlock), 0, st_, a);
-                HP_LAUNCH(30, k_connect_mis, dim3(gf), dim3(kBlock), 0, st_, a);
+            // staged connections (chunked, see upload_impl); subpaths beyond 17 vertices (open-ended strategy buckets: an item there holds several
+            // strategies) keep the one-kernel form
+            if (K.staged_connect && !open) {
+                for (uint32_t c = 0; c < s->n_chunks; ++c) {
+                    const uint32_t g = c == 0 ? gf : std::max<uint32_t>(1u, gf / 8u);   // (later chunks are normally empty: small grids, they only loop longer when not)
+                    HP_LAUNCH(28, k_connect_eval, dim3(g), dim3(kBlock), 0, st_, a, c);
+                    HP_LAUNCH(29, k_connect_shadow, dim3(g), dim3(kBlock), 0, st_, a, c);
+                    HP_LAUNCH(30, k_connect_mis, dim3(g), dim3(kBlock), 0, st_, a, c);
+                }
             } else {
                 HP_LAUNCH(21, k_connect_strat, dim3(gf), dim3(kBlock), 0, st_, a);
                 if (open) HP_LAUNCH(22, k_connect_strat_open, dim3(std::max<uint32_t>(1u, gf / 8u)), dim3(kBlock), 0, st_, a);
@@ -1235,12 +1254,9 @@ static void release_device(wtgpu_scene* s) {
         if (st_) (void)hipStreamDestroy(st_);
     s->streams.clear();
     s->slices.clear();
-    if (getenv("WTGPU_VERBOSE") && s->pend_cap && !s->slices.empty())
-        fprintf(stderr, "[wtgpu] pending connections of a batch, high water: %llu (%.2f per sample of a full batch; pool %u)\n", (unsigned long long)s->pend_high_water,
-                (double)s->pend_high_water / (double)s->slices[0].cap, s->pend_cap);
     s->d_path_slices.clear();
     s->d_tri_class = nullptr;
-    s->pend_cap = 0;
+    s->pend_cap = s->n_chunks = 0;
     s->uploaded = false;
 }
 
@@ -1254,6 +1270,7 @@ void wtgpu_scene_destroy(wtgpu_scene* s) {
 int wtgpu_cancel(wtgpu_scene* s) {
     if (!s) return fail(WTGPU_ERR_INVALID, "null scene");
     s->cancel.store(1, std::memory_order_relaxed);
+    s->paused.store(0, std::memory_order_relaxed);   // cancel is a full reset: a pause that was in force does not hold up the NEXT render (pause itself is sticky)
     return WTGPU_OK;
 }
 int wtgpu_pause(wtgpu_scene* s) {

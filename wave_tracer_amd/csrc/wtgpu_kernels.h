@@ -61,7 +61,6 @@ constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane 
 enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
                   CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23,
                   CTL_CLS_COUNT0 = 33, CTL_CLS_HEAD0 = 37,   // the material-sorted pass A: sizes and dequeue heads of the kNumWalkClasses class queues (k_classify / k_interact_cls)
-                  CTL_PEND_COUNT = 41, CTL_PEND_HEAD = 42, CTL_MIS_HEAD = 43, CTL_SURV_COUNT = 44,   // the staged connections (k_connect_eval / k_connect_shadow / k_connect_mis)
                   CTL_WORDS = 48 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
@@ -115,10 +114,15 @@ struct bdpt_ext_t {
     const unsigned char* tri_class = nullptr;
     uint32_t* cls_queue = nullptr;   // [kNumWalkClasses][2 cap]
     // staged connections: the connections that wait for their shadow ray (k_connect_eval -> k_connect_shadow -> k_connect_mis)
+    // The strategy items of a batch are connected in CHUNKS of pend_cap items (in bucket order), each chunk through the three kernels in turn: a
+    // chunk's connections cannot outnumber its items, so the pending list cannot overflow whatever the scene's depth.  chunk_ctl: kChunkCtlWords
+    // counters per chunk (zeroed by k_connect_scan).
     struct conn_pending_t* pend = nullptr;
     uint32_t* surv = nullptr;        // [pend_cap] the pending connections whose ray arrived (indices into pend)
-    uint32_t pend_cap = 0;
+    uint32_t* chunk_ctl = nullptr;   // [n_chunks][kChunkCtlWords]
+    uint32_t pend_cap = 0, n_chunks = 0;
 };
+enum : uint32_t { CHUNK_EVAL_HEAD = 0, CHUNK_PEND_COUNT = 1, CHUNK_PEND_HEAD = 2, CHUNK_SURV_COUNT = 3, CHUNK_MIS_HEAD = 4, kChunkCtlWords = 8 };
 struct conn_pending_t {   // 52 B
     uint32_t i;    // sample of the batch
     uint32_t st;   // s | t << 16 | kPendShadow
@@ -251,6 +255,7 @@ __global__ void k_interact_diffuse(launch_args_t a, int in);
 __global__ void k_interact_dielectric(launch_args_t a, int in);
 __global__ void k_interact_spm(launch_args_t a, int in);
 __global__ void k_interact_any(launch_args_t a, int in);
+__global__ void k_interact_sorted(launch_args_t a, int in);
 __global__ void k_edges(launch_args_t a);
 __global__ void k_interact_b(launch_args_t a, int in);
 __global__ void k_flux_split(launch_args_t a);
@@ -268,10 +273,9 @@ __global__ void k_connect_enum(launch_args_t a);
 __global__ void k_connect_scan(launch_args_t a);
 __global__ void k_connect_strat(launch_args_t a);
 __global__ void k_connect_strat_open(launch_args_t a);
-__global__ void k_connect_eval(launch_args_t a);
-__global__ void k_connect_eval_open(launch_args_t a);
-__global__ void k_connect_shadow(launch_args_t a);
-__global__ void k_connect_mis(launch_args_t a);
+__global__ void k_connect_eval(launch_args_t a, uint32_t chunk);
+__global__ void k_connect_shadow(launch_args_t a, uint32_t chunk);
+__global__ void k_connect_mis(launch_args_t a, uint32_t chunk);
 __global__ void k_connect_splat(launch_args_t a);
 __global__ void k_connect_splat_tiled(launch_args_t a);
 __global__ void k_calib_copy(const uint32_t* in, uint32_t* out, size_t n);
