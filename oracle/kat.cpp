@@ -57,6 +57,16 @@ int kat_cone_tri(const float* c, const float* tri, float rmin, float rmax, float
     out[0] = hit ? h.dist : -1.f;
     return hit;
 }
+// ... with the cone given by all its parameters (replays the queries of a render: oracle/indep/prims2.cpp's WT_SS_DUMP): rec = o3 d3 x3 x0 tan_alpha e a3 b3 c3 zmin zmax
+int kat_cone_tri_raw(const float* r, float* out) {
+    const cone_t cone = make_cone_raw(vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, vec3{r[6], r[7], r[8]}, r[9], r[10], 1.f / r[11], r[11]);
+    const vec3 a{r[12], r[13], r[14]}, b{r[15], r[16], r[17]}, cc{r[18], r[19], r[20]};
+    const vec3 n = normalize(cross(b - a, cc - a));
+    cone_tri_hit_t h;
+    const bool hit = intersect_cone_tri(cone, a, b, cc, n, range_t{r[21], r[22]}, h);
+    out[0] = hit ? h.dist : -1.f;
+    return hit;
+}
 // cone_box_outside (wt/bvh.h: the conservative cone x AABB cull of the traversals): 1 = culled.  box: min3, max3 (world)
 int kat_cone_box_outside(const float* c, const float* box, float rmin, float rmax) {
     const vec3 d = normalize(vec3{c[3], c[4], c[5]});

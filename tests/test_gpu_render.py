@@ -731,7 +731,38 @@ def test_two_gpus_strong_scaling_through_rccl(built):
     two = run(["--gpus", "2", "--backend", "nccl", "--scaling", "strong"])
     one = run(["--gpus", "1"])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["film_reduce"]["ranks"] == 2 and "RCCL" in two["film_reduce"]["through"]
+    assert two["film_reduce"]["rccl_version"] and len(two["per_rank"]) == 2
     assert two["config"]["samples_per_step"] == one["config"]["samples_per_step"] == 2 * 256 * 256
+    for k in ("value", "weight", "light"):
+        a, b = two["film_sums"][k], one["film_sums"][k]
+        assert abs(a - b) <= 1e-9 * abs(b) + 1e-30, (k, a, b)
+
+
+@pytest.mark.gpu
+def test_two_ranks_strong_scaling_through_gloo_on_one_gpu(built):
+    """The same driver line (`bench.py --gpus 2 --scaling strong`) where only ONE GPU is visible: two ranks share it, the films travel through
+    gloo instead of RCCL (--backend gloo).  Everything but the collective is the multi-GPU path — sample-index sharding, per-rank films, the
+    reduce onto rank 0, the max-over-ranks clock — and the line carries what makes a first real 8-GPU run self-diagnosing: per-rank rates, the
+    reduce's byte count, the backend."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--steps", "3", "--warmup", "0", "--scene", "cornell_box", "--res", "128", "--mesh-detail", "0", "--spp-per-step", "2", "--no-cpu-baseline", "--no-traffic", "--film-sums"]
+
+    def run(extra):
+        out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py")] + extra + common, env=env, stderr=subprocess.DEVNULL, timeout=300).decode()
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out
+        return json.loads(lines[0])
+    two = run(["--gpus", "2", "--backend", "gloo", "--scaling", "strong"])
+    one = run(["--gpus", "1"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["film_reduce"]["ranks"] == 2 and two["film_reduce"]["backend"] == "gloo"
+    assert two["film_reduce"]["bytes_per_rank"] == 128 * 128 * 8 * (3 + 1 + 3)
+    assert len(two["per_rank"]) == 2 and all(r["msamples_per_s"] > 0 for r in two["per_rank"])
+    assert two["config"]["samples_per_step"] == one["config"]["samples_per_step"] == 2 * 128 * 128
     for k in ("value", "weight", "light"):
         a, b = two["film_sums"][k], one["film_sums"][k]
         assert abs(a - b) <= 1e-9 * abs(b) + 1e-30, (k, a, b)

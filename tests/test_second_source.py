@@ -211,3 +211,60 @@ def test_fraunhofer_pattern_of_a_uniform_polygon_is_its_fourier_transform(lib):
             worst = max(worst, err)
             assert err < 5e-4, (x, g, ref)
     print(f"uniform polygons: worst relative error of the edge sum against the area Fourier integral {worst:.1e}")
+
+
+# ---- whole renders on second-source primitives (oracle/indep/prims2.cpp, libindep2.so) -----------------------------------------------------
+_lib2 = None
+
+
+def _indep2():
+    global _lib2
+    if _lib2 is None:
+        import ctypes as C
+        import subprocess
+        from oracle_util import ROOT
+        p = os.path.join(ROOT, "oracle", "_build", "libindep2.so")
+        if not os.path.exists(p):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+        _lib2 = C.CDLL(p)
+        _lib2.indep_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib2.indep_render_path.argtypes = _lib2.indep_render.argtypes
+    return _lib2
+
+
+@pytest.mark.parametrize("name,res,spp,kw", [
+    ("furnace", 16, 8, {}),                                    # diffuse walls: cone queries, the surface step
+    ("furnace", 16, 8, {"fsd": 1, "lut": (64, 64)}),           # ... with Fraunhofer interactions: interaction regions from second-source cone queries
+    ("furnace_spm", 16, 8, {}),                                # rough conductors: Fresnel (complex index) -> Mueller
+    ("lens_b", 16, 8, {}),                                     # dielectric interfaces: Fresnel coefficients of both directions, total internal reflection
+    ("double_slits", 48, 8, {"lut": (64, 64)}),                # the diffraction gate's scene
+    ("bidir_room", 20, 4, {"mesh_detail": 0, "lut": (64, 64), "polarimetric": 1}),   # Stokes film: every Mueller entry counts
+    ("etoile", 32, 8, {"mesh_detail": 0}),                     # plt_path: UTD wedges from second-source cone queries, ITU materials
+])
+def test_render_on_second_source_primitives(name, res, spp, kw):
+    """A whole render in which NEITHER the composition NOR the riskiest primitives are the ones the GPU is checked against: oracle/indep/indep.cpp
+    (the integrators restated a second time, f64) on oracle/indep/prims2.cpp (cone x triangle as a convex programme in f64, every box cull
+    replaced by none, Fresnel coefficients from the angle / permittivity forms, Mueller matrices by the Kronecker construction), against
+    liboracle.so.  The random numbers are the same, the arithmetic is not (f64 closest points, different formulas): a sample may take another
+    discrete branch now and then; the images must agree like a GPU render agrees with the checker."""
+    import ctypes as C
+    from oracle_util import oracle_render
+    from wave_tracer_amd import Scene
+    sc = Scene(name, res=res, **kw)
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 77, threads=1)
+    H, W, Cn = sc.height, sc.width, sc.channels
+    v, w, l = np.zeros((H, W, Cn)), np.zeros((H, W)), np.zeros((H, W, Cn))
+    ctr = np.zeros(8, np.uint64)
+    entry = _indep2().indep_render if int(sc.info.integrator) == 0 else _indep2().indep_render_path
+    assert entry(sc.host_desc(), 0, spp, 77, v.ctypes.data, w.ctypes.data, l.ctypes.data, ctr.ctypes.data) == 0
+    ic = dict(zip(["segments", "vertices", "connections", "surface", "fsd_interactions", "null_interactions", "light_splats", "shadow_rays"], [int(x) for x in ctr]))
+    for k in ("segments", "connections") if int(sc.info.integrator) else ("segments", "vertices", "connections"):
+        assert abs(ic[k] - oc[k]) <= 1e-2 * max(100, oc[k]) + 2, (k, ic[k], oc[k])
+    assert np.allclose(w, ow, rtol=1e-5, atol=1e-9)
+    a = v.sum(axis=2) + l.sum(axis=2)
+    b = ov.sum(axis=2) + ol.sum(axis=2)
+    assert b.sum() > 0
+    rel = np.abs(a - b).sum() / b.sum()
+    same = (np.abs(a - b) <= 1e-3 * np.abs(b) + 1e-9 * b.max()).mean()
+    print(f"{name}: image rel. L1 {rel:.2e}, {same:.3f} of the pixels agree to 1e-3; counters {ic['segments']}/{oc['segments']} segments, {ic['connections']}/{oc['connections']} connections")
+    assert rel < 2e-2 and same > 0.9, (rel, same)

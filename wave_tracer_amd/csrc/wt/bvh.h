@@ -328,6 +328,9 @@ WT_HD bool ads_shadow_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& ra
 // the axis must not exceed the cone's radius at the largest admissible z (containment x^2+(e y)^2 <= r(z)^2 with e >= 1
 // implies Euclidean lateral distance <= r(z) <= r(z_hi)).  b0/b1: box corners relative to the cone origin.
 WT_HD bool cone_box_outside(float b0x, float b0y, float b0z, float b1x, float b1y, float b1z, vec3 rd, float ta, float ix, const range_t& range) {
+#if WT_SS_ACTIVE
+    return false;   // second source of the cone x box culls: none — every child is visited, the query's result cannot depend on a box test
+#endif
     const float cx = 0.5f * (b0x + b1x), cy = 0.5f * (b0y + b1y), cz = 0.5f * (b0z + b1z);
     const float hx = 0.5f * (b1x - b0x), hy = 0.5f * (b1y - b0y), hz = 0.5f * (b1z - b0z);
     const float zc = cx * rd.x + cy * rd.y + cz * rd.z;
@@ -466,8 +469,13 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
         tmin = fmaxf_(tmin, dminy);
         tmax = fminf_(tmax, dmaxz);
         tmin = fmaxf_(tmin, dminz);
+#if WT_SS_ACTIVE
+        const bool hit = cp != 0;
+        tmin = 0.f;
+#else
         const bool hit = cp != 0 && tmin <= tmax && tmax >= range.min && tmin <= range.max && !(tmin >= range.max) &&
                          !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range);
+#endif
         const bool acc = hit && room > 0;
         full = full || (hit && !acc);   // the stack cannot hold this child
         room -= acc ? 1 : 0;
@@ -711,7 +719,12 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             tmin = fmaxf_(tmin, dminy);
             tmax = fminf_(tmax, dmaxz);
             tmin = fmaxf_(tmin, dminz);
+#if WT_SS_ACTIVE
+            const bool hit = cp != 0;
+            tmin = 0.f;
+#else
             const bool hit = cp != 0 && tmin <= tmax && tmax >= range.min && tmin <= range.max && !cone_box_outside(b0x, b0y, b0z, b1x, b1y, b1z, rd, ta, ix, range);
+#endif
             const bool acc = hit && room > 0;
             full = full || (hit && !acc);
             room -= acc ? 1 : 0;

@@ -521,6 +521,15 @@ WT_HD bool cone_tri_maybe(const cone_t& cone, vec3 a, vec3 b, vec3 c, const rang
     if (farthest_z < range.min || closest_z > range.max) return false;
     return !cone_tri_laterally_outside(cone, vs, fminf_(farthest_z, range.max));
 }
+// WT_SECOND_SOURCE (CPU only; oracle/indep/prims2.cpp, libindep2.so): independent derivations in double precision take the place of a handful of
+// primitives, so that whole renders can be compared between the two sources (tests/test_second_source.py).
+#if defined(WT_SECOND_SOURCE) && !defined(__HIP_DEVICE_COMPILE__)
+#define WT_SS_ACTIVE 1
+extern "C" int ss_intersect_cone_tri(const float o[3], const float d[3], const float x[3], float x0, float tan_alpha, float e, const float a[3], const float b[3],
+                                     const float c[3], float zmin, float zmax, float* dist);
+#else
+#define WT_SS_ACTIVE 0
+#endif
 #ifdef WT_PROFILE_CONE_TRI
 inline unsigned long long g_cone_tri_exits[8] = {0};
 #define WT_CT_EXIT(i) (g_cone_tri_exits[i]++)
@@ -540,6 +549,15 @@ WT_HD bool intersect_cone_tri(const cone_t& cone, vec3 a, vec3 b, vec3 c, vec3 n
         }
         return false;
     }
+#if WT_SS_ACTIVE
+    {
+        float dist = 0.f;
+        if (!ss_intersect_cone_tri(&cone.o.x, &cone.d.x, &cone.x.x, cone.x0, cone.tan_alpha, cone.e, &a.x, &b.x, &c.x, range.min, range.max, &dist)) return false;
+        out.dist = dist;
+        out.p = cone.o + dist * cone.d;
+        return true;
+    }
+#endif
     const frame_t frame = cone_frame(cone);
     const vec3 o = cone.o;
     const vec3 vs[3] = {to_local(frame, a - o), to_local(frame, b - o), to_local(frame, c - o)};

@@ -34,6 +34,15 @@ WT_HD refract_t refract(float eta_12, vec3 w, vec3 n) {
     return refract_t{vec3{0, 0, 1}, 0.f, eta_12, true};
 }
 
+#if defined(WT_SECOND_SOURCE) && !defined(__HIP_DEVICE_COMPILE__)
+// (oracle/indep/prims2.cpp: see the note at WT_SS_ACTIVE in wt/cone.h)
+extern "C" void ss_fresnel_dielectric(double eta, double ci, double out[5]);
+extern "C" void ss_fresnel_conductor(double eta_re, double eta_im, double ci, double out[4]);
+extern "C" void ss_mueller_from_jones(double fs_re, double fs_im, double fp_re, double fp_im, float M[16]);
+#define WT_SS_POLAR 1
+#else
+#define WT_SS_POLAR 0
+#endif
 struct fresnel_t {
     vec3 t;
     cplx eta_12;
@@ -52,6 +61,14 @@ WT_HD fresnel_t fresnel(cplx eta_12, vec3 w, vec3 n) {
         return fresnel_t{vec3{0, 0, 1}, cplx{refr.eta_12, 0.f}, 1.f, {1, 0}, {1, 0}, {0, 0}, {0, 0}, 0.f, 0.f};
     const float cost = refr.cost;
     const float eta = refr.eta_12;
+#if WT_SS_POLAR
+    {
+        double c[5];
+        ss_fresnel_dielectric(eta, abs_cosi, c);
+        const float rs2 = (float)c[0], rp2 = (float)c[1], ts2 = (float)c[2], tp2 = (float)c[3], Z2 = (float)c[4];
+        return fresnel_t{refr.t, cplx{eta, 0.f}, Z2, {rs2, 0}, {rp2, 0}, {ts2, 0}, {tp2, 0}, fminf_(1.f, Z2 * ts2 * ts2), fminf_(1.f, Z2 * tp2 * tp2)};
+    }
+#endif
     const float rs = (eta * abs_cosi - cost) / (eta * abs_cosi + cost);
     const float rp = (abs_cosi - eta * cost) / (abs_cosi + eta * cost);
     const float ts = rs + 1.f;
@@ -66,6 +83,13 @@ struct fresnel_conductor_t {
 WT_HD fresnel_conductor_t fresnel_reflection(cplx eta_12, vec3 w, vec3 n) {
     const float wn = dot(w, n);
     if ((eta_12.re == 1.f && eta_12.im == 0.f) || wn < 0.f) return {{0, 0}, {0, 0}};
+#if WT_SS_POLAR
+    {
+        double c[4];
+        ss_fresnel_conductor(eta_12.re, eta_12.im, wn, c);
+        return {{(float)c[0], (float)c[1]}, {(float)c[2], (float)c[3]}};
+    }
+#endif
     const cplx t2 = cplx{1.f, 0.f} - (1.f - sqr(wn)) * (eta_12 * eta_12);
     const cplx t = csqrt(t2);
     const cplx i{wn, 0.f};
@@ -171,6 +195,13 @@ WT_HD mueller_t mueller_rotation(vec2 t1, vec2 t2) {
 }
 // mueller.hpp:244-259
 WT_HD mueller_t mueller_fresnel(cplx fs, cplx fp) {
+#if WT_SS_POLAR
+    {
+        mueller_t M2;
+        ss_mueller_from_jones(fs.re, fs.im, fp.re, fp.im, M2.m);
+        return M2;
+    }
+#endif
     const float Rs = cnorm(fs), Rp = cnorm(fp);
     const float m00 = (Rs + Rp) / 2.f, m01 = (Rs - Rp) / 2.f;
     const cplx x = fp * conj(fs);
