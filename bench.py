@@ -38,6 +38,8 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
     n_tiles = ((sc.width + 23) // 24) * ((sc.height + 23) // 24)
     # work unit of the checker = one 24x24 block x one sample index: >= 8 blocks per core, spp work items per block
     stride = max(1, n_tiles // (8 * cores))
+    from oracle_util import load_oracle
+    load_oracle().oracle_set_fine_items(1)     # work items of one block x one sample index: no thread waits for a block of 576 x spp samples at the end
     t = time.time()
     _, _, _, _, n1, _ = oracle_render_tiles(sc, 0, 1, 123, stride, 0, threads=cores)      # calibration pass
     dt1 = max(1e-3, time.time() - t)
@@ -46,8 +48,8 @@ def cpu_baseline(scene_name, res, seconds_target=15.0, mesh_detail=1, polarimetr
     _, _, _, _, n, _ = oracle_render_tiles(sc, 1, 1 + spp, 123, stride, 0, threads=cores)
     dt = time.time() - t
     import ctypes
-    from oracle_util import load_oracle
     lib = load_oracle()
+    lib.oracle_set_fine_items(0)
     lib.oracle_last_utilisation.restype = ctypes.c_double
     util = float(lib.oracle_last_utilisation())
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "thread_utilisation": util,

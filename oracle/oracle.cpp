@@ -58,6 +58,7 @@ int g_split_step = 0;
 // 1: every (s,t) strategy the way the device's staged connection kernels run it (wt/bdpt.h: bdpt_strategy<true> — flux without the shadow ray, the
 // ray, MIS + splat with the temporary vertex formed again).  The results must be identical (test_staged_connections_are_the_connections).
 int g_staged_connect = 0;
+int g_fine_items = 0;   // oracle_set_fine_items
 double g_last_utilisation = 1.0;   // of the worker threads of the last render (oracle_last_utilisation)
 
 void add_counters(bdpt_counters_t& a, const bdpt_counters_t& b) {
@@ -157,7 +158,9 @@ static int oracle_render_impl(const void* scene_host, uint64_t sample_begin, uin
     for (auto& c : ctrs) std::memset(&c, 0, sizeof(c));
     std::vector<double> busy(n_threads, 0.0);
     const uint64_t n_spp = sample_end > sample_begin ? sample_end - sample_begin : 0;
-    const uint32_t items_per_block = (n_threads > 1 && n_spp > 1 && n_spp <= 4096) ? (uint32_t)n_spp : 1u;
+    // (one sample index of a block per work item only on request — bench.py's cpu_baseline: several threads then add to the same pixel in an
+    // order that differs from run to run, and the tests compare multi-threaded renders bit for bit)
+    const uint32_t items_per_block = (g_fine_items && n_threads > 1 && n_spp > 1 && n_spp <= 4096) ? (uint32_t)n_spp : 1u;
     // FSD aperture pool: per thread, reset per sample (apertures only live for one sample)
     auto worker = [&](int tid) {
         sample_scratch_t scr;
@@ -466,6 +469,7 @@ void oracle_set_traverse_axis(int on) { g_traverse_axis = on; }
 void oracle_set_walk_axis(int on) { g_walk_axis = on; }
 void oracle_set_split_step(int mode) { g_split_step = mode; }
 double oracle_last_utilisation() { return g_last_utilisation; }
+void oracle_set_fine_items(int on) { g_fine_items = on; }
 void oracle_set_staged_connect(int on) { g_staged_connect = on; }
 
 // Region summaries of cone queries of any size: what the reference's unbounded intersection record yields (`list`: every triangle

@@ -489,8 +489,9 @@ def test_which_of_the_shipped_scene_files_load(built):
 
 def test_constant_radiance_textures_on_area_emitters(built, tmp_path):
     """<texture name="radiance"> on an area emitter (area.hpp:103-116: radiance->f({uv, k}).x times the emitter's own `scale`): a texture that is
-    the same everywhere makes the uniform emitter with the colour's uplifted spectrum — the film of the rgb= spectrum twin, bit for bit, also
-    through a `scale` wrapper; a spatially varying one is refused with the reason."""
+    the same everywhere makes the uniform emitter.  A constant texture is a LUMINANCE texture, wavelength independent at any wavenumber (not
+    the RGB uplift, which is zero outside 380-720 nm: an infrared or radio sensor would see a dark emitter): the film of the constant-spectrum
+    twin, bit for bit, also through a `scale` wrapper; a spatially varying texture is refused with the reason."""
     from wave_tracer_amd import Scene
     from wave_tracer_amd.api import WtgpuError
     xml = """<scene version="0.1.0">
@@ -510,7 +511,7 @@ def test_constant_radiance_textures_on_area_emitters(built, tmp_path):
         f = tmp_path / f"{tag}.xml"
         f.write_text(xml.replace("$radiance", radiance))
         return Scene.from_xml(str(f))
-    ref, cref = _render_dev(scene('<spectrum name="radiance" rgb=".5, .5, .5"><float name="scale" value="3"/></spectrum>', "rgb"))
+    ref, cref = _render_dev(scene('<spectrum name="radiance" constant=".5"><float name="scale" value="3"/></spectrum>', "flat"))
     assert ref.sum() > 0
     img, c = _render_dev(scene('<texture name="radiance" type="constant"><spectrum constant=".5"/></texture><float name="scale" value="3"/>', "const"))
     assert np.array_equal(img, ref) and c == cref

@@ -14,7 +14,7 @@ disp = defaultdict(set)
 for f in files:
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:].replace(",", ";")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("wtk::", "").split("(")[0][-60:].replace(",", ";")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add((f, r["Dispatch_Id"]))
 counters = sorted({c for k in acc for c in acc[k]})

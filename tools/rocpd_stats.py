@@ -14,7 +14,7 @@ rows = db.execute(f"""select s.kernel_name, count(*), sum(d.end-d.start)/1e6, av
 total = sum(r[2] for r in rows)
 lines = ["kernel,calls,total_ms,avg_ms,min_ms,max_ms,percent,arch_vgpr,accum_vgpr,sgpr,lds_bytes,scratch_bytes_per_lane,workgroup"]
 for r in rows:
-    name = r[0].split('(')[0][-60:]
+    name = r[0].replace('wtk::', '').split('(')[0][-60:]
     lines.append(f"{name},{r[1]},{r[2]:.3f},{r[3]:.4f},{r[4]:.4f},{r[5]:.4f},{100*r[2]/total:.2f},{r[6]},{r[7]},{r[8]},{r[9]},{r[10]},{r[11]}")
 out = "\n".join(lines)
 print(out)

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);
                 // plt_bdpt: the bounded list (64 triangles + their cone-hit distances) of the interaction region; see k_trace
                 uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
-                tris = uint_list_t{slot, 1u, a.collect_list ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
+                tris = uint_list_t{slot, 1u, (a.collect_list & 1u) ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
                 env = walk_trace_envelope(a.sc, wk);
                 ray_hit_t ah;
                 // (The axis query in a kernel of its own was built twice: round 3 as a grid-stride kernel — 60 vs 56 ms per pass — and round 4 as a
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                 // section spends ~3): the two kernels together took 24.2 ms of the long rounds against 23.4 ms with the query in here, 22.4 vs 22.5
                 // Msamples/s — the fetch section's rays overlap other wavefronts' cone queries, which a separate kernel gives up.  Not kept.)
                 const bool axis_hit = ads_intersect_ray(a.sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
-                aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !a.collect_list, a.lane_cache ? wk.prev_offset_tuid : kInvalid);
+                aw_begin(aw, wavenum_to_wavelen_m(wk.k), WT_INF, axis_hit, ah, a.cone_budget, true, !(a.collect_list & 1u) || (a.collect_list & 2u), a.lane_cache ? wk.prev_offset_tuid : kInvalid);
                 aw.use_cache = a.lane_cache;
                 fin = !policy_next_query(a.sc, env, rt, stack, aw, q, r);
                 st = fin ? 0 : 1;
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
                     ctr.segments += 1;
                     ctr.ray_queries += r.n_ray_queries;
                     ctr.cone_queries += r.n_cone_queries;
-                    if (a.collect_list) ctr.cone_tri_overflow += r.overflow;
+                    if (a.collect_list & 1u) ctr.cone_tri_overflow += r.overflow;
                 }
             }
             wave_append(a.st.heavy_queue, ctl + CTL_HEAVY_COUNT, heavy, w_fin);
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
         if (item >= n) break;
         const uint32_t w = hq[item];
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
-        const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, a.collect_list ? kMaxConeTris : 0u};   // see k_trace
+        const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, (a.collect_list & 1u) ? kMaxConeTris : 0u};   // see k_trace
         const cone_t env = walk_trace_envelope(a.sc, wk);
         unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const long long tt0 = a.profile == 2 ? clock64() : 0;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
         axis.front_face = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(front_face)];
         const uint32_t short0 = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(overflow)];
         const trav_result_t tr2 = coop_traverse(a.sc, env, wavenum_to_wavelen_m(wk.k), WT_INF, rt, sh, tris, a.profile == 2 ? prof : nullptr, true, seg0, dist0, nray0, ncone0,
-                                                &axis, !a.collect_list, a.heavy_probe != 0, a.heavy_cache ? short0 : kInvalid, a.heavy_cache ? wk.prev_offset_tuid : kInvalid, a.heavy_cache != 0);
+                                                &axis, !(a.collect_list & 1u) || (a.collect_list & 2u), a.heavy_probe != 0, a.heavy_cache ? short0 : kInvalid, a.heavy_cache ? wk.prev_offset_tuid : kInvalid, a.heavy_cache != 0);
         if (a.profile == 2 && threadIdx.x == 0) {
             prof[3] = (unsigned long long)(clock64() - tt0);
             for (int q = 0; q < 4; ++q) atomicAdd(a.st.counters + kNumCounters + q, prof[q]);
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
             ctr.segments += 1;
             ctr.ray_queries += tr2.n_ray_queries;
             ctr.cone_queries += tr2.n_cone_queries;
-            if (a.collect_list) ctr.cone_tri_overflow += tr2.overflow;
+            if (a.collect_list & 1u) ctr.cone_tri_overflow += tr2.overflow;
         }
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);

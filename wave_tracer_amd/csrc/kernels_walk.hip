@@ -35,9 +35,13 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
 // pass-B queue.  k_edges then gathers the classified-edge set of their regions.  PASS 1 (B): Fraunhofer aperture construction,
 // null interactions; the one walk in eight whose aperture has edges goes on to the pass-C queue (k_interact_c).
 // No BVH query happens in these passes (the trace kernels resolved the primary triangle): they carry no traversal stack.
-template <int PASS>
+// COOP: the walk and traversal records come in, and the appended vertex and the walk record go out, by wave-cooperative transfers through LDS
+// (wtgpu_kernels.h: wave_load_records / wave_store_records) instead of lane by lane.
+template <int PASS, bool COOP = false>
 __device__ inline __attribute__((always_inline)) void interact_body(const launch_args_t& a, int in, int first_round) {
     constexpr bool PASS_B = PASS == 1;
+    __shared__ uint32_t s_io[COOP ? (kBlock / 64) * kIoRows * io_pitch<(int)kVertexWords>() : 1];
+    uint32_t* io = s_io + (COOP ? (threadIdx.x >> 6) * kIoRows * io_pitch<(int)kVertexWords>() : 0);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = PASS_B ? ctl[CTL_INTB_COUNT] : queue_count(ctl, in);
     if (!PASS_B && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -67,20 +71,30 @@ __device__ inline __attribute__((always_inline)) void interact_body(const launch
         defer.gather_flux = 0.f;
         defer.gather_edges = nullptr;
         bool need_gather = false;
-        if (qi < n) {
-            w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
+        const bool valid = qi < n;
+        if (valid) w = PASS_B ? a.st.intb_queue[qi] : queue_walk(a, ctl, in, qi, first_round);
+        walk_t wk;
+        trav_result_t tr;
+        if constexpr (COOP) {
+            wave_load_records<(int)kWalkWords>(a.st.walks, a.st.walk_words, w, valid, io, wk);
+            wave_load_records<(int)kTravWords>(a.st.trav, kTravWords, w, valid, io, tr);
+        }
+        vertex_t staged;
+        uint32_t staged_idx = kInvalid;
+        bool store_walk = false;
+        if (valid) {
             uint32_t i, stream;
             walk_ident(a, w, i, stream);
             const uint64_t j = a.j0 + i;
             const uint32_t pix = (uint32_t)(j % a.npix);
             const uint64_t s = a.sample_begin + j / a.npix;
             const uint64_t sample_id = ((uint64_t)pix << 32) | (s & 0xFFFFFFFFull);
-            walk_t wk;
-            soa_load(a.st.walks, a.st.walk_words, w, wk);
-            trav_result_t tr;
-            soa_load(a.st.trav, kTravWords, w, tr);
+            if constexpr (!COOP) {
+                soa_load(a.st.walks, a.st.walk_words, w, wk);
+                soa_load(a.st.trav, kTravWords, w, tr);
+            }
             const uint_list_t tris{a.st.tris + (size_t)w * kTriListWords, 1u, kMaxConeTris};
-            const vertex_store_t vs{a.st.verts, a.st.vert_words, w};
+            const vertex_store_t vs{a.st.verts, a.st.vert_words, w, COOP ? &staged : nullptr, COOP ? &staged_idx : nullptr};
             const bool queued_for_c = PASS_B && tr.tuid == kApertureMarker;   // k_edges built the aperture and queued the walk for pass C
             if (PASS_B && tr.tuid == kNullApertureMarker) {   // k_edges built the aperture: no segments (the step restarts the beam)
                 defer.have_aperture = 1;
@@ -103,11 +117,16 @@ __device__ inline __attribute__((always_inline)) void interact_body(const launch
             }
             // a region that did not fit the bounded list: its edge set comes from a walk of the whole region (k_edges)
             // (... or whose list holds more than kMaxEdgeIds / 3 triangles: the per-lane edge set of pass B is bounded)
-            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list)) need_gather = true;
+            if (!PASS_B && defer.no_primary && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !(a.collect_list & 1u))) need_gather = true;
             if (!defer.no_primary && !defer.to_sampling_pass && !queued_for_c) {
                 wk.active = cont ? 1u : 0u;
-                soa_store(a.st.walks, a.st.walk_words, w, wk);
+                store_walk = true;
+                if constexpr (!COOP) soa_store(a.st.walks, a.st.walk_words, w, wk);
             }
+        }
+        if constexpr (COOP) {
+            wave_store_records<(int)kVertexWords>(a.st.verts, a.st.vert_words, w, staged_idx == kInvalid ? 0u : staged_idx * (uint32_t)kVertexWords, valid && staged_idx != kInvalid, io, staged);
+            wave_store_records<(int)kWalkWords>(a.st.walks, a.st.walk_words, w, 0u, store_walk, io, wk);
         }
         if (!PASS_B) wave_append(a.st.intb_queue, ctl + CTL_INTB_COUNT, defer.no_primary != 0, w);
         if (!PASS_B) wave_append(a.st.gather_queue, ctl + CTL_GATHER_COUNT, need_gather, w);
@@ -157,7 +176,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(launch_args_t a, int in, in
                 tv[WT_TRAV_WORD(pdist)] = __float_as_uint(ph.dist);
             }
             // a region that did not fit the bounded list (or whose list holds more than kMaxEdgeIds / 3 triangles): its edge set comes from k_edges
-            need_gather = cls == WCLS_NO_PRIMARY && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !a.collect_list);
+            need_gather = cls == WCLS_NO_PRIMARY && !tr.ballistic && a.sc.opts.FSD && (tr.overflow > 0 || tr.ntris > kMaxEdgeIds / 3 || !(a.collect_list & 1u));
         }
 #pragma unroll
         for (uint32_t c = 0; c < kNumWalkClasses; ++c) wave_append(x.cls_queue + (size_t)c * W2, ctl + CTL_CLS_COUNT0 + c, cls == c, w);
@@ -326,6 +345,10 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
 }
 
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT) k_interact(launch_args_t a, int in, int first_round) { interact_body<0>(a, in, first_round); }
+#ifndef WTGPU_LB_INTERACT_COOP
+#define WTGPU_LB_INTERACT_COOP 3
+#endif
+__global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_COOP) k_interact_coop(launch_args_t a, int in, int first_round) { interact_body<0, true>(a, in, first_round); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
 
 }   // namespace wtk

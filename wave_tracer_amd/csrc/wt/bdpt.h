@@ -86,6 +86,11 @@ struct vertex_store_t {
     uint32_t* base;
     size_t stride;
     size_t idx;
+    // Device, optional: the vertex a step appends is kept in `*stage` (its index in *staged_idx) instead of being written lane by lane — the
+    // kernel writes the staged vertices of a wavefront afterwards, record by record with consecutive lanes on consecutive words (wtgpu_kernels.h:
+    // wave_store_records).  Words stored into the staged vertex later (its rr_weight: walk_continue) go to the staged copy.
+    vertex_t* stage = nullptr;
+    uint32_t* staged_idx = nullptr;
     WT_HD void load(uint32_t v, vertex_t& out) const { soa_load(base + (size_t)v * kVertexWords, stride, idx, out); }
     // the beam-less part of a vertex (+ its wavenumber)
     WT_HD void load(uint32_t v, vertex_nb_t& out) const {
@@ -101,12 +106,23 @@ struct vertex_store_t {
         constexpr size_t o = (offsetof(vertex_t, surf) + offsetof(surface_t, wp)) / 4;
         return vec3{load_word<float>(v, o), load_word<float>(v, o + 1), load_word<float>(v, o + 2)};
     }
-    WT_HD void store(uint32_t v, const vertex_t& in) const { soa_store(base + (size_t)v * kVertexWords, stride, idx, in); }
+    WT_HD void store(uint32_t v, const vertex_t& in) const {
+        if (stage) {
+            *stage = in;
+            *staged_idx = v;
+            return;
+        }
+        soa_store(base + (size_t)v * kVertexWords, stride, idx, in);
+    }
     template <class F>
     WT_HD void store_word(uint32_t v, size_t word, F value) const {
         static_assert(sizeof(F) == 4, "");
         uint32_t w;
         __builtin_memcpy(&w, &value, 4);
+        if (stage && *staged_idx == v) {
+            reinterpret_cast<uint32_t*>(stage)[word] = w;
+            return;
+        }
         base[idx * stride + (size_t)v * kVertexWords + word] = w;
     }
     template <class F>

@@ -117,7 +117,7 @@ struct wtgpu_scene {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 1, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
-        uint32_t sorted_interact = 0, staged_connect = 0, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
+        uint32_t coop_io = 0, primary_axis = 0, sorted_interact = 0, staged_connect = 0, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -469,6 +469,8 @@ static void read_knobs(wtgpu_scene* s) {
     //   WTGPU_SORTED_INTERACT  0: k_interact (one kernel, every walk); 1: k_classify + one kernel per material class; 2: k_classify + k_interact_sorted
     //   WTGPU_STAGED_CONNECT   0: k_connect_strat (one kernel per strategy item); 1: k_connect_eval -> k_connect_shadow -> k_connect_mis, in chunks
     k.sorted_interact = u("WTGPU_SORTED_INTERACT", 0);
+    k.primary_axis = u("WTGPU_PRIMARY_AXIS", 0);
+    k.coop_io = u("WTGPU_COOP_IO", 0);   // pass A with wave-cooperative record transfers (k_interact_coop)
     k.staged_connect = u("WTGPU_STAGED_CONNECT", 0);
     k.conn_pool = std::max(1u, u("WTGPU_CONN_POOL", 16));
     if (const char* e = getenv("WTGPU_GRID_CLS")) {
@@ -828,7 +830,9 @@ struct batch_launcher_t {
                 HP_LAUNCH(26, k_interact_spm, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[2])), dim3(kBlock), 0, st_, a, in);
                 HP_LAUNCH(27, k_interact_any, dim3(std::max<uint32_t>(1u, g0 / K.grid_div_cls[3])), dim3(kBlock), 0, st_, a, in);
                 }
-            } else
+            } else if (K.coop_io)
+                HP_LAUNCH(11, k_interact_coop, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
+            else
                 HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec(r, st_);
             HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
@@ -1007,7 +1011,9 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
     // Bounded triangle lists (64) are the fast path of an interaction region; a region that overflows its list is handled exactly by
     // walks of the WHOLE region: primary triangle (resolve_primary), classified edges (k_edges), intercepted power (k_flux_*).
     // WTGPU_NO_LISTS=1 (plt_bdpt, diagnostic): no lists at all, every region is gathered.
-    a.collect_list = (h.opts.integrator != INTEGRATOR_BDPT || !K.no_lists) ? 1u : 0u;
+    // bit 0: the cone queries keep the region's bounded triangle list; bit 1 (plt_bdpt, WTGPU_PRIMARY_AXIS=1): the triangle under the beam axis of EVERY
+    // diffusive hit comes from the trace kernels' axis query (as it does for regions beyond the list), not from a scan of the list in pass A
+    a.collect_list = ((h.opts.integrator != INTEGRATOR_BDPT || !K.no_lists) ? 1u : 0u) | ((h.opts.integrator == INTEGRATOR_BDPT && K.primary_axis) ? 2u : 0u);
     batch_launcher_t L(s);
 
     // the internal streams start after everything already enqueued on the caller's stream ...

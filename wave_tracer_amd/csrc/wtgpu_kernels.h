@@ -168,7 +168,7 @@ struct launch_args_t {
     uint32_t profile;   // WTGPU_PROFILE=1: clock64() breakdown of the heavy traversals into counters[kNumCounters..]
     uint32_t split_queues;   // round queues keep sensor and emitter walks apart (queue_append); 0: one mixed queue (A/B)
     uint32_t lane_cache, heavy_cache;   // diagnostic switches of the remembered rejecting triangles (wt::traverse_axis / coop_traverse); default on
-    uint32_t collect_list;    // plt_path: the cone queries keep the bounded triangle list of the interaction region (plt_bdpt: closest hit only)
+    uint32_t collect_list;    // bit 0: the cone queries keep the bounded triangle list of the interaction region; bit 1: primary triangles from the axis query always (wtgpu.hip)
 };
 
 // (block size as a constant: blockDim would pull 256 bytes of hidden kernel arguments into the kernel-argument segment)
@@ -239,6 +239,73 @@ __device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int o
     if (back) a.st.queue[out][2 * (size_t)a.st.cap - 1 - (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = w;
 }
 
+// ---- wave-cooperative record transfer -------------------------------------------------------------------------------------------------------
+// The per-walk records are record-major in memory (one contiguous record per walk) and the walks a wavefront holds are scattered over the batch.
+// A lane that loads its own record word by word makes every load INSTRUCTION touch 64 different cache lines for 4 bytes each (57 instructions x
+// 64 lines for a walk); a lane that stores its record word by word leaves 64 partially written lines behind every instruction, which the L2
+// evicts before the other 85 words of a vertex arrive (measured, run r5g: k_interact moves 82 GB per step for 13 GB of records).  Here the
+// wavefront moves the records of its lanes ONE RECORD AT A TIME, consecutive lanes on consecutive words (a 228-byte walk = one instruction
+// touching 2-3 lines), through an LDS buffer of kIoRows rows that the owning lanes then read / have written row-wise (odd pitch: no bank
+// conflicts): 64 x 3 line visits instead of 57 x 64.  Half a wavefront at a time, so that the buffer is 11 KB per wavefront.
+constexpr int kIoRows = 32;
+template <int W>
+constexpr int io_pitch() { return (W & 1) ? W : W + 1; }
+// `idx`: the lane's record, `valid`: the lane takes part; lds: this wavefront's buffer (>= kIoRows * io_pitch<W>() words)
+template <int W, class T>
+__device__ inline void wave_load_records(const uint32_t* base, size_t stride, uint32_t idx, bool valid, uint32_t* lds, T& out) {
+    static_assert(sizeof(T) == 4 * W, "record size");
+    constexpr int P = io_pitch<W>();
+    const int lane = threadIdx.x & 63;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+    const unsigned long long all = __ballot(valid);
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long m = all & (h ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
+        while (m) {
+            const int r = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t* src = base + (size_t)__builtin_amdgcn_readlane(idx, r) * stride;
+#pragma unroll
+            for (int w0 = 0; w0 < W; w0 += 64)
+                if (w0 + lane < W) lds[(r & 31) * P + w0 + lane] = src[w0 + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (lane >> 5) == h) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) o[i] = lds[(lane & 31) * P + i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// ... `off`: word offset of the lane's record behind base + idx * stride (a vertex of the walk's vertex array)
+template <int W, class T>
+__device__ inline void wave_store_records(uint32_t* base, size_t stride, uint32_t idx, uint32_t off, bool valid, uint32_t* lds, const T& in) {
+    static_assert(sizeof(T) == 4 * W, "record size");
+    constexpr int P = io_pitch<W>();
+    const int lane = threadIdx.x & 63;
+    const uint32_t* o = reinterpret_cast<const uint32_t*>(&in);
+    const unsigned long long all = __ballot(valid);
+    if (!all) return;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if (valid && (lane >> 5) == h) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) lds[(lane & 31) * P + i] = o[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long m = all & (h ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull);
+        while (m) {
+            const int r = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            uint32_t* dst = base + (size_t)__builtin_amdgcn_readlane(idx, r) * stride + __builtin_amdgcn_readlane(off, r);
+#pragma unroll
+            for (int w0 = 0; w0 < W; w0 += 64)
+                if (w0 + lane < W) dst[w0 + lane] = lds[(r & 31) * P + w0 + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- kernels (definitions: kernels_*.hip)
 constexpr uint32_t kFlushGrid = 64;          // k_path_flush
 constexpr int kEnumBlock = 1024;             // k_connect_enum
@@ -256,6 +323,7 @@ __global__ void k_interact_dielectric(launch_args_t a, int in);
 __global__ void k_interact_spm(launch_args_t a, int in);
 __global__ void k_interact_any(launch_args_t a, int in);
 __global__ void k_interact_sorted(launch_args_t a, int in);
+__global__ void k_interact_coop(launch_args_t a, int in, int first_round);
 __global__ void k_edges(launch_args_t a);
 __global__ void k_interact_b(launch_args_t a, int in);
 __global__ void k_flux_split(launch_args_t a);
