@@ -13,7 +13,7 @@ namespace wtk {
 //                     control flow, coalesced vertex loads; the t>1 fluxes are summed per sample (f64 atomics), t<=1 strategies
 //                     splat into the light image directly,
 //   k_connect_splat : one film splat per sample with the summed flux (film.hpp:214-342).
-__device__ inline bool strategy_valid(const integrator_opts_t& o, int s, int t, int nS, int nT) {
+WT_D bool strategy_valid(const integrator_opts_t& o, int s, int t, int nS, int nT) {
     const int depth = t + s - 2;
     if (t > nT || s > nS) return false;
     if ((t == 1 && s == 1) || depth < 0 || depth > o.max_depth) return false;
@@ -24,7 +24,7 @@ __device__ inline bool strategy_valid(const integrator_opts_t& o, int s, int t, 
     return true;
 }
 // bucket (sk, tk): does it hold a valid strategy of a sample with nS / nT vertices?  (the last row / column stands for every s / t >= kKeyDim-1)
-__device__ inline bool strategy_class_valid(const integrator_opts_t& o, int sk, int tk, int nS, int nT) {
+WT_D bool strategy_class_valid(const integrator_opts_t& o, int sk, int tk, int nS, int nT) {
     const int K = (int)kKeyDim - 1;
     const int t1 = tk < K ? tk : nT, s1 = sk < K ? sk : nS;
     for (int t = tk; t <= t1; ++t)
@@ -32,7 +32,7 @@ __device__ inline bool strategy_class_valid(const integrator_opts_t& o, int sk, 
             if (strategy_valid(o, s, t, nS, nT)) return true;
     return false;
 }
-__device__ inline int wave_max_i(int v) {
+WT_D int wave_max_i(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
     return v;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64) k_connect_scan(launch_args_t a) {
 // buckets of the last row / column, whose items loop over every longer strategy of their sample — a kernel of its own so that the loop and
 // the subpath lengths it needs do not weigh on the common case's registers.
 template <bool OPEN>
-__device__ inline __attribute__((always_inline)) void connect_strat_body(const launch_args_t& a) {
+WT_D void connect_strat_body(const launch_args_t& a) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     __shared__ uint32_t s_prefix[kNumKeys + 1];
     constexpr int K = (int)kKeyDim - 1;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CONNECT) k_connect_strat_open
 //                     numbers (bdpt_connect_temp), streaming MIS weight (plt_bdpt_detail.hpp:604-720), flux sum or light-image splat.
 // Same functions, same numbers as the one-piece form (the CPU checker runs both: tests/test_oracle.py::test_staged_connections_are_the_connections).
 constexpr uint32_t kPendShadow = 0x80000000u;   // conn_pending_t::st: the connection waits for its ray (t in bits 16..30, s in bits 0..15)
-__device__ inline void pending_append(const launch_args_t& a, uint32_t* cctl, bool keep, uint32_t i, int s, int t, const connect_ret_t& cr) {
+WT_D void pending_append(const launch_args_t& a, uint32_t* cctl, bool keep, uint32_t i, int s, int t, const connect_ret_t& cr) {
     const bdpt_ext_t& x = *a.st.ext;
     const unsigned long long m = __ballot(keep);
     if (!m) return;

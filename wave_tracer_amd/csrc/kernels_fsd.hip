@@ -10,7 +10,6 @@ namespace wtk {
 // into subtrees of <= kFluxTaskTris (2048; swept 128 / 512 / 2048: 247 / 216 / 208 ms per pass) triangles, k_flux_tasks sums every subtree on whichever wavefront is free (f64 atomics).
 __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     __shared__ coop_gather_shared_t sh;
-    __shared__ uint32_t s_item;
     coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_INTC_COUNT];
@@ -19,10 +18,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     // split — bidir_room: 400,000 items a round, a few thousand to split; one item per grab was 11.5 ms of a 125-ms batch there), the
     // wavefront then cuts the regions of the flagged ones, one after the other
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSPLIT_HEAD, 64u);
-        __syncthreads();
-        const uint32_t base = s_item;
-        __syncthreads();
+        const uint32_t base = wave_grab0(ctl + CTL_FSPLIT_HEAD, 64u);
         if (base >= n) break;
         uint32_t w_mine = 0;
         bool need = false;
@@ -53,16 +49,12 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
 }
 __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t a) {
     __shared__ coop_gather_shared_t sh;
-    __shared__ uint32_t s_item;
     coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = min(ctl[CTL_FTASK_COUNT], a.st.ftask_cap);
     const size_t W2 = 2 * (size_t)a.st.cap;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FTASK_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        const uint32_t item = wave_grab0(ctl + CTL_FTASK_HEAD, 1u);
         if (item >= n) break;
         const uint2 task = a.st.ftasks[item];
         const uint32_t w = task.x;
@@ -105,7 +97,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t 
 constexpr uint32_t kEasyTries = 512;
 constexpr uint32_t kStageSegs = 256;
 template <int BLOCK>
-__device__ inline __attribute__((always_inline)) void interact_c_body(const launch_args_t& a, int in) {
+WT_D void interact_c_body(const launch_args_t& a, int in) {
     constexpr bool HARD = BLOCK > 64;
     __shared__ uint32_t s_item;
     __shared__ uint32_t s_tmin;
@@ -122,10 +114,14 @@ __device__ inline __attribute__((always_inline)) void interact_c_body(const laun
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
         const long long pl0 = a.profile == 3 ? clock64() : 0;
-        if (tid == 0) s_item = atomicAdd(ctl + (HARD ? CTL_INTD_HEAD : CTL_INTC_HEAD), 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        uint32_t item = 0;
+        if (HARD) {   // four wavefronts: through the shared word, between real barriers — the first one BEFORE the branch on the thread index
+            __syncthreads();   // (wtgpu_kernels.h: wave_grab0 says why; it also keeps the last iteration's readers ahead of the write)
+            if (tid == 0) s_item = atomicAdd(ctl + CTL_INTD_HEAD, 1u);
+            __syncthreads();
+            item = s_item;
+        } else
+            item = wave_grab0(ctl + CTL_INTC_HEAD, 1u);
         if (item >= n) break;
         const uint32_t w = queue_in[item];
         uint32_t i, stream;

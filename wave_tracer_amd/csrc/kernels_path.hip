@@ -32,7 +32,12 @@ __global__ void __launch_bounds__(kBlock) k_path_generate(launch_args_t a) {
 // do_fsd (plt_path_detail.hpp:311-346) by ONE WAVEFRONT: lane = wedge (strided over apertures of any size) — the Fermat point on the wedge, the
 // UTD coefficients and the two shadow rays (per-lane any-hit traversals on the lane's LDS stack) — coherent sums in f64 by wave reduction; the
 // direct path is evaluated redundantly by all lanes (uniform control flow).  Returns (|ts|^2 + |th|^2) / 2.
-__device__ inline float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const path_geo_t& src_geo, vec3 dst, const utd_aperture_t& ap, const utd_edge_rec_t* recs,
+#ifdef WTGPU_FSD_WATCH
+extern "C" int wtgpu_debug_set_watch(unsigned int* host_mapped) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_watch), &host_mapped, sizeof(host_mapped));
+}
+#endif
+WT_D float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const path_geo_t& src_geo, vec3 dst, const utd_aperture_t& ap, const utd_edge_rec_t* recs,
                                     float k, const stack_ref_t& stack, bdpt_counters_t* ctr) {
     const int lane = threadIdx.x & 63;
     const vec3 src = cone_from_src.o;
@@ -40,8 +45,14 @@ __device__ inline float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_s
     double tsr = 0, tsi = 0, thr = 0, thi = 0;
     for (uint32_t i = (uint32_t)lane; i < ap.n_edges; i += 64u) {
         utd_diffracting_edge_t f;
+        WT_WATCH_ADD(12);
+        if (lane == 0) WT_WATCH(13, i);
+        if (lane == 0) WT_WATCH(14, ap.n_edges);
+        if (lane == 0) WT_WATCH(5, i);
         if (!utd_f_edge(sc, ap, recs[i], src, dst, f)) continue;
+        if (lane == 0) WT_WATCH(6, i);
         const path_geo_t eintr = path_geo_edge(f.edge, f.p);
+        WT_WATCH_ADD(15);
         if (path_shadow(sc, eintr, src_geo, stack, ctr) || path_shadow(sc, eintr, dst_geo, stack, ctr)) continue;
         const cplx phase = cpolar(1.f, -k_times_len(k, f.ro + f.ri));
         const cplx a = phase * f.utd.Ds, b = phase * f.utd.Dh;
@@ -74,7 +85,6 @@ __device__ inline float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_s
 __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_state_t* __restrict__ ps, uint32_t round) {
     const path_state_t& P = *ps;
     __shared__ stack_entry_t lds[kLdsStack * 64];
-    __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t qin = round & 1u;
     const uint32_t n = ctl[CTL_FSDQ_COUNT0 + qin];
@@ -85,10 +95,7 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_
     memset(&ctr, 0, sizeof(ctr));
     const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_FSDQ_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        const uint32_t item = wave_grab0(ctl + CTL_FSDQ_HEAD, 1u);
         if (item >= n) break;
         const uint32_t w = P.fsdq[qin][item];
         const uint32_t empty = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)];
@@ -99,6 +106,14 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_
                           __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
         const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
         const vec3 interaction_wp = origin + dist * pw.w.beam.env.d;
+        if (threadIdx.x == 0) {
+            WT_WATCH(0, item);
+            WT_WATCH(1, n);
+            WT_WATCH(2, w);
+            WT_WATCH(3, pw.ap.n_edges);
+            WT_WATCH(4, round);
+            WT_WATCH(7, pw.ap.edge_offset);
+        }
 #ifdef WTGPU_FSD_DEBUG
         if (pw.ap.n_edges > pw.ap.edge_cap || pw.ap.n_edges > 100000u || !pw.has_fsd) {
             if (threadIdx.x == 0) printf("[k_path_fsd] round %u item %u/%u walk %u: n_edges %u cap %u offset %u has_fsd %u active %u nverts %u\n", round, item, n, w, pw.ap.n_edges, pw.ap.edge_cap, pw.ap.edge_offset, pw.has_fsd, pw.w.active, pw.w.nverts);
@@ -120,16 +135,12 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const pat
     __shared__ coop_shared_t csh;
     __shared__ coop_gather_shared_t sh;
     __shared__ coop_edges_t eg;
-    __shared__ uint32_t s_item;
     coop_set_dropped_counter(csh, a.st.counters + kDroppedSlot);
     coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_GATHER_COUNT];
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        const uint32_t item = wave_grab0(ctl + CTL_GATHER_HEAD, 1u);
         if (item >= n) break;
         const uint32_t w = a.st.gather_queue[item];
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
@@ -162,10 +173,7 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const pat
             const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
             n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges;
             dropped = bitmap ? 0u : g.edge_overflow;
-            if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
-            __syncthreads();
-            off = s_item;
-            __syncthreads();
+            off = wave_grab0(ctl + CTL_EPOOL_COUNT, n_edges);
             if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported
                 dropped += n_edges;
                 n_edges = 0;
@@ -184,7 +192,7 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const pat
 
 // PASS 0: the round's queue; walks whose classified-edge set needs a wavefront are only queued for k_path_edges.  PASS 1: those walks, with it.
 template <int PASS>
-__device__ inline __attribute__((always_inline)) void path_interact_body(const launch_args_t& a, const path_state_t& P, int in, int first_round, uint32_t round) {
+WT_D void path_interact_body(const launch_args_t& a, const path_state_t& P, int in, int first_round, uint32_t round) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = PASS ? ctl[CTL_GATHER_COUNT] : queue_count(ctl, in);
@@ -262,7 +270,6 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_PATH) k_path_interact_b(launc
 __global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, const path_state_t* __restrict__ ps, uint32_t round) {
     const path_state_t& P = *ps;
     __shared__ stack_entry_t lds[kLdsStack * 64];
-    __shared__ uint32_t s_item;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_NEEQ_COUNT];
     stack_entry_t spill[kSpillStack];
@@ -272,10 +279,7 @@ __global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, const path_
     memset(&ctr, 0, sizeof(ctr));
     const utd_edge_rec_t* cur_pool = P.utd[round & 1u];
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_NEEQ_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        const uint32_t item = wave_grab0(ctl + CTL_NEEQ_HEAD, 1u);
         if (item >= n) break;
         const uint32_t w = P.neeq[item];
         const path_nee_rec_t r = P.nee_recs[w];   // uniform address

@@ -29,7 +29,7 @@ namespace wtk {
 #define WTGPU_REFILL_MIN 16
 #endif
 // the policy up to its next cone query (TRUE) or its end (FALSE: `r` is final); the tests of the remembered triangles run right here
-__device__ inline bool policy_next_query(const scene_t& sc, const cone_t& env, bool rt, const stack_ref_t& stack, axis_walk_t& aw, cone_query_t& q, trav_result_t& r) {
+WT_D bool policy_next_query(const scene_t& sc, const cone_t& env, bool rt, const stack_ref_t& stack, axis_walk_t& aw, cone_query_t& q, trav_result_t& r) {
     for (;;) {
         const int need = aw_next(sc, env, rt, stack, aw, q, r);
         if (need != AW_TEST) return need == AW_QUERY;
@@ -222,7 +222,6 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_
 // Heavy traversals: one wavefront (64-thread block) per walk, persistent blocks pulling from the heavy queue.
 __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_t a) {
     __shared__ coop_shared_t sh;
-    __shared__ uint32_t s_item;
     coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_HEAVY_COUNT];
@@ -233,10 +232,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
     const size_t W2 = 2 * (size_t)a.st.cap;
     const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(head, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        const uint32_t item = wave_grab0(head, 1u);
         if (item >= n) break;
         const uint32_t w = hq[item];
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast

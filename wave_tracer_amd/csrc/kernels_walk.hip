@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
 // COOP: the walk and traversal records come in, and the appended vertex and the walk record go out, by wave-cooperative transfers through LDS
 // (wtgpu_kernels.h: wave_load_records / wave_store_records) instead of lane by lane.
 template <int PASS, bool COOP = false>
-__device__ inline __attribute__((always_inline)) void interact_body(const launch_args_t& a, int in, int first_round) {
+WT_D void interact_body(const launch_args_t& a, int in, int first_round) {
     constexpr bool PASS_B = PASS == 1;
     __shared__ uint32_t s_io[COOP ? (kBlock / 64) * kIoRows * io_pitch<(int)kVertexWords>() : 1];
     uint32_t* io = s_io + (COOP ? (threadIdx.x >> 6) * kIoRows * io_pitch<(int)kVertexWords>() : 0);
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(launch_args_t a, int in, in
     }
 }
 template <int CLS>
-__device__ inline __attribute__((always_inline)) void interact_cls_body(const launch_args_t& a, int in) {
+WT_D void interact_cls_body(const launch_args_t& a, int in) {
     constexpr uint32_t cls = CLS < 0 ? (uint32_t)WCLS_ANY : (uint32_t)CLS;
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_CLS_COUNT0 + cls];
@@ -269,17 +269,13 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_CLS_SPM) k_interact_any(launc
 __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
     __shared__ coop_gather_shared_t sh;
     __shared__ coop_edges_t eg;
-    __shared__ uint32_t s_item;
     coop_set_dropped_counter(sh, a.st.counters + kDroppedSlot);
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_GATHER_COUNT];
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(ctl + CTL_GATHER_HEAD, 1u);
-        __syncthreads();
-        const uint32_t item = s_item;
-        __syncthreads();
+        const uint32_t item = wave_grab0(ctl + CTL_GATHER_HEAD, 1u);
         if (item >= n) break;
         const uint32_t w = a.st.gather_queue[item];
         walk_t wk;
@@ -294,10 +290,7 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
         // edges.  (Until round 4 that list went into the walk's triangle-list slot, which a later pass may still read as triangles.)
         const bool bitmap = a.sc.n_edges <= kCoopEdgeBits;
         uint32_t n_edges = bitmap ? coop_edge_count(a.sc, eg) : g.n_edges, dropped = bitmap ? 0u : g.edge_overflow, off = 0;
-        if (threadIdx.x == 0) s_item = n_edges ? atomicAdd(ctl + CTL_EPOOL_COUNT, n_edges) : 0u;
-        __syncthreads();
-        off = s_item;
-        __syncthreads();
+        off = wave_grab0(ctl + CTL_EPOOL_COUNT, n_edges);
         if (off + n_edges > a.st.epool_cap) {   // pool exhausted (8M ids per round): reported, cannot happen in the shipped scenes
             dropped += n_edges;
             n_edges = 0;
@@ -311,10 +304,8 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
         if (n_edges >= a.coop_aperture_min) {
             const uint32_t* eids = a.st.epool + off;
             __syncthreads();   // the ids were written by other lanes
-            if (threadIdx.x == 0) s_item = fsd_pool_alloc(pool);
-            __syncthreads();
-            slot = s_item;
-            __syncthreads();
+            if (threadIdx.x == 0) slot = fsd_pool_alloc(pool);
+            slot = wave_bcast0(slot);
             if (slot < pool.cap) {
                 fsd_aperture_t ap;
                 const vec3 sd3 = beam_footprint(wk.beam, beam_dist) / kBeamEnvelope;

@@ -107,6 +107,18 @@ struct uint_list_t {   // bounded output list with the same (pointer,stride) add
 };
 
 constexpr int kRayLeafShortcut = 16;   // src/ads/bvh8w.cpp:29
+#if defined(WTGPU_FSD_WATCH) && defined(__HIPCC__)
+// (bring-up aid, tools/r05/watch_path.py: a host-mapped buffer the kernels of a hanging launch write their progress into — device printf never
+// flushes from a kernel that does not end)
+__device__ volatile unsigned int* g_watch = nullptr;
+#endif
+#if defined(WTGPU_FSD_WATCH) && defined(__HIP_DEVICE_COMPILE__)
+#define WT_WATCH(slot, value) do { if (g_watch) g_watch[(blockIdx.x & 63u) * 16u + (slot)] = (unsigned int)(value); } while (0)
+#define WT_WATCH_ADD(slot) do { if (g_watch) atomicAdd((unsigned int*)g_watch + (blockIdx.x & 63u) * 16u + (slot), 1u); } while (0)
+#else
+#define WT_WATCH(slot, value) ((void)0)
+#define WT_WATCH_ADD(slot) ((void)0)
+#endif
 
 // The children of a node that passed their box test go on the stack far-first (descending tmin; equal tmin: in child order) — the result
 // of the reference's insertion sort of the freshly pushed entries (bvh8w.cpp:45-57).  Here every entry is written ONCE, at its final
@@ -295,7 +307,13 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
     ray_query_t q;
     rq_begin(sc, range, stack, q);
     while (rq_running(q)) {
-        while (q.s > 0 && q.lcnt == 0) rq_node_step(sc, ro, rd, stack, q, ctr);
+        while (q.s > 0 && q.lcnt == 0) {
+            WT_WATCH_ADD(8);
+            WT_WATCH(9, q.s);
+            rq_node_step(sc, ro, rd, stack, q, ctr);
+        }
+        WT_WATCH_ADD(10);
+        WT_WATCH(11, q.lcnt);
         if (q.lcnt != 0 && rq_leaf_step<shadow>(sc, ro, rd, stack, q, ctr)) break;
     }
     rec = q.rec;

@@ -53,7 +53,7 @@ constexpr uint32_t kCoopSurvCap = 128;   // candidates that passed the cheap fil
 constexpr uint32_t kCoopSpherePrefetch = WT_COOP_SPHERE_PREFETCH;   // batches of 64 bounding spheres fetched ahead of their tests (coop_cone_query, phase B1a)
 // The triangles' bounding spheres (centre, radius: tri_bounding_sphere, wt/cone.h) are uploaded right behind the scene's triangles, in the
 // same allocation (wtgpu_scene_upload) — reached through tri_geo, so that the kernels' launch block does not grow by another pointer.
-__device__ inline const float4* coop_tri_spheres(const scene_t& sc) { return reinterpret_cast<const float4*>(sc.tri_geo + sc.n_tris); }
+WT_D const float4* coop_tri_spheres(const scene_t& sc) { return reinterpret_cast<const float4*>(sc.tri_geo + sc.n_tris); }
 struct coop_shared_t {
     unsigned long long* dropped;   // the scene's counter of children a full stack could not hold
     stack_entry_t stack[kCoopStack];
@@ -77,18 +77,18 @@ struct coop_edges_t {
 constexpr uint32_t kCoopEdgeBits = 32768;
 
 template <class SH>
-__device__ inline void coop_set_dropped_counter(SH& sh, unsigned long long* slot) {
+WT_D void coop_set_dropped_counter(SH& sh, unsigned long long* slot) {
     if (threadIdx.x == 0) sh.dropped = slot;
     __syncthreads();
 }
-__device__ inline float wave_min(float v) {
+WT_D float wave_min(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
     return v;
 }
 
 // cone x AABB of child i (bvh8w.cpp:187-230); returns hit + tmin
-__device__ inline bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec3 rd, vec3 rinvd, bool sx, bool sy, bool sz, float ta, float ix,
+WT_D bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec3 rd, vec3 rinvd, bool sx, bool sy, bool sz, float ta, float ix,
                                        const range_t& range, float& tmin_out) {
     float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
     float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
@@ -127,7 +127,7 @@ __device__ inline bool cone_child_test(const bvh8_node_t& n, int i, vec3 ro, vec
 //     search slab shrinks after every batch with hits exactly like intersection_record_work_t::search_range;
 //     any_hit = true : the any-hit probe (bvh_cone_any_hit): returns at the first batch with a hit.
 template <bool any_hit>
-__device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
+WT_D bool coop_cone_query(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
                                        const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr, float min_progress = -WT_INF) {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
@@ -154,7 +154,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
     // axis]; a 64-wide batch is tested against the slab as it was before the batch.  Compacting whenever the slab shrinks keeps
     // the list = the triangles that meet the cone inside the current interaction region (the sequential list may keep a few more
     // that it saw before its slab shrank) and keeps the bounded list for the triangles that matter.
-    auto compact = [&](float zmax) {
+    auto compact = [&](float zmax) __attribute__((always_inline)) {
         if (rec.ntris == 0) return;
         __syncthreads();
         const bool mine = (uint32_t)lane < rec.ntris;
@@ -172,7 +172,7 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
         __syncthreads();
     };
     // phase B2: exact cone-triangle test of the buffered survivors, a full wave at a time; TRUE = any-hit probe satisfied
-    auto flush = [&]() -> bool {
+    auto flush = [&]() __attribute__((always_inline)) -> bool {
         __syncthreads();
         bool any = false;
         for (uint32_t b2 = 0; b2 < nsurv && !any; b2 += 64) {
@@ -401,12 +401,12 @@ __device__ inline bool coop_cone_query(const scene_t& sc, const cone_t& cone, co
     return rec.ntris > 0;
 }
 
-__device__ inline void coop_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
+WT_D void coop_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, coop_shared_t& sh,
                                  const uint_list_t& tris, cone_hit_t& rec, unsigned long long* prof = nullptr, float min_progress = -WT_INF) {
     coop_cone_query<false>(sc, cone, searchrange, z_scale, sh, tris, rec, prof, min_progress);
 }
 // Wave-cooperative any-hit probe (see bvh_cone_any_hit).
-__device__ inline bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh, unsigned long long* prof = nullptr,
+WT_D bool coop_cone_any(const scene_t& sc, const cone_t& cone, const range_t& range, coop_shared_t& sh, unsigned long long* prof = nullptr,
                                      uint32_t* hit_tuid = nullptr) {
     cone_hit_t rec;
     const uint_list_t none{nullptr, 0, 0};
@@ -427,7 +427,7 @@ struct gather_out_t {
     uint32_t n_tris;   // triangles of the region (met by the cone inside the slab)
 };
 template <class SH>
-__device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
+WT_D gather_out_t coop_gather(const scene_t& sc, const cone_t& tcone, const range_t& slab, const cone_t& envelope, const frame_t& beam_frame,
                                            const range_t& izr, vec2 sigma, bool want_front, SH& sh, bool do_flux, bool do_edges,
                                            unsigned long long* stats = nullptr, int32_t root = 1, coop_edges_t* eg = nullptr) {
     uint32_t* edges = eg ? eg->edge_ids : nullptr;   // eg: required when do_edges
@@ -453,7 +453,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
     uint32_t leaf_total = 0, nsurv = 0;
     if (lane == 0) sh.stack[0] = stack_entry_t{0.f, root};   // (root: a subtree of the region, k_flux_tasks)
     __syncthreads();
-    auto flush = [&]() {
+    auto flush = [&]() __attribute__((always_inline)) {
         __syncthreads();
         if (stats) stats[1] += nsurv;
         for (uint32_t b2 = 0; b2 < nsurv; b2 += 64) {
@@ -620,7 +620,7 @@ __device__ inline gather_out_t coop_gather(const scene_t& sc, const cone_t& tcon
 }
 
 // The bitmap edge set left in sh.edge_bits by coop_gather(do_edges): number of ids / the first `cap` ids in ascending order -> dst.
-__device__ inline uint32_t coop_edge_count(const scene_t& sc, coop_edges_t& sh) {
+WT_D uint32_t coop_edge_count(const scene_t& sc, coop_edges_t& sh) {
     __syncthreads();
     uint32_t c = 0;
     for (uint32_t j = threadIdx.x & 63; j < (sc.n_edges + 31u) / 32u; j += 64) c += (uint32_t)__popc(sh.edge_bits[j]);
@@ -628,7 +628,7 @@ __device__ inline uint32_t coop_edge_count(const scene_t& sc, coop_edges_t& sh) 
     for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
     return c;
 }
-__device__ inline void coop_edge_write(const scene_t& sc, coop_edges_t& sh, uint32_t* dst, uint32_t cap) {
+WT_D void coop_edge_write(const scene_t& sc, coop_edges_t& sh, uint32_t* dst, uint32_t cap) {
     const int lane = threadIdx.x & 63;
     uint32_t base = 0;
     const uint32_t nw = (sc.n_edges + 31u) / 32u;
@@ -656,7 +656,7 @@ __device__ inline void coop_edge_write(const scene_t& sc, coop_edges_t& sh, uint
 // (ptr: child reference as in bvh8_node_t::child).  One wavefront; emit is called by ONE lane per subtree, possibly several lanes at
 // once.  Used to spread the region sums of interaction regions with 10^3..10^5 triangles over many wavefronts (k_flux_split).
 template <class SH, class Emit>
-__device__ inline void coop_split(const scene_t& sc, const cone_t& tcone, const range_t& slab, SH& sh, uint32_t max_tris, Emit&& emit) {
+WT_D void coop_split(const scene_t& sc, const cone_t& tcone, const range_t& slab, SH& sh, uint32_t max_tris, Emit&& emit) {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
     if (sc.n_nodes == 0) return;
@@ -706,7 +706,7 @@ __device__ inline void coop_split(const scene_t& sc, const cone_t& tcone, const 
 // 8 stack entries x 8 children per step, buffered leaves tested 64 triangles per step.  A serial per-lane traversal is a
 // chain of ~30 dependent loads (~1 us each at this occupancy); this one is ~10 steps.  Equal-distance ties (a ray through
 // a shared edge) are resolved towards the lowest buffered triangle instead of the first visited one.
-__device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, coop_shared_t& sh, ray_hit_t& rec) {
+WT_D bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, coop_shared_t& sh, ray_hit_t& rec) {
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 3, sub = lane & 7;
     rec.dist = WT_INF;
@@ -840,7 +840,7 @@ __device__ inline bool coop_ray_query(const scene_t& sc, vec3 ro, vec3 rd, const
 // axis (`axis`, from the per-lane kernel's hand-over; computed here when nullptr) stands in for the per-segment ray queries, bounds
 // the cone queries and names the triangle under the axis of an overflowed region.  resume: continue with the cone query of segment
 // seg0 at distance dist0 (everything before is settled).
-__device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
+WT_D trav_result_t coop_traverse(const scene_t& sc, const cone_t& envelope, float lambda_m, float distance, bool force_ray_tracing,
                                               coop_shared_t& sh, const uint_list_t& tris, unsigned long long* prof = nullptr, bool resume = false,
                                               uint32_t seg0 = 0, float dist0 = 0.f, uint32_t nray0 = 0, uint32_t ncone0 = 0, const ray_hit_t* axis = nullptr,
                                               bool primary_always = false, bool probe_resumed = true, uint32_t short_tuid = kInvalid,
@@ -878,7 +878,7 @@ __device__ inline trav_result_t coop_traverse(const scene_t& sc, const cone_t& e
         axis_hit = coop_ray_query(sc, ro, rd, range_t{0.f, distance}, sh, ah);
         WT_COOP_PROF(0, tq0)
     }
-    auto ballistic_hit = [&]() {
+    auto ballistic_hit = [&]() __attribute__((always_inline)) {
         r.empty = 0;
         r.dist = ah.dist;
         r.tuid = ah.tuid;

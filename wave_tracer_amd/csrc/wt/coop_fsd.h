@@ -18,18 +18,18 @@
 
 namespace wt {
 
-__device__ inline double wave_sum(double v) {
+WT_D double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-__device__ inline uint32_t wave_sum_u32(uint32_t v) {
+WT_D uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
     return v;
 }
 // inclusive prefix sum over the 64 lanes
-__device__ inline uint32_t wave_scan_u32(uint32_t v) {
+WT_D uint32_t wave_scan_u32(uint32_t v) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -41,7 +41,7 @@ __device__ inline uint32_t wave_scan_u32(uint32_t v) {
 
 // All 64 lanes of a 64-thread block call with identical arguments.  `slot`: the aperture's pool slot (allocated by the caller).
 // Returns FALSE when the segment pool is exhausted (the aperture is left empty, like fsd_pool_alloc_edges' failure in bdpt_walk_step).
-__device__ inline bool coop_build_aperture(const scene_t& sc, const frame_t& frame, float k, const cone_t& beam, const uint32_t* eids, uint32_t n_ids,
+WT_D bool coop_build_aperture(const scene_t& sc, const frame_t& frame, float k, const cone_t& beam, const uint32_t* eids, uint32_t n_ids,
                                            vec2 sigma, const fsd_pool_t& pool, uint32_t slot, fsd_aperture_t& ap) {
     const int lane = threadIdx.x & 63;
     fsd_build_state_t st = fsd_build_begin(frame, k, 1.f, sigma, ap);

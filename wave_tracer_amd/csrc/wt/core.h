@@ -21,7 +21,7 @@
 #include <hip/hip_runtime.h>
 // always_inline: a real call on AMDGPU passes the big by-reference PODs (walk_t, vertex_t, ...) through scratch memory
 #define WT_HD __host__ __device__ inline __attribute__((always_inline))
-#define WT_D __device__ inline
+#define WT_D __device__ inline __attribute__((always_inline))   // (coop_gather, called from four kernels, was left as a CALL by one build of round 5: k_flux_tasks at 262 VGPRs, one wavefront per SIMD)
 #else
 #define WT_HD inline
 #endif

@@ -8,14 +8,55 @@
 // "accuracy usually within 1-3% rel. err." (gaussian2d.hpp).  On a GPU neither is acceptable, so the same
 // quantity is evaluated *exactly up to quadrature error* through the polar form
 //      I = (1/2pi) * Sum_edges  Int_{phi_p}^{phi_q} ( 1 - exp(-h^2 / (2 cos^2 phi)) ) dphi ,
-// (h = distance of the edge's line from the origin, phi measured from the line's normal) with an 8-point
-// Gauss-Legendre rule on up to two sub-intervals per edge.  This is deterministic, branch-light and agrees with
-// the closed forms for half-planes/wedges to ~1e-6 (tests/test_kat.py::test_gauss_triangle).
+// (h = distance of the edge's line from the origin, phi measured from the line's normal) with 8-point Gauss-Legendre rules: one in phi
+// on |phi| <= pi/4, and — round 5 — log-graded pieces in u = ln(h tan phi) beyond, where the integrand has a boundary layer of width ~h
+// (gauss_edge_side).  Deterministic; agrees with a double-precision quadrature of the same integral to 4e-6 over random triangles of every
+// scale, edges through the beam axis included (tests/test_kat.py::test_gaussian_triangle_integral; round 4's rule: 1.2e-3 on such edges).
 #pragma once
 #include "core.h"
 
 namespace wt {
 
+// The two integrands of an edge term: in the polar angle phi (KIND 0, par = h^2 / 2) and in u = ln(h tan phi) (KIND 1, par = h)
+template <int KIND>
+WT_HD float gauss_edge_integrand(float par, float x) {
+    if (KIND == 0) {
+        const float c = cosf(x);
+        return 1.f - expf(-par / (c * c));
+    }
+    const float s = expf(x);
+    return (1.f - expf(-0.5f * (par * par + s * s))) * (par * s / (par * par + s * s));
+}
+// 8-point Gauss-Legendre rule on [a, b]
+template <int KIND>
+WT_HD float gauss_gl8(float a, float b, float par) {
+    const float c = 0.5f * (a + b), r = 0.5f * (b - a);
+    const float s = 0.3626837833783620f * (gauss_edge_integrand<KIND>(par, c + r * 0.1834346424956498f) + gauss_edge_integrand<KIND>(par, c - r * 0.1834346424956498f)) +
+                    0.3137066458778873f * (gauss_edge_integrand<KIND>(par, c + r * 0.5255324099163290f) + gauss_edge_integrand<KIND>(par, c - r * 0.5255324099163290f)) +
+                    0.2223810344533745f * (gauss_edge_integrand<KIND>(par, c + r * 0.7966664774136267f) + gauss_edge_integrand<KIND>(par, c - r * 0.7966664774136267f)) +
+                    0.1012285362903763f * (gauss_edge_integrand<KIND>(par, c + r * 0.9602898564975363f) + gauss_edge_integrand<KIND>(par, c - r * 0.9602898564975363f));
+    return s * r;
+}
+// Int ( 1 - exp(-h^2 / (2 cos^2 phi)) ) dphi over the part of an edge beyond phi = pi/4, in the variable u = ln s, s = h tan phi — which is simply
+// the coordinate ALONG the edge's line measured from the foot of the perpendicular (no tangent to evaluate): [s_lo, s_hi], h <= s_lo < s_hi,
+// phi_hi = atan(s_hi / h).  Towards pi/2 the integrand climbs from 1 - exp(-h^2) to 1 inside a layer of width ~h, which no fixed rule in phi
+// resolves for an edge whose line passes close to the beam axis (h << 1: round 4's two 8-point halves were off by up to 1.2e-3 there); in u the
+// integrand  (1 - exp(-(h^2 + s^2) / 2)) h s / (h^2 + s^2)  is smooth, and pieces of 1.25 in u get it to float rounding.  Beyond s = 8 the
+// exponential is gone: closed form.
+WT_HD float gauss_edge_side(float h, float s_lo, float s_hi, float phi_hi) {
+    float tail = 0.f;
+    if (s_hi > 8.f) {
+        tail = phi_hi - atan2f(fmaxf_(s_lo, 8.f), h);
+        s_hi = 8.f;
+    }
+    if (s_hi <= s_lo) return tail;
+    const float u1 = logf(s_lo), u2 = logf(s_hi);
+    const int n = (int)fmaxf_(1.f, ceilf((u2 - u1) / 1.25f));
+    const float du = (u2 - u1) / (float)n;
+    float sum = 0.f;
+    for (int i = 0; i < n; ++i) sum += gauss_gl8<1>(u1 + du * (float)i, i + 1 == n ? u2 : u1 + du * (float)(i + 1), h);
+    return sum + tail;
+}
 WT_HD float gauss_edge_term(vec2 p, vec2 q) {
     const vec2 d = q - p;
     const float len = length(d);
@@ -28,28 +69,22 @@ WT_HD float gauss_edge_term(vec2 p, vec2 q) {
         h = -h;
         nn = -n;
     }
-    // angles of p and q measured from the normal direction nn, in the basis (nn, tt) with tt = rot90(nn)
+    // angles of p and q measured from the normal direction nn, in the basis (nn, tt) with tt = rot90(nn); y = h tan phi: the coordinate along the line
     const vec2 tt{-nn.y, nn.x};
-    const float phip = atan2f(dot(p, tt), dot(p, nn));
-    const float phiq = atan2f(dot(q, tt), dot(q, nn));
+    const float yp = dot(p, tt), yq = dot(q, tt);
+    const float phip = atan2f(yp, dot(p, nn));
+    const float phiq = atan2f(yq, dot(q, nn));
     if (h == 0.f) return 0.f;   // the line passes through the origin: rho = 0 => integrand 0
-    // 8-point Gauss-Legendre on [phip,phiq], split in two halves for accuracy on long edges
-    const float xs[4] = {0.1834346424956498f, 0.5255324099163290f, 0.7966664774136267f, 0.9602898564975363f};
-    const float ws[4] = {0.3626837833783620f, 0.3137066458778873f, 0.2223810344533745f, 0.1012285362903763f};
-    const float h2 = 0.5f * h * h;
+    // [phip, phiq] in three parts: |phi| <= pi/4, i.e. |y| <= h (the integrand is smooth in phi: one 8-point rule), and the two sides beyond
+    const float kQuarterPi = 0.78539816339744831f;
+    const bool fwd = phiq >= phip;
+    const float lo = fwd ? phip : phiq, hi = fwd ? phiq : phip, ylo = fwd ? yp : yq, yhi = fwd ? yq : yp;
     float total = 0.f;
-    for (int half = 0; half < 2; ++half) {
-        const float a = half == 0 ? phip : 0.5f * (phip + phiq);
-        const float b = half == 0 ? 0.5f * (phip + phiq) : phiq;
-        const float c = 0.5f * (a + b), r = 0.5f * (b - a);
-        float s = 0.f;
-        for (int i = 0; i < 4; ++i) {
-            const float c1 = cosf(c + r * xs[i]), c2 = cosf(c - r * xs[i]);
-            s += ws[i] * ((1.f - expf(-h2 / (c1 * c1))) + (1.f - expf(-h2 / (c2 * c2))));
-        }
-        total += s * r;
-    }
-    return total * kInvTwoPi;
+    const float a = fmaxf_(lo, -kQuarterPi), b = fminf_(hi, kQuarterPi);
+    if (b > a) total += gauss_gl8<0>(a, b, 0.5f * h * h);
+    if (yhi > h) total += gauss_edge_side(h, fmaxf_(ylo, h), yhi, hi);
+    if (ylo < -h) total += gauss_edge_side(h, fmaxf_(-yhi, h), -ylo, -lo);
+    return (fwd ? total : -total) * kInvTwoPi;
 }
 
 // Integral of the standard normal over triangle (a,b,c) given in canonical coordinates; result in [0,1].

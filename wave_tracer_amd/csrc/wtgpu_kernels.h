@@ -172,11 +172,11 @@ struct launch_args_t {
 };
 
 // (block size as a constant: blockDim would pull 256 bytes of hidden kernel arguments into the kernel-argument segment)
-__device__ inline void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s, uint32_t block = kBlock) {
+WT_D void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s, uint32_t block = kBlock) {
     s = make_stack_ref(lds + threadIdx.x, block, kLdsStack + kSpillStack, kLdsStack, spill);
 }
 
-__device__ inline void flush_counters(unsigned long long* g, const bdpt_counters_t& c) {
+WT_D void flush_counters(unsigned long long* g, const bdpt_counters_t& c) {
     const unsigned long long* p = reinterpret_cast<const unsigned long long*>(&c);
 #pragma unroll
     for (size_t i = 0; i < kNumCounters; ++i) {
@@ -188,7 +188,7 @@ __device__ inline void flush_counters(unsigned long long* g, const bdpt_counters
 }
 
 // walk id -> (sample index, stream)
-__device__ inline void walk_ident(const launch_args_t& a, uint32_t w, uint32_t& i, uint32_t& stream) {
+WT_D void walk_ident(const launch_args_t& a, uint32_t w, uint32_t& i, uint32_t& stream) {
     if (w < a.st.cap) {
         i = w;
         stream = STREAM_SENSOR_WALK;
@@ -201,20 +201,36 @@ __device__ inline void walk_ident(const launch_args_t& a, uint32_t w, uint32_t& 
 // walks from its end backwards (count CTL_BACK*).  A traversal costs an emitter walk of the headline workload 5-10x what it costs a
 // sensor walk (wide beams from the spots against pixel-sized beams from the camera): wavefronts that hold one kind waste fewer lanes.
 // queue item -> walk id; the first round's queue is the identity over [0,nb) (sensor walks) and [cap,cap+nb) (emitter walks)
-__device__ inline uint32_t queue_count(const uint32_t* ctl, int in) { return ctl[CTL_COUNT0 + in] + ctl[CTL_BACK0 + in]; }
-__device__ inline uint32_t queue_walk(const launch_args_t& a, const uint32_t* ctl, int in, uint32_t qi, int first_round) {
+WT_D uint32_t queue_count(const uint32_t* ctl, int in) { return ctl[CTL_COUNT0 + in] + ctl[CTL_BACK0 + in]; }
+WT_D uint32_t queue_walk(const launch_args_t& a, const uint32_t* ctl, int in, uint32_t qi, int first_round) {
     if (first_round) return qi < a.nb ? qi : (uint32_t)a.st.cap + (qi - a.nb);
     const uint32_t front = ctl[CTL_COUNT0 + in];
     return qi < front ? a.st.queue[in][qi] : a.st.queue[in][2 * (size_t)a.st.cap - 1 - (qi - front)];
 }
-// one wavefront grabs the next 64 queue items
-__device__ inline uint32_t wave_grab(uint32_t* head) {
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0) base = atomicAdd(head, 64u);
-    return (uint32_t)__shfl((int)base, 0, 64);
+// The next `inc` items of a device queue for one WAVEFRONT: every lane gets the old head.  Written WITHOUT a branch on the lane index.
+// The usual idiom — `if (threadIdx.x == 0) word = atomicAdd(head, 1); __syncthreads(); item = word; __syncthreads();`, or lane 0's value
+// through readfirstlane — is what rounds 2-5 had at the top of every persistent loop, and in round 5 it stopped k_path_fsd in one of two build
+// layouts.  What the compiler did, read off the ISA: the loop body ENDS with `if (threadIdx.x == 0) result[w] = f;` and BEGINS
+// with `if (threadIdx.x == 0) …atomicAdd…`; the two branches on the same condition were threaded across the back edge (lane 0: store, then
+// atomic; the others: neither), the join — the read of the shared word / the readfirstlane — became the header of a loop with TWO back edges,
+// these were split into nested loops, and the structuriser ran the inner one (lanes 1-63, which skip the atomic) to completion while lane 0
+// waited outside: 63 lanes re-read the same item (the stale shared word, or lane 1's zero) for ever.  The barriers of a one-wavefront block
+// compile to nothing, so nothing stood in the way.  Here there is no branch to thread — all lanes issue the atomic, lane 0 adds `inc` and
+// the others 0 (the compiler's atomic optimiser folds them into one memory operation per wavefront) — and a convergent marker in front.
+WT_D uint32_t wave_grab0(uint32_t* head, uint32_t inc) {
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t old = atomicAdd(head, (threadIdx.x & 63u) == 0u ? inc : 0u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);   // lane 0's: the head before this wavefront's items
+}
+WT_D uint32_t wave_grab(uint32_t* head) { return wave_grab0(head, 64u); }   // 64 items, one per lane (any block size: per wavefront)
+// One value from lane 0 of a one-wavefront block to all of its lanes, for values that only lane 0 may compute (an allocation).  Call sites keep
+// a convergent operation (a barrier, a shuffle) between this and any earlier `if (threadIdx.x == 0)`, see above.
+WT_D uint32_t wave_bcast0(uint32_t v) {
+    __builtin_amdgcn_wave_barrier();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 // wave-aggregated append of `w` (for lanes with `pred`) to a device queue
-__device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, uint32_t w) {
+WT_D void wave_append(uint32_t* queue, uint32_t* count, bool pred, uint32_t w) {
     const unsigned long long m = __ballot(pred);
     if (!m) return;
     const int lane = threadIdx.x & 63;
@@ -226,7 +242,7 @@ __device__ inline void wave_append(uint32_t* queue, uint32_t* count, bool pred, 
 }
 
 // ... of walk `w` (for lanes with `pred`) to round queue `out`: sensor walks (and plt_path's) at the front, emitter walks at the back
-__device__ inline void queue_append(const launch_args_t& a, uint32_t* ctl, int out, bool pred, uint32_t w) {
+WT_D void queue_append(const launch_args_t& a, uint32_t* ctl, int out, bool pred, uint32_t w) {
     const bool back = pred && w >= a.st.cap && a.split_queues;
     wave_append(a.st.queue[out], ctl + CTL_COUNT0 + out, pred && !back, w);
     const unsigned long long m = __ballot(back);
@@ -252,7 +268,7 @@ template <int W>
 constexpr int io_pitch() { return (W & 1) ? W : W + 1; }
 // `idx`: the lane's record, `valid`: the lane takes part; lds: this wavefront's buffer (>= kIoRows * io_pitch<W>() words)
 template <int W, class T>
-__device__ inline void wave_load_records(const uint32_t* base, size_t stride, uint32_t idx, bool valid, uint32_t* lds, T& out) {
+WT_D void wave_load_records(const uint32_t* base, size_t stride, uint32_t idx, bool valid, uint32_t* lds, T& out) {
     static_assert(sizeof(T) == 4 * W, "record size");
     constexpr int P = io_pitch<W>();
     const int lane = threadIdx.x & 63;
@@ -279,7 +295,7 @@ __device__ inline void wave_load_records(const uint32_t* base, size_t stride, ui
 }
 // ... `off`: word offset of the lane's record behind base + idx * stride (a vertex of the walk's vertex array)
 template <int W, class T>
-__device__ inline void wave_store_records(uint32_t* base, size_t stride, uint32_t idx, uint32_t off, bool valid, uint32_t* lds, const T& in) {
+WT_D void wave_store_records(uint32_t* base, size_t stride, uint32_t idx, uint32_t off, bool valid, uint32_t* lds, const T& in) {
     static_assert(sizeof(T) == 4 * W, "record size");
     constexpr int P = io_pitch<W>();
     const int lane = threadIdx.x & 63;
