@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(64, 3) k_flux_split(launch_args_t a) {
     // split — bidir_room: 400,000 items a round, a few thousand to split; one item per grab was 11.5 ms of a 125-ms batch there), the
     // wavefront then cuts the regions of the flagged ones, one after the other
     for (;;) {
-        const uint32_t base = wave_grab0(ctl + CTL_FSPLIT_HEAD, 64u);
+        const uint32_t base = wave_grab(ctl + CTL_FSPLIT_HEAD);
         if (base >= n) break;
         uint32_t w_mine = 0;
         bool need = false;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_FLUX) k_flux_tasks(launch_args_t 
     const uint32_t n = min(ctl[CTL_FTASK_COUNT], a.st.ftask_cap);
     const size_t W2 = 2 * (size_t)a.st.cap;
     for (;;) {
-        const uint32_t item = wave_grab0(ctl + CTL_FTASK_HEAD, 1u);
+        const uint32_t item = wave_grab_item(ctl + CTL_FTASK_HEAD);
         if (item >= n) break;
         const uint2 task = a.st.ftasks[item];
         const uint32_t w = task.x;
@@ -121,7 +121,7 @@ WT_D void interact_c_body(const launch_args_t& a, int in) {
             __syncthreads();
             item = s_item;
         } else
-            item = wave_grab0(ctl + CTL_INTC_HEAD, 1u);
+            item = wave_grab_item(ctl + CTL_INTC_HEAD);
         if (item >= n) break;
         const uint32_t w = queue_in[item];
         uint32_t i, stream;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_
     memset(&ctr, 0, sizeof(ctr));
     const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
     for (;;) {
-        const uint32_t item = wave_grab0(ctl + CTL_FSDQ_HEAD, 1u);
+        const uint32_t item = wave_grab_item(ctl + CTL_FSDQ_HEAD);
         if (item >= n) break;
         const uint32_t w = P.fsdq[qin][item];
         const uint32_t empty = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)];
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(64, 2) k_path_edges(launch_args_t a, const pat
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_GATHER_COUNT];
     for (;;) {
-        const uint32_t item = wave_grab0(ctl + CTL_GATHER_HEAD, 1u);
+        const uint32_t item = wave_grab_item(ctl + CTL_GATHER_HEAD);
         if (item >= n) break;
         const uint32_t w = a.st.gather_queue[item];
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, const path_
     memset(&ctr, 0, sizeof(ctr));
     const utd_edge_rec_t* cur_pool = P.utd[round & 1u];
     for (;;) {
-        const uint32_t item = wave_grab0(ctl + CTL_NEEQ_HEAD, 1u);
+        const uint32_t item = wave_grab_item(ctl + CTL_NEEQ_HEAD);
         if (item >= n) break;
         const uint32_t w = P.neeq[item];
         const path_nee_rec_t r = P.nee_recs[w];   // uniform address

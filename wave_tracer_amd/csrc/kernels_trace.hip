@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(64, WTGPU_LB_HEAVY) k_trace_heavy(launch_args_
     const size_t W2 = 2 * (size_t)a.st.cap;
     const bool rt = a.sc.sensor.ray_trace_only || a.sc.opts.force_ray_tracing;
     for (;;) {
-        const uint32_t item = wave_grab0(head, 1u);
+        const uint32_t item = wave_grab_item(head);
         if (item >= n) break;
         const uint32_t w = hq[item];
         const walk_trace_in_t wk = walk_load_trace_in(a.st.walks, a.st.walk_words, w);   // uniform address: broadcast

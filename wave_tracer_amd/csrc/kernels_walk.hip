@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(64, 3) k_edges(launch_args_t a) {
     const size_t W2 = 2 * (size_t)a.st.cap;
     const fsd_pool_t pool{a.st.fsd_hdr, a.st.fsd_edges, ctl + CTL_FSD_COUNTER, a.st.fsd_cap, ctl + CTL_FSD_ECOUNTER, a.st.fsd_ecap};
     for (;;) {
-        const uint32_t item = wave_grab0(ctl + CTL_GATHER_HEAD, 1u);
+        const uint32_t item = wave_grab_item(ctl + CTL_GATHER_HEAD);
         if (item >= n) break;
         const uint32_t w = a.st.gather_queue[item];
         walk_t wk;

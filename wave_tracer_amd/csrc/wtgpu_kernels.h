@@ -207,22 +207,30 @@ WT_D uint32_t queue_walk(const launch_args_t& a, const uint32_t* ctl, int in, ui
     const uint32_t front = ctl[CTL_COUNT0 + in];
     return qi < front ? a.st.queue[in][qi] : a.st.queue[in][2 * (size_t)a.st.cap - 1 - (qi - front)];
 }
-// The next `inc` items of a device queue for one WAVEFRONT: every lane gets the old head.  Written WITHOUT a branch on the lane index.
-// The usual idiom — `if (threadIdx.x == 0) word = atomicAdd(head, 1); __syncthreads(); item = word; __syncthreads();`, or lane 0's value
-// through readfirstlane — is what rounds 2-5 had at the top of every persistent loop, and in round 5 it stopped k_path_fsd in one of two build
-// layouts.  What the compiler did, read off the ISA: the loop body ENDS with `if (threadIdx.x == 0) result[w] = f;` and BEGINS
-// with `if (threadIdx.x == 0) …atomicAdd…`; the two branches on the same condition were threaded across the back edge (lane 0: store, then
-// atomic; the others: neither), the join — the read of the shared word / the readfirstlane — became the header of a loop with TWO back edges,
-// these were split into nested loops, and the structuriser ran the inner one (lanes 1-63, which skip the atomic) to completion while lane 0
-// waited outside: 63 lanes re-read the same item (the stale shared word, or lane 1's zero) for ever.  The barriers of a one-wavefront block
-// compile to nothing, so nothing stood in the way.  Here there is no branch to thread — all lanes issue the atomic, lane 0 adds `inc` and
-// the others 0 (the compiler's atomic optimiser folds them into one memory operation per wavefront) — and a convergent marker in front.
+// The next `inc` entries of a device queue for one WAVEFRONT: lane 0 moves the head, every lane gets the old value.
+// Until round 5 every persistent loop began with `if (threadIdx.x == 0) word = atomicAdd(head, 1); __syncthreads(); item = word; __syncthreads();`
+// (one-wavefront blocks) or the same through a shuffle, and in round 5 that stopped k_path_fsd in one of two build layouts.  What
+// the compiler did, read off the ISA: the loop body ENDS with `if (threadIdx.x == 0) result[w] = f;` and BEGINS with `if (threadIdx.x == 0)
+// …atomicAdd…`; the two branches on the same condition were threaded across the back edge (lane 0: store, then atomic; the others: neither), the
+// join — the read of the shared word / the readfirstlane — became the header of a loop with TWO back edges, these were split into nested loops,
+// and the structuriser ran the inner one (lanes 1-63, which skip the atomic) to completion while lane 0 waited outside: 63 lanes re-read the
+// same item (the stale shared word, or lane 1's zero) for ever.  The barriers of a one-wavefront block compile to nothing, so nothing stood in
+// the way.  Two things stand in the way here: a convergent marker IN FRONT of the branch (a block that holds one is not duplicated, and
+// threading an edge through the loop header means duplicating it), and a lane index the optimiser does not connect with threadIdx.x.
+// (Measured alternatives, run r5n / r5o: every lane issues the atomic, lane 0 adding `inc` and the others 0 — correct, and 1 % of a pass slower:
+// the compiler's scan over lane-dependent addends costs a wavefront-per-item kernel ~1 us per item; every lane adding 1 — free, but correct
+// only where the compiler folds the 64 atomics into one, which it does for pointers it knows to be global and not for the chunk words of the
+// staged connections: five parity tests failed.)
+WT_D bool wave_first_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u; }
 WT_D uint32_t wave_grab0(uint32_t* head, uint32_t inc) {
     __builtin_amdgcn_wave_barrier();
-    const uint32_t old = atomicAdd(head, (threadIdx.x & 63u) == 0u ? inc : 0u);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);   // lane 0's: the head before this wavefront's items
+    uint32_t old = 0;
+    if (wave_first_lane()) old = atomicAdd(head, inc);
+    __builtin_amdgcn_wave_barrier();
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
 }
-WT_D uint32_t wave_grab(uint32_t* head) { return wave_grab0(head, 64u); }   // 64 items, one per lane (any block size: per wavefront)
+WT_D uint32_t wave_grab(uint32_t* head) { return wave_grab0(head, 64u); }        // 64 queue items, one per lane: the first lane's
+WT_D uint32_t wave_grab_item(uint32_t* head) { return wave_grab0(head, 1u); }    // one queue item for a one-wavefront block
 // One value from lane 0 of a one-wavefront block to all of its lanes, for values that only lane 0 may compute (an allocation).  Call sites keep
 // a convergent operation (a barrier, a shuffle) between this and any earlier `if (threadIdx.x == 0)`, see above.
 WT_D uint32_t wave_bcast0(uint32_t v) {
