@@ -345,3 +345,36 @@ def test_staged_connections_are_the_connections(built, name, kw, spp):
         assert np.array_equal(a, b)
     assert ref[0].sum() + ref[2].sum() > 0 and ref[3]["connections"] > 100
     assert ref[3] == dev[3]
+
+
+def test_dead_apertures_carry_nothing(built):
+    """The one deliberate deviation inside the Fraunhofer sampler (an aperture whose segment amplitudes cancel to rounding is
+    classified DEAD when it is built and fails its sample at once, where the reference's rejection loop spins through n x 1024 tries and then
+    fails as well — but for the odd try that rounding noise lets through) measured IN THE IMAGE, on the dense crop of the headline workload:
+    the same samples rendered with the shortcut and with the reference's full loop (oracle_set_fsd_dead_ratio(0)).  The two films differ by
+    less than 1e-5 of the mean pixel (measured 7e-7 at 64 spp; the Monte-Carlo floor of the same sample count is 2: six orders above), the
+    film sums by less than 1e-6, and the full loop has a fraction of a percent MORE diffracted interactions (the noise acceptances) — i.e. the
+    shortcut does fire in this scene.  (tools/fsd_dead_effect.py is the long form: 256 spp, a second seed for the floor.)"""
+    from wave_tracer_amd import Scene
+    lib = load_oracle()
+    lib.oracle_set_fsd_dead_ratio.argtypes = [C.c_float]
+    sc = Scene("cornell_box", res=32, mesh_detail=1, lut=(128, 128), crop_of=1440)
+    spp = 48
+    try:
+        lib.oracle_set_fsd_dead_ratio(1e-10)
+        v1, _, l1, c1 = oracle_render(sc, 0, spp, 31)
+        lib.oracle_set_fsd_dead_ratio(0.0)
+        v0, _, l0, c0 = oracle_render(sc, 0, spp, 31)
+    finally:
+        lib.oracle_set_fsd_dead_ratio(1e-10)
+    a, b = v1.sum(axis=2) + l1.sum(axis=2), v0.sum(axis=2) + l0.sum(axis=2)
+    assert a.mean() > 0 and c1["fsd_interactions"] > 1000
+    nrmse = math.sqrt(np.mean((a - b) ** 2)) / a.mean()
+    print(f"full loop vs shortcut, {spp} spp: image nRMSE {nrmse:.2e}, film sums {abs(a.sum() - b.sum()) / a.sum():.2e} apart, "
+          f"fsd interactions {c0['fsd_interactions']} vs {c1['fsd_interactions']}")
+    assert nrmse < 1e-5
+    assert abs(a.sum() - b.sum()) < 1e-6 * a.sum()
+    assert c1["fsd_interactions"] <= c0["fsd_interactions"] <= 1.02 * c1["fsd_interactions"]
+    assert c0["fsd_interactions"] > c1["fsd_interactions"]   # (the shortcut fired: some of the full loop's noise acceptances are gone)
+    for k in ("segments", "vertices", "connections"):         # the walks are otherwise the same to a fraction of a percent
+        assert abs(c0[k] - c1[k]) <= 0.005 * c1[k]
