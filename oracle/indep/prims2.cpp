@@ -3,8 +3,8 @@
 // oracle/indep/indep.cpp restates the COMPOSITION of both integrators a second time, but the primitives it calls are the shared ones of
 // wave_tracer_amd/csrc/wt/*.h (wrapped in prims.cpp).  This file holds independent derivations, in double precision and without a line of a
 // wt/ header, of the primitives a mistaken restatement would most plausibly hide in; `make -C oracle` links them into libindep2.so, where
-// the wt/ headers — compiled with -DWT_SECOND_SOURCE — hand these calls over (the hooks are marked WT_SECOND_SOURCE in wt/cone.h, wt/bvh.h
-// and wt/polar.h).  tests/test_second_source.py::test_render_on_second_source_primitives renders whole images through libindep2.so and compares
+// the wt/ headers — compiled with -DWT_SECOND_SOURCE — hand these calls over (the hooks are marked WT_SECOND_SOURCE in wt/cone.h, wt/bvh.h,
+// wt/polar.h, wt/fsd.h and wt/utd.h).  tests/test_second_source.py::test_render_on_second_source_primitives renders whole images through libindep2.so and compares
 // them with liboracle.so's: an image that needs BOTH the second composition and these second primitives to agree with the checker.
 //
 //   ss_intersect_cone_tri   closest distance along the axis at which an elliptic cone meets a triangle inside a z-slab
@@ -21,6 +21,17 @@
 //   ss_mueller_from_jones   the Mueller matrix of a diagonal Jones matrix diag(fs, fp) as  A (J (x) J*) A^-1  (reference mueller.hpp:244-259
 //                           writes the eight non-zero entries down).  The handedness of the (U, V) block is a convention of the reference's
 //                           Stokes vectors, not physics: this construction takes the Kronecker product in the order that reproduces it.
+//   ss_fraunhofer_segment   the two amplitudes a Fraunhofer aperture segment contributes at a direction xi (reference: include/wt/interaction/
+//                           fsd/fsd.hpp:65-121 — closed forms alpha_1, alpha_2 in zeta = (xi . e, xi x e)).  Here: Stokes' theorem turns the
+//                           Fourier integral of the aperture into a line integral over its boundary; a segment's share is
+//                           (xi x e) / |xi|^2  int c(t) exp(-i xi . x(t)) dt  with the field amplitude c linear along the segment — evaluated by
+//                           composite Gauss-Legendre quadrature in f64 and split into the same two real amplitudes (hooks in wt/fsd.h).
+//   ss_wedge_utd            soft / hard UTD coefficients of a wedge (reference: include/wt/interaction/fsd/utd.hpp:25-57 + fsd/common.hpp:42-88:
+//                           the transition function through erfc below |x| = 6 and a four-term asymptote above).  Here: Kouyoumjian & Pathak's
+//                           four cotangent terms in f64, N+- from their defining equations by search, and the transition function
+//                           F(x) = 2 i sqrt(x) e^{ix} int_{sqrt x}^inf e^{-i t^2} dt from a quadrature of that integral on the contour rotated by
+//                           -pi/4, where the integrand decays like a Gaussian and nothing cancels: no series, no asymptote, any x.  Prefactor and
+//                           sign are the reference's convention (its -D (D1 + D2 -+ (D3 + D4)) with D_i = -cot(.) F(.)), hook in wt/utd.h.
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -28,9 +39,15 @@
 #include <cstdlib>
 #include <vector>
 
+#include <atomic>
+#include <cstdint>
+
 namespace {
 
 typedef std::complex<double> cd;
+// how often each second source was asked (tests: a render that is said to run on them did)
+enum { SS_CONE_TRI, SS_FRESNEL_DIELECTRIC, SS_FRESNEL_CONDUCTOR, SS_MUELLER, SS_FRAUNHOFER, SS_UTD, SS_COUNT };
+std::atomic<uint64_t> g_calls[SS_COUNT];
 
 struct v3 {
     double x, y, z;
@@ -163,6 +180,47 @@ bool cone_tri_min_z(const v3 P[3], double ta, double x0, double e, double zmin, 
     return found;
 }
 
+// ---- Fraunhofer: one segment's share of the aperture's boundary integral ----------------------------------------------------------------------
+// 16-point Gauss-Legendre on [-1, 1]
+static const double kGL16x[8] = {0.0950125098376374402, 0.2816035507792589132, 0.4580167776572273863, 0.6178762444026437484,
+                                 0.7554044083550030339, 0.8656312023878317439, 0.9445750230732325761, 0.9894009349916499326};
+static const double kGL16w[8] = {0.1894506104550684963, 0.1826034150449235888, 0.1691565193950025382, 0.1495959888165767321,
+                                 0.1246289712555338720, 0.0951585116824927848, 0.0622535239386478929, 0.0271524594117540949};
+template <class F>
+static cd gl16(double a, double b, F f) {
+    const double c = 0.5 * (a + b), r = 0.5 * (b - a);
+    cd s = 0;
+    for (int i = 0; i < 8; ++i) s += kGL16w[i] * (f(c + r * kGL16x[i]) + f(c - r * kGL16x[i]));
+    return r * s;
+}
+// ---- UTD: wedge coefficients ------------------------------------------------------------------------------------------------------------------
+// F(x) = 2 i sqrt(x) e^{ix} int_{sqrt x}^inf e^{-i t^2} dt, x >= 0.  With t = s + u e^{-i pi/4} (s = sqrt x):  -i t^2 = -i s^2 - sqrt2 s u (1 + i) - u^2,
+// so  F(x) = 2 s e^{i pi/4} int_0^inf exp(-u^2 - sqrt2 s u) (cos(sqrt2 s u) - i sin(sqrt2 s u)) du:  F(0) = 0, F(inf) = 1, every x in between
+// from one smooth integral (support: u < 7 and sqrt2 s u < 45).
+static cd utd_transition(double x) {
+    if (!(x > 0.0)) return 0.0;
+    const double s = std::sqrt(x), a = std::sqrt(2.0) * s;
+    const double U = std::min(7.0, 45.0 / a);
+    const int panels = 24;
+    cd I = 0;
+    for (int p = 0; p < panels; ++p)
+        I += gl16(U * p / panels, U * (p + 1) / panels, [&](double u) { return std::exp(-u * u - a * u) * cd(std::cos(a * u), -std::sin(a * u)); });
+    return 2.0 * s * std::exp(cd(0, M_PI / 4)) * I;
+}
+// a+-(beta) = 2 cos^2((2 pi n N+- - beta) / 2), N+- the integer that most nearly satisfies 2 pi n N - beta = +-pi (searched, not rounded)
+static double utd_a_pm(double beta, double n, int sgn) {
+    int best = 0;
+    double err = 1e300;
+    for (int N = -4; N <= 4; ++N) {
+        const double d = std::fabs(2.0 * M_PI * n * N - beta - sgn * M_PI);
+        if (d < err - 1e-12) {   // (ties — beta = -+pi exactly... — keep the smaller |N| first met from below, as rounding half away from zero would not matter: a is the same)
+            err = d;
+            best = N;
+        }
+    }
+    const double c = std::cos(0.5 * (2.0 * M_PI * n * best - beta));
+    return 2.0 * c * c;
+}
 }   // namespace
 
 extern "C" {
@@ -171,6 +229,7 @@ extern "C" {
 // closest distance along the axis inside [zmin, zmax], or 0.
 int ss_intersect_cone_tri(const float o[3], const float d[3], const float x[3], float x0, float tan_alpha, float e, const float a[3], const float b[3], const float c[3],
                           float zmin, float zmax, float* dist) {
+    g_calls[SS_CONE_TRI].fetch_add(1, std::memory_order_relaxed);
     const v3 O{o[0], o[1], o[2]}, Z{d[0], d[1], d[2]}, X{x[0], x[1], x[2]};
     const v3 Y = cross(Z, X);
     const float* vs[3] = {a, b, c};
@@ -195,6 +254,7 @@ int ss_intersect_cone_tri(const float o[3], const float d[3], const float x[3], 
 // Dielectric interface, real relative index eta = n1 / n2 as seen from the incident side, |cos theta_i| = ci > 0, no total internal
 // reflection (the caller has handled it): amplitude coefficients from the angle forms.  out: rs, rp, ts, tp, Z = n2 cos tt / (n1 cos ti).
 void ss_fresnel_dielectric(double eta, double ci, double out[5]) {
+    g_calls[SS_FRESNEL_DIELECTRIC].fetch_add(1, std::memory_order_relaxed);
     const double ti = std::acos(std::min(1.0, ci));
     const double st = eta * std::sin(ti);
     const double tt = std::asin(std::min(1.0, st));
@@ -215,6 +275,7 @@ void ss_fresnel_dielectric(double eta, double ci, double out[5]) {
 }
 // Reflection off an absorbing medium: eta = n1 / n2 complex; m = 1 / eta the relative refractive index of the second medium.  out: rs, rp (re, im).
 void ss_fresnel_conductor(double eta_re, double eta_im, double ci, double out[4]) {
+    g_calls[SS_FRESNEL_CONDUCTOR].fetch_add(1, std::memory_order_relaxed);
     const cd m = 1.0 / cd(eta_re, eta_im);
     const double s2 = 1 - ci * ci;
     const cd root = std::sqrt(m * m - s2);   // m cos(theta_t), principal branch
@@ -229,6 +290,7 @@ void ss_fresnel_conductor(double eta_re, double eta_im, double ci, double out[4]
 // Ep Es*, Ep Ep*)^T, A = [[1,0,0,1],[1,0,0,-1],[0,1,1,0],[0,i,-i,0]] — with the conjugate on the FIRST factor, which is the handedness of the
 // reference's V component.
 void ss_mueller_from_jones(double fs_re, double fs_im, double fp_re, double fp_im, float M[16]) {
+    g_calls[SS_MUELLER].fetch_add(1, std::memory_order_relaxed);
     const cd J[2] = {cd(fs_re, fs_im), cd(fp_re, fp_im)};
     const cd I(0, 1);
     const cd A[4][4] = {{1, 0, 0, 1}, {1, 0, 0, -1}, {0, 1, 1, 0}, {0, I, -I, 0}};
@@ -243,6 +305,60 @@ void ss_mueller_from_jones(double fs_re, double fs_im, double fp_re, double fp_i
             for (int k = 0; k < 4; ++k) s += A[r][k] * K[k] * Ai[k][c];
             M[4 * r + c] = (float)s.real();
         }
+}
+
+// The segment runs from x0 = v - e/2 to v + e/2 with field amplitude ca at its start and cb at its end (the record holds ab = ca - cb and
+// iab = (ca + cb) / 2, its mid point v is applied by the caller as the phase exp(-i xi . v) and |e|^2 as a factor).  Its share of
+//   B(xi) = sum (xi x e) / |xi|^2  int_0^1 c(t) exp(-i xi . (x0 + t e)) dt
+// is  exp(-i xi . v) |e|^2 (xi x e) / (|xi|^2 |e|^2)  I,   I = int_{-1/2}^{1/2} (iab - s ab) exp(-i (xi . e) s) ds,
+// and the caller's complex amplitude (a1 + i a2) is i B / (2 pi) without the two factors in front:  a2 - i a1 = (xi x e) / (2 pi |xi|^2 |e|^2) I.
+void ss_fraunhofer_segment(const float e[2], float ab, float iab, const float xi[2], float out[2]) {
+    g_calls[SS_FRAUNHOFER].fetch_add(1, std::memory_order_relaxed);
+    const double ex = e[0], ey = e[1], X = xi[0], Y = xi[1];
+    const double xi2 = X * X + Y * Y, e2 = ex * ex + ey * ey;
+    out[0] = out[1] = 0.f;
+    if (xi2 == 0.0 || e2 == 0.0) return;
+    const double zx = X * ex + Y * ey, zy = X * ey - Y * ex;
+    const int panels = 1 + (int)std::ceil(std::fabs(zx) / 6.0);
+    cd I = 0;
+    for (int p = 0; p < panels; ++p) {
+        const double a = -0.5 + (double)p / panels, b = -0.5 + (double)(p + 1) / panels;
+        I += gl16(a, b, [&](double s) { return ((double)iab - s * (double)ab) * std::exp(cd(0, -zx * s)); });
+    }
+    const cd q = zy / (2.0 * M_PI * xi2 * e2) * I;
+    out[0] = (float)(-q.imag());
+    out[1] = (float)q.real();
+}
+
+void ss_utd_transition(double x, double out[2]) {   // (for the known-answer test of the contour quadrature itself: against scipy's Fresnel integrals)
+    const cd f = utd_transition(x);
+    out[0] = f.real();
+    out[1] = f.imag();
+}
+// out = (Re Ds, Im Ds, Re Dh, Im Dh), including the reference's prefactor e^{-i pi/4} / (2 n sqrt(2 pi k ro) sin beta0) (k ro: the spreading factor of
+// the reference's caller is folded in) and its overall sign.
+void ss_wedge_utd(double n, double k_Li, double k_ro, double sin_beta, double phii, double phio, double out[4]) {
+    g_calls[SS_UTD].fetch_add(1, std::memory_order_relaxed);
+    const double bm = phii - phio, bp = phii + phio;
+    const auto cot = [](double x) { return std::cos(x) / std::sin(x); };
+    const cd T1 = cot((M_PI + bm) / (2 * n)) * utd_transition(k_Li * utd_a_pm(bm, n, +1));
+    const cd T2 = cot((M_PI - bm) / (2 * n)) * utd_transition(k_Li * utd_a_pm(bm, n, -1));
+    const cd T3 = cot((M_PI + bp) / (2 * n)) * utd_transition(k_Li * utd_a_pm(bp, n, +1));
+    const cd T4 = cot((M_PI - bp) / (2 * n)) * utd_transition(k_Li * utd_a_pm(bp, n, -1));
+    const cd D = std::exp(cd(0, -M_PI / 4)) / (2.0 * n * std::sqrt(2.0 * M_PI * k_ro) * sin_beta);
+    const cd Ds = D * (T1 + T2 - (T3 + T4)), Dh = D * (T1 + T2 + (T3 + T4));
+    out[0] = Ds.real();
+    out[1] = Ds.imag();
+    out[2] = Dh.real();
+    out[3] = Dh.imag();
+}
+
+// calls since the last reset: cone x triangle, Fresnel (dielectric), Fresnel (conductor), Mueller, Fraunhofer segment, UTD wedge
+void ss_calls(uint64_t out[6], int reset) {
+    for (int i = 0; i < SS_COUNT; ++i) {
+        out[i] = g_calls[i].load();
+        if (reset) g_calls[i].store(0);
+    }
 }
 
 }   // extern "C"

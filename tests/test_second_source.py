@@ -244,8 +244,9 @@ def _indep2():
 def test_render_on_second_source_primitives(name, res, spp, kw):
     """A whole render in which NEITHER the composition NOR the riskiest primitives are the ones the GPU is checked against: oracle/indep/indep.cpp
     (the integrators restated a second time, f64) on oracle/indep/prims2.cpp (cone x triangle as a convex programme in f64, every box cull
-    replaced by none, Fresnel coefficients from the angle / permittivity forms, Mueller matrices by the Kronecker construction), against
-    liboracle.so.  The random numbers are the same, the arithmetic is not (f64 closest points, different formulas): a sample may take another
+    replaced by none, Fresnel coefficients from the angle / permittivity forms, Mueller matrices by the Kronecker construction, the Fraunhofer
+    segment amplitudes from a quadrature of the aperture's boundary integral, the UTD wedge coefficients with the transition function from a
+    quadrature of its Fresnel integral on a rotated contour), against liboracle.so.  The random numbers are the same, the arithmetic is not (f64 closest points, different formulas): a sample may take another
     discrete branch now and then; the images must agree like a GPU render agrees with the checker."""
     import ctypes as C
     from oracle_util import oracle_render
@@ -256,7 +257,18 @@ def test_render_on_second_source_primitives(name, res, spp, kw):
     v, w, l = np.zeros((H, W, Cn)), np.zeros((H, W)), np.zeros((H, W, Cn))
     ctr = np.zeros(8, np.uint64)
     entry = _indep2().indep_render if int(sc.info.integrator) == 0 else _indep2().indep_render_path
+    calls = np.zeros(6, np.uint64)
+    _indep2().ss_calls(calls.ctypes.data_as(C.c_void_p), 1)
     assert entry(sc.host_desc(), 0, spp, 77, v.ctypes.data, w.ctypes.data, l.ctypes.data, ctr.ctypes.data) == 0
+    _indep2().ss_calls(calls.ctypes.data_as(C.c_void_p), 1)
+    used = dict(zip(["cone_tri", "fresnel_dielectric", "fresnel_conductor", "mueller", "fraunhofer_segment", "utd_wedge"], [int(x) for x in calls]))
+    # the render did run on the second sources its scene is here for
+    need = {"furnace": ["cone_tri"], "furnace_spm": ["cone_tri", "fresnel_conductor", "mueller"], "lens_b": ["fresnel_dielectric", "mueller"],
+            "double_slits": ["cone_tri", "fraunhofer_segment"], "bidir_room": ["cone_tri", "mueller"], "etoile": ["cone_tri", "utd_wedge"]}[name]
+    if kw.get("fsd"):
+        need = need + ["fraunhofer_segment"]
+    for k in need:
+        assert used[k] > 0, (k, used)
     ic = dict(zip(["segments", "vertices", "connections", "surface", "fsd_interactions", "null_interactions", "light_splats", "shadow_rays"], [int(x) for x in ctr]))
     for k in ("segments", "connections") if int(sc.info.integrator) else ("segments", "vertices", "connections"):
         assert abs(ic[k] - oc[k]) <= 1e-2 * max(100, oc[k]) + 2, (k, ic[k], oc[k])
@@ -268,3 +280,111 @@ def test_render_on_second_source_primitives(name, res, spp, kw):
     same = (np.abs(a - b) <= 1e-3 * np.abs(b) + 1e-9 * b.max()).mean()
     print(f"{name}: image rel. L1 {rel:.2e}, {same:.3f} of the pixels agree to 1e-3; counters {ic['segments']}/{oc['segments']} segments, {ic['connections']}/{oc['connections']} connections")
     assert rel < 2e-2 and same > 0.9, (rel, same)
+
+
+def test_second_source_utd_transition_function_is_the_fresnel_integral():
+    """prims2.cpp's transition function — F(x) = 2 i sqrt(x) e^{ix} int_{sqrt x}^inf e^{-i t^2} dt evaluated on the contour rotated by -pi/4 —
+    against scipy's Fresnel integrals, x from 1e-8 to 1e3 (2e-13), and its limits; then what the render comparison rests on: the checker's
+    utd_F (wt/utd.h, restating utd.hpp:36-57: erfc series below |x| = 6, four-term asymptote above) against it — 1e-6 below 6 and the
+    asymptote's truncation error above (4e-3 at x = 6, 1e-4 at x = 12)."""
+    import ctypes as C
+    import math
+    from scipy import special
+    from oracle_util import load_oracle
+    l2, lib = _indep2(), load_oracle()
+    l2.ss_utd_transition.argtypes = [C.c_double, C.c_void_p]
+    lib.kat_utd_F.argtypes = [C.c_float, C.c_void_p]
+
+    def tail(a):
+        S, Cc = special.fresnel(a * math.sqrt(2 / math.pi))
+        return math.sqrt(math.pi / 2) * ((0.5 - Cc) - 1j * (0.5 - S))
+
+    def ss(x):
+        o = np.zeros(2)
+        l2.ss_utd_transition(x, o.ctypes.data_as(C.c_void_p))
+        return complex(o[0], o[1])
+
+    worst = 0.0
+    for x in 10 ** np.linspace(-8, 3, 300):
+        ref = 2j * math.sqrt(x) * np.exp(1j * x) * tail(math.sqrt(x))
+        worst = max(worst, abs(ss(x) - ref) / abs(ref))
+    assert worst < 1e-11, worst
+    assert ss(0.0) == 0 and abs(ss(1e6) - complex(1, 5e-7)) < 1e-11
+    lo = hi = 0.0
+    for x in 10 ** np.linspace(-4, 2.5, 300):
+        o = np.zeros(2, np.float32)
+        lib.kat_utd_F(C.c_float(x), o.ctypes.data_as(C.c_void_p))
+        err = abs(complex(o[0], o[1]) - ss(float(np.float32(x)))) / abs(ss(float(np.float32(x))))
+        if x < 6:
+            lo = max(lo, err)
+        else:
+            hi = max(hi, err)
+    print(f"contour quadrature vs scipy {worst:.1e}; the checker's utd_F vs it: {lo:.1e} below x = 6, {hi:.1e} above (the reference's four-term asymptote)")
+    assert lo < 2e-6 and hi < 5e-3
+
+
+def test_second_source_wedge_coefficients_against_the_checker():
+    """ss_wedge_utd (textbook Kouyoumjian-Pathak in f64, N+- by search, exact transition function) against wedge_UTD (wt/utd.h) over random wedges,
+    directions, wavenumbers and distances, both fed the azimuths the reference measures (atan2: (-pi, pi]): agreement to the asymptote's
+    truncation (2e-3 of the larger coefficient), i.e. prefactor, signs, the four cotangents and the a+- arguments are the same function."""
+    import ctypes as C
+    from oracle_util import load_oracle
+    l2, lib = _indep2(), load_oracle()
+    l2.ss_wedge_utd.argtypes = [C.c_double] * 6 + [C.c_void_p]
+    lib.kat_wedge_UTD.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(2)
+    nff, tff = np.array([0, 1, 0.]), np.array([1, 0, 0.])
+    e = np.cross(nff, tff)
+    worst = 0.0
+    for it in range(1500):
+        alpha = rng.uniform(0.05, np.pi * 0.95)
+        n = 2 - alpha / np.pi
+        phii, phio = rng.uniform(0.01, n * np.pi - 0.01, 2)
+        beta = rng.uniform(0.3, np.pi - 0.3)
+        wi = np.sin(beta) * (np.cos(phii) * tff + np.sin(phii) * nff) + np.cos(beta) * e
+        wo = np.sin(beta) * (np.cos(phio) * tff + np.sin(phio) * nff) - np.cos(beta) * e
+        k, ro = 10 ** rng.uniform(-3, 1), 10 ** rng.uniform(-2, 1.5)
+        wd = fa([0, 0, 0, 1.0, *nff, *tff, 0, 0, 0, alpha])
+        wif, wof = fa(wi), fa(wo)
+        out = np.zeros(4, np.float32)
+        lib.kat_wedge_UTD(p(wd), C.c_float(k), p(wif), p(wof), C.c_float(ro), p(out))
+        sb2 = 1 - float(wif.astype(np.float64) @ e) ** 2
+        pi_, po_ = np.arctan2(nff @ wif, tff @ wif), np.arctan2(nff @ wof, tff @ wof)
+        o2 = np.zeros(4)
+        l2.ss_wedge_utd(n, k * 1e3 * ro * sb2, k * 1e3 * ro, np.sqrt(sb2), float(pi_), float(po_), o2.ctypes.data_as(C.c_void_p))
+        if not np.any(out):      # (the reference's exclusion of grazing directions)
+            continue
+        worst = max(worst, np.abs(out - o2).max() / np.abs(o2).max())
+    print(f"wedge coefficients, checker vs second source: worst {worst:.1e} of the larger coefficient")
+    assert worst < 4e-3
+
+
+def test_second_source_fraunhofer_segment_against_the_closed_forms():
+    """ss_fraunhofer_segment (quadrature of the segment's boundary integral, f64) against a_b alpha_1 / iab_2 alpha_2 (wt/fsd.h, restating
+    fsd.hpp:65-121) over random segments and directions: 3e-4 of the larger amplitude — the closed form's own f32 cancellation in
+    cos(x/2) - sinc(x/2) at small xi . e is what is left (against f64 closed forms: 1e-6)."""
+    import ctypes as C
+    import math
+    from oracle_util import load_oracle
+    l2, lib = _indep2(), load_oracle()
+    lib.kat_fsd_alpha1.restype = lib.kat_fsd_alpha2.restype = C.c_float
+    lib.kat_fsd_alpha1.argtypes = lib.kat_fsd_alpha2.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(1)
+    worst32 = worst64 = 0.0
+    for it in range(1500):
+        e = fa(rng.normal(size=2) * 10 ** rng.uniform(-1, 0.5))
+        xi = fa(rng.normal(size=2) * 10 ** rng.uniform(-2, 1.5))
+        ab, iab = np.float32(rng.normal()), np.float32(rng.uniform(0.1, 2))
+        out = np.zeros(2, np.float32)
+        l2.ss_fraunhofer_segment(p(e), C.c_float(ab), C.c_float(iab), p(xi), p(out))
+        zx, zy = np.float32(xi @ e), np.float32(xi[0] * e[1] - xi[1] * e[0])
+        a1, a2 = ab * lib.kat_fsd_alpha1(zx, zy), iab * lib.kat_fsd_alpha2(zx, zy)
+        worst32 = max(worst32, max(abs(out[0] - a1), abs(out[1] - a2)) / max(abs(a1), abs(a2), 1e-12))
+        x, y = float(xi.astype(np.float64) @ e.astype(np.float64)), float(xi[0]) * float(e[1]) - float(xi[1]) * float(e[0])
+        sinc = math.sin(x / 2) / (x / 2)
+        d1 = float(ab) * y / (2 * math.pi * x * (x * x + y * y)) * (math.cos(x / 2) - sinc)
+        d2 = float(iab) * y / (2 * math.pi * (x * x + y * y)) * sinc
+        worst64 = max(worst64, max(abs(out[0] - d1), abs(out[1] - d2)) / max(abs(d1), abs(d2), 1e-12))
+    print(f"Fraunhofer segment amplitudes, quadrature vs closed forms: {worst32:.1e} (f32 closed forms), {worst64:.1e} (f64 closed forms)")
+    assert worst32 < 1e-3 and worst64 < 2e-6
+

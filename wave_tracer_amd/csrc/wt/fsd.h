@@ -63,6 +63,14 @@ struct fsd_edges_ref_t {
 
 WT_HD float fsd_alpha1(float x, float y) { return x == 0.f ? 0.f : kInvTwoPi * y / (x * (x * x + y * y)) * (cosf(x / 2.f) - sincf_(x / 2.f)); }
 WT_HD float fsd_alpha2(float x, float y) { return x == 0.f ? 0.f : kInvTwoPi * y / (x * x + y * y) * sincf_(x / 2.f); }
+#if defined(WT_SECOND_SOURCE) && !defined(__HIP_DEVICE_COMPILE__)
+// (oracle/indep/prims2.cpp, see the note at WT_SS_ACTIVE in wt/cone.h: the two amplitudes of a segment — a_b alpha_1 and iab_2 alpha_2 — from a
+// quadrature in f64 of the boundary line integral they are the closed form of)
+extern "C" void ss_fraunhofer_segment(const float e[2], float ab, float iab, const float xi[2], float out_a1_a2[2]);
+#define WT_SS_FSD 1
+#else
+#define WT_SS_FSD 0
+#endif
 WT_HD float fsd_chi_e(vec2 xi) {
     const float chi = 0.830092714835359f;
     const float t = 1.f + chi * dot(xi, xi);
@@ -76,16 +84,28 @@ WT_HD float fsd_chi_0(vec2 xi) {
 // zeta = xi * Xi, Xi = mat2(e, m), m = (e.y,-e.x)   (vec * mat: (dot(xi,e), dot(xi,m)))
 WT_HD vec2 fsd_zeta(const fsd_edge_t& e, vec2 xi) { return {dot(xi, e.e), xi.x * e.e.y - xi.y * e.e.x}; }
 WT_HD cplx fsd_Psi(const fsd_edge_t& e, vec2 xi) {
+#if WT_SS_FSD
+    float a12[2];
+    ss_fraunhofer_segment(&e.e.x, e.ab, e.iab, &xi.x, a12);
+    const float a1 = a12[0], a2 = a12[1];
+#else
     const vec2 z = fsd_zeta(e, xi);
     const float a1 = e.ab * fsd_alpha1(z.x, z.y);
     const float a2 = e.iab * fsd_alpha2(z.x, z.y);
+#endif
     const float ee2 = length2(e.e);
     return cpolar(ee2, -dot(e.v, xi)) * cplx{a1, a2};
 }
 WT_HD float fsd_Psi2(const fsd_edge_t& e, vec2 xi) {
+#if WT_SS_FSD
+    float a12[2];
+    ss_fraunhofer_segment(&e.e.x, e.ab, e.iab, &xi.x, a12);
+    const float a1 = a12[0], a2 = a12[1];
+#else
     const vec2 z = fsd_zeta(e, xi);
     const float a1 = e.ab * fsd_alpha1(z.x, z.y);
     const float a2 = e.iab * fsd_alpha2(z.x, z.y);
+#endif
     return sqr(length2(e.e)) * (a1 * a1 + a2 * a2);
 }
 WT_HD float fsd_ASF_unclamped(const fsd_aperture_t& ap, const fsd_edges_ref_t& ed, vec2 xi) {
@@ -326,9 +346,15 @@ WT_HD void fsd_density_and_ASF(const fsd_aperture_t& ap, const fsd_edges_ref_t& 
     float d = 0.f;
     for (uint32_t i = 0; i < ap.n_edges; ++i) {
         const fsd_edge_t e = ed.get(i);
+#if WT_SS_FSD
+        float a12[2];
+        ss_fraunhofer_segment(&e.e.x, e.ab, e.iab, &xi.x, a12);
+        const float a1 = a12[0], a2 = a12[1];
+#else
         const vec2 z = fsd_zeta(e, xi);
         const float a1 = e.ab * fsd_alpha1(z.x, z.y);
         const float a2 = e.iab * fsd_alpha2(z.x, z.y);
+#endif
         const float ee2 = length2(e.e);
         amp = amp + cpolar(ee2, -dot(e.v, xi)) * cplx{a1, a2};
         d += sqr(ee2) * (a1 * a1 + a2 * a2);

@@ -36,6 +36,14 @@ WT_HD float utd_a(float phi, float n) {
     return 2.f * sqr(cosf(kPi * n * N - phi / 2.f));
 }
 
+#if defined(WT_SECOND_SOURCE) && !defined(__HIP_DEVICE_COMPILE__)
+// (oracle/indep/prims2.cpp, see the note at WT_SS_ACTIVE in wt/cone.h: the wedge's soft / hard diffraction coefficients from the textbook form of
+// Kouyoumjian & Pathak in f64, the transition function from a quadrature of its defining Fresnel integral — no erfc series, no asymptote)
+extern "C" void ss_wedge_utd(double n, double k_Li, double k_ro, double sin_beta, double phii, double phio, double out_DsDh[4]);
+#define WT_SS_UTD 1
+#else
+#define WT_SS_UTD 0
+#endif
 // utd.hpp:36-57.  |x| < 6: (1+i) sqrt(pi/2) sqrt|x| e^{i|x|} erfc(e^{i pi/4} sqrt|x|); otherwise the 4-term asymptote.
 WT_HD cplx utd_F(float x) {
     const float absx = fabsf(x);
@@ -126,6 +134,15 @@ WT_HD utd_ret_t wedge_UTD(const utd_wedge_t& w, float k, vec3 wi, vec3 wo, float
     const float Li = ro * sin_beta2;
     const float kLi = k_times_len(k, Li);
 
+#if WT_SS_UTD
+    {
+        const float t1s = modf_floor(phii + phio, kPi2), t2s = modf_floor(phii - phio, kPi2);   // (the reference's exclusion of the grazing directions, as below)
+        if (fabsf(t1s) < 1e-5f || fabsf(t2s) < 1e-5f) return utd_ret_t{cplx{0.f, 0.f}, cplx{0.f, 0.f}};
+        double o[4];
+        ss_wedge_utd((double)n, (double)kLi, (double)k_times_len(k, ro), (double)sin_beta, (double)phii, (double)phio, o);
+        return utd_ret_t{cplx{(float)o[0], (float)o[1]}, cplx{(float)o[2], (float)o[3]}};
+    }
+#endif
     const float a1 = utd_a<+1>(phii - phio, n);
     const float a2 = utd_a<-1>(phii - phio, n);
     const float a3 = utd_a<+1>(phii + phio, n);
