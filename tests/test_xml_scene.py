@@ -324,6 +324,36 @@ def test_obj_meshes(built, tmp_path):
         Scene.from_xml(OBJ, defines={"obj": str(d), "with_obj": "true"})
 
 
+def test_obj_material_groups(built, tmp_path):
+    """The `mtl` attribute of an obj shape keeps the faces of one material (src/scene/shape.cpp:358-391, src/mesh/obj_loader.cpp:66-73, through
+    tinyobjloader: `mtllib` files beside the OBJ file give the names, `usemtl` selects).  The reference's filter with its quirk: faces WITHOUT a
+    material (none selected, or a name no library defines) pass any non-empty `mtl`; an empty `mtl` drops them, and everything else with them."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    base = Scene.from_xml(OBJ, lut=(32, 32))
+    (tmp_path / "two.mtl").write_text("# three materials\nnewmtl red\nKd 1 0 0\n\n  newmtl shiny blue\nKd 0 0 1\nnewmtl green\n")
+    g = tmp_path / "g.obj"
+    g.write_text("mtllib two.mtl missing.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\nv 1 0 1\n"
+                 "f 1 2 3\n"                      # no material yet
+                 "usemtl red\nf 1 2 3 4\n"       # a quad: 2 triangles
+                 "usemtl shiny\nf 1 2 5\n"       # `usemtl` takes one word: "shiny" is not "shiny blue" -> no material
+                 "usemtl undefined\nf 2 3 6\nf 3 4 6\n"
+                 "usemtl red\nf 4 1 5\n"
+                 "usemtl green\nf 4 2 6\n")
+    n = lambda **d: Scene.from_xml(OBJ, defines=dict({"obj": str(g)}, **d), lut=(32, 32)).info.n_tris - base.info.n_tris
+    assert n(with_obj="true") == 8                                        # no `mtl`: every face
+    assert n(with_obj_mtl="true", obj_mtl="red") == 3 + 4                 # red's 3 triangles + the 4 of faces without a material (the quirk)
+    assert n(with_obj_mtl="true", obj_mtl="green") == 1 + 4
+    assert n(with_obj_mtl="true", obj_mtl="shiny blue") == 4              # defined, never selected: only the faces without a material
+    assert n(with_obj_mtl="true", obj_mtl="nowhere") == 4
+    with pytest.raises(WtgpuError, match="No faces found for supplied 'mtl'"):
+        n(with_obj_mtl="true", obj_mtl="")
+    x = tmp_path / "ply_with_mtl.xml"       # the same scene file with the attribute on its ply shape
+    x.write_text(open(OBJ).read().replace('<path value="$mesh"/>', '<path value="$mesh"/>\n\t\t<string name="mtl" value="red"/>'))
+    with pytest.raises(WtgpuError, match="ply shape do not support 'mtl'"):
+        Scene.from_xml(str(x), defines={"mesh": str(g), "with_mesh": "true"})
+
+
 _MINI = """<scene version="0.1.0">
   <integrator type="plt_bdpt"><integer name="max_depth" value="4"/><boolean name="FSD" value="false"/></integrator>
   <sensor type="perspective"><quantity name="fov" value="40°"/>
@@ -853,6 +883,130 @@ def test_png_bitmaps(built, tmp_path):
     (tmp_path / "il.png").write_bytes(bytes(data))
     with pytest.raises(WtgpuError, match="interlaced"):
         film(tmp_path / "il.png")
+
+
+def _write_exr(path, chans, compression=0, origin=(0, 0), decreasing_y=False, version=2):
+    """A scan-line OpenEXR file as OpenEXR itself lays it out.  chans: {name: (H x W array, "half" | "float" | "uint")}; compression 0 NONE, 1 RLE,
+    2 ZIPS, 3 ZIP (blocks of 16 lines); `origin`: dataWindow.min."""
+    import struct
+    import zlib
+    names = sorted(chans)
+    H, W = chans[names[0]][0].shape
+    tcode = {"uint": 0, "half": 1, "float": 2}
+    npt = {"uint": np.uint32, "half": np.float16, "float": np.float32}
+    attr = lambda n, t, d: n.encode() + b"\0" + t.encode() + b"\0" + struct.pack("<i", len(d)) + d
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", tcode[chans[n][1]], 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<iiii", origin[0], origin[1], origin[0] + W - 1, origin[1] + H - 1)
+    hdr = struct.pack("<ii", 20000630, version) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, W + origin[0] + 3, H + origin[1] + 2))
+    hdr += attr("lineOrder", "lineOrder", bytes([1 if decreasing_y else 0])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1)) + b"\0"
+    lpb = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, H, lpb):
+        raw = b"".join(np.ascontiguousarray(chans[n][0][y], dtype=npt[chans[n][1]]).tobytes() for y in range(y0, min(H, y0 + lpb)) for n in names)
+        data = raw
+        if compression:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]]).astype(np.int32)          # split even / odd bytes, then the delta predictor
+            t[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+            t = bytes(t.astype(np.uint8))
+            if compression == 1:    # RLE: runs of 3 .. 128 equal bytes as (n - 1, byte), everything else as literal stretches (-n, bytes)
+                out, i = bytearray(), 0
+                while i < len(t):
+                    j = i
+                    while j + 1 < len(t) and t[j + 1] == t[i] and j - i < 127:
+                        j += 1
+                    if j - i >= 2:
+                        out += bytes([j - i, t[i]])
+                        i = j + 1
+                    else:
+                        k = i
+                        while k < len(t) and k - i < 127 and not (k + 2 < len(t) and t[k] == t[k + 1] == t[k + 2]):
+                            k += 1
+                        out += bytes([(256 - (k - i)) & 255]) + t[i:k]
+                        i = k
+                t = bytes(out)
+            else:
+                t = zlib.compress(t)
+            data = t if len(t) < len(raw) else raw                              # a block that does not shrink is stored as is
+        blocks.append((origin[1] + y0, data))
+    order = list(reversed(blocks)) if decreasing_y else blocks                  # the file stores blocks in line order; the offset table is by y
+    pos, first = {}, len(hdr) + 8 * len(blocks)
+    body = b""
+    for y, d in order:
+        pos[y] = first + len(body)
+        body += struct.pack("<ii", y, len(d)) + d
+    open(path, "wb").write(hdr + struct.pack("<%dQ" % len(blocks), *[pos[y] for y, _ in blocks]) + body)
+
+
+def test_exr_bitmaps(built, tmp_path):
+    """OpenEXR textures (src/bitmap/load2d.cpp:38-75 through RgbaInputFile, texture2d_loader.cpp:195-200): the data window's pixels, linear,
+    THROUGH HALF PRECISION whatever the file stores, RGBA as soon as any of R / G / B / A is there (missing colour 0, missing alpha 1), else
+    luminance; compression NONE / RLE / ZIPS / ZIP, pixel types half / float / uint, a data window that does not start at the origin, decreasing
+    line order, an extra channel.  Checked against the same texels — rounded to half here — written as a float PFM: the rendered films are equal."""
+    from wave_tracer_amd import Scene
+    from wave_tracer_amd.api import WtgpuError
+    from wave_tracer_amd.imageio import write_exr, write_pfm
+    rng = np.random.default_rng(9)
+    half = lambda a: np.clip(a, -65504, 65504).astype(np.float16).astype(np.float32)
+    film = lambda bitmap: _render_dev(Scene.from_xml(TEX, defines={"variant": 2, "bitmap": str(bitmap)}))[0]
+    rgb = rng.uniform(0.05, 0.9, (19, 7, 3)).astype(np.float32)          # 19 lines: two ZIP blocks, the second short
+    rgb[3:9, :, :] = 0.25                                                  # runs for the RLE coder
+    write_pfm(str(tmp_path / "rgb.pfm"), half(rgb))
+    ref = film(tmp_path / "rgb.pfm")
+    assert ref.sum() > 0
+    ch = lambda t: {"R": (rgb[..., 0], t), "G": (rgb[..., 1], t), "B": (rgb[..., 2], t)}
+    for comp in (0, 1, 2, 3):
+        for t in ("float", "half"):
+            _write_exr(str(tmp_path / "a.exr"), ch(t), compression=comp)
+            assert np.abs(film(tmp_path / "a.exr") - ref).max() <= 1e-6 * ref.max(), (comp, t)
+    # data window away from the origin, decreasing line order, an alpha and a depth channel beside the colours, mixed pixel types
+    c = ch("half")
+    c["A"] = (rng.uniform(0, 1, rgb.shape[:2]).astype(np.float32), "float")
+    c["Z"] = (rng.uniform(1, 9, rgb.shape[:2]).astype(np.float32), "float")
+    c["G"] = (rgb[..., 1], "float")
+    _write_exr(str(tmp_path / "b.exr"), c, compression=3, origin=(-4, 11), decreasing_y=True)
+    assert np.abs(film(tmp_path / "b.exr") - ref).max() <= 1e-6 * ref.max()
+    # what this repository's own writer writes (uncompressed float RGB) reads back
+    write_exr(str(tmp_path / "w.exr"), rgb)
+    assert np.abs(film(tmp_path / "w.exr") - ref).max() <= 1e-6 * ref.max()
+    # luminance; uint texels (0 / 1: a mask); only R present: G and B read 0
+    y = rng.uniform(0.05, 0.9, (6, 5)).astype(np.float32)
+    _write_exr(str(tmp_path / "y.exr"), {"Y": (y, "float")}, compression=2)
+    write_pfm(str(tmp_path / "y.pfm"), half(y))
+    assert np.abs(film(tmp_path / "y.exr") - film(tmp_path / "y.pfm")).max() <= 1e-6 * ref.max()
+    u = rng.integers(0, 2, (6, 5))
+    _write_exr(str(tmp_path / "u.exr"), {"Y": (u, "uint")}, compression=1)
+    write_pfm(str(tmp_path / "u.pfm"), u.astype(np.float32))
+    assert np.abs(film(tmp_path / "u.exr") - film(tmp_path / "u.pfm")).max() <= 1e-6 * ref.max()
+    _write_exr(str(tmp_path / "r.exr"), {"R": (rgb[..., 0], "half")})
+    write_pfm(str(tmp_path / "r.pfm"), half(rgb * np.array([1, 0, 0], np.float32)))
+    assert np.abs(film(tmp_path / "r.exr") - film(tmp_path / "r.pfm")).max() <= 1e-6 * ref.max()
+    # half precision is what arrives: a float file whose texels differ below half's resolution renders like its rounded twin, not like itself
+    fine = (0.5 + 1e-4 * rng.uniform(0, 1, (6, 5))).astype(np.float32)
+    _write_exr(str(tmp_path / "f.exr"), {"Y": (fine, "float")})
+    write_pfm(str(tmp_path / "f16.pfm"), half(fine))
+    write_pfm(str(tmp_path / "f32.pfm"), fine)
+    a, b16, b32 = film(tmp_path / "f.exr"), film(tmp_path / "f16.pfm"), film(tmp_path / "f32.pfm")
+    assert np.abs(a - b16).max() <= 1e-7 * b16.max() < np.abs(a - b32).max()
+    # refusals
+    _write_exr(str(tmp_path / "piz.exr"), ch("half"), compression=0)
+    d = bytearray((tmp_path / "piz.exr").read_bytes())
+    i = d.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    d[i] = 4
+    (tmp_path / "piz.exr").write_bytes(bytes(d))
+    with pytest.raises(WtgpuError, match="compression PIZ is not read"):
+        film(tmp_path / "piz.exr")
+    _write_exr(str(tmp_path / "tiled.exr"), ch("half"), version=2 | 0x200)
+    with pytest.raises(WtgpuError, match="tiled files are not read"):
+        film(tmp_path / "tiled.exr")
+    (tmp_path / "bad.exr").write_bytes(b"not an exr file")
+    with pytest.raises(WtgpuError, match="not an OpenEXR file"):
+        film(tmp_path / "bad.exr")
+    (tmp_path / "cut.exr").write_bytes((tmp_path / "a.exr").read_bytes()[:-40])
+    with pytest.raises(WtgpuError, match="exr loader"):
+        film(tmp_path / "cut.exr")
 
 
 def test_emitter_spectra_keep_their_bins_and_iors_resolve_under_line_sensors(built, tmp_path):

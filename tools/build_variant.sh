@@ -21,5 +21,5 @@ for T in $ALL; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/wave_tracer_amd/_v/libwtgpu_$NAME.so $OBJS $C/_build/scene_builder.o $C/_build/scenes.o \
-  $C/_build/xml_scene.o $C/_build/ply_loader.o $C/_build/obj_loader.o $C/_build/spectrum_db.o $C/_build/png_loader.o -L/opt/rocm/lib -lrccl -lz -Wl,-rpath,/opt/rocm/lib
+  $C/_build/xml_scene.o $C/_build/ply_loader.o $C/_build/obj_loader.o $C/_build/spectrum_db.o $C/_build/png_loader.o $C/_build/exr_loader.o -L/opt/rocm/lib -lrccl -lz -Wl,-rpath,/opt/rocm/lib
 echo built $R/wave_tracer_amd/_v/libwtgpu_$NAME.so

@@ -1,10 +1,17 @@
 // wave_tracer_amd — Wavefront OBJ reader: what src/mesh/obj_loader.cpp:26-140 builds from a file through
 // tinyobjloader — every face corner becomes its own vertex (position, normal unless face normals are requested, uv), triangles (i,
 // i+1, i+2); faces with more than three corners are fan-triangulated like tinyobjloader's default `triangulate` does for convex
-// polygons; a file that gives normals or uvs for some corners and not for others is rejected like the reference does.  Materials
-// (`mtl`) are not read.  Tested with generated files (tests/test_xml_scene.py).
+// polygons; a file that gives normals or uvs for some corners and not for others is rejected like the reference does.
+// Material groups: the shape's `mtl` attribute keeps the faces of one material (obj_loader.cpp:66-73).  As tinyobjloader does, `mtllib` files are
+// looked up beside the OBJ file and read for their `newmtl` names (the rest of the line), `usemtl <word>` selects one of them for the faces that
+// follow, and a name no library defines — or no `usemtl` at all — is "no material" (-1).  The reference's filter, restated with its quirk: a face
+// is dropped when it has no material and `mtl` is EMPTY, or when it has a material of another name; faces without a material pass any non-empty
+// `mtl`.  Nothing else of a material library is read (the reference takes its BSDFs from the scene file).  Tested with generated files
+// (tests/test_xml_scene.py).
 #include <cmath>
 #include <fstream>
+#include <map>
+#include <cstdio>
 #include <sstream>
 #include <stdexcept>
 
@@ -12,13 +19,18 @@
 
 namespace wth {
 
-mesh_t load_obj(const std::string& path, bool face_normals, double scale) {
+mesh_t load_obj(const std::string& path, bool face_normals, double scale, const std::string* mtl) {
     std::ifstream f(path);
     if (!f) throw std::runtime_error("(obj loader) cannot open " + path);
     std::vector<dvec3> pos, nrm;
     std::vector<std::array<float, 2>> tex;
     mesh_t m;
     bool first = true, has_n = false, has_uv = false;
+    std::map<std::string, int> materials;   // name -> id, from the mtllib files met so far
+    int cur_mtl = -1;
+    std::vector<std::string> mtl_names;
+    const size_t slash = path.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? std::string(".") : path.substr(0, slash);
     std::string line;
     size_t lineno = 0;
     auto fail = [&](const std::string& w) { throw std::runtime_error("(obj loader) " + path + ":" + std::to_string(lineno) + ": " + w); };
@@ -41,7 +53,34 @@ mesh_t load_obj(const std::string& path, bool face_normals, double scale) {
             if (!(ls >> u)) fail("vt: coordinates expected");
             ls >> v;
             tex.push_back({u, v});
+        } else if (kw == "mtllib") {
+            std::string lib;
+            while (ls >> lib) {
+                std::ifstream mf(dir + "/" + lib);
+                if (!mf) {
+                    std::fprintf(stderr, "(obj loader) %s: material library %s not found\n", path.c_str(), lib.c_str());   // a warning in tinyobjloader too
+                    continue;
+                }
+                std::string ml;
+                while (std::getline(mf, ml)) {
+                    if (!ml.empty() && ml.back() == '\r') ml.pop_back();
+                    const size_t b = ml.find_first_not_of(" \t");
+                    if (b == std::string::npos || ml.compare(b, 7, "newmtl ") != 0) continue;
+                    const size_t nb = ml.find_first_not_of(" \t", b + 7);
+                    const std::string name = nb == std::string::npos ? std::string() : ml.substr(nb);
+                    if (!materials.count(name)) {
+                        materials[name] = (int)mtl_names.size();
+                        mtl_names.push_back(name);
+                    }
+                }
+            }
+        } else if (kw == "usemtl") {
+            std::string name;
+            ls >> name;
+            const auto it = materials.find(name);
+            cur_mtl = it == materials.end() ? -1 : it->second;
         } else if (kw == "f") {
+            if (mtl && ((cur_mtl == -1 && mtl->empty()) || (cur_mtl >= 0 && mtl_names[cur_mtl] != *mtl))) continue;   // obj_loader.cpp:68-73
             struct corner_t {
                 long v, t, n;
             };
@@ -90,8 +129,9 @@ mesh_t load_obj(const std::string& path, bool face_normals, double scale) {
                 m.tris.push_back({i, i + 1, i + 2});
             }
         }
-        // o, g, s, usemtl, mtllib, ...: ignored
+        // o, g, s, ...: ignored
     }
+    if (m.tris.empty() && mtl) throw std::runtime_error("(obj loader) " + path + ": No faces found for supplied 'mtl' (\"" + *mtl + "\")");   // (a warning and an empty mesh there)
     if (m.tris.empty()) throw std::runtime_error("(obj loader) " + path + ": no faces");
     return m;
 }

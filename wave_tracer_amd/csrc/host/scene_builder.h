@@ -61,12 +61,14 @@ mesh_t mesh_lens(dvec3 centre, double radius, double R1c, double R2c, double thi
 // PLY file (host/ply_loader.cpp; src/mesh/ply_loader.cpp:22-98): positions x `scale`, vertex normals unless face_normals, uvs, triangles
 mesh_t load_ply(const std::string& path, bool face_normals, double scale);
 // Wavefront OBJ (host/obj_loader.cpp; src/mesh/obj_loader.cpp:26-140): one vertex per face corner, polygons fan-triangulated
-mesh_t load_obj(const std::string& path, bool face_normals, double scale);
+mesh_t load_obj(const std::string& path, bool face_normals, double scale, const std::string* mtl = nullptr);   // mtl: keep the faces of this material
 // Portable float map (PF: RGB, Pf: grey; little or big endian), rows returned from the image's TOP (the file stores them bottom-up)
 std::vector<float> load_pfm(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels);
 // PNG, bit depth 8 or 16 (host/png_loader.cpp; src/bitmap/load2d.cpp:200-300): normalised, linearised floats, rows from the top.
 // encoding: 0 = the file's default (8 bit sRGB, 16 bit linear), 1 linear, 2 sRGB, 3 gamma
 std::vector<float> load_png(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels, int encoding, double gamma);
+// OpenEXR scan-line files (host/exr_loader.cpp; src/bitmap/load2d.cpp:38-75): the data window, linear, through half precision; 4 channels (RGBA) or 1 (Y)
+std::vector<float> load_exr(const std::string& path, uint32_t& width, uint32_t& height, uint32_t& channels);
 
 class scene_builder_t {
 public:

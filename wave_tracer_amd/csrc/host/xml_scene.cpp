@@ -974,8 +974,12 @@ struct loader_t {
                 px = load_png(file, W, H, C, enc, gamma);
             } else if (ext == ".pfm")
                 px = load_pfm(file, W, H, C);
-            else
-                throw std::runtime_error("(bitmap loader) " + file + ": PNG (8 / 16 bit) and PFM files only");
+            else if (ext == ".exr") {   // linear floats (src/bitmap/texture2d_loader.cpp:195-200, load2d.cpp:38-75)
+                if (const xnode_t* ce = n.named("colour_encoding"))
+                    if (ce->get("value") != "linear") throw std::runtime_error("(bitmap loader) " + file + ": an EXR image is read as linear; colour_encoding \"" + ce->get("value") + "\" is not applied to float texels here");
+                px = load_exr(file, W, H, C);
+            } else
+                throw std::runtime_error("(bitmap loader) " + file + ": PNG (8 / 16 bit), EXR and PFM files only");
             return b.add_texture_bitmap(W, H, C, px.data(), bilinear, uw, vw);
         }
         if (type == "function") {   // src/texture/function.cpp:38-124: nested NAMED textures are the variables, then u, v, k; the expression inline
@@ -1468,8 +1472,12 @@ struct loader_t {
                         }
                         throw std::runtime_error(full + " is a Git-LFS pointer file: the asset is absent from this checkout and has no bundled stand-in");
                     }
-                    else
-                        mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0));
+                    else {
+                        const xnode_t* mt = n.named("mtl");   // <string name="mtl" value=…/>: the faces of one OBJ material (src/scene/shape.cpp:358-391)
+                        if (mt && type == "ply") throw std::runtime_error("(shape loader) ply shape do not support 'mtl'");
+                        const std::string mtl_name = mt ? mt->get("value") : std::string();
+                        mesh = type == "ply" ? load_ply(full, face_normals, len("scale", 1.0)) : load_obj(full, face_normals, len("scale", 1.0), mt ? &mtl_name : nullptr);
+                    }
                 } else
                     throw std::runtime_error("shape type \"" + type + "\" is not supported by the minimal reader");
                 const int shape = b.add_shape(mesh, M, mat, face_normals);
