@@ -1,5 +1,5 @@
-// wave_tracer_amd — the whole device code and the host side as ONE translation unit (`make unity`): the layout of rounds 1-4.  The default build
-// compiles one translation unit per kernel group (wtgpu_kernels.h).
+// wave_tracer_amd — the whole device code and the host side as ONE translation unit: the DEFAULT build (`make` = `make unity`), the layout of
+// rounds 1-4 and the one the GPU suite ran on.  `make split` compiles one translation unit per kernel group instead (wtgpu_kernels.h, Makefile).
 #include "wtgpu.hip"
 #include "kernels_trace.hip"
 #include "kernels_walk.hip"
