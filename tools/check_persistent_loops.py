@@ -44,7 +44,8 @@ for i, l in enumerate(lines):
         continue
     pending = None
     if "; wave barrier" in l:
-        if grab is not None and grab.get("read_loop") is not None:       # the closing marker of wave_grab0
+        if grab is not None and grab.get("read_loop") is not None and i - grab["read_line"] <= 24:       # the closing marker of wave_grab0: right behind its readfirstlane
+            # (a barrier of a one-wavefront block leaves the same marker; an atomic and the optimiser's readfirstlane between two of THOSE are not a grab)
             grab["close_loop"] = loop
             sites.append(grab)
             if len({grab["marker_loop"], grab["atomic_loop"], grab["close_loop"]} | grab["read_loops"]) != 1:
@@ -60,6 +61,7 @@ for i, l in enumerate(lines):
             grab["atomic_loop"] = loop
         elif "v_readfirstlane_b32" in l and grab["atomic_loop"] is not None:      # the optimiser's own and the helper's: all of them
             grab["read_loop"] = loop
+            grab["read_line"] = i
             grab["read_loops"].add(loop)
 per = {}
 for s in sites:
