@@ -162,7 +162,13 @@ std::vector<float> load_exr(const std::string& path, uint32_t& width, uint32_t& 
     static const char* kCodec[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
     if (compression > 3)
         fail(std::string("compression ") + (compression < 10 ? kCodec[compression] : "(unknown)") + " is not read (NONE, RLE, ZIPS and ZIP are): re-save the image with ZIP compression");
-    const uint32_t W = (uint32_t)(dw[2] - dw[0] + 1), H = (uint32_t)(dw[3] - dw[1] + 1);
+    const int64_t W64 = (int64_t)dw[2] - dw[0] + 1, H64 = (int64_t)dw[3] - dw[1] + 1;
+    if (W64 > 65536 || H64 > 65536) fail("data window of " + std::to_string(W64) + " x " + std::to_string(H64) + " pixels: 65536 x 65536 at most");
+    const uint32_t W = (uint32_t)W64, H = (uint32_t)H64;
+    {   // a scan-line block costs the file at least its 8-byte table entry and its 8-byte header: a window the file cannot hold is a damaged header
+        const uint64_t blocks = ((uint64_t)H + (compression == 3 ? 15u : 0u)) / (compression == 3 ? 16u : 1u);
+        if (blocks * 16 > b.size()) fail("data window of " + std::to_string(H64) + " lines in a file of " + std::to_string(b.size()) + " bytes");
+    }
     int slot[5] = {-1, -1, -1, -1, -1};   // R G B A Y -> index into chans
     size_t row_bytes = 0;
     std::vector<size_t> chan_off(chans.size());
