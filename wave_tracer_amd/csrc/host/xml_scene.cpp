@@ -1432,6 +1432,12 @@ struct loader_t {
                 }
                 // defaults: src/scene/shape.cpp:196-380
                 const std::string type = n.get("type");
+                // (a bound, so that a typing error ends in a message and not in 10^12 triangles; the reference has none)
+                auto tess = [&](int def) {
+                    const double t = num("tessellation", def);
+                    if (!(t >= 3 && t <= 4096)) throw std::runtime_error("(shape loader) " + type + ": tessellation " + std::to_string(t) + " — 3 … 4096 expected");
+                    return (int)t;
+                };
                 xform_t M = to_world(n, {0, 1, 0});
                 bool face_normals = false;
                 if (const xnode_t* fn = n.named("face_normals")) face_normals = eval_number(fn->get("value")) != 0.0;
@@ -1444,14 +1450,14 @@ struct loader_t {
                 } else if (type == "cube")
                     mesh = mesh_cube(len("length", 2.0));
                 else if (type == "sphere")
-                    mesh = mesh_sphere(pt("center", false), len("radius", 1e-3), (int)num("tessellation", 32));
+                    mesh = mesh_sphere(pt("center", false), len("radius", 1e-3), tess(32));
                 else if (type == "cylinder")
-                    mesh = mesh_cylinder(pt("p0"), pt("p1"), len("radius", 1e-3), (int)num("tessellation", 32));
+                    mesh = mesh_cylinder(pt("p0"), pt("p1"), len("radius", 1e-3), tess(32));
                 else if (type == "prism") {
                     const xnode_t* a = n.named("angle");
                     mesh = mesh_prism(len("length", 1.0), len("height", 1.0), a ? parse_dim(a->get("value"), DIM_ANGLE, "angle") : M_PI / 2);
                 } else if (type == "lens")
-                    mesh = mesh_lens(pt("center", false), len("radius", 1e-3), num("R1", 0), num("R2", 0), len("thickness", 0.0), (int)num("tessellation", 50));
+                    mesh = mesh_lens(pt("center", false), len("radius", 1e-3), num("R1", 0), num("R2", 0), len("thickness", 0.0), tess(50));
                 else if (type == "ply" || type == "obj") {
                     const xnode_t* pth = n.child("path");
                     if (!pth) throw std::runtime_error(type + " shape: <path value=…/> expected");
