@@ -61,4 +61,9 @@ for cfg in "${CFGS[@]}"; do
   if echo "$OUT" | grep -q "^rc 0" && ! echo "$OUT" | grep -q "ERROR\|runtime error"; then printf "%-64s %s\n" "$cfg" "$(echo "$OUT" | tail -1)"; else BAD=$((BAD+1)); echo "$cfg: REPORT"; echo "$OUT"; fi
 done
 echo "${#CFGS[@]} renders under ASan + UBSan + float-cast-overflow: $BAD with a report"
+# The known-answer tests against a sanitized build of the checker library (round 5: 128 tests, no report):
+#   g++ -std=c++17 -O1 -g -fsanitize=address,undefined,float-cast-overflow -fno-sanitize=float-divide-by-zero -march=x86-64-v3 -ffp-contract=off -fno-strict-aliasing \
+#       -fPIC -shared -pthread -Wno-unknown-pragmas -DWT_ORACLE_UNBOUNDED -o /tmp/liboracle_san.so oracle/oracle.cpp oracle/kat.cpp
+#   LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 WT_ORACLE_LIB=/tmp/liboracle_san.so \
+#       python -m pytest tests/test_kat*.py tests/test_oracle.py tests/test_polarimetric.py tests/test_wrappers.py tests/test_textures.py tests/test_emitters.py -m "not gpu" -s 2>&1 | grep -c "runtime error"
 exit $BAD
