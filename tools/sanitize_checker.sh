@@ -3,7 +3,10 @@
 # AddressSanitizer + UndefinedBehaviorSanitizer (+ float-cast-overflow: a float -> int conversion out of range is undefined, and x86 and gfx950
 # resolve it differently), over whole renders of the bundled scenes: both integrators, Fraunhofer and UTD diffraction, the polarimetric film,
 # textures, wrappers, the split-step and staged-connection flavours.  An out-of-bounds read in a shared header would be one on the device as well.
-# usage: tools/sanitize_checker.sh [quick]        (round 5: 38 renders, no report — profiles/r05_sanitized_checker.log)
+# `msan`: the same renders under MemorySanitizer instead (ROCm's clang; only the checker and the wt/ headers are instrumented and heap memory counts as
+# initialised — libstdc++ is not instrumented — so what it finds are uninitialised STACK values: a local or a struct member read before it is written,
+# the kind of defect that makes two compilers of the same header disagree).
+# usage: tools/sanitize_checker.sh [quick] [msan]        (round 5: 38 renders each way, no report — profiles/r05_sanitized_checker.log)
 set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/wave_tracer_amd/csrc; D=$(mktemp -d /tmp/wtgpu_san_XXXX)
 cat > $D/main.cpp <<'CPP'
@@ -45,22 +48,31 @@ int main(int argc, char** argv) {   // name res spp [key=value ...]
     return rc;
 }
 CPP
-( cd $C && g++ -O1 -g -std=c++17 -fsanitize=address,undefined,float-cast-overflow -fno-sanitize=float-divide-by-zero -ffp-contract=off -fno-strict-aliasing -pthread \
-    -Wno-unknown-pragmas -DWT_ORACLE_UNBOUNDED -I. -o $D/render $D/main.cpp $R/oracle/oracle.cpp host/scene_builder.cpp host/scenes.cpp host/xml_scene.cpp host/ply_loader.cpp \
-    host/obj_loader.cpp host/spectrum_db.cpp host/png_loader.cpp host/exr_loader.cpp -lz )
+SRCS="$D/main.cpp $R/oracle/oracle.cpp host/scene_builder.cpp host/scenes.cpp host/xml_scene.cpp host/ply_loader.cpp host/obj_loader.cpp host/spectrum_db.cpp host/png_loader.cpp host/exr_loader.cpp"
+if [[ " $* " == *" msan "* ]]; then
+  WHAT="MemorySanitizer (stack values)"
+  printf 'src:*host/*\nsrc:*main.cpp\n' > $D/ignore.txt
+  ( cd $C && /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=memory -fsanitize-memory-track-origins=1 -fsanitize-ignorelist=$D/ignore.txt -fno-omit-frame-pointer \
+      -ffp-contract=off -fno-strict-aliasing -pthread -Wno-everything -DWT_ORACLE_UNBOUNDED -I. -o $D/render $SRCS -lz )
+  export MSAN_OPTIONS=poison_in_malloc=0:poison_in_free=0
+else
+  WHAT="ASan + UBSan + float-cast-overflow"
+  ( cd $C && g++ -O1 -g -std=c++17 -fsanitize=address,undefined,float-cast-overflow -fno-sanitize=float-divide-by-zero -ffp-contract=off -fno-strict-aliasing -pthread \
+      -Wno-unknown-pragmas -DWT_ORACLE_UNBOUNDED -I. -o $D/render $SRCS -lz )
+fi
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 ASAN_OPTIONS=detect_leaks=0
 CFGS=("bidir_room 24 2 polarimetric=1" "bidir_room 24 2" "cornell_box 32 4 mesh_detail=1" "cornell_box 32 8 mesh_detail=1 crop_of=1440 lut=64" "cornell_box_path 24 4"
  "double_slits 48 4" "double_slits_overview 32 2" "etoile 32 8" "etoile 24 4 mesh_detail=1" "etoile_bdpt 24 4" "etoile_open 24 4" "etoile_path_backward 24 4"
  "furnace 16 8 max_depth=32 rr=0" "furnace 16 4 fsd=1" "furnace 16 4 fsd=1 flavour=1" "furnace 16 4 fsd=1 flavour=2" "cornell_box 24 4 flavour=3" "furnace_path 16 8" "furnace_spm 16 8"
  "furnace_wall_mask 16 8" "furnace_wall_composite 16 4" "furnace_wall_step_gap 16 4" "lens_a 24 4" "lens_b 24 4" "lens_c 24 4" "sunlit 24 8" "sunlit_path 24 8"
  "white_furnace 16 8" "white_furnace_path 16 8" "tex_checker 24 4" "tex_bitmap 24 4" "tex_normal_tilt 24 4" "tex_mask 24 4" "tex_bilinear_ramp 24 4")
-[ "$1" = quick ] || CFGS+=("cornell_box 32 48 mesh_detail=1 crop_of=1440 lut=128" "bidir_room 48 8 polarimetric=1 mesh_detail=1" "etoile 48 16 mesh_detail=2" "double_slits 96 8 lut=128")
+[[ " $* " == *" quick "* ]] || CFGS+=("cornell_box 32 48 mesh_detail=1 crop_of=1440 lut=128" "bidir_room 48 8 polarimetric=1 mesh_detail=1" "etoile 48 16 mesh_detail=2" "double_slits 96 8 lut=128")
 BAD=0
 for cfg in "${CFGS[@]}"; do
   OUT=$($D/render $cfg 2>&1 | grep -v "^wtgpu:" | tail -12); RC=$?
-  if echo "$OUT" | grep -q "^rc 0" && ! echo "$OUT" | grep -q "ERROR\|runtime error"; then printf "%-64s %s\n" "$cfg" "$(echo "$OUT" | tail -1)"; else BAD=$((BAD+1)); echo "$cfg: REPORT"; echo "$OUT"; fi
+  if echo "$OUT" | grep -q "^rc 0" && ! echo "$OUT" | grep -q "ERROR\|runtime error\|WARNING: MemorySanitizer"; then printf "%-64s %s\n" "$cfg" "$(echo "$OUT" | tail -1)"; else BAD=$((BAD+1)); echo "$cfg: REPORT"; echo "$OUT"; fi
 done
-echo "${#CFGS[@]} renders under ASan + UBSan + float-cast-overflow: $BAD with a report"
+echo "${#CFGS[@]} renders under $WHAT: $BAD with a report"
 # The known-answer tests against a sanitized build of the checker library (round 5: 128 tests, no report):
 #   g++ -std=c++17 -O1 -g -fsanitize=address,undefined,float-cast-overflow -fno-sanitize=float-divide-by-zero -march=x86-64-v3 -ffp-contract=off -fno-strict-aliasing \
 #       -fPIC -shared -pthread -Wno-unknown-pragmas -DWT_ORACLE_UNBOUNDED -o /tmp/liboracle_san.so oracle/oracle.cpp oracle/kat.cpp
