@@ -433,6 +433,71 @@ int oracle_trace_rays(const void* scene_host, const float* rays, uint32_t n, flo
     }
     return 0;
 }
+// The same queries through the device's 128-BYTE NODES (wt/bvh.h: bvh8_qnode_t, child boxes on a 16-bit grid over the scene, rounded outwards), built here
+// from the scene's nodes exactly as wtgpu.hip builds them at upload: what a closest-hit ray query / a cone query finds must not depend on the node source.
+struct grid_scene_t {
+    std::vector<bvh8_qnode_t> nodes;
+    qgrid_t grid;
+    bool ok = false;
+};
+static grid_scene_t make_grid_nodes(const scene_t& sc) {
+    grid_scene_t g;
+    vec3 mn{WT_INF, WT_INF, WT_INF}, mx{-WT_INF, -WT_INF, -WT_INF};
+    for (uint32_t i = 0; i < sc.n_nodes; ++i)
+        for (int c = 0; c < 8; ++c)
+            if (sc.nodes[i].child[c] != 0) {
+                mn = vmin(mn, vec3{sc.nodes[i].minx[c], sc.nodes[i].miny[c], sc.nodes[i].minz[c]});
+                mx = vmax(mx, vec3{sc.nodes[i].maxx[c], sc.nodes[i].maxy[c], sc.nodes[i].maxz[c]});
+            }
+    g.grid = qgrid_make(mn, mx);
+    g.nodes.resize(sc.n_nodes);
+    g.ok = true;
+    for (uint32_t i = 0; i < sc.n_nodes; ++i) g.ok = qnode_make(sc.nodes[i], g.grid, g.nodes[i]) && g.ok;
+    return g;
+}
+int oracle_trace_rays_grid(const void* scene_host, const float* rays, uint32_t n, float* out_dist, uint32_t* out_tuid) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const grid_scene_t g = make_grid_nodes(sc);
+    if (!g.ok) return 1;
+    const grid_nodes_t ns{g.nodes.data(), g.grid};
+    stack_entry_t st[kOracleStack];
+    const stack_ref_t stack = make_flat_stack(st, kOracleStack);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* r = rays + 8 * i;
+        ray_hit_t h;
+        bvh_traverse_ray_ns<false>(ns, sc, vec3{r[0], r[1], r[2]}, vec3{r[3], r[4], r[5]}, range_t{r[6], r[7]}, stack, h);
+        out_dist[i] = h.dist;
+        out_tuid[i] = h.tuid;
+    }
+    return 0;
+}
+// cones: n x {ox,oy,oz, dx,dy,dz, tan_alpha, x0, ecc, lambda_m}: ONE cone query over [0, inf) (closest distance, number of listed triangles) through the
+// exact nodes (which = 0) or the grid nodes (1)
+int oracle_cone_queries(const void* scene_host, const float* cones, uint32_t n, int which, float* out_dist, uint32_t* out_ntris) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const grid_scene_t g = make_grid_nodes(sc);
+    if (!g.ok) return 1;
+    const grid_nodes_t gs{g.nodes.data(), g.grid};
+    const wide_nodes_t ws{sc.nodes};
+    stack_entry_t st[kOracleStack];
+    const stack_ref_t stack = make_flat_stack(st, kOracleStack);
+    std::vector<uint32_t> tl(kOracleConeTris);
+    std::vector<float> dl(kOracleConeTris);
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* c = cones + 10 * (size_t)i;
+        const vec3 d = normalize(vec3{c[3], c[4], c[5]});
+        const cone_t env = make_cone(vec3{c[0], c[1], c[2]}, d, build_orthogonal_frame(d).t, c[6], c[8], c[7]);
+        const uint_list_t tris{tl.data(), 1, kOracleConeTris, dl.data()};
+        cone_hit_t ch;
+        if (which)
+            bvh_traverse_cone_ns(gs, sc, env, range_t{0.f, WT_INF}, kMajorAxisToZScale, stack, tris, ch);
+        else
+            bvh_traverse_cone_ns(ws, sc, env, range_t{0.f, WT_INF}, kMajorAxisToZScale, stack, tris, ch);
+        out_dist[i] = ch.dist;
+        out_ntris[i] = ch.ntris;
+    }
+    return 0;
+}
 // cones: n x {ox,oy,oz, dx,dy,dz, tan_alpha, x0, ecc, lambda_m}; runs the full traverse() policy.
 // out: dist, ballistic flag, ntris, sorted tri ids (cap per query)
 int oracle_traverse_cones(const void* scene_host, const float* cones, uint32_t n, uint32_t cap, float* out_dist, uint32_t* out_flags, uint32_t* out_ntris,

@@ -167,3 +167,26 @@ def test_whole_region_queries_beyond_the_list_cap(built):
     assert (diff & (o["nedges"][:, 1] > 0)).sum() > 20
     df = np.abs(g["flux"][diff] - o["flux"][diff, 1])         # fp32 sums of up to 10^4 terms in another order, a boundary triangle here and there
     assert df.max() < 1e-3 and np.percentile(df, 95) < 2e-5, (df.max(), np.percentile(df, 95))
+
+
+@pytest.mark.parametrize("name,kw,spp", [("furnace", dict(res=48, fsd=1, lut=(64, 64)), 3), ("double_slits", dict(res=96, lut=(64, 64)), 2),
+                                         ("cornell_box", dict(res=96, mesh_detail=0, lut=(32, 32)), 2), ("bidir_room", dict(res=64, mesh_detail=0, lut=(32, 32)), 2),
+                                         ("etoile", dict(res=64, mesh_detail=0), 3)])
+@pytest.mark.parametrize("form", ["staged", "sm"])
+def test_trace_kernels_write_identical_records(built, monkeypatch, name, kw, spp, form):
+    """The two per-lane trace kernels — k_trace_refill (whole steps per lane) and k_trace_sm (one phase per step for all lanes in it, exact tests
+    deferred until many lanes wait for one) — run the same sequence of visits per walk: replayed on the SAME round queues (WTGPU_TRACE_AB: the
+    queue, the walk records and the scene as the pipeline left them), they must write the same traversal records, the same triangle lists and
+    hand the same walks to the wave-cooperative kernel, word for word."""
+    from wave_tracer_amd import Scene, render
+    monkeypatch.setenv("WTGPU_TRACE_AB", "12")
+    monkeypatch.setenv("WTGPU_TRACE_STAGED", "1" if form == "staged" else "0")
+    monkeypatch.setenv("WTGPU_TRACE_SM", "0" if form == "staged" else "1")
+    sc = Scene(name, **kw)
+    sc.upload(0)
+    render(sc, spp, seed=5)
+    st = sc.trace_ab_stats()
+    print(name, st)
+    sc.close()
+    assert st["rounds"] >= 2 and st["walks"] > 0
+    assert st["differing_words"] == 0, st

@@ -378,3 +378,56 @@ def test_dead_apertures_carry_nothing(built):
     assert c0["fsd_interactions"] > c1["fsd_interactions"]   # (the shortcut fired: some of the full loop's noise acceptances are gone)
     for k in ("segments", "vertices", "connections"):         # the walks are otherwise the same to a fraction of a percent
         assert abs(c0[k] - c1[k]) <= 0.005 * c1[k]
+
+
+def test_grid_nodes_answer_like_exact_nodes(built):
+    """The device's per-lane CONE queries read 128-byte nodes whose child boxes are 16-bit coordinates on one grid over the scene, rounded outwards
+    (wt/bvh.h: bvh8_qnode_t; built at upload from the scene's nodes).  A box test only decides what is looked at: closest distance and the number
+    of triangles inside the final slab must be those of the exact nodes, for beams of every width.  RAY queries keep the exact nodes, and this is
+    why: a ray IN the plane of an axis-aligned wall fails the slab test of the wall's flat exact box (0 x inf) and never sees the coplanar
+    triangles — the reference's behaviour, its boxes being exact floats too — while a box rounded outwards is entered and the tolerant
+    ray-triangle test reports the wall's rim (measured below on the city-block scene)."""
+    import ctypes as C
+    from wave_tracer_amd import Scene
+    lib = load_oracle()
+    for name, kw, lo, hi, sx in (("etoile", dict(res=64, mesh_detail=2), [-400, -300, 0.5], [400, 300, 50], 100.), ("cornell_box", dict(res=32, mesh_detail=0), [-.9, -.9, -.9], [.9, .9, .9], 1.)):
+        sc = Scene(name, **kw)
+        n = 20000
+        rng = np.random.default_rng(3)
+        d = rng.normal(size=(n, 3))
+        cones = np.zeros((n, 10), np.float32)
+        cones[:, :3], cones[:, 3:6] = rng.uniform(lo, hi, (n, 3)), d / np.linalg.norm(d, axis=1, keepdims=True)
+        cones[:, 6], cones[:, 7], cones[:, 8], cones[:, 9] = 10 ** rng.uniform(-4, -0.7, n), 10 ** rng.uniform(-4, -1, n) * sx, rng.uniform(0, 0.9, n), 0.03
+        res = []
+        for which in (0, 1):
+            dist, nt = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+            assert lib.oracle_cone_queries(C.c_void_p(sc.host_desc()), cones.ctypes.data_as(C.c_void_p), n, which, dist.ctypes.data_as(C.c_void_p), nt.ctypes.data_as(C.c_void_p)) == 0
+            res.append((dist, nt))
+        assert np.isfinite(res[0][0]).sum() > 20
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), name
+    # rays: generic directions agree up to ties between coplanar neighbours; rays in the plane of the walls do not
+    sc = Scene("etoile", res=64, mesh_detail=2)
+    rng = np.random.default_rng(5)
+    n = 40000
+    d = rng.normal(size=(n, 3))
+    d[:, 2] *= 0.2
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, :3], rays[:, 3:6], rays[:, 7] = rng.uniform([-400, -300, 1], [400, 300, 40], (n, 3)), d / np.linalg.norm(d, axis=1, keepdims=True), np.inf
+
+    def both(r):
+        a = oracle_trace(sc, r)[0]
+        b, tb = np.zeros(len(r), np.float32), np.zeros(len(r), np.uint32)
+        assert lib.oracle_trace_rays_grid(C.c_void_p(sc.host_desc()), r.ctypes.data_as(C.c_void_p), len(r), b.ctypes.data_as(C.c_void_p), tb.ctypes.data_as(C.c_void_p)) == 0
+        return a, b
+    a, b = both(rays)
+    hit = np.isfinite(a)
+    assert np.array_equal(hit, np.isfinite(b)) and np.allclose(a[hit], b[hit], rtol=1e-6)
+    p = (rays[hit, :3].astype(np.float64) + a[hit, None].astype(np.float64) * rays[hit, 3:6]).astype(np.float32)
+    r2 = np.zeros((len(p), 8), np.float32)
+    dd = rng.normal(size=(len(p), 3)).astype(np.float32)
+    dd[:, 0] = 0      # in the plane of the walls that face +-x
+    r2[:, :3], r2[:, 3:6], r2[:, 7] = p, dd / np.linalg.norm(dd, axis=1, keepdims=True), np.inf
+    a2, b2 = both(r2)
+    only_grid = (~np.isfinite(a2) & np.isfinite(b2)).sum()
+    print("in-plane rays: hits with exact boxes", np.isfinite(a2).sum(), "only with grid boxes", only_grid, "only with exact boxes", (np.isfinite(a2) & ~np.isfinite(b2)).sum())
+    assert (np.isfinite(a2) & ~np.isfinite(b2)).sum() == 0 and only_grid > 0   # (the reason rays keep the exact nodes)

@@ -92,6 +92,7 @@ def load_library():
     lib.wtgpu_scene_create_from_xml.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), u32, C.POINTER(SceneParams), C.POINTER(vp)]
     lib.wtgpu_scene_compare.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
     lib.wtgpu_scene_compare_part.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.wtgpu_trace_ab_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.wtgpu_render_progressive.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64, u32, PROGRESS_CB, vp, C.POINTER(u64)]
     lib.wtgpu_cancel.argtypes = [vp]
     lib.wtgpu_pause.argtypes = [vp]
@@ -344,6 +345,12 @@ class Scene:
 
     def reset_counters(self):
         _check(load_library().wtgpu_reset_counters(self._h))
+
+    def trace_ab_stats(self):
+        """Test hook (WTGPU_TRACE_AB=n at upload: the first n rounds of every batch replay their trace queue through both per-lane trace kernels)."""
+        a, b, d, w, r = C.c_double(0), C.c_double(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(load_library().wtgpu_trace_ab_stats(self._h, C.byref(a), C.byref(b), C.byref(d), C.byref(w), C.byref(r)))
+        return {"ms_refill": a.value, "ms_sm": b.value, "differing_words": int(d.value), "walks": int(w.value), "rounds": int(r.value)}
 
     def timings(self):
         t = (C.c_float * 12)()

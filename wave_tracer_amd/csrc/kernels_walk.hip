@@ -11,6 +11,7 @@ __global__ void __launch_bounds__(kBlock) k_generate(launch_args_t a) {
         ctl[CTL_COUNT1] = 0;
         ctl[CTL_BACK0] = ctl[CTL_BACK1] = 0;
         ctl[CTL_HEAD_TRACE] = ctl[CTL_HEAD_INTERACT] = ctl[CTL_HEAVY_COUNT] = ctl[CTL_HEAVY_HEAD] = ctl[CTL_FSD_COUNTER] = ctl[CTL_ROUNDS] = 0;
+        ctl[CTL_TPOL_COUNT0] = ctl[CTL_TPOL_COUNT1] = ctl[CTL_TPOL_HEAD] = ctl[CTL_TCONE_COUNT0] = ctl[CTL_TCONE_COUNT1] = ctl[CTL_TCONE_HEAD] = 0;   // the staged trace kernels' queues
         ctl[CTL_INTB_COUNT] = ctl[CTL_INTB_HEAD] = ctl[CTL_GATHER_COUNT] = ctl[CTL_GATHER_HEAD] = ctl[CTL_INTC_COUNT] = ctl[CTL_INTC_HEAD] = 0;
         ctl[CTL_FTASK_COUNT] = ctl[CTL_FTASK_HEAD] = ctl[CTL_FSPLIT_HEAD] = ctl[CTL_EPOOL_COUNT] = ctl[CTL_FSD_ECOUNTER] = 0;
         ctl[CTL_INTD_COUNT] = ctl[CTL_INTD_HEAD] = 0;

@@ -106,7 +106,132 @@ struct uint_list_t {   // bounded output list with the same (pointer,stride) add
     WT_HD uint32_t& operator[](uint32_t i) const { return p[(size_t)i * stride]; }
 };
 
-constexpr int kRayLeafShortcut = 16;   // src/ads/bvh8w.cpp:29
+// ---- node sources of the traversals -----------------------------------------------------------------------------------------------
+// The traversal steps below read a node through a NODE SOURCE: the reference-layout node (bvh8_node_t, 256 B, exact float boxes: the CPU checker,
+// the wave-cooperative kernels, which read a node with 64 lanes) or — the device's per-lane traversals — a 128-BYTE node whose child boxes are
+// 16-bit coordinates on ONE grid over the scene's bounding box, rounded OUTWARDS (bvh8_qnode_t, built at upload from the same tree: same indices, same
+// child references).  Why: a lane fetches a whole node by itself, so 256 B are two cache lines per lane and 64 registers in flight; the 5.7 MB of
+// nodes of the headline scene do not fit the 4 MB L2 of an XCD, 2.8 MB do.  What it may change: nothing but the amount of work.  A decoded box
+// CONTAINS the exact one, so a query visits a superset of the children the exact boxes admit; every triangle test is the exact one; a closest
+// hit, an any-hit answer and the set of triangles inside a query's final slab do not depend on which boxes were opened.  One grid
+// for the whole scene instead of one per node (the round-1 experiment: 8 bits relative to the node, many false positives): a cell is 1 / 65533 of
+// the scene's extent — 0.1 mm in a 6 m room whose leaf boxes measure millimetres — and a node needs no origin / scale of its own: 96 B of boxes +
+// 32 B of child references, no change of the tree's layout.  (The coordinate is decoded with ONE fused multiply-add, which rounds once, on the
+// host exactly as on the device: the builder checks every decoded bound against the float it must enclose and steps outwards until it does.)
+struct alignas(16) bvh8_qchild_t {   // 16 B: one 128-bit load per child
+    uint16_t lo[3];   // box minimum (x, y, z), rounded down by at least one cell
+    uint16_t hi[3];   // maximum, rounded up by at least one cell; an empty child: lo = 65535, hi = 0
+    int32_t child;    // as bvh8_node_t::child
+};
+struct alignas(16) bvh8_qnode_t {
+    bvh8_qchild_t c[8];
+};
+static_assert(sizeof(bvh8_qnode_t) == 128, "one cache line per node");
+struct qgrid_t {
+    vec3 origin, cell;   // coordinate = fma(q, cell, origin)
+};
+WT_HD float qgrid_decode(float origin, float cell, uint32_t q) { return fmaf((float)q, cell, origin); }
+// the grid over [mn, mx] (two cells of slack on either side; a flat axis gets cells of its own)
+WT_HD qgrid_t qgrid_make(vec3 mn, vec3 mx) {
+    qgrid_t g;
+    const float ex = mx.x - mn.x, ey = mx.y - mn.y, ez = mx.z - mn.z;
+    const float fx = fmaxf_(fabsf(mn.x), fabsf(mx.x)) * 1e-6f + 1e-30f, fy = fmaxf_(fabsf(mn.y), fabsf(mx.y)) * 1e-6f + 1e-30f,
+                fz = fmaxf_(fabsf(mn.z), fabsf(mx.z)) * 1e-6f + 1e-30f;
+    g.cell = vec3{fmaxf_(ex / 65530.f, fx), fmaxf_(ey / 65530.f, fy), fmaxf_(ez / 65530.f, fz)};
+    g.origin = vec3{mn.x - 2.f * g.cell.x, mn.y - 2.f * g.cell.y, mn.z - 2.f * g.cell.z};
+    return g;
+}
+// host: the 16-bit coordinate ONE CELL BEYOND the largest whose decoded value is <= v (down) / the smallest whose decoded value is >= v (up): the
+// decoded box encloses the exact one with at least a cell to spare on every side, which is what lets a traversal fold the decoding into its own
+// arithmetic (t = fma(q, cell / d, (origin - o) / d) rounds differently from ((fma(q, cell, origin) - o) / d) by a few ulp, a cell is 2^-16 of the scene)
+inline uint16_t qgrid_encode(float origin, float cell, float v, bool up) {
+    const double t = ((double)v - (double)origin) / (double)cell;
+    long q = (long)(up ? std::ceil(t) : std::floor(t));
+    if (q < 0) q = 0;
+    if (q > 65535) q = 65535;
+    if (up) {
+        while (q < 65535 && qgrid_decode(origin, cell, (uint32_t)q) < v) ++q;
+        while (q > 0 && qgrid_decode(origin, cell, (uint32_t)(q - 1)) >= v) --q;
+        if (q < 65535) ++q;
+    } else {
+        while (q > 0 && qgrid_decode(origin, cell, (uint32_t)q) > v) --q;
+        while (q < 65535 && qgrid_decode(origin, cell, (uint32_t)(q + 1)) <= v) ++q;
+        if (q > 0) --q;
+    }
+    return (uint16_t)q;
+}
+// FALSE: the grid cannot enclose this node (a box outside the grid's range) — such a scene is refused at upload
+inline bool qnode_make(const bvh8_node_t& n, const qgrid_t& g, bvh8_qnode_t& out) {
+    bool ok = true;
+    const float* mn[3] = {n.minx, n.miny, n.minz};
+    const float* mx[3] = {n.maxx, n.maxy, n.maxz};
+    const float o[3] = {g.origin.x, g.origin.y, g.origin.z}, c[3] = {g.cell.x, g.cell.y, g.cell.z};
+    for (int i = 0; i < 8; ++i) {
+        out.c[i].child = n.child[i];
+        for (int ax = 0; ax < 3; ++ax) {
+            if (n.child[i] == 0) {
+                out.c[i].lo[ax] = 65535;
+                out.c[i].hi[ax] = 0;
+                continue;
+            }
+            out.c[i].lo[ax] = qgrid_encode(o[ax], c[ax], mn[ax][i], false);
+            out.c[i].hi[ax] = qgrid_encode(o[ax], c[ax], mx[ax][i], true);
+            // (strictly beyond: a cell to spare)
+            ok = ok && qgrid_decode(o[ax], c[ax], out.c[i].lo[ax]) < mn[ax][i] && qgrid_decode(o[ax], c[ax], out.c[i].hi[ax]) > mx[ax][i];
+        }
+    }
+    return ok;
+}
+struct node_box_t {
+    float x0, y0, z0, x1, y1, z1;
+};
+struct wide_nodes_t {   // the reference-layout nodes
+    typedef bvh8_node_t node_t;
+    const bvh8_node_t* p;
+    WT_HD node_t fetch(int32_t idx) const { return p[idx]; }
+    WT_HD int32_t child(const node_t& n, int i) const { return n.child[i]; }
+    WT_HD node_box_t box(const node_t& n, int i) const { return node_box_t{n.minx[i], n.miny[i], n.minz[i], n.maxx[i], n.maxy[i], n.maxz[i]}; }
+    // the box of child i relative to a query's origin `o`; rel(o) is computed once per step
+    WT_HD vec3 rel(vec3 o) const { return o; }
+    WT_HD node_box_t box_rel(const node_t& n, int i, vec3 r) const {
+        return node_box_t{n.minx[i] - r.x, n.miny[i] - r.y, n.minz[i] - r.z, n.maxx[i] - r.x, n.maxy[i] - r.y, n.maxz[i] - r.z};
+    }
+};
+struct grid_nodes_t {   // the 128-byte nodes on the scene grid
+    typedef bvh8_qnode_t node_t;
+    const bvh8_qnode_t* p;
+    qgrid_t g;
+    WT_HD node_t fetch(int32_t idx) const { return p[idx]; }
+    WT_HD int32_t child(const node_t& n, int i) const { return n.c[i].child; }
+    WT_HD node_box_t box(const node_t& n, int i) const {
+        const bvh8_qchild_t& c = n.c[i];
+        return node_box_t{qgrid_decode(g.origin.x, g.cell.x, c.lo[0]), qgrid_decode(g.origin.y, g.cell.y, c.lo[1]), qgrid_decode(g.origin.z, g.cell.z, c.lo[2]),
+                          qgrid_decode(g.origin.x, g.cell.x, c.hi[0]), qgrid_decode(g.origin.y, g.cell.y, c.hi[1]), qgrid_decode(g.origin.z, g.cell.z, c.hi[2])};
+    }
+    // ... relative to a query's origin: the decoding folded into the subtraction (one fused multiply-add per coordinate; qgrid_encode's spare cell
+    // covers the different rounding)
+    WT_HD vec3 rel(vec3 o) const { return vec3{g.origin.x - o.x, g.origin.y - o.y, g.origin.z - o.z}; }
+    WT_HD node_box_t box_rel(const node_t& n, int i, vec3 r) const {
+        const bvh8_qchild_t& c = n.c[i];
+        return node_box_t{qgrid_decode(r.x, g.cell.x, c.lo[0]), qgrid_decode(r.y, g.cell.y, c.lo[1]), qgrid_decode(r.z, g.cell.z, c.lo[2]),
+                          qgrid_decode(r.x, g.cell.x, c.hi[0]), qgrid_decode(r.y, g.cell.y, c.hi[1]), qgrid_decode(r.z, g.cell.z, c.hi[2])};
+    }
+};
+// What a traversal that is not handed a node source reads: on the device the 128-byte nodes — stored BEHIND the scene's nodes in the same allocation,
+// followed by the grid (wtgpu.hip: upload_impl; a scene whose boxes the grid cannot enclose gets cell.x = 0 there, and its kernels the exact
+// nodes: lane_nodes_usable) —, on the host the exact ones.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WT_NO_QNODES)
+typedef grid_nodes_t lane_nodes_t;
+WT_HD lane_nodes_t lane_nodes(const scene_t& sc) {
+    const bvh8_qnode_t* q = reinterpret_cast<const bvh8_qnode_t*>(sc.nodes + sc.n_nodes);
+    const float* g = reinterpret_cast<const float*>(q + sc.n_nodes);
+    return lane_nodes_t{q, qgrid_t{vec3{g[0], g[1], g[2]}, vec3{g[3], g[4], g[5]}}};
+}
+#else
+typedef wide_nodes_t lane_nodes_t;
+WT_HD lane_nodes_t lane_nodes(const scene_t& sc) { return lane_nodes_t{sc.nodes}; }
+#endif
+
 #if defined(WTGPU_FSD_WATCH) && defined(__HIPCC__)
 // (bring-up aid, tools/r05/watch_path.py: a host-mapped buffer the kernels of a hanging launch write their progress into — device printf never
 // flushes from a kernel that does not end)
@@ -231,11 +356,43 @@ WT_HD void rq_begin(const scene_t& sc, const range_t& range, const stack_ref_t& 
     q.s = 1;
     stack.set(0, stack_entry_t{0.f, 1});
 }
-// pops one entry: a leaf (or a node with few triangles) is kept for rq_leaf_step, a node's children are tested and pushed far-first
-// (requires q.s > 0, q.lcnt == 0)
-WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& stack, ray_query_t& q, bvh_counters_t* ctr = nullptr) {
+// the children of a fetched node `n`, tested and pushed far-first (the entry that named it has been popped: q.s is the stack size without it)
+template <class NS>
+WT_HD void rq_node_children(const NS& ns, const typename NS::node_t& n, vec3 ro, vec3 rd, const stack_ref_t& stack, ray_query_t& q, bvh_counters_t* ctr = nullptr) {
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
     const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
+    const int s = q.s;
+    const vec3 rel = ns.rel(ro);
+    if (ctr) ctr->nodes++;
+    const float tfar = fminf_(q.rec.dist, q.range.max);
+    // all eight slab tests without a branch, then one write per accepted child at its sorted position (stack_push_sorted)
+    float tm[8];
+    int32_t cps[8];
+    uint32_t ok = 0;
+    int room = (int)stack.cap - s;   // (a full stack drops the children that do not fit, in child order)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int32_t cp = ns.child(n, i);
+        const node_box_t b = ns.box_rel(n, i, rel);
+        const float bminx = sx ? b.x1 : b.x0, bmaxx = sx ? b.x0 : b.x1;
+        const float bminy = sy ? b.y1 : b.y0, bmaxy = sy ? b.y0 : b.y1;
+        const float bminz = sz ? b.z1 : b.z0, bmaxz = sz ? b.z0 : b.z1;
+        const float t1x = bminx * rinvd.x, t2x = bmaxx * rinvd.x;
+        const float t1y = bminy * rinvd.y, t2y = bmaxy * rinvd.y;
+        const float t1z = bminz * rinvd.z, t2z = bmaxz * rinvd.z;
+        const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, q.range.min));
+        const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
+        const bool acc = cp != 0 && rmin <= rmax && room > 0;
+        room -= acc ? 1 : 0;
+        ok |= acc ? 1u << i : 0u;
+        tm[i] = rmin;
+        cps[i] = cp;
+    }
+    q.s = stack_push_sorted(stack, s, tm, cps, ok);
+}
+// pops one entry: a leaf is kept for rq_leaf_step, a node is fetched and its children tested (requires q.s > 0, q.lcnt == 0)
+template <class NS>
+WT_HD void rq_node_step(const NS& ns, vec3 ro, vec3 rd, const stack_ref_t& stack, ray_query_t& q, bvh_counters_t* ctr = nullptr) {
     int s = q.s;
     const stack_entry_t top = stack.get(s - 1);
     --s;
@@ -247,39 +404,22 @@ WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& 
         q.lcnt = leaf.count;
         return;
     }
-    // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+    // by value: the whole node is fetched with wide loads issued back to back (one memory latency per node instead of
     // one per child field); the unrolled child loop then runs from registers
-    const bvh8_node_t n = sc.nodes[top.ptr - 1];
-    if ((int)n.tris_count <= kRayLeafShortcut) {
-        q.lt0 = n.tris_start;
-        q.lcnt = n.tris_count;
-        return;
-    }
-    if (ctr) ctr->nodes++;
-    const float tfar = fminf_(q.rec.dist, q.range.max);
-    // all eight slab tests without a branch, then one write per accepted child at its sorted position (stack_push_sorted)
-    float tm[8];
-    int32_t cps[8];
-    uint32_t ok = 0;
-    int room = (int)stack.cap - s;   // (a full stack drops the children that do not fit, in child order)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int32_t cp = n.child[i];
-        const float bminx = sx ? n.maxx[i] : n.minx[i], bmaxx = sx ? n.minx[i] : n.maxx[i];
-        const float bminy = sy ? n.maxy[i] : n.miny[i], bmaxy = sy ? n.miny[i] : n.maxy[i];
-        const float bminz = sz ? n.maxz[i] : n.minz[i], bmaxz = sz ? n.minz[i] : n.maxz[i];
-        const float t1x = (bminx - ro.x) * rinvd.x, t2x = (bmaxx - ro.x) * rinvd.x;
-        const float t1y = (bminy - ro.y) * rinvd.y, t2y = (bmaxy - ro.y) * rinvd.y;
-        const float t1z = (bminz - ro.z) * rinvd.z, t2z = (bmaxz - ro.z) * rinvd.z;
-        const float rmin = fmaxf_(fmaxf_(t1x, t1y), fmaxf_(t1z, q.range.min));
-        const float rmax = fminf_(fminf_(t2x, t2y), fminf_(t2z, tfar));
-        const bool acc = cp != 0 && rmin <= rmax && room > 0;
-        room -= acc ? 1 : 0;
-        ok |= acc ? 1u << i : 0u;
-        tm[i] = rmin;
-        cps[i] = cp;
-    }
-    q.s = stack_push_sorted(stack, s, tm, cps, ok);
+    // (The reference tests the triangles of a subtree of <= 16 one after the other instead of descending, src/ads/bvh8w.cpp:29,512: a shortcut for
+    // its 8-wide SIMD box test, not a different answer — the closest hit is the closest hit.  It is not taken here, by the checker or by the device:
+    // lanes of a wavefront with 1 to 16 triangles each run the longest loop, and the 128-byte nodes do not carry a subtree's triangle count.)
+    const typename NS::node_t n = ns.fetch(top.ptr - 1);
+    rq_node_children(ns, n, ro, rd, stack, q, ctr);
+}
+// RAY queries always read the exact nodes.  A ray that lies IN the plane of an axis-aligned wall grazes that wall's flat box: (box - origin) / d is
+// 0 x inf for that axis, the slab test fails, and the coplanar triangles are never tested — as in the reference, whose boxes are exact floats too.
+// A box rounded outwards is entered, and the tolerant ray-triangle test then reports a hit at the wall's rim: on the city-block scene (etoile: rays
+// leaving diffraction points along the walls) 0.1 % of such rays found an occluder the exact boxes do not show, 2.5e-3 of the film's energy
+// (profiles/r06_ab_experiments.log).  Cone queries grow every box by the beam's radius first: no such degenerate case, and both node sources give
+// the same answers (tests/test_oracle.py::test_grid_nodes_answer_like_exact_nodes).
+WT_HD void rq_node_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& stack, ray_query_t& q, bvh_counters_t* ctr = nullptr) {
+    rq_node_step(wide_nodes_t{sc.nodes}, ro, rd, stack, q, ctr);
 }
 // tests the held triangles (requires q.lcnt != 0); TRUE: an any-hit (shadow) query is decided
 template <bool shadow>
@@ -298,9 +438,9 @@ WT_HD bool rq_leaf_step(const scene_t& sc, vec3 ro, vec3 rd, const stack_ref_t& 
     }
     return false;
 }
-template <bool shadow>
-WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack, ray_hit_t& rec,
-                            bvh_counters_t* ctr = nullptr) {
+template <bool shadow, class NS>
+WT_HD bool bvh_traverse_ray_ns(const NS& ns, const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack, ray_hit_t& rec,
+                               bvh_counters_t* ctr = nullptr) {
     // "while-while" form (Aila & Laine): every lane of a wavefront first descends through nodes until it holds a leaf (lanes that
     // found theirs wait at the inner loop's exit), then all of them test their leaf's triangles together — instead of paying the node
     // path AND the leaf path in every iteration because some lane needs each.  Per lane the order of visits is unchanged.
@@ -310,7 +450,7 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
         while (q.s > 0 && q.lcnt == 0) {
             WT_WATCH_ADD(8);
             WT_WATCH(9, q.s);
-            rq_node_step(sc, ro, rd, stack, q, ctr);
+            rq_node_step(ns, ro, rd, stack, q, ctr);
         }
         WT_WATCH_ADD(10);
         WT_WATCH(11, q.lcnt);
@@ -318,6 +458,11 @@ WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& 
     }
     rec = q.rec;
     return rec.dist < WT_INF;
+}
+template <bool shadow>
+WT_HD bool bvh_traverse_ray(const scene_t& sc, vec3 ro, vec3 rd, const range_t& range, const stack_ref_t& stack, ray_hit_t& rec,
+                            bvh_counters_t* ctr = nullptr) {
+    return bvh_traverse_ray_ns<shadow>(wide_nodes_t{sc.nodes}, sc, ro, rd, range, stack, rec, ctr);   // (exact nodes: see rq_node_step)
 }
 
 // ads_t::intersect(ray) + ray_work_to_intersection_record (traversal_common.hpp:94-113)
@@ -355,6 +500,9 @@ WT_HD bool cone_box_outside(float b0x, float b0y, float b0z, float b1x, float b1
     const float he = fabsf(rd.x) * hx + fabsf(rd.y) * hy + fabsf(rd.z) * hz;
     const float slack = 1e-5f * (fabsf(zc) + he) + 1e-12f;
     if (zc - he > range.max + slack || zc + he < range.min - slack) return true;
+#if defined(WT_CONE_BOX_NO_LATERAL)
+    return false;   // (A/B: the axial test alone)
+#endif
     const float rho2 = fmaxf_(0.f, cx * cx + cy * cy + cz * cz - zc * zc);
     const float rbox = cull_sqrtf(hx * hx + hy * hy + hz * hz);   // (the test below carries a 5e-4 margin)
     const float zhi = fminf_(range.max, zc + he);
@@ -430,24 +578,16 @@ WT_HD void cq_stop(cone_query_t& q) {
     q.s = 0;
     q.leaf = 0;
 }
-// pops one entry: a leaf is kept for cq_leaf_step, a node's children are tested and pushed far-first (requires q.s > 0, q.leaf == 0)
-WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, cone_query_t& q, bvh_counters_t* ctr = nullptr) {
+// the children of a fetched node `n`: budget charge, box tests, sorted push (the entry that named it has been popped: q.s is the stack size without it)
+template <class NS>
+WT_HD void cq_node_children(const NS& ns, const typename NS::node_t& n, const cone_t& cone, const stack_ref_t& stack, cone_query_t& q, bvh_counters_t* ctr = nullptr) {
     const vec3 ro = cone.o, rd = cone.d;
     const vec3 rinvd{1.f / rd.x, 1.f / rd.y, 1.f / rd.z};
     const bool sx = __builtin_signbit(rinvd.x), sy = __builtin_signbit(rinvd.y), sz = __builtin_signbit(rinvd.z);
     const float ta = cone.tan_alpha, ix = cone.x0;
     const range_t range = q.range;
+    const vec3 rel = ns.rel(ro);
     int s = q.s;
-    const stack_entry_t top = stack.get(s - 1);
-    --s;
-    if (top.ptr < 0) {
-        q.leaf = top.ptr;
-        q.s = s;
-        return;
-    }
-    // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
-    // one per child field); the unrolled child loop then runs from registers
-    const bvh8_node_t n = sc.nodes[top.ptr - 1];
     if (ctr) ctr->cone_nodes++;
     q.tests += kNodeBudgetCost;   // an 8-wide node visit costs a lane about as much as a few triangle tests
     if (q.tests > q.budget) {
@@ -463,10 +603,11 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
     bool full = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int32_t cp = n.child[i];
+        const int32_t cp = ns.child(n, i);
         // cone_cluster_intersect (bvh8w.cpp:187-230): grow the box by the cone radius at its far z
-        float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
-        float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+        const node_box_t nb = ns.box_rel(n, i, rel);
+        float ominx = nb.x0, ominy = nb.y0, ominz = nb.z0;
+        float omaxx = nb.x1, omaxy = nb.y1, omaxz = nb.z1;
         const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
         const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
         const float dot_d_b = rd.x * bx + rd.y * by + rd.z * bz;
@@ -515,6 +656,26 @@ WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t
     }
     s = stack_push_sorted(stack, s, tm, cps, ok);
     q.s = s;
+}
+// pops one entry: a leaf is kept for cq_leaf_step, a node's children are tested and pushed far-first (requires q.s > 0, q.leaf == 0)
+template <class NS>
+WT_HD void cq_node_step(const NS& ns, const cone_t& cone, const stack_ref_t& stack, cone_query_t& q, bvh_counters_t* ctr = nullptr) {
+    int s = q.s;
+    const stack_entry_t top = stack.get(s - 1);
+    --s;
+    if (top.ptr < 0) {
+        q.leaf = top.ptr;
+        q.s = s;
+        return;
+    }
+    // by value: the whole node is fetched with wide loads issued back to back (one memory latency per node instead of
+    // one per child field); the unrolled child loop then runs from registers
+    const typename NS::node_t n = ns.fetch(top.ptr - 1);
+    q.s = s;
+    cq_node_children(ns, n, cone, stack, q, ctr);
+}
+WT_HD void cq_node_step(const scene_t& sc, const cone_t& cone, const stack_ref_t& stack, cone_query_t& q, bvh_counters_t* ctr = nullptr) {
+    cq_node_step(lane_nodes(sc), cone, stack, q, ctr);
 }
 // What follows from a hit of the running query at distance `dist` on triangle `tuid`: closest distance, list entry, early exit, slab
 // shrink and stack pruning (the body of the reference's leaf loop, bvh8w.cpp:134-185).
@@ -648,18 +809,24 @@ WT_HD bool cq_end(const cone_t& cone, const uint_list_t& tris, cone_query_t& q) 
     }
     return rec.ntris + rec.overflow > 0;
 }
-WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack,
-                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr, uint32_t budget = 0xFFFFFFFFu,
-                             float min_progress = -WT_INF) {
+template <class NS>
+WT_HD bool bvh_traverse_cone_ns(const NS& ns, const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack,
+                                const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr, uint32_t budget = 0xFFFFFFFFu,
+                                float min_progress = -WT_INF) {
     cone_query_t q;
     cq_begin(sc, cone, searchrange, z_scale, stack, budget, min_progress, q);
     while (cq_running(q)) {   // "while-while" form, see bvh_traverse_ray
-        while (q.s > 0 && q.leaf == 0) cq_node_step(sc, cone, stack, q, ctr);
+        while (q.s > 0 && q.leaf == 0) cq_node_step(ns, cone, stack, q, ctr);
         if (q.leaf != 0) cq_leaf_step(sc, cone, stack, tris, q, ctr);
     }
     const bool any = cq_end(cone, tris, q);
     rec = q.rec;
     return any;
+}
+WT_HD bool bvh_traverse_cone(const scene_t& sc, const cone_t& cone, const range_t& searchrange, float z_scale, const stack_ref_t& stack,
+                             const uint_list_t& tris, cone_hit_t& rec, bvh_counters_t* ctr = nullptr, uint32_t budget = 0xFFFFFFFFu,
+                             float min_progress = -WT_INF) {
+    return bvh_traverse_cone_ns(lane_nodes(sc), sc, cone, searchrange, z_scale, stack, tris, rec, ctr, budget, min_progress);
 }
 
 // Any-hit cone probe: TRUE if some triangle intersects the cone inside `range` (first hit terminates).
@@ -677,6 +844,8 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
     uint32_t tests = 0;
     int s = 1;
     stack.set(0, stack_entry_t{0.f, 1});
+    const lane_nodes_t ns = lane_nodes(sc);
+    const vec3 rel = ns.rel(ro);
     while (s > 0) {
         const stack_entry_t top = stack.get(s - 1);
         --s;
@@ -703,9 +872,9 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
             }
             continue;
         }
-        // by value: the whole 256-B node is fetched with wide loads issued back to back (one memory latency per node instead of
+        // by value: the whole node is fetched with wide loads issued back to back (one memory latency per node instead of
         // one per child field); the unrolled child loop then runs from registers
-        const bvh8_node_t n = sc.nodes[top.ptr - 1];
+        const typename lane_nodes_t::node_t n = ns.fetch(top.ptr - 1);
         if (ctr) ctr->probe_nodes++;
         tests += kNodeBudgetCost;
         if (tests > budget) {
@@ -719,9 +888,10 @@ WT_HD bool bvh_cone_any_hit(const scene_t& sc, const cone_t& cone, const range_t
         bool full = false;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int32_t cp = n.child[i];
-            float ominx = n.minx[i] - ro.x, ominy = n.miny[i] - ro.y, ominz = n.minz[i] - ro.z;
-            float omaxx = n.maxx[i] - ro.x, omaxy = n.maxy[i] - ro.y, omaxz = n.maxz[i] - ro.z;
+            const int32_t cp = ns.child(n, i);
+            const node_box_t nb = ns.box_rel(n, i, rel);
+            float ominx = nb.x0, ominy = nb.y0, ominz = nb.z0;
+            float omaxx = nb.x1, omaxy = nb.y1, omaxz = nb.z1;
             const float b0x = ominx, b0y = ominy, b0z = ominz, b1x = omaxx, b1y = omaxy, b1z = omaxz;
             const float bx = sx ? ominx : omaxx, by = sy ? ominy : omaxy, bz = sz ? ominz : omaxz;
             const float maxz = clampf(rd.x * bx + rd.y * by + rd.z * bz, 0.f, range.max);
@@ -1123,7 +1293,7 @@ WT_HD trav_result_t traverse_axis(const scene_t& sc, const cone_t& envelope, flo
             continue;
         }
         while (cq_running(q)) {
-            while (q.s > 0 && q.leaf == 0) cq_node_step(sc, envelope, stack, q, ctr);
+            while (q.s > 0 && q.leaf == 0) cq_node_step(lane_nodes(sc), envelope, stack, q, ctr);
             if (q.leaf != 0) cq_leaf_step(sc, envelope, stack, tris, q, ctr);
         }
         cq_end(envelope, tris, q);

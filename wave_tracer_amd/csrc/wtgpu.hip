@@ -112,12 +112,18 @@ struct wtgpu_scene {
     void* capture_user = nullptr;
     uint32_t* query_scratch = nullptr;   // wtgpu_traverse_cones
     size_t query_scratch_bytes = 0;
+    // WTGPU_TRACE_AB (diagnostic, tests/test_gpu_traversal.py): accumulated over the replayed rounds — milliseconds of k_trace_refill / k_trace_sm on the
+    // same queue, words of their outputs that differ (traversal records + triangle lists + heavy-queue checksums), walks replayed
+    double ab_ms[2] = {0, 0};
+    uint64_t ab_mismatch = 0, ab_walks = 0, ab_rounds = 0;
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
         uint32_t shrink_r1 = 8, shrink_f1 = 4, shrink_r2 = 16, shrink_f2 = 32, shrink_h1 = 4, decay_q = 0, decay_c = 4;   // persistent-grid sizes of the later rounds (see wtgpu_render_async)
         uint32_t heavy_waves_per_cu = 8, round_blocks_per_cu = 8, grid_div_b = 4, grid_div_c = 1, grid_div_hard = 4, grid_mul_flux = 2, coop_aperture_min = 8, heavy_probe = 1, flux_task_tris = kFluxTaskTris;
         uint32_t coop_io = 0, primary_axis = 0, sorted_interact = 0, staged_connect = 0, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
+        uint32_t trace_staged = 1, trace_stages = 3, trace_staged_rounds = 4;   // ... for the first WTGPU_TRACE_STAGED_ROUNDS rounds of a batch (the long ones: a stage is a launch, and a short round is bound by its launches)   // WTGPU_TRACE_STAGED=1: the traversal in stages (k_tr_axis / k_tr_cone / k_tr_policy / k_tr_tail), WTGPU_TRACE_STAGES cone stages before the tail
+        uint32_t trace_sm = 0, trace_ab = 0;   // WTGPU_TRACE_SM=1: the phase-machine trace kernel (k_trace_sm); WTGPU_TRACE_AB=n: the first n rounds replay their trace queue through both kernels (timed, outputs compared)
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -368,6 +374,15 @@ static int scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, const char*
     return diff.empty() ? 0 : 1;
 }
 int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, size_t n_what) { return scene_compare(a, b, nullptr, what, n_what); }
+int wtgpu_trace_ab_stats(wtgpu_scene* s, double* ms_refill, double* ms_sm, uint64_t* differing_words, uint64_t* walks, uint64_t* rounds) {
+    if (!s) return fail(WTGPU_ERR_INVALID, "null scene");
+    if (ms_refill) *ms_refill = s->ab_ms[0];
+    if (ms_sm) *ms_sm = s->ab_ms[1];
+    if (differing_words) *differing_words = s->ab_mismatch;
+    if (walks) *walks = s->ab_walks;
+    if (rounds) *rounds = s->ab_rounds;
+    return WTGPU_OK;
+}
 int wtgpu_scene_compare_part(const wtgpu_scene* a, const wtgpu_scene* b, const char* part, char* what, size_t n_what) {
     if (!part) return fail(WTGPU_ERR_INVALID, "null part");
     return scene_compare(a, b, part, what, n_what);
@@ -464,6 +479,11 @@ static void read_knobs(wtgpu_scene* s) {
     k.grid_div_hard = std::max(1u, u("WTGPU_GRID_HARD", 4));
     k.grid_mul_flux = std::max(1u, u("WTGPU_GRID_FLUX", 2));
     k.heavy_probe = u("WTGPU_HEAVY_PROBE", 1);
+    k.trace_sm = u("WTGPU_TRACE_SM", k.trace_sm);
+    k.trace_ab = u("WTGPU_TRACE_AB", 0);
+    k.trace_staged = u("WTGPU_TRACE_STAGED", k.trace_staged);
+    k.trace_staged_rounds = u("WTGPU_TRACE_STAGED_ROUNDS", k.trace_staged_rounds);
+    k.trace_stages = std::min(16u, std::max(1u, u("WTGPU_TRACE_STAGES", k.trace_stages)));
     // Pass A and the connections each exist in two forms (DESIGN.md §4 has the measurements: the one-kernel forms are 1-6 % faster on the headline
     // workload and are the default; the sorted / staged forms move a third of the bytes):
     //   WTGPU_SORTED_INTERACT  0: k_interact (one kernel, every walk); 1: k_classify + one kernel per material class; 2: k_classify + k_interact_sorted
@@ -510,7 +530,32 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
     UP(tri_meta, h.n_tris)
     UP(tri_shade, h.n_tris)
     UP(edges, h.n_edges)
-    UP(nodes, h.n_nodes)
+    {   // the nodes, and behind them — same allocation — the 128-byte nodes of the per-lane traversals and their grid (wt/bvh.h: lane_nodes)
+        d.nodes = nullptr;
+        if (h.n_nodes > 0 && h.nodes) {
+            const size_t nn = h.n_nodes;
+            vec3 mn{WT_INF, WT_INF, WT_INF}, mx{-WT_INF, -WT_INF, -WT_INF};
+            for (size_t i = 0; i < nn; ++i)
+                for (int c = 0; c < 8; ++c)
+                    if (h.nodes[i].child[c] != 0) {
+                        mn = vmin(mn, vec3{h.nodes[i].minx[c], h.nodes[i].miny[c], h.nodes[i].minz[c]});
+                        mx = vmax(mx, vec3{h.nodes[i].maxx[c], h.nodes[i].maxy[c], h.nodes[i].maxz[c]});
+                    }
+            const qgrid_t g = qgrid_make(mn, mx);
+            std::vector<bvh8_qnode_t> qn(nn);
+            bool ok = finitef(mn.x) && finitef(mn.y) && finitef(mn.z) && finitef(mx.x) && finitef(mx.y) && finitef(mx.z);
+            for (size_t i = 0; i < nn && ok; ++i) ok = qnode_make(h.nodes[i], g, qn[i]);
+            if (!ok) return fail(WTGPU_ERR_INVALID, "the scene's BVH boxes cannot be enclosed by the 16-bit node grid (non-finite or out-of-range box)");
+            const float gw[8] = {g.origin.x, g.origin.y, g.origin.z, g.cell.x, g.cell.y, g.cell.z, 0.f, 0.f};
+            void* p = nullptr;
+            HIP_CHECK(hipMalloc(&p, nn * (sizeof(bvh8_node_t) + sizeof(bvh8_qnode_t)) + sizeof(gw)));
+            s->dev_allocs.push_back(p);
+            HIP_CHECK(hipMemcpy(p, h.nodes, nn * sizeof(bvh8_node_t), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(static_cast<char*>(p) + nn * sizeof(bvh8_node_t), qn.data(), nn * sizeof(bvh8_qnode_t), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(static_cast<char*>(p) + nn * (sizeof(bvh8_node_t) + sizeof(bvh8_qnode_t)), gw, sizeof(gw), hipMemcpyHostToDevice));
+            d.nodes = static_cast<const bvh8_node_t*>(p);
+        }
+    }
     UP(leaves, h.n_leaves)
     UP(shapes, h.n_shapes)
     size_t total_shape_tris = 0;
@@ -567,7 +612,7 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         // (WTGPU_STATE_GB, default 224 of the 288 GB, and never more than 85 % of what is free) by shrinking the batches of deep scenes — more, smaller batches, same results
         const bool pm = h.opts.integrator != INTEGRATOR_BDPT;
         const uint64_t mv = (uint64_t)h.opts.max_depth + 2;
-        uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
+        uint64_t per_sample = 4ull * (2 * ((pm ? kPathWalkWords : kWalkWords) + (pm ? 0 : mv * kVertexWords) + kTravWords + kStageWords + 2 + kTriListWords) + kCtxWords) + 64ull * 28ull + 2048ull;
         // plt_path: two wedge pools of 48 records per walk, the deferred-NEE records, the queues of the wave-per-walk kernels
         if (pm) per_sample += 2ull * 48ull * sizeof(utd_edge_rec_t) + sizeof(path_nee_rec_t) + 3ull * 4ull + 4ull + sizeof(uint2);
         else per_sample += (s->knobs.staged_connect ? (uint64_t)s->knobs.conn_pool * (sizeof(conn_pending_t) + 4ull) : 0ull) + (s->knobs.sorted_interact ? 4ull * 2ull * kNumWalkClasses : 0ull);   // pending connections, class queues
@@ -643,11 +688,11 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         }
         if ((rc = dmalloc(s, &st.verts, path_mode ? 1 : (size_t)st.max_verts * kVertexWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.ctx, kCtxWords * (size_t)st.cap))) return rc;
-        if ((rc = dmalloc(s, &st.trav, kTravWords * W2))) return rc;
+        if ((rc = dmalloc(s, &st.trav, (kTravWords + kStageWords) * W2))) return rc;   // (+ the staged trace kernels' records: trace_stage_words)
         if ((rc = dmalloc(s, &st.tris, (size_t)kTriListWords * W2))) return rc;
         if ((rc = dmalloc(s, &st.queue[0], W2))) return rc;
         if ((rc = dmalloc(s, &st.queue[1], W2))) return rc;
-        if ((rc = dmalloc(s, &st.heavy_queue, W2))) return rc;
+        if ((rc = dmalloc(s, &st.heavy_queue, 3 * W2))) return rc;   // (+ the staged trace kernels' two queues: trace_pol_queue / trace_cone_queue)
         if ((rc = dmalloc(s, &st.intb_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.gather_queue, W2))) return rc;
         if ((rc = dmalloc(s, &st.intc_queue, W2))) return rc;
@@ -716,6 +761,97 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
         s->acc[3] += elapsed(r.ev[e], r.ev[e + 1]);
     }
     r.busy = false;
+    return WTGPU_OK;
+}
+
+// ---- WTGPU_TRACE_AB: in-situ replay of a round's trace queue through both per-lane trace kernels (the "replay harness": each variant sees exactly the
+// queue, walk records and scene the pipeline produced, so what is timed is the real mix of beam widths and what is compared is every word they write)
+__global__ void __launch_bounds__(256) k_ab_compare(const uint32_t* x, const uint32_t* y, size_t n, unsigned long long* out) {
+    unsigned long long bad = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) bad += x[i] != y[i] ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
+}
+__global__ void __launch_bounds__(256) k_ab_queue_sums(const uint32_t* q, const uint32_t* count, unsigned long long* out) {   // order-independent checksums of a queue
+    unsigned long long s1 = 0, s2 = 0;
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        s1 += q[i];
+        s2 += (unsigned long long)q[i] * 2654435761ull + ((unsigned long long)q[i] << 7 ^ q[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, s1);
+        atomicAdd(out + 1, s2);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 2, (unsigned long long)n);
+}
+// the per-lane traversal of a round in its alternative forms (the default, k_trace_refill, is launched by batch_launcher_t::rounds itself)
+static void launch_trace_alt(const wtgpu_scene* s, const launch_args_t& a, hipStream_t st_, int in, int first, uint32_t round, uint32_t g0) {
+    const wtgpu_scene::knobs_t& K = s->knobs;
+    if (K.trace_staged) {
+        hipLaunchKernelGGL(k_tr_axis, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+        for (uint32_t it = 0; it < K.trace_stages; ++it) {
+            const uint32_t g = std::max<uint32_t>(1u, g0 >> std::min(it, 4u));   // (the queues shrink from stage to stage; a grid that is too small only loops longer)
+            if (it > 0) hipLaunchKernelGGL(k_tr_policy, dim3(g), dim3(kBlock), 0, st_, a, it);
+            hipLaunchKernelGGL(k_tr_cone, dim3(g), dim3(kBlock), 0, st_, a, it);
+        }
+        hipLaunchKernelGGL(k_tr_tail, dim3(std::max<uint32_t>(1u, g0 >> 3)), dim3(kBlock), 0, st_, a, K.trace_stages);
+    } else
+        hipLaunchKernelGGL(k_trace_sm, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+}
+static int trace_ab_round(wtgpu_scene* s, const launch_args_t& a, hipStream_t st_, int in, int first, uint32_t round, uint32_t g0) {
+    const size_t n_trav = 2 * (size_t)a.st.cap * kTravWords, n_tris = 2 * (size_t)a.st.cap * kTriListWords;
+    uint32_t *b_trav = nullptr, *b_tris = nullptr;
+    unsigned long long* d_out = nullptr;
+    uint32_t h_n[2] = {0, 0};
+    HIP_CHECK(hipMalloc(&b_trav, n_trav * 4));
+    HIP_CHECK(hipMalloc(&b_tris, n_tris * 4));
+    HIP_CHECK(hipMalloc(&d_out, 8 * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemsetAsync(d_out, 0, 8 * sizeof(unsigned long long), st_));
+    hipEvent_t ev[4];
+    for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    HIP_CHECK(hipMemcpyAsync(h_n, a.st.ctl + CTL_COUNT0 + in, 4, hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipMemcpyAsync(h_n + 1, a.st.ctl + CTL_BACK0 + in, 4, hipMemcpyDeviceToHost, st_));
+    // A: k_trace_refill
+    HIP_CHECK(hipEventRecord(ev[0], st_));
+    hipLaunchKernelGGL(k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+    HIP_CHECK(hipEventRecord(ev[1], st_));
+    HIP_CHECK(hipMemcpyAsync(b_trav, a.st.trav, n_trav * 4, hipMemcpyDeviceToDevice, st_));
+    HIP_CHECK(hipMemcpyAsync(b_tris, a.st.tris, n_tris * 4, hipMemcpyDeviceToDevice, st_));
+    hipLaunchKernelGGL(k_ab_queue_sums, dim3(64), dim3(256), 0, st_, a.st.heavy_queue, a.st.ctl + CTL_HEAVY_COUNT, d_out + 1);
+    // the queue again from its start, an empty heavy queue
+    HIP_CHECK(hipMemsetAsync(a.st.ctl + CTL_HEAD_TRACE, 0, 4, st_));
+    HIP_CHECK(hipMemsetAsync(a.st.ctl + CTL_HEAVY_COUNT, 0, 4, st_));
+    // B: the alternative form the knobs select (k_trace_sm, or the staged kernels)
+    HIP_CHECK(hipEventRecord(ev[2], st_));
+    launch_trace_alt(s, a, st_, in, first, round, g0);
+    HIP_CHECK(hipEventRecord(ev[3], st_));
+    hipLaunchKernelGGL(k_ab_compare, dim3(2048), dim3(256), 0, st_, b_trav, a.st.trav, n_trav, d_out);
+    hipLaunchKernelGGL(k_ab_compare, dim3(2048), dim3(256), 0, st_, b_tris, a.st.tris, n_tris, d_out);
+    hipLaunchKernelGGL(k_ab_queue_sums, dim3(64), dim3(256), 0, st_, a.st.heavy_queue, a.st.ctl + CTL_HEAVY_COUNT, d_out + 4);
+    unsigned long long h_out[8];
+    HIP_CHECK(hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipStreamSynchronize(st_));
+    float ms_a = 0.f, ms_b = 0.f;
+    (void)hipEventElapsedTime(&ms_a, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&ms_b, ev[2], ev[3]);
+    const uint64_t bad = h_out[0] + (h_out[1] != h_out[4]) + (h_out[2] != h_out[5]) + (h_out[3] != h_out[6]);
+    s->ab_ms[0] += ms_a;
+    s->ab_ms[1] += ms_b;
+    s->ab_mismatch += bad;
+    s->ab_walks += (uint64_t)h_n[0] + h_n[1];
+    s->ab_rounds++;
+    if (getenv("WTGPU_TRACE_AB_VERBOSE"))
+        fprintf(stderr, "[trace ab] round %2u: %8u walks  refill %8.3f ms  alt %8.3f ms  heavy %llu / %llu  differing words %llu\n", round, h_n[0] + h_n[1], ms_a, ms_b,
+                h_out[3], h_out[6], (unsigned long long)bad);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipFree(b_trav);
+    (void)hipFree(b_tris);
+    (void)hipFree(d_out);
     return WTGPU_OK;
 }
 
@@ -803,7 +939,13 @@ struct batch_launcher_t {
                 gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
             }
             if (dbg_stage >= 2 + 3 * (int)round) {
-                HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
+                if (round < K.trace_ab) {
+                    const int rc = trace_ab_round(s, a, st_, in, first, round, g0);
+                    if (rc) return rc;
+                } else if (K.trace_sm || (K.trace_staged && round < K.trace_staged_rounds))
+                    launch_trace_alt(s, a, st_, in, first, round, g0);
+                else
+                    HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
             }
             rec(r, st_);
             if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
@@ -1147,6 +1289,16 @@ int wtgpu_get_counters(wtgpu_scene* s, wtgpu_counters* out) {
         HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
         const char* nm[6] = {"serve", "fetch", "store", "nodes", "leaf", "(ray in fetch)"};
         for (int i = 0; i < 6; ++i) fprintf(stderr, "[refill prof] %-16s %10.1f Mticks  lanes %.1f\n", nm[i], p[i] * 1e-6, p[i] ? double(p[8 + i]) / p[i] : 0.);
+    }
+#endif
+#ifdef WTGPU_SM_PROF
+    {
+        unsigned long long p[64];
+        HIP_CHECK(hipMemcpy(p, s->slices[0].counters + kNumCounters, sizeof(p), hipMemcpyDeviceToHost));
+        const char* nm[7] = {"serve", "fetch", "aw_next", "store", "NODE", "TRI", "EXACT"};
+        for (int i = 0; i < 7; ++i)
+            fprintf(stderr, "[sm prof] %-8s %10.1f Mticks  %10.2f Msteps  %7.0f ticks/step  lanes %.1f\n", nm[i], p[32 + i] * 1e-6, p[48 + i] * 1e-6, p[48 + i] ? double(p[32 + i]) / p[48 + i] : 0.,
+                    p[32 + i] ? double(p[40 + i]) / p[32 + i] : 0.);
     }
 #endif
     if (s->knobs.profile == 2) {

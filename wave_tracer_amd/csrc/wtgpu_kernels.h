@@ -54,12 +54,13 @@ constexpr int kBlock = 128;
 #define WTGPU_LDS_STACK 20
 #endif
 constexpr int kLdsStack = WTGPU_LDS_STACK;   // LDS-resident stack entries per lane
-constexpr uint32_t kConeBudget = 64;     // work units (1 per cone-triangle test, 2 per node) one lane may spend on a cone query before it is handed to a wavefront (with lane refill, round 3: 32 / 48 / 64 / 96 / 128 -> 14.6 / 14.8 / 15.2 / 14.4 / 12.8 Msamples/s; round 2's kernel without refill: optimum 28-32)
+constexpr uint32_t kConeBudget = 96;     // work units (1 per cone-triangle test, 2 per node) one lane may spend on a cone query before it is handed to a wavefront (with lane refill, round 3: 32 / 48 / 64 / 96 / 128 -> 14.6 / 14.8 / 15.2 / 14.4 / 12.8 Msamples/s; round 2's kernel without refill: optimum 28-32)
 constexpr int kSpillStack = 64 - kLdsStack;   // scratch spill entries per lane (total 64, the reference's ray stack size)
 
 // control block of one state slice (device memory)
 enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 = 27, CTL_FSDQ_COUNT0 = 28, CTL_FSDQ_COUNT1 = 29, CTL_FSDQ_HEAD = 30, CTL_NEEQ_COUNT = 31, CTL_NEEQ_HEAD = 32, CTL_COUNT0 = 0, CTL_COUNT1 = 1, CTL_HEAD_TRACE = 2, CTL_HEAD_INTERACT = 3, CTL_HEAVY_COUNT = 4, CTL_HEAVY_HEAD = 5, CTL_FSD_COUNTER = 6,
                   CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23,
+                  CTL_TPOL_COUNT0 = 41, CTL_TPOL_COUNT1 = 42, CTL_TPOL_HEAD = 43, CTL_TCONE_COUNT0 = 44, CTL_TCONE_COUNT1 = 45, CTL_TCONE_HEAD = 46,   // the staged trace kernels' queues (trace_stage_t)
                   CTL_CLS_COUNT0 = 33, CTL_CLS_HEAD0 = 37,   // the material-sorted pass A: sizes and dequeue heads of the kNumWalkClasses class queues (k_classify / k_interact_cls)
                   CTL_WORDS = 48 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
@@ -146,6 +147,14 @@ constexpr size_t kWalkWords = sizeof(walk_t) / 4;
 constexpr size_t kCtxWords = sizeof(sample_ctx_t) / 4;
 constexpr size_t kTravWords = sizeof(trav_result_t) / 4;
 #define WT_TRAV_WORD(field) (offsetof(trav_result_t, field) / 4)
+// The staged trace kernels (k_tr_axis / k_tr_cone / k_tr_policy / k_tr_tail, kernels_trace.hip) keep a walk's traversal state in memory between
+// their stages: the traced envelope and the policy's state.  The records live BEHIND the slice's traversal records, the two queues behind its heavy
+// queue (same allocations: the launch block is at its 984-byte limit, see path_state_t).
+struct trace_stage_t {
+    cone_t env;
+    axis_walk_t aw;
+};
+constexpr size_t kStageWords = sizeof(trace_stage_t) / 4;
 constexpr size_t kNumCounters = sizeof(bdpt_counters_t) / sizeof(unsigned long long);
 constexpr size_t kProfSlots = 128;   // WTGPU_PROFILE scratch counters behind the public ones
 constexpr size_t kDroppedSlot = kNumCounters + kProfSlots;   // ... and behind those: children a full cooperative traversal stack could not hold (wt/coop.h)
@@ -171,6 +180,9 @@ struct launch_args_t {
     uint32_t collect_list;    // bit 0: the cone queries keep the bounded triangle list of the interaction region; bit 1: primary triangles from the axis query always (wtgpu.hip)
 };
 
+WT_D uint32_t* trace_stage_words(const launch_args_t& a) { return a.st.trav + kTravWords * 2 * (size_t)a.st.cap; }   // [2 cap][kStageWords]
+WT_D uint32_t* trace_pol_queue(const launch_args_t& a) { return a.st.heavy_queue + 2 * (size_t)a.st.cap; }
+WT_D uint32_t* trace_cone_queue(const launch_args_t& a) { return a.st.heavy_queue + 4 * (size_t)a.st.cap; }
 // (block size as a constant: blockDim would pull 256 bytes of hidden kernel arguments into the kernel-argument segment)
 WT_D void lds_stack(stack_entry_t* lds, stack_entry_t* spill, stack_ref_t& s, uint32_t block = kBlock) {
     s = make_stack_ref(lds + threadIdx.x, block, kLdsStack + kSpillStack, kLdsStack, spill);
@@ -339,6 +351,11 @@ constexpr uint32_t kSplatCols = kBlock + 2;  // k_connect_splat_tiled: columns o
 #endif
 __global__ void k_generate(launch_args_t a);
 __global__ void k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round);
+__global__ void k_trace_sm(launch_args_t a, int in, int first_round, uint32_t round);
+__global__ void k_tr_axis(launch_args_t a, int in, int first_round, uint32_t round);
+__global__ void k_tr_cone(launch_args_t a, uint32_t it);
+__global__ void k_tr_policy(launch_args_t a, uint32_t it);
+__global__ void k_tr_tail(launch_args_t a, uint32_t it);
 __global__ void k_trace_heavy(launch_args_t a);
 __global__ void k_interact(launch_args_t a, int in, int first_round);
 __global__ void k_classify(launch_args_t a, int in, int first_round);

@@ -14,6 +14,10 @@ int wtgpu_scene_create_named_hooks(const char* name, const wtgpu_scene_params* p
 int wtgpu_scene_compare(const wtgpu_scene* a, const wtgpu_scene* b, char* what, size_t n_what);
 /* the same restricted to one part: "sensor", "opts" or "emitters" (records that do not depend on the geometry) */
 int wtgpu_scene_compare_part(const wtgpu_scene* a, const wtgpu_scene* b, const char* part, char* what, size_t n_what);
+/* WTGPU_TRACE_AB=n (environment, read at upload): the first n rounds of every batch replay their trace queue through k_trace_refill and k_trace_sm (the
+ * pipeline continues from the second one's output).  Accumulated since upload: event-timed milliseconds of each kernel, words of their outputs
+ * (traversal records, triangle lists, heavy-queue checksums) that differ, walks and rounds replayed. */
+int wtgpu_trace_ab_stats(wtgpu_scene* s, double* ms_refill, double* ms_sm, uint64_t* differing_words, uint64_t* walks, uint64_t* rounds);
 #ifdef __cplusplus
 }
 #endif
