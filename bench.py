@@ -304,8 +304,8 @@ def main():
             sc.close()
             torch.cuda.empty_cache()
             # (the brackets of the material-sorted pass A and of the staged connections span several kernels: their bytes are summed)
-            staged = os.environ.get("WTGPU_STAGED_CONNECT", "1") != "0"
-            sorted_a = os.environ.get("WTGPU_SORTED_INTERACT", "1") != "0"
+            staged = os.environ.get("WTGPU_STAGED_CONNECT", "0") != "0"
+            sorted_a = os.environ.get("WTGPU_SORTED_INTERACT", "0") != "0"
             kname = {"k_trace": "k_trace_refill", "k_connect": ("k_connect_eval", "k_connect_shadow", "k_connect_mis") if staged else "k_connect_strat",
                      "k_interact": ("k_classify", "k_interact_diffuse", "k_interact_dielectric", "k_interact_spm", "k_interact_any") if sorted_a else "k_interact",
                      "k_edges+k_interact_b": "k_interact_b",

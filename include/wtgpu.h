@@ -86,11 +86,11 @@ int wtgpu_scene_create_from_desc(const wtgpu_scene_desc* scene_desc_host, wtgpu_
  * with units, <include>, enabled=..., shared elements and <ref>s (bsdfs, textures, spectra, transforms); plt_bdpt / plt_path integrators; <sampler> of type
  * independent / uniform / sobolld (all served by the library's counter-based streams); perspective and virtual-plane sensors with array films (RGB / monochromatic response, polarimetric flag); spot, directional, point and area
  * emitters; diffuse, dielectric, surface_spm (dirac / fractal / gaussian profile, constant or textured roughness), twosided, scale (constant,
- * spectrum, texture), mask, normalmap and composite BSDFs; constant, checkerboard, bitmap (PNG, PFM), scale, transform, function and mix
+ * spectrum, texture), mask, normalmap and composite BSDFs; constant, checkerboard, bitmap (PNG, PFM, OpenEXR: scan-line files, NONE / RLE / ZIPS / ZIP, read through half precision), scale, transform, function and mix
  * textures; spectra by constant, rgb, blackbody, discrete, piecewise linear, ITU material, or material / emitter name (baked tables or the
  * database files of data/ior, data/emission); rectangle, cube, sphere, cylinder, prism, lens shapes and PLY / OBJ meshes with general to_world
- * transforms (a Git-LFS pointer in place of an asset: a stand-in, or skipped with -Dwtgpu_missing_assets=skip).  Not read: textured area-emitter
- * radiance, bicubic filtering, JPEG / EXR images, OBJ material groups; `sobolld`'s low-discrepancy point set itself is not reproduced (a scene that asks for it
+ * transforms (a Git-LFS pointer in place of an asset: a stand-in, or skipped with -Dwtgpu_missing_assets=skip).  OBJ meshes take a material group with `mtl` (the reference's filter).  Not read: textured area-emitter
+ * radiance, JPEG images, tiled / deep / PIZ-compressed EXR files; `sobolld`'s low-discrepancy point set itself is not reproduced (a scene that asks for it
  * renders with the same counter-based streams as every other sampler type).  `defines`: n_defines strings "name=value", the -D
  * defines of the reference's command line (src/main.cpp:805-928).  params (may be NULL): res (becomes the define "res" unless given), max_depth /
  * fsd / mis / rr / force_ray_tracing overrides, lut_* resolution, polarimetric.  Anything outside that vocabulary fails with a message. */

@@ -129,7 +129,7 @@ typedef struct wtgpu_texture {
     float scale;
     uint32_t width, height, channels, offset;   /* TEX_BITMAP: texel (x, y) channel c = texture_data[offset + (y * width + x) * channels + c] */
                                                 /* TEX_FUNCTION: the program = texture_data[offset .. offset + width) */
-    uint32_t bilinear;    /* 0: nearest, 1: bilinear */
+    uint32_t bilinear;    /* the filter — 0: nearest, 1: bilinear, 2: bicubic (the name is the public header's) */
     uint32_t uwrap, vwrap;
 } wtgpu_texture;
 

@@ -440,3 +440,20 @@ void kat_fsd_lut_sample(const void* scene_host, int which, uint64_t seed, uint32
 
 // texture addressing (wt/scene.h: tex_wrap_coord) for tests/test_textures.py
 extern "C" int kat_tex_wrap(uint32_t mode, int c, int dim) { return wt::tex_wrap_coord(mode, c, dim); }
+// one lookup of a 1-channel bitmap texture (wt/scene.h: tex_bitmap) with the given filter (0 nearest, 1 bilinear, 2 bicubic) and wrap modes
+extern "C" float kat_tex_bitmap(const float* texels, uint32_t w, uint32_t h, uint32_t filter, uint32_t uwrap, uint32_t vwrap, float u, float v) {
+    wt::scene_t sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.texture_data = texels;
+    wt::texture_t t;
+    std::memset(&t, 0, sizeof(t));
+    t.type = wt::TEX_BITMAP;
+    t.width = w;
+    t.height = h;
+    t.channels = 1;
+    t.offset = 0;
+    t.bilinear = filter;
+    t.uwrap = uwrap;
+    t.vwrap = vwrap;
+    return wt::tex_bitmap(sc, t, wt::vec2{u, v}).r;
+}

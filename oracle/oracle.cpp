@@ -308,6 +308,97 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
 }
 
 
+// Per traverse() call of a tile subset: what a predictor of "this walk's cone queries will exceed the per-lane budget" could look at, and what the
+// queries then cost.  out: n x 8 float {max work units of the call's cone queries (2 per node + 1 per triangle test; device form, unbounded budget),
+// cone radius at the axis hit, bounding-sphere radius of the axis-hit triangle, axis-hit distance, tan_alpha, x0, emitter walk (0 / 1), number of cone queries}.
+// Diagnostic tool (tools/heavy_predictor.py), not part of any parity claim.
+uint64_t oracle_profile_heavy(const void* scene_host, uint64_t seed, uint32_t tile_stride, float* out, uint64_t cap) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const uint32_t W = sc.sensor.width, H = sc.sensor.height, B = 24;
+    const uint32_t bx = (W + B - 1) / B, by = (H + B - 1) / B;
+    sample_scratch_t scr;
+    scr.tris.resize(kOracleConeTris);
+    scr.dists.resize(kOracleConeTris);
+    scr.svert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+    scr.evert.resize(((size_t)sc.opts.max_depth + 2) * kVertexWords);
+    std::vector<fsd_aperture_t> hdr(2 * (size_t)kMaxWalkIters + 8);
+    std::vector<fsd_edge_t> edges(hdr.size() * (size_t)kFsdMaxEdges);
+    uint32_t pool_counter = 0;
+    const fsd_pool_t pool{hdr.data(), edges.data(), &pool_counter, (uint32_t)hdr.size(), nullptr, 0};
+    bdpt_counters_t ctr;
+    std::memset(&ctr, 0, sizeof(ctr));
+    const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
+    uint64_t n_calls = 0;
+    for (uint32_t blk = 0; blk < bx * by; ++blk) {
+        if (tile_stride > 1 && blk % tile_stride != 0) continue;
+        const uint32_t x0 = (blk % bx) * B, y0 = (blk / bx) * B;
+        for (uint32_t y = y0; y < std::min(H, y0 + B); ++y)
+            for (uint32_t x = x0; x < std::min(W, x0 + B); ++x) {
+                const uint64_t pix = (uint64_t)y * W + x;
+                const uint64_t sample_id = (pix << 32);
+                pool_counter = 0;
+                sample_ctx_t ctx;
+                walk_t sw, ew;
+                const vertex_store_t svs{scr.svert.data(), 1, 0}, evs{scr.evert.data(), 1, 0};
+                bdpt_generate(sc, seed, sample_id, x, y, ctx, sw, ew, svs, evs);
+                for (int which = 0; which < 2; ++which) {
+                    walk_t& w = which ? ew : sw;
+                    const vertex_store_t& vs = which ? evs : svs;
+                    const uint_list_t tris{scr.tris.data(), 1, kMaxConeTris, scr.dists.data()};
+                    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+                        const cone_t env = walk_trace_envelope(sc, w);
+                        const float lambda_m = wavenum_to_wavelen_m(w.beam.k);
+                        const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
+                        // the device form of the policy, query by query
+                        float max_units = 0.f, nq = 0.f;
+                        ray_hit_t ah;
+                        const bool axis_hit = ads_intersect_ray(sc, env.o, env.d, range_t{0.f, WT_INF}, stack, ah);
+                        axis_walk_t a;
+                        aw_begin(a, lambda_m, WT_INF, axis_hit, ah, 0xFFFFFFFFu, true, false, w.prev_offset_tuid);
+                        trav_result_t r;
+                        cone_query_t q;
+                        for (;;) {
+                            const int need = aw_next(sc, env, rt, stack, a, q, r);
+                            if (need == AW_FINAL) break;
+                            if (need == AW_TEST) {
+                                aw_test_done(a, cone_attempt_too_short_by(sc, env, a.cand, a.sr, a.min_df_prog));
+                                continue;
+                            }
+                            bvh_counters_t cc;
+                            std::memset(&cc, 0, sizeof(cc));
+                            while (cq_running(q)) {
+                                while (q.s > 0 && q.leaf == 0) cq_node_step(sc, env, stack, q, &cc);
+                                if (q.leaf != 0) cq_leaf_step(sc, env, stack, tris, q, &cc);
+                            }
+                            cq_end(env, tris, q);
+                            max_units = std::max(max_units, float(kNodeBudgetCost * cc.cone_nodes + cc.cone_tri_tests));
+                            nq += 1.f;
+                            if (aw_query_done(sc, env, a, q.rec, r)) break;
+                        }
+                        if (n_calls < cap) {
+                            float* o = out + 8 * n_calls;
+                            float sph[4] = {0, 0, 0, 0};
+                            if (axis_hit) tri_bounding_sphere(sc.tri_geo[ah.tuid].a, sc.tri_geo[ah.tuid].b, sc.tri_geo[ah.tuid].c, sph);
+                            o[0] = max_units;
+                            o[1] = axis_hit ? cone_axes(env, ah.dist).x : -1.f;
+                            o[2] = sph[3];
+                            o[3] = axis_hit ? ah.dist : -1.f;
+                            o[4] = env.tan_alpha;
+                            o[5] = env.x0;
+                            o[6] = (float)which;
+                            o[7] = nq;
+                        }
+                        ++n_calls;
+                        const trav_result_t tr = traverse(sc, env, lambda_m, WT_INF, rt, stack, uint_list_t{scr.tris.data(), 1, kOracleConeTris, scr.dists.data()});
+                        w.active = bdpt_walk_step(sc, w, tr, uint_list_t{scr.tris.data(), 1, kOracleConeTris, scr.dists.data()}, vs, pool, seed, sample_id,
+                                                  which ? STREAM_EMITTER_WALK : STREAM_SENSOR_WALK, &ctr) ? 1u : 0u;
+                    }
+                }
+            }
+    }
+    return n_calls;
+}
+
 // Work profile of wt::traverse_axis (the device form of the traversal policy) on a tile subset, per CONE QUERY: how the attempts of a
 // segment end (too short / accepted / empty), what they cost, and whether the triangle that made an attempt too short — or the
 // triangle the beam started from — would also have decided the next one (the "rejecting-triangle cache" of traverse_axis).

@@ -127,3 +127,44 @@ def test_wrap_modes_and_texel_addressing():
         for dim in (1, 2, 5):
             for c in range(-12, 13):
                 assert lib.kat_tex_wrap(mi, c, dim) == ref(mode, c, dim), (mode, c, dim)
+
+
+def test_bicubic_filter_is_the_reference_s_catmull_rom(built):
+    """texture2d_t::bicubic_native (include/wt/bitmap/texture2d.hpp:316-343), the reference's DEFAULT bitmap filter (texture2d_storage.hpp:73): the 4 x 4
+    texels around the sample, rows filtered first, with p1 + x/2 (p2 - p0) + x^2/2 (2 p0 - 5 p1 + 4 p2 - p3) + x^3/2 (-p0 + 3 p1 - 3 p2 + p3), wrapped
+    per axis, negative lobes clamped to 0 — restated here in numpy; it interpolates the texels and reproduces a linear ramp exactly."""
+    import ctypes as C
+    from oracle_util import load_oracle
+    lib = load_oracle()
+    lib.kat_tex_bitmap.restype = C.c_float
+    lib.kat_tex_bitmap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+    lib.kat_tex_wrap.restype = C.c_int
+    rng = np.random.default_rng(4)
+    W, H = 7, 5
+    tex = rng.uniform(0.1, 1.0, (H, W)).astype(np.float32)
+
+    def cubic(x, p0, p1, p2, p3):
+        return p1 + .5 * x * (-p0 + p2) + .5 * x * x * (2 * p0 - 5 * p1 + 4 * p2 - p3) + .5 * x * x * x * (-p0 + 3 * p1 - 3 * p2 + p3)
+
+    def texel(x, y, uw, vw):
+        x, y = lib.kat_tex_wrap(uw, int(x), W), lib.kat_tex_wrap(vw, int(y), H)
+        if x < 0 or y < 0:
+            return 0.0 if (uw if x < 0 else vw) == 0 else 1.0
+        return float(tex[y, x])
+
+    for uw, vw in ((3, 3), (2, 4), (0, 1)):   # repeat / clamp, mirror / black, white
+        for _ in range(200):
+            u, v = rng.uniform(-0.3, 1.3, 2)
+            got = lib.kat_tex_bitmap(tex.ctypes.data, W, H, 2, uw, vw, u, v)
+            x, y = np.float32(W) * np.float32(u) - np.float32(.5), np.float32(H) * (np.float32(1) - np.float32(v)) - np.float32(.5)   # (v is flipped: texture2d.hpp:368)
+            ix, iy = int(np.floor(x)), int(np.floor(y))
+            fx, fy = float(x - np.floor(x)), float(y - np.floor(y))
+            rows = [cubic(fx, *(texel(ix + dx, iy + dy, uw, vw) for dx in (-1, 0, 1, 2))) for dy in (-1, 0, 1, 2)]
+            want = max(0.0, cubic(fy, *rows))
+            assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (uw, vw, u, v, got, want)
+    # at texel centres the filter returns the texel; on a linear ramp it is exact between them
+    for x in range(1, W - 2):
+        assert abs(lib.kat_tex_bitmap(tex.ctypes.data, W, H, 2, 2, 2, (x + .5) / W, 1 - 2.5 / H) - tex[2, x]) < 1e-6
+    ramp = (0.1 + 0.1 * np.arange(8, dtype=np.float32))[None, :].repeat(4, 0).copy()
+    for u in np.linspace(0.2, 0.8, 13):
+        assert abs(lib.kat_tex_bitmap(ramp.ctypes.data, 8, 4, 2, 2, 2, u, 0.5) - (0.1 + 0.1 * (8 * u - .5))) < 1e-6

@@ -11,6 +11,7 @@
 // Read here: single-part scan-line files, compression NONE, RLE, ZIPS, ZIP, pixel types UINT / HALF / FLOAT, any data window, any line order,
 // x / y sampling 1.  Refused with a message: tiled, multi-part and deep files, luminance-chroma (RY / BY) files, the PIZ / PXR24 / B44 / DWA
 // codecs (re-save such a file with ZIP compression).
+#include <limits>
 #include <zlib.h>
 
 #include <algorithm>
@@ -168,6 +169,11 @@ std::vector<float> load_exr(const std::string& path, uint32_t& width, uint32_t& 
     {   // a scan-line block costs the file at least its 8-byte table entry and its 8-byte header: a window the file cannot hold is a damaged header
         const uint64_t blocks = ((uint64_t)H + (compression == 3 ? 15u : 0u)) / (compression == 3 ? 16u : 1u);
         if (blocks * 16 > b.size()) fail("data window of " + std::to_string(H64) + " lines in a file of " + std::to_string(b.size()) + " bytes");
+        // ... and its pixels at least 1/1000 of their raw size (a flat image under ZIP shrinks ~1000-fold at best): a window the file cannot plausibly hold
+        // would otherwise be met with a multi-gigabyte allocation instead of a message
+        const uint64_t raw_bytes = (uint64_t)W * H * 2u * (uint64_t)chans.size();
+        if (raw_bytes / 1000u > b.size() + 65536u)
+            fail("data window of " + std::to_string(W64) + " x " + std::to_string(H64) + " pixels in a file of " + std::to_string(b.size()) + " bytes");
     }
     int slot[5] = {-1, -1, -1, -1, -1};   // R G B A Y -> index into chans
     size_t row_bytes = 0;
@@ -183,10 +189,17 @@ std::vector<float> load_exr(const std::string& path, uint32_t& width, uint32_t& 
         for (int k = 0; k < 5; ++k)
             if (c.name == names[k]) slot[k] = (int)i;
     }
+    // (a luminance file with alpha — Y + A, no colours — is RGBA with R = G = B = Y, as RgbaInputFile reads it)
+    const bool y_as_rgb = slot[4] >= 0 && slot[0] < 0 && slot[1] < 0 && slot[2] < 0 && slot[3] >= 0;
     const bool rgba = slot[0] >= 0 || slot[1] >= 0 || slot[2] >= 0 || slot[3] >= 0;
     if (!rgba && slot[4] < 0) fail("none of the channels R, G, B, A, Y");
     const uint32_t C = rgba ? 4u : 1u;
-    std::vector<float> px((size_t)W * H * C);
+    std::vector<float> px;
+    try {
+        px.assign((size_t)W * H * C, 0.f);
+    } catch (const std::bad_alloc&) {
+        fail("data window of " + std::to_string(W64) + " x " + std::to_string(H64) + " pixels: out of memory");
+    }
     if (rgba)
         for (size_t i = 0; i < (size_t)W * H; ++i) px[4 * i + 3] = 1.f;   // RgbaInputFile's fill value for a missing A (missing colours: 0)
     const uint32_t lines_per_block = compression == 3 ? 16u : 1u;
@@ -246,12 +259,13 @@ std::vector<float> load_exr(const std::string& path, uint32_t& width, uint32_t& 
                 }
                 uint32_t u;
                 std::memcpy(&u, q + 4 * (size_t)x, 4);
-                return through_half((float)std::min<uint32_t>(u, 65504u));
+                return u > 65504u ? std::numeric_limits<float>::infinity() : through_half((float)u);   // (beyond half's range: +inf, like the half conversion)
             };
             for (uint32_t x = 0; x < W; ++x) {
                 if (rgba) {
                     for (int k = 0; k < 4; ++k)
                         if (slot[k] >= 0) out[4 * (size_t)x + (size_t)k] = read(slot[k], x);
+                    if (y_as_rgb) out[4 * (size_t)x] = out[4 * (size_t)x + 1] = out[4 * (size_t)x + 2] = read(slot[4], x);
                 } else
                     out[x] = read(slot[4], x);
             }

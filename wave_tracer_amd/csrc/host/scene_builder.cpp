@@ -680,14 +680,15 @@ int scene_builder_t::add_texture_checkerboard(int tex1, int tex2) {
     textures_.push_back(t);
     return (int)textures_.size() - 1;
 }
-int scene_builder_t::add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, bool bilinear, uint32_t uwrap, uint32_t vwrap) {
+int scene_builder_t::add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, uint32_t filter, uint32_t uwrap, uint32_t vwrap) {
     if (!width || !height || channels < 1 || channels > 4 || !texels) throw std::runtime_error("bitmap texture: width, height > 0 and 1..4 channels expected");
     texture_t t = texture_base(TEX_BITMAP);
     t.width = width;
     t.height = height;
     t.channels = channels;
     t.offset = (uint32_t)texture_data_.size();
-    t.bilinear = bilinear ? 1u : 0u;
+    if (filter > 2u) throw std::runtime_error("bitmap texture: filter 0 (nearest), 1 (bilinear) or 2 (bicubic) expected");
+    t.bilinear = filter;
     t.uwrap = uwrap;
     t.vwrap = vwrap;
     texture_data_.insert(texture_data_.end(), texels, texels + (size_t)width * height * channels);

@@ -91,7 +91,7 @@ public:
     int add_texture_constant(float r, float g, float b, float a = 1.f);
     int add_texture_checkerboard(int tex1, int tex2);
     // float texels, rows from the image's top, 1..4 channels; wrap: wt::WRAP_*
-    int add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, bool bilinear, uint32_t uwrap, uint32_t vwrap);
+    int add_texture_bitmap(uint32_t width, uint32_t height, uint32_t channels, const float* texels, uint32_t filter /* 0 nearest, 1 bilinear, 2 bicubic */, uint32_t uwrap, uint32_t vwrap);
     // function / mix textures (texture/function.hpp, texture/mix.hpp): a postfix program of (wt::TOP_*, argument) pairs; TOP_TEX arguments are
     // texture ids — a nested FUNCTION texture is inlined (its own transform / scale must be the identity: wrap its operands instead)
     int add_texture_function(const std::vector<float>& program);

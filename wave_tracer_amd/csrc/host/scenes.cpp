@@ -551,17 +551,17 @@ static void build_textured(const scene_params_t& p, scene_builder_t& b, const st
                 tx[y * 4 + x] = ((iu % 2) == (iv % 2)) ? .8f : .2f;
             }
         mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
-        b.material(mat).refl_tex = 1 + b.add_texture_bitmap(4, 4, 1, tx, false, WRAP_REPEAT, WRAP_REPEAT);
+        b.material(mat).refl_tex = 1 + b.add_texture_bitmap(4, 4, 1, tx, 0u, WRAP_REPEAT, WRAP_REPEAT);
     } else if (variant == "bilinear_flat") {   // bilinear filtering of equal texels, scaled by 2 (texture/scale.hpp): 0.25 * 2 = the plain 0.5
         const float tx[6] = {.25f, .25f, .25f, .25f, .25f, .25f};
         mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
-        const int t = b.add_texture_bitmap(3, 2, 1, tx, true, WRAP_MIRROR, WRAP_CLAMP);
+        const int t = b.add_texture_bitmap(3, 2, 1, tx, 1u, WRAP_MIRROR, WRAP_CLAMP);
         b.texture_set_scale(t, 2.f);
         b.material(mat).refl_tex = 1 + t;
     } else if (variant == "bilinear_ramp") {   // 2 x 1 texels 0.2 | 0.8, clamped: a linear ramp in u between the texel centres u = .25 and .75
         const float tx[2] = {.2f, .8f};
         mat = b.add_material(mat_diffuse(b.spectrum_const(1.f), 1.f, true));
-        b.material(mat).refl_tex = 1 + b.add_texture_bitmap(2, 1, 1, tx, true, WRAP_CLAMP, WRAP_CLAMP);
+        b.material(mat).refl_tex = 1 + b.add_texture_bitmap(2, 1, 1, tx, 1u, WRAP_CLAMP, WRAP_CLAMP);
     } else if (variant == "mask") {   // holes: opacity 1 / 0 in a checkerboard
         const int inner = b.add_material(mat_diffuse(b.spectrum_const(.5f), 1.f, false));
         mat = b.add_material(mat_mask(inner, 1.f, true));

@@ -878,7 +878,7 @@ struct loader_t {
     // ---- textures (src/texture/texture_loader.cpp:30-62): constant, checkerboard (colour1 / colour2: a texture or a constant spectrum,
     // defaults 0 and 1), scale (constant `scale` spectrum x nested texture), transform (<matrix value="a,b,c,d"/>, <translate value="x,y"/>
     // on the uv of a nested texture), bitmap (<path>: a PNG (host/png_loader.cpp) or PFM file, colour_encoding, gamma, filter_type
-    // nearest | bilinear, wrap_mode[_u|_v] black | white | clamp | repeat | mirror).  Luminance (wavelength-independent) values; RGB bitmaps
+    // nearest | bilinear | bicubic (the default, as in the reference), wrap_mode[_u|_v] black | white | clamp | repeat | mirror).  Luminance (wavelength-independent) values; RGB bitmaps
     // only for normal maps.  Returns the texture id.
     static float const_of(const xnode_t& sp, const char* what) {
         if (!sp.attr("constant")) throw std::runtime_error(std::string(what) + ": a constant spectrum is expected here");
@@ -938,11 +938,11 @@ struct loader_t {
             std::string file = pth ? pth->get("value") : n.get("bitmap");
             if (file.empty()) throw std::runtime_error("(bitmap texture loader) path must be provided");
             if (file[0] != '/') file = base_dir + "/" + file;
-            bool bilinear = true;
+            uint32_t bilinear = 2u;   // the filter: bicubic unless the scene says otherwise, like the reference (texture2d_storage.hpp:73)
             if (const xnode_t* f = n.named("filter_type")) {
                 const std::string v = f->get("value");
-                if (v != "nearest" && v != "bilinear") throw std::runtime_error("bitmap filter_type \"" + v + "\" is not supported (nearest | bilinear)");
-                bilinear = v == "bilinear";
+                if (v != "nearest" && v != "bilinear" && v != "bicubic") throw std::runtime_error("bitmap filter_type \"" + v + "\" is not supported (nearest | bilinear | bicubic)");
+                bilinear = v == "nearest" ? 0u : (v == "bilinear" ? 1u : 2u);
             }
             uint32_t uw = WRAP_REPEAT, vw = WRAP_REPEAT;
             if (const xnode_t* w = n.named("wrap_mode")) uw = vw = wrap_of(w->get("value"));

@@ -294,29 +294,30 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_MIS) k_connect_mis(launch_arg
     for (;;) {
         const uint32_t k = wave_grab(cctl + CHUNK_MIS_HEAD) + (threadIdx.x & 63);
         if (k - (threadIdx.x & 63) >= n) break;
-        if (k >= n) continue;
-        const conn_pending_t& r = x.pend[x.surv[k]];
-        const uint32_t i = r.i, st = r.st;
-        const int s = (int)(st & 0xFFFFu), t = (int)((st >> 16) & 0x7FFFu);
-        stokes_t L;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) L.s[c] = r.L[c];
-        const uint64_t j = a.j0 + i;
-        const uint32_t pix = (uint32_t)(j % a.npix);
-        const uint64_t smp = a.sample_begin + j / a.npix;
-        const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
-        sample_ctx_t ctx;
-        soa_load(a.st.ctx, kCtxWords, i, ctx);
-        const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
-        vertex_nb_t tv;
-        sensor_element_t element;
-        bool has_element = false;
-        if (s <= 1 || t <= 1) bdpt_connect_temp(a.sc, svs, evs, s, t, a.seed, sample_id, tv, element, has_element);
-        const stokes_t flux = bdpt_strategy_finish(a.sc, pool, a.film, svs, evs, s, t, ctx, L, tv, element, has_element, &ctr);
-        if (t > 1) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
+        if (k < n) {   // (no divergent `continue` in front of the loop header's grab: wave_grab0 assumes a converged wavefront)
+            const conn_pending_t& r = x.pend[x.surv[k]];
+            const uint32_t i = r.i, st = r.st;
+            const int s = (int)(st & 0xFFFFu), t = (int)((st >> 16) & 0x7FFFu);
+            stokes_t L;
+    #pragma unroll
+            for (int c = 0; c < 4; ++c) L.s[c] = r.L[c];
+            const uint64_t j = a.j0 + i;
+            const uint32_t pix = (uint32_t)(j % a.npix);
+            const uint64_t smp = a.sample_begin + j / a.npix;
+            const uint64_t sample_id = ((uint64_t)pix << 32) | (smp & 0xFFFFFFFFull);
+            sample_ctx_t ctx;
+            soa_load(a.st.ctx, kCtxWords, i, ctx);
+            const vertex_store_t svs{a.st.verts, a.st.vert_words, i}, evs{a.st.verts, a.st.vert_words, (size_t)a.st.cap + i};
+            vertex_nb_t tv;
+            sensor_element_t element;
+            bool has_element = false;
+            if (s <= 1 || t <= 1) bdpt_connect_temp(a.sc, svs, evs, s, t, a.seed, sample_id, tv, element, has_element);
+            const stokes_t flux = bdpt_strategy_finish(a.sc, pool, a.film, svs, evs, s, t, ctx, L, tv, element, has_element, &ctr);
+            if (t > 1) {
+    #pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (flux.s[c] != 0.f) unsafeAtomicAdd(&a.st.lacc[(size_t)c * a.st.cap + i], (double)flux.s[c]);
+            }
         }
     }
     if (a.count_stats) {

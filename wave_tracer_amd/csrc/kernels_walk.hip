@@ -139,7 +139,7 @@ WT_D void interact_body(const launch_args_t& a, int in, int first_round) {
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 
-// ---- pass A, material-sorted (the default; k_interact, one kernel for every walk, stays as the A/B reference: WTGPU_SORTED_INTERACT=0) ------------------------------
+// ---- pass A, material-sorted (WTGPU_SORTED_INTERACT=1|2; the default is k_interact above, one kernel for every walk: DESIGN.md §4) ------------------------------
 // k_classify (lane / walk of the round's queue): the primary triangle (wt/bdpt.h: bdpt_classify — ballistic hit, the trace kernels' axis hit of an
 // overflowed region, or a scan of the region's list) goes back into the walk's traversal record, and the walk goes into the queue of its CLASS — the
 // BSDF type of the hit shape's material (one byte per triangle, built at upload), WCLS_ANY for wrapped materials — or, without a primary triangle,

@@ -129,7 +129,7 @@ struct texture_t {
     float scale;
     uint32_t width, height, channels, offset;   // TEX_BITMAP: texel (x, y) channel c = texture_data[offset + (y * width + x) * channels + c]
                                                 // TEX_FUNCTION: the program = texture_data[offset .. offset + width)
-    uint32_t bilinear;    // 0: nearest, 1: bilinear
+    uint32_t bilinear;    // the filter — 0: nearest, 1: bilinear, 2: bicubic (the name is the public header's)
     uint32_t uwrap, vwrap;
 };
 
@@ -310,12 +310,31 @@ WT_HD rgba_t tex_texel(const scene_t& sc, const texture_t& t, int x, int y) {
 WT_HD rgba_t tex_mix(rgba_t a, rgba_t b, float f) { return {a.r + (b.r - a.r) * f, a.g + (b.g - a.g) * f, a.b + (b.b - a.b) * f, a.a + (b.a - a.a) * f}; }
 // texture2d.hpp:284-310, 356-392 (v is flipped: uv (0,0) is the image's bottom-left corner); filtered texels are clamped to be
 // non-negative (the default texel_clamp_mode)
+// the reference's cubic (texture2d.hpp:323-329), term by term
+WT_HD float tex_cubic(float x, float p0, float p1, float p2, float p3) {
+    return p1 + .5f * x * (-p0 + p2) + .5f * x * x * (2.f * p0 - 5.f * p1 + 4.f * p2 - p3) + .5f * x * x * x * (-p0 + 3.f * p1 - 3.f * p2 + p3);
+}
 WT_HD rgba_t tex_bitmap(const scene_t& sc, const texture_t& t, vec2 uv) {
     uv.y = 1.f - uv.y;
     const float u = float(t.width) * uv.x - .5f, v = float(t.height) * uv.y - .5f;
     rgba_t r;
     if (!t.bilinear) {
         r = tex_texel(sc, t, (int)roundf(u), (int)roundf(v));
+    } else if (t.bilinear == 2u) {
+        // texture2d_t::bicubic_native (include/wt/bitmap/texture2d.hpp:316-343: Catmull-Rom over the 4 x 4 texels around the sample, rows first) — the
+        // reference's DEFAULT filter (texture2d_storage.hpp:73); negative lobes are clamped below like every other filter's result
+        const float fu = floorf(u), fv = floorf(v);
+        const int iu = (int)fu, iv = (int)fv;
+        const float fx = u - fu, fy = v - fv;
+        rgba_t ts[4];
+        for (int y = 0; y < 4; ++y) {
+            const rgba_t p0 = tex_texel(sc, t, iu - 1, iv + y - 1), p1 = tex_texel(sc, t, iu, iv + y - 1), p2 = tex_texel(sc, t, iu + 1, iv + y - 1),
+                         p3 = tex_texel(sc, t, iu + 2, iv + y - 1);
+            ts[y] = rgba_t{tex_cubic(fx, p0.r, p1.r, p2.r, p3.r), tex_cubic(fx, p0.g, p1.g, p2.g, p3.g), tex_cubic(fx, p0.b, p1.b, p2.b, p3.b),
+                           tex_cubic(fx, p0.a, p1.a, p2.a, p3.a)};
+        }
+        r = rgba_t{tex_cubic(fy, ts[0].r, ts[1].r, ts[2].r, ts[3].r), tex_cubic(fy, ts[0].g, ts[1].g, ts[2].g, ts[3].g), tex_cubic(fy, ts[0].b, ts[1].b, ts[2].b, ts[3].b),
+                   tex_cubic(fy, ts[0].a, ts[1].a, ts[2].a, ts[3].a)};
     } else {
         const float fu = floorf(u), fv = floorf(v);
         const int iu = (int)fu, iv = (int)fv;
