@@ -242,7 +242,7 @@ double shading_normals_correction(bool backward, double wig, double wog, double 
 // checks, what reaches the vertex bookkeeping — over primitives that each do one thing (a ray-triangle test, a BSDF sample, one
 // triangle's Gaussian integral, an aperture construction: prims.h).
 void random_walk(ctx_t& c, walk& w, int guard = 0) {
-    if (guard >= 96) return;   // the checker's iteration cap (wt/bdpt.h: kMaxWalkIters, typed again here); never reached in the shipped scenes
+    if (guard >= 4096) return;   // the checker's bound against a walk that never ends (wt/bdpt.h: kWalkIterLimit, typed again here); never reached in the shipped scenes
     const vertex& last = w.verts.back();
     uint32_t off_tuid = 0xFFFFFFFFu;
     float png[3] = {0, 0, 1};
@@ -826,7 +826,7 @@ cpair do_fsd(path_ctx_t& c, const prim_beam& cone_from_src, const prim_geo& src_
 double power_mis(double pd1, double pd2) { return pd2 == 0 ? 1.0 : pd1 * pd1 / (pd1 * pd1 + pd2 * pd2); }
 
 void path_random_walk(path_ctx_t& c, path_walk& w, double L[4], int depth, int guard, uint32_t& n_wedges) {
-    if (guard >= 96) return;   // the checker's iteration cap (wt/bdpt.h: kMaxWalkIters, typed again here)
+    if (guard >= 4096) return;   // the checker's bound against a walk that never ends (wt/bdpt.h: kWalkIterLimit, typed again here)
     prim_trav tr;
     prim_trace(c.sc, &w.beam, w.prev_geo.kind == 1 ? w.prev_geo.id : 0xFFFFFFFFu, w.prev_geo.ng, &tr);
     c.ctr[0]++;

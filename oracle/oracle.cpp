@@ -71,7 +71,7 @@ void run_walk(const scene_t& sc, walk_t& w, const vertex_store_t& vs, const fsd_
               sample_scratch_t& scr, bdpt_counters_t& ctr) {
     const stack_ref_t stack = make_flat_stack(scr.stack, kOracleStack);
     const uint_list_t tris{scr.tris.data(), 1, kOracleConeTris, g_region_filter ? scr.dists.data() : nullptr};
-    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+    for (uint32_t it = 0; it < kWalkIterLimit && w.active; ++it) {
         const cone_t env = walk_trace_envelope(sc, w);
         const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
         trav_result_t tr = g_walk_axis ? traverse_axis(sc, env, wavenum_to_wavelen_m(w.beam.k), WT_INF, rt, stack, tris, nullptr, g_walk_axis == 4 ? 12u : 0xFFFFFFFFu, g_walk_axis != 3, false,
@@ -122,7 +122,7 @@ void run_path_sample(const scene_t& sc, const film_t& film, uint64_t seed, uint6
     const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
     path_walk_t pw;
     path_generate(sc, seed, sample_id, x, y, pw);
-    for (uint32_t it = 0; it < kMaxWalkIters && pw.w.active; ++it) {
+    for (uint32_t it = 0; it < kWalkIterLimit && pw.w.active; ++it) {
         const cone_t env = walk_trace_envelope(sc, pw.w);
         const trav_result_t tr = g_walk_axis ? traverse_axis(sc, env, wavenum_to_wavelen_m(pw.w.beam.k), WT_INF, rt, stack, tris, nullptr, 0xFFFFFFFFu, g_walk_axis != 3, false, g_walk_axis == 1 ? pw.w.prev_offset_tuid : kInvalid)
                                              : traverse(sc, env, wavenum_to_wavelen_m(pw.w.beam.k), WT_INF, rt, stack, tris);
@@ -282,7 +282,7 @@ uint64_t oracle_profile_traversal(const void* scene_host, uint64_t seed, uint32_
                     walk_t& w = which ? ew : sw;
                     const vertex_store_t& vs = which ? evs : svs;
                     const uint_list_t tris{scr.tris.data(), 1, unbounded == 1 ? kOracleConeTris : kMaxConeTris, g_region_filter ? scr.dists.data() : nullptr};   // bounded like the device unless asked otherwise
-                    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+                    for (uint32_t it = 0; it < kWalkIterLimit && w.active; ++it) {
                         const cone_t env = walk_trace_envelope(sc, w);
                         const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
                         bvh_counters_t bc;
@@ -345,7 +345,7 @@ uint64_t oracle_profile_heavy(const void* scene_host, uint64_t seed, uint32_t ti
                     walk_t& w = which ? ew : sw;
                     const vertex_store_t& vs = which ? evs : svs;
                     const uint_list_t tris{scr.tris.data(), 1, kMaxConeTris, scr.dists.data()};
-                    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+                    for (uint32_t it = 0; it < kWalkIterLimit && w.active; ++it) {
                         const cone_t env = walk_trace_envelope(sc, w);
                         const float lambda_m = wavenum_to_wavelen_m(w.beam.k);
                         const bool rt = sc.sensor.ray_trace_only || sc.opts.force_ray_tracing;
@@ -445,7 +445,7 @@ uint64_t oracle_profile_axis(const void* scene_host, uint64_t seed, uint32_t til
                     walk_t& w = which ? ew : sw;
                     const vertex_store_t& vs = which ? evs : svs;
                     const uint_list_t tris{scr.tris.data(), 1, kMaxConeTris, scr.dists.data()};
-                    for (uint32_t it = 0; it < kMaxWalkIters && w.active; ++it) {
+                    for (uint32_t it = 0; it < kWalkIterLimit && w.active; ++it) {
                         const cone_t env = walk_trace_envelope(sc, w);
                         const float lambda_m = wavenum_to_wavelen_m(w.beam.k);
                         // the policy loop of traverse_axis, instrumented

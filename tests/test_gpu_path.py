@@ -5,6 +5,7 @@ import math
 import numpy as np
 import pytest
 
+import parity
 from test_gpu_render import _both, _rel_l1
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +33,7 @@ def test_path_image_parity(built, name, res, spp, kw, tol):
     assert np.isfinite(gpu).all() and (gpu >= 0).all()
     assert cpu.sum() > 0
     assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
-    assert _rel_l1(gpu, cpu) < tol, _rel_l1(gpu, cpu)
+    parity.check(f"gpu_path/{name}-{res}-{spp}-{sorted(kw.items())}", _rel_l1(gpu, cpu), tol)
     for key in ("segments", "connections", "surface_interactions", "null_interactions", "light_splats", "shadow_rays"):
         # (the bounded device lists — 64 triangles, 32 wedges per aperture — change a few apertures of the widest beams: DESIGN.md §5)
         assert abs(gc[key] - oc[key]) <= 1.5e-2 * max(100, oc[key]), (key, gc[key], oc[key])

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from oracle_util import oracle_render
+import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +54,7 @@ def test_image_parity_small(built, name, res, spp, kw):
     assert np.isfinite(gpu).all()
     # film weights are pure geometry: must agree to fp32 rounding
     assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
-    assert _rel_l1(gpu, cpu) < 1e-2, _rel_l1(gpu, cpu)
+    parity.check(f"image_parity_small/{name}-{res}-{spp}-{sorted(kw.items())}", _rel_l1(gpu, cpu), 1e-2)
     for key in ("segments", "vertices", "connections", "surface_interactions"):
         assert abs(gc[key] - oc[key]) <= 2e-3 * max(1, oc[key]), (key, gc[key], oc[key])
 
@@ -69,7 +70,7 @@ def test_image_parity_scenes(built, name, res, spp, kw, tol):
     sc, gpu, cpu, gc, oc, gf, cf = _both(name, res, spp, 7, **kw)
     assert np.isfinite(gpu).all()
     assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
-    assert _rel_l1(gpu, cpu) < tol, _rel_l1(gpu, cpu)
+    parity.check(f"image_parity_scenes/{name}-{res}-{spp}-{sorted(kw.items())}", _rel_l1(gpu, cpu), tol)
     for key in ("segments", "vertices", "connections", "surface_interactions"):
         assert abs(gc[key] - oc[key]) <= 5e-3 * max(20, oc[key]), (key, gc[key], oc[key])
     # the bounded device triangle list can change which silhouette edges a wide beam sees: 2 %
@@ -88,7 +89,7 @@ def test_cornell_dense_mesh_parity(built):
     assert np.allclose(gf[1], cf[1], rtol=1e-5, atol=1e-6)
     print("dense crop: rel L1", _rel_l1(gpu, cpu), "fsd", gc["fsd_interactions"], oc["fsd_interactions"], "overflow counters",
           {k: gc[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow")}, {k: oc[k] for k in ("edge_overflow", "fsd_edge_overflow")})
-    assert _rel_l1(gpu, cpu) < 2e-2, _rel_l1(gpu, cpu)
+    parity.check("cornell_dense_mesh_parity", _rel_l1(gpu, cpu), 2e-2)
     for key in ("segments", "vertices", "connections"):
         assert abs(gc[key] - oc[key]) <= 5e-3 * oc[key], (key, gc[key], oc[key])
     assert abs(gc["fsd_interactions"] - oc["fsd_interactions"]) <= 1.5e-2 * oc["fsd_interactions"] + 3, (gc["fsd_interactions"], oc["fsd_interactions"])
@@ -111,7 +112,7 @@ def test_gpu_matches_committed_golden(built, case):
     meta = json.loads(str(g["meta"]))
     img, counters = run_case(CASES[case], renderer=gpu_renderer)
     ref = g["image"].astype(np.float64)
-    assert np.abs(img - ref).sum() <= 2e-2 * np.abs(ref).sum()
+    parity.check(f"committed_golden/{case}", np.abs(img - ref).sum() / np.abs(ref).sum(), 2e-2)
     for k, v in meta["counters"].items():
         tol = 3e-2 if k == "fsd_interactions" else 5e-3      # bounded device triangle lists: see test_image_parity_scenes
         assert abs(counters[k] - v) <= tol * max(50, v), (k, counters[k], v)
@@ -324,7 +325,20 @@ def test_full_size_properties_1440(built):
     frac_same = (np.abs(gv[inner] - ov[inner]).sum(axis=1) <= 1e-3 * np.abs(ov[inner]).sum(axis=1) + 1e-30).mean()
     print("full size: rel L1", rel, "frac_same", frac_same, "counters", {k: c[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow", "fsd_interactions")},
           "oracle tiles", {k: oc5[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_interactions")})
-    assert rel < 2e-2, rel
+    parity.check("full_size_properties_1440/blocks_value", rel, 2e-2)
+    assert frac_same > 0.99, frac_same
+    # (6) the WHOLE film — value, weight and the light plane (the t <= 1 splats, which land anywhere on the film and cannot be compared block by
+    # block) — against the checker rendering all 2,073,600 samples of the same pass (15 s on the GPU box's host cores)
+    fv, fw, fl, fc = oracle_render(sc, 0, 1, 5)
+    g0 = [t.cpu().numpy() for t in films[0]]
+    assert np.allclose(g0[1], fw, rtol=1e-5, atol=1e-7)
+    parity.check("full_size_properties_1440/light_plane", np.abs(g0[2] - fl).sum() / np.abs(fl).sum(), 2e-2)
+    parity.check("full_size_properties_1440/light_sum", abs(g0[2].sum() - fl.sum()) / fl.sum(), 2e-3)
+    parity.check("full_size_properties_1440/value_plane", np.abs(g0[0] - fv).sum() / np.abs(fv).sum(), 2e-2)
+    from wave_tracer_amd import develop
+    gi, oi = develop(sc, *g0, 1).astype(np.float64), develop(sc, fv, fw, fl, 1).astype(np.float64)
+    parity.check("full_size_properties_1440/developed_image", np.abs(gi - oi).sum() / np.abs(oi).sum(), 2e-2)
+    print("full size, whole film: light rel L1", np.abs(g0[2] - fl).sum() / np.abs(fl).sum(), "light sums", g0[2].sum(), fl.sum(), "image rel L1", np.abs(gi - oi).sum() / np.abs(oi).sum())
     # 5 % of the diffusive segments of this workload see more than kMaxConeTris = 64 triangles (CPU profile: p99 = 2400, max
     # 82,000): those regions are walked in full on the device, so all but a fraction of a per cent of the pixels agree
     # with the CPU checker's unbounded lists to fp32 rounding
@@ -352,7 +366,7 @@ def test_xml_scene_renders_like_the_checker(built):
     ov, ow, ol, oc = oracle_render(sc, 0, spp, 21)
     gi, oi = develop(sc, v, w, l, spp).astype(np.float64), develop(sc, ov, ow, ol, spp).astype(np.float64)
     assert oc["fsd_interactions"] > 100 and oi.sum() > 0
-    assert np.abs(gi - oi).sum() < 2e-2 * np.abs(oi).sum()
+    parity.check("xml_scene_renders_like_the_checker", np.abs(gi - oi).sum() / np.abs(oi).sum(), 2e-2)
     c = sc.counters()
     assert abs(c["fsd_interactions"] - oc["fsd_interactions"]) <= 0.02 * oc["fsd_interactions"]
 
@@ -372,7 +386,7 @@ def test_function_textures_render_like_the_checker(built, variant, fn):
     ov, ow, ol, oc = oracle_render(sc, 0, spp, 9)
     gi, oi = develop(sc, v, w, l, spp).astype(np.float64), develop(sc, ov, ow, ol, spp).astype(np.float64)
     assert oi.sum() > 0 and np.allclose(w, ow, rtol=1e-5, atol=1e-7)
-    assert _rel_l1(gi, oi) < 1e-2, _rel_l1(gi, oi)
+    parity.check(f"function_textures/{variant}", _rel_l1(gi, oi), 1e-2)
     c = sc.counters()
     for key in ("segments", "vertices", "connections"):
         assert abs(c[key] - oc[key]) <= 5e-3 * oc[key], (key, c[key], oc[key])
@@ -419,7 +433,7 @@ def test_double_slits_full_size_1440(built):
     gi, oi = develop(sc, *g, 2).astype(np.float64), develop(sc, ov, ow, ol, 2).astype(np.float64)
     rel = np.abs(gi - oi).sum() / np.abs(oi).sum()
     print("double slits 1440x360: rel L1", rel, {k: (c[k], oc[k]) for k in ("segments", "vertices", "fsd_interactions", "light_splats")})
-    assert rel < 2e-2, rel
+    parity.check("double_slits_full_size_1440/image", rel, 2e-2)
     for k in ("segments", "vertices", "connections", "fsd_interactions", "light_splats"):
         assert abs(c[k] - oc[k]) <= 5e-3 * max(oc[k], 200), (k, c[k], oc[k])
     # (3) fringes
@@ -704,7 +718,7 @@ def test_render_with_preview_on_the_gpu(built):
     rgb = np.repeat(final, 3, axis=-1)[..., :3] if final.shape[-1] == 1 else final[..., :3]
     assert np.allclose(shown, np.moveaxis(rgb, -1, 0), rtol=1e-6, atol=0)
     ov, ow, ol, _ = oracle_render(sc, 0, 12, 5)
-    assert _rel_l1(final, develop(sc, ov, ow, ol, 12).reshape(final.shape)) < 1e-2
+    parity.check("render_with_preview", _rel_l1(final, develop(sc, ov, ow, ol, 12).reshape(final.shape)), 1e-2)
 
 
 def test_two_gpus_strong_scaling_through_rccl(built):
@@ -875,8 +889,9 @@ def test_full_size_etoile_720(built):
     gl = films[2][2].cpu().numpy()
     print("etoile 720x540:", "film sum GPU", gl.sum(), "CPU", ol.sum(), "rel L1", _rel_l1(g, cpu), {k: (c[k], oc[k]) for k in ("segments", "fsd_interactions", "light_splats", "shadow_rays")},
           "overflows", {k: c[k] for k in ("cone_tri_overflow", "edge_overflow", "fsd_edge_overflow")})
-    assert cpu.sum() > 0 and abs(gl.sum() - ol.sum()) < 1e-3 * ol.sum()
-    assert _rel_l1(g, cpu) < 2e-2
+    assert cpu.sum() > 0
+    parity.check("full_size_etoile_720/film_sum", abs(gl.sum() - ol.sum()) / ol.sum(), 1e-3)
+    parity.check("full_size_etoile_720/image", _rel_l1(g, cpu), 2e-2)
     # classified-edge sets and wedge lists are complete (k_path_edges + the per-round wedge pools): nothing truncated, like the reference's vectors
     assert c["edge_overflow"] == 0 and c["fsd_edge_overflow"] == 0 and c["fsd_pool_overflow"] == 0
     for key in ("segments", "fsd_interactions", "light_splats"):
@@ -916,7 +931,7 @@ def test_full_size_bidir_room_1920_polarimetric(built):
         assert torch.allclose(films[0][k] + films[1][k], films[2][k], rtol=1e-7, atol=1e-30)
     # (the walk-iteration cap — 96 trace/interact rounds per subpath, the CPU checker's too; the reference recurses without one — is reached by
     # a few walks in 10^6 here: beams that restart behind empty apertures over and over)
-    assert c["samples"] == 2 * npix and c["walk_iteration_cap_hits"] <= 2e-5 * c["samples"] and c["fsd_pool_overflow"] == 0 and c["traversal_stack_dropped"] == 0
+    assert c["samples"] == 2 * npix and c["walk_iteration_cap_hits"] == 0 and c["fsd_pool_overflow"] == 0 and c["traversal_stack_dropped"] == 0
     ov, ow, ol, oc5, n5, mask = oracle_render_tiles(sc, 0, 1, 5, 97)
     inner = mask.copy()
     inner[1:, :] &= mask[:-1, :]
@@ -932,7 +947,8 @@ def test_full_size_bidir_room_1920_polarimetric(built):
     print("iteration cap hits", c["walk_iteration_cap_hits"], "of", c["samples"])
     print("bidir_room 1920x1088 polarimetric: rel L1", rel, "frac_same", frac_same, "fsd", c["fsd_interactions"], "overflows",
           {k: c[k] for k in ("edge_overflow", "fsd_edge_overflow", "fsd_pool_overflow")})
-    assert rel < 2e-2 and frac_same > 0.99, (rel, frac_same)
+    parity.check("full_size_bidir_room_1920_polarimetric/blocks_value", rel, 2e-2)
+    assert frac_same > 0.99, frac_same
 
 
 def test_c1_against_the_committed_cpu_record(built):

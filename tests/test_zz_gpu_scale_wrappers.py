@@ -4,6 +4,8 @@ tests/test_gpu_render.py::test_image_parity_small.  (Last in the alphabet on pur
 import os
 
 import numpy as np
+
+import parity
 import pytest
 
 from oracle_util import oracle_render
@@ -24,7 +26,7 @@ BOX = '''<scene version="0.1.0">
 </scene>'''
 
 
-def _parity(sc, spp, seed):
+def _parity(sc, spp, seed, label):
     from wave_tracer_amd import render, develop
     v, w, l = render(sc, spp, seed=seed)
     ov, ow, ol, oc = oracle_render(sc, 0, spp, seed)
@@ -32,7 +34,7 @@ def _parity(sc, spp, seed):
     assert np.isfinite(g).all() and c.sum() > 0
     assert np.allclose(w, ow, rtol=1e-5, atol=1e-6)
     rel = np.abs(g - c).sum() / np.abs(c).sum()
-    assert rel < 1e-2, rel
+    parity.check(f"scale_wrappers/{label}", rel, 1e-2)
     gc = sc.counters()
     for key in ("segments", "vertices", "connections", "surface_interactions"):
         assert abs(gc[key] - oc[key]) <= 2e-3 * max(1, oc[key]), (key, gc[key], oc[key])
@@ -42,7 +44,7 @@ def _parity(sc, spp, seed):
 @pytest.mark.gpu
 def test_textured_scale_factor_gpu_parity(built):
     from wave_tracer_amd import Scene
-    g = _parity(Scene.from_xml(os.path.join(HERE, "data", "xml", "textured.xml"), defines={"variant": 5}), 8, 5)
+    g = _parity(Scene.from_xml(os.path.join(HERE, "data", "xml", "textured.xml"), defines={"variant": 5}), 8, 5, "textured_scale_factor")
     assert g.max() > 2 * np.median(g[g > 0])      # the checks are visible
 
 
@@ -51,7 +53,7 @@ def test_spectral_scale_factor_gpu_parity(built, tmp_path):
     from wave_tracer_amd import Scene
     f = tmp_path / "box.xml"
     f.write_text(BOX)
-    g = _parity(Scene.from_xml(str(f), lut=(32, 32)), 8, 5)
+    g = _parity(Scene.from_xml(str(f), lut=(32, 32)), 8, 5, "spectral_scale_factor")
     assert g[..., 0].sum() > 1.5 * g[..., 2].sum()     # reddish walls
 
 
@@ -67,4 +69,4 @@ def test_rgb_bitmap_uplift_gpu_parity(built, tmp_path):
     end = BOX.index('</bsdf></bsdf></bsdf>') + len('</bsdf></bsdf></bsdf>')
     f = tmp_path / "box.xml"
     f.write_text(BOX[:start] + walls + BOX[end:])
-    _parity(Scene.from_xml(str(f), lut=(32, 32)), 8, 5)
+    _parity(Scene.from_xml(str(f), lut=(32, 32)), 8, 5, "rgb_bitmap_uplift")

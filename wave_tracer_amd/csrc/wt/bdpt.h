@@ -30,10 +30,15 @@ constexpr uint32_t kMaxVerts = 18;
 // (wtgpu_counters::walk_iteration_cap_hits): none in the cornell / etoile workloads, 29 of 4.2 M samples of the full-size bidir_room test.
 // 128 rounds were measured in round 4: 16 of 4.2 M still reach the cap (those beams restart behind empty apertures over and over — a longer
 // loop is not what they lack) and the 32 more empty rounds per batch cost 2-4 % of a pass.  Kept at 96.
+// Round 6: no walk is dropped at 96 any more.  kMaxWalkIters is what the device driver launches WITHOUT LOOKING at most (and what its per-round
+// timing events are sized for); a batch whose round queue is not empty after that keeps getting rounds, eight at a time, until it is
+// (wtgpu.hip: render_finish_part), and the checker's loops run to kWalkIterLimit — a bound against a walk that never ends, 43 x the old cap, counted
+// like before if it is ever reached (walk_iteration_cap_hits; the full-size tests assert zero).
 #ifndef WT_MAX_WALK_ITERS
 #define WT_MAX_WALK_ITERS 96
 #endif
 constexpr uint32_t kMaxWalkIters = WT_MAX_WALK_ITERS;
+constexpr uint32_t kWalkIterLimit = 4096;
 constexpr uint32_t kMaxConeTris = 64;    // device cap of the cone query's triangle list
 #ifdef WT_ORACLE_UNBOUNDED
 constexpr uint32_t kMaxEdgeIds = 16384;  // CPU checker: effectively unbounded

@@ -745,7 +745,6 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
     s->acc[5] += rounds;
     s->acc[6] += 1;
     s->rounds_launched_total += r.rounds_launched;
-    if (r.rounds_launched == kMaxWalkIters) note_rounds(s, rounds);   // (a batch that got every round: what it really needed)
     if (s->timing) {
         // (an event pair that cannot be resolved contributes 0 ms: timings are diagnostics, the render itself has completed)
         auto elapsed = [](hipEvent_t a, hipEvent_t b) {
@@ -754,7 +753,7 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
         };
         s->acc[0] += elapsed(r.ev[0], r.ev[1]);
         size_t e = 1;
-        for (uint32_t k = 0; k < r.rounds_launched; ++k, e += 6) {
+        for (uint32_t k = 0; k < std::min<uint32_t>(r.rounds_launched, kMaxWalkIters); ++k, e += 6) {
             static const int slot[6] = {1, 7, 2, 8, 9, 10};   // trace, heavy trace, pass A, edges + pass B, region flux, pass C
             for (int q = 0; q < 6; ++q) s->acc[slot[q]] += elapsed(r.ev[e + q], r.ev[e + q + 1]);
         }
@@ -900,6 +899,7 @@ struct batch_launcher_t {
     } while (0)
     void rec(chunk_rec_t& r, hipStream_t st_) {
         const auto hp0_ = std::chrono::steady_clock::now();
+        if (s->timing && r.ev_used + 1 >= r.ev.size()) return;   // (rounds beyond kMaxWalkIters — a batch with a very long walk — are not timed: the last event is the batch's)
         if (s->timing && hipEventRecord(r.ev[r.ev_used++], st_) != hipSuccess) ev_fail = true;
         if (hp_on) { hp_t[31] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp0_).count(); hp_n[31]++; }
     }
@@ -1060,8 +1060,11 @@ static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
     hipStream_t st_ = s->streams[k];
     // Is the round queue empty?  If not — a batch whose walks outlasted the expectation — another kRoundsStep rounds, and look again.
     constexpr uint32_t kRoundsStep = 8;
+    // (No walk is dropped: the reference's walk has no iteration cap — null interactions and restarts behind empty apertures add rounds without adding
+    // depth, plt_bdpt_detail.hpp:421-526 — and until round 6 walks alive after kMaxWalkIters = 96 rounds were dropped and counted, 29 of 4.2 M samples of
+    // the full-size bidir_room.  kWalkIterLimit bounds a walk that never ends.)
     uint32_t launched = p.rounds_first;
-    while (launched < kMaxWalkIters) {
+    while (launched < kWalkIterLimit) {
         HIP_CHECK(hipEventSynchronize(r.ev_mid));
         const uint32_t q = launched & 1u;
         const uint32_t left = r.h_mid[CTL_COUNT0 + q] + r.h_mid[CTL_BACK0 + q];
@@ -1070,14 +1073,12 @@ static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
             break;
         }
         s->round_fallbacks++;
-        const uint32_t next = std::min<uint32_t>(kMaxWalkIters, launched + kRoundsStep);
+        const uint32_t next = std::min<uint32_t>(kWalkIterLimit, launched + kRoundsStep);
         const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, next);
         if (rc) return rc;
         launched = next;
-        if (launched < kMaxWalkIters) {
-            HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-            HIP_CHECK(hipEventRecord(r.ev_mid, st_));
-        }   // (else: every round has been launched; what the batch needed is noted when it is drained)
+        HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipEventRecord(r.ev_mid, st_));
     }
     return L.tail(a, r, st_);
 }
@@ -1192,19 +1193,14 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         rc = L.rounds(a, s->d_path_slices[k], r, st_, 0, r1);
         if (rc) return rc;
         HIP_CHECK(hipGetLastError());
-        if (r1 < kMaxWalkIters) {
-            HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-            HIP_CHECK(hipEventRecord(r.ev_mid, st_));
-        }
+        HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        HIP_CHECK(hipEventRecord(r.ev_mid, st_));
         wtgpu_scene::pending_t& p = s->pending[k];
         std::memcpy(p.args, &a, sizeof(a));
         p.rec = &r;
         p.rounds_first = r1;
         p.active = true;
-        if (r1 >= kMaxWalkIters) {   // nothing to wait for: the whole batch goes out at once, as before round 4
-            rc = render_finish_part(s, k, L);
-            if (rc) return rc;
-        }
+
     }
     L.report();
     // (wtgpu_join enqueues what is pending and makes the caller's stream continue after all of it)
