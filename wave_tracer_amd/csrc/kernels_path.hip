@@ -38,13 +38,19 @@ extern "C" int wtgpu_debug_set_watch(unsigned int* host_mapped) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_watch), &host_mapped, sizeof(host_mapped));
 }
 #endif
+// G: lanes per aperture (a power of two <= 64; the 64 / G apertures of a wavefront are independent: shuffles stay inside an aligned group of G lanes).
+// The apertures of the city-block workload hold 11 wedges on average: one aperture per wavefront leaves 5 of 6 lanes without a wedge.
+#ifndef WTGPU_FSD_GROUP
+#define WTGPU_FSD_GROUP 8   // (etoile 720 x 540: 64 / 32 / 16 / 8 lanes per aperture -> 61.8 / 73.3 / 80.6 / 84.6 Msamples/s, profiles/r06_ab_experiments.log)
+#endif
+template <int G>
 WT_D float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const path_geo_t& src_geo, vec3 dst, const utd_aperture_t& ap, const utd_edge_rec_t* recs,
-                                    float k, const stack_ref_t& stack, bdpt_counters_t* ctr) {
-    const int lane = threadIdx.x & 63;
+                                    float k, const stack_ref_t& stack, bdpt_counters_t* ctr, bool have = true) {   // have = false: the group holds no aperture (it only takes part in the shuffles)
+    const int lane = threadIdx.x & (G - 1);
     const vec3 src = cone_from_src.o;
     const path_geo_t dst_geo = path_geo_point(dst);
     double tsr = 0, tsi = 0, thr = 0, thi = 0;
-    for (uint32_t i = (uint32_t)lane; i < ap.n_edges; i += 64u) {
+    for (uint32_t i = (uint32_t)lane; have && i < ap.n_edges; i += (uint32_t)G) {
         utd_diffracting_edge_t f;
         WT_WATCH_ADD(12);
         if (lane == 0) WT_WATCH(13, i);
@@ -63,14 +69,14 @@ WT_D float coop_do_fsd(const scene_t& sc, const cone_t& cone_from_src, const pat
         thi += b.im;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = G / 2; off > 0; off >>= 1) {
         tsr += __shfl_xor(tsr, off, 64);
         tsi += __shfl_xor(tsi, off, 64);
         thr += __shfl_xor(thr, off, 64);
         thi += __shfl_xor(thi, off, 64);
     }
     cplx ts{(float)tsr, (float)tsi}, th{(float)thr, (float)thi};
-    if (cone_contains(cone_from_src, dst)) {
+    if (have && cone_contains(cone_from_src, dst)) {
         bdpt_counters_t* c0 = lane == 0 ? ctr : nullptr;
         if (!path_shadow(sc, src_geo, dst_geo, stack, c0)) {
             const cplx phase = cpolar(1.f, -k_times_len(k, length(dst - src)));
@@ -95,34 +101,30 @@ __global__ void __launch_bounds__(64, 3) k_path_fsd(launch_args_t a, const path_
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
     const utd_edge_rec_t* prev_pool = P.utd[(round + 1u) & 1u];
+    constexpr int G = WTGPU_FSD_GROUP, NG = 64 / G;
+    const uint32_t group = (threadIdx.x & 63u) / (uint32_t)G;
     for (;;) {
-        const uint32_t item = wave_grab_item(ctl + CTL_FSDQ_HEAD);
-        if (item >= n) break;
-        const uint32_t w = P.fsdq[qin][item];
-        const uint32_t empty = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)];
-        if (empty) continue;   // (the step ends before do_fsd: plt_path_detail.hpp:577-581)
+        const uint32_t item = wave_grab0(ctl + CTL_FSDQ_HEAD, (uint32_t)NG) + group;   // NG walks per wavefront, G lanes each
+        if (item - group >= n) break;
+        uint32_t w = 0;
+        bool have = item < n;
+        if (have) {
+            w = P.fsdq[qin][item];
+            have = a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(empty)] == 0;   // (an empty record: the step ends before do_fsd, plt_path_detail.hpp:577-581)
+        }
+        // (the lanes of a group read the same words: one record per group; fields the sum does not use are never loaded)
         path_walk_t pw;
-        soa_load(a.st.walks, a.st.walk_words, w, pw);   // uniform address: broadcast
-        const vec3 origin{__uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.x)]), __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.y)]),
-                          __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
-        const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
-        const vec3 interaction_wp = origin + dist * pw.w.beam.env.d;
-        if (threadIdx.x == 0) {
-            WT_WATCH(0, item);
-            WT_WATCH(1, n);
-            WT_WATCH(2, w);
-            WT_WATCH(3, pw.ap.n_edges);
-            WT_WATCH(4, round);
-            WT_WATCH(7, pw.ap.edge_offset);
+        memset(&pw, 0, sizeof(pw));
+        vec3 interaction_wp{0.f, 0.f, 0.f};
+        if (have) {
+            soa_load(a.st.walks, a.st.walk_words, w, pw);
+            const vec3 origin{__uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.x)]), __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.y)]),
+                              __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(origin.z)])};
+            const float dist = __uint_as_float(a.st.trav[(size_t)w * kTravWords + WT_TRAV_WORD(dist)]);
+            interaction_wp = origin + dist * pw.w.beam.env.d;
         }
-#ifdef WTGPU_FSD_DEBUG
-        if (pw.ap.n_edges > pw.ap.edge_cap || pw.ap.n_edges > 100000u || !pw.has_fsd) {
-            if (threadIdx.x == 0) printf("[k_path_fsd] round %u item %u/%u walk %u: n_edges %u cap %u offset %u has_fsd %u active %u nverts %u\n", round, item, n, w, pw.ap.n_edges, pw.ap.edge_cap, pw.ap.edge_offset, pw.has_fsd, pw.w.active, pw.w.nverts);
-            continue;
-        }
-#endif
-        const float f = coop_do_fsd(a.sc, pw.prev_beam.env, path_geo_prev(pw.w), interaction_wp, pw.ap, prev_pool + pw.ap.edge_offset, pw.w.beam.k, stack, &ctr);
-        if (threadIdx.x == 0) P.fsd_f[w] = f;
+        const float f = coop_do_fsd<G>(a.sc, pw.prev_beam.env, path_geo_prev(pw.w), interaction_wp, pw.ap, prev_pool + pw.ap.edge_offset, pw.w.beam.k, stack, &ctr, have);
+        if (have && (threadIdx.x & (uint32_t)(G - 1)) == 0) P.fsd_f[w] = f;
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
@@ -279,17 +281,33 @@ __global__ void __launch_bounds__(64, 3) k_path_nee(launch_args_t a, const path_
     bdpt_counters_t ctr;
     memset(&ctr, 0, sizeof(ctr));
     const utd_edge_rec_t* cur_pool = P.utd[round & 1u];
+    constexpr int G = WTGPU_FSD_GROUP, NG = 64 / G;
+    const uint32_t group = (threadIdx.x & 63u) / (uint32_t)G;
     for (;;) {
-        const uint32_t item = wave_grab_item(ctl + CTL_NEEQ_HEAD);
-        if (item >= n) break;
-        const uint32_t w = P.neeq[item];
-        const path_nee_rec_t r = P.nee_recs[w];   // uniform address
+        const uint32_t item = wave_grab0(ctl + CTL_NEEQ_HEAD, (uint32_t)NG) + group;   // NG walks per wavefront, G lanes each
+        if (item - group >= n) break;
+        const bool have = item < n;
+        const uint32_t w = have ? P.neeq[item] : 0u;
+        // what the coherent sum reads of the walk's record (the whole record — two beams — only in the lane that splats)
+        cone_t env;
+        memset(&env, 0, sizeof(env));
+        env.d = vec3{0.f, 0.f, 1.f};
+        path_geo_t src_geo{vec3{0.f, 0.f, 0.f}, 0u, vec3{0.f, 0.f, 1.f}, kInvalid};
+        vec3 dst{0.f, 0.f, 0.f};
+        float k = 0.f;
         utd_aperture_t ap;
-        soa_load(a.st.walks + offsetof(path_walk_t, ap) / 4, a.st.walk_words, w, ap);   // the aperture k_path_interact just stored
-        const path_geo_t src_geo{r.src_wp, r.src_kind, r.src_ng, r.src_tuid};
-        const float k = r.beam.k;
-        const float f = coop_do_fsd(a.sc, r.beam.env, src_geo, r.sd_beam.env.o, ap, cur_pool + ap.edge_offset, k, stack, &ctr);
-        if (threadIdx.x == 0 && f != 0.f) {
+        memset(&ap, 0, sizeof(ap));
+        if (have) {
+            const path_nee_rec_t& r = P.nee_recs[w];
+            env = r.beam.env;
+            src_geo = path_geo_t{r.src_wp, r.src_kind, r.src_ng, r.src_tuid};
+            dst = r.sd_beam.env.o;
+            k = r.beam.k;
+            soa_load(a.st.walks + offsetof(path_walk_t, ap) / 4, a.st.walk_words, w, ap);   // the aperture k_path_interact just stored
+        }
+        const float f = coop_do_fsd<G>(a.sc, env, src_geo, dst, ap, cur_pool + ap.edge_offset, k, stack, &ctr, have);
+        if (have && (threadIdx.x & (uint32_t)(G - 1)) == 0 && f != 0.f) {
+            const path_nee_rec_t r = P.nee_recs[w];
             beam_t fsd_beam = r.beam;
             beam_transform_region_interaction(fsd_beam, r.interaction_wp, r.dist, -r.sd_beam.env.d, f);
             const stokes_t sL = integrate_beams(r.sd_beam, fsd_beam);
