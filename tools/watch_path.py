@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Bring-up aid for a kernel that does not end: renders a plt_path scene with a library built with -DWTGPU_FSD_WATCH, whose k_path_fsd (and the ray
 traversal it calls) write their progress into a HOST-MAPPED buffer; a second thread prints the buffer after a few seconds and ends the process.
-usage: WTGPU_LIB=.../libwtgpu_watch.so python tools/r05/watch_path.py [scene] [res] [spp] [seconds]"""
+usage: WTGPU_LIB=.../libwtgpu_watch.so python tools/watch_path.py [scene] [res] [spp] [seconds]"""
 import ctypes as C
 import os
 import sys

@@ -636,8 +636,19 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_axis(launch_args_
     if (a.count_stats) flush_counters(a.st.counters, ctr);
 }
 // stage `it` of the cone queries: consumes the cone queue (count [it & 1]), fills the policy queue (count [(it + 1) & 1])
+// WTGPU_CONE_DEFER = n > 0: the exact cone-triangle tests of the leaf steps are DEFERRED — a leaf step only fetches and filters (cone_tri_maybe);
+// a triangle that passes waits in the lane's LDS slot until n lanes of the wavefront hold one (or nothing else can move), then all of them run
+// intersect_cone_tri together.  Same tests in the same order per lane, so the same records.
+#ifndef WTGPU_CONE_DEFER
+#define WTGPU_CONE_DEFER 0
+#endif
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_t a, uint32_t it) {
     __shared__ stack_entry_t lds[kLdsStack * kBlock];
+#if WTGPU_CONE_DEFER
+    __shared__ float lds_tri[12 * kBlock];   // the triangle a lane holds for its exact test: word k of lane l at [k * kBlock + l]
+    float* my_tri = lds_tri + threadIdx.x;
+    bool wait = false;
+#endif
     uint32_t* ctl = a.st.ctl;
     const uint32_t n = ctl[CTL_TCONE_COUNT0 + (it & 1u)];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -664,12 +675,16 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
     memset(&env, 0, sizeof(env));
     memset(&q, 0, sizeof(q));
     bool exhausted = false;   // wave-uniform: the queue holds no more queries
+    SP_DECL();
     for (;;) {
         // ---- service section: ended queries go back to the policy (or are final), idle lanes fetch
         uint32_t* slot = a.st.tris + (size_t)w * kTriListWords;
         const uint_list_t tris{slot, 1u, (a.collect_list & 1u) ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot + kMaxConeTris)};
         bool fin = false, again = false;
         trav_result_t r;
+        SP_BEGIN();
+        const unsigned long long sp_m0 = __ballot(st == 2);
+        (void)sp_m0;
         if (st == 2) {
             cq_end(env, tris, q);
             axis_walk_t aw;
@@ -684,6 +699,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
         }
         wave_append(polq, pol_count, again, w);
         tr_finish(a, ctl, ctr, fin, w, r);
+        SP_END(0, sp_m0);
         {
             const unsigned long long im = __ballot(st == 0);
             const int n_run = __popcll(__ballot(st == 1));
@@ -693,6 +709,9 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
                 base = (uint32_t)__shfl((int)base, 0, 64);
                 if (base + (uint32_t)__popcll(im) >= n) exhausted = true;
                 const uint32_t qi = base + (uint32_t)__popcll(im & below);
+                SP_BEGIN();
+                const unsigned long long sp_m1 = __ballot(st == 0 && qi < n);
+                (void)sp_m1;
                 if (st == 0 && qi < n) {
                     w = coneq[qi];
                     soa_load(stage, kStageWords, w, env);   // (the record begins with the envelope)
@@ -702,6 +721,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
                     cq_begin(a.sc, env, sr, kMajorAxisToZScale, stack, a.cone_budget, min_df_prog, q);   // (aw.probe_first is set: wt::aw_next)
                     st = cq_running(q) ? 1 : 2;
                 }
+                SP_END(1, sp_m1);
             }
         }
         const int running = __popcll(__ballot(st == 1));
@@ -714,20 +734,104 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
         uint32_t* slot2 = a.st.tris + (size_t)w * kTriListWords;
         const uint_list_t tris2{slot2, 1u, (a.collect_list & 1u) ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot2 + kMaxConeTris)};
         const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
+#if WTGPU_CONE_DEFER
+        for (;;) {
+            for (;;) {   // nodes: every lane that holds no leaf descends, until the lanes with a leaf (or a staged triangle) are the majority
+                const bool at_node = st == 1 && !wait && q.leaf == 0 && q.s > 0;
+                if (!__ballot(at_node)) break;
+                SP_BEGIN();
+                if (at_node) {
+                    cq_node_step(ns, env, stack, q);
+                    if (q.leaf != 0) {   // a leaf: charged to the budget now, its triangles filtered below
+                        const bvh8_leaf_t leaf = cq_take_leaf(q);
+                        q.leaf = leaf.count ? -(int32_t)((leaf.tris_ptr << 3) | leaf.count) : 0;   // (count 0: over budget, the query stopped)
+                    }
+                }
+                SP_END(4, __ballot(at_node));
+                if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && (q.leaf != 0 || wait))) >= WTGPU_LEAF_NUM * running) break;
+            }
+            SP_BEGIN();
+            const unsigned long long sp_m5 = __ballot(st == 1 && !wait && q.leaf != 0);
+            (void)sp_m5;
+            if (st == 1 && !wait && q.leaf != 0) {   // fetch + filter the leaf's remaining triangles up to the first that passes
+                bvh8_leaf_t leaf = bvh_leaf_of(q.leaf);
+                while (leaf.count) {
+                    const tri_geo_t tri = a.sc.tri_geo[leaf.tris_ptr];
+                    if (cone_tri_maybe(env, tri.a, tri.b, tri.c, q.range)) {
+                        my_tri[0 * kBlock] = tri.a.x; my_tri[1 * kBlock] = tri.a.y; my_tri[2 * kBlock] = tri.a.z;
+                        my_tri[3 * kBlock] = tri.b.x; my_tri[4 * kBlock] = tri.b.y; my_tri[5 * kBlock] = tri.b.z;
+                        my_tri[6 * kBlock] = tri.c.x; my_tri[7 * kBlock] = tri.c.y; my_tri[8 * kBlock] = tri.c.z;
+                        my_tri[9 * kBlock] = tri.n.x; my_tri[10 * kBlock] = tri.n.y; my_tri[11 * kBlock] = tri.n.z;
+                        wait = true;
+                        break;
+                    }
+                    ++leaf.tris_ptr;
+                    --leaf.count;
+                }
+                q.leaf = leaf.count ? -(int32_t)((leaf.tris_ptr << 3) | leaf.count) : 0;
+            }
+            SP_END(5, sp_m5);
+            {
+                const int c_wait = __popcll(__ballot(wait));
+                const bool others = __ballot(st == 1 && !wait && (q.leaf != 0 || q.s > 0)) != 0;
+                if (c_wait >= WTGPU_CONE_DEFER || (c_wait > 0 && !others)) {
+                    SP_BEGIN();
+                    const unsigned long long sp_m6 = __ballot(wait);
+                    (void)sp_m6;
+                    if (wait) {
+                        tri_geo_t tri;
+                        tri.a = vec3{my_tri[0 * kBlock], my_tri[1 * kBlock], my_tri[2 * kBlock]};
+                        tri.b = vec3{my_tri[3 * kBlock], my_tri[4 * kBlock], my_tri[5 * kBlock]};
+                        tri.c = vec3{my_tri[6 * kBlock], my_tri[7 * kBlock], my_tri[8 * kBlock]};
+                        tri.n = vec3{my_tri[9 * kBlock], my_tri[10 * kBlock], my_tri[11 * kBlock]};
+                        bvh8_leaf_t leaf = bvh_leaf_of(q.leaf);
+                        cq_exact_step_tri(env, stack, tris2, q, leaf.tris_ptr, tri);
+                        wait = false;
+                        if (q.rec.too_short)   // (cq_stop: nothing is left to visit)
+                            q.leaf = 0;
+                        else {
+                            ++leaf.tris_ptr;
+                            --leaf.count;
+                            q.leaf = leaf.count ? -(int32_t)((leaf.tris_ptr << 3) | leaf.count) : 0;
+                        }
+                    }
+                    SP_END(6, sp_m6);
+                }
+            }
+            if (st == 1 && !wait && !cq_running(q)) st = 2;
+            const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
+            if (waiting >= leave_at || !__ballot(st == 1)) break;
+        }
+#else
         for (;;) {
             for (;;) {   // nodes: every lane that holds no leaf descends, until the lanes with a leaf are the majority
                 const bool at_node = st == 1 && q.leaf == 0 && q.s > 0;
                 if (!__ballot(at_node)) break;
+                SP_BEGIN();
                 if (at_node) cq_node_step(ns, env, stack, q);
+                SP_END(4, __ballot(at_node));
                 if (WTGPU_LEAF_DEN * __popcll(__ballot(st == 1 && q.leaf != 0)) >= WTGPU_LEAF_NUM * running) break;
             }
+            SP_BEGIN();
+            const unsigned long long sp_m5 = __ballot(st == 1 && q.leaf != 0);
+            (void)sp_m5;
             if (st == 1 && q.leaf != 0) cq_leaf_step(a.sc, env, stack, tris2, q);
+            SP_END(5, sp_m5);
             if (st == 1 && !cq_running(q)) st = 2;
             const int waiting = __popcll(__ballot(st == 2)) + (exhausted ? 0 : __popcll(__ballot(st == 0)));
             if (waiting >= leave_at || !__ballot(st == 1)) break;
         }
+#endif
     }
     if (a.count_stats) flush_counters(a.st.counters, ctr);
+#ifdef WTGPU_SM_PROF
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(a.st.counters + kNumCounters + 32 + i, sp_t[i]);
+            atomicAdd(a.st.counters + kNumCounters + 40 + i, sp_l[i]);
+            atomicAdd(a.st.counters + kNumCounters + 48 + i, sp_n[i]);
+        }
+#endif
 }
 // stage `it` (>= 1) of the policy: consumes the policy queue (count [it & 1]), fills the cone queue (count [it & 1])
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_policy(launch_args_t a, uint32_t it) {

@@ -233,7 +233,7 @@ WT_HD lane_nodes_t lane_nodes(const scene_t& sc) { return lane_nodes_t{sc.nodes}
 #endif
 
 #if defined(WTGPU_FSD_WATCH) && defined(__HIPCC__)
-// (bring-up aid, tools/r05/watch_path.py: a host-mapped buffer the kernels of a hanging launch write their progress into — device printf never
+// (bring-up aid, tools/watch_path.py: a host-mapped buffer the kernels of a hanging launch write their progress into — device printf never
 // flushes from a kernel that does not end)
 __device__ volatile unsigned int* g_watch = nullptr;
 #endif

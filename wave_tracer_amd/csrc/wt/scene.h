@@ -314,27 +314,45 @@ WT_HD rgba_t tex_mix(rgba_t a, rgba_t b, float f) { return {a.r + (b.r - a.r) * 
 WT_HD float tex_cubic(float x, float p0, float p1, float p2, float p3) {
     return p1 + .5f * x * (-p0 + p2) + .5f * x * x * (2.f * p0 - 5.f * p1 + 4.f * p2 - p3) + .5f * x * x * x * (-p0 + 3.f * p1 - 3.f * p2 + p3);
 }
+// texture2d_t::bicubic_native (include/wt/bitmap/texture2d.hpp:316-343: Catmull-Rom over the 4 x 4 texels around the sample) — the reference's DEFAULT
+// filter (texture2d_storage.hpp:73); negative lobes are clamped by the caller like every other filter's result.  The reference filters the four rows
+// along x and then the results along y with p1 + x/2 (p2 - p0) + x^2/2 (2 p0 - 5 p1 + 4 p2 - p3) + x^3/2 (-p0 + 3 p1 - 3 p2 + p3); here the same
+// polynomial as a weight per texel, w(x) x w(y), accumulated in ONE loop the compiler must not unroll around ONE texel fetch (equal to the nested
+// form up to float rounding, tests/test_textures.py).  Why: sixteen inlined fetches with their wrap logic at every texture lookup site of every
+// kernel multiplied the device code's compile time by eight; a non-inlined function, or row buffers in local arrays, cost every kernel that can
+// meet a texture 50-120 spilled registers whether or not the scene has a bicubic bitmap (profiles/r06_ab_experiments.log).
+WT_HD float tex_cubic_weight(float x, int i) {
+    const float x2 = x * x, x3 = x2 * x;
+    const float w0 = .5f * (-x + 2.f * x2 - x3), w1 = .5f * (2.f - 5.f * x2 + 3.f * x3), w2 = .5f * (x + 4.f * x2 - 3.f * x3), w3 = .5f * (-x2 + x3);
+    return i == 0 ? w0 : (i == 1 ? w1 : (i == 2 ? w2 : w3));
+}
+WT_HD rgba_t tex_bicubic(const scene_t& sc, const texture_t& t, float u, float v) {
+    const float fu = floorf(u), fv = floorf(v);
+    const int iu = (int)fu, iv = (int)fv;
+    const float fx = u - fu, fy = v - fv;
+    rgba_t acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const int x = i & 3, y = i >> 2;
+        const float w = tex_cubic_weight(fx, x) * tex_cubic_weight(fy, y);
+        const rgba_t q = tex_texel(sc, t, iu + x - 1, iv + y - 1);
+        acc.r += w * q.r;
+        acc.g += w * q.g;
+        acc.b += w * q.b;
+        acc.a += w * q.a;
+    }
+    return acc;
+}
 WT_HD rgba_t tex_bitmap(const scene_t& sc, const texture_t& t, vec2 uv) {
     uv.y = 1.f - uv.y;
     const float u = float(t.width) * uv.x - .5f, v = float(t.height) * uv.y - .5f;
     rgba_t r;
     if (!t.bilinear) {
         r = tex_texel(sc, t, (int)roundf(u), (int)roundf(v));
+#if !defined(WT_NO_BICUBIC)
     } else if (t.bilinear == 2u) {
-        // texture2d_t::bicubic_native (include/wt/bitmap/texture2d.hpp:316-343: Catmull-Rom over the 4 x 4 texels around the sample, rows first) — the
-        // reference's DEFAULT filter (texture2d_storage.hpp:73); negative lobes are clamped below like every other filter's result
-        const float fu = floorf(u), fv = floorf(v);
-        const int iu = (int)fu, iv = (int)fv;
-        const float fx = u - fu, fy = v - fv;
-        rgba_t ts[4];
-        for (int y = 0; y < 4; ++y) {
-            const rgba_t p0 = tex_texel(sc, t, iu - 1, iv + y - 1), p1 = tex_texel(sc, t, iu, iv + y - 1), p2 = tex_texel(sc, t, iu + 1, iv + y - 1),
-                         p3 = tex_texel(sc, t, iu + 2, iv + y - 1);
-            ts[y] = rgba_t{tex_cubic(fx, p0.r, p1.r, p2.r, p3.r), tex_cubic(fx, p0.g, p1.g, p2.g, p3.g), tex_cubic(fx, p0.b, p1.b, p2.b, p3.b),
-                           tex_cubic(fx, p0.a, p1.a, p2.a, p3.a)};
-        }
-        r = rgba_t{tex_cubic(fy, ts[0].r, ts[1].r, ts[2].r, ts[3].r), tex_cubic(fy, ts[0].g, ts[1].g, ts[2].g, ts[3].g), tex_cubic(fy, ts[0].b, ts[1].b, ts[2].b, ts[3].b),
-                   tex_cubic(fy, ts[0].a, ts[1].a, ts[2].a, ts[3].a)};
+        r = tex_bicubic(sc, t, u, v);
+#endif
     } else {
         const float fu = floorf(u), fv = floorf(v);
         const int iu = (int)fu, iv = (int)fv;
