@@ -1,5 +1,6 @@
 // wave_tracer_amd — generation and the per-lane interaction passes A / B of plt_bdpt, the classified-edge gather (k_edges) (see wtgpu_kernels.h for the list of kernel translation units).
 #include "wtgpu_kernels.h"
+#include "kernels_trace_refill.h"
 
 namespace wtk {
 
@@ -344,5 +345,61 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT) k_interact(launch_a
 #endif
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_COOP) k_interact_coop(launch_args_t a, int in, int first_round) { interact_body<0, true>(a, in, first_round); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
+
+constexpr uint32_t kLightMaxWalks = 2048;
+// ---- LIGHT ROUNDS: many rounds of a (nearly) empty queue in ONE launch.
+// A handful of walks of some scenes outlive their batch by THOUSANDS of rounds (bidir_room: beams that graze a finely tessellated object restart behind
+// empty apertures 1800-3800 times; the reference's walk has no iteration cap, plt_bdpt_detail.hpp:421-526, and until round 6 such walks were dropped
+// after 96 rounds).  Run as rounds they cost nine launches each, paced by the host: 240 ms of host time per batch, 36 -> 16 Msamples/s.  What those
+// rounds DO is three lane-per-walk stages — trace, pass A, pass B (a null interaction is committed by pass B) — on a dozen walks.  Here ONE block
+// runs exactly those three stage bodies, round after round, with a block barrier where the stream order stood, until the queue is empty, `max_rounds`
+// are done, or a walk needs a stage this kernel does not hold — the wave-cooperative traversal (heavy queue), the whole-region edge walk (k_edges),
+// the Fraunhofer sampling passes: then it stops BEFORE that stage, says which (CTL_LIGHT_STOP), and the host continues that round with the ordinary
+// kernels (wtgpu.hip: render_finish_part).  Same stage code, same order per walk: the same results as rounds.
+__global__ void __launch_bounds__(kBlock, 2) k_light_rounds(launch_args_t a, int in, uint32_t round, uint32_t max_rounds) {
+    uint32_t* ctl = a.st.ctl;
+    uint32_t done = 0, stop = 0;
+    // (one block: a queue that is not nearly empty — a batch that outlives its expected rounds wholesale — is the host's to continue with full grids)
+    if (queue_count(ctl, in) > kLightMaxWalks) {
+        if (threadIdx.x == 0) {
+            ctl[CTL_LIGHT_DONE] = 0;
+            ctl[CTL_LIGHT_STOP] = 4;
+        }
+        return;
+    }
+    if (queue_count(ctl, in) == 0) max_rounds = 0;
+    for (; done < max_rounds; ++done) {
+        trace_refill_body(a, in, 0, round + done);
+        __threadfence();
+        __syncthreads();
+        if (ctl[CTL_HEAVY_COUNT] != 0) {
+            stop = 1;
+            break;
+        }
+        interact_body<0>(a, in, 0);
+        __threadfence();
+        __syncthreads();
+        if (ctl[CTL_GATHER_COUNT] != 0) {
+            stop = 2;
+            break;
+        }
+        interact_body<1>(a, in, 0);
+        __threadfence();
+        __syncthreads();
+        if (ctl[CTL_INTC_COUNT] != 0) {
+            stop = 3;
+            break;
+        }
+        in = 1 - in;
+        if (queue_count(ctl, in) == 0) {
+            ++done;
+            break;
+        }
+    }
+    if (threadIdx.x == 0) {
+        ctl[CTL_LIGHT_DONE] = done;
+        ctl[CTL_LIGHT_STOP] = stop;
+    }
+}
 
 }   // namespace wtk

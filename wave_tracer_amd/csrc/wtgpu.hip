@@ -62,6 +62,7 @@ struct chunk_rec_t {
     hipEvent_t ev_mid = nullptr;
     hipEvent_t ev_stagger = nullptr;   // recorded after the batch's round `stagger_round`: the next batch (on the next stream) starts there
     uint32_t rounds_launched = 0;
+    uint32_t rounds_timed = 0;   // ... of which bracketed by timing events (6 per round, in launch order)
     size_t ev_used = 0;           // timing events recorded so far (the next one closes the batch)
     size_t ev_final = 0;          // index of the event recorded after the batch's last kernel
     bool busy = false;
@@ -116,6 +117,7 @@ struct wtgpu_scene {
     // same queue, words of their outputs that differ (traversal records + triangle lists + heavy-queue checksums), walks replayed
     double ab_ms[2] = {0, 0};
     uint64_t ab_mismatch = 0, ab_walks = 0, ab_rounds = 0;
+    uint64_t light_rounds_run = 0;   // rounds k_light_rounds ran (diagnostic)
     // tuning knobs (environment, read ONCE at upload: wtgpu_scene_upload)
     struct knobs_t {
         uint32_t cone_budget = 0, count_stats = 1, profile = 0, no_lists = 0, stagger_round = 0, lane_cache = 1, heavy_cache = 1, split_queues = 1;
@@ -124,6 +126,8 @@ struct wtgpu_scene {
         uint32_t coop_io = 0, primary_axis = 0, sorted_interact = 0, staged_connect = 0, conn_pool = 16, grid_div_cls[4] = {1, 4, 2, 4};   // WTGPU_SORTED_INTERACT / WTGPU_STAGED_CONNECT = 0: the one-kernel forms (A/B); WTGPU_GRID_CLS=a,b,c,d: persistent grids of the class kernels relative to the round's
         uint32_t trace_staged = 1, trace_stages = 3, trace_staged_rounds = 4;   // ... for the first WTGPU_TRACE_STAGED_ROUNDS rounds of a batch (the long ones: a stage is a launch, and a short round is bound by its launches)   // WTGPU_TRACE_STAGED=1: the traversal in stages (k_tr_axis / k_tr_cone / k_tr_policy / k_tr_tail), WTGPU_TRACE_STAGES cone stages before the tail
         uint32_t trace_sm = 0, trace_ab = 0;   // WTGPU_TRACE_SM=1: the phase-machine trace kernel (k_trace_sm); WTGPU_TRACE_AB=n: the first n rounds replay their trace queue through both kernels (timed, outputs compared)
+        uint32_t light_rounds = 1;   // WTGPU_LIGHT_ROUNDS=0: the rounds beyond the expected ones as ordinary rounds only (k_light_rounds off)
+        uint32_t max_rounds = kWalkIterLimit;   // WTGPU_MAX_ROUNDS: rounds a batch may get before its surviving walks are dropped and counted (default: wt/bdpt.h kWalkIterLimit — nothing is dropped in any workload seen; 96 = rounds 1-5)
         uint32_t first_rounds = 0, rounds_margin = 2, tiled_splat = 1;   // WTGPU_TILED_SPLAT=0: the plain per-sample splat kernel   // WTGPU_FIRST_ROUNDS (0: adaptive), WTGPU_ROUNDS_MARGIN
         int dbg_stage = 1 << 30;
     } knobs;
@@ -460,6 +464,8 @@ static void read_knobs(wtgpu_scene* s) {
     k.shrink_r1 = u("WTGPU_SHRINK_R1", k.shrink_r1);
     k.first_rounds = std::min<uint32_t>(u("WTGPU_FIRST_ROUNDS", k.first_rounds), kMaxWalkIters);
     k.rounds_margin = u("WTGPU_ROUNDS_MARGIN", k.rounds_margin);
+    k.light_rounds = u("WTGPU_LIGHT_ROUNDS", k.light_rounds);
+    k.max_rounds = std::min<uint32_t>(kWalkIterLimit, std::max<uint32_t>(8u, u("WTGPU_MAX_ROUNDS", k.max_rounds)));
     k.tiled_splat = u("WTGPU_TILED_SPLAT", k.tiled_splat);
     k.shrink_f1 = std::max(1u, u("WTGPU_SHRINK_F1", k.shrink_f1));
     k.shrink_r2 = u("WTGPU_SHRINK_R2", k.shrink_r2);
@@ -753,11 +759,11 @@ static int drain_rec(wtgpu_scene* s, chunk_rec_t& r) {
         };
         s->acc[0] += elapsed(r.ev[0], r.ev[1]);
         size_t e = 1;
-        for (uint32_t k = 0; k < std::min<uint32_t>(r.rounds_launched, kMaxWalkIters); ++k, e += 6) {
+        for (uint32_t k = 0; k < r.rounds_timed; ++k, e += 6) {
             static const int slot[6] = {1, 7, 2, 8, 9, 10};   // trace, heavy trace, pass A, edges + pass B, region flux, pass C
             for (int q = 0; q < 6; ++q) s->acc[slot[q]] += elapsed(r.ev[e + q], r.ev[e + q + 1]);
         }
-        s->acc[3] += elapsed(r.ev[e], r.ev[e + 1]);
+        s->acc[3] += elapsed(r.ev[e], r.ev[r.ev_final]);   // (the connections' bracket: from the last timed round's end to the batch's end)
     }
     r.busy = false;
     return WTGPU_OK;
@@ -899,7 +905,7 @@ struct batch_launcher_t {
     } while (0)
     void rec(chunk_rec_t& r, hipStream_t st_) {
         const auto hp0_ = std::chrono::steady_clock::now();
-        if (s->timing && r.ev_used + 1 >= r.ev.size()) return;   // (rounds beyond kMaxWalkIters — a batch with a very long walk — are not timed: the last event is the batch's)
+        if (s->timing && r.ev_used + 1 >= r.ev.size()) return;   // (rounds beyond what the event array holds — a batch with a very long walk — are not timed: the last event is the batch's)
         if (s->timing && hipEventRecord(r.ev[r.ev_used++], st_) != hipSuccess) ev_fail = true;
         if (hp_on) { hp_t[31] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp0_).count(); hp_n[31]++; }
     }
@@ -907,6 +913,7 @@ struct batch_launcher_t {
     void generate(const launch_args_t& a, chunk_rec_t& r, hipStream_t st_) {
         r.ev_used = 0;
         r.rounds_launched = 0;
+        r.rounds_timed = 0;
         rec(r, st_);
         if (path_mode)
             HP_LAUNCH(0, k_path_generate, dim3((a.nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
@@ -914,12 +921,14 @@ struct batch_launcher_t {
             HP_LAUNCH(1, k_generate, dim3((a.nb + kBlock - 1) / kBlock), dim3(kBlock), 0, st_, a);
         rec(r, st_);
     }
-    int rounds(const launch_args_t& a, const path_state_t* ps, chunk_rec_t& r, hipStream_t st_, uint32_t r_begin, uint32_t r_end) {
+    // stage_from (plt_bdpt): the first round of the range begins at this stage — 0 trace, 1 wave-cooperative trace, 3 k_edges, 5 region sums (a round k_light_rounds stopped in)
+    int rounds(const launch_args_t& a, const path_state_t* ps, chunk_rec_t& r, hipStream_t st_, uint32_t r_begin, uint32_t r_end, int stage_from = 0) {
         const uint32_t nb = a.nb, walks_per_sample = path_mode ? 1u : 2u, gf = g_full(nb);
         const uint32_t grid_div_b = K.grid_div_b, grid_div_c = K.grid_div_c, grid_mul_flux = K.grid_mul_flux;   // persistent grids of the expensive-interaction passes relative to the round's
         const int dbg_stage = K.dbg_stage;
         for (uint32_t round = r_begin; round < r_end; ++round) {
             const int in = (int)(round & 1u), first = round == 0 ? 1 : 0;
+            if (s->timing && r.ev_used + 7 < r.ev.size()) r.rounds_timed++;   // (rec() below records this round's six events only while they fit)
             if (round == K.stagger_round && K.stagger_round > 0) {
                 HIP_CHECK(hipEventRecord(r.ev_stagger, st_));
                 s->ev_stagger_last = r.ev_stagger;
@@ -938,7 +947,8 @@ struct batch_launcher_t {
                 g0 = std::max<uint32_t>(1u, gf / shrink);
                 gh = std::max<uint32_t>(1u, std::min<uint32_t>(grid_heavy, walks_per_sample * nb) / (round < K.shrink_r1 ? 1u : (round < K.shrink_r2 ? K.shrink_h1 : 32u)));
             }
-            if (dbg_stage >= 2 + 3 * (int)round) {
+            const int sf = round == r_begin ? stage_from : 0;
+            if (sf <= 0 && dbg_stage >= 2 + 3 * (int)round) {
                 if (round < K.trace_ab) {
                     const int rc = trace_ab_round(s, a, st_, in, first, round, g0);
                     if (rc) return rc;
@@ -948,7 +958,7 @@ struct batch_launcher_t {
                     HP_LAUNCH(3, k_trace_refill, dim3(g0), dim3(kBlock), 0, st_, a, in, first, round);
             }
             rec(r, st_);
-            if (dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
+            if (sf <= 1 && dbg_stage >= 3 + 3 * (int)round) HP_LAUNCH(5, k_trace_heavy, dim3(gh), dim3(64), 0, st_, a);
             rec(r, st_);
             if (path_mode) {
                 if (round > 0) HP_LAUNCH(6, k_path_fsd, dim3(gh), dim3(64), 0, st_, a, ps, round);
@@ -962,7 +972,8 @@ struct batch_launcher_t {
                 rec(r, st_);
                 continue;
             }
-            if (K.sorted_interact) {
+            if (sf > 2) {
+            } else if (K.sorted_interact) {
                 HP_LAUNCH(11, k_classify, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
                 if (K.sorted_interact >= 2)
                     HP_LAUNCH(24, k_interact_sorted, dim3(g0), dim3(kBlock), 0, st_, a, in);
@@ -977,8 +988,8 @@ struct batch_launcher_t {
             else
                 HP_LAUNCH(11, k_interact, dim3(g0), dim3(kBlock), 0, st_, a, in, first);
             rec(r, st_);
-            HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
-            HP_LAUNCH(13, k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
+            if (sf <= 3) HP_LAUNCH(12, k_edges, dim3(gh), dim3(64), 0, st_, a);
+            if (sf <= 4) HP_LAUNCH(13, k_interact_b, dim3(std::max<uint32_t>(1u, g0 / grid_div_b)), dim3(kBlock), 0, st_, a, in);
             rec(r, st_);
             HP_LAUNCH(14, k_flux_split, dim3(std::max<uint32_t>(1u, gh / 4u)), dim3(64), 0, st_, a);
             HP_LAUNCH(15, k_flux_tasks, dim3(std::max<uint32_t>(1u, gh * grid_mul_flux)), dim3(64), 0, st_, a);
@@ -989,6 +1000,12 @@ struct batch_launcher_t {
         }
         r.rounds_launched = r_end;
         return WTGPU_OK;
+    }
+    // k_light_rounds (kernels_walk.hip) behind the rounds launched so far: whatever the batch's last walks still need, in one launch of one block
+    // (nothing, when the queue is empty; plt_bdpt only)
+    void light(const launch_args_t& a, hipStream_t st_, uint32_t launched) {
+        if (path_mode || !K.light_rounds || launched >= K.max_rounds) return;
+        HP_LAUNCH(2, k_light_rounds, dim3(1), dim3(kBlock), 0, st_, a, (int)(launched & 1u), launched, K.max_rounds - launched);
     }
     // after the batch's last round: connections (plt_bdpt) / what is left of the walks (plt_path), the control block's snapshot, the closing event
     int tail(const launch_args_t& a, chunk_rec_t& r, hipStream_t st_) {
@@ -1045,9 +1062,17 @@ static uint32_t expected_rounds(const wtgpu_scene* s) {
     if (s->knobs.first_rounds) return s->knobs.first_rounds;
     if (s->rounds_hist_n == 0) return std::min<uint32_t>(kMaxWalkIters, 32u);   // nothing seen yet: a guess
     const uint32_t n = std::min<uint32_t>(s->rounds_hist_n, 8u);
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < n; ++i) sum += s->rounds_hist[i];
-    return std::min<uint32_t>(kMaxWalkIters, (sum + n - 1) / n + s->knobs.rounds_margin);
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        sum += s->rounds_hist[i];
+        mx = std::max(mx, s->rounds_hist[i]);
+    }
+    const uint32_t mean = (sum + n - 1) / n;
+    (void)mx;
+    // (Batches that need THOUSANDS of rounds — bidir_room: a handful of walks restart behind empty apertures 1800-3800 times per 4.2 M-sample batch — are
+    // not given them up front: 4096 rounds are 37,000 launches, 330 ms of host time per batch, measured 11.9 Msamples/s against 15.8 with the rounds
+    // added as the host sees the queue still filled.  Both are far from the 36.1 of WTGPU_MAX_ROUNDS=96, which drops those walks: DESIGN.md §0.)
+    return std::min<uint32_t>(kMaxWalkIters, mean + s->knobs.rounds_margin);
 }
 // the second part of the batch pending on slice k (see batch_launcher_t); blocks the calling thread until its first part has run
 static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
@@ -1059,27 +1084,43 @@ static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
     std::memcpy(&a, p.args, sizeof(a));
     hipStream_t st_ = s->streams[k];
     // Is the round queue empty?  If not — a batch whose walks outlasted the expectation — another kRoundsStep rounds, and look again.
-    constexpr uint32_t kRoundsStep = 8;
-    // (No walk is dropped: the reference's walk has no iteration cap — null interactions and restarts behind empty apertures add rounds without adding
-    // depth, plt_bdpt_detail.hpp:421-526 — and until round 6 walks alive after kMaxWalkIters = 96 rounds were dropped and counted, 29 of 4.2 M samples of
-    // the full-size bidir_room.  kWalkIterLimit bounds a walk that never ends.)
+    uint32_t kRoundsStep = 8;   // (doubles with every look, up to 64: a batch far beyond its expectation is not looked at every 8 rounds)
     uint32_t launched = p.rounds_first;
-    while (launched < kWalkIterLimit) {
+    const bool light = !L.path_mode && s->knobs.light_rounds != 0;   // (a k_light_rounds launch stands behind the rounds enqueued so far)
+    for (;;) {
         HIP_CHECK(hipEventSynchronize(r.ev_mid));
-        const uint32_t q = launched & 1u;
-        const uint32_t left = r.h_mid[CTL_COUNT0 + q] + r.h_mid[CTL_BACK0 + q];
-        if (left == 0) {
-            note_rounds(s, r.h_mid[CTL_ROUNDS]);
-            break;
+        uint32_t stop = 0;
+        if (light && launched < s->knobs.max_rounds) {
+            launched += r.h_mid[CTL_LIGHT_DONE];
+            stop = r.h_mid[CTL_LIGHT_STOP];
+            s->light_rounds_run += r.h_mid[CTL_LIGHT_DONE];
         }
-        s->round_fallbacks++;
-        const uint32_t next = std::min<uint32_t>(kWalkIterLimit, launched + kRoundsStep);
-        const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, next);
-        if (rc) return rc;
-        launched = next;
+        if (stop >= 1 && stop <= 3) {
+            // a walk needs a stage the light kernel does not hold: the rest of THAT round by the ordinary kernels, then light again
+            static const int from[4] = {0, 1, 3, 5};
+            const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, launched + 1, from[stop]);
+            if (rc) return rc;
+            launched += 1;
+        } else {
+            const uint32_t q = launched & 1u;
+            const uint32_t left = r.h_mid[CTL_COUNT0 + q] + r.h_mid[CTL_BACK0 + q];
+            if (left == 0) {
+                note_rounds(s, std::min<uint32_t>(r.h_mid[CTL_ROUNDS], kMaxWalkIters));
+                break;
+            }
+            if (launched >= s->knobs.max_rounds) break;   // (WTGPU_MAX_ROUNDS: what is left is dropped and counted, drain_rec)
+            s->round_fallbacks++;
+            const uint32_t next = std::min<uint32_t>(s->knobs.max_rounds, launched + kRoundsStep);
+            const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, next);
+            if (rc) return rc;
+            launched = next;
+            kRoundsStep = std::min<uint32_t>(64u, kRoundsStep * 2u);
+        }
+        L.light(a, st_, launched);
         HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
         HIP_CHECK(hipEventRecord(r.ev_mid, st_));
     }
+    r.rounds_launched = launched;
     return L.tail(a, r, st_);
 }
 static int finish_all_pending(wtgpu_scene* s) {
@@ -1193,6 +1234,7 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         rc = L.rounds(a, s->d_path_slices[k], r, st_, 0, r1);
         if (rc) return rc;
         HIP_CHECK(hipGetLastError());
+        L.light(a, st_, r1);   // (the batch's last walks — a handful that restart thousands of times in some scenes — without another host round trip)
         HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
         HIP_CHECK(hipEventRecord(r.ev_mid, st_));
         wtgpu_scene::pending_t& p = s->pending[k];

@@ -62,7 +62,8 @@ enum : uint32_t { CTL_STRAT_HEAD_OPEN = 25, CTL_UTD_COUNT0 = 26, CTL_UTD_COUNT1 
                   CTL_ROUNDS = 7, CTL_STRAT_HEAD = 8, CTL_INTB_COUNT = 9, CTL_INTB_HEAD = 10, CTL_GATHER_COUNT = 11, CTL_GATHER_HEAD = 12, CTL_INTC_COUNT = 13, CTL_INTC_HEAD = 14, CTL_FTASK_COUNT = 15, CTL_FTASK_HEAD = 16, CTL_FSPLIT_HEAD = 17, CTL_EPOOL_COUNT = 18, CTL_FSD_ECOUNTER = 19, CTL_INTD_COUNT = 20, CTL_INTD_HEAD = 21, CTL_BACK0 = 22, CTL_BACK1 = 23,
                   CTL_TPOL_COUNT0 = 41, CTL_TPOL_COUNT1 = 42, CTL_TPOL_HEAD = 43, CTL_TCONE_COUNT0 = 44, CTL_TCONE_COUNT1 = 45, CTL_TCONE_HEAD = 46,   // the staged trace kernels' queues (trace_stage_t)
                   CTL_CLS_COUNT0 = 33, CTL_CLS_HEAD0 = 37,   // the material-sorted pass A: sizes and dequeue heads of the kNumWalkClasses class queues (k_classify / k_interact_cls)
-                  CTL_WORDS = 48 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
+                  CTL_LIGHT_DONE = 47, CTL_LIGHT_STOP = 48,   // k_light_rounds: whole rounds it ran, the stage the host has to continue the next one from (0: none)
+                  CTL_WORDS = 56 };   // (CTL_BACK*: see queue_append)   // (CTL_GATHER_*: queue of k_edges)
 constexpr uint32_t kTriListWords = 128;   // per-walk list storage: 64 triangle ids, or (after coop_gather) up to 96 edge ids
 constexpr uint32_t kGatherMarker = 0xFFFFFFFEu;   // trav.tuid of a walk whose interaction region was gathered
 // ... and whose Fraunhofer aperture k_edges built as well (pool slot in trav.by): with segments — the walk is already queued for pass
@@ -367,6 +368,7 @@ __global__ void k_interact_sorted(launch_args_t a, int in);
 __global__ void k_interact_coop(launch_args_t a, int in, int first_round);
 __global__ void k_edges(launch_args_t a);
 __global__ void k_interact_b(launch_args_t a, int in);
+__global__ void k_light_rounds(launch_args_t a, int in, uint32_t round, uint32_t max_rounds);
 __global__ void k_flux_split(launch_args_t a);
 __global__ void k_flux_tasks(launch_args_t a);
 __global__ void k_interact_c(launch_args_t a, int in);
