@@ -73,7 +73,7 @@ def measure_traffic(kernel, scene_args, timeout_s=240):
     # counter -> bytes factors: the newest committed calibration (profiles/rNN_pmc_traffic.json["calibration"], written by
     # tools/make_traffic_json.py from the k_calib_copy passes of tools/profile_round.sh); without one, the guide's value for FETCH_SIZE (x2) and 1
     kf, kw, cal_src = 2.0, 1.0, "MI355X_MICROARCH.md (FETCH_SIZE x 2), uncalibrated"
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
                 cal = json.load(f)["calibration"]
@@ -306,7 +306,7 @@ def main():
             # (the brackets of the material-sorted pass A and of the staged connections span several kernels: their bytes are summed)
             staged = os.environ.get("WTGPU_STAGED_CONNECT", "0") != "0"
             sorted_a = os.environ.get("WTGPU_SORTED_INTERACT", "0") != "0"
-            kname = {"k_trace": "k_trace_refill", "k_connect": ("k_connect_eval", "k_connect_shadow", "k_connect_mis") if staged else "k_connect_strat",
+            kname = {"k_trace": ("k_tr_axis", "k_tr_cone", "k_tr_policy", "k_tr_tail", "k_trace_refill") if os.environ.get("WTGPU_TRACE_STAGED", "1") != "0" else "k_trace_refill", "k_connect": ("k_connect_eval", "k_connect_shadow", "k_connect_mis") if staged else "k_connect_strat",
                      "k_interact": ("k_classify", "k_interact_diffuse", "k_interact_dielectric", "k_interact_spm", "k_interact_any") if sorted_a else "k_interact",
                      "k_edges+k_interact_b": "k_interact_b",
                      "k_flux_split+k_flux_tasks": "k_flux_tasks",
@@ -330,6 +330,31 @@ def main():
                     traffic_src = dict(traffic_src or {}, fallback="profiles/" + os.path.basename(f.name))
             except (OSError, KeyError, ValueError, StopIteration):
                 pass
+        # the same fraction against the kernels' EXCLUSIVE time: the newest committed one-stream rocprofv3 statistics of this workload (profiles/
+        # rNN_kernel_stats_streams1.csv: three 2-spp steps = 6 passes of the film), when the dominant bracket's kernels are in it — the HIP-event bracket
+        # above includes the time a kernel shares the GPU with the other two streams' kernels, this one does not
+        excl = None
+        if (args.scene, args.res) == ("cornell_box", 1440):
+            import csv
+            import glob
+            import re
+            names = {"k_trace": ("k_tr_axis", "k_tr_cone", "k_tr_policy", "k_tr_tail", "k_trace_refill"), "k_interact": ("k_interact",), "k_trace_heavy": ("k_trace_heavy",),
+                     "k_connect": ("k_connect_enum", "k_connect_scan", "k_connect_strat", "k_connect_splat_tiled")}.get(dom)
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats_streams1.csv")))
+            if names and files:
+                try:
+                    ms = 0.0
+                    with open(files[-1]) as fh:
+                        for row in csv.DictReader(fh):
+                            m = re.search(r"_ZN3wtk\d+(k_\w+?)E", row["kernel"])
+                            if m and m.group(1) in names:
+                                ms += float(row["total_ms"])
+                    if ms > 0:
+                        ms_pass = ms / 6.0
+                        ach = share * npix / (ms_pass * 1e-3) / 1e9
+                        excl = {"ms_per_pass": ms_pass, "achieved": ach, "frac": ach / 8000.0, "source": "profiles/" + os.path.basename(files[-1]), "kernels": list(names)}
+                except (OSError, KeyError, ValueError):
+                    excl = None
         out = {
             "metric": ("Msamples/sec (whole node), cornell-box 1440^2 wave-mode" if (args.scene, args.res) == ("cornell_box", 1440)
                        else f"Msamples/sec (whole node), {args.scene} res={args.res}"),
@@ -349,6 +374,7 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_per_launch,
                          "alg_bytes_per_sample_all_kernels": bytes_per_sample,
                          "whole_path": {"alg_bytes_per_step": bytes_per_sample * npix * s_rank, "achieved": whole, "frac": whole / 8000.0},
+                         "exclusive": excl,
                          # HIP-event brackets on the concurrent slice streams: each includes the time the kernel shares the GPU with the
                          # other streams' kernels, so the sum exceeds ms_per_step (exclusive times: profiles/r03_kernel_stats_streams1.csv)
                          "kernel_ms_per_step_stream_summed": {k: v / K for k, v in kernels.items()}},

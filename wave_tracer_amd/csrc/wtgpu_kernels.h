@@ -34,7 +34,7 @@ namespace wtk {
 #define WTGPU_LB_HEAVY 2   // 215 VGPRs, no spills, no scratch frame: as fast as 3 waves with 93 spilled registers, 27 GB per pass less HBM traffic
 #endif
 #ifndef WTGPU_LB_INTERACT
-#define WTGPU_LB_INTERACT 4
+#define WTGPU_LB_INTERACT 3   // (round 6, with the bicubic texture path in the kernel: 4 / 3 / 2 waves per SIMD -> 29.1-29.3 / 29.9-30.2 / 30.2 Msamples/s; until round 5: 4)
 #endif
 #ifndef WTGPU_LB_INTERACT_B
 #define WTGPU_LB_INTERACT_B 3
