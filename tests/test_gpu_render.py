@@ -206,8 +206,11 @@ def test_batches_enqueued_in_two_parts_render_the_same(built, monkeypatch):
     from wave_tracer_amd.render import alloc_films
     for name, kw in (("cornell_box", dict(res=48, mesh_detail=0)), ("etoile", dict(res=48, mesh_detail=0))):
         out = {}
-        for mode in ("96", "2", "0"):
-            monkeypatch.setenv("WTGPU_FIRST_ROUNDS", mode)
+        for mode in ("96", "2", "0", "2-nolight"):
+            # ("2": from the third round on the batch's walks run as LIGHT ROUNDS — k_light_rounds: trace, pass A and pass B of every round in one
+            # one-block launch that stops before any stage it does not hold — "2-nolight": the same rounds as ordinary rounds, eight at a time)
+            monkeypatch.setenv("WTGPU_FIRST_ROUNDS", mode.split("-")[0])
+            monkeypatch.setenv("WTGPU_LIGHT_ROUNDS", "0" if mode.endswith("nolight") else "1")
             sc = Scene(name, **kw)
             sc.upload(0, 512)                       # 512 samples per batch: ~4 batches per sample per element
             dev = torch.device("cuda", 0)
@@ -223,7 +226,7 @@ def test_batches_enqueued_in_two_parts_render_the_same(built, monkeypatch):
             sc.close()
         ref, cref, tref = out["96"]
         assert tref["rounds_per_batch"] == 96
-        for mode in ("2", "0"):
+        for mode in ("2", "0", "2-nolight"):
             films, c, t = out[mode]
             for a, b in zip(films, ref):
                 assert np.allclose(a, b, rtol=1e-9, atol=1e-30), (name, mode)
