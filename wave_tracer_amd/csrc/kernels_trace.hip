@@ -427,6 +427,9 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_axis(launch_args_
 // WTGPU_CONE_DEFER = n > 0: the exact cone-triangle tests of the leaf steps are DEFERRED — a leaf step only fetches and filters (cone_tri_maybe);
 // a triangle that passes waits in the lane's LDS slot until n lanes of the wavefront hold one (or nothing else can move), then all of them run
 // intersect_cone_tri together.  Same tests in the same order per lane, so the same records.
+#ifndef WTGPU_CONE_REFILL_MIN
+#define WTGPU_CONE_REFILL_MIN 16   // idle lanes of a wavefront before it fetches queries again (k_trace_refill has its own: WTGPU_REFILL_MIN)
+#endif
 #ifndef WTGPU_CONE_DEFER
 #define WTGPU_CONE_DEFER 0
 #endif
@@ -491,7 +494,7 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
         {
             const unsigned long long im = __ballot(st == 0);
             const int n_run = __popcll(__ballot(st == 1));
-            if (!exhausted && im && (__popcll(im) >= WTGPU_REFILL_MIN || n_run == 0)) {
+            if (!exhausted && im && (__popcll(im) >= WTGPU_CONE_REFILL_MIN || n_run == 0)) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(ctl + CTL_TCONE_HEAD, (uint32_t)__popcll(im));
                 base = (uint32_t)__shfl((int)base, 0, 64);
@@ -518,10 +521,10 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_STAGE) k_tr_cone(launch_args_
             if (exhausted) break;
             continue;
         }
-        // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_REFILL_MIN) wait to be served
+        // ---- traversal loop: until a quarter of the lanes that entered it (at most WTGPU_CONE_REFILL_MIN) wait to be served
         uint32_t* slot2 = a.st.tris + (size_t)w * kTriListWords;
         const uint_list_t tris2{slot2, 1u, (a.collect_list & 1u) ? kMaxConeTris : 0u, reinterpret_cast<float*>(slot2 + kMaxConeTris)};
-        const int leave_at = running < 4 * WTGPU_REFILL_MIN ? (running + 3) / 4 : WTGPU_REFILL_MIN;
+        const int leave_at = running < 4 * WTGPU_CONE_REFILL_MIN ? (running + 3) / 4 : WTGPU_CONE_REFILL_MIN;
 #if WTGPU_CONE_DEFER
         for (;;) {
             for (;;) {   // nodes: every lane that holds no leaf descends, until the lanes with a leaf (or a staged triangle) are the majority
