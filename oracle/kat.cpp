@@ -322,7 +322,35 @@ void kat_emitter_sample_consistency(const void* scene_host, int ei, float k, uin
         o[0] = es.dpd;
         o[1] = emitter_pdf_direction(sc, ei, es.beam.env.d, es.has_surface ? &es.surface : nullptr);
         o[2] = es.ppd;
-        o[3] = emitter_pdf_position(sc, ei);
+        o[3] = emitter_pdf_position(sc, ei, es.has_surface ? &es.surface : nullptr);
+    }
+}
+// Textured area emitters (wt/sources.h area_table_*; src/emitter/area.cpp:153-271).  kat_area_table: the emitter's tables as stored —
+// returns the number of words (0: no radiance texture) and copies up to `cap` of them.  kat_area_samples: n position samples, out: n x
+// {mesh triangle, alpha, beta, sampled ppd, pdf_position at the sampled surface, u, v, radiance at k}
+uint32_t kat_area_table(const void* scene_host, int ei, float* out, uint32_t cap) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const emitter_t& e = sc.emitters[ei];
+    if (e.type != EMIT_AREA || e.radiance_tex <= 0) return 0;
+    for (uint32_t i = 0; i < e.tab_words && i < cap; ++i) out[i] = sc.texture_data[e.tab + i];
+    return e.tab_words;
+}
+void kat_area_samples(const void* scene_host, int ei, float k, uint64_t seed, uint32_t n, float* out) {
+    const scene_t& sc = *static_cast<const scene_t*>(scene_host);
+    const emitter_t e = sc.emitters[ei];
+    for (uint32_t i = 0; i < n; ++i) {
+        sampler_t s = make_sampler(seed, i, 5);
+        float ppd = 0.f;
+        const surface_t srf = area_sample_position(sc, e, s, ppd);
+        float* o = out + 8 * i;
+        o[0] = (float)sc.tri_meta[srf.tuid].shape_tri_idx;
+        o[1] = srf.bary.x;
+        o[2] = srf.bary.y;
+        o[3] = ppd;
+        o[4] = area_pdf_position(sc, e, &srf);
+        o[5] = srf.uv.x;
+        o[6] = srf.uv.y;
+        o[7] = area_spectral_radiance(sc, e, srf, k);
     }
 }
 

@@ -521,7 +521,8 @@ def test_constant_radiance_textures_on_area_emitters(built, tmp_path):
     """<texture name="radiance"> on an area emitter (area.hpp:103-116: radiance->f({uv, k}).x times the emitter's own `scale`): a texture that is
     the same everywhere makes the uniform emitter.  A constant texture is a LUMINANCE texture, wavelength independent at any wavenumber (not
     the RGB uplift, which is zero outside 380-720 nm: an infrared or radio sensor would see a dark emitter): the film of the constant-spectrum
-    twin, bit for bit, also through a `scale` wrapper; a spatially varying texture is refused with the reason."""
+    twin, bit for bit, also through a `scale` wrapper.  A bitmap makes the spatially varying emitter (tests/test_textured_emitter.py); a texture
+    without a mean spectrum (checkerboard, function) is refused, as the reference refuses it (src/emitter/area.cpp:322-323)."""
     from wave_tracer_amd import Scene
     from wave_tracer_amd.api import WtgpuError
     xml = """<scene version="0.1.0">
@@ -548,7 +549,7 @@ def test_constant_radiance_textures_on_area_emitters(built, tmp_path):
     img, c = _render_dev(scene('<texture name="radiance" type="scale"><spectrum name="scale" constant=".25"/><texture type="constant"><spectrum constant="2"/></texture>'
                                '</texture><float name="scale" value="3"/>', "scaled"))
     assert np.array_equal(img, ref) and c == cref
-    with pytest.raises(WtgpuError, match="spatially varying radiance"):
+    with pytest.raises(WtgpuError, match="mean_spectrum"):
         scene('<texture name="radiance" type="checkerboard"/><float name="scale" value="3"/>', "checker")
 
 

@@ -915,6 +915,95 @@ int scene_builder_t::add_emitter_area(int shape, int spectrum, float scale, floa
     return (int)emitters_.size() - 1;
 }
 
+// An area emitter whose radiance is a bitmap texture (src/emitter/area.cpp:295-340, 153-216).  The emitter's spectrum is the texture's mean
+// spectrum (src/texture/bitmap.cpp:45-57: the mean texel, uplifted if the image is RGB, flat otherwise), which the emitter selection and the
+// spectral sampling use; positions are drawn per triangle from the luminance of the texture on a barycentric grid of
+// ceil(min(resolution, 512) x longest uv edge) cells a side.  Every accumulation is in single precision, in the reference's order.
+int scene_builder_t::add_emitter_area_textured(int shape, int tex, float scale, float pse_scale) {
+    const texture_t t = textures_.at(tex);
+    if (t.type != TEX_BITMAP) throw std::runtime_error("(area emitter loader) the radiance texture must provide mean_spectrum(): a bitmap (constant textures: add_emitter_area)");
+    const shape_rec_t& r = shape_recs_.at(shape);
+    // texture2d_t::compute_texture_data (bitmap/texture2d.hpp:46-61): the mean texel
+    float mean[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t y = 0; y < t.height; ++y)
+        for (uint32_t x = 0; x < t.width; ++x)
+            for (uint32_t c = 0; c < t.channels && c < 4; ++c) mean[c] += texture_data_[t.offset + ((size_t)y * t.width + x) * t.channels + c];
+    for (float& m : mean) m /= float(t.width * t.height);
+    const bool rgb = t.channels >= 3;
+    const int spec = rgb ? spectrum_rgb(mean[0] * t.scale, mean[1] * t.scale, mean[2] * t.scale) : spectrum_const(mean[0] * t.scale);
+    const int ei = add_emitter_area(shape, spec, scale, pse_scale);
+
+    // working resolution: transform_t::resolution over bitmap_t::resolution (texture/transform.hpp:89-94, bitmap.hpp:70-72), at most 512
+    const float r0x = std::max(1.f, float(t.width)), r0y = std::max(1.f, float(t.height));
+    const float rrx = t.m[0] * (1.f / r0x) + t.m[1] * (1.f / r0y), rry = t.m[2] * (1.f / r0x) + t.m[3] * (1.f / r0y);
+    const float res = std::min(std::max(std::max(1.f, 1.f / rrx), std::max(1.f, 1.f / rry)), 512.f);
+
+    scene_t view{};   // texture lookups through the device's own code (wt/scene.h)
+    view.textures = textures_.data();
+    view.n_textures = (uint32_t)textures_.size();
+    view.texture_data = texture_data_.data();
+    const uint32_t T = r.tri_count;
+    std::vector<float> tab(T + 1 + 4 * (size_t)T, 0.f), powers(T, 0.f);
+    float total_I = 0.f;
+    for (uint32_t i = 0; i < T; ++i) {
+        const wtri_t& w = wtris_[r.tri_begin + i];
+        float* h = &tab[T + 1 + 4 * (size_t)i];
+        const size_t off = tab.size();
+        if (!w.has_uv) {   // a single empty cell
+            h[0] = 0.f, h[1] = 0.f, h[2] = 0.f, h[3] = float(off);
+            tab.push_back(0.f);
+            tab.push_back(1.f);
+            continue;
+        }
+        const float tarea = .5f * length(cross(w.c - w.a, w.b - w.a));
+        const float max_uv_dist = std::max(length(w.uv1 - w.uv0), std::max(length(w.uv2 - w.uv0), length(w.uv2 - w.uv1)));
+        const uint32_t texels = (uint32_t)std::ceil(res * max_uv_dist);
+        const float step = 1.f / float(texels);
+        const size_t cells = (size_t)texels * (texels + 1) / 2;
+        if (texels == 0 || off + cells + 1 >= (size_t(1) << 24))
+            throw std::runtime_error("(area emitter) the per-triangle sampling tables of this radiance texture need 2^24 words or more (or a triangle has no uv extent)");
+        tab.resize(off + cells + 1);
+        float* cdf = &tab[off];
+        h = &tab[T + 1 + 4 * (size_t)i];
+        cdf[0] = 0.f;
+        float I = 0.f;
+        size_t n = 0;
+        for (uint32_t b = 0; b < texels; ++b)
+            for (uint32_t a = 0; a <= b; ++a) {
+                const float alpha = float(a) * step + .5f * step, beta = 1.f - (float(b) * step + .5f * step);
+                const vec2 uv = alpha * w.uv0 + beta * w.uv1 + std::max(0.f, 1.f - alpha - beta) * w.uv2;
+                const rgba_t c = texture_rgba(view, tex, uv);
+                const float lum = std::max(0.f, (rgb ? .2126f * c.r + .7152f * c.g + .0722f * c.b : c.r));   // colourspace::luminance (BT.709)
+                I += lum;
+                cdf[n + 1] = cdf[n] + std::max(0.f, lum);   // discrete_distribution_t: accumulate, then normalise (discrete_distribution.hpp:60-84)
+                ++n;
+            }
+        const float sum = cdf[cells];
+        if (sum > 0.f) {
+            const float recp = 1.f / sum;
+            for (size_t k = 0; k <= cells; ++k) cdf[k] *= recp;
+        } else
+            cdf[cells] = 1.f;
+        powers[i] = I / float(cells) * tarea;
+        total_I += powers[i];
+        h[0] = float(texels), h[1] = step, h[2] = 1.f / (step * step * tarea), h[3] = float(off);
+    }
+    if (!(total_I > 0.f)) std::fprintf(stderr, "wtgpu: (area emitter) radiance texture is zero everywhere\n");
+    tab[0] = 0.f;
+    for (uint32_t i = 0; i < T; ++i) tab[i + 1] = tab[i] + std::max(0.f, powers[i]);
+    if (tab[T] > 0.f) {
+        const float recp = 1.f / tab[T];
+        for (uint32_t i = 0; i <= T; ++i) tab[i] *= recp;
+    } else
+        tab[T] = 1.f;
+    emitter_t& e = emitters_[ei];
+    e.radiance_tex = 1 + tex;
+    e.tab = (uint32_t)texture_data_.size();
+    e.tab_words = (uint32_t)tab.size();
+    texture_data_.insert(texture_data_.end(), tab.begin(), tab.end());
+    return ei;
+}
+
 // include/wt/sensor/sensor/perspective.hpp:103-155
 void scene_builder_t::set_sensor_perspective(const xform_t& to_world, double fov, uint32_t w, uint32_t h, float pse_scale, bool rt_only) {
     sensor_t& s = sc_.sensor;

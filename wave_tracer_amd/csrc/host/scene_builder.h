@@ -96,6 +96,7 @@ public:
     // texture ids — a nested FUNCTION texture is inlined (its own transform / scale must be the identity: wrap its operands instead)
     int add_texture_function(const std::vector<float>& program);
     bool texture_is_function(int tex) const { return textures_.at(tex).type == wt::TEX_FUNCTION; }
+    bool texture_is_bitmap(int tex) const { return textures_.at(tex).type == wt::TEX_BITMAP; }
     void texture_set_transform(int tex, const float M[4], const float t[2]);   // uv' = M uv + t (texture/transform.hpp)
     void texture_set_scale(int tex, float scale);                               // texture/scale.hpp with a constant scale
     float texture_scale(int tex) const { return textures_.at(tex).scale; }
@@ -112,6 +113,8 @@ public:
     int add_shape(const mesh_t& mesh, const xform_t& to_world, int material, bool face_normals = false);
     int add_emitter_spot(const xform_t& to_world, int spectrum, float scale, float cutoff_rad, float falloff_rad, float extent_m, float pse_scale);
     int add_emitter_area(int shape, int spectrum, float scale, float pse_scale);
+    // radiance = scale x the BITMAP texture `tex` over the shape's uv (per-triangle sampling tables: src/emitter/area.cpp:153-260)
+    int add_emitter_area_textured(int shape, int tex, float scale, float pse_scale);
     int add_emitter_point(dvec3 position, int spectrum, float scale, float extent_m, float pse_scale);
     void permute_emitters(const std::vector<int>& new_order);   // new_order[i]: current index of the emitter that becomes emitter i
     // directional (sun-like) emitter: `dir_to_emitter`, irradiance spectrum, solid angle subtended at the target (default: the sun's)

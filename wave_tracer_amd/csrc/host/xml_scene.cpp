@@ -1492,26 +1492,37 @@ struct loader_t {
                     const xnode_t* sp = em->named("radiance");
                     if (!sp) throw std::runtime_error("area emitter: radiance expected");
                     double scale = 1.0;
-                    int spec = -2;
+                    int spec = -2, radiance_tex = -1;
                     if (sp->name == "texture" || (sp->name == "ref" && deref(sp)->name == "texture")) {
-                        // A radiance TEXTURE (area.hpp:103-116: radiance->f({uv, k}).x times the emitter's own `scale`; src/emitter/area.cpp:153-260: positions
-                        // drawn from per-triangle texel tables).  Served when the texture is the same everywhere — a constant, or the mid-grey that stands
-                        // in for an image missing from the checkout: then the emitter is a uniform one with the colour's uplifted spectrum (positions are
-                        // drawn uniformly over the shape, which is what the reference's tables reduce to).  Spatially varying radiance is not built.
+                        // A radiance TEXTURE (area.hpp:103-116: radiance->f({uv, k}).x times the emitter's own `scale`).  A texture that is the same
+                        // everywhere — a constant, or the mid-grey that stands in for an image missing from the checkout — makes a uniform emitter
+                        // with the colour's spectrum (positions drawn uniformly over the shape, which is what the reference's tables reduce to).
+                        // A bitmap makes a spatially varying emitter with per-triangle texel tables (src/emitter/area.cpp:153-260).  Checkerboard
+                        // and function textures provide no mean_spectrum() in the reference either (area.cpp:322-323 throws).
                         const int t = texture(*deref(sp));
-                        float rgb[3];
-                        if (!b.texture_constant_rgb(t, rgb))
-                            throw std::runtime_error("area emitter: a spatially varying radiance texture (per-triangle sampling tables, src/emitter/area.cpp:153-260) is not supported");
                         if (const xnode_t* sc = em->named("scale")) scale = eval_number(sc->get("value"));
-                        // a luminance texture (every constant texture is one) is wavelength independent — area.hpp: scale * radiance->f({uv, k}).x —
-                        // at ANY wavenumber: a flat spectrum, not the RGB uplift, which is zero outside 380-720 nm (an IR / radio sensor would see a
-                        // dark emitter); only a genuinely coloured stand-in (an RGB bitmap's mean colour) is uplifted
-                        spec = (rgb[0] == rgb[1] && rgb[1] == rgb[2]) ? b.spectrum_const(rgb[0]) : b.spectrum_rgb(rgb[0], rgb[1], rgb[2]);
+                        float rgb[3];
+                        if (b.texture_constant_rgb(t, rgb)) {
+                            // a luminance texture (every constant texture is one) is wavelength independent — area.hpp: scale * radiance->f({uv, k}).x —
+                            // at ANY wavenumber: a flat spectrum, not the RGB uplift, which is zero outside 380-720 nm (an IR / radio sensor would see a
+                            // dark emitter); only a genuinely coloured stand-in (an RGB bitmap's mean colour) is uplifted
+                            spec = (rgb[0] == rgb[1] && rgb[1] == rgb[2]) ? b.spectrum_const(rgb[0]) : b.spectrum_rgb(rgb[0], rgb[1], rgb[2]);
+                        } else if (b.texture_is_bitmap(t))
+                            radiance_tex = t;
+                        else
+                            throw std::runtime_error("(area emitter loader) the radiance texture must provide mean_spectrum().");
                     } else {
                         if (const xnode_t* sc = sp->named("scale")) scale = eval_number(sc->get("value"));
                         const xnode_t unscaled = without_scale(*sp);
                         spec = spectrum(unscaled, true);
                     }
+                    if (radiance_tex >= 0) {
+                        float pse = 1.f;
+                        if (const xnode_t* r = em->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));
+                        b.add_emitter_area_textured(shape, radiance_tex, (float)scale, pse);
+                        emitter_keys.push_back({1, std::string(), (int)n_emitters});
+                        ++n_emitters;
+                    } else
                     if (spec != -2) {
                         float pse = 1.f;
                         if (const xnode_t* r = em->named("phase_space_extent_scale")) pse = (float)eval_number(r->get("value"));

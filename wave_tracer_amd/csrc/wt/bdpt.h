@@ -271,7 +271,7 @@ WT_HD float vertex_pdf_next_from_emitter(const scene_t& sc, const V& v, const N&
 template <class V>
 WT_HD float vertex_pdf_emitter(const scene_t& sc, const V& v) {
     const int ei = vertex_get_emitter(v);
-    return sc.emitters[ei].select_pmf * pd_density_or_zero(emitter_pdf_position(sc, ei));
+    return sc.emitters[ei].select_pmf * pd_density_or_zero(emitter_pdf_position(sc, ei, vertex_has_real_surface(sc, v) ? &v.surf : nullptr));
 }
 // vertex_t::pdf (vertex.hpp:444-487); of `prev` only the position matters
 template <class V, class N>

@@ -483,7 +483,7 @@ WT_HD bool path_walk_step(const scene_t& sc, path_walk_t& pw, const trav_result_
             float mis = 1.f;
             if (!pd_is_discrete(w.pdf_from_prev)) {
                 const float emitter_pm = sc.emitters[ei].select_pmf;
-                const float emitter_ppd = pd_density_or_zero(emitter_pdf_position(sc, ei));
+                const float emitter_ppd = pd_density_or_zero(emitter_pdf_position(sc, ei, &srf));
                 const float dn = dot(-beam.env.d, srf.geo.n);
                 const float recp_dn = dn != 0.f ? 1.f / fabsf(dn) : 0.f;
                 const float l2 = length2(beam.env.o - srf.wp);

@@ -150,6 +150,11 @@ struct emitter_t {
     float target_radius, target_area, far_dist, tan_alpha_at_target;
     // area
     int32_t shape;
+    // area, spatially varying radiance (area.hpp:103-116, src/emitter/area.cpp:153-260): radiance = scale x texture.f({uv, k}).x of the BITMAP
+    // texture radiance_tex - 1 (0: `spectrum` alone), `spectrum` holds the texture's mean spectrum (emitter selection, spectral sampling), and positions are
+    // drawn from per-triangle texel tables in texture_data[tab .. tab + tab_words): see wt/sources.h area_table_*
+    int32_t radiance_tex;
+    uint32_t tab, tab_words;
     // sampling tables
     float select_pmf;           // emitters_power_distribution.pdf
     int32_t k_dist;             // index into kdists

@@ -98,9 +98,14 @@ WT_HD vec3 uniform_sphere(vec2 u) {
 }
 WT_HD float emitter_spectral_value(const scene_t& sc, const emitter_t& e, float k) { return spectrum_f(sc, e.spectrum, k) * e.scale; }
 
+// area_t::spectral_radiance (area.hpp:103-116): scale x radiance texture at the surface's uv, or scale x the (average) spectrum
+WT_HD float area_spectral_radiance(const scene_t& sc, const emitter_t& e, const surface_t& surface, float k) {
+    if (e.radiance_tex > 0) return e.scale * texture_spectral_leaf(sc, e.radiance_tex - 1, surface.uv, k);
+    return emitter_spectral_value(sc, e, k);
+}
 // area_t::Le (area.hpp:156-166): radiance * max(0, d.ng)
 WT_HD beam_t area_Le(const scene_t& sc, const emitter_t& e, vec3 ro, vec3 rd, float k, const surface_t& surface) {
-    const float I = emitter_spectral_value(sc, e, k) * fmaxf_(0.f, dot(rd, surface.geo.n));
+    const float I = area_spectral_radiance(sc, e, surface, k) * fmaxf_(0.f, dot(rd, surface.geo.n));
     return make_forward_beam(ro, rd, I, k, area_sourcing_geometry(e, k));
 }
 
@@ -113,6 +118,64 @@ WT_HD surface_t shape_sample_position(const scene_t& sc, int shape_idx, sampler_
     const vec2 bary = uniform_triangle(vec2{r.x, r.y});
     ppd = sh.recp_surface_area;
     return make_surface_at_bary(sc, sc.shape_tri_tuid[sh.tri_offset + idx], bary);
+}
+
+// ---- textured area emitters: per-triangle texel tables (src/emitter/area.cpp:153-260) -------------------------------------------------
+// texture_data[e.tab ..): the triangle distribution's normalised cdf (T + 1 knots, T = the shape's triangle count: discrete_distribution_t::
+// dcdf), then 4 words per triangle {texels, 1 / texels, texel_to_area_density, offset of its cdf from e.tab}, then per triangle the cdf of its
+// texels (texels (texels + 1) / 2 + 1 knots): row b = 0 .. texels - 1 holds the cells a = 0 .. b, cell (a, b) covering the barycentrics
+// alpha in [a, a + 1) / texels, beta in 1 - (b, b + 1] / texels.  Integers are stored as floats (the host refuses tables beyond 2^24 words).
+struct area_table_tri_t {
+    uint32_t texels;
+    float recp_texels, texel_to_area_density;
+    const float* cdf;   // texels (texels + 1) / 2 + 1 knots
+};
+WT_HD area_table_tri_t area_table_tri(const scene_t& sc, const emitter_t& e, uint32_t tid) {
+    const float* tab = sc.texture_data + e.tab;
+    const float* h = tab + (sc.shapes[e.shape].tri_count + 1) + 4 * tid;
+    return {(uint32_t)h[0], h[1], h[2], tab + (uint32_t)h[3]};
+}
+// sampling_data_t::sample (area.cpp:218-247)
+WT_HD surface_t area_table_sample(const scene_t& sc, const emitter_t& e, sampler_t& sampler, float& ppd) {
+    const float rx = sampler_r(sampler), ry = sampler_r(sampler), rz = sampler_r(sampler), rw = sampler_r(sampler);   // sampler.r4()
+    const shape_t sh = sc.shapes[e.shape];
+    const float* tcdf = sc.texture_data + e.tab;
+    const uint32_t tid = cdf_icdf(tcdf, sh.tri_count, rx);
+    const float tpdf = tcdf[tid + 1] - tcdf[tid];
+    const area_table_tri_t t = area_table_tri(sc, e, tid);
+    const uint32_t cell = cdf_icdf(t.cdf, t.texels * (t.texels + 1) / 2, ry);
+    const float cell_pdf = t.cdf[cell + 1] - t.cdf[cell];
+    const uint32_t b = (uint32_t)ceilf(-.5f + sqrtf(.25f + float(2 * (cell + 1)))) - 1;
+    const uint32_t a = cell - b * (b + 1) / 2;
+    const float alpha = clampf(float(a) * t.recp_texels + rz * t.recp_texels, 0.f, 1.f);
+    const float beta = clampf(1.f - (float(b) * t.recp_texels + rw * t.recp_texels), 0.f, 1.f - alpha);
+    ppd = tpdf * cell_pdf * t.texel_to_area_density;
+    return make_surface_at_bary(sc, sc.shape_tri_tuid[sh.tri_offset + tid], vec2{alpha, beta});
+}
+// sampling_data_t::pdf (area.cpp:248-271).  The cell indices are clamped into the table (the reference indexes its vector with whatever the
+// rounding gives: on a triangle's border that can be one past a row)
+WT_HD float area_table_pdf(const scene_t& sc, const emitter_t& e, const surface_t& surface) {
+    if (surface.shape != (uint32_t)e.shape) return 0.f;
+    const uint32_t tid = sc.tri_meta[surface.tuid].shape_tri_idx;
+    const float* tcdf = sc.texture_data + e.tab;
+    const float tpdf = tcdf[tid + 1] - tcdf[tid];
+    const area_table_tri_t t = area_table_tri(sc, e, tid);
+    if (t.texels == 0) return 0.f;
+    const float fa = roundf(surface.bary.x * float(t.texels) - .5f), fb = roundf((1.f - surface.bary.y) * float(t.texels) - .5f);
+    const uint32_t b = (uint32_t)clampf(fb, 0.f, float(t.texels - 1));
+    const uint32_t a = (uint32_t)clampf(fa, 0.f, float(b));
+    const uint32_t cell = b * (b + 1) / 2 + a;
+    return tpdf * (t.cdf[cell + 1] - t.cdf[cell]) * t.texel_to_area_density;
+}
+// area_t::sample_position (area.cpp:109-120)
+WT_HD surface_t area_sample_position(const scene_t& sc, const emitter_t& e, sampler_t& sampler, float& ppd) {
+    if (e.radiance_tex > 0) return area_table_sample(sc, e, sampler, ppd);
+    return shape_sample_position(sc, e.shape, sampler, ppd);
+}
+// area_t::pdf_position (area.cpp:122-130)
+WT_HD float area_pdf_position(const scene_t& sc, const emitter_t& e, const surface_t* surface) {
+    if (e.radiance_tex > 0) return surface ? area_table_pdf(sc, e, *surface) : 0.f;
+    return sc.shapes[e.shape].recp_surface_area;
 }
 
 // emitter_t::sample
@@ -147,7 +210,7 @@ WT_HD emitter_sample_t emitter_sample(const scene_t& sc, int ei, float k, sample
         r.dpd = kInvTwoPi * .5f;
     } else {
         float ppd;
-        r.surface = shape_sample_position(sc, e.shape, sampler, ppd);
+        r.surface = area_sample_position(sc, e, sampler, ppd);
         r.has_surface = 1;
         vec3 d = cosine_hemisphere(sampler_r2(sampler));
         const float dn = d.z;
@@ -162,12 +225,12 @@ WT_HD emitter_sample_t emitter_sample(const scene_t& sc, int ei, float k, sample
     }
     return r;
 }
-// emitter_t::pdf_position
-WT_HD float emitter_pdf_position(const scene_t& sc, int ei) {
+// emitter_t::pdf_position (the surface: the point's, for an area emitter with a radiance texture)
+WT_HD float emitter_pdf_position(const scene_t& sc, int ei, const surface_t* surface = nullptr) {
     const emitter_t e = sc.emitters[ei];
     if (e.type == EMIT_SPOT || e.type == EMIT_POINT) return pd_discrete(1.f);
     if (e.type == EMIT_DIRECTIONAL) return 0.f;   // infinite emitters have no position density (vertex.hpp:557-558)
-    return sc.shapes[e.shape].recp_surface_area;
+    return area_pdf_position(sc, e, surface);
 }
 // emitter_t::pdf_direction (solid-angle density)
 WT_HD float emitter_pdf_direction(const scene_t& sc, int ei, vec3 dir, const surface_t* surface) {
@@ -180,7 +243,7 @@ WT_HD float emitter_pdf_direction(const scene_t& sc, int ei, vec3 dir, const sur
 }
 // area_t::pdf_direct (area.cpp:127-135)
 WT_HD float area_pdf_direct(const scene_t& sc, const emitter_t& e, vec3 wp, vec3 ro, vec3 rd, const surface_t& surface) {
-    const float ppd = sc.shapes[e.shape].recp_surface_area;
+    const float ppd = area_pdf_position(sc, e, &surface);
     const float l2 = length2(wp - ro);
     const float dn = fmaxf_(0.f, dot(rd, surface.geo.n));
     const float recp_dn = dn > 0.f ? 1.f / dn : 0.f;
@@ -221,7 +284,7 @@ WT_HD emitter_direct_sample_t emitter_sample_direct(const scene_t& sc, int ei, v
         r.dpd = pd_discrete(1.f);
     } else {
         float ppd;
-        r.surface = shape_sample_position(sc, e.shape, sampler, ppd);
+        r.surface = area_sample_position(sc, e, sampler, ppd);
         r.has_surface = 1;
         const vec3 d = normalize(wp - r.surface.wp);
         const float dpd = area_pdf_direct(sc, e, wp, r.surface.wp, d, r.surface);

@@ -581,6 +581,8 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
             tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width * h.textures[i].height * h.textures[i].channels);
         else if (h.textures[i].type == TEX_FUNCTION)
             tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width);
+    for (uint32_t i = 0; i < h.n_emitters; ++i)   // the texel tables of textured area emitters live in texture_data as well
+        if (h.emitters[i].type == EMIT_AREA && h.emitters[i].radiance_tex > 0) tex_words = std::max(tex_words, (size_t)h.emitters[i].tab + (size_t)h.emitters[i].tab_words);
     UP(texture_data, tex_words)
     UP(emitters, h.n_emitters)
     UP(emitter_cdf, h.n_emitters + 1)
