@@ -9,7 +9,8 @@ namespace wtk {
 
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_TRACE) k_trace_refill(launch_args_t a, int in, int first_round, uint32_t round) { trace_refill_body(a, in, first_round, round); }
 
-// ---- The per-lane trace kernel as a PHASE MACHINE (round 6; the default — WTGPU_TRACE_SM=0 selects k_trace_refill).
+// ---- The per-lane trace kernel as a PHASE MACHINE (round 6; NOT the default: 1.7x slower than the staged kernels, kept as a parity-tested form —
+// WTGPU_TRACE_SM=1 selects it; DESIGN.md §4 "The other forms").
 // k_trace_refill above keeps a wavefront's lanes busy with different WALKS, but inside a step they still do different THINGS: the axis query of a
 // freshly fetched walk is a whole ray traversal (a loop nest whose trip counts differ in every lane), a leaf step loops over one to four triangles
 // per lane and, for the 3 % of them that pass the conservative filters, runs the exact cone-triangle intersection (intersect_cone_tri: ~10x a
