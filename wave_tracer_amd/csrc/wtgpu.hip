@@ -582,7 +582,13 @@ static int upload_impl(wtgpu_scene* s, int device, uint64_t max_batch) {
         else if (h.textures[i].type == TEX_FUNCTION)
             tex_words = std::max(tex_words, (size_t)h.textures[i].offset + (size_t)h.textures[i].width);
     for (uint32_t i = 0; i < h.n_emitters; ++i)   // the texel tables of textured area emitters live in texture_data as well
-        if (h.emitters[i].type == EMIT_AREA && h.emitters[i].radiance_tex > 0) tex_words = std::max(tex_words, (size_t)h.emitters[i].tab + (size_t)h.emitters[i].tab_words);
+        if (h.emitters[i].type == EMIT_AREA && h.emitters[i].radiance_tex > 0) {
+            const emitter_t& e = h.emitters[i];
+            if ((uint32_t)e.radiance_tex > h.n_textures || h.textures[e.radiance_tex - 1].type != TEX_BITMAP || e.shape < 0 || (uint32_t)e.shape >= h.n_shapes ||
+                e.tab_words < h.shapes[e.shape].tri_count * 5ull + 1)
+                return fail(WTGPU_ERR_INVALID, "area emitter " + std::to_string(i) + ": radiance_tex must name a bitmap texture and tab / tab_words the emitter's sampling tables (wt/sources.h area_table_*)");
+            tex_words = std::max(tex_words, (size_t)e.tab + (size_t)e.tab_words);
+        }
     UP(texture_data, tex_words)
     UP(emitters, h.n_emitters)
     UP(emitter_cdf, h.n_emitters + 1)
