@@ -126,7 +126,7 @@ int wtgpu_render(wtgpu_scene* scene, void* stream, double* d_value, double* d_we
  * join.  A batch is enqueued in two parts: generation and the rounds its walks are expected to need, and — after the host has seen
  * its round queue empty (looking again every 8 rounds otherwise) — the connections.  wtgpu_render_async enqueues the first part of
  * its batches (and the second part of whichever earlier batch still holds the state slice it reuses: it may wait for that one);
- * wtgpu_join WAITS on the host for the first parts of the batches still pending, enqueues their second parts, and makes `stream`
+ * wtgpu_join WAITS on the host for the first parts of the batches still pending (serving whichever is ready first), enqueues their second parts, and makes `stream`
  * continue after them. */
 int wtgpu_render_async(wtgpu_scene* scene, void* stream, double* d_value, double* d_weight, double* d_light, uint64_t sample_begin,
                        uint64_t sample_end, uint64_t seed);

@@ -94,6 +94,7 @@ struct wtgpu_scene {
         unsigned char args[1024];   // the batch's launch block (launch_args_t, defined below)
         chunk_rec_t* rec = nullptr;
         uint32_t rounds_first = 0;
+        uint32_t launched = 0, rounds_step = 8;   // rounds enqueued so far; rounds to add at the next look (finish_look)
     };
     std::vector<pending_t> pending;   // per slice
     uint32_t rounds_hist[8] = {0};    // rounds with work of the last batches seen (the expectation is their maximum + a margin)
@@ -1082,65 +1083,95 @@ static uint32_t expected_rounds(const wtgpu_scene* s) {
     // added as the host sees the queue still filled.  Both are far from the 36.1 of WTGPU_MAX_ROUNDS=96, which drops those walks: DESIGN.md §0.)
     return std::min<uint32_t>(kMaxWalkIters, mean + s->knobs.rounds_margin);
 }
-// the second part of the batch pending on slice k (see batch_launcher_t); blocks the calling thread until its first part has run
-static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
+// One LOOK at the batch pending on slice k, whose ev_mid has completed (its control block is in r.h_mid): is the round queue empty?  Then the
+// connections (the batch's second part) are enqueued and the batch is no longer pending.  If not — a batch whose walks outlasted the expectation —
+// the next rounds are enqueued with another copy of the control block behind them, and the batch waits for its next look.
+static int finish_look(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
     wtgpu_scene::pending_t& p = s->pending[k];
-    if (!p.active) return WTGPU_OK;
-    p.active = false;
     chunk_rec_t& r = *p.rec;
     launch_args_t a;
     std::memcpy(&a, p.args, sizeof(a));
     hipStream_t st_ = s->streams[k];
-    // Is the round queue empty?  If not — a batch whose walks outlasted the expectation — another kRoundsStep rounds, and look again.
-    uint32_t kRoundsStep = 8;   // (doubles with every look, up to 64: a batch far beyond its expectation is not looked at every 8 rounds)
-    uint32_t launched = p.rounds_first;
+    uint32_t& launched = p.launched;
     const bool light = !L.path_mode && s->knobs.light_rounds != 0;   // (a k_light_rounds launch stands behind the rounds enqueued so far)
-    for (;;) {
-        HIP_CHECK(hipEventSynchronize(r.ev_mid));
-        uint32_t stop = 0;
-        if (light && launched < s->knobs.max_rounds) {
-            launched += r.h_mid[CTL_LIGHT_DONE];
-            stop = r.h_mid[CTL_LIGHT_STOP];
-            s->light_rounds_run += r.h_mid[CTL_LIGHT_DONE];
-        }
-        if (stop >= 1 && stop <= 3) {
-            // a walk needs a stage the light kernel does not hold: the rest of THAT round by the ordinary kernels, then light again
-            static const int from[4] = {0, 1, 3, 5};
-            const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, launched + 1, from[stop]);
-            if (rc) return rc;
-            launched += 1;
-        } else {
-            const uint32_t q = launched & 1u;
-            const uint32_t left = r.h_mid[CTL_COUNT0 + q] + r.h_mid[CTL_BACK0 + q];
-            if (left == 0) {
-                note_rounds(s, std::min<uint32_t>(r.h_mid[CTL_ROUNDS], kMaxWalkIters));
-                break;
-            }
-            if (launched >= s->knobs.max_rounds) break;   // (WTGPU_MAX_ROUNDS: what is left is dropped and counted, drain_rec)
+    uint32_t stop = 0;
+    if (light && launched < s->knobs.max_rounds) {
+        launched += r.h_mid[CTL_LIGHT_DONE];
+        stop = r.h_mid[CTL_LIGHT_STOP];
+        s->light_rounds_run += r.h_mid[CTL_LIGHT_DONE];
+    }
+    bool done = false;
+    if (stop >= 1 && stop <= 3) {
+        // a walk needs a stage the light kernel does not hold: the rest of THAT round by the ordinary kernels, then light again
+        static const int from[4] = {0, 1, 3, 5};
+        const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, launched + 1, from[stop]);
+        if (rc) return rc;
+        launched += 1;
+    } else {
+        const uint32_t q = launched & 1u;
+        const uint32_t left = r.h_mid[CTL_COUNT0 + q] + r.h_mid[CTL_BACK0 + q];
+        if (left == 0) {
+            note_rounds(s, std::min<uint32_t>(r.h_mid[CTL_ROUNDS], kMaxWalkIters));
+            done = true;
+        } else if (launched >= s->knobs.max_rounds)
+            done = true;   // (WTGPU_MAX_ROUNDS: what is left is dropped and counted, drain_rec)
+        else {
             s->round_fallbacks++;
-            const uint32_t next = std::min<uint32_t>(s->knobs.max_rounds, launched + kRoundsStep);
+            const uint32_t next = std::min<uint32_t>(s->knobs.max_rounds, launched + p.rounds_step);
             const int rc = L.rounds(a, s->d_path_slices[k], r, st_, launched, next);
             if (rc) return rc;
             launched = next;
-            kRoundsStep = std::min<uint32_t>(64u, kRoundsStep * 2u);
+            p.rounds_step = std::min<uint32_t>(64u, p.rounds_step * 2u);   // (a batch far beyond its expectation is not looked at every 8 rounds)
         }
-        L.light(a, st_, launched);
-        HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
-        HIP_CHECK(hipEventRecord(r.ev_mid, st_));
     }
-    r.rounds_launched = launched;
-    return L.tail(a, r, st_);
+    if (done) {
+        p.active = false;
+        r.rounds_launched = launched;
+        return L.tail(a, r, st_);
+    }
+    L.light(a, st_, launched);
+    HIP_CHECK(hipMemcpyAsync(r.h_mid, a.st.ctl, CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+    HIP_CHECK(hipEventRecord(r.ev_mid, st_));
+    return WTGPU_OK;
+}
+// Serves the pending batches — whichever has its control block back gets its look (finish_look) — until the one on slice k (k = npos: every one)
+// is finished.  The calling thread waits here for the GPU; it does not wait for ONE batch while another's stream stands idle behind a finished
+// first part (round 6: a batch of bidir_room needs some hundred looks for the walks that restart thousands of times).
+static int serve_pending(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
+    const size_t n = s->pending.size();
+    for (;;) {
+        bool any = false, progressed = false;
+        for (size_t j = 0; j < n; ++j) {
+            wtgpu_scene::pending_t& p = s->pending[j];
+            if (!p.active) continue;
+            if (k != (size_t)-1 && !s->pending[k].active) break;
+            any = true;
+            const hipError_t q = hipEventQuery(p.rec->ev_mid);
+            if (q == hipSuccess) {
+                const int rc = finish_look(s, j, L);
+                if (rc) return rc;
+                progressed = true;
+            } else if (q != hipErrorNotReady)
+                HIP_CHECK(q);
+        }
+        if (k != (size_t)-1 ? !s->pending[k].active : !any) return WTGPU_OK;
+        if (!progressed) {
+            (void)hipGetLastError();   // (hipErrorNotReady of the queries)
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+}
+// the second part of the batch pending on slice k (see batch_launcher_t); blocks the calling thread until its first part has run
+static int render_finish_part(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
+    if (!s->pending[k].active) return WTGPU_OK;
+    return serve_pending(s, k, L);
 }
 static int finish_all_pending(wtgpu_scene* s) {
     bool any = false;
     for (const auto& p : s->pending) any = any || p.active;
     if (!any) return WTGPU_OK;
     batch_launcher_t L(s);
-    for (size_t k = 0; k < s->pending.size(); ++k) {
-        const int rc = render_finish_part(s, k, L);
-        if (rc) return rc;
-    }
-    return WTGPU_OK;
+    return serve_pending(s, (size_t)-1, L);
 }
 static int drain_all(wtgpu_scene* s) {
     {
@@ -1249,6 +1280,8 @@ int wtgpu_render_async(wtgpu_scene* s, void* stream_, double* d_value, double* d
         std::memcpy(p.args, &a, sizeof(a));
         p.rec = &r;
         p.rounds_first = r1;
+        p.launched = r1;
+        p.rounds_step = 8;
         p.active = true;
 
     }
