@@ -1157,7 +1157,7 @@ static int serve_pending(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
         if (k != (size_t)-1 ? !s->pending[k].active : !any) return WTGPU_OK;
         if (!progressed) {
             (void)hipGetLastError();   // (hipErrorNotReady of the queries)
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            std::this_thread::sleep_for(std::chrono::microseconds(20));   // (0 / 5 / 20 / 100 us measured alike: the looks, not the polling, are the tail)
         }
     }
 }
