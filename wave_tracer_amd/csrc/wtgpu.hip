@@ -1101,6 +1101,14 @@ static int finish_look(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
         s->light_rounds_run += r.h_mid[CTL_LIGHT_DONE];
     }
     bool done = false;
+    static const bool diag = getenv("WTGPU_TAIL_DIAG") != nullptr;   // diagnostic: why the host was called back, printed at exit
+    if (diag) {
+        static unsigned long long looks = 0, by_stop[8] = {0}, light_done = 0, left_sum = 0;
+        static bool reg = false;
+        if (!reg) { reg = true; atexit([] { fprintf(stderr, "[tail diag] looks %llu (stop 0/1/2/3/4: %llu %llu %llu %llu %llu), light rounds %llu, walks left at looks (sum) %llu\n", looks, by_stop[0], by_stop[1], by_stop[2], by_stop[3], by_stop[4], light_done, left_sum); }); }
+        looks++; by_stop[stop < 8 ? stop : 7]++; light_done += light ? r.h_mid[CTL_LIGHT_DONE] : 0;
+        left_sum += r.h_mid[CTL_COUNT0 + (launched & 1u)] + r.h_mid[CTL_BACK0 + (launched & 1u)];
+    }
     if (stop >= 1 && stop <= 3) {
         // a walk needs a stage the light kernel does not hold: the rest of THAT round by the ordinary kernels, then light again
         static const int from[4] = {0, 1, 3, 5};
