@@ -1144,7 +1144,7 @@ static int finish_look(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
 }
 // Serves the pending batches — whichever has its control block back gets its look (finish_look) — until the one on slice k (k = npos: every one)
 // is finished.  The calling thread waits here for the GPU; it does not wait for ONE batch while another's stream stands idle behind a finished
-// first part (round 6: a batch of bidir_room needs some hundred looks for the walks that restart thousands of times).
+// first part (round 6: a batch of bidir_room needs fifteen looks, a hundred light rounds apart, for the walks that restart thousands of times).
 static int serve_pending(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
     const size_t n = s->pending.size();
     for (;;) {
@@ -1161,10 +1161,11 @@ static int serve_pending(wtgpu_scene* s, size_t k, batch_launcher_t& L) {
                 progressed = true;
             } else if (q != hipErrorNotReady)
                 HIP_CHECK(q);
+            else
+                (void)hipGetLastError();   // (not ready is not an error: nothing of it may reach the next hipGetLastError check)
         }
         if (k != (size_t)-1 ? !s->pending[k].active : !any) return WTGPU_OK;
         if (!progressed) {
-            (void)hipGetLastError();   // (hipErrorNotReady of the queries)
             std::this_thread::sleep_for(std::chrono::microseconds(20));   // (0 / 5 / 20 / 100 us measured alike: the looks, not the polling, are the tail)
         }
     }
