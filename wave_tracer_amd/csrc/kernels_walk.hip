@@ -346,7 +346,10 @@ __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT) k_interact(launch_a
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_COOP) k_interact_coop(launch_args_t a, int in, int first_round) { interact_body<0, true>(a, in, first_round); }
 __global__ void __launch_bounds__(kBlock, WTGPU_LB_INTERACT_B) k_interact_b(launch_args_t a, int in) { interact_body<1>(a, in, 0); }
 
-constexpr uint32_t kLightMaxWalks = 2048;
+#ifndef WTGPU_LIGHT_MAX_WALKS
+#define WTGPU_LIGHT_MAX_WALKS 2048
+#endif
+constexpr uint32_t kLightMaxWalks = WTGPU_LIGHT_MAX_WALKS;
 // ---- LIGHT ROUNDS: many rounds of a (nearly) empty queue in ONE launch.
 // A handful of walks of some scenes outlive their batch by THOUSANDS of rounds (bidir_room: beams that graze a finely tessellated object restart behind
 // empty apertures 1800-3800 times; the reference's walk has no iteration cap, plt_bdpt_detail.hpp:421-526, and until round 6 such walks were dropped
