@@ -359,6 +359,22 @@ constexpr uint32_t kLightMaxWalks = WTGPU_LIGHT_MAX_WALKS;
 // are done, or a walk needs a stage this kernel does not hold — the wave-cooperative traversal (heavy queue), the whole-region edge walk (k_edges),
 // the Fraunhofer sampling passes: then it stops BEFORE that stage, says which (CTL_LIGHT_STOP), and the host continues that round with the ordinary
 // kernels (wtgpu.hip: render_finish_part).  Same stage code, same order per walk: the same results as rounds.
+// Between two stages of a light round: what the lanes of this block wrote must be read by the lanes of this block — ONE block, one CU, one XCD.
+// The block barrier orders the stores (written through to the XCD's L2) and an agent-scope ACQUIRE drops the CU's L1 lines that queue counters updated
+// by L2 atomics would otherwise be read from; the RELEASE half of __threadfence() — a write-back of the XCD's whole L2 (buffer_wbl2: microseconds,
+// MI355X_MICROARCH.md), needed only for readers on other XCDs — is what a round does not pay three times (WTGPU_LIGHT_FENCE=1: the full fence; bidir_room 30.4 -> 30.9 Msamples/s, the same films).
+#ifndef WTGPU_LIGHT_FENCE
+#define WTGPU_LIGHT_FENCE 0
+#endif
+WT_D void light_stage_barrier() {
+#if WTGPU_LIGHT_FENCE
+    __threadfence();
+    __syncthreads();
+#else
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
 __global__ void __launch_bounds__(kBlock, 2) k_light_rounds(launch_args_t a, int in, uint32_t round, uint32_t max_rounds) {
     uint32_t* ctl = a.st.ctl;
     uint32_t done = 0, stop = 0;
@@ -373,22 +389,19 @@ __global__ void __launch_bounds__(kBlock, 2) k_light_rounds(launch_args_t a, int
     if (queue_count(ctl, in) == 0) max_rounds = 0;
     for (; done < max_rounds; ++done) {
         trace_refill_body(a, in, 0, round + done);
-        __threadfence();
-        __syncthreads();
+        light_stage_barrier();
         if (ctl[CTL_HEAVY_COUNT] != 0) {
             stop = 1;
             break;
         }
         interact_body<0>(a, in, 0);
-        __threadfence();
-        __syncthreads();
+        light_stage_barrier();
         if (ctl[CTL_GATHER_COUNT] != 0) {
             stop = 2;
             break;
         }
         interact_body<1>(a, in, 0);
-        __threadfence();
-        __syncthreads();
+        light_stage_barrier();
         if (ctl[CTL_INTC_COUNT] != 0) {
             stop = 3;
             break;
