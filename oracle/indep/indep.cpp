@@ -153,7 +153,7 @@ double pdf_next_from_emitter(const ctx_t& c, const vertex& v, const vertex& next
 }
 double pdf_emitter(const ctx_t& c, const vertex& v) {
     const int e = emitter_of(v);
-    return (double)prim_emitter_select_pmf(c.sc, e) * density_or_zero(prim_emitter_pdf_position(c.sc, e));
+    return (double)prim_emitter_select_pmf(c.sc, e) * density_or_zero(prim_emitter_pdf_position(c.sc, e, real_surface(c, v) ? &v.surface : nullptr));
 }
 float beam_k(const prim_beam& b) {
     float o[3], d[3], k, I;
@@ -981,7 +981,7 @@ void path_random_walk(path_ctx_t& c, path_walk& w, double L[4], int depth, int g
             uint32_t tuid, shape;
             prim_surface_info(&srf, swp, g, sn, &tuid, &shape);
             const double emitter_pm = prim_emitter_select_pmf(c.sc, emitter_of_shape);
-            const double emitter_ppd = density_or_zero(prim_emitter_pdf_position(c.sc, emitter_of_shape));
+            const double emitter_ppd = density_or_zero(prim_emitter_pdf_position(c.sc, emitter_of_shape, &srf));
             const double dn = -dot(from(bd), from(g));
             const double recp_dn = dn != 0 ? 1.0 / std::fabs(dn) : 0.0;
             const double l2 = len2(from(bo) - from(swp));

@@ -345,7 +345,11 @@ int prim_emitter_flags(const void* sc, int ei) {
     return (emitter_is_area(e) ? 1 : 0) | (emitter_is_delta_direction(e) ? 2 : 0) | (emitter_is_delta_position(e) ? 4 : 0) | (emitter_is_infinite(e) ? 8 : 0);
 }
 float prim_emitter_select_pmf(const void* sc, int ei) { return S(sc).emitters[ei].select_pmf; }
-float prim_emitter_pdf_position(const void* sc, int ei) { return emitter_pdf_position(S(sc), ei); }
+float prim_emitter_pdf_position(const void* sc, int ei, const prim_surface* s) {
+    surface_t srf;
+    if (s) srf = get<surface_t>(s);
+    return emitter_pdf_position(S(sc), ei, s ? &srf : nullptr);
+}
 float prim_emitter_pdf_direction(const void* sc, int ei, const float d[3], const prim_surface* s) {
     surface_t srf;
     if (s) srf = get<surface_t>(s);

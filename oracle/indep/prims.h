@@ -85,7 +85,7 @@ int prim_material_is_delta_only(const void* sc, int mat, float k);
 float prim_fsd_pdf(int slot, const float wo_world[3]);
 int prim_emitter_flags(const void* sc, int ei);   /* 1 area, 2 delta direction, 4 delta position, 8 infinite */
 float prim_emitter_select_pmf(const void* sc, int ei);
-float prim_emitter_pdf_position(const void* sc, int ei);
+float prim_emitter_pdf_position(const void* sc, int ei, const prim_surface* s);   /* s: the point's surface (textured area emitters read their tables at it), or NULL */
 float prim_emitter_pdf_direction(const void* sc, int ei, const float d[3], const prim_surface* s);
 float prim_directional_pdf_target_position(const void* sc, int ei, const float wp[3]);
 void prim_emitter_Li(const void* sc, int ei, const prim_beam* b, const prim_surface* s, float L[4]);

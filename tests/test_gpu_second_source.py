@@ -30,11 +30,25 @@ CASES = [
 
 @pytest.mark.parametrize("name,res,spp,kw,tol", CASES)
 def test_gpu_film_equals_the_second_composition_on_second_source_primitives(built, name, res, spp, kw, tol):
-    from wave_tracer_amd import Scene, render
-    sc = Scene(name, res=res, **kw)
+    from wave_tracer_amd import Scene
+    _compare(Scene(name, res=res, **kw), name, spp, tol)
+
+
+@pytest.mark.parametrize("defs", [{"integrator": "plt_bdpt"}, {"integrator": "plt_path", "direction": "backward"}], ids=["bdpt", "backward"])
+def test_gpu_textured_emitter_equals_the_second_composition(built, defs):
+    """The area emitter with a bitmap radiance (tests/data/xml/textured_emitter.xml): positions from per-triangle texel tables, their densities read
+    back at the hit surface by the MIS weights of both integrators — HIP film against the second composition."""
+    import os
+    from wave_tracer_amd import Scene
+    xml = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "xml", "textured_emitter.xml")
+    _compare(Scene.from_xml(xml, res=24, defines=defs), "textured_emitter-" + defs["integrator"], 8, (1e-3, 0.999, 2e-3))
+
+
+def _compare(sc, name, spp, tol):
+    from wave_tracer_amd import render
+    H, W, Cn = sc.height, sc.width, sc.channels
     gv, gw, gl = render(sc, spp, seed=77, device=0)
     gc = sc.counters()
-    H, W, Cn = sc.height, sc.width, sc.channels
     v, w, l = np.zeros((H, W, Cn)), np.zeros((H, W)), np.zeros((H, W, Cn))
     ctr = np.zeros(8, np.uint64)
     lib = _indep2()

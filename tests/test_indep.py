@@ -80,7 +80,9 @@ def test_independent_composition_matches_the_checker(built, name, res, spp, kw):
 
 
 XML_CASES = [("textured.xml", {"variant": 1}, 4), ("textured.xml", {"variant": 3}, 4), ("textured.xml", {"variant": 5}, 4), ("objects.xml", {}, 2),
-             ("single_slit.xml", {}, 4)]
+             ("single_slit.xml", {}, 4),
+             # an area emitter with a bitmap radiance: the densities of its positions come from per-triangle tables AT the point's surface
+             ("textured_emitter.xml", {"res": 16}, 6), ("textured_emitter.xml", {"res": 16, "filter": "bicubic", "mscale": 2}, 4)]
 
 
 @pytest.mark.parametrize("file,defines,spp", XML_CASES)
@@ -110,6 +112,21 @@ def indep_render_path(sc, b, e, seed):
     assert lib.indep_render_path(sc.host_desc(), b, e, seed, v.ctypes.data, w.ctypes.data, l.ctypes.data, ctr.ctypes.data) == 0
     return v, w, l, dict(zip(["segments", "-", "connections", "surface_interactions", "fsd_interactions", "null_interactions", "light_splats", "edge_queries"],
                              [int(x) for x in ctr]))
+
+
+def test_independent_plt_path_on_a_textured_emitter(built):
+    """Backward plt_path on tests/data/xml/textured_emitter.xml: next-event estimation against, and emission weighted by, the table densities of
+    an area emitter with a bitmap radiance (read at the hit surface) — second composition against the checker, sample for sample."""
+    from wave_tracer_amd import Scene, develop
+    sc = Scene.from_xml(os.path.join(ROOT, "tests", "data", "xml", "textured_emitter.xml"), defines={"res": 16, "integrator": "plt_path", "direction": "backward"})
+    spp = 8
+    ov, ow, ol, oc = oracle_render(sc, 0, spp, 9, threads=1)
+    iv, iw, il, ic = indep_render_path(sc, 0, spp, 9)
+    for k in ("segments", "connections", "surface_interactions", "null_interactions", "light_splats"):
+        assert ic[k] == oc[k], (k, ic[k], oc[k])
+    a, b = develop(sc, ov, ow, ol, spp).astype(np.float64), develop(sc, iv, iw, il, spp).astype(np.float64)
+    assert a.sum() > 0 and oc["connections"] > 100
+    assert np.abs(a - b).max() <= 1e-4 * a.max() and np.abs(a - b).sum() <= 1e-5 * a.sum()
 
 
 PATH_CASES = [
