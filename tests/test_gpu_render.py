@@ -99,6 +99,9 @@ def test_cornell_dense_mesh_parity(built):
 @pytest.mark.parametrize("case", ["furnace_r16", "furnace_fsd_r16", "white_furnace_r12", "double_slits_r96", "cornell_box_r12", "etoile_r48",
                                   "white_furnace_path_r12", "sunlit_r16", "cornell_box_stokes_r12"])
 def test_gpu_matches_committed_golden(built, case):
+    """tests/golden/*.npz are THIS repository's checker output (tests/golden/make_golden.py), committed: they pin regressions of the device path
+    and of the checker against a fixed state of both, not correctness against the reference (no reference output exists here; what pins the
+    checker is in DESIGN.md §7: closed forms, the second composition, second-source primitives)."""
     import json
     import os
     from golden.make_golden import CASES, run_case
