@@ -6,7 +6,7 @@
 # `msan`: the same renders under MemorySanitizer instead (ROCm's clang; only the checker and the wt/ headers are instrumented and heap memory counts as
 # initialised — libstdc++ is not instrumented — so what it finds are uninitialised STACK values: a local or a struct member read before it is written,
 # the kind of defect that makes two compilers of the same header disagree).
-# usage: tools/sanitize_checker.sh [quick] [msan]        (round 5: 38 renders each way, no report — profiles/r05_sanitized_checker.log)
+# usage: tools/sanitize_checker.sh [quick] [msan] [only=<substring of a configuration>]        (round 5: 38 renders each way, no report — profiles/r05_sanitized_checker.log)
 set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/wave_tracer_amd/csrc; D=$(mktemp -d /tmp/wtgpu_san_XXXX)
 cat > $D/main.cpp <<'CPP'
@@ -25,7 +25,9 @@ int main(int argc, char** argv) {   // name res spp [key=value ...]
     const int spp = atoi(argv[3]);
     p.max_depth = p.fsd = p.mis = p.rr = -1; p.mesh_detail = 0; p.lut_n_theta = 32; p.lut_m = 32; p.polarimetric = -1;
     int flavour = 0;
+    std::vector<std::string> defines;   // -Dname=value: the defines of a scene FILE (argv[1] ends in .xml)
     for (int i = 4; i < argc; ++i) {
+        if (!strncmp(argv[i], "-D", 2)) { defines.push_back(argv[i] + 2); continue; }
         const char* e = strchr(argv[i], '=');
         const std::string k(argv[i], e - argv[i]);
         const int v = atoi(e + 1);
@@ -33,6 +35,10 @@ int main(int argc, char** argv) {   // name res spp [key=value ...]
         else if (k == "rr") p.rr = v; else if (k == "crop_of") p.crop_of = (uint32_t)v; else if (k == "flavour") flavour = v; else if (k == "lut") p.lut_n_theta = p.lut_m = (uint32_t)v;
     }
     wth::scene_builder_t b;
+    const std::string name = argv[1];
+    if (name.size() > 4 && name.substr(name.size() - 4) == ".xml") {
+        try { wth::build_scene_from_xml(name, defines, p, b); } catch (const std::exception& e) { std::printf("%s: %s\n", argv[1], e.what()); return 2; }
+    } else
     if (!wth::build_named_scene(argv[1], p, b)) { std::printf("unknown scene %s\n", argv[1]); return 2; }
     const wt::scene_t sc = b.scene();
     const size_t n = (size_t)sc.sensor.height * sc.sensor.width;
@@ -65,7 +71,13 @@ CFGS=("bidir_room 24 2 polarimetric=1" "bidir_room 24 2" "cornell_box 32 4 mesh_
  "double_slits 48 4" "double_slits_overview 32 2" "etoile 32 8" "etoile 24 4 mesh_detail=1" "etoile_bdpt 24 4" "etoile_open 24 4" "etoile_path_backward 24 4"
  "furnace 16 8 max_depth=32 rr=0" "furnace 16 4 fsd=1" "furnace 16 4 fsd=1 flavour=1" "furnace 16 4 fsd=1 flavour=2" "cornell_box 24 4 flavour=3" "furnace_path 16 8" "furnace_spm 16 8"
  "furnace_wall_mask 16 8" "furnace_wall_composite 16 4" "furnace_wall_step_gap 16 4" "lens_a 24 4" "lens_b 24 4" "lens_c 24 4" "sunlit 24 8" "sunlit_path 24 8"
- "white_furnace 16 8" "white_furnace_path 16 8" "tex_checker 24 4" "tex_bitmap 24 4" "tex_normal_tilt 24 4" "tex_mask 24 4" "tex_bilinear_ramp 24 4")
+ "white_furnace 16 8" "white_furnace_path 16 8" "tex_checker 24 4" "tex_bitmap 24 4" "tex_normal_tilt 24 4" "tex_mask 24 4" "tex_bilinear_ramp 24 4"
+ "$R/tests/data/xml/textured_emitter.xml 24 8" "$R/tests/data/xml/textured_emitter.xml 24 8 -Dfilter=bicubic -Dmscale=2" "$R/tests/data/xml/textured_emitter.xml 24 8 -Dintegrator=plt_path -Ddirection=backward"
+ "$R/tests/data/xml/textured_emitter.xml 24 16 -Dintegrator=plt_path -Ddirection=forward -Dplane=true")
+# (round 6: the area emitter with a bitmap radiance — per-triangle texel tables indexed from random numbers and from barycentrics)
+# (MemorySanitizer: named scenes only — the XML reader lives in the uninstrumented host code with libstdc++'s strings and maps, which MSan reports on falsely)
+if [[ " $* " == *" msan "* ]]; then NEW=(); for c in "${CFGS[@]}"; do [[ "$c" == *".xml "* ]] || NEW+=("$c"); done; CFGS=("${NEW[@]}"); fi
+if [[ " $* " == *" only="* ]]; then ONLY=$(echo " $* " | sed 's/.* only=\([^ ]*\) .*/\1/'); NEW=(); for c in "${CFGS[@]}"; do [[ "$c" == *"$ONLY"* ]] && NEW+=("$c"); done; CFGS=("${NEW[@]}"); fi
 [[ " $* " == *" quick "* ]] || CFGS+=("cornell_box 32 48 mesh_detail=1 crop_of=1440 lut=128" "bidir_room 48 8 polarimetric=1 mesh_detail=1" "etoile 48 16 mesh_detail=2" "double_slits 96 8 lut=128")
 BAD=0
 for cfg in "${CFGS[@]}"; do
